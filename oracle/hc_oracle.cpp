@@ -1,0 +1,1395 @@
+// hc_oracle.cpp -- CPU ORACLE for the HydroChrono hydro-force hot path.
+//
+// *** TEST INFRASTRUCTURE, NOT PRODUCT. ***  Only tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py may load this library; nothing under hydrochrono_amd/ links,
+// imports or calls it.  It is a plain C++17 (no Eigen, no Chrono) restatement of the
+// reference algorithm, written to follow the reference's loop structure line by line so that
+// it doubles as the "reference CPU path" that is timed beside the GPU numbers
+// (OpenMP-over-IRF-steps, thread-local accumulators, bounds-checked accessor with per-access
+// rho multiply, nested-vector velocity history with front insertion).
+//
+// Parity status: PINNED for single-body heave against the reference's own golden trajectories
+// (tests/golden/sphere_goldens.npz <- tests/regression/reference_data/sphere/**): decay,
+// regular waves 1/5/10, irregular waves.  UNPINNED (no reference data available: rm3/oswec/
+// f3of/deepcwind .h5 are missing blobs) for multi-body coupling, rotations/torques and
+// TaperedDirect; those are covered by analytic known-answer tests only.
+//
+// Every function cites the reference file:line (relative to /root/reference) it restates.
+// Third-party arithmetic restated here because the libraries are absent from the container:
+//   * Eigen 3.4.0 VectorXd::LinSpaced, SplineFitting<Spline<double,6>>::Interpolate
+//     (KnotAveraging + collocation solve) and Spline::operator() -- published algorithms
+//     (The NURBS Book A2.1/A2.2; Eigen/src/Splines).
+//   * std::mt19937 + libstdc++/MSVC std::uniform_real_distribution<double> (two 32-bit draws,
+//     low word first) -- see orc::Mt19937 / orc::canonical53.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace orc {
+
+constexpr int kDofPerBody  = 6;  // src/hydro_forces.cpp:35
+constexpr int kDofLinOrRot = 3;  // src/hydro_forces.cpp:36
+
+// ---------------------------------------------------------------------------------------------
+// Eigen::VectorXd::LinSpaced(n, low, high)  (Eigen 3.4 linspaced_op_impl<double,false>)
+// step = (high-low)/(n-1); value(i) = low + i*step, last element forced to `high`; when
+// |high| < |low| the sequence is generated from the high end instead.
+// ---------------------------------------------------------------------------------------------
+static std::vector<double> LinSpaced(int n, double low, double high) {
+    std::vector<double> v(std::max(n, 0));
+    if (n <= 0) return v;
+    if (n == 1) {
+        v[0] = high;  // Eigen: LinSpaced(1, low, high) returns high
+        return v;
+    }
+    const int size1   = n - 1;
+    const double step = (high - low) / double(n - 1);
+    const bool flip   = std::fabs(high) < std::fabs(low);
+    for (int i = 0; i < n; ++i) {
+        if (flip)
+            v[i] = (i == 0) ? low : (high - double(size1 - i) * step);
+        else
+            v[i] = (i == size1) ? high : (low + double(i) * step);
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// std::mt19937 (standard algorithm, 32-bit) and the two-draw canonical used by
+// std::uniform_real_distribution<double> in libstdc++ (generate_canonical<double,53>):
+//   sum = g1 + g2 * 2^32 (in double), ret = sum / 2^64, clamp below 1.
+// src/wave_types.cpp:665-669 draws one phase per frequency: dist(0, 2*pi) = 2*pi*canonical + 0.
+// ---------------------------------------------------------------------------------------------
+struct Mt19937 {
+    uint32_t mt[624];
+    int idx;
+    explicit Mt19937(uint32_t seed) {
+        mt[0] = seed;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + uint32_t(i);
+        idx = 624;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; ++i) {
+                uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+                mt[i]      = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+};
+
+static double canonical53(Mt19937& g) {
+    const double r = 4294967296.0;  // 2^32
+    double sum     = 0.0;
+    double tmp     = 1.0;
+    for (int k = 0; k < 2; ++k) {
+        sum += double(g.next()) * tmp;
+        tmp *= r;
+    }
+    double ret = sum / tmp;
+    if (ret >= 1.0) ret = std::nextafter(1.0, 0.0);
+    return ret;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Eigen::SplineFitting<Spline<double,6>>::Interpolate(pts(6 x n), degree=3, u(n)) followed by
+// spline(u_new).  Knots by KnotAveraging; collocation matrix rows 1..n-2 hold the 4 non-zero
+// basis functions at u_i, rows 0 and n-1 are unit rows.  Eigen solves the dense system with
+// HouseholderQR; the system has a unique solution and is banded (bandwidth 3), so it is solved
+// here with banded Gaussian elimination with partial pivoting.
+// ---------------------------------------------------------------------------------------------
+struct CubicBSpline {
+    int n = 0;
+    static constexpr int p = 3;
+    std::vector<double> knots;                  // n + p + 1
+    std::array<std::vector<double>, 6> ctrl;    // 6 x n
+
+    int Span(double u) const {  // Eigen Spline::Span
+        if (u <= knots[0]) return p;
+        const double* first = knots.data() + p - 1;
+        const double* last  = knots.data() + knots.size() - p - 1;
+        const double* pos   = std::upper_bound(first, last, u);
+        return int(pos - knots.data()) - 1;
+    }
+    void Basis(double u, int span, double N[p + 1]) const {  // NURBS book A2.2
+        double left[p + 1], right[p + 1];
+        N[0] = 1.0;
+        for (int j = 1; j <= p; ++j) {
+            left[j]      = u - knots[span + 1 - j];
+            right[j]     = knots[span + j] - u;
+            double saved = 0.0;
+            for (int r = 0; r < j; ++r) {
+                const double tmp = N[r] / (right[r + 1] + left[j - r]);
+                N[r]             = saved + right[r + 1] * tmp;
+                saved            = left[j - r] * tmp;
+            }
+            N[j] = saved;
+        }
+    }
+    void Fit(const std::vector<double>& u, const std::array<std::vector<double>, 6>& pts) {
+        n = int(u.size());
+        if (n < p + 1) throw std::runtime_error("spline fit needs at least 4 points");
+        knots.assign(n + p + 1, 0.0);
+        for (int j = 1; j < n - p; ++j) knots[j + p] = (u[j] + u[j + 1] + u[j + 2]) / 3.0;
+        for (int j = 0; j <= p; ++j) knots[knots.size() - 1 - j] = 1.0;
+        // band storage: row i holds columns [i-3, i+3] -> 7 wide (+3 fill-in for pivoting)
+        const int kl = 3, ku = 3, w = kl + ku + kl + 1;  // 10
+        std::vector<double> A(size_t(n) * w, 0.0);
+        auto at = [&](int i, int j) -> double& { return A[size_t(i) * w + (j - i + kl)]; };
+        at(0, 0)         = 1.0;
+        at(n - 1, n - 1) = 1.0;
+        for (int i = 1; i < n - 1; ++i) {
+            const int span = Span(u[i]);
+            double N[p + 1];
+            Basis(u[i], span, N);
+            for (int k = 0; k <= p; ++k) at(i, span - p + k) = N[k];
+        }
+        std::array<std::vector<double>, 6> rhs = pts;
+        // Gaussian elimination with partial pivoting inside the band
+        for (int c = 0; c < n; ++c) {
+            int piv     = c;
+            double best = std::fabs(at(c, c));
+            for (int r = c + 1; r <= std::min(n - 1, c + kl); ++r) {
+                if (std::fabs(at(r, c)) > best) {
+                    best = std::fabs(at(r, c));
+                    piv  = r;
+                }
+            }
+            if (best == 0.0) throw std::runtime_error("singular spline collocation matrix");
+            if (piv != c) {
+                for (int j = c; j <= std::min(n - 1, c + ku + kl); ++j) {
+                    // element (c,j) and (piv,j); both inside the widened band
+                    std::swap(A[size_t(c) * w + (j - c + kl)], A[size_t(piv) * w + (j - piv + kl)]);
+                }
+                for (int d = 0; d < 6; ++d) std::swap(rhs[d][c], rhs[d][piv]);
+            }
+            for (int r = c + 1; r <= std::min(n - 1, c + kl); ++r) {
+                const double f = at(r, c) / at(c, c);
+                if (f == 0.0) continue;
+                for (int j = c; j <= std::min(n - 1, c + ku + kl); ++j) {
+                    A[size_t(r) * w + (j - r + kl)] -= f * A[size_t(c) * w + (j - c + kl)];
+                }
+                for (int d = 0; d < 6; ++d) rhs[d][r] -= f * rhs[d][c];
+            }
+        }
+        for (int d = 0; d < 6; ++d) {
+            ctrl[d].assign(n, 0.0);
+            for (int i = n - 1; i >= 0; --i) {
+                double s = rhs[d][i];
+                for (int j = i + 1; j <= std::min(n - 1, i + ku + kl); ++j) s -= A[size_t(i) * w + (j - i + kl)] * ctrl[d][j];
+                ctrl[d][i] = s / at(i, i);
+            }
+        }
+    }
+    void Eval(double u, double out[6]) const {  // Eigen Spline::operator()
+        const int span = Span(u);
+        double N[p + 1];
+        Basis(u, span, N);
+        for (int d = 0; d < 6; ++d) {
+            double s = 0.0;
+            for (int k = 0; k <= p; ++k) s += ctrl[d][span - p + k] * N[k];
+            out[d] = s;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// src/helper.cpp:8-22  get_lower_index
+// ---------------------------------------------------------------------------------------------
+static size_t get_lower_index(double value, const std::vector<double>& ticks) {
+    auto it    = std::upper_bound(ticks.begin(), ticks.end(), value);
+    size_t idx = size_t(it - ticks.begin()) - 1;
+    if (ticks[idx] == value) idx -= 1;
+    if (idx <= 0 || idx >= ticks.size() - 1) {
+        throw std::runtime_error("Could not find index for value " + std::to_string(value) + " in array with bounds (" +
+                                 std::to_string(ticks.front()) + ", " + std::to_string(ticks.back()) + ").");
+    }
+    return idx;
+}
+
+// src/wave_types.cpp:608-620  GetWidthArray (also src/hydro_forces.cpp:181-190)
+static std::vector<double> GetWidthArray(const std::vector<double>& a) {
+    std::vector<double> w(a.size());
+    for (int ii = 0; ii < int(w.size()); ii++) {
+        w[ii] = 0.0;
+        if (ii < int(a.size()) - 1) w[ii] += 0.5 * std::fabs(a[ii + 1] - a[ii]);
+        if (ii > 0) w[ii] += 0.5 * std::fabs(a[ii] - a[ii - 1]);
+    }
+    return w;
+}
+
+// src/wave_types.cpp:178-255  ComputeWaveNumber (incl. the factor-2 derivative at :227)
+static double ComputeWaveNumber(double omega, double water_depth, double g, double tolerance = 1e-6,
+                                int max_iterations = 100) {
+    constexpr double DEEP_WATER_THRESHOLD = 1000.0;
+    if (omega <= 0.0) throw std::runtime_error("Angular frequency must be positive.");
+    if (water_depth < 0.0) throw std::runtime_error("Water depth cannot be negative.");
+    if (g <= 0.0) throw std::runtime_error("Gravity must be positive.");
+    if (water_depth == 0.0 || water_depth > DEEP_WATER_THRESHOLD || std::isinf(water_depth)) return omega * omega / g;
+    double k       = omega * omega / g;
+    int iterations = 0;
+    double error   = 1.0;
+    while (error > tolerance && iterations < max_iterations) {
+        double tanh_kh = std::tanh(k * water_depth);
+        double f       = omega * omega - g * k * tanh_kh;
+        double df      = -2.0 * g * tanh_kh - g * k * water_depth * (1.0 - tanh_kh * tanh_kh);
+        if (std::fabs(df) < tolerance) throw std::runtime_error("Numerical instability: derivative too close to zero.");
+        double delta_k = f / df;
+        k -= delta_k;
+        error = std::fabs(delta_k);
+        iterations++;
+    }
+    if (iterations >= max_iterations) throw std::runtime_error("Failed to converge within maximum iterations.");
+    return k;
+}
+
+// src/wave_types.cpp:679-693
+static std::vector<double> PiersonMoskowitzSpectrumHz(std::vector<double>& f, double Hs, double Tp) {
+    std::sort(f.begin(), f.end());
+    std::vector<double> S(f.size());
+    for (size_t i = 0; i < f.size(); ++i) {
+        S[i] = 1.25 * std::pow(1 / Tp, 4) * std::pow(Hs / 2, 2) * std::pow(f[i], -5) *
+               std::exp(-1.25 * std::pow(1 / Tp, 4) * std::pow(f[i], -4));
+    }
+    return S;
+}
+
+// src/wave_types.cpp:695-715
+static std::vector<double> JONSWAPSpectrumHz(std::vector<double>& f, double Hs, double Tp, double gamma,
+                                             bool is_normalized) {
+    auto S                      = PiersonMoskowitzSpectrumHz(f, Hs, Tp);
+    double normalization_factor = (1 - 0.287 * std::log(gamma));
+    for (size_t i = 0; i < S.size(); ++i) {
+        double sigma = (f[i] <= 1.0 / Tp) ? 0.07 : 0.09;
+        S[i] *= std::pow(gamma, std::exp(-(1.0 / (2.0 * std::pow(sigma, 2))) * std::pow(f[i] * Tp - 1.0, 2)));
+        if (is_normalized) S[i] *= normalization_factor;
+    }
+    return S;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HydroData (include/hydroc/h5fileinfo.h, src/h5fileinfo.cpp)
+// Eigen::Tensor<double,3>(d0,d1,d2) is column-major: offset = i + d0*(j + d1*k).
+// ---------------------------------------------------------------------------------------------
+struct Tensor3 {
+    int d0 = 0, d1 = 0, d2 = 0;
+    std::vector<double> v;
+    void resize(int a, int b, int c) {
+        d0 = a; d1 = b; d2 = c;
+        v.assign(size_t(a) * b * c, 0.0);
+    }
+    double& operator()(int i, int j, int k) { return v[size_t(i) + size_t(d0) * (size_t(j) + size_t(d1) * k)]; }
+    double operator()(int i, int j, int k) const { return v[size_t(i) + size_t(d0) * (size_t(j) + size_t(d1) * k)]; }
+    // src/h5fileinfo.cpp:287-295: copy from the row-major file buffer
+    void from_row_major(const double* temp, int a, int b, int c) {
+        resize(a, b, c);
+        for (int i = 0; i < a; i++)
+            for (int j = 0; j < b; j++)
+                for (int k = 0; k < c; k++) (*this)(i, j, k) = temp[size_t(k) + size_t(c) * (size_t(j) + size_t(i) * b)];
+    }
+};
+
+struct BodyInfo {  // include/hydroc/h5fileinfo.h BodyInfo
+    double disp_vol = 0.0;
+    std::vector<double> cg{0, 0, 0}, cb{0, 0, 0};
+    std::vector<double> lin_matrix;      // 6x6, (i,j) -> [i*6+j]
+    std::vector<double> inf_added_mass;  // 6 x D (i,j) -> [i*D+j], already * rho
+    std::vector<double> rirf_time_vector;
+    Tensor3 rirf_matrix;  // [6][D][S]
+};
+struct RegularWaveInfo {
+    std::vector<double> freq_list;
+    Tensor3 excitation_mag_matrix;    // [6][1][nw] already * rho*g
+    Tensor3 excitation_phase_matrix;  // [6][1][nw]
+};
+struct IrregularWaveInfo {
+    std::vector<double> excitation_irf_time;
+    std::vector<std::vector<double>> excitation_irf_matrix;  // 6 x n, already * rho*g
+};
+
+struct HydroData {
+    double rho = 0, g = 0, water_depth = 0;
+    std::vector<BodyInfo> body_data_;
+    std::vector<RegularWaveInfo> reg_wave_data_;
+    std::vector<IrregularWaveInfo> irreg_wave_data_;
+    // src/h5fileinfo.cpp:321-323
+    double GetRIRFVal(int b, int dof, int col, int s) const { return body_data_[b].rirf_matrix(dof, col, s) * rho; }
+    int GetRIRFDims(int i) const {
+        const auto& t = body_data_[0].rirf_matrix;
+        return i == 0 ? t.d0 : (i == 1 ? t.d1 : t.d2);
+    }
+    // src/h5fileinfo.cpp:329-343
+    std::vector<double> GetRIRFTimeVector() const {
+        double tol = 1e-10;
+        auto& ref  = body_data_[0].rirf_time_vector;
+        for (size_t ii = 1; ii < body_data_.size(); ii++)
+            for (size_t jj = 0; jj < body_data_[ii].rirf_time_vector.size(); jj++)
+                if (std::fabs(body_data_[ii].rirf_time_vector[jj] - ref[jj]) > tol)
+                    throw std::runtime_error("RIRF time vectors have to be exactly the same for all bodies.");
+        return ref;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Wave models (src/wave_types.cpp)
+// ---------------------------------------------------------------------------------------------
+enum class WaveMode { noWaveCIC = 0, regular = 1, irregular = 2 };
+
+struct WaveBase {
+    virtual ~WaveBase() = default;
+    virtual void Initialize()                           = 0;
+    virtual std::vector<double> GetForceAtTime(double t) = 0;
+    virtual WaveMode GetWaveMode()                      = 0;
+    double g_ = 9.81, water_depth_ = 0.0;
+};
+
+struct NoWave : WaveBase {  // src/wave_types.cpp:257-264
+    unsigned num_bodies_;
+    explicit NoWave(unsigned nb = 1) : num_bodies_(nb) {}
+    void Initialize() override {}
+    std::vector<double> GetForceAtTime(double) override { return std::vector<double>(num_bodies_ * 6, 0.0); }
+    WaveMode GetWaveMode() override { return WaveMode::noWaveCIC; }
+};
+
+struct RegularWave : WaveBase {  // src/wave_types.cpp:266-352
+    unsigned num_bodies_;
+    double regular_wave_amplitude_ = 0, regular_wave_omega_ = 0, regular_wave_phase_ = 0;
+    std::vector<RegularWaveInfo> wave_info_;
+    std::vector<double> excitation_force_mag_, excitation_force_phase_;
+    double wavenumber_ = 0;
+    explicit RegularWave(unsigned nb = 1) : num_bodies_(nb) {}
+    void Initialize() override { wavenumber_ = ComputeWaveNumber(regular_wave_omega_, water_depth_, g_); }  // :274-276
+    WaveMode GetWaveMode() override { return WaveMode::regular; }
+    double GetOmegaDelta() const {  // :329-333
+        double omega_max = wave_info_[0].freq_list[wave_info_[0].freq_list.size() - 1];
+        double num_freqs = double(wave_info_[0].freq_list.size());
+        return omega_max / num_freqs;
+    }
+    static double Interp(const Tensor3& m, int i, int j, double freq_index_des) {  // :335-352
+        double freq_interp_val = freq_index_des - std::floor(freq_index_des);
+        int k0                 = (int)std::floor(freq_index_des);
+        if (k0 < 0 || k0 + 1 >= m.d2) throw std::out_of_range("regular wave frequency outside the BEM frequency list");
+        double lo = m(i, j, k0);
+        double hi = m(i, j, k0 + 1);
+        return (freq_interp_val * (hi - lo)) + lo;
+    }
+    void AddH5Data(const std::vector<RegularWaveInfo>& reg, const HydroData& sim) {  // :278-299
+        wave_info_     = reg;
+        water_depth_   = sim.water_depth;
+        g_             = sim.g;
+        int total_dofs = 6 * num_bodies_;
+        excitation_force_mag_.assign(total_dofs, 0.0);
+        excitation_force_phase_.assign(total_dofs, 0.0);
+        double wave_omega_delta = GetOmegaDelta();
+        double freq_index_des   = (regular_wave_omega_ / wave_omega_delta) - 1;
+        for (unsigned b = 0; b < num_bodies_; b++)
+            for (int rowEx = 0; rowEx < 6; rowEx++) {
+                int body_offset                              = 6 * b;
+                excitation_force_mag_[body_offset + rowEx]   = Interp(wave_info_[b].excitation_mag_matrix, rowEx, 0, freq_index_des);
+                excitation_force_phase_[body_offset + rowEx] = Interp(wave_info_[b].excitation_phase_matrix, rowEx, 0, freq_index_des);
+            }
+    }
+    std::vector<double> GetForceAtTime(double t) override {  // :315-327 (phase indexed by rowEx only -- reproduced)
+        std::vector<double> f(num_bodies_ * 6);
+        for (unsigned b = 0; b < num_bodies_; b++) {
+            int body_offset = 6 * b;
+            for (int rowEx = 0; rowEx < 6; rowEx++)
+                f[body_offset + rowEx] = excitation_force_mag_[body_offset + rowEx] * regular_wave_amplitude_ *
+                                         std::cos(regular_wave_omega_ * t + excitation_force_phase_[rowEx]);
+        }
+        return f;
+    }
+};
+
+struct IrregularWaveParams {  // include/hydroc/wave_types.h:277-292
+    unsigned num_bodies_            = 1;
+    double simulation_dt_           = 0;
+    double simulation_duration_     = 0;
+    double ramp_duration_           = 0.0;
+    double wave_height_             = 0.0;
+    double wave_period_             = 0.0;
+    double frequency_min_           = 0.001;
+    double frequency_max_           = 1.0;
+    double nfrequencies_            = 0;
+    double peak_enhancement_factor_ = 1.0;
+    bool is_normalized_             = false;
+    int seed_                       = 1;
+};
+
+struct IrregularWaves : WaveBase {
+    IrregularWaveParams params_;
+    std::vector<IrregularWaveInfo> wave_info_;
+    std::vector<std::vector<std::vector<double>>> ex_irf_sampled_;  // [b][6][L]
+    std::vector<std::vector<double>> ex_irf_time_sampled_, ex_irf_width_sampled_;
+    std::vector<double> spectrum_frequencies_, spectral_densities_, spectral_widths_, wave_phases_, wavenumbers_;
+    std::vector<double> free_surface_time_sampled_, free_surface_elevation_sampled_;
+    bool spectrumCreated_ = false;
+
+    explicit IrregularWaves(const IrregularWaveParams& p) : params_(p) {}
+    void Initialize() override {}
+    WaveMode GetWaveMode() override { return WaveMode::irregular; }
+
+    void AddH5Data(const std::vector<IrregularWaveInfo>& irreg, const HydroData& sim) {  // :506-513
+        wave_info_   = irreg;
+        water_depth_ = sim.water_depth;
+        g_           = sim.g;
+        InitializeIRFVectors();
+    }
+    void CalculateWidthIRF() {  // :622-628
+        for (unsigned b = 0; b < params_.num_bodies_; b++) ex_irf_width_sampled_[b] = GetWidthArray(ex_irf_time_sampled_[b]);
+    }
+    void InitializeIRFVectors() {  // :432-459 (eta-file branch deliberately not restated: UB in the reference)
+        ex_irf_sampled_.resize(params_.num_bodies_);
+        ex_irf_time_sampled_.resize(params_.num_bodies_);
+        ex_irf_width_sampled_.resize(params_.num_bodies_);
+        for (unsigned b = 0; b < params_.num_bodies_; b++) {
+            ex_irf_sampled_[b]      = wave_info_[b].excitation_irf_matrix;
+            ex_irf_time_sampled_[b] = wave_info_[b].excitation_irf_time;
+            CalculateWidthIRF();
+        }
+        if (params_.simulation_dt_ > 0.0) ResampleIRF(params_.simulation_dt_);
+        if (params_.wave_height_ != 0.0 && params_.wave_period_ != 0.0) {
+            CreateSpectrum();
+            CreateFreeSurfaceElevation();
+            spectrumCreated_ = true;
+        }
+    }
+    void ResampleIRF(double dt) {  // :572-606
+        for (unsigned b = 0; b < params_.num_bodies_; b++) {
+            auto& time_array    = ex_irf_time_sampled_[b];
+            auto& val_array     = ex_irf_sampled_[b];
+            auto time_array_old = time_array;
+            auto t0             = time_array_old[0];
+            auto t1             = time_array_old[time_array_old.size() - 1];
+            time_array          = LinSpaced(static_cast<int>(std::ceil((t1 - t0) / dt)), t0, t1);
+            CalculateWidthIRF();
+            std::vector<double> t_old_scaled = LinSpaced(int(time_array_old.size()), 0, 1);
+            std::vector<double> t_new_scaled = LinSpaced(int(time_array.size()), 0, 1);
+            CubicBSpline spline;
+            std::array<std::vector<double>, 6> pts;
+            for (int d = 0; d < 6; ++d) pts[d] = val_array[d];
+            spline.Fit(t_old_scaled, pts);
+            std::vector<std::vector<double>> vals_new(6, std::vector<double>(time_array.size()));
+            for (size_t i = 0; i < time_array.size(); i++) {
+                double out[6];
+                spline.Eval(t_new_scaled[i], out);
+                for (int d = 0; d < 6; ++d) vals_new[d][i] = out[d];
+            }
+            val_array = vals_new;
+        }
+    }
+    void CreateSpectrum() {  // :643-676
+        int nf;
+        if (params_.nfrequencies_ == 0) {
+            double df = 1.0 / params_.simulation_duration_;
+            nf        = int(std::ceil((params_.frequency_max_ - params_.frequency_min_) / df));
+        } else {
+            nf = int(params_.nfrequencies_);
+        }
+        spectrum_frequencies_ = LinSpaced(nf, params_.frequency_min_, params_.frequency_max_);
+        spectral_densities_   = JONSWAPSpectrumHz(spectrum_frequencies_, params_.wave_height_, params_.wave_period_,
+                                                  params_.peak_enhancement_factor_, params_.is_normalized_);
+        spectral_widths_      = GetWidthArray(spectrum_frequencies_);
+        wave_phases_.assign(nf, 0.0);
+        Mt19937 rng(uint32_t(params_.seed_));
+        for (int i = 0; i < nf; ++i) wave_phases_[i] = (2 * M_PI - 0.0) * canonical53(rng) + 0.0;
+        wavenumbers_.assign(nf, 0.0);
+        for (int i = 0; i < nf; ++i) wavenumbers_[i] = ComputeWaveNumber(2 * M_PI * spectrum_frequencies_[i], water_depth_, g_);
+    }
+    // :14-25, :27-44  (position is the origin, src/wave_types.cpp:752)
+    double GetEtaIrregular(double x_pos, double time) const {
+        double eta = 0.0;
+        for (size_t i = 0; i < spectrum_frequencies_.size(); ++i) {
+            auto amplitude = std::sqrt(2 * spectral_densities_[i] * spectral_widths_[i]);
+            auto omega     = 2 * M_PI * spectrum_frequencies_[i];
+            eta += amplitude * std::cos(wavenumbers_[i] * x_pos - omega * time + wave_phases_[i]);
+        }
+        return eta;
+    }
+    void CreateFreeSurfaceElevation() {  // :717-774
+        double t_irf_min = 0.0, t_irf_max = 0.0;
+        for (size_t ii = 0; ii < ex_irf_time_sampled_.size(); ii++) {
+            const auto& ta = ex_irf_time_sampled_[ii];
+            if (ta[0] < t_irf_min) t_irf_min = ta[0];
+            if (ta[0] > t_irf_max) t_irf_max = ta[0];
+            if (ta[ta.size() - 1] > t_irf_max) t_irf_max = ta[ta.size() - 1];
+            if (ta[ta.size() - 1] < t_irf_min) t_irf_min = ta[ta.size() - 1];
+        }
+        auto duration      = params_.simulation_duration_ + 2 * (t_irf_max - t_irf_min);
+        auto num_timesteps = static_cast<int>(std::ceil(duration / params_.simulation_dt_));
+        free_surface_time_sampled_ = LinSpaced(num_timesteps + 1, 0, num_timesteps * params_.simulation_dt_);
+        for (size_t ii = 0; ii < free_surface_time_sampled_.size(); ii++) free_surface_time_sampled_[ii] += -t_irf_max;
+        free_surface_elevation_sampled_.assign(free_surface_time_sampled_.size(), 0.0);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)  // init only; the reference loop (:53-57) is serial, sums are per-sample
+#endif
+        for (long j = 0; j < long(free_surface_time_sampled_.size()); ++j)
+            free_surface_elevation_sampled_[j] = GetEtaIrregular(0.0, free_surface_time_sampled_[j]);
+        if (params_.ramp_duration_ > 0.0) {
+            for (size_t i = 0; i < free_surface_time_sampled_.size(); ++i) {
+                if (free_surface_time_sampled_[i] < params_.ramp_duration_) {
+                    if (free_surface_time_sampled_[i] <= 0.0)
+                        free_surface_elevation_sampled_[i] *= 0.0;
+                    else
+                        free_surface_elevation_sampled_[i] *= free_surface_time_sampled_[i] / params_.ramp_duration_;
+                }
+            }
+        }
+    }
+    double ExcitationConvolution(int body, int dof, double time) {  // :776-844
+        double f_ex           = 0.0;
+        auto& irf_time_array  = ex_irf_time_sampled_[body];
+        auto& irf_val_mat     = ex_irf_sampled_[body];
+        auto& irf_width_array = ex_irf_width_sampled_[body];
+        auto tmin             = free_surface_time_sampled_.front();
+        auto tmax             = free_surface_time_sampled_.back();
+        double t_tau0         = time - irf_time_array[0];
+        long idx              = 0;
+        if (t_tau0 <= tmin)
+            idx = 0;
+        else if (t_tau0 >= tmax)
+            idx = long(free_surface_time_sampled_.size()) - 2;
+        else
+            idx = long(get_lower_index(t_tau0, free_surface_time_sampled_));
+        for (size_t j = 0; j < irf_time_array.size(); ++j) {
+            double tau   = irf_time_array[j];
+            double t_tau = time - tau;
+            if (tmin <= t_tau && t_tau <= tmax) {
+                while (free_surface_time_sampled_[idx] > t_tau) idx -= 1;
+                auto t1 = free_surface_time_sampled_[idx];
+                auto t2 = free_surface_time_sampled_[idx + 1];
+                double eta_val;
+                if (t_tau == t1) {
+                    eta_val = free_surface_elevation_sampled_[idx];
+                } else if (t_tau == t2) {
+                    eta_val = free_surface_elevation_sampled_[idx + 1];
+                } else if (t_tau > t1 && t_tau < t2) {
+                    auto eta1 = free_surface_elevation_sampled_[idx];
+                    auto eta2 = free_surface_elevation_sampled_[idx + 1];
+                    auto w1   = (t2 - t_tau) / (t2 - t1);
+                    auto w2   = 1.0 - w1;
+                    eta_val   = w1 * eta1 + w2 * eta2;
+                } else {
+                    throw std::runtime_error("Excitation convolution: wrong tau value " + std::to_string(tau) + " not between " +
+                                             std::to_string(t1) + " and " + std::to_string(t2) + ".");
+                }
+                f_ex += irf_val_mat[dof][j] * eta_val * irf_width_array[j];
+            } else {
+                throw std::runtime_error(
+                    "Excitation convolution: trying to find free surface elevation at a time out of bounds from the "
+                    "precomputed free surface elevation (" + std::to_string(t_tau) + "not in [" + std::to_string(tmin) + ", " +
+                    std::to_string(tmax) + "]). Excitation force ignored at this time step.");
+            }
+        }
+        return f_ex;
+    }
+    std::vector<double> GetForceAtTime(double t) override {  // :552-570
+        unsigned total_dofs = params_.num_bodies_ * 6;
+        std::vector<double> f(total_dofs, 0.0);
+        for (unsigned body = 0; body < params_.num_bodies_; body++)
+            for (int dof = 0; dof < 6; ++dof) f[body * 6 + dof] = ExcitationConvolution(int(body), dof, t);
+        return f;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Body state handed over at the boundary (what the reference pulls out of ChBody each step:
+// GetPos, GetRot().GetCardanAnglesXYZ, GetPosDt, GetAngVelParent; src/hydro_forces.cpp:279-280,567-568)
+// ---------------------------------------------------------------------------------------------
+struct BodyState {
+    double pos[3], rpy[3], linvel[3], angvel[3];
+};
+
+struct TaperedDirectOptions {  // include/hydroc/hydro_forces.h:246-259
+    int smoothing                = 0;  // 0 = "sg", 1 = "moving_average"
+    int window_length            = 5;
+    double rirf_end_time         = -1.0;
+    double taper_start_percent   = 0.8;
+    double taper_end_percent     = 1.0;
+    double taper_final_amplitude = 0.0;
+};
+
+struct ProfileStats {  // include/hydroc/hydro_forces.h:153-160
+    double hydrostatics_seconds = 0, radiation_seconds = 0, waves_seconds = 0;
+    int hydrostatics_calls = 0, radiation_calls = 0, waves_calls = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// TestHydro (src/hydro_forces.cpp:170-767) + ChLoadAddedMass (src/chloadaddedmass.cpp)
+// ---------------------------------------------------------------------------------------------
+struct TestHydro {
+    int num_bodies_;
+    HydroData file_info_;
+    std::shared_ptr<WaveBase> user_waves_;
+    std::vector<BodyState> bodies_;  // current Chrono-side state
+    double ch_time_ = 0.0;           // bodies_[0]->GetChTime()
+    double g_sys_[3] = {0.0, 0.0, -9.81};  // system->GetGravitationalAcceleration()
+
+    std::vector<double> force_hydrostatic_, force_radiation_damping_, force_waves_, total_force_;
+    std::vector<double> equilibrium_, cb_minus_cg_;
+    std::vector<double> rirf_time_vector, rirf_width_vector;
+    std::vector<std::vector<std::vector<double>>> velocity_history_;
+    std::vector<double> time_history_;
+    double prev_time = -1;
+    int convolution_mode_ = 0;  // 0 Baseline, 1 TaperedDirect
+    bool rirf_processed_ready_ = false;
+    std::vector<Tensor3> rirf_processed_;
+    TaperedDirectOptions tapered_opts_;
+    std::vector<double> infinite_added_mass;  // D x D row-major (chloadaddedmass.cpp:18-21)
+    ProfileStats profile_stats_;
+
+    explicit TestHydro(int nb) : num_bodies_(nb) {
+        file_info_.body_data_.resize(nb);
+        file_info_.reg_wave_data_.resize(nb);
+        file_info_.irreg_wave_data_.resize(nb);
+        bodies_.resize(nb);
+    }
+
+    void Construct() {  // src/hydro_forces.cpp:170-242
+        prev_time        = -1;
+        rirf_time_vector = file_info_.GetRIRFTimeVector();
+        rirf_width_vector.resize(rirf_time_vector.size());
+        for (int ii = 0; ii < int(rirf_width_vector.size()); ii++) {
+            rirf_width_vector[ii] = 0.0;
+            if (ii < int(rirf_time_vector.size()) - 1) rirf_width_vector[ii] += 0.5 * std::fabs(rirf_time_vector[ii + 1] - rirf_time_vector[ii]);
+            if (ii > 0) rirf_width_vector[ii] += 0.5 * std::fabs(rirf_time_vector[ii] - rirf_time_vector[ii - 1]);
+        }
+        int total_dofs = kDofPerBody * num_bodies_;
+        time_history_.clear();
+        velocity_history_.clear();
+        for (int b = 0; b < num_bodies_; ++b) velocity_history_.push_back(std::vector<std::vector<double>>(0));
+        force_hydrostatic_.assign(total_dofs, 0.0);
+        force_radiation_damping_.assign(total_dofs, 0.0);
+        force_waves_.assign(total_dofs, 0.0);
+        total_force_.assign(total_dofs, 0.0);
+        equilibrium_.assign(total_dofs, 0.0);
+        cb_minus_cg_.assign(kDofLinOrRot * num_bodies_, 0.0);
+        for (int b = 0; b < num_bodies_; ++b)
+            for (int i = 0; i < kDofLinOrRot; ++i) {
+                equilibrium_[i + kDofPerBody * b]  = file_info_.body_data_[b].cg[i];
+                cb_minus_cg_[i + kDofLinOrRot * b] = file_info_.body_data_[b].cb[i] - file_info_.body_data_[b].cg[i];
+            }
+        // ChLoadAddedMass ctor, src/chloadaddedmass.cpp:12-25
+        infinite_added_mass.assign(size_t(total_dofs) * total_dofs, 0.0);
+        for (int i = 0; i < num_bodies_; i++) {
+            const auto& blk = file_info_.body_data_[i].inf_added_mass;
+            if (blk.size() != size_t(6) * total_dofs) throw std::runtime_error("added mass block has wrong shape");
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < total_dofs; ++c) infinite_added_mass[size_t(i * 6 + r) * total_dofs + c] = blk[size_t(r) * total_dofs + c];
+        }
+        rirf_processed_ready_ = false;
+        user_waves_           = std::make_shared<NoWave>();  // default argument of the ctor (hydro_forces.h:180)
+    }
+
+    void AddWaves(std::shared_ptr<WaveBase> waves) {  // :244-261
+        user_waves_ = waves;
+        switch (user_waves_->GetWaveMode()) {
+            case WaveMode::regular:
+                std::static_pointer_cast<RegularWave>(user_waves_)->AddH5Data(file_info_.reg_wave_data_, file_info_);
+                break;
+            case WaveMode::irregular:
+                std::static_pointer_cast<IrregularWaves>(user_waves_)->AddH5Data(file_info_.irreg_wave_data_, file_info_);
+                break;
+            default:
+                break;
+        }
+        user_waves_->Initialize();
+    }
+
+    std::vector<double> ComputeForceHydrostatics() {  // :263-322
+        const double rho         = file_info_.rho;
+        const double glen        = std::sqrt(g_sys_[0] * g_sys_[0] + g_sys_[1] * g_sys_[1] + g_sys_[2] * g_sys_[2]);
+        const double rho_times_g = rho * glen;
+        for (int b = 0; b < num_bodies_; ++b) {
+            const int body_offset = kDofPerBody * b;
+            double* const fh      = &force_hydrostatic_[body_offset];
+            const double* const eq = &equilibrium_[body_offset];
+            double dq[6];
+            for (int k = 0; k < 3; ++k) dq[k] = bodies_[b].pos[k] - eq[k];
+            for (int k = 0; k < 3; ++k) dq[3 + k] = bodies_[b].rpy[k] - eq[3 + k];
+            const std::vector<double> K = file_info_.body_data_[b].lin_matrix;  // per-step copy like :292
+            for (int i = 0; i < kDofPerBody; ++i) {
+                double s = 0.0;
+                for (int j = 0; j < kDofPerBody; ++j) s += K[i * 6 + j] * dq[j];
+                fh[i] += -rho_times_g * s;
+            }
+            const double V = file_info_.body_data_[b].disp_vol;
+            double fb[3];
+            for (int k = 0; k < 3; ++k) fb[k] = rho * (-g_sys_[k]) * V;
+            fh[0] += fb[0];
+            fh[1] += fb[1];
+            fh[2] += fb[2];
+            const double* r = &cb_minus_cg_[kDofLinOrRot * b];
+            fh[3] += r[1] * fb[2] - r[2] * fb[1];
+            fh[4] += r[2] * fb[0] - r[0] * fb[2];
+            fh[5] += r[0] * fb[1] - r[1] * fb[0];
+        }
+        profile_stats_.hydrostatics_calls++;
+        return force_hydrostatic_;
+    }
+
+    static void PruneHistory(std::vector<double>& th, std::vector<std::vector<std::vector<double>>>& vh, int nb, double tmin) {  // :327-340
+        while (th.size() > 1 && th[th.size() - 2] < tmin) {
+            th.pop_back();
+            for (int b = 0; b < nb; ++b)
+                if (!vh[b].empty()) vh[b].pop_back();
+        }
+    }
+    static void InterpolateVelocity6D(const std::vector<std::vector<double>>& vhb, size_t newer_index, double query_time,
+                                      double older_time, double newer_time, double out[6]) {  // :343-371
+        if (query_time == older_time) {
+            const auto& o = vhb[newer_index + 1];
+            for (int d = 0; d < 6; ++d) out[d] = o[d];
+            return;
+        }
+        if (query_time == newer_time) {
+            const auto& nn = vhb[newer_index];
+            for (int d = 0; d < 6; ++d) out[d] = nn[d];
+            return;
+        }
+        if (query_time > older_time && query_time < newer_time) {
+            const double time_delta   = (newer_time - older_time);
+            const double weight_older = (time_delta != 0.0) ? ((newer_time - query_time) / time_delta) : 0.0;
+            const double weight_newer = 1.0 - weight_older;
+            const auto& o             = vhb[newer_index + 1];
+            const auto& nn            = vhb[newer_index];
+            for (int d = 0; d < 6; ++d) out[d] = weight_older * o[d] + weight_newer * nn[d];
+            return;
+        }
+        throw std::runtime_error("Radiation convolution: interpolation error; query_time not bracketed by history.");
+    }
+    static bool AdvanceToBracket(const std::vector<double>& th, size_t& index, double query_time) {  // :374-381
+        while ((index + 1) < th.size() && th[index + 1] > query_time) ++index;
+        return ((index + 1) < th.size());
+    }
+
+    void EnsureProcessedRIRF() {  // :385-535 (CSV export omitted: diagnostics only)
+        if (rirf_processed_ready_) return;
+        const int steps = file_info_.GetRIRFDims(2);
+        const int cols  = kDofPerBody * num_bodies_;
+        const int rows  = kDofPerBody;
+        rirf_processed_.clear();
+        rirf_processed_.resize(num_bodies_);
+        const double sg5[5] = {-3.0 / 35.0, 12.0 / 35.0, 17.0 / 35.0, 12.0 / 35.0, -3.0 / 35.0};
+        for (int b = 0; b < num_bodies_; ++b) {
+            Tensor3 processed;
+            processed.resize(rows, cols, steps);
+            int effective_steps = steps;
+            if (tapered_opts_.rirf_end_time > 0.0) {
+                double dt       = rirf_time_vector[1] - rirf_time_vector[0];
+                int end_step    = static_cast<int>(std::floor(tapered_opts_.rirf_end_time / dt));
+                effective_steps = std::min(end_step, steps);
+            }
+            for (int row_dof = 0; row_dof < rows; ++row_dof) {
+                for (int col = 0; col < cols; ++col) {
+                    std::vector<double> k_raw(steps);
+                    for (int s = 0; s < steps; ++s) k_raw[s] = file_info_.GetRIRFVal(b, row_dof, col, s);
+                    if (tapered_opts_.rirf_end_time > 0.0) k_raw.resize(effective_steps);
+                    std::vector<double> k_smooth(effective_steps);
+                    if (tapered_opts_.smoothing == 1) {
+                        const int w    = std::max(3, tapered_opts_.window_length);
+                        const int half = w / 2;
+                        for (int s = 0; s < effective_steps; ++s) {
+                            int a      = std::max(0, s - half);
+                            int bb     = std::min(effective_steps - 1, s + half);
+                            double sum = 0.0;
+                            int cnt    = 0;
+                            for (int i = a; i <= bb; ++i) {
+                                sum += k_raw[i];
+                                ++cnt;
+                            }
+                            k_smooth[s] = (cnt > 0) ? (sum / cnt) : k_raw[s];
+                        }
+                    } else {
+                        if (effective_steps >= 5) {
+                            k_smooth[0] = k_raw[0];
+                            k_smooth[1] = k_raw[1];
+                            for (int s = 2; s <= effective_steps - 3; ++s)
+                                k_smooth[s] = sg5[0] * k_raw[s - 2] + sg5[1] * k_raw[s - 1] + sg5[2] * k_raw[s] + sg5[3] * k_raw[s + 1] + sg5[4] * k_raw[s + 2];
+                            k_smooth[effective_steps - 2] = k_raw[effective_steps - 2];
+                            k_smooth[effective_steps - 1] = k_raw[effective_steps - 1];
+                        } else {
+                            k_smooth = k_raw;
+                        }
+                    }
+                    int tc_index = static_cast<int>(std::floor(tapered_opts_.taper_start_percent * static_cast<double>(effective_steps)));
+                    int tc_end   = static_cast<int>(std::floor(tapered_opts_.taper_end_percent * static_cast<double>(effective_steps)));
+                    tc_index     = std::max(0, std::min(tc_index, effective_steps));
+                    tc_end       = std::max(tc_index, std::min(tc_end, effective_steps));
+                    int taper_len = tc_end - tc_index;
+                    const double pi_const = 3.14159265358979323846;
+                    for (int s = 0; s < effective_steps; ++s) {
+                        double val = k_smooth[s];
+                        if (s < tc_index) {
+                        } else if (s < tc_end && taper_len > 0) {
+                            double t = (static_cast<double>(s - tc_index)) / static_cast<double>(taper_len);
+                            double w = tapered_opts_.taper_final_amplitude +
+                                       (1.0 - tapered_opts_.taper_final_amplitude) * 0.5 * (1.0 + std::cos(pi_const * t));
+                            val *= w;
+                        } else {
+                            val = 0.0;
+                        }
+                        processed(row_dof, col, s) = val;
+                    }
+                    for (int s = effective_steps; s < steps; ++s) processed(row_dof, col, s) = 0.0;
+                }
+            }
+            rirf_processed_[b] = std::move(processed);
+        }
+        rirf_processed_ready_ = true;
+    }
+
+    double GetRIRFval(int row, int col, int st) {  // :693-711
+        if (row < 0 || row >= kDofPerBody * num_bodies_ || col < 0 || col >= kDofPerBody * num_bodies_ || st < 0 ||
+            st >= file_info_.GetRIRFDims(2)) {
+            throw std::out_of_range("rirfval index out of range in TestHydro");
+        }
+        int body_index = row / kDofPerBody;
+        int row_dof    = row % kDofPerBody;
+        if (convolution_mode_ == 1) {
+            EnsureProcessedRIRF();
+            return rirf_processed_[body_index](row_dof, col, st);
+        }
+        return file_info_.GetRIRFVal(body_index, row_dof, col, st);
+    }
+
+    std::vector<double> ComputeForceRadiationDampingConv() {  // :537-691 (the OpenMP branch is the shipped one)
+        const int rirf_steps = file_info_.GetRIRFDims(2);
+        const int total_dofs = kDofPerBody * num_bodies_;
+        if (convolution_mode_ == 1) EnsureProcessedRIRF();
+        const double simulation_time = ch_time_;
+        const int rirf_last_index    = static_cast<int>(rirf_time_vector.size()) - 1;
+        const double history_min_time = simulation_time - (rirf_last_index >= 0 ? rirf_time_vector[rirf_last_index] : 0.0);
+        if (!time_history_.empty() && simulation_time == time_history_.front())
+            throw std::runtime_error("Tried to compute the radiation damping convolution twice within the same time step!");
+        time_history_.insert(time_history_.begin(), simulation_time);
+        for (int b = 0; b < num_bodies_; ++b) {
+            auto& vhb = velocity_history_[b];
+            std::vector<double> v = {bodies_[b].linvel[0], bodies_[b].linvel[1], bodies_[b].linvel[2],
+                                     bodies_[b].angvel[0], bodies_[b].angvel[1], bodies_[b].angvel[2]};
+            vhb.insert(vhb.begin(), std::move(v));
+        }
+        PruneHistory(time_history_, velocity_history_, num_bodies_, history_min_time);
+        profile_stats_.radiation_calls++;
+        if (time_history_.size() <= 1) return force_radiation_damping_;
+        size_t history_index = 0;
+#ifdef _OPENMP
+        const int num_threads = omp_get_max_threads();
+        std::vector<std::vector<double>> thread_locals(num_threads, std::vector<double>(total_dofs, 0.0));
+        std::string omp_error;
+#pragma omp parallel
+        {
+            const int tid   = omp_get_thread_num();
+            auto& local_out = thread_locals[tid];
+            size_t history_index_local = history_index;
+#pragma omp for schedule(static)
+            for (int step = 0; step < rirf_steps; ++step) {
+                try {
+                    const double rirf_query_time = simulation_time - rirf_time_vector[step];
+                    size_t time_index            = history_index_local;
+                    if (!AdvanceToBracket(time_history_, time_index, rirf_query_time)) continue;
+                    history_index_local     = time_index;
+                    const double newer_time = time_history_[history_index_local];
+                    const double older_time = time_history_[history_index_local + 1];
+                    for (int body_index = 0; body_index < num_bodies_; ++body_index) {
+                        const auto& vhb = velocity_history_[body_index];
+                        if (vhb.size() <= history_index_local) continue;
+                        double v[kDofPerBody];
+                        InterpolateVelocity6D(vhb, history_index_local, rirf_query_time, older_time, newer_time, v);
+                        const double step_width = rirf_width_vector[step];
+                        if (step_width == 0.0) continue;
+                        const int body_col_offset = body_index * kDofPerBody;
+                        for (int dof = 0; dof < kDofPerBody; ++dof) {
+                            const int col                   = body_col_offset + dof;
+                            const double contribution_scale = v[dof] * step_width;
+                            if (contribution_scale == 0.0) continue;
+                            for (int row = 0; row < total_dofs; ++row) local_out[row] += GetRIRFval(row, col, step) * contribution_scale;
+                        }
+                    }
+                } catch (const std::exception& e) {  // an exception may not leave an OpenMP region
+#pragma omp critical
+                    omp_error = e.what();
+                }
+            }
+        }
+        if (!omp_error.empty()) throw std::runtime_error(omp_error);
+        for (int t = 0; t < num_threads; ++t) {
+            const auto& local = thread_locals[t];
+            for (int row = 0; row < total_dofs; ++row) force_radiation_damping_[row] += local[row];
+        }
+#else
+        double* out = force_radiation_damping_.data();
+        for (int step = 0; step < rirf_steps; ++step) {
+            const double rirf_query_time = simulation_time - rirf_time_vector[step];
+            size_t time_index            = history_index;
+            if (!AdvanceToBracket(time_history_, time_index, rirf_query_time)) break;
+            history_index           = time_index;
+            const double newer_time = time_history_[history_index];
+            const double older_time = time_history_[history_index + 1];
+            for (int body_index = 0; body_index < num_bodies_; ++body_index) {
+                const auto& vhb = velocity_history_[body_index];
+                if (vhb.size() <= history_index) continue;
+                double v[kDofPerBody];
+                InterpolateVelocity6D(vhb, history_index, rirf_query_time, older_time, newer_time, v);
+                const double step_width   = rirf_width_vector[step];
+                const int body_col_offset = body_index * kDofPerBody;
+                for (int dof = 0; dof < kDofPerBody; ++dof) {
+                    const int col                   = body_col_offset + dof;
+                    const double contribution_scale = v[dof] * step_width;
+                    if (contribution_scale == 0.0) continue;
+                    for (int row = 0; row < total_dofs; ++row) out[row] += GetRIRFval(row, col, step) * contribution_scale;
+                }
+            }
+        }
+#endif
+        return force_radiation_damping_;
+    }
+
+    std::vector<double> ComputeForceWaves() {  // :713-725
+        if (bodies_.empty()) throw std::runtime_error("bodies_ array is empty in ComputeForceWaves");
+        force_waves_ = user_waves_->GetForceAtTime(ch_time_);
+        profile_stats_.waves_calls++;
+        return force_waves_;
+    }
+
+    double CoordinateFuncForBody(int b, int dof_index) {  // :727-767
+        if (dof_index < 0 || dof_index >= kDofPerBody || b < 1 || b > num_bodies_)
+            throw std::out_of_range("Invalid index in CoordinateFuncForBody");
+        const int body_num_offset = kDofPerBody * (b - 1);
+        const int total_dofs      = kDofPerBody * num_bodies_;
+        if (ch_time_ == prev_time) return total_force_[body_num_offset + dof_index];
+        prev_time = ch_time_;
+        std::fill(total_force_.begin(), total_force_.end(), 0.0);
+        std::fill(force_hydrostatic_.begin(), force_hydrostatic_.end(), 0.0);
+        std::fill(force_radiation_damping_.begin(), force_radiation_damping_.end(), 0.0);
+        std::fill(force_waves_.begin(), force_waves_.end(), 0.0);
+        force_hydrostatic_       = ComputeForceHydrostatics();
+        force_radiation_damping_ = ComputeForceRadiationDampingConv();
+        force_waves_             = ComputeForceWaves();
+        if (int(force_waves_.size()) < total_dofs)  // the reference reads past a 6-vector here; refuse instead
+            throw std::runtime_error("wave model returns fewer than 6N force entries (default NoWave with N>1)");
+        for (int index = 0; index < total_dofs; index++)
+            total_force_[index] = force_hydrostatic_[index] - force_radiation_damping_[index] + force_waves_[index];
+        return total_force_[body_num_offset + dof_index];
+    }
+
+    // src/chloadaddedmass.cpp:55-70 with M = system-sized matrix holding the DxD block top-left (:27-44)
+    void AddedMassMv(double* R, const double* w, double c, int n_sys) const {
+        const int D = kDofPerBody * num_bodies_;
+        if (n_sys < D) throw std::runtime_error("system has fewer coordinates than the added-mass block");
+        for (int i = 0; i < D; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < D; ++j) s += infinite_added_mass[size_t(i) * D + j] * w[j];
+            R[i] += c * s;
+        }
+    }
+};
+
+}  // namespace orc
+
+// =================================================================================================
+// C interface for the tests (ctypes).  Return 0 = ok, 1 = std::runtime_error, 2 = std::out_of_range,
+// 3 = other.  orc_last_error() gives the message.
+// =================================================================================================
+struct orc_ctx {
+    std::unique_ptr<orc::TestHydro> hydro;
+    std::string err;
+    bool constructed = false;
+};
+
+#define ORC_TRY try {
+#define ORC_CATCH(ctx)                                   \
+    }                                                    \
+    catch (const std::out_of_range& e) {                 \
+        (ctx)->err = e.what();                           \
+        return 2;                                        \
+    }                                                    \
+    catch (const std::runtime_error& e) {                \
+        (ctx)->err = e.what();                           \
+        return 1;                                        \
+    }                                                    \
+    catch (const std::exception& e) {                    \
+        (ctx)->err = e.what();                           \
+        return 3;                                        \
+    }                                                    \
+    return 0;
+
+extern "C" {
+
+orc_ctx* orc_create(int num_bodies) {
+    auto* c  = new orc_ctx;
+    c->hydro = std::make_unique<orc::TestHydro>(num_bodies);
+    return c;
+}
+void orc_destroy(orc_ctx* c) { delete c; }
+const char* orc_last_error(orc_ctx* c) { return c->err.c_str(); }
+int orc_num_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+// ---- ingest: the values H5FileInfo::ReadH5Data reads, scaling applied as in src/h5fileinfo.cpp:60-90
+int orc_set_simulation_parameters(orc_ctx* c, double rho, double g, double water_depth) {
+    ORC_TRY
+    c->hydro->file_info_.rho         = rho;
+    c->hydro->file_info_.g           = g;
+    c->hydro->file_info_.water_depth = water_depth;
+    ORC_CATCH(c)
+}
+int orc_set_body(orc_ctx* c, int b, double disp_vol, const double* cg, const double* cb, const double* lin36,
+                 const double* inf_added_mass /*[6][D] unscaled*/, const double* rirf_t, int S,
+                 const double* rirf_K /*[6][D][S] unscaled, file order*/) {
+    ORC_TRY
+    auto& h = *c->hydro;
+    if (b < 0 || b >= h.num_bodies_) throw std::out_of_range("body index");
+    const int D = 6 * h.num_bodies_;
+    auto& bd    = h.file_info_.body_data_[b];
+    bd.disp_vol = disp_vol;
+    bd.cg.assign(cg, cg + 3);
+    bd.cb.assign(cb, cb + 3);
+    bd.lin_matrix.assign(lin36, lin36 + 36);
+    bd.inf_added_mass.assign(inf_added_mass, inf_added_mass + size_t(6) * D);
+    for (auto& x : bd.inf_added_mass) x *= h.file_info_.rho;  // h5fileinfo.cpp:61
+    bd.rirf_time_vector.assign(rirf_t, rirf_t + S);
+    bd.rirf_matrix.from_row_major(rirf_K, 6, D, S);
+    ORC_CATCH(c)
+}
+int orc_set_body_excitation_rao(orc_ctx* c, int b, const double* w, int nw, const double* mag, const double* phase) {
+    ORC_TRY
+    auto& h = *c->hydro;
+    if (b < 0 || b >= h.num_bodies_) throw std::out_of_range("body index");
+    auto& r = h.file_info_.reg_wave_data_[b];
+    r.freq_list.assign(w, w + nw);
+    r.excitation_mag_matrix.from_row_major(mag, 6, 1, nw);
+    const double rg = h.file_info_.rho * h.file_info_.g;
+    for (auto& x : r.excitation_mag_matrix.v) x = x * rg;  // h5fileinfo.cpp:73-75
+    r.excitation_phase_matrix.from_row_major(phase, 6, 1, nw);
+    ORC_CATCH(c)
+}
+int orc_set_body_excitation_irf(orc_ctx* c, int b, const double* t, int n, const double* f /*[6][1][n]*/) {
+    ORC_TRY
+    auto& h = *c->hydro;
+    if (b < 0 || b >= h.num_bodies_) throw std::out_of_range("body index");
+    auto& r = h.file_info_.irreg_wave_data_[b];
+    r.excitation_irf_time.assign(t, t + n);
+    r.excitation_irf_matrix.assign(6, std::vector<double>(n));
+    const double rg = h.file_info_.rho * h.file_info_.g;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < n; ++j) {
+            r.excitation_irf_matrix[i][j] = f[size_t(i) * n + j];  // SqueezeMid, h5fileinfo.cpp:183-195
+            r.excitation_irf_matrix[i][j] *= rg;                   // :90
+        }
+    ORC_CATCH(c)
+}
+int orc_construct(orc_ctx* c) {
+    ORC_TRY
+    c->hydro->Construct();
+    c->constructed = true;
+    ORC_CATCH(c)
+}
+int orc_set_gravity(orc_ctx* c, const double* g3) {
+    ORC_TRY
+    for (int k = 0; k < 3; ++k) c->hydro->g_sys_[k] = g3[k];
+    ORC_CATCH(c)
+}
+int orc_add_waves_none(orc_ctx* c, int num_bodies_arg) {
+    ORC_TRY
+    c->hydro->AddWaves(std::make_shared<orc::NoWave>(unsigned(num_bodies_arg)));
+    ORC_CATCH(c)
+}
+int orc_add_waves_regular(orc_ctx* c, int num_bodies_arg, double amplitude, double omega) {
+    ORC_TRY
+    auto w                     = std::make_shared<orc::RegularWave>(unsigned(num_bodies_arg));
+    w->regular_wave_amplitude_ = amplitude;
+    w->regular_wave_omega_     = omega;
+    c->hydro->AddWaves(w);
+    ORC_CATCH(c)
+}
+int orc_add_waves_irregular(orc_ctx* c, int num_bodies_arg, double simulation_dt, double simulation_duration,
+                            double ramp_duration, double wave_height, double wave_period, double frequency_min,
+                            double frequency_max, double nfrequencies, double peak_enhancement_factor, int is_normalized,
+                            int seed) {
+    ORC_TRY
+    orc::IrregularWaveParams p;
+    p.num_bodies_              = unsigned(num_bodies_arg);
+    p.simulation_dt_           = simulation_dt;
+    p.simulation_duration_     = simulation_duration;
+    p.ramp_duration_           = ramp_duration;
+    p.wave_height_             = wave_height;
+    p.wave_period_             = wave_period;
+    p.frequency_min_           = frequency_min;
+    p.frequency_max_           = frequency_max;
+    p.nfrequencies_            = nfrequencies;
+    p.peak_enhancement_factor_ = peak_enhancement_factor;
+    p.is_normalized_           = is_normalized != 0;
+    p.seed_                    = seed;
+    c->hydro->AddWaves(std::make_shared<orc::IrregularWaves>(p));
+    ORC_CATCH(c)
+}
+int orc_set_convolution_mode(orc_ctx* c, int mode) {
+    ORC_TRY
+    c->hydro->convolution_mode_ = mode;
+    ORC_CATCH(c)
+}
+int orc_set_tapered_direct_options(orc_ctx* c, int smoothing, int window_length, double rirf_end_time,
+                                   double taper_start_percent, double taper_end_percent, double taper_final_amplitude) {
+    ORC_TRY
+    auto& o                 = c->hydro->tapered_opts_;
+    o.smoothing             = smoothing;
+    o.window_length         = window_length;
+    o.rirf_end_time         = rirf_end_time;
+    o.taper_start_percent   = taper_start_percent;
+    o.taper_end_percent     = taper_end_percent;
+    o.taper_final_amplitude = taper_final_amplitude;
+    c->hydro->rirf_processed_ready_ = false;
+    ORC_CATCH(c)
+}
+
+static void orc_load_state(orc::TestHydro& h, double t, const double* pos, const double* rpy, const double* linvel,
+                           const double* angvel) {
+    h.ch_time_ = t;
+    for (int b = 0; b < h.num_bodies_; ++b)
+        for (int k = 0; k < 3; ++k) {
+            h.bodies_[b].pos[k]    = pos[3 * b + k];
+            h.bodies_[b].rpy[k]    = rpy[3 * b + k];
+            h.bodies_[b].linvel[k] = linvel[3 * b + k];
+            h.bodies_[b].angvel[k] = angvel[3 * b + k];
+        }
+}
+
+// All 6N ComponentFunc::GetVal callbacks of one Chrono update (src/hydro_forces.cpp:79-85,136-144,727-767)
+int orc_step(orc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel,
+             double* total_out) {
+    ORC_TRY
+    auto& h = *c->hydro;
+    orc_load_state(h, t, pos, rpy, linvel, angvel);
+    for (int b = 1; b <= h.num_bodies_; ++b)
+        for (int i = 0; i < 6; ++i) total_out[6 * (b - 1) + i] = h.CoordinateFuncForBody(b, i);
+    ORC_CATCH(c)
+}
+int orc_coordinate_func_for_body(orc_ctx* c, int b, int dof, double* out) {
+    ORC_TRY
+    *out = c->hydro->CoordinateFuncForBody(b, dof);
+    ORC_CATCH(c)
+}
+int orc_get_force_components(orc_ctx* c, double* hs, double* rad, double* waves) {
+    ORC_TRY
+    auto& h = *c->hydro;
+    const int D = 6 * h.num_bodies_;
+    for (int i = 0; i < D; ++i) {
+        if (hs) hs[i] = h.force_hydrostatic_[i];
+        if (rad) rad[i] = h.force_radiation_damping_[i];
+        if (waves) waves[i] = i < int(h.force_waves_.size()) ? h.force_waves_[i] : 0.0;
+    }
+    ORC_CATCH(c)
+}
+// Direct call of the public ComputeForceRadiationDampingConv (keeps the duplicate-time throw reachable)
+int orc_compute_radiation(orc_ctx* c, double t, const double* linvel, const double* angvel, double* out) {
+    ORC_TRY
+    auto& h    = *c->hydro;
+    h.ch_time_ = t;
+    for (int b = 0; b < h.num_bodies_; ++b)
+        for (int k = 0; k < 3; ++k) {
+            h.bodies_[b].linvel[k] = linvel[3 * b + k];
+            h.bodies_[b].angvel[k] = angvel[3 * b + k];
+        }
+    std::fill(h.force_radiation_damping_.begin(), h.force_radiation_damping_.end(), 0.0);
+    auto r = h.ComputeForceRadiationDampingConv();
+    std::copy(r.begin(), r.end(), out);
+    ORC_CATCH(c)
+}
+int orc_get_rirf_val(orc_ctx* c, int row, int col, int st, double* out) {
+    ORC_TRY
+    *out = c->hydro->GetRIRFval(row, col, st);
+    ORC_CATCH(c)
+}
+int orc_get_rirf_width(orc_ctx* c, double* out) {
+    ORC_TRY
+    std::copy(c->hydro->rirf_width_vector.begin(), c->hydro->rirf_width_vector.end(), out);
+    ORC_CATCH(c)
+}
+int orc_history_size(orc_ctx* c) { return int(c->hydro->time_history_.size()); }
+
+// State injection used only to time the steady state without running S warm-up steps:
+// times newest-first, vel[n][6N]
+int orc_prefill_history(orc_ctx* c, int n, const double* times_newest_first, const double* vel) {
+    ORC_TRY
+    auto& h = *c->hydro;
+    const int D = 6 * h.num_bodies_;
+    h.time_history_.assign(times_newest_first, times_newest_first + n);
+    for (int b = 0; b < h.num_bodies_; ++b) {
+        h.velocity_history_[b].assign(n, std::vector<double>(6));
+        for (int k = 0; k < n; ++k)
+            for (int d = 0; d < 6; ++d) h.velocity_history_[b][k][d] = vel[size_t(k) * D + 6 * b + d];
+    }
+    h.prev_time = n > 0 ? times_newest_first[0] : -1;
+    ORC_CATCH(c)
+}
+
+// ---- irregular-wave init products
+static orc::IrregularWaves* orc_irreg(orc_ctx* c) {
+    if (!c->hydro->user_waves_ || c->hydro->user_waves_->GetWaveMode() != orc::WaveMode::irregular)
+        throw std::runtime_error("no irregular wave model attached");
+    return static_cast<orc::IrregularWaves*>(c->hydro->user_waves_.get());
+}
+int orc_irreg_sizes(orc_ctx* c, int* L, int* nf, int* nt) {
+    ORC_TRY
+    auto* w = orc_irreg(c);
+    *L      = int(w->ex_irf_time_sampled_[0].size());
+    *nf     = int(w->spectrum_frequencies_.size());
+    *nt     = int(w->free_surface_time_sampled_.size());
+    ORC_CATCH(c)
+}
+int orc_irreg_get_irf(orc_ctx* c, int b, double* t, double* width, double* vals /*[6][L]*/) {
+    ORC_TRY
+    auto* w     = orc_irreg(c);
+    const int L = int(w->ex_irf_time_sampled_[b].size());
+    std::copy(w->ex_irf_time_sampled_[b].begin(), w->ex_irf_time_sampled_[b].end(), t);
+    std::copy(w->ex_irf_width_sampled_[b].begin(), w->ex_irf_width_sampled_[b].end(), width);
+    for (int d = 0; d < 6; ++d) std::copy(w->ex_irf_sampled_[b][d].begin(), w->ex_irf_sampled_[b][d].end(), vals + size_t(d) * L);
+    ORC_CATCH(c)
+}
+int orc_irreg_get_spectrum(orc_ctx* c, double* f, double* S, double* df, double* phase, double* k) {
+    ORC_TRY
+    auto* w = orc_irreg(c);
+    std::copy(w->spectrum_frequencies_.begin(), w->spectrum_frequencies_.end(), f);
+    std::copy(w->spectral_densities_.begin(), w->spectral_densities_.end(), S);
+    std::copy(w->spectral_widths_.begin(), w->spectral_widths_.end(), df);
+    std::copy(w->wave_phases_.begin(), w->wave_phases_.end(), phase);
+    std::copy(w->wavenumbers_.begin(), w->wavenumbers_.end(), k);
+    ORC_CATCH(c)
+}
+int orc_irreg_get_eta(orc_ctx* c, double* t, double* eta) {
+    ORC_TRY
+    auto* w = orc_irreg(c);
+    std::copy(w->free_surface_time_sampled_.begin(), w->free_surface_time_sampled_.end(), t);
+    std::copy(w->free_surface_elevation_sampled_.begin(), w->free_surface_elevation_sampled_.end(), eta);
+    ORC_CATCH(c)
+}
+int orc_regular_get_coeffs(orc_ctx* c, double* mag, double* phase, double* wavenumber) {
+    ORC_TRY
+    if (c->hydro->user_waves_->GetWaveMode() != orc::WaveMode::regular) throw std::runtime_error("no regular wave attached");
+    auto* w = static_cast<orc::RegularWave*>(c->hydro->user_waves_.get());
+    std::copy(w->excitation_force_mag_.begin(), w->excitation_force_mag_.end(), mag);
+    std::copy(w->excitation_force_phase_.begin(), w->excitation_force_phase_.end(), phase);
+    *wavenumber = w->wavenumber_;
+    ORC_CATCH(c)
+}
+
+// ---- added mass (src/chloadaddedmass.cpp)
+int orc_added_mass_matrix(orc_ctx* c, double* M /*[D][D]*/) {
+    ORC_TRY
+    std::copy(c->hydro->infinite_added_mass.begin(), c->hydro->infinite_added_mass.end(), M);
+    ORC_CATCH(c)
+}
+int orc_added_mass_mv(orc_ctx* c, double* R, const double* w, double cc, int n_sys) {
+    ORC_TRY
+    c->hydro->AddedMassMv(R, w, cc, n_sys);
+    ORC_CATCH(c)
+}
+
+// ---- building blocks exposed for known-answer tests of the restated third-party arithmetic
+void orc_linspaced(int n, double lo, double hi, double* out) {
+    auto v = orc::LinSpaced(n, lo, hi);
+    std::copy(v.begin(), v.end(), out);
+}
+void orc_mt19937_raw(unsigned seed, int n, unsigned* out) {
+    orc::Mt19937 g(seed);
+    for (int i = 0; i < n; ++i) out[i] = g.next();
+}
+void orc_uniform_phases(unsigned seed, int n, double* out) {
+    orc::Mt19937 g(seed);
+    for (int i = 0; i < n; ++i) out[i] = (2 * M_PI - 0.0) * orc::canonical53(g) + 0.0;
+}
+int orc_spline_resample(int n_old, const double* vals /*[6][n_old]*/, int n_new, double* out /*[6][n_new]*/) {
+    try {
+        auto u_old = orc::LinSpaced(n_old, 0, 1);
+        auto u_new = orc::LinSpaced(n_new, 0, 1);
+        std::array<std::vector<double>, 6> pts;
+        for (int d = 0; d < 6; ++d) pts[d].assign(vals + size_t(d) * n_old, vals + size_t(d + 1) * n_old);
+        orc::CubicBSpline s;
+        s.Fit(u_old, pts);
+        for (int i = 0; i < n_new; ++i) {
+            double o[6];
+            s.Eval(u_new[i], o);
+            for (int d = 0; d < 6; ++d) out[size_t(d) * n_new + i] = o[d];
+        }
+    } catch (...) {
+        return 1;
+    }
+    return 0;
+}
+int orc_get_lower_index(double value, const double* ticks, int n, long* out) {
+    try {
+        std::vector<double> t(ticks, ticks + n);
+        *out = long(orc::get_lower_index(value, t));
+    } catch (...) {
+        return 1;
+    }
+    return 0;
+}
+double orc_wave_number(double omega, double depth, double g) {
+    try {
+        return orc::ComputeWaveNumber(omega, depth, g);
+    } catch (...) {
+        return std::numeric_limits<double>::quiet_NaN();
+    }
+}
+
+// ---- mock Chrono loop for the single-body heave goldens:
+// v_{n+1} = v_n + h*F(z_n, v_n, t_n)/(m + rho*Ainf_33);  z_{n+1} = z_n + h*v_{n+1};
+// F = F_hydro,z - m*g - c_pto*v.  Body is otherwise at (0,0,z), no rotation.
+int orc_run_heave_1dof(orc_ctx* c, double mass, double g, double pto_damping, double z0, double dt, int nsteps,
+                       double* z_out, double* fz_out /* may be NULL */) {
+    ORC_TRY
+    auto& h = *c->hydro;
+    if (h.num_bodies_ != 1) throw std::runtime_error("1-DOF heave driver needs exactly one body");
+    const double a33 = h.infinite_added_mass[2 * 6 + 2];
+    double z = z0, v = 0.0;
+    for (int n = 0; n < nsteps; ++n) {
+        const double t = n * dt;
+        double pos[3] = {0, 0, z}, rpy[3] = {0, 0, 0}, lv[3] = {0, 0, v}, av[3] = {0, 0, 0};
+        orc_load_state(h, t, pos, rpy, lv, av);
+        const double fz = h.CoordinateFuncForBody(1, 2);
+        if (fz_out) fz_out[n] = fz;
+        const double F = fz - mass * g - pto_damping * v;
+        v += dt * F / (mass + a33);
+        z += dt * v;
+        z_out[n] = z;
+    }
+    ORC_CATCH(c)
+}
+
+}  // extern "C"

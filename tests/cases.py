@@ -1,0 +1,45 @@
+"""Test inputs shared by the oracle tests and the GPU parity tests.
+
+A *case* is the set of raw BEMIO arrays H5FileInfo::ReadH5Data reads (src/h5fileinfo.cpp:35-90),
+unscaled and in file order, so the oracle and the product ingest exactly the same numbers.
+"""
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SPHERE_MASS = 261.8e3  # tests/regression/sphere/demo_sphere_decay.cpp: SetMass(261.8e3)
+SPHERE_G = 9.81        # system.SetGravitationalAcceleration(0,0,-9.81)
+SPHERE_DT = 0.015
+
+
+def sphere_case():
+    z = np.load(os.path.join(GOLDEN_DIR, "sphere_bemio.npz"))
+    body = dict(
+        disp_vol=float(z["body1/disp_vol"][0]), cg=z["body1/cg"], cb=z["body1/cb"],
+        lin=z["body1/linear_restoring_stiffness"], added_mass_inf=z["body1/added_mass_inf_freq"],
+        rirf_t=z["body1/rirf_t"], rirf_K=z["body1/rirf_K"], w=z["w"],
+        ex_mag=z["body1/excitation_mag"], ex_phase=z["body1/excitation_phase"],
+        ex_irf_t=z["body1/excitation_irf_t"], ex_irf_f=z["body1/excitation_irf_f"])
+    return dict(N=1, rho=float(z["rho"][0]), g=float(z["g"][0]), water_depth=float(z["water_depth"][0]), bodies=[body])
+
+
+def goldens():
+    return np.load(os.path.join(GOLDEN_DIR, "sphere_goldens.npz"))
+
+
+def load_into_oracle(case, oracle_cls=None):
+    from oracle import Oracle
+    o = (oracle_cls or Oracle)(case["N"])
+    o.set_simulation_parameters(case["rho"], case["g"], case["water_depth"])
+    for b, bd in enumerate(case["bodies"]):
+        o.set_body(b, bd["disp_vol"], bd["cg"], bd["cb"], bd["lin"], bd["added_mass_inf"], bd["rirf_t"], bd["rirf_K"])
+        if "w" in bd:
+            o.set_body_excitation_rao(b, bd["w"], bd["ex_mag"], bd["ex_phase"])
+        if "ex_irf_t" in bd:
+            o.set_body_excitation_irf(b, bd["ex_irf_t"], bd["ex_irf_f"])
+    o.construct()
+    if "g_sys" in case:
+        o.set_gravity(case["g_sys"])
+    return o

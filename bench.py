@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the hydro-force path: all-body force evaluations per second.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], "C3"): synthetic 64-body array, 1024 radiation-IRF samples, irregular JONSWAP
+sea state with 512 wave components, prescribed body motion with dt = dt_rirf = 0.01 s, steady state (velocity history
+pre-filled over the whole 10.23 s IRF window).  A "step" = one evaluation of all 6N hydrodynamic forces
+(hydrostatic - radiation + waves) through hc_step_device, body states already resident in HBM.
+
+Multi-GPU (weak scaling): every rank owns one independent 64-body farm (a block-diagonal 64*G-body array whose
+cross-farm coupling blocks are structurally zero); after each step the per-farm force vectors are all-gathered
+over RCCL so every rank holds the full 6*64*G vector a host integrator needs -- the single exchange step of the
+path.  value = farms * K / max-over-ranks time.
+
+The JSON line also carries
+  roofline      HBM roofline of the convolution kernel: algorithmic bytes per launch / mean HIP-event duration
+  cpu_baseline  the CPU oracle (reference-faithful OpenMP restatement, oracle/) timed on this box's host cores on a
+                bounded sample of the same workload (rank 0, N=1 only); it is also used to check the GPU forces.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+WAVES = dict(simulation_dt=0.01, simulation_duration=60.0, ramp_duration=0.0, wave_height=2.0, wave_period=8.0,
+             frequency_min=0.02, frequency_max=0.5, nfrequencies=512, peak_enhancement_factor=3.3, seed=1)
+N_BODIES, S_RIRF, N_EXC, DT = 64, 1024, 1024, 0.01
+T0 = 20.0  # start of the timed window (history covers [T0 - 10.29, T0))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--bodies", type=int, default=N_BODIES, help="bodies per GPU (default: the C3 configuration)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline time budget")
+    return ap.parse_args()
+
+
+def cpu_baseline(case, motion, t_hist, v_hist, budget_s):
+    """Times the oracle in its reference-faithful OpenMP form on all host cores; returns (dict, forces at T0)."""
+    import oracle as orc_mod
+    from cases import load_into_oracle
+    cores = os.cpu_count() or 1
+    orc_mod.set_num_threads(cores)
+    orc = load_into_oracle(case)
+    orc.add_waves_irregular(**WAVES)
+    orc.prefill_history(t_hist, v_hist)
+    durations, first = [], None
+    t_begin = time.perf_counter()
+    n = 0
+    while True:
+        t = T0 + n * DT
+        st = motion.state(t)
+        a = time.perf_counter()
+        f = orc.step(t, *st)
+        durations.append(time.perf_counter() - a)
+        if first is None:
+            first = f.copy()
+        n += 1
+        if n >= 3 and (time.perf_counter() - t_begin > budget_s or n >= 100):
+            break
+    med = float(np.median(durations))
+    info = {"value": 1.0 / med, "unit": "evals/s", "cores": cores, "kind": "port", "ms_per_step": med * 1e3,
+            "sample": f"{n} consecutive steady-state steps of the same workload (median), oracle -O2 -fopenmp, "
+                      f"OMP threads = {orc_mod.num_threads()}"}
+    return info, first
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from hydrochrono_amd.hydro import HydroForces
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the hydro-force path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    N = args.bodies
+    D = 6 * N
+    case = many_body_case(N, S=S_RIRF, dt_rirf=DT, n_exc=N_EXC, dt_exc=DT, seed=20251031 + rank)
+    gpu = HydroForces.from_case(case, device=local_rank)
+    gpu.add_waves_irregular(**WAVES)
+    motion = PrescribedMotion(N, rest_positions(case), seed=20251031 + rank)
+
+    nhist = S_RIRF + 5
+    t_hist = T0 - DT * np.arange(1, nhist + 1)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    gpu.set_history(t_hist, v_hist)
+
+    total = args.warmup + args.steps
+    states = torch.tensor(np.stack([motion.packed(T0 + k * DT) for k in range(total)]), device="cuda")
+    forces = torch.zeros(total, D, dtype=torch.float64, device="cuda")
+    gathered = torch.zeros(world * D, dtype=torch.float64, device="cuda") if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(k0, k1):
+        for k in range(k0, k1):
+            gpu.step_device(T0 + k * DT, states[k].data_ptr(), forces[k].data_ptr(), stream)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, forces[k])
+
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    gpu.enable_profiling(True)
+    gpu.reset_profile()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    run(args.warmup, total)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    prof = gpu.profile()
+    gpu.enable_profiling(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        conv_s = prof["conv_kernel_seconds"] / max(1, prof["conv_kernel_launches"])
+        achieved = prof["conv_kernel_bytes"] / conv_s / 1e9 if conv_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")
+        if os.path.exists(tpath) and N == N_BODIES:
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "hydro-force evals/sec (all bodies)",
+            "value": world * args.steps / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C3: synthetic {N}-body array per GPU, {S_RIRF} radiation-IRF samples, irregular JONSWAP "
+                            f"waves with {WAVES['nfrequencies']} components (excitation-IRF convolution, L={gpu.sizes()['L']}), "
+                            "prescribed motion, dt = dt_rirf = 0.01 s, steady-state history",
+                "bodies_per_gpu": N, "irf_samples": S_RIRF, "wave_components": WAVES["nfrequencies"],
+                "sharding": "one independent farm per GPU + RCCL all-gather of forces" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "hc::conv_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": prof["conv_kernel_bytes"], "mean_kernel_us": conv_s * 1e6,
+                "launches_timed": prof["conv_kernel_launches"],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, f_cpu = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds)
+            f_gpu = forces[0].cpu().numpy()  # step k = 0 is t = T0 on both sides
+            out["cpu_baseline"] = base
+            out["parity_max_rel_err_vs_oracle"] = float(np.max(np.abs(f_gpu - f_cpu)) / np.max(np.abs(f_cpu)))
+            out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""Build recipe for the native libraries (hipcc, gfx950 only).  Used by __graft_entry__.build() and `python -m hydrochrono_amd.build`.
+
+  hydrochrono_amd/lib/libhydrochrono_amd.so   C ABI + HIP kernels (include/hydrochrono_amd.h)
+  hydrochrono_amd/lib/libhc_bemio.so          optional BEMIO-HDF5 reader (only where libhdf5 is installed)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+MAIN_LIB = os.path.join(LIBDIR, "libhydrochrono_amd.so")
+BEMIO_LIB = os.path.join(LIBDIR, "libhc_bemio.so")
+
+SOURCES = ["hc_kernels.hip", "hc_api.cpp", "hc_host_math.cpp"]
+HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_host_math.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h")]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _find_hdf5():
+    for prefix in (os.environ.get("HDF5_ROOT"), "/opt/conda", "/usr", "/usr/local"):
+        if not prefix:
+            continue
+        inc = os.path.join(prefix, "include", "hdf5.h")
+        for libdir in ("lib", "lib64", "lib/x86_64-linux-gnu"):
+            lib = os.path.join(prefix, libdir, "libhdf5.so")
+            if os.path.exists(inc) and os.path.exists(lib):
+                return os.path.join(prefix, "include"), os.path.join(prefix, libdir)
+    return None
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    if force or _newer(MAIN_LIB, deps):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
+               "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")] + srcs + ["-o", MAIN_LIB, "-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    h5 = _find_hdf5()
+    bemio_src = os.path.join(CSRC, "hc_bemio.cpp")
+    if h5 and (force or _newer(BEMIO_LIB, [bemio_src, MAIN_LIB])):
+        inc, lib = h5
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", bemio_src, "-o", BEMIO_LIB, "-I", inc, "-I", os.path.join(ROOT, "include"),
+               "-L", lib, "-lhdf5", "-L", LIBDIR, "-lhydrochrono_amd", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{lib}"]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd)
+        if r.returncode != 0:
+            print("warning: BEMIO-HDF5 reader not built (hc_load_bemio_h5 will return HC_ERR_UNSUPPORTED)", file=sys.stderr)
+    return MAIN_LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

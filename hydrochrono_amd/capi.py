@@ -1,0 +1,107 @@
+"""ctypes binding of the C ABI in include/hydrochrono_amd.h (libhydrochrono_amd.so).
+
+This module only declares signatures and loads the library.  It fails loudly if the HIP library is missing:
+the hydro-force path has no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libhydrochrono_amd.so")
+
+HC_OK, HC_ERR_RUNTIME, HC_ERR_OUT_OF_RANGE, HC_ERR_INVALID, HC_ERR_DEVICE, HC_ERR_UNSUPPORTED = range(6)
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class IrregularWaveParams(C.Structure):
+    """hc_irregular_wave_params == IrregularWaveParams (include/hydroc/wave_types.h:277-292)."""
+    _fields_ = [("num_bodies", C.c_int), ("simulation_dt", C.c_double), ("simulation_duration", C.c_double),
+                ("ramp_duration", C.c_double), ("wave_height", C.c_double), ("wave_period", C.c_double),
+                ("frequency_min", C.c_double), ("frequency_max", C.c_double), ("nfrequencies", C.c_double),
+                ("peak_enhancement_factor", C.c_double), ("is_normalized", C.c_int), ("seed", C.c_int)]
+
+
+class TaperedDirectOptions(C.Structure):
+    """hc_tapered_direct_options == TestHydro::TaperedDirectOptions (include/hydroc/hydro_forces.h:246-259)."""
+    _fields_ = [("smoothing", C.c_int), ("window_length", C.c_int), ("rirf_end_time", C.c_double),
+                ("taper_start_percent", C.c_double), ("taper_end_percent", C.c_double),
+                ("taper_final_amplitude", C.c_double)]
+
+
+class ProfileStats(C.Structure):
+    _fields_ = [("hydrostatics_seconds", C.c_double), ("radiation_seconds", C.c_double), ("waves_seconds", C.c_double),
+                ("hydrostatics_calls", C.c_int), ("radiation_calls", C.c_int), ("waves_calls", C.c_int),
+                ("conv_kernel_seconds", C.c_double), ("conv_kernel_launches", C.c_longlong),
+                ("conv_kernel_bytes", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/hydrochrono_amd.h declares
+SIGNATURES = {
+    "hc_version": (C.c_char_p, []),
+    "hc_device_count": (C.c_int, []),
+    "hc_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "hc_create_sharded": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "hc_destroy": (None, [C.c_void_p]),
+    "hc_last_error": (C.c_char_p, [C.c_void_p]),
+    "hc_set_simulation_parameters": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "hc_set_body_properties": (C.c_int, [C.c_void_p, C.c_int, C.c_double, c_double_p, c_double_p]),
+    "hc_set_hydrostatic_stiffness": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    "hc_set_added_mass_inf": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    "hc_set_rirf": (C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_int, c_double_p]),
+    "hc_set_excitation_rao": (C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_int, c_double_p, c_double_p]),
+    "hc_set_excitation_irf": (C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_int, c_double_p]),
+    "hc_load_bemio_h5": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "hc_finalize": (C.c_int, [C.c_void_p]),
+    "hc_set_gravity": (C.c_int, [C.c_void_p, c_double_p]),
+    "hc_set_wave_none": (C.c_int, [C.c_void_p, C.c_int]),
+    "hc_set_wave_regular": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double]),
+    "hc_irregular_wave_params_default": (None, [C.POINTER(IrregularWaveParams)]),
+    "hc_set_wave_irregular": (C.c_int, [C.c_void_p, C.POINTER(IrregularWaveParams)]),
+    "hc_set_convolution_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "hc_tapered_direct_options_default": (None, [C.POINTER(TaperedDirectOptions)]),
+    "hc_set_tapered_direct_options": (C.c_int, [C.c_void_p, C.POINTER(TaperedDirectOptions)]),
+    "hc_step": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "hc_step_device": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_get_force_components": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "hc_compute_radiation": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p, c_double_p]),
+    "hc_compute_hydrostatics": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "hc_compute_waves": (C.c_int, [C.c_void_p, C.c_double, c_double_p]),
+    "hc_reset_history": (C.c_int, [C.c_void_p]),
+    "hc_set_history": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p]),
+    "hc_get_history": (C.c_int, [C.c_void_p, c_int_p, c_double_p, c_double_p]),
+    "hc_added_mass_matrix": (C.c_int, [C.c_void_p, c_double_p]),
+    "hc_added_mass_mv": (C.c_int, [C.c_void_p, c_double_p, C.c_double, c_double_p, C.c_int]),
+    "hc_enable_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "hc_get_profile": (C.c_int, [C.c_void_p, C.POINTER(ProfileStats)]),
+    "hc_reset_profile": (C.c_int, [C.c_void_p]),
+    "hc_get_sizes": (C.c_int, [C.c_void_p] + [c_int_p] * 8),
+    "hc_get_rirf_width": (C.c_int, [C.c_void_p, c_double_p]),
+    "hc_get_rirf_effective": (C.c_int, [C.c_void_p, c_double_p]),
+    "hc_get_excitation_irf_resampled": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "hc_get_spectrum": (C.c_int, [C.c_void_p] + [c_double_p] * 5),
+    "hc_get_eta_table": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "hc_get_regular_coeffs": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "hc_synth_fill": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_int, C.c_double, C.c_int, C.c_double]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libhydrochrono_amd.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -m hydrochrono_amd.build, or "
+            "__graft_entry__.build()).  The hydro-force path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,1180 @@
+// hc_api.cpp -- implementation of the C ABI declared in include/hydrochrono_amd.h.
+//
+// Host bookkeeping only: ingest/scaling, the time history mirror (push / prune exactly like
+// src/hydro_forces.cpp:327-340,549-584), error rules of the reference, and the three kernel launches per step.
+// All arithmetic of the per-step force path runs in hc_kernels.hip on the GPU; there is no CPU fallback.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+
+#include "hc_context.hpp"
+#include "hc_host_math.hpp"
+
+using hc::Error;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+const char* kVersion = "hydrochrono_amd 0.1 (gfx950)";
+
+#define HC_API_BEGIN(ctx)                                    \
+    if (!(ctx)) return HC_ERR_INVALID;                       \
+    try {                                                    \
+        HC_HIP(hipSetDevice((ctx)->device));
+
+#define HC_API_END(ctx)                                      \
+    }                                                        \
+    catch (const Error& e) {                                 \
+        (ctx)->err = e.what();                               \
+        return e.status;                                     \
+    }                                                        \
+    catch (const std::out_of_range& e) {                     \
+        (ctx)->err = e.what();                               \
+        return HC_ERR_OUT_OF_RANGE;                          \
+    }                                                        \
+    catch (const std::exception& e) {                        \
+        (ctx)->err = e.what();                               \
+        return HC_ERR_RUNTIME;                               \
+    }                                                        \
+    return HC_OK;
+
+void require(bool cond, int status, const char* msg) {
+    if (!cond) throw Error(status, msg);
+}
+
+void check_body(const hc_ctx* c, int body) {
+    if (body < 0 || body >= c->N) throw Error(HC_ERR_OUT_OF_RANGE, "body index out of range");
+}
+bool is_local(const hc_ctx* c, int body) { return body >= c->b0 && body < c->b1; }
+
+// ---- history ring -----------------------------------------------------------------------------
+void ring_alloc(hc_ctx* c, int cap) {
+    c->d_ring_t.alloc(cap);
+    c->d_ring_v.alloc(static_cast<size_t>(cap) * c->D);
+    HC_HIP(hipMemsetAsync(c->d_ring_t.p, 0, cap * sizeof(double), c->stream));
+    HC_HIP(hipMemsetAsync(c->d_ring_v.p, 0, static_cast<size_t>(cap) * c->D * sizeof(double), c->stream));
+    c->Hcap = cap;
+    c->head = -1;
+}
+
+// Grow the ring so that `need` samples fit, keeping the `have` newest stored samples (k = 0..have-1) in order.
+void ring_grow(hc_ctx* c, int need, int have) {
+    HC_HIP(hipDeviceSynchronize());  // rare; steps may have been enqueued on a caller's stream (hc_step_device)
+    const int cap2 = std::max(2 * c->Hcap, need + 16);
+    hc::DeviceBuffer<double> nt, nv;
+    nt.alloc(cap2);
+    nv.alloc(static_cast<size_t>(cap2) * c->D);
+    HC_HIP(hipMemsetAsync(nt.p, 0, cap2 * sizeof(double), c->stream));
+    HC_HIP(hipMemsetAsync(nv.p, 0, static_cast<size_t>(cap2) * c->D * sizeof(double), c->stream));
+    // new layout: sample k -> slot (have-1-k); oldest at slot 0, newest at slot have-1
+    for (int k = 0; k < have; ++k) {
+        const int src = ((c->head - k) % c->Hcap + c->Hcap) % c->Hcap;
+        const int dst = have - 1 - k;
+        HC_HIP(hipMemcpyAsync(nt.p + dst, c->d_ring_t.p + src, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HC_HIP(hipMemcpyAsync(nv.p + static_cast<size_t>(dst) * c->D, c->d_ring_v.p + static_cast<size_t>(src) * c->D,
+                              c->D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    HC_HIP(hipStreamSynchronize(c->stream));
+    std::swap(c->d_ring_t.p, nt.p);
+    std::swap(c->d_ring_t.n, nt.n);
+    std::swap(c->d_ring_v.p, nv.p);
+    std::swap(c->d_ring_v.n, nv.n);
+    c->Hcap = cap2;
+    c->head = have - 1;
+}
+
+// Push the time of this step and prune like PruneHistory; returns H (samples incl. the current one).
+int history_push(hc_ctx* c, double t) {
+    if (!c->times.empty() && t == c->times.front())
+        throw Error(HC_ERR_RUNTIME, "Tried to compute the radiation damping convolution twice within the same time step!");
+    if (!c->times.empty() && t < c->times.front())
+        throw Error(HC_ERR_INVALID, "hc_step: time must not decrease (the velocity history is ordered newest first)");
+    const double tau_last         = c->tau.empty() ? 0.0 : c->tau.back();
+    const double history_min_time = t - tau_last;
+    c->times.push_front(t);
+    while (c->times.size() > 1 && c->times[c->times.size() - 2] < history_min_time) c->times.pop_back();
+    const int H = static_cast<int>(c->times.size());
+    if (H > c->Hcap) ring_grow(c, H, H - 1);
+    c->head = (c->head + 1) % c->Hcap;
+    return H;
+}
+
+// ---- profiling --------------------------------------------------------------------------------
+void profile_drain(hc_ctx* c) {
+    if (c->events_used == 0) return;
+    HC_HIP(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->events_used; ++i) {
+        float ms01 = 0, ms12 = 0, ms23 = 0;
+        HC_HIP(hipEventElapsedTime(&ms01, c->events[i].e[0], c->events[i].e[1]));
+        HC_HIP(hipEventElapsedTime(&ms12, c->events[i].e[1], c->events[i].e[2]));
+        HC_HIP(hipEventElapsedTime(&ms23, c->events[i].e[2], c->events[i].e[3]));
+        c->prof.radiation_seconds += (ms01 + ms12) * 1e-3;
+        c->prof.hydrostatics_seconds += ms23 * 1e-3;
+        c->prof.conv_kernel_seconds += ms12 * 1e-3;
+        c->prof.conv_kernel_launches += 1;
+    }
+    c->events_used = 0;
+}
+
+hc::EventSet* profile_next(hc_ctx* c) {
+    if (!c->profiling) return nullptr;
+    if (c->events_used == c->events.size()) {
+        if (c->events.size() < 4096) {
+            hc::EventSet es;
+            for (auto& e : es.e) HC_HIP(hipEventCreate(&e));
+            c->events.push_back(es);
+        } else {
+            profile_drain(c);
+        }
+    }
+    return &c->events[c->events_used++];
+}
+
+// ---- GEMV tiling ------------------------------------------------------------------------------
+void choose_conv_config(hc_ctx* c) {
+    c->rows_per_tile = (c->Dloc % 12 == 0) ? 12 : 6;
+    c->nrowtiles     = c->Dloc / c->rows_per_tile;
+    const long long F = static_cast<long long>(c->S) * c->D;
+    // aim for >= 8 workgroups per CU (256 CUs); a chunk is a multiple of 512 columns (one pass of 256 lanes x 2)
+    const int target_wgs = 4096;
+    long long nch        = std::max<long long>(1, target_wgs / std::max(1, c->nrowtiles));
+    long long cols       = (F + nch - 1) / nch;
+    cols                 = std::max<long long>(512, ((cols + 511) / 512) * 512);
+    c->chunk_cols        = static_cast<int>(cols);
+    c->nchunks_rad       = static_cast<int>((F + cols - 1) / cols);
+}
+
+void choose_exc_config(hc_ctx* c) {
+    if (c->wave_kind != hc::kWaveIrregular || c->L == 0) {
+        c->nchunks_ex = 0;
+        c->chunk_cols_ex = 512;
+        return;
+    }
+    long long cols   = 2048;
+    c->chunk_cols_ex = static_cast<int>(cols);
+    c->nchunks_ex    = static_cast<int>((c->Lpad + cols - 1) / cols);
+}
+
+void alloc_partials(hc_ctx* c) {
+    const size_t n = static_cast<size_t>(c->nchunks_rad + c->nchunks_ex) * c->Dloc;
+    if (c->d_partials.n < n) c->d_partials.alloc(n);
+}
+
+// ---- TaperedDirect ----------------------------------------------------------------------------
+void ensure_processed(hc_ctx* c) {
+    if (c->conv_mode != 1 || c->proc_ready) return;
+    const int steps = c->S;
+    int effective   = steps;
+    if (c->taper.rirf_end_time > 0.0) {
+        require(c->S >= 2, HC_ERR_INVALID, "TaperedDirect truncation needs at least two IRF samples");
+        const double dt = c->tau[1] - c->tau[0];
+        const int end   = static_cast<int>(std::floor(c->taper.rirf_end_time / dt));
+        effective       = std::min(end, steps);
+    }
+    int tc_index = static_cast<int>(std::floor(c->taper.taper_start_percent * static_cast<double>(effective)));
+    int tc_end   = static_cast<int>(std::floor(c->taper.taper_end_percent * static_cast<double>(effective)));
+    tc_index     = std::max(0, std::min(tc_index, effective));
+    tc_end       = std::max(tc_index, std::min(tc_end, effective));
+    if (c->dKproc.n != c->dK.n) c->dKproc.alloc(c->dK.n);
+    hc::TaperArgs a{};
+    a.Kraw            = c->dK.p;
+    a.Kproc           = c->dKproc.p;
+    a.ldk             = c->ldk;
+    a.Dloc            = c->Dloc;
+    a.D               = c->D;
+    a.S               = c->S;
+    a.effective_steps = effective;
+    a.smoothing       = c->taper.smoothing;
+    a.window          = std::max(3, c->taper.window_length);
+    a.tc_index        = tc_index;
+    a.tc_end          = tc_end;
+    a.final_amplitude = c->taper.taper_final_amplitude;
+    HC_HIP(hipDeviceSynchronize());  // once per option change; orders against steps on a caller's stream
+    hc::launch_taper(a, c->stream);
+    HC_HIP(hipGetLastError());
+    HC_HIP(hipStreamSynchronize(c->stream));
+    c->proc_ready = true;
+}
+
+// ---- the step ---------------------------------------------------------------------------------
+struct StepFlags {
+    bool hs = true, rad = true, waves = true;
+};
+
+void check_wave_ready(hc_ctx* c, double t) {
+    if (c->wave_nb_arg < c->N)
+        throw Error(HC_ERR_RUNTIME, "wave model was created for fewer bodies than the hydro system (force vector shorter than 6N)");
+    if (c->wave_kind == hc::kWaveIrregular) {
+        // ExcitationConvolution bounds (src/wave_types.cpp:784-794,833-840) and get_lower_index (src/helper.cpp:8-22)
+        const double tmin = c->eta_t.front(), tmax = c->eta_t.back();
+        const double q0 = t - c->ex_tau.front(), q1 = t - c->ex_tau.back();
+        if (!(tmin <= q0 && q0 <= tmax) || !(tmin <= q1 && q1 <= tmax))
+            throw Error(HC_ERR_RUNTIME,
+                        "Excitation convolution: trying to find free surface elevation at a time out of bounds from the "
+                        "precomputed free surface elevation. Excitation force ignored at this time step.");
+        if (q0 > tmin && q0 < tmax && q0 <= c->eta_t[1])
+            throw Error(HC_ERR_RUNTIME, "Could not find index for value in free-surface time array (get_lower_index)");
+    }
+}
+
+// Enqueue prep -> conv -> finalize for time t. d_state: device pointer to the 12N state. user_out may be null.
+void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f) {
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    const bool irregular = c->wave_kind == hc::kWaveIrregular;
+    if (f.waves) check_wave_ready(c, t);
+    int H = 0;
+    if (f.rad) {
+        ensure_processed(c);
+        H = history_push(c, t);
+    }
+    hc::EventSet* ev = profile_next(c);
+    if (ev) HC_HIP(hipEventRecord(ev->e[0], stream));
+
+    const bool run_rad = f.rad && H >= 2;  // "Nothing to convolve with if we don't yet have at least 2 time points" (:580)
+    hc::PrepArgs p{};
+    p.state         = d_state;
+    p.N             = c->N;
+    p.D             = c->D;
+    p.t             = t;
+    p.S             = c->S;
+    p.tau           = c->d_tau.p;
+    p.width         = c->d_width.p;
+    p.ring_t        = c->d_ring_t.p;
+    p.ring_v        = c->d_ring_v.p;
+    p.head          = c->head;
+    p.H             = H;
+    p.Hcap          = c->Hcap;
+    p.u             = c->d_u.p;
+    p.do_radiation  = f.rad ? 1 : 0;
+    p.L             = c->L;
+    p.Lpad          = c->Lpad;
+    p.ex_tau        = c->d_ex_tau.p;
+    p.ex_width      = c->d_ex_width.p;
+    p.eta_t         = c->d_eta_t.p;
+    p.eta           = c->d_eta.p;
+    p.nt            = c->nt;
+    p.eta_dt        = irregular ? c->irr.simulation_dt : 1.0;
+    p.e             = c->d_e.p;
+    p.do_excitation = (f.waves && irregular) ? 1 : 0;
+    p.error_flag    = c->d_err.p;
+    if (f.rad && !run_rad) {
+        // first sample: only the ring push is needed; u is not consumed
+        p.S = 0;
+    }
+    hc::launch_prep(p, stream);
+    if (ev) HC_HIP(hipEventRecord(ev->e[1], stream));
+
+    hc::ConvArgs a{};
+    a.K             = (c->conv_mode == 1) ? c->dKproc.p : c->dK.p;
+    a.ldk           = c->ldk;
+    a.u             = c->d_u.p;
+    a.F             = c->S * c->D;
+    a.chunk_cols    = c->chunk_cols;
+    a.nchunks_rad   = run_rad ? c->nchunks_rad : 0;
+    a.Kex           = c->d_kex.p;
+    a.ldkex         = static_cast<size_t>(c->Lpad);
+    a.e             = c->d_e.p;
+    a.Lpad          = c->Lpad;
+    a.chunk_cols_ex = c->chunk_cols_ex;
+    a.nchunks_ex    = p.do_excitation ? c->nchunks_ex : 0;
+    a.partials      = c->d_partials.p;
+    a.Dloc          = c->Dloc;
+    a.nrowtiles     = c->nrowtiles;
+    hc::launch_conv(a, c->rows_per_tile, stream);
+    if (ev) HC_HIP(hipEventRecord(ev->e[2], stream));
+
+    hc::FinalizeArgs z{};
+    z.partials    = c->d_partials.p;
+    z.nchunks_rad = a.nchunks_rad;
+    z.nchunks_ex  = a.nchunks_ex;
+    z.Dloc        = c->Dloc;
+    z.N           = c->N;
+    z.b0          = c->b0;
+    z.state       = d_state;
+    z.lin         = c->d_lin.p;
+    z.cg          = c->d_cg.p;
+    z.cb_m_cg     = c->d_cbmcg.p;
+    z.disp_vol    = c->d_vol.p;
+    z.rho         = c->rho;
+    z.gx          = c->gsys[0];
+    z.gy          = c->gsys[1];
+    z.gz          = c->gsys[2];
+    z.wave_mode   = c->wave_kind;
+    z.reg_mag     = c->d_reg_mag.p;
+    for (int i = 0; i < 6; ++i) z.reg_phase[i] = c->reg_phase.size() >= 6 ? c->reg_phase[i] : 0.0;
+    z.reg_amplitude = c->reg_amp;
+    z.reg_omega     = c->reg_omega;
+    z.t             = t;
+    z.do_hs         = f.hs;
+    z.do_rad        = run_rad;
+    z.do_waves      = f.waves;
+    z.hs            = c->d_hs.p;
+    z.rad           = c->d_rad.p;
+    z.waves         = c->d_waves.p;
+    z.total         = c->d_total.p;
+    z.user_out      = d_user_out;
+    hc::launch_finalize(z, stream);
+    if (ev) HC_HIP(hipEventRecord(ev->e[3], stream));
+    HC_HIP(hipGetLastError());
+
+    if (f.hs) c->prof.hydrostatics_calls++;
+    if (f.rad) c->prof.radiation_calls++;
+    if (f.waves) c->prof.waves_calls++;
+}
+
+void check_device_flag(hc_ctx* c) {
+    HC_HIP(hipMemcpyAsync(c->h_err.p, c->d_err.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    if (*c->h_err.p != 0) {
+        const int code = *c->h_err.p;
+        HC_HIP(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
+        if (code == 1) throw Error(HC_ERR_RUNTIME, "Radiation convolution: interpolation error; query_time not bracketed by history.");
+        throw Error(HC_ERR_RUNTIME, "Excitation convolution: tau value not bracketed by the free-surface table");
+    }
+}
+
+void stage_state(hc_ctx* c, const double* pos, const double* rpy, const double* linvel, const double* angvel) {
+    const int n3 = 3 * c->N;
+    double* h    = c->h_state.p;
+    const double* src[4] = {pos, rpy, linvel, angvel};
+    for (int k = 0; k < 4; ++k) {
+        if (src[k]) std::memcpy(h + k * n3, src[k], n3 * sizeof(double));
+        else std::memset(h + k * n3, 0, n3 * sizeof(double));
+    }
+    HC_HIP(hipMemcpyAsync(c->d_state.p, h, 4 * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* hc_version(void) { return kVersion; }
+
+int hc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* hc_last_error(const hc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int hc_create_sharded(int num_bodies, int body_begin, int body_end, int device_id, hc_ctx** out) {
+    if (!out) return HC_ERR_INVALID;
+    *out = nullptr;
+    try {
+        require(num_bodies > 0, HC_ERR_INVALID, "num_bodies must be positive");
+        require(body_begin >= 0 && body_begin < body_end && body_end <= num_bodies, HC_ERR_INVALID, "invalid body shard");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            throw Error(HC_ERR_DEVICE, "no HIP device available: the hydro-force path has no CPU fallback");
+        require(device_id >= 0 && device_id < ndev, HC_ERR_DEVICE, "device_id out of range");
+        HC_HIP(hipSetDevice(device_id));
+        hipDeviceProp_t prop;
+        HC_HIP(hipGetDeviceProperties(&prop, device_id));
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+            throw Error(HC_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+        std::unique_ptr<hc_ctx> c(new hc_ctx);
+        c->N      = num_bodies;
+        c->b0     = body_begin;
+        c->b1     = body_end;
+        c->nloc   = body_end - body_begin;
+        c->D      = 6 * num_bodies;
+        c->Dloc   = 6 * c->nloc;
+        c->device = device_id;
+        c->bodies.resize(num_bodies);
+        HC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        hc_tapered_direct_options_default(&c->taper);
+        hc_irregular_wave_params_default(&c->irr);
+        *out = c.release();
+    } catch (const Error& e) {
+        g_create_error = e.what();
+        return e.status;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return HC_ERR_RUNTIME;
+    }
+    return HC_OK;
+}
+
+int hc_create(int num_bodies, int device_id, hc_ctx** out) { return hc_create_sharded(num_bodies, 0, num_bodies, device_id, out); }
+
+void hc_destroy(hc_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& es : ctx->events)
+        for (auto& e : es.e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+// ---- ingest -----------------------------------------------------------------------------------
+int hc_set_simulation_parameters(hc_ctx* c, double rho, double g, double water_depth) {
+    HC_API_BEGIN(c)
+    require(!c->finalized, HC_ERR_INVALID, "context already finalized");
+    c->rho = rho;
+    c->g = g;
+    c->depth = water_depth;
+    c->have_sim = true;
+    HC_API_END(c)
+}
+
+int hc_set_body_properties(hc_ctx* c, int body, double disp_vol, const double cg[3], const double cb[3]) {
+    HC_API_BEGIN(c)
+    check_body(c, body);
+    require(cg && cb, HC_ERR_INVALID, "null pointer");
+    auto& b = c->bodies[body];
+    b.disp_vol = disp_vol;
+    std::copy(cg, cg + 3, b.cg);
+    std::copy(cb, cb + 3, b.cb);
+    b.have_props = true;
+    HC_API_END(c)
+}
+
+int hc_set_hydrostatic_stiffness(hc_ctx* c, int body, const double lin[36]) {
+    HC_API_BEGIN(c)
+    check_body(c, body);
+    require(lin, HC_ERR_INVALID, "null pointer");
+    std::copy(lin, lin + 36, c->bodies[body].lin);
+    c->bodies[body].have_lin = true;
+    HC_API_END(c)
+}
+
+int hc_set_added_mass_inf(hc_ctx* c, int body, const double* A) {
+    HC_API_BEGIN(c)
+    check_body(c, body);
+    require(A, HC_ERR_INVALID, "null pointer");
+    require(c->have_sim, HC_ERR_INVALID, "set simulation parameters first (rho scales the added mass)");
+    auto& b = c->bodies[body];
+    b.have_ainf = true;
+    if (is_local(c, body)) {
+        b.ainf.assign(A, A + static_cast<size_t>(6) * c->D);
+        for (auto& x : b.ainf) x *= c->rho;  // src/h5fileinfo.cpp:61
+    }
+    HC_API_END(c)
+}
+
+int hc_set_rirf(hc_ctx* c, int body, const double* t, int S, const double* K) {
+    HC_API_BEGIN(c)
+    check_body(c, body);
+    require(t && K && S > 0, HC_ERR_INVALID, "null pointer or empty IRF");
+    require(c->have_sim, HC_ERR_INVALID, "set simulation parameters first (rho scales the radiation IRF)");
+    require(!c->finalized, HC_ERR_INVALID, "context already finalized");
+    if (c->S == 0) {
+        c->S = S;
+        c->tau.assign(t, t + S);
+        c->ldk = static_cast<size_t>(S) * c->D;
+        c->dK.alloc(static_cast<size_t>(c->Dloc) * c->ldk);
+        c->d_stage.alloc(static_cast<size_t>(6) * c->D * S);
+    } else {
+        require(S == c->S, HC_ERR_RUNTIME, "RIRF time vectors have to be exactly the same for all bodies (length differs)");
+        for (int j = 0; j < S; ++j)
+            if (std::fabs(t[j] - c->tau[j]) > 1e-10)
+                throw Error(HC_ERR_RUNTIME, "RIRF time vectors have to be exactly the same for all bodies.");
+    }
+    c->bodies[body].have_rirf = true;
+    if (is_local(c, body)) {
+        HC_HIP(hipMemcpyAsync(c->d_stage.p, K, static_cast<size_t>(6) * c->D * S * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hc::launch_relayout_rirf(c->d_stage.p, c->dK.p, c->D, S, c->ldk, 6 * (body - c->b0), c->rho, c->stream);
+        HC_HIP(hipGetLastError());
+        HC_HIP(hipStreamSynchronize(c->stream));
+        c->proc_ready = false;
+    }
+    HC_API_END(c)
+}
+
+int hc_set_excitation_rao(hc_ctx* c, int body, const double* w, int nw, const double* mag, const double* phase) {
+    HC_API_BEGIN(c)
+    check_body(c, body);
+    require(w && mag && phase && nw > 0, HC_ERR_INVALID, "null pointer or empty RAO");
+    require(c->have_sim, HC_ERR_INVALID, "set simulation parameters first (rho*g scales the excitation magnitude)");
+    auto& b = c->bodies[body];
+    b.rao_w.assign(w, w + nw);
+    b.rao_mag.assign(mag, mag + static_cast<size_t>(6) * nw);
+    const double rg = c->rho * c->g;
+    for (auto& x : b.rao_mag) x = x * rg;  // src/h5fileinfo.cpp:73-75
+    b.rao_phase.assign(phase, phase + static_cast<size_t>(6) * nw);
+    b.have_rao = true;
+    HC_API_END(c)
+}
+
+int hc_set_excitation_irf(hc_ctx* c, int body, const double* t, int n, const double* f) {
+    HC_API_BEGIN(c)
+    check_body(c, body);
+    require(t && f && n > 0, HC_ERR_INVALID, "null pointer or empty excitation IRF");
+    require(c->have_sim, HC_ERR_INVALID, "set simulation parameters first (rho*g scales the excitation IRF)");
+    auto& b = c->bodies[body];
+    b.exirf_t.assign(t, t + n);
+    b.have_exirf = true;
+    if (is_local(c, body)) {
+        b.exirf_f.assign(f, f + static_cast<size_t>(6) * n);
+        const double rg = c->rho * c->g;
+        for (auto& x : b.exirf_f) x *= rg;  // src/h5fileinfo.cpp:90
+    }
+    HC_API_END(c)
+}
+
+int hc_load_bemio_h5(hc_ctx* c, const char* path) {
+    HC_API_BEGIN(c)
+    require(path, HC_ERR_INVALID, "null path");
+    // The HDF5 reader lives in libhc_bemio.so (built only where libhdf5 exists) next to this library.
+    Dl_info info;
+    std::string dir = ".";
+    if (dladdr(reinterpret_cast<void*>(&hc_version), &info) && info.dli_fname) {
+        std::string full(info.dli_fname);
+        const size_t slash = full.find_last_of('/');
+        if (slash != std::string::npos) dir = full.substr(0, slash);
+    }
+    const std::string lib = dir + "/libhc_bemio.so";
+    void* h = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) throw Error(HC_ERR_UNSUPPORTED, std::string("BEMIO HDF5 reader not available: ") + dlerror());
+    using fn_t = int (*)(hc_ctx*, const char*, char*, size_t);
+    fn_t fn = reinterpret_cast<fn_t>(dlsym(h, "hc_bemio_load"));
+    if (!fn) throw Error(HC_ERR_UNSUPPORTED, "libhc_bemio.so lacks hc_bemio_load");
+    char msg[1024] = {0};
+    const int rc = fn(c, path, msg, sizeof msg);
+    if (rc != HC_OK) throw Error(rc, msg[0] ? std::string(msg) : c->err);
+    HC_API_END(c)
+}
+
+int hc_finalize(hc_ctx* c) {
+    HC_API_BEGIN(c)
+    require(!c->finalized, HC_ERR_INVALID, "context already finalized");
+    require(c->have_sim, HC_ERR_INVALID, "simulation parameters missing");
+    require(c->S > 0, HC_ERR_INVALID, "radiation IRF missing");
+    for (int b = c->b0; b < c->b1; ++b) {
+        const auto& bd = c->bodies[b];
+        require(bd.have_props && bd.have_lin && bd.have_ainf && bd.have_rirf, HC_ERR_INVALID,
+                "a local body lacks properties, hydrostatic stiffness, added mass or radiation IRF");
+    }
+    // trapezoid widths (src/hydro_forces.cpp:181-190)
+    c->width = hc::trapezoid_widths(c->tau);
+    c->d_tau.upload(c->tau, c->stream);
+    c->d_width.upload(c->width, c->stream);
+    // hydrostatics tables; equilibrium = cg, cb - cg (:208-216)
+    std::vector<double> lin(static_cast<size_t>(c->nloc) * 36), cg(static_cast<size_t>(c->nloc) * 3), cbm(static_cast<size_t>(c->nloc) * 3),
+        vol(c->nloc);
+    for (int bl = 0; bl < c->nloc; ++bl) {
+        const auto& bd = c->bodies[c->b0 + bl];
+        std::copy(bd.lin, bd.lin + 36, lin.begin() + static_cast<size_t>(bl) * 36);
+        for (int k = 0; k < 3; ++k) {
+            cg[bl * 3 + k]  = bd.cg[k];
+            cbm[bl * 3 + k] = bd.cb[k] - bd.cg[k];
+        }
+        vol[bl] = bd.disp_vol;
+    }
+    c->d_lin.upload(lin, c->stream);
+    c->d_cg.upload(cg, c->stream);
+    c->d_cbmcg.upload(cbm, c->stream);
+    c->d_vol.upload(vol, c->stream);
+    // added mass rows (src/chloadaddedmass.cpp:18-21)
+    c->ainf_host.assign(static_cast<size_t>(c->Dloc) * c->D, 0.0);
+    for (int bl = 0; bl < c->nloc; ++bl) {
+        const auto& bd = c->bodies[c->b0 + bl];
+        std::copy(bd.ainf.begin(), bd.ainf.end(), c->ainf_host.begin() + static_cast<size_t>(bl) * 6 * c->D);
+    }
+    c->d_ainf.upload(c->ainf_host, c->stream);
+    c->d_vec_w.alloc(c->D);
+    c->d_vec_R.alloc(c->Dloc);
+    c->d_stage.release();
+    // history ring
+    ring_alloc(c, std::max(64, c->S + 2));
+    c->times.clear();
+    c->have_prev = false;
+    c->prev_time = -1.0;
+    // GEMV scratch
+    choose_conv_config(c);
+    c->d_u.alloc(static_cast<size_t>(c->S) * c->D);
+    HC_HIP(hipMemsetAsync(c->d_u.p, 0, c->d_u.n * sizeof(double), c->stream));
+    // step I/O
+    c->d_state.alloc(static_cast<size_t>(12) * c->N);
+    c->d_hs.alloc(c->Dloc);
+    c->d_rad.alloc(c->Dloc);
+    c->d_waves.alloc(c->Dloc);
+    c->d_total.alloc(c->Dloc);
+    for (auto* b : {&c->d_hs, &c->d_rad, &c->d_waves, &c->d_total}) HC_HIP(hipMemsetAsync(b->p, 0, b->n * sizeof(double), c->stream));
+    c->d_err.alloc(1);
+    HC_HIP(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
+    c->h_state.alloc(static_cast<size_t>(12) * c->N);
+    c->h_out.alloc(static_cast<size_t>(4) * c->Dloc);
+    c->h_err.alloc(1);
+    // default wave model: NoWave for all bodies (the reference's default NoWave() covers one body only and is
+    // read out of bounds for N > 1, src/hydro_forces.cpp:758-760; that overread is deliberately not reproduced)
+    c->wave_kind   = hc::kWaveNone;
+    c->wave_nb_arg = c->N;
+    choose_exc_config(c);
+    alloc_partials(c);
+    c->prof.conv_kernel_bytes = 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
+    HC_HIP(hipStreamSynchronize(c->stream));
+    c->finalized = true;
+    HC_API_END(c)
+}
+
+// ---- configuration ----------------------------------------------------------------------------
+int hc_set_gravity(hc_ctx* c, const double g[3]) {
+    HC_API_BEGIN(c)
+    require(g, HC_ERR_INVALID, "null pointer");
+    std::copy(g, g + 3, c->gsys);
+    HC_API_END(c)
+}
+
+int hc_set_wave_none(hc_ctx* c, int num_bodies_arg) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(num_bodies_arg >= 0, HC_ERR_INVALID, "negative body count");
+    c->wave_kind   = hc::kWaveNone;
+    c->wave_nb_arg = num_bodies_arg;
+    choose_exc_config(c);
+    HC_API_END(c)
+}
+
+int hc_set_wave_regular(hc_ctx* c, int num_bodies_arg, double amplitude, double omega) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(num_bodies_arg >= 1 && num_bodies_arg <= c->N, HC_ERR_OUT_OF_RANGE, "regular wave created for more bodies than the hydro data holds");
+    for (int b = 0; b < num_bodies_arg; ++b) require(c->bodies[b].have_rao, HC_ERR_INVALID, "excitation RAO missing for a body");
+    // RegularWave::AddH5Data (src/wave_types.cpp:278-299), GetOmegaDelta (:329-333), Get*Interp (:335-352)
+    const auto& w0        = c->bodies[0].rao_w;
+    const double nfreq    = static_cast<double>(w0.size());
+    const double dw       = w0.back() / nfreq;
+    const double idx_des  = (omega / dw) - 1;
+    const double frac     = idx_des - std::floor(idx_des);
+    const int k0          = static_cast<int>(std::floor(idx_des));
+    std::vector<double> mag(c->D, 0.0), ph(c->D, 0.0);
+    for (int b = 0; b < num_bodies_arg; ++b) {
+        const auto& bd = c->bodies[b];
+        const int nw   = static_cast<int>(bd.rao_w.size());
+        if (k0 < 0 || k0 + 1 >= nw) throw Error(HC_ERR_OUT_OF_RANGE, "regular wave frequency outside the BEM frequency list");
+        for (int r = 0; r < 6; ++r) {
+            const double m0 = bd.rao_mag[static_cast<size_t>(r) * nw + k0], m1 = bd.rao_mag[static_cast<size_t>(r) * nw + k0 + 1];
+            const double p0 = bd.rao_phase[static_cast<size_t>(r) * nw + k0], p1 = bd.rao_phase[static_cast<size_t>(r) * nw + k0 + 1];
+            mag[6 * b + r] = (frac * (m1 - m0)) + m0;
+            ph[6 * b + r]  = (frac * (p1 - p0)) + p0;
+        }
+    }
+    const double k = hc::wave_number(omega, c->depth, c->g);  // RegularWave::Initialize (:274-276)
+    c->reg_mag = mag;
+    c->reg_phase = ph;
+    c->reg_amp = amplitude;
+    c->reg_omega = omega;
+    c->reg_wavenumber = k;
+    std::vector<double> local(mag.begin() + 6 * c->b0, mag.begin() + 6 * c->b1);
+    c->d_reg_mag.upload(local, c->stream);
+    c->wave_kind   = hc::kWaveRegular;
+    c->wave_nb_arg = num_bodies_arg;
+    choose_exc_config(c);
+    HC_API_END(c)
+}
+
+void hc_irregular_wave_params_default(hc_irregular_wave_params* p) {
+    if (!p) return;
+    p->num_bodies = 1;
+    p->simulation_dt = 0.0;
+    p->simulation_duration = 0.0;
+    p->ramp_duration = 0.0;
+    p->wave_height = 0.0;
+    p->wave_period = 0.0;
+    p->frequency_min = 0.001;
+    p->frequency_max = 1.0;
+    p->nfrequencies = 0;
+    p->peak_enhancement_factor = 1.0;
+    p->is_normalized = 0;
+    p->seed = 1;
+}
+
+int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(pp, HC_ERR_INVALID, "null parameters");
+    const hc_irregular_wave_params p = *pp;
+    require(p.num_bodies == c->N, HC_ERR_INVALID, "IrregularWaveParams.num_bodies_ must equal the number of hydro bodies");
+    require(p.simulation_dt > 0.0, HC_ERR_INVALID, "simulation_dt must be positive");
+    require(p.wave_height != 0.0 && p.wave_period != 0.0, HC_ERR_INVALID,
+            "wave_height and wave_period must be non-zero (the reference leaves the free-surface table empty otherwise)");
+    for (int b = c->b0; b < c->b1; ++b) require(c->bodies[b].have_exirf, HC_ERR_INVALID, "excitation IRF missing for a local body");
+    // All bodies must share the excitation-IRF time grid (BEMIO writes one grid per file); the reference would
+    // allow per-body grids, this path does not.
+    const auto& t_old = c->bodies[c->b0].exirf_t;
+    for (int b = 0; b < c->N; ++b) {
+        if (!c->bodies[b].have_exirf) continue;
+        const auto& tb = c->bodies[b].exirf_t;
+        require(tb.size() == t_old.size(), HC_ERR_UNSUPPORTED, "bodies with different excitation-IRF time grids are not supported");
+        for (size_t j = 0; j < tb.size(); ++j)
+            require(std::fabs(tb[j] - t_old[j]) <= 1e-10, HC_ERR_UNSUPPORTED, "bodies with different excitation-IRF time grids are not supported");
+    }
+    const int n_old = static_cast<int>(t_old.size());
+    // ResampleIRF (src/wave_types.cpp:572-606)
+    const double t0 = t_old.front(), t1 = t_old.back();
+    const int L = static_cast<int>(std::ceil((t1 - t0) / p.simulation_dt));
+    require(L >= 2, HC_ERR_INVALID, "excitation IRF resamples to fewer than two points");
+    std::vector<double> ex_tau   = hc::linspaced(L, t0, t1);
+    std::vector<double> ex_width = hc::trapezoid_widths(ex_tau);
+    const int Lpad = (L + 1) & ~1;
+    std::vector<double> vals(static_cast<size_t>(c->Dloc) * L);
+    std::vector<double> kex(static_cast<size_t>(c->Dloc) * Lpad, 0.0);
+    for (int bl = 0; bl < c->nloc; ++bl) {
+        const auto r = hc::resample_cubic_bspline6(c->bodies[c->b0 + bl].exirf_f, n_old, L);
+        for (int d = 0; d < 6; ++d) {
+            std::copy(r.begin() + static_cast<size_t>(d) * L, r.begin() + static_cast<size_t>(d + 1) * L,
+                      vals.begin() + static_cast<size_t>(6 * bl + d) * L);
+            std::copy(r.begin() + static_cast<size_t>(d) * L, r.begin() + static_cast<size_t>(d + 1) * L,
+                      kex.begin() + static_cast<size_t>(6 * bl + d) * Lpad);
+        }
+    }
+    // CreateSpectrum (:643-676)
+    int nf;
+    if (p.nfrequencies == 0) {
+        const double df = 1.0 / p.simulation_duration;
+        nf              = static_cast<int>(std::ceil((p.frequency_max - p.frequency_min) / df));
+    } else {
+        nf = static_cast<int>(p.nfrequencies);
+    }
+    require(nf >= 1, HC_ERR_INVALID, "no wave components");
+    std::vector<double> f = hc::linspaced(nf, p.frequency_min, p.frequency_max);
+    std::sort(f.begin(), f.end());  // PiersonMoskowitzSpectrumHz sorts its argument in place (:681)
+    std::vector<double> Sd    = hc::jonswap_spectrum_hz(f, p.wave_height, p.wave_period, p.peak_enhancement_factor, p.is_normalized != 0);
+    std::vector<double> dfv   = hc::trapezoid_widths(f);
+    std::vector<double> phase = hc::random_phases(nf, p.seed);
+    std::vector<double> kk(nf), amp(nf), omg(nf);
+    const double two_pi = 2 * M_PI;
+    for (int i = 0; i < nf; ++i) {
+        kk[i]  = hc::wave_number(two_pi * f[i], c->depth, c->g);
+        amp[i] = std::sqrt(2 * Sd[i] * dfv[i]);  // GetEtaIrregular (:39-40)
+        omg[i] = two_pi * f[i];
+    }
+    // CreateFreeSurfaceElevation (:717-774); all bodies share ex_tau, so the min/max scan reduces to its ends
+    double t_irf_min = 0.0, t_irf_max = 0.0;
+    if (ex_tau.front() < t_irf_min) t_irf_min = ex_tau.front();
+    if (ex_tau.front() > t_irf_max) t_irf_max = ex_tau.front();
+    if (ex_tau.back() > t_irf_max) t_irf_max = ex_tau.back();
+    if (ex_tau.back() < t_irf_min) t_irf_min = ex_tau.back();
+    const double duration = p.simulation_duration + 2 * (t_irf_max - t_irf_min);
+    const int nts         = static_cast<int>(std::ceil(duration / p.simulation_dt));
+    std::vector<double> eta_t = hc::linspaced(nts + 1, 0, nts * p.simulation_dt);
+    for (auto& x : eta_t) x += -t_irf_max;
+    const int nt = nts + 1;
+    require(nt >= 2, HC_ERR_INVALID, "free-surface table too short");
+
+    hc::DeviceBuffer<double> d_amp, d_omg, d_ph;
+    d_amp.upload(amp, c->stream);
+    d_omg.upload(omg, c->stream);
+    d_ph.upload(phase, c->stream);
+    c->d_eta_t.upload(eta_t, c->stream);
+    c->d_eta.alloc(nt);
+    hc::launch_eta_synthesis(c->d_eta_t.p, nt, d_amp.p, d_omg.p, d_ph.p, nf, p.ramp_duration, c->d_eta.p, c->stream);
+    HC_HIP(hipGetLastError());
+    std::vector<double> eta(nt);
+    HC_HIP(hipMemcpyAsync(eta.data(), c->d_eta.p, nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+
+    c->d_kex.upload(kex, c->stream);
+    c->d_ex_tau.upload(ex_tau, c->stream);
+    c->d_ex_width.upload(ex_width, c->stream);
+    c->d_e.alloc(Lpad);
+    HC_HIP(hipMemsetAsync(c->d_e.p, 0, Lpad * sizeof(double), c->stream));
+    c->irr = p;
+    c->L = L;
+    c->Lpad = Lpad;
+    c->nf = nf;
+    c->nt = nt;
+    c->ex_tau.swap(ex_tau);
+    c->ex_width.swap(ex_width);
+    c->ex_vals.swap(vals);
+    c->spec_f.swap(f);
+    c->spec_S.swap(Sd);
+    c->spec_df.swap(dfv);
+    c->spec_phase.swap(phase);
+    c->spec_k.swap(kk);
+    c->eta_t.swap(eta_t);
+    c->eta.swap(eta);
+    c->wave_kind   = hc::kWaveIrregular;
+    c->wave_nb_arg = p.num_bodies;
+    choose_exc_config(c);
+    alloc_partials(c);
+    c->prof.conv_kernel_bytes = 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D +
+                                       static_cast<double>(c->Dloc) * L + L);
+    HC_HIP(hipStreamSynchronize(c->stream));
+    HC_API_END(c)
+}
+
+int hc_set_convolution_mode(hc_ctx* c, int mode) {
+    HC_API_BEGIN(c)
+    require(mode == 0 || mode == 1, HC_ERR_INVALID, "mode must be 0 (Baseline) or 1 (TaperedDirect)");
+    c->conv_mode = mode;
+    HC_API_END(c)
+}
+
+void hc_tapered_direct_options_default(hc_tapered_direct_options* o) {
+    if (!o) return;
+    o->smoothing = 0;
+    o->window_length = 5;
+    o->rirf_end_time = -1.0;
+    o->taper_start_percent = 0.8;
+    o->taper_end_percent = 1.0;
+    o->taper_final_amplitude = 0.0;
+}
+
+int hc_set_tapered_direct_options(hc_ctx* c, const hc_tapered_direct_options* o) {
+    HC_API_BEGIN(c)
+    require(o, HC_ERR_INVALID, "null options");
+    require(o->smoothing == 0 || o->smoothing == 1, HC_ERR_INVALID, "smoothing must be 0 (sg) or 1 (moving_average)");
+    c->taper      = *o;
+    c->proc_ready = false;
+    HC_API_END(c)
+}
+
+// ---- per-step ---------------------------------------------------------------------------------
+int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel, double* force_out) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(pos && rpy && linvel && angvel && force_out, HC_ERR_INVALID, "null pointer");
+    if (c->have_prev && t == c->prev_time) {  // src/hydro_forces.cpp:742-744
+        std::memcpy(force_out, c->h_out.p + 3 * c->Dloc, c->Dloc * sizeof(double));
+        return HC_OK;
+    }
+    c->prev_time = t;  // :747 (set before the terms are computed, so a throwing step is not retried)
+    c->have_prev = true;
+    stage_state(c, pos, rpy, linvel, angvel);
+    enqueue_step(c, t, c->d_state.p, nullptr, c->stream, StepFlags{});
+    const size_t nb = c->Dloc * sizeof(double);
+    HC_HIP(hipMemcpyAsync(c->h_out.p + 3 * c->Dloc, c->d_total.p, nb, hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipMemcpyAsync(c->h_err.p, c->d_err.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    if (*c->h_err.p != 0) check_device_flag(c);
+    std::memcpy(force_out, c->h_out.p + 3 * c->Dloc, nb);
+    HC_API_END(c)
+}
+
+int hc_step_device(hc_ctx* c, double t, const double* d_state, double* d_force_out, void* stream) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(d_state && d_force_out, HC_ERR_INVALID, "null pointer");
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    if (c->have_prev && t == c->prev_time) {
+        HC_HIP(hipMemcpyAsync(d_force_out, c->d_total.p, c->Dloc * sizeof(double), hipMemcpyDeviceToDevice, s));
+        return HC_OK;
+    }
+    c->prev_time = t;
+    c->have_prev = true;
+    enqueue_step(c, t, d_state, d_force_out, s, StepFlags{});
+    HC_API_END(c)
+}
+
+int hc_get_force_components(hc_ctx* c, double* hs, double* rad, double* waves) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    HC_HIP(hipDeviceSynchronize());
+    const size_t nb = c->Dloc * sizeof(double);
+    HC_HIP(hipMemcpyAsync(c->h_out.p, c->d_hs.p, nb, hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipMemcpyAsync(c->h_out.p + c->Dloc, c->d_rad.p, nb, hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipMemcpyAsync(c->h_out.p + 2 * c->Dloc, c->d_waves.p, nb, hipMemcpyDeviceToHost, c->stream));
+    check_device_flag(c);  // synchronises
+    if (hs) std::memcpy(hs, c->h_out.p, nb);
+    if (rad) std::memcpy(rad, c->h_out.p + c->Dloc, nb);
+    if (waves) std::memcpy(waves, c->h_out.p + 2 * c->Dloc, nb);
+    HC_API_END(c)
+}
+
+int hc_compute_radiation(hc_ctx* c, double t, const double* linvel, const double* angvel, double* rad_out) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(linvel && angvel && rad_out, HC_ERR_INVALID, "null pointer");
+    stage_state(c, nullptr, nullptr, linvel, angvel);
+    StepFlags f;
+    f.hs = false;
+    f.waves = false;
+    enqueue_step(c, t, c->d_state.p, nullptr, c->stream, f);
+    HC_HIP(hipMemcpyAsync(c->h_out.p + c->Dloc, c->d_rad.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    check_device_flag(c);
+    std::memcpy(rad_out, c->h_out.p + c->Dloc, c->Dloc * sizeof(double));
+    HC_API_END(c)
+}
+
+int hc_compute_hydrostatics(hc_ctx* c, const double* pos, const double* rpy, double* hs_out) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(pos && rpy && hs_out, HC_ERR_INVALID, "null pointer");
+    stage_state(c, pos, rpy, nullptr, nullptr);
+    StepFlags f;
+    f.rad = false;
+    f.waves = false;
+    enqueue_step(c, 0.0, c->d_state.p, nullptr, c->stream, f);
+    HC_HIP(hipMemcpyAsync(c->h_out.p, c->d_hs.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(hs_out, c->h_out.p, c->Dloc * sizeof(double));
+    HC_API_END(c)
+}
+
+int hc_compute_waves(hc_ctx* c, double t, double* waves_out) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(waves_out, HC_ERR_INVALID, "null pointer");
+    stage_state(c, nullptr, nullptr, nullptr, nullptr);
+    StepFlags f;
+    f.hs = false;
+    f.rad = false;
+    enqueue_step(c, t, c->d_state.p, nullptr, c->stream, f);
+    HC_HIP(hipMemcpyAsync(c->h_out.p + 2 * c->Dloc, c->d_waves.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    check_device_flag(c);
+    std::memcpy(waves_out, c->h_out.p + 2 * c->Dloc, c->Dloc * sizeof(double));
+    HC_API_END(c)
+}
+
+int hc_reset_history(hc_ctx* c) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    HC_HIP(hipStreamSynchronize(c->stream));
+    c->times.clear();
+    c->head = -1;
+    c->have_prev = false;
+    c->prev_time = -1.0;
+    HC_API_END(c)
+}
+
+int hc_set_history(hc_ctx* c, int n, const double* times, const double* vel) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(n >= 0 && (n == 0 || (times && vel)), HC_ERR_INVALID, "bad history arguments");
+    for (int k = 1; k < n; ++k) require(times[k] < times[k - 1], HC_ERR_INVALID, "history times must be strictly decreasing (newest first)");
+    HC_HIP(hipStreamSynchronize(c->stream));
+    if (n > c->Hcap) ring_alloc(c, n + 16);
+    c->times.assign(times, times + n);
+    // sample k -> slot n-1-k, head = n-1
+    std::vector<double> tt(n), vv(static_cast<size_t>(n) * c->D);
+    for (int k = 0; k < n; ++k) {
+        tt[n - 1 - k] = times[k];
+        std::copy(vel + static_cast<size_t>(k) * c->D, vel + static_cast<size_t>(k + 1) * c->D, vv.begin() + static_cast<size_t>(n - 1 - k) * c->D);
+    }
+    if (n) {
+        HC_HIP(hipMemcpy(c->d_ring_t.p, tt.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        HC_HIP(hipMemcpy(c->d_ring_v.p, vv.data(), vv.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    c->head      = n - 1;
+    c->have_prev = n > 0;
+    c->prev_time = n > 0 ? times[0] : -1.0;
+    HC_API_END(c)
+}
+
+int hc_get_history(hc_ctx* c, int* n, double* times, double* vel) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    HC_HIP(hipDeviceSynchronize());
+    const int H = static_cast<int>(c->times.size());
+    if (n) *n = H;
+    if (times) std::copy(c->times.begin(), c->times.end(), times);
+    if (vel) {
+        for (int k = 0; k < H; ++k) {
+            const int slot = ((c->head - k) % c->Hcap + c->Hcap) % c->Hcap;
+            HC_HIP(hipMemcpy(vel + static_cast<size_t>(k) * c->D, c->d_ring_v.p + static_cast<size_t>(slot) * c->D, c->D * sizeof(double),
+                             hipMemcpyDeviceToHost));
+        }
+    }
+    HC_API_END(c)
+}
+
+// ---- added mass -------------------------------------------------------------------------------
+int hc_added_mass_matrix(hc_ctx* c, double* M) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(M, HC_ERR_INVALID, "null pointer");
+    std::copy(c->ainf_host.begin(), c->ainf_host.end(), M);
+    HC_API_END(c)
+}
+
+int hc_added_mass_mv(hc_ctx* c, const double* w, double cc, double* R, int n_sys) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(w && R, HC_ERR_INVALID, "null pointer");
+    require(n_sys >= c->D, HC_ERR_INVALID, "system has fewer coordinates than the added-mass block");
+    const int row0 = 6 * c->b0;
+    std::memcpy(c->h_state.p, w, c->D * sizeof(double));
+    std::memcpy(c->h_out.p, R + row0, c->Dloc * sizeof(double));
+    HC_HIP(hipMemcpyAsync(c->d_vec_w.p, c->h_state.p, c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(hipMemcpyAsync(c->d_vec_R.p, c->h_out.p, c->Dloc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hc::launch_added_mass_mv(c->d_ainf.p, c->Dloc, c->D, c->d_vec_w.p, cc, c->d_vec_R.p, c->stream);
+    HC_HIP(hipGetLastError());
+    HC_HIP(hipMemcpyAsync(c->h_out.p, c->d_vec_R.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(R + row0, c->h_out.p, c->Dloc * sizeof(double));
+    HC_API_END(c)
+}
+
+// ---- introspection ----------------------------------------------------------------------------
+int hc_enable_profiling(hc_ctx* c, int on) {
+    HC_API_BEGIN(c)
+    if (!on) profile_drain(c);
+    c->profiling = on != 0;
+    HC_API_END(c)
+}
+
+int hc_get_profile(hc_ctx* c, hc_profile_stats* out) {
+    HC_API_BEGIN(c)
+    require(out, HC_ERR_INVALID, "null pointer");
+    profile_drain(c);
+    *out = c->prof;
+    HC_API_END(c)
+}
+
+int hc_reset_profile(hc_ctx* c) {
+    HC_API_BEGIN(c)
+    profile_drain(c);
+    const double bytes = c->prof.conv_kernel_bytes;
+    c->prof = hc_profile_stats{};
+    c->prof.conv_kernel_bytes = bytes;
+    HC_API_END(c)
+}
+
+int hc_get_sizes(hc_ctx* c, int* N, int* n_local, int* S, int* L, int* nf, int* nt, int* H, int* Hcap) {
+    HC_API_BEGIN(c)
+    if (N) *N = c->N;
+    if (n_local) *n_local = c->nloc;
+    if (S) *S = c->S;
+    if (L) *L = c->L;
+    if (nf) *nf = c->nf;
+    if (nt) *nt = c->nt;
+    if (H) *H = static_cast<int>(c->times.size());
+    if (Hcap) *Hcap = c->Hcap;
+    HC_API_END(c)
+}
+
+int hc_get_rirf_width(hc_ctx* c, double* w) {
+    HC_API_BEGIN(c)
+    require(c->finalized && w, HC_ERR_INVALID, "not finalized or null pointer");
+    std::copy(c->width.begin(), c->width.end(), w);
+    HC_API_END(c)
+}
+
+int hc_get_rirf_effective(hc_ctx* c, double* out) {
+    HC_API_BEGIN(c)
+    require(c->finalized && out, HC_ERR_INVALID, "not finalized or null pointer");
+    ensure_processed(c);
+    const size_t n = static_cast<size_t>(c->Dloc) * c->D * c->S;
+    hc::DeviceBuffer<double> tmp;
+    tmp.alloc(n);
+    hc::launch_unrelayout(c->conv_mode == 1 ? c->dKproc.p : c->dK.p, c->ldk, c->Dloc, c->D, c->S, tmp.p, c->stream);
+    HC_HIP(hipGetLastError());
+    HC_HIP(hipMemcpyAsync(out, tmp.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    HC_API_END(c)
+}
+
+int hc_get_excitation_irf_resampled(hc_ctx* c, int body, double* t, double* width, double* vals) {
+    HC_API_BEGIN(c)
+    require(c->wave_kind == hc::kWaveIrregular, HC_ERR_INVALID, "no irregular wave model attached");
+    check_body(c, body);
+    require(is_local(c, body), HC_ERR_INVALID, "body is not owned by this context");
+    if (t) std::copy(c->ex_tau.begin(), c->ex_tau.end(), t);
+    if (width) std::copy(c->ex_width.begin(), c->ex_width.end(), width);
+    if (vals) {
+        const size_t off = static_cast<size_t>(6) * (body - c->b0) * c->L;
+        std::copy(c->ex_vals.begin() + off, c->ex_vals.begin() + off + static_cast<size_t>(6) * c->L, vals);
+    }
+    HC_API_END(c)
+}
+
+int hc_get_spectrum(hc_ctx* c, double* f, double* S, double* df, double* phase, double* k) {
+    HC_API_BEGIN(c)
+    require(c->wave_kind == hc::kWaveIrregular, HC_ERR_INVALID, "no irregular wave model attached");
+    if (f) std::copy(c->spec_f.begin(), c->spec_f.end(), f);
+    if (S) std::copy(c->spec_S.begin(), c->spec_S.end(), S);
+    if (df) std::copy(c->spec_df.begin(), c->spec_df.end(), df);
+    if (phase) std::copy(c->spec_phase.begin(), c->spec_phase.end(), phase);
+    if (k) std::copy(c->spec_k.begin(), c->spec_k.end(), k);
+    HC_API_END(c)
+}
+
+int hc_get_eta_table(hc_ctx* c, double* t, double* eta) {
+    HC_API_BEGIN(c)
+    require(c->wave_kind == hc::kWaveIrregular, HC_ERR_INVALID, "no irregular wave model attached");
+    if (t) std::copy(c->eta_t.begin(), c->eta_t.end(), t);
+    if (eta) std::copy(c->eta.begin(), c->eta.end(), eta);
+    HC_API_END(c)
+}
+
+int hc_get_regular_coeffs(hc_ctx* c, double* mag, double* phase, double* wavenumber) {
+    HC_API_BEGIN(c)
+    require(c->wave_kind == hc::kWaveRegular, HC_ERR_INVALID, "no regular wave model attached");
+    if (mag) std::copy(c->reg_mag.begin(), c->reg_mag.end(), mag);
+    if (phase) std::copy(c->reg_phase.begin(), c->reg_phase.end(), phase);
+    if (wavenumber) *wavenumber = c->reg_wavenumber;
+    HC_API_END(c)
+}
+
+// ---- synthetic inputs generated in HBM --------------------------------------------------------
+int hc_synth_fill(hc_ctx* c, unsigned long long seed, int S, double dt_rirf, int n_exc, double dt_exc) {
+    HC_API_BEGIN(c)
+    require(!c->finalized, HC_ERR_INVALID, "context already finalized");
+    require(S > 0 && dt_rirf > 0, HC_ERR_INVALID, "bad synthetic sizes");
+    if (!c->have_sim) {
+        c->rho = 1000.0;
+        c->g = 9.81;
+        c->depth = std::numeric_limits<double>::infinity();
+        c->have_sim = true;
+    }
+    c->S = S;
+    c->tau.resize(S);
+    for (int s = 0; s < S; ++s) c->tau[s] = s * dt_rirf;
+    c->ldk = static_cast<size_t>(S) * c->D;
+    c->dK.alloc(static_cast<size_t>(c->Dloc) * c->ldk);
+    hc::launch_synth_rirf(c->dK.p, c->ldk, c->Dloc, c->D, S, 6 * c->b0, dt_rirf, seed, c->rho, c->stream);
+    HC_HIP(hipGetLastError());
+    // small per-body tables from the same counter-based stream, on the host
+    auto mix = [](uint64_t x) {
+        x += 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        return x ^ (x >> 31);
+    };
+    auto u01 = [](uint64_t h) { return static_cast<double>(h >> 11) * (1.0 / 9007199254740992.0); };
+    for (int b = 0; b < c->N; ++b) {
+        auto& bd = c->bodies[b];
+        const uint64_t hb = mix(seed ^ (0xB0D1ull << 40) ^ static_cast<uint64_t>(b));
+        bd.disp_vol = 200.0 + 100.0 * u01(mix(hb + 1));
+        for (int k = 0; k < 3; ++k) {
+            bd.cg[k] = (k == 2 ? -2.0 : 20.0 * (b % 8) * (k == 0) + 20.0 * (b / 8) * (k == 1));
+            bd.cb[k] = bd.cg[k] + (k == 2 ? 0.1 : 0.0);
+        }
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) {
+                const double r = u01(mix(hb + 100 + 6 * std::min(i, j) + std::max(i, j)));
+                bd.lin[6 * i + j] = (i == j ? 50.0 + 50.0 * r : 2.0 * (r - 0.5));
+            }
+        bd.have_props = bd.have_lin = bd.have_ainf = bd.have_rirf = true;
+        if (is_local(c, b)) {
+            bd.ainf.resize(static_cast<size_t>(6) * c->D);
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < c->D; ++j) {
+                    const int gi = 6 * b + i;
+                    const uint64_t h = mix(seed ^ (0xA1ull << 48) ^ (static_cast<uint64_t>(std::min(gi, j)) << 24) ^ static_cast<uint64_t>(std::max(gi, j)));
+                    const double r = u01(h);
+                    bd.ainf[static_cast<size_t>(i) * c->D + j] = c->rho * (gi == j ? 100.0 + 50.0 * r : (r - 0.5) * (j / 6 == b ? 5.0 : 0.5));
+                }
+            if (n_exc > 0) {
+                bd.exirf_f.resize(static_cast<size_t>(6) * n_exc);
+                for (int i = 0; i < 6; ++i) {
+                    const uint64_t h = mix(seed ^ (0xE7ull << 48) ^ static_cast<uint64_t>(6 * b + i));
+                    const double a = 1.0 + u01(mix(h + 1)), wd = 1.0 + 2.0 * u01(mix(h + 2)), om = 0.5 + 1.5 * u01(mix(h + 3));
+                    for (int j = 0; j < n_exc; ++j) {
+                        const double tt = (j - (n_exc - 1) * 0.5) * dt_exc;
+                        bd.exirf_f[static_cast<size_t>(i) * n_exc + j] = c->rho * c->g * a * std::exp(-(tt * tt) / (wd * wd)) * std::cos(om * tt);
+                    }
+                }
+            }
+        }
+        if (n_exc > 0) {
+            bd.exirf_t.resize(n_exc);
+            for (int j = 0; j < n_exc; ++j) bd.exirf_t[j] = (j - (n_exc - 1) * 0.5) * dt_exc;
+            bd.have_exirf = true;
+        }
+    }
+    HC_HIP(hipStreamSynchronize(c->stream));
+    HC_API_END(c)
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// hc_bemio.cpp -- BEMIO-HDF5 ingest (libhc_bemio.so; optional, needs libhdf5).
+//
+// Reads exactly the datasets H5FileInfo::ReadH5Data reads (src/h5fileinfo.cpp:35-90) for body1..bodyN and hands
+// them, unscaled, to the raw-array setters of the C ABI, which apply the reference's rho / rho*g scaling.
+// HDF5 C API only; dataset element order is the file's row-major order, as the setters expect.
+#include <hdf5.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/hydrochrono_amd.h"
+
+namespace {
+
+struct H5Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+struct File {
+    hid_t id;
+    explicit File(const char* path) {
+        H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);
+        id = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+        if (id < 0) throw H5Error(std::string("Unable to open/read HDF5 hydro data file: ") + path);
+    }
+    ~File() {
+        if (id >= 0) H5Fclose(id);
+    }
+};
+
+std::vector<double> read_doubles(hid_t file, const std::string& name, std::vector<hsize_t>* dims_out = nullptr) {
+    hid_t ds = H5Dopen2(file, name.c_str(), H5P_DEFAULT);
+    if (ds < 0) throw H5Error("missing dataset " + name);
+    hid_t sp      = H5Dget_space(ds);
+    const int rk  = H5Sget_simple_extent_ndims(sp);
+    std::vector<hsize_t> dims(rk > 0 ? rk : 0);
+    if (rk > 0) H5Sget_simple_extent_dims(sp, dims.data(), nullptr);
+    size_t n = 1;
+    for (auto d : dims) n *= static_cast<size_t>(d);
+    std::vector<double> out(n);
+    const herr_t rc = H5Dread(ds, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, out.data());
+    H5Sclose(sp);
+    H5Dclose(ds);
+    if (rc < 0) throw H5Error("cannot read dataset " + name);
+    if (dims_out) *dims_out = dims;
+    return out;
+}
+
+// InitScalar (src/h5fileinfo.cpp:197-226): numeric scalar, or the string "infinite" -> +inf
+double read_scalar(hid_t file, const std::string& name) {
+    hid_t ds = H5Dopen2(file, name.c_str(), H5P_DEFAULT);
+    if (ds < 0) throw H5Error("missing dataset " + name);
+    hid_t ty             = H5Dget_type(ds);
+    const H5T_class_t cl = H5Tget_class(ty);
+    double v             = 0.0;
+    if (cl == H5T_STRING) {
+        const size_t sz = H5Tget_size(ty);
+        std::vector<char> buf(sz + 1, 0);
+        if (H5Tis_variable_str(ty) > 0) {
+            char* p = nullptr;
+            if (H5Dread(ds, ty, H5S_ALL, H5S_ALL, H5P_DEFAULT, &p) >= 0 && p) {
+                if (std::strcmp(p, "infinite") == 0) v = std::numeric_limits<double>::infinity();
+                H5free_memory(p);
+            }
+        } else if (H5Dread(ds, ty, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf.data()) >= 0) {
+            if (std::string(buf.data()) == "infinite") v = std::numeric_limits<double>::infinity();
+        }
+    } else {
+        if (H5Dread(ds, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, &v) < 0) {
+            H5Tclose(ty);
+            H5Dclose(ds);
+            throw H5Error("cannot read dataset " + name);
+        }
+    }
+    H5Tclose(ty);
+    H5Dclose(ds);
+    return v;
+}
+
+void ok(hc_ctx* ctx, int rc) {
+    if (rc != HC_OK) throw H5Error(hc_last_error(ctx));
+}
+
+}  // namespace
+
+extern "C" int hc_bemio_load(hc_ctx* ctx, const char* path, char* err, size_t errlen) {
+    try {
+        int N = 0;
+        ok(ctx, hc_get_sizes(ctx, &N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+        File f(path);
+        const double rho   = read_scalar(f.id, "simulation_parameters/rho");
+        const double g     = read_scalar(f.id, "simulation_parameters/g");
+        const double depth = read_scalar(f.id, "simulation_parameters/water_depth");
+        ok(ctx, hc_set_simulation_parameters(ctx, rho, g, depth));
+        const std::vector<double> w = read_doubles(f.id, "simulation_parameters/w");
+        const int D = 6 * N;
+        for (int b = 0; b < N; ++b) {
+            const std::string body = "body" + std::to_string(b + 1);
+            const double vol = read_scalar(f.id, body + "/properties/disp_vol");
+            const auto cg    = read_doubles(f.id, body + "/properties/cg");
+            const auto cb    = read_doubles(f.id, body + "/properties/cb");
+            if (cg.size() < 3 || cb.size() < 3) throw H5Error(body + ": cg/cb must have 3 entries");
+            ok(ctx, hc_set_body_properties(ctx, b, vol, cg.data(), cb.data()));
+            const auto lin = read_doubles(f.id, body + "/hydro_coeffs/linear_restoring_stiffness");
+            if (lin.size() != 36) throw H5Error(body + ": linear_restoring_stiffness must be 6x6");
+            ok(ctx, hc_set_hydrostatic_stiffness(ctx, b, lin.data()));
+            const auto ainf = read_doubles(f.id, body + "/hydro_coeffs/added_mass/inf_freq");
+            if (ainf.size() != static_cast<size_t>(6) * D) throw H5Error(body + ": added_mass/inf_freq must be 6 x 6N");
+            ok(ctx, hc_set_added_mass_inf(ctx, b, ainf.data()));
+            const auto t = read_doubles(f.id, body + "/hydro_coeffs/radiation_damping/impulse_response_fun/t");
+            std::vector<hsize_t> kd;
+            const auto K = read_doubles(f.id, body + "/hydro_coeffs/radiation_damping/impulse_response_fun/K", &kd);
+            if (kd.size() != 3 || kd[0] != 6 || kd[1] != static_cast<hsize_t>(D) || kd[2] != t.size())
+                throw H5Error(body + ": impulse_response_fun/K must be {6, 6N, len(t)}");
+            ok(ctx, hc_set_rirf(ctx, b, t.data(), static_cast<int>(t.size()), K.data()));
+            const auto mag = read_doubles(f.id, body + "/hydro_coeffs/excitation/mag");
+            const auto ph  = read_doubles(f.id, body + "/hydro_coeffs/excitation/phase");
+            if (mag.size() != 6 * w.size() || ph.size() != 6 * w.size()) throw H5Error(body + ": excitation mag/phase must be {6,1,len(w)}");
+            ok(ctx, hc_set_excitation_rao(ctx, b, w.data(), static_cast<int>(w.size()), mag.data(), ph.data()));
+            const auto et = read_doubles(f.id, body + "/hydro_coeffs/excitation/impulse_response_fun/t");
+            const auto ef = read_doubles(f.id, body + "/hydro_coeffs/excitation/impulse_response_fun/f");
+            if (ef.size() != 6 * et.size()) throw H5Error(body + ": excitation impulse_response_fun/f must be {6,1,len(t)}");
+            ok(ctx, hc_set_excitation_irf(ctx, b, et.data(), static_cast<int>(et.size()), ef.data()));
+        }
+    } catch (const std::exception& e) {
+        if (err && errlen) std::snprintf(err, errlen, "%s", e.what());
+        return HC_ERR_RUNTIME;
+    }
+    return HC_OK;
+}

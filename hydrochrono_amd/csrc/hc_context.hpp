@@ -1,0 +1,156 @@
+// hc_context.hpp -- host-side state behind an hc_ctx (see include/hydrochrono_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <deque>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/hydrochrono_amd.h"
+#include "hc_kernels.hpp"
+
+namespace hc {
+
+// Error carrying the C status it maps to.
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const std::string& what) : std::runtime_error(what), status(st) {}
+};
+
+#define HC_HIP(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess)                                                                                 \
+            throw ::hc::Error(HC_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(_e));       \
+    } while (0)
+
+template <class T>
+struct DeviceBuffer {
+    T* p     = nullptr;
+    size_t n = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer&)            = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    ~DeviceBuffer() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count) {
+        release();
+        if (count == 0) return;
+        HC_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        n = count;
+    }
+    void upload(const std::vector<T>& h, hipStream_t s) {
+        if (n != h.size()) alloc(h.size());
+        if (n) {
+            HC_HIP(hipMemcpyAsync(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice, s));
+            HC_HIP(hipStreamSynchronize(s));  // source is pageable; keep lifetime simple at init
+        }
+    }
+};
+
+template <class T>
+struct PinnedBuffer {
+    T* p     = nullptr;
+    size_t n = 0;
+    PinnedBuffer() = default;
+    PinnedBuffer(const PinnedBuffer&)            = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    ~PinnedBuffer() {
+        if (p) (void)hipHostFree(p);
+    }
+    void alloc(size_t count) {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+        if (count == 0) return;
+        HC_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocDefault));
+        n = count;
+    }
+};
+
+struct BodyHost {
+    bool have_props = false, have_lin = false, have_ainf = false, have_rirf = false, have_rao = false, have_exirf = false;
+    double disp_vol = 0.0, cg[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
+    double lin[36]  = {0};
+    std::vector<double> ainf;       // [6][D], rho-scaled (local bodies only)
+    std::vector<double> rao_w;      // [nw]
+    std::vector<double> rao_mag;    // [6][nw] rho*g-scaled
+    std::vector<double> rao_phase;  // [6][nw]
+    std::vector<double> exirf_t;    // [n]
+    std::vector<double> exirf_f;    // [6][n] rho*g-scaled (local bodies only)
+};
+
+enum WaveKind { kWaveNone = 0, kWaveRegular = 1, kWaveIrregular = 2 };
+
+struct EventSet {
+    hipEvent_t e[4];
+};
+
+}  // namespace hc
+
+struct hc_ctx {
+    int N = 0, b0 = 0, b1 = 0, nloc = 0, D = 0, Dloc = 0, device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    bool have_sim = false;
+    double rho = 0, g = 0, depth = 0;
+    double gsys[3] = {0.0, 0.0, -9.81};
+    std::vector<hc::BodyHost> bodies;
+
+    // radiation IRF
+    int S = 0;
+    std::vector<double> tau, width;
+    hc::DeviceBuffer<double> dK, dKproc, d_tau, d_width, d_stage;
+    size_t ldk = 0;
+    int conv_mode = 0;
+    bool proc_ready = false;
+    hc_tapered_direct_options taper{};
+    bool finalized = false;
+
+    // history (host mirror of times, newest first) + ring in HBM
+    std::deque<double> times;
+    int head = -1, Hcap = 0;
+    hc::DeviceBuffer<double> d_ring_t, d_ring_v;
+    bool have_prev = false;
+    double prev_time = -1.0;
+
+    // hydrostatics / added mass
+    hc::DeviceBuffer<double> d_lin, d_cg, d_cbmcg, d_vol, d_ainf, d_vec_w, d_vec_R;
+    std::vector<double> ainf_host;  // [Dloc][D]
+
+    // waves
+    int wave_kind = hc::kWaveNone;
+    int wave_nb_arg = 0;
+    double reg_amp = 0, reg_omega = 0, reg_wavenumber = 0;
+    std::vector<double> reg_mag, reg_phase;  // [D] each (all bodies)
+    hc::DeviceBuffer<double> d_reg_mag;      // [Dloc]
+    hc_irregular_wave_params irr{};
+    int L = 0, Lpad = 0, nf = 0, nt = 0;
+    std::vector<double> ex_tau, ex_width, ex_vals;  // ex_vals [Dloc][L]
+    std::vector<double> spec_f, spec_S, spec_df, spec_phase, spec_k;
+    std::vector<double> eta_t, eta;
+    hc::DeviceBuffer<double> d_kex, d_ex_tau, d_ex_width, d_eta_t, d_eta, d_e;
+
+    // GEMV configuration + scratch
+    int rows_per_tile = 6, nrowtiles = 0;
+    int chunk_cols = 0, nchunks_rad = 0, chunk_cols_ex = 0, nchunks_ex = 0;
+    hc::DeviceBuffer<double> d_u, d_partials;
+
+    // step I/O
+    hc::DeviceBuffer<double> d_state, d_hs, d_rad, d_waves, d_total;
+    hc::DeviceBuffer<int> d_err;
+    hc::PinnedBuffer<double> h_state, h_out;
+    hc::PinnedBuffer<int> h_err;
+
+    // profiling
+    bool profiling = false;
+    std::vector<hc::EventSet> events;
+    size_t events_used = 0;
+    hc_profile_stats prof{};
+};

@@ -1,0 +1,439 @@
+// hc_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the hydro-force path.
+//
+// Per step three launches run back to back on one stream:
+//   prep_kernel      velocity-ring push, bracket search + linear interpolation of the velocity history at
+//                    t - tau_s (-> u[S*D], trapezoid width folded in), eta(t - tau_j) lookup (-> e[L])
+//   conv_kernel      the Cummins convolution as a streamed FP64 GEMV  partial[chunk][row] = K[row, chunk] . u[chunk]
+//                    (HBM-bound: K is read exactly once, 16 B per lane, fully coalesced; u comes from L2)
+//   finalize_kernel  fixed-order reduction of the partials, hydrostatics, regular-wave term,
+//                    total = hydrostatic - radiation + waves
+// Reference semantics: src/hydro_forces.cpp:263-322,537-691,727-767; src/wave_types.cpp:315-327,776-844.
+#include "hc_kernels.hpp"
+
+#include <cstdint>
+
+namespace hc {
+
+static constexpr int kConvThreads = 256;  // 4 waves of 64
+static constexpr int kWave        = 64;
+
+// ------------------------------------------------------------------------------------------------
+// K re-layout at ingest: file order [i][col][s] (s fastest) -> HBM order [row][s][col] (col fastest) so that
+// the (s,col) axis the per-step GEMV contracts over is contiguous.  32x32 LDS-tiled transpose; rho folded in
+// (HydroData::GetRIRFVal, src/h5fileinfo.cpp:321-323).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) relayout_rirf_kernel(const double* __restrict__ Kb, double* __restrict__ K, int D, int S,
+                                                             size_t ldk, int row0, double rho) {
+    __shared__ double tile[32][33];
+    const int i    = blockIdx.z;          // DoF row of this body, 0..5
+    const int col0 = blockIdx.x * 32;
+    const int s0   = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const double* src = Kb + (size_t)i * D * S;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = col0 + ty + 8 * k, s = s0 + tx;
+        if (c < D && s < S) tile[ty + 8 * k][tx] = src[(size_t)c * S + s];
+    }
+    __syncthreads();
+    double* dst = K + (size_t)(row0 + i) * ldk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int s = s0 + ty + 8 * k, c = col0 + tx;
+        if (c < D && s < S) dst[(size_t)s * D + c] = tile[tx][ty + 8 * k] * rho;
+    }
+}
+
+void launch_relayout_rirf(const double* d_Kb, double* d_K, int D, int S, size_t ldk, int row0, double rho, hipStream_t stream) {
+    dim3 grid((D + 31) / 32, (S + 31) / 32, 6);
+    hipLaunchKernelGGL(relayout_rirf_kernel, grid, dim3(256), 0, stream, d_Kb, d_K, D, S, ldk, row0, rho);
+}
+
+__global__ void __launch_bounds__(256) unrelayout_kernel(const double* __restrict__ K, size_t ldk, int Dloc, int D, int S,
+                                                          double* __restrict__ out) {
+    const size_t n   = (size_t)Dloc * D * S;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    const int s   = (int)(gid % S);
+    const int col = (int)((gid / S) % D);
+    const int row = (int)(gid / ((size_t)S * D));
+    out[gid]      = K[(size_t)row * ldk + (size_t)s * D + col];
+}
+
+void launch_unrelayout(const double* d_K, size_t ldk, int Dloc, int D, int S, double* d_out, hipStream_t stream) {
+    const size_t n = (size_t)Dloc * D * S;
+    hipLaunchKernelGGL(unrelayout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_K, ldk, Dloc, D, S, d_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep_kernel.  Block roles by blockIdx.x:
+//   [0, S)                 radiation sample s: bracket search in the time ring, interpolate all D columns
+//   [S, S + nexc)          excitation samples, one thread per tau_j
+//   S + nexc               ring push of the current sample
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double state_velocity(const double* __restrict__ state, int N, int col) {
+    const int b = col / 6, d = col - 6 * b;
+    return d < 3 ? state[6 * N + 3 * b + d] : state[9 * N + 3 * b + (d - 3)];
+}
+
+__global__ void __launch_bounds__(256) prep_kernel(PrepArgs a) {
+    const int nrad  = a.do_radiation ? a.S : 0;
+    const int nexc  = a.do_excitation ? (a.L + 255) / 256 : 0;
+    const int bid   = blockIdx.x;
+    const int tid   = threadIdx.x;
+
+    if (bid < nrad) {
+        // ---- AdvanceToBracket + InterpolateVelocity6D (src/hydro_forces.cpp:343-381,600-636) ----
+        const int s    = bid;
+        const double q = a.t - a.tau[s];
+        auto hist_time = [&](int k) -> double { return k == 0 ? a.t : a.ring_t[(a.head - k + a.Hcap) % a.Hcap]; };
+        // smallest i in [0, H-2] with time(i+1) <= q ; none -> no older sample -> contributes nothing
+        int lo = 0, hi = a.H - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (hist_time(mid + 1) <= q) hi = mid; else lo = mid + 1;
+        }
+        double* __restrict__ urow = a.u + (size_t)s * a.D;
+        if (lo >= a.H - 1) {
+            for (int c = tid; c < a.D; c += blockDim.x) urow[c] = 0.0;
+            return;
+        }
+        const double newer = hist_time(lo), older = hist_time(lo + 1);
+        double wo, wn;
+        if (q == older) { wo = 1.0; wn = 0.0; }
+        else if (q == newer) { wo = 0.0; wn = 1.0; }
+        else if (q > older && q < newer) {
+            const double td = newer - older;
+            wo = (td != 0.0) ? ((newer - q) / td) : 0.0;
+            wn = 1.0 - wo;
+        } else {
+            if (tid == 0) *a.error_flag = 1;  // "query_time not bracketed by history" (:370)
+            wo = 0.0; wn = 0.0;
+        }
+        const double w        = a.width[s];
+        const int slot_older  = (a.head - (lo + 1) + a.Hcap) % a.Hcap;
+        const int slot_newer  = (a.head - lo + a.Hcap) % a.Hcap;
+        const double* v_older = a.ring_v + (size_t)slot_older * a.D;
+        const double* v_newer = a.ring_v + (size_t)slot_newer * a.D;
+        for (int c = tid; c < a.D; c += blockDim.x) {
+            const double vn = (lo == 0) ? state_velocity(a.state, a.N, c) : v_newer[c];
+            const double vo = v_older[c];
+            double v;
+            if (wn == 0.0) v = vo;           // exact copies, as the reference's early returns
+            else if (wo == 0.0) v = vn;
+            else v = wo * vo + wn * vn;
+            urow[c] = v * w;
+        }
+        return;
+    }
+    if (bid < nrad + nexc) {
+        // ---- eta(t - tau_j), linear interpolation in the precomputed table (src/wave_types.cpp:797-831) ----
+        const int j = (bid - nrad) * 256 + tid;
+        if (j >= a.Lpad) return;
+        if (j >= a.L) { a.e[j] = 0.0; return; }
+        const double q    = a.t - a.ex_tau[j];
+        const double tmin = a.eta_t[0];
+        int idx = (int)floor((q - tmin) / a.eta_dt);
+        idx     = max(0, min(idx, a.nt - 2));
+        while (idx > 0 && a.eta_t[idx] > q) --idx;
+        while (idx < a.nt - 2 && a.eta_t[idx + 1] <= q) ++idx;
+        const double t1 = a.eta_t[idx], t2 = a.eta_t[idx + 1];
+        double val;
+        if (q == t1) val = a.eta[idx];
+        else if (q == t2) val = a.eta[idx + 1];
+        else if (q > t1 && q < t2) {
+            const double w1 = (t2 - q) / (t2 - t1);
+            const double w2 = 1.0 - w1;
+            val = w1 * a.eta[idx] + w2 * a.eta[idx + 1];
+        } else {
+            *a.error_flag = 2;  // outside the table: the host has already refused the step (:833-840)
+            val = 0.0;
+        }
+        a.e[j] = val * a.ex_width[j];
+        if (j + 1 == a.L && a.Lpad > a.L) a.e[a.L] = 0.0;
+        return;
+    }
+    // ---- ring push (src/hydro_forces.cpp:559-574) ----
+    if (a.do_radiation) {
+        if (tid == 0) a.ring_t[a.head] = a.t;
+        double* slot = a.ring_v + (size_t)a.head * a.D;
+        for (int c = tid; c < a.D; c += blockDim.x) slot[c] = state_velocity(a.state, a.N, c);
+    }
+}
+
+void launch_prep(const PrepArgs& a, hipStream_t stream) {
+    const int nrad = a.do_radiation ? a.S : 0;
+    const int nexc = a.do_excitation ? (a.L + 255) / 256 : 0;
+    hipLaunchKernelGGL(prep_kernel, dim3(nrad + nexc + 1), dim3(256), 0, stream, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_kernel<R>: the dominant kernel.  HBM-bound FP64 GEMV, 0.25 flop/B.
+//   grid   = nrowtiles * (nchunks_rad + nchunks_ex) workgroups of 4 waves
+//   each lane streams 16-byte pieces of R rows (R independent global_load_dwordx4 in flight per column block,
+//   straight to VGPRs -- no LDS round trip for data that is used once), multiplies with the matching pair of u
+//   (L2-resident, re-used by all row tiles) and keeps R FP64 accumulators; a wave64 xor-shuffle tree and a
+//   4-entry LDS step reduce them in a FIXED order, so results are bitwise reproducible run to run.
+// ------------------------------------------------------------------------------------------------
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+template <int R>
+__global__ void __launch_bounds__(kConvThreads) conv_kernel(ConvArgs a) {
+    const int nct   = a.nchunks_rad + a.nchunks_ex;
+    const int chunk = blockIdx.x % nct;
+    const int rt    = blockIdx.x / nct;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const double* __restrict__ M;
+    const double* __restrict__ x;
+    size_t ld;
+    int c0, c1;
+    if (chunk < a.nchunks_rad) {
+        M = a.K; x = a.u; ld = a.ldk;
+        c0 = chunk * a.chunk_cols;
+        c1 = min(a.F, c0 + a.chunk_cols);
+    } else {
+        M = a.Kex; x = a.e; ld = a.ldkex;
+        c0 = (chunk - a.nchunks_rad) * a.chunk_cols_ex;
+        c1 = min(a.Lpad, c0 + a.chunk_cols_ex);
+    }
+    const double* __restrict__ rows = M + (size_t)(rt * R) * ld;
+
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+
+#pragma unroll 2
+    for (int col = c0 + 2 * tid; col < c1; col += 2 * kConvThreads) {
+        const dvec2 xv = *reinterpret_cast<const dvec2*>(x + col);
+        dvec2 kv[R];
+        // K is streamed exactly once per step: non-temporal loads keep it from evicting u / the ring from L2
+#pragma unroll
+        for (int r = 0; r < R; ++r) kv[r] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(rows + (size_t)r * ld + col));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r] = fma(kv[r].x, xv.x, acc[r]);
+            acc[r] = fma(kv[r].y, xv.y, acc[r]);
+        }
+    }
+
+    __shared__ double red[kConvThreads / kWave][R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double s = wave_sum(acc[r]);
+        if (lane == 0) red[wave][r] = s;
+    }
+    __syncthreads();
+    if (tid < R) a.partials[(size_t)chunk * a.Dloc + rt * R + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+void launch_conv(const ConvArgs& a, int rows_per_tile, hipStream_t stream) {
+    const int nblocks = a.nrowtiles * (a.nchunks_rad + a.nchunks_ex);
+    if (nblocks <= 0) return;
+    if (rows_per_tile == 12)
+        hipLaunchKernelGGL(conv_kernel<12>, dim3(nblocks), dim3(kConvThreads), 0, stream, a);
+    else
+        hipLaunchKernelGGL(conv_kernel<6>, dim3(nblocks), dim3(kConvThreads), 0, stream, a);
+}
+
+const char* conv_kernel_name() { return "conv_kernel"; }
+
+// ------------------------------------------------------------------------------------------------
+// finalize_kernel: one thread per owned output row.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.Dloc) return;
+    const int bl = row / 6, i = row - 6 * bl;  // local body, DoF
+    const int b  = a.b0 + bl;                  // global body
+
+    double rad = 0.0, wav = 0.0, hs = 0.0;
+    if (a.do_rad)
+        for (int c = 0; c < a.nchunks_rad; ++c) rad += a.partials[(size_t)c * a.Dloc + row];
+    if (a.do_waves) {
+        if (a.wave_mode == 2) {
+            for (int c = 0; c < a.nchunks_ex; ++c) wav += a.partials[(size_t)(a.nchunks_rad + c) * a.Dloc + row];
+        } else if (a.wave_mode == 1) {
+            // RegularWave::GetForceAtTime (src/wave_types.cpp:315-327)
+            wav = a.reg_mag[row] * a.reg_amplitude * cos(a.reg_omega * a.t + a.reg_phase[i]);
+        }
+    }
+    if (a.do_hs) {
+        // ComputeForceHydrostatics (src/hydro_forces.cpp:263-322)
+        const double* pos = a.state + 3 * b;
+        const double* rpy = a.state + 3 * a.N + 3 * b;
+        const double* cg  = a.cg + 3 * bl;
+        double dq[6];
+        dq[0] = pos[0] - cg[0]; dq[1] = pos[1] - cg[1]; dq[2] = pos[2] - cg[2];
+        dq[3] = rpy[0] - 0.0;   dq[4] = rpy[1] - 0.0;   dq[5] = rpy[2] - 0.0;  // equilibrium rotations are zero (:208-216)
+        const double* Krow = a.lin + 36 * bl + 6 * i;
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s += Krow[j] * dq[j];
+        const double glen = sqrt(a.gx * a.gx + a.gy * a.gy + a.gz * a.gz);
+        hs                = -(a.rho * glen) * s;
+        const double V    = a.disp_vol[bl];
+        const double fbx = a.rho * (-a.gx) * V, fby = a.rho * (-a.gy) * V, fbz = a.rho * (-a.gz) * V;
+        const double* r  = a.cb_m_cg + 3 * bl;
+        double add;
+        switch (i) {
+            case 0: add = fbx; break;
+            case 1: add = fby; break;
+            case 2: add = fbz; break;
+            case 3: add = r[1] * fbz - r[2] * fby; break;
+            case 4: add = r[2] * fbx - r[0] * fbz; break;
+            default: add = r[0] * fby - r[1] * fbx; break;
+        }
+        hs += add;
+    }
+    const double total = hs - rad + wav;  // src/hydro_forces.cpp:758-760
+    a.hs[row]    = hs;
+    a.rad[row]   = rad;
+    a.waves[row] = wav;
+    a.total[row] = total;
+    if (a.user_out) a.user_out[row] = total;
+}
+
+void launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(finalize_kernel, dim3((a.Dloc + 255) / 256), dim3(256), 0, stream, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// TaperedDirect preprocessing (TestHydro::EnsureProcessedRIRF, src/hydro_forces.cpp:385-535), once per
+// option change: per (row, col) series along s -> truncate, smooth (SG-5 / moving average), half-cosine taper.
+// Thread = one (row, col) series; consecutive threads = consecutive col -> coalesced for every s.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) taper_kernel(TaperArgs a) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)a.Dloc * a.D) return;
+    const int row = (int)(gid / a.D), col = (int)(gid % a.D);
+    const double* __restrict__ in = a.Kraw + (size_t)row * a.ldk + col;
+    double* __restrict__ out      = a.Kproc + (size_t)row * a.ldk + col;
+    const int E = a.effective_steps;
+    const size_t st = (size_t)a.D;  // stride between consecutive s
+    const double sg0 = -3.0 / 35.0, sg1 = 12.0 / 35.0, sg2 = 17.0 / 35.0;
+    const int taper_len = a.tc_end - a.tc_index;
+    for (int s = 0; s < E; ++s) {
+        double v;
+        if (a.smoothing == 1) {
+            const int half = a.window / 2;
+            const int lo = max(0, s - half), hi = min(E - 1, s + half);
+            double sum = 0.0;
+            for (int k = lo; k <= hi; ++k) sum += in[(size_t)k * st];
+            const int cnt = hi - lo + 1;
+            v = (cnt > 0) ? (sum / cnt) : in[(size_t)s * st];
+        } else if (E >= 5 && s >= 2 && s <= E - 3) {
+            v = sg0 * in[(size_t)(s - 2) * st] + sg1 * in[(size_t)(s - 1) * st] + sg2 * in[(size_t)s * st] +
+                sg1 * in[(size_t)(s + 1) * st] + sg0 * in[(size_t)(s + 2) * st];
+        } else {
+            v = in[(size_t)s * st];
+        }
+        if (s < a.tc_index) {
+        } else if (s < a.tc_end && taper_len > 0) {
+            const double tt = (double)(s - a.tc_index) / (double)taper_len;
+            const double w  = a.final_amplitude + (1.0 - a.final_amplitude) * 0.5 * (1.0 + cos(3.14159265358979323846 * tt));
+            v *= w;
+        } else {
+            v = 0.0;
+        }
+        out[(size_t)s * st] = v;
+    }
+    for (int s = max(E, 0); s < a.S; ++s) out[(size_t)s * st] = 0.0;
+}
+
+void launch_taper(const TaperArgs& a, hipStream_t stream) {
+    const size_t n = (size_t)a.Dloc * a.D;
+    hipLaunchKernelGGL(taper_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// eta(t) synthesis at init (GetEtaIrregularTimeSeries, src/wave_types.cpp:14-59 with x = 0, then the ramp of
+// :759-769).  Thread = one time sample; components are summed in index order like the reference loop.
+// amp/omega/phase are wave-uniform reads (scalar loads).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) eta_kernel(const double* __restrict__ t, int nt, const double* __restrict__ amp,
+                                                   const double* __restrict__ omega, const double* __restrict__ phase, int nf,
+                                                   double ramp, double* __restrict__ eta) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nt) return;
+    const double tj = t[j];
+    double acc = 0.0;
+    for (int i = 0; i < nf; ++i) acc += amp[i] * cos(0.0 - omega[i] * tj + phase[i]);
+    if (ramp > 0.0 && tj < ramp) {
+        if (tj <= 0.0) acc *= 0.0;
+        else acc *= tj / ramp;
+    }
+    eta[j] = acc;
+}
+
+void launch_eta_synthesis(const double* d_t, int nt, const double* d_amp, const double* d_omega, const double* d_phase, int nf,
+                          double ramp_duration, double* d_eta, hipStream_t stream) {
+    hipLaunchKernelGGL(eta_kernel, dim3((nt + 255) / 256), dim3(256), 0, stream, d_t, nt, d_amp, d_omega, d_phase, nf,
+                       ramp_duration, d_eta);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Added-mass product (ChLoadAddedMass::LoadIntLoadResidual_Mv, src/chloadaddedmass.cpp:55-70): one wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) added_mass_mv_kernel(const double* __restrict__ M, int rows, int cols,
+                                                             const double* __restrict__ w, double c, double* __restrict__ R) {
+    const int row  = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const double* __restrict__ m = M + (size_t)row * cols;
+    double acc = 0.0;
+    for (int j = lane; j < cols; j += kWave) acc = fma(m[j], w[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) R[row] += c * acc;
+}
+
+void launch_added_mass_mv(const double* d_M, int rows, int cols, const double* d_w, double c, double* d_R, hipStream_t stream) {
+    hipLaunchKernelGGL(added_mass_mv_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, d_M, rows, cols, d_w, c, d_R);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Synthetic radiation kernels generated in HBM (benchmark inputs):
+//   K[row][col][s] = a * exp(-tau_s / tau_d) * cos(om * tau_s),  tau_s = s*dt,
+//   (a, tau_d, om) = per-(row,col) draws of a counter-based splitmix64 stream; same-body blocks x10.
+// hydrochrono_amd/synthetic.py holds the identical formula for host-side generation.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline double u01(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+
+__global__ void __launch_bounds__(256) synth_rirf_kernel(double* __restrict__ K, size_t ldk, int Dloc, int D, int S, int row0, double dt,
+                                                          unsigned long long seed, double rho) {
+    const size_t n   = (size_t)Dloc * S * D;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    const int col = (int)(gid % D);
+    const int s   = (int)((gid / D) % S);
+    const int row = (int)(gid / ((size_t)D * S));
+    const int grow = row0 + row;
+    const uint64_t base = splitmix64(seed ^ (((uint64_t)grow << 32) | (uint64_t)col));
+    const double ua = u01(splitmix64(base + 1)), ud = u01(splitmix64(base + 2)), uo = u01(splitmix64(base + 3));
+    double amp   = (2.0 * ua - 1.0);
+    if (grow / 6 == col / 6) amp *= 10.0;
+    const double tau_d = 1.0 + 3.0 * ud;
+    const double om    = 0.5 + 2.5 * uo;
+    const double tau   = s * dt;
+    K[(size_t)row * ldk + (size_t)s * D + col] = (amp * exp(-tau / tau_d) * cos(om * tau)) * rho;
+}
+
+void launch_synth_rirf(double* d_K, size_t ldk, int Dloc, int D, int S, int row0, double dt, unsigned long long seed, double rho,
+                       hipStream_t stream) {
+    const size_t n = (size_t)Dloc * S * D;
+    hipLaunchKernelGGL(synth_rirf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_K, ldk, Dloc, D, S, row0, dt, seed, rho);
+}
+
+}  // namespace hc

@@ -1,0 +1,251 @@
+"""HydroForces -- Python mirror of the reference's `TestHydro` surface (include/hydroc/hydro_forces.h:164-285),
+implemented purely by calls into the C ABI (include/hydrochrono_amd.h).  No arithmetic happens here."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class HydroError(RuntimeError):
+    """A non-zero hc_status; .status holds it (1 = the reference throws std::runtime_error, 2 = std::out_of_range)."""
+
+    def __init__(self, status, message):
+        super().__init__(f"[hc_status={status}] {message}")
+        self.status = status
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(capi.c_double_p)
+
+
+def _arr(x, n=None):
+    a = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} values, got {a.size}")
+    return a
+
+
+class HydroForces:
+    def __init__(self, num_bodies, device=0, body_range=None):
+        self.lib = capi.load()
+        self.N = int(num_bodies)
+        self.D = 6 * self.N
+        self.b0, self.b1 = (0, self.N) if body_range is None else (int(body_range[0]), int(body_range[1]))
+        self.n_local = self.b1 - self.b0
+        self.D_local = 6 * self.n_local
+        ctx = C.c_void_p()
+        rc = self.lib.hc_create_sharded(self.N, self.b0, self.b1, int(device), C.byref(ctx))
+        if rc != capi.HC_OK:
+            raise HydroError(rc, self.lib.hc_last_error(None).decode())
+        self.ctx = ctx
+
+    # -- plumbing --
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.hc_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != capi.HC_OK:
+            raise HydroError(rc, self.lib.hc_last_error(self.ctx).decode())
+
+    # -- ingest (H5FileInfo::ReadH5Data) --
+    def load_bemio_h5(self, path):
+        self._chk(self.lib.hc_load_bemio_h5(self.ctx, str(path).encode()))
+
+    def set_simulation_parameters(self, rho, g, water_depth):
+        self._chk(self.lib.hc_set_simulation_parameters(self.ctx, rho, g, water_depth))
+
+    def set_body(self, b, disp_vol, cg, cb, lin, added_mass_inf, rirf_t, rirf_K):
+        cg, cb, lin = _arr(cg, 3), _arr(cb, 3), _arr(lin, 36)
+        A = _arr(added_mass_inf, 6 * self.D)
+        t = _arr(rirf_t)
+        K = _arr(rirf_K, 6 * self.D * t.size)
+        self._chk(self.lib.hc_set_body_properties(self.ctx, b, float(disp_vol), _dp(cg), _dp(cb)))
+        self._chk(self.lib.hc_set_hydrostatic_stiffness(self.ctx, b, _dp(lin)))
+        self._chk(self.lib.hc_set_added_mass_inf(self.ctx, b, _dp(A)))
+        self._chk(self.lib.hc_set_rirf(self.ctx, b, _dp(t), t.size, _dp(K)))
+
+    def set_body_excitation_rao(self, b, w, mag, phase):
+        w = _arr(w)
+        mag, phase = _arr(mag, 6 * w.size), _arr(phase, 6 * w.size)
+        self._chk(self.lib.hc_set_excitation_rao(self.ctx, b, _dp(w), w.size, _dp(mag), _dp(phase)))
+
+    def set_body_excitation_irf(self, b, t, f):
+        t = _arr(t)
+        f = _arr(f, 6 * t.size)
+        self._chk(self.lib.hc_set_excitation_irf(self.ctx, b, _dp(t), t.size, _dp(f)))
+
+    def synth_fill(self, seed, S, dt_rirf, n_exc=0, dt_exc=0.0):
+        self._chk(self.lib.hc_synth_fill(self.ctx, seed, S, dt_rirf, n_exc, dt_exc))
+
+    def finalize(self):
+        self._chk(self.lib.hc_finalize(self.ctx))
+
+    @classmethod
+    def from_case(cls, case, device=0, body_range=None):
+        """Build from a raw-array case dict (see tests/cases.py, hydrochrono_amd/synthetic.py)."""
+        h = cls(case["N"], device=device, body_range=body_range)
+        h.set_simulation_parameters(case["rho"], case["g"], case["water_depth"])
+        for b, bd in enumerate(case["bodies"]):
+            h.set_body(b, bd["disp_vol"], bd["cg"], bd["cb"], bd["lin"], bd["added_mass_inf"], bd["rirf_t"], bd["rirf_K"])
+            if "w" in bd:
+                h.set_body_excitation_rao(b, bd["w"], bd["ex_mag"], bd["ex_phase"])
+            if "ex_irf_t" in bd:
+                h.set_body_excitation_irf(b, bd["ex_irf_t"], bd["ex_irf_f"])
+        h.finalize()
+        if "g_sys" in case:
+            h.set_gravity(case["g_sys"])
+        return h
+
+    # -- configuration --
+    def set_gravity(self, g3):
+        g3 = _arr(g3, 3)
+        self._chk(self.lib.hc_set_gravity(self.ctx, _dp(g3)))
+
+    def add_waves_none(self, num_bodies=None):
+        self._chk(self.lib.hc_set_wave_none(self.ctx, self.N if num_bodies is None else int(num_bodies)))
+
+    def add_waves_regular(self, amplitude, omega, num_bodies=None):
+        self._chk(self.lib.hc_set_wave_regular(self.ctx, self.N if num_bodies is None else int(num_bodies), amplitude, omega))
+
+    def add_waves_irregular(self, simulation_dt, simulation_duration, ramp_duration=0.0, wave_height=0.0, wave_period=0.0,
+                            frequency_min=0.001, frequency_max=1.0, nfrequencies=0, peak_enhancement_factor=1.0,
+                            is_normalized=False, seed=1, num_bodies=None):
+        p = capi.IrregularWaveParams()
+        self.lib.hc_irregular_wave_params_default(C.byref(p))
+        p.num_bodies = self.N if num_bodies is None else int(num_bodies)
+        p.simulation_dt, p.simulation_duration, p.ramp_duration = simulation_dt, simulation_duration, ramp_duration
+        p.wave_height, p.wave_period = wave_height, wave_period
+        p.frequency_min, p.frequency_max, p.nfrequencies = frequency_min, frequency_max, nfrequencies
+        p.peak_enhancement_factor, p.is_normalized, p.seed = peak_enhancement_factor, int(is_normalized), int(seed)
+        self._chk(self.lib.hc_set_wave_irregular(self.ctx, C.byref(p)))
+
+    def set_convolution_mode(self, mode):
+        self._chk(self.lib.hc_set_convolution_mode(self.ctx, int(mode)))
+
+    def set_tapered_direct_options(self, smoothing=0, window_length=5, rirf_end_time=-1.0, taper_start_percent=0.8,
+                                   taper_end_percent=1.0, taper_final_amplitude=0.0):
+        o = capi.TaperedDirectOptions(int(smoothing), int(window_length), rirf_end_time, taper_start_percent,
+                                      taper_end_percent, taper_final_amplitude)
+        self._chk(self.lib.hc_set_tapered_direct_options(self.ctx, C.byref(o)))
+
+    # -- per step --
+    def step(self, t, pos, rpy, linvel, angvel):
+        n3 = 3 * self.N
+        a = [_arr(x, n3) for x in (pos, rpy, linvel, angvel)]
+        out = np.empty(self.D_local)
+        self._chk(self.lib.hc_step(self.ctx, float(t), _dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(a[3]), _dp(out)))
+        return out
+
+    def step_device(self, t, state_ptr, out_ptr, stream_ptr=None):
+        """state_ptr / out_ptr: integer device addresses (e.g. torch.Tensor.data_ptr())."""
+        self._chk(self.lib.hc_step_device(self.ctx, float(t), C.c_void_p(state_ptr), C.c_void_p(out_ptr),
+                                          C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def components(self):
+        hs, rad, wv = (np.empty(self.D_local) for _ in range(3))
+        self._chk(self.lib.hc_get_force_components(self.ctx, _dp(hs), _dp(rad), _dp(wv)))
+        return hs, rad, wv
+
+    def compute_radiation(self, t, linvel, angvel):
+        lv, av = _arr(linvel, 3 * self.N), _arr(angvel, 3 * self.N)
+        out = np.empty(self.D_local)
+        self._chk(self.lib.hc_compute_radiation(self.ctx, float(t), _dp(lv), _dp(av), _dp(out)))
+        return out
+
+    def compute_hydrostatics(self, pos, rpy):
+        p, r = _arr(pos, 3 * self.N), _arr(rpy, 3 * self.N)
+        out = np.empty(self.D_local)
+        self._chk(self.lib.hc_compute_hydrostatics(self.ctx, _dp(p), _dp(r), _dp(out)))
+        return out
+
+    def compute_waves(self, t):
+        out = np.empty(self.D_local)
+        self._chk(self.lib.hc_compute_waves(self.ctx, float(t), _dp(out)))
+        return out
+
+    def reset_history(self):
+        self._chk(self.lib.hc_reset_history(self.ctx))
+
+    def set_history(self, times_newest_first, vel):
+        t = _arr(times_newest_first)
+        v = _arr(vel, t.size * self.D)
+        self._chk(self.lib.hc_set_history(self.ctx, t.size, _dp(t), _dp(v)))
+
+    def get_history(self):
+        n = C.c_int()
+        self._chk(self.lib.hc_get_history(self.ctx, C.byref(n), None, None))
+        t, v = np.empty(n.value), np.empty((n.value, self.D))
+        self._chk(self.lib.hc_get_history(self.ctx, C.byref(n), _dp(t), _dp(v.reshape(-1))))
+        return t, v
+
+    # -- added mass (ChLoadAddedMass) --
+    def added_mass_matrix(self):
+        M = np.empty((self.D_local, self.D))
+        self._chk(self.lib.hc_added_mass_matrix(self.ctx, _dp(M.reshape(-1))))
+        return M
+
+    def added_mass_mv(self, R, w, c):
+        R = _arr(R).copy()
+        w = _arr(w)
+        self._chk(self.lib.hc_added_mass_mv(self.ctx, _dp(w), float(c), _dp(R), R.size))
+        return R
+
+    # -- introspection --
+    def sizes(self):
+        v = [C.c_int() for _ in range(8)]
+        self._chk(self.lib.hc_get_sizes(self.ctx, *[C.byref(x) for x in v]))
+        return dict(zip(("N", "n_local", "S", "L", "nf", "nt", "H", "Hcap"), (x.value for x in v)))
+
+    def enable_profiling(self, on=True):
+        self._chk(self.lib.hc_enable_profiling(self.ctx, int(on)))
+
+    def reset_profile(self):
+        self._chk(self.lib.hc_reset_profile(self.ctx))
+
+    def profile(self):
+        p = capi.ProfileStats()
+        self._chk(self.lib.hc_get_profile(self.ctx, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in capi.ProfileStats._fields_}
+
+    def rirf_width(self):
+        w = np.empty(self.sizes()["S"])
+        self._chk(self.lib.hc_get_rirf_width(self.ctx, _dp(w)))
+        return w
+
+    def rirf_effective(self):
+        S = self.sizes()["S"]
+        out = np.empty((self.D_local, self.D, S))
+        self._chk(self.lib.hc_get_rirf_effective(self.ctx, _dp(out.reshape(-1))))
+        return out
+
+    def irreg_irf(self, b=0):
+        L = self.sizes()["L"]
+        t, w, v = np.empty(L), np.empty(L), np.empty((6, L))
+        self._chk(self.lib.hc_get_excitation_irf_resampled(self.ctx, b, _dp(t), _dp(w), _dp(v.reshape(-1))))
+        return t, w, v
+
+    def irreg_spectrum(self):
+        nf = self.sizes()["nf"]
+        arrs = [np.empty(nf) for _ in range(5)]
+        self._chk(self.lib.hc_get_spectrum(self.ctx, *[_dp(a) for a in arrs]))
+        return dict(zip(("f", "S", "df", "phase", "k"), arrs))
+
+    def irreg_eta(self):
+        nt = self.sizes()["nt"]
+        t, e = np.empty(nt), np.empty(nt)
+        self._chk(self.lib.hc_get_eta_table(self.ctx, _dp(t), _dp(e)))
+        return t, e
+
+    def regular_coeffs(self):
+        mag, ph, k = np.empty(self.D), np.empty(self.D), C.c_double()
+        self._chk(self.lib.hc_get_regular_coeffs(self.ctx, _dp(mag), _dp(ph), C.byref(k)))
+        return mag, ph, k.value

@@ -1,0 +1,218 @@
+/* hydrochrono_amd.h -- C ABI of the MI355X-native HydroChrono hydro-force path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each entry point names
+ * the reference interface (file:line relative to the HydroChrono tree @2025-10-31) it replaces.
+ * INTEGRATION.md shows the Chrono-side binding (ChFunction / ChLoadCustomMultiple subclasses) that
+ * forwards to these calls; hydrochrono_amd/csrc/hydro_forces_amd.hpp is that binding.
+ *
+ * Conventions
+ *   N   = number of hydro bodies of the whole system, D = 6N degrees of freedom.
+ *   A context may own only the output rows of bodies [body_begin, body_end) (multi-GPU row sharding,
+ *   SURVEY 8e); n_local = body_end - body_begin, D_local = 6*n_local.  Per-step INPUTS are always
+ *   the full N-body state, per-step OUTPUTS have D_local entries.
+ *   All arrays are IEEE double, row-major ("file order" of the BEMIO HDF5 datasets) unless stated.
+ *   Every function returns an hc_status; hc_last_error() holds the message of the last failure.
+ *   One host thread drives a context (same contract as TestHydro: its per-time cache is
+ *   unsynchronised, src/hydro_forces.cpp:742-748).
+ *   The library computes on the GPU only.  There is no CPU fallback: hc_create fails with
+ *   HC_ERR_DEVICE when no gfx950 device is usable.
+ */
+#ifndef HYDROCHRONO_AMD_H
+#define HYDROCHRONO_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hc_ctx hc_ctx;
+
+typedef enum hc_status {
+    HC_OK               = 0,
+    HC_ERR_RUNTIME      = 1, /* the reference throws std::runtime_error here */
+    HC_ERR_OUT_OF_RANGE = 2, /* the reference throws std::out_of_range here  */
+    HC_ERR_INVALID      = 3, /* bad argument / call order                     */
+    HC_ERR_DEVICE       = 4, /* HIP runtime failure or no usable GPU         */
+    HC_ERR_UNSUPPORTED  = 5  /* optional component not built (e.g. HDF5)      */
+} hc_status;
+
+/* ------------------------------------------------------------------------------------------------
+ * Lifecycle.  Replaces TestHydro::TestHydro / ~TestHydro (src/hydro_forces.cpp:170-242).
+ * ---------------------------------------------------------------------------------------------- */
+const char* hc_version(void);
+int hc_device_count(void); /* number of visible HIP devices; does not initialise a context */
+int hc_create(int num_bodies, int device_id, hc_ctx** out);
+/* Row-sharded context: owns output rows of bodies [body_begin, body_end) only. */
+int hc_create_sharded(int num_bodies, int body_begin, int body_end, int device_id, hc_ctx** out);
+void hc_destroy(hc_ctx* ctx);
+const char* hc_last_error(const hc_ctx* ctx); /* ctx may be NULL: error of the last failed hc_create */
+
+/* ------------------------------------------------------------------------------------------------
+ * Ingest.  Replaces H5FileInfo::ReadH5Data (src/h5fileinfo.cpp:27-180); the raw-array setters take
+ * exactly the datasets it reads, UNSCALED (the rho / rho*g scaling of :60-61,73-75,89-90 is applied
+ * inside), so tests need no HDF5.
+ * ---------------------------------------------------------------------------------------------- */
+/* simulation_parameters/{rho,g,water_depth}  (src/h5fileinfo.cpp:35-37; "infinite" -> +inf, :207-220) */
+int hc_set_simulation_parameters(hc_ctx* ctx, double rho, double g, double water_depth);
+/* bodyK/properties/{disp_vol,cg,cb}  (:48,56-57) */
+int hc_set_body_properties(hc_ctx* ctx, int body, double disp_vol, const double cg[3], const double cb[3]);
+/* bodyK/hydro_coeffs/linear_restoring_stiffness {6,6}  (:58-59) */
+int hc_set_hydrostatic_stiffness(hc_ctx* ctx, int body, const double lin[36]);
+/* bodyK/hydro_coeffs/added_mass/inf_freq {6,D}  (:60-61) */
+int hc_set_added_mass_inf(hc_ctx* ctx, int body, const double* A_6xD);
+/* bodyK/hydro_coeffs/radiation_damping/impulse_response_fun/{t,K}; K is {6,D,S} (:49-50,62-63).
+ * All bodies must carry the same t within 1e-10 (HydroData::GetRIRFTimeVector, :329-343). */
+int hc_set_rirf(hc_ctx* ctx, int body, const double* t, int S, const double* K_6xDxS);
+/* simulation_parameters/w and bodyK/hydro_coeffs/excitation/{mag,phase} {6,1,nw}  (:68-78) */
+int hc_set_excitation_rao(hc_ctx* ctx, int body, const double* w, int nw, const double* mag_6x1xnw,
+                          const double* phase_6x1xnw);
+/* bodyK/hydro_coeffs/excitation/impulse_response_fun/{t,f}; f is {6,1,n}  (:83-90) */
+int hc_set_excitation_irf(hc_ctx* ctx, int body, const double* t, int n, const double* f_6x1xn);
+/* Reads all of the above for bodies "body1".."bodyN" from a BEMIO HDF5 file (needs libhdf5 at build
+ * time, else HC_ERR_UNSUPPORTED). */
+int hc_load_bemio_h5(hc_ctx* ctx, const char* path);
+/* End of ingest = rest of the TestHydro constructor (src/hydro_forces.cpp:176-238): trapezoid widths,
+ * equilibrium, cb-cg, K re-laid-out into HBM, added-mass assembly (src/chloadaddedmass.cpp:12-25),
+ * default NoWave. */
+int hc_finalize(hc_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Configuration.
+ * ---------------------------------------------------------------------------------------------- */
+/* ChSystem::GetGravitationalAcceleration(), read by ComputeForceHydrostatics (src/hydro_forces.cpp:268).
+ * Default (0,0,-9.81). */
+int hc_set_gravity(hc_ctx* ctx, const double g[3]);
+/* TestHydro::AddWaves(std::make_shared<NoWave>(num_bodies_arg))  (src/hydro_forces.cpp:244-261,
+ * src/wave_types.cpp:257-264).  num_bodies_arg < N reproduces the reference's short force vector as an
+ * error (HC_ERR_RUNTIME at the first step) instead of an out-of-bounds read. */
+int hc_set_wave_none(hc_ctx* ctx, int num_bodies_arg);
+/* AddWaves(RegularWave(num_bodies_arg)) with regular_wave_amplitude_/regular_wave_omega_
+ * (src/wave_types.cpp:274-352). */
+int hc_set_wave_regular(hc_ctx* ctx, int num_bodies_arg, double amplitude, double omega);
+
+/* IrregularWaveParams (include/hydroc/wave_types.h:277-292); eta_file_path_ is not supported (that
+ * reference branch is undefined behaviour), wave_stretching_ does not affect forces. */
+typedef struct hc_irregular_wave_params {
+    int num_bodies;
+    double simulation_dt;
+    double simulation_duration;
+    double ramp_duration;
+    double wave_height;
+    double wave_period;
+    double frequency_min;           /* default 0.001 */
+    double frequency_max;           /* default 1.0   */
+    double nfrequencies;            /* 0 = ceil((fmax-fmin)*duration) */
+    double peak_enhancement_factor; /* 1.0 = Pierson-Moskowitz */
+    int is_normalized;
+    int seed;                       /* default 1 */
+} hc_irregular_wave_params;
+void hc_irregular_wave_params_default(hc_irregular_wave_params* p);
+/* AddWaves(IrregularWaves(params)): excitation-IRF resampling, spectrum, phases, eta(t) table
+ * (src/wave_types.cpp:432-459,572-606,643-676,717-774). */
+int hc_set_wave_irregular(hc_ctx* ctx, const hc_irregular_wave_params* params);
+
+/* TestHydro::SetRadiationConvolutionMode: 0 = Baseline, 1 = TaperedDirect (include/hydroc/hydro_forces.h:234-243) */
+int hc_set_convolution_mode(hc_ctx* ctx, int mode);
+/* TestHydro::TaperedDirectOptions (include/hydroc/hydro_forces.h:246-259) */
+typedef struct hc_tapered_direct_options {
+    int smoothing;                /* 0 = "sg" (Savitzky-Golay 5), 1 = "moving_average" */
+    int window_length;            /* moving average only, >= 3 */
+    double rirf_end_time;         /* <= 0: full length */
+    double taper_start_percent;   /* 0.8 */
+    double taper_end_percent;     /* 1.0 */
+    double taper_final_amplitude; /* 0.0 */
+} hc_tapered_direct_options;
+void hc_tapered_direct_options_default(hc_tapered_direct_options* o);
+int hc_set_tapered_direct_options(hc_ctx* ctx, const hc_tapered_direct_options* opts);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-step force evaluation.  Replaces the 6N ComponentFunc::GetVal -> ForceFunc6d::CoordinateFunc ->
+ * TestHydro::CoordinateFuncForBody callbacks of one Chrono update (src/hydro_forces.cpp:79-85,136-144,
+ * 727-767): total = hydrostatic - radiation + waves, evaluated once per distinct time `t` and cached.
+ *   pos     [N][3]  ChBody::GetPos()
+ *   rpy     [N][3]  ChBody::GetRot().GetCardanAnglesXYZ()
+ *   linvel  [N][3]  ChBody::GetPosDt()
+ *   angvel  [N][3]  ChBody::GetAngVelParent()
+ *   force_out [D_local] world-frame force (x,y,z) and torque (x,y,z) per owned body.
+ * Errors kept from the reference: excitation window exceeded (src/wave_types.cpp:833-840) -> HC_ERR_RUNTIME.
+ * ---------------------------------------------------------------------------------------------- */
+int hc_step(hc_ctx* ctx, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel,
+            double* force_out);
+/* Same evaluation with the body state already in HBM and the result left in HBM:
+ *   d_state     device pointer, 12N doubles = pos[3N] | rpy[3N] | linvel[3N] | angvel[3N]
+ *   d_force_out device pointer, D_local doubles
+ *   stream      hipStream_t (NULL = the context's own stream).  Asynchronous: returns after enqueue. */
+int hc_step_device(hc_ctx* ctx, double t, const double* d_state, double* d_force_out, void* stream);
+/* force_hydrostatic_, force_radiation_damping_, force_waves_ of the last evaluated step (D_local each;
+ * any pointer may be NULL).  Synchronises the context's stream. */
+int hc_get_force_components(hc_ctx* ctx, double* hydrostatic, double* radiation, double* waves);
+/* TestHydro::ComputeForceRadiationDampingConv called directly (src/hydro_forces.cpp:537-691): pushes
+ * (t, velocities) into the history and returns the radiation term only.  Calling it twice with the
+ * same t is the reference's duplicate-time error (:555-557) -> HC_ERR_RUNTIME. */
+int hc_compute_radiation(hc_ctx* ctx, double t, const double* linvel, const double* angvel, double* rad_out);
+/* TestHydro::ComputeForceHydrostatics (:263-322) and ComputeForceWaves (:713-725) on their own. */
+int hc_compute_hydrostatics(hc_ctx* ctx, const double* pos, const double* rpy, double* hs_out);
+int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
+/* Forget the velocity history and the per-time cache (fresh TestHydro state). */
+int hc_reset_history(hc_ctx* ctx);
+/* Injects a history as if those steps had been evaluated (times newest first, vel [n][D]); used to start
+ * benchmarks in the steady state.  The only cross-step state of the path is this history plus the cached
+ * time (checkpoint/resume). */
+int hc_set_history(hc_ctx* ctx, int n, const double* times_newest_first, const double* vel_nxD);
+int hc_get_history(hc_ctx* ctx, int* n, double* times_newest_first, double* vel_nxD); /* NULL arrays: size query */
+
+/* ------------------------------------------------------------------------------------------------
+ * Added mass.  Replaces ChLoadAddedMass (src/chloadaddedmass.cpp:12-70).
+ * ---------------------------------------------------------------------------------------------- */
+/* infinite_added_mass: D_local x D row-major, rho-scaled -- what ComputeJacobian puts top-left in M (:27-44) */
+int hc_added_mass_matrix(hc_ctx* ctx, double* M_DlocalxD);
+/* LoadIntLoadResidual_Mv: R[row0 + i] += c * sum_j M[i][j] * w[j], i < D_local (:55-70); w has >= D entries,
+ * R has n_sys entries (n_sys >= D), row0 = 6*body_begin. */
+int hc_added_mass_mv(hc_ctx* ctx, const double* w, double c, double* R_inout, int n_sys);
+
+/* ------------------------------------------------------------------------------------------------
+ * Introspection (exporter / diagnostics parity).
+ * ---------------------------------------------------------------------------------------------- */
+/* HydroProfileStats (include/hydroc/hydro_forces.h:153-160), filled from HIP events; *_seconds are GPU
+ * time of the kernels of each term.  conv_kernel_* describe the radiation GEMV kernel alone. */
+typedef struct hc_profile_stats {
+    double hydrostatics_seconds, radiation_seconds, waves_seconds;
+    int hydrostatics_calls, radiation_calls, waves_calls;
+    double conv_kernel_seconds; /* sum of HIP-event durations of the convolution kernel */
+    long long conv_kernel_launches;
+    double conv_kernel_bytes;   /* algorithmic bytes one launch streams (8*D_local*D*S + vectors) */
+} hc_profile_stats;
+int hc_enable_profiling(hc_ctx* ctx, int on); /* HIP events around each kernel; off by default */
+int hc_get_profile(hc_ctx* ctx, hc_profile_stats* out);
+int hc_reset_profile(hc_ctx* ctx);
+
+/* Sizes: S radiation samples, L resampled excitation samples, nf wave components, nt eta samples,
+ * H current history length, Hcap ring capacity. Any pointer may be NULL. */
+int hc_get_sizes(hc_ctx* ctx, int* N, int* n_local, int* S, int* L, int* nf, int* nt, int* H, int* Hcap);
+/* rirf_width_vector (src/hydro_forces.cpp:181-190) */
+int hc_get_rirf_width(hc_ctx* ctx, double* w_S);
+/* The kernel actually convolved, mapped back to reference indexing: value = GetRIRFval(row, col, s)
+ * (src/hydro_forces.cpp:693-711), i.e. rho-scaled and, in TaperedDirect mode, processed (:385-535).
+ * rows are local; out is [D_local][D][S].  Meant for small cases. */
+int hc_get_rirf_effective(hc_ctx* ctx, double* out_DlocalxDxS);
+/* ex_irf_time_sampled_, ex_irf_width_sampled_, ex_irf_sampled_ (6 x L) of a local body (src/wave_types.cpp:572-628) */
+int hc_get_excitation_irf_resampled(hc_ctx* ctx, int body, double* t_L, double* width_L, double* vals_6xL);
+/* spectrum_frequencies_, spectral_densities_, spectral_widths_, wave_phases_, wavenumbers_ (:643-676) */
+int hc_get_spectrum(hc_ctx* ctx, double* f, double* S, double* df, double* phase, double* k);
+/* free_surface_time_sampled_ / free_surface_elevation_sampled_ (:717-774; exporter: runner:668-679) */
+int hc_get_eta_table(hc_ctx* ctx, double* t_nt, double* eta_nt);
+/* RegularWave::excitation_force_mag_/phase_ and wavenumber_ (:278-299) */
+int hc_get_regular_coeffs(hc_ctx* ctx, double* mag_D, double* phase_D, double* wavenumber);
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic many-body inputs generated directly in HBM (benchmark configurations C3/C4 of SURVEY 8d;
+ * not part of the reference).  Fills K, K_hs, A_inf, excitation IRF for all local bodies from a
+ * counter-based generator so that a 77 GB kernel never exists on the host.  hc_finalize still applies.
+ * ---------------------------------------------------------------------------------------------- */
+int hc_synth_fill(hc_ctx* ctx, unsigned long long seed, int S, double dt_rirf, int n_exc, double dt_exc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYDROCHRONO_AMD_H */

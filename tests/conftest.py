@@ -12,3 +12,20 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+def _gpu_available():
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container (run on the MI355X box with -m gpu)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

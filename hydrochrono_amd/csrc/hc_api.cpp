@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -141,7 +142,15 @@ void choose_conv_config(hc_ctx* c) {
     c->nrowtiles     = c->Dloc / c->rows_per_tile;
     const long long F = static_cast<long long>(c->S) * c->D;
     // aim for >= 8 workgroups per CU (256 CUs); a chunk is a multiple of 512 columns (one pass of 256 lanes x 2)
-    const int target_wgs = 4096;
+    int target_wgs = 4096;
+    if (const char* e = std::getenv("HC_CONV_TARGET_WGS")) target_wgs = std::max(1, std::atoi(e));  // tuning experiments only
+    if (const char* e = std::getenv("HC_CONV_ROWS")) {
+        const int r = std::atoi(e);
+        if ((r == 6 || r == 12) && c->Dloc % r == 0) {
+            c->rows_per_tile = r;
+            c->nrowtiles     = c->Dloc / r;
+        }
+    }
     long long nch        = std::max<long long>(1, target_wgs / std::max(1, c->nrowtiles));
     long long cols       = (F + nch - 1) / nch;
     cols                 = std::max<long long>(512, ((cols + 511) / 512) * 512);
@@ -249,6 +258,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     p.head          = c->head;
     p.H             = H;
     p.Hcap          = c->Hcap;
+    p.dt_hint       = (H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
     p.u             = c->d_u.p;
     p.do_radiation  = f.rad ? 1 : 0;
     p.L             = c->L;

@@ -87,8 +87,19 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs a) {
         const int s    = bid;
         const double q = a.t - a.tau[s];
         auto hist_time = [&](int k) -> double { return k == 0 ? a.t : a.ring_t[(a.head - k + a.Hcap) % a.Hcap]; };
-        // smallest i in [0, H-2] with time(i+1) <= q ; none -> no older sample -> contributes nothing
+        // smallest i in [0, H-2] with time(i+1) <= q ; none (i == H-1) -> no older sample -> contributes nothing.
+        // Histories are close to uniformly spaced, so first try the index the previous step size predicts
+        // (2-3 dependent loads); any miss falls back to the full binary search.
         int lo = 0, hi = a.H - 1;
+        if (a.H >= 3) {
+            int gi = (int)((a.t - q) / a.dt_hint) - 1;
+            gi     = max(0, min(gi, a.H - 2));
+#pragma unroll 1
+            for (int k = 0; k < 3; ++k, ++gi) {
+                if (gi > a.H - 2) break;
+                if (hist_time(gi + 1) <= q && (gi == 0 || hist_time(gi) > q)) { lo = hi = gi; break; }
+            }
+        }
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (hist_time(mid + 1) <= q) hi = mid; else lo = mid + 1;
@@ -245,24 +256,39 @@ void launch_conv(const ConvArgs& a, int rows_per_tile, hipStream_t stream) {
 const char* conv_kernel_name() { return "conv_kernel"; }
 
 // ------------------------------------------------------------------------------------------------
-// finalize_kernel: one thread per owned output row.
+// finalize_kernel: 16 lanes per owned output row (16 rows per 256-thread workgroup).  Lane l adds the partials of
+// chunks l, l+16, ... in ascending order, a 4-step xor-shuffle tree adds the 16 lane sums -- a fixed order, so the
+// result is bitwise reproducible -- then lane 0 of the row adds hydrostatics / the regular-wave term and writes.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane16_sum(double v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 16);
+    return v;
+}
+
 __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= a.Dloc) return;
+    const int sub = threadIdx.x & 15;
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = row < a.Dloc;
+    const int rrow  = live ? row : 0;
+
+    double rad = 0.0, wav = 0.0;
+    if (a.do_rad) {
+        for (int c = sub; c < a.nchunks_rad; c += 16) rad += a.partials[(size_t)c * a.Dloc + rrow];
+        rad = lane16_sum(rad);
+    }
+    if (a.do_waves && a.wave_mode == 2) {
+        for (int c = sub; c < a.nchunks_ex; c += 16) wav += a.partials[(size_t)(a.nchunks_rad + c) * a.Dloc + rrow];
+        wav = lane16_sum(wav);
+    }
+    if (!live || sub != 0) return;
+
     const int bl = row / 6, i = row - 6 * bl;  // local body, DoF
     const int b  = a.b0 + bl;                  // global body
-
-    double rad = 0.0, wav = 0.0, hs = 0.0;
-    if (a.do_rad)
-        for (int c = 0; c < a.nchunks_rad; ++c) rad += a.partials[(size_t)c * a.Dloc + row];
-    if (a.do_waves) {
-        if (a.wave_mode == 2) {
-            for (int c = 0; c < a.nchunks_ex; ++c) wav += a.partials[(size_t)(a.nchunks_rad + c) * a.Dloc + row];
-        } else if (a.wave_mode == 1) {
-            // RegularWave::GetForceAtTime (src/wave_types.cpp:315-327)
-            wav = a.reg_mag[row] * a.reg_amplitude * cos(a.reg_omega * a.t + a.reg_phase[i]);
-        }
+    double hs = 0.0;
+    if (a.do_waves && a.wave_mode == 1) {
+        // RegularWave::GetForceAtTime (src/wave_types.cpp:315-327)
+        wav = a.reg_mag[row] * a.reg_amplitude * cos(a.reg_omega * a.t + a.reg_phase[i]);
     }
     if (a.do_hs) {
         // ComputeForceHydrostatics (src/hydro_forces.cpp:263-322)
@@ -301,7 +327,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 }
 
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(finalize_kernel, dim3((a.Dloc + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(finalize_kernel, dim3((a.Dloc + 15) / 16), dim3(256), 0, stream, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -23,6 +23,7 @@ struct PrepArgs {
     double* ring_t;
     double* ring_v;
     int head, H, Hcap;    // H counts the current sample
+    double dt_hint;       // t - previous sample time (search hint only, > 0)
     double* u;            // [S*D] out: interpolated velocity * width  (0 where no bracket exists)
     int do_radiation;
     // excitation side (irregular waves)

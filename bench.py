@@ -9,10 +9,14 @@ sea state with 512 wave components, prescribed body motion with dt = dt_rirf = 0
 pre-filled over the whole 10.23 s IRF window).  A "step" = one evaluation of all 6N hydrodynamic forces
 (hydrostatic - radiation + waves) through hc_step_device, body states already resident in HBM.
 
-Multi-GPU (weak scaling): every rank owns one independent 64-body farm (a block-diagonal 64*G-body array whose
-cross-farm coupling blocks are structurally zero); after each step the per-farm force vectors are all-gathered
+Multi-GPU, default (weak scaling): every rank owns one independent 64-body farm (a block-diagonal 64*G-body array
+whose cross-farm coupling blocks are structurally zero); after each step the per-farm force vectors are all-gathered
 over RCCL so every rank holds the full 6*64*G vector a host integrator needs -- the single exchange step of the
 path.  value = farms * K / max-over-ranks time.
+
+--scaling strong --bodies 512 is configuration C4: ONE coupled 512-body array (K = 77.3 GB FP64, generated in HBM by
+hc_synth_fill) row-sharded over the ranks (hydrochrono_amd.parallel.body_shard), forces all-gathered every step;
+value = K / time.  It also runs on one GPU (77 GB fits in 288 GB).
 
 The JSON line also carries
   roofline      HBM roofline of the convolution kernel: algorithmic bytes per launch / mean HIP-event duration
@@ -46,6 +50,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--bodies", type=int, default=N_BODIES, help="bodies per GPU (default: the C3 configuration)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline time budget")
     return ap.parse_args()
@@ -104,12 +109,27 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    from hydrochrono_amd.parallel import ForceExchange, body_shard
+    strong = args.scaling == "strong"
     N = args.bodies
     D = 6 * N
-    case = many_body_case(N, S=S_RIRF, dt_rirf=DT, n_exc=N_EXC, dt_exc=DT, seed=20251031 + rank)
-    gpu = HydroForces.from_case(case, device=local_rank)
-    gpu.add_waves_irregular(**WAVES)
-    motion = PrescribedMotion(N, rest_positions(case), seed=20251031 + rank)
+    case = None
+    if strong:
+        # one coupled N-body array, this rank owns the output rows of bodies [b0, b1); inputs generated in HBM
+        b0, b1 = body_shard(N, world, rank)
+        gpu = HydroForces(N, device=local_rank, body_range=(b0, b1))
+        gpu.synth_fill(20251031, S_RIRF, DT, N_EXC, DT)
+        gpu.finalize()
+        motion = PrescribedMotion(N, np.zeros((N, 3)), seed=20251031)
+        exchange = ForceExchange(N, world, rank, device="cuda")
+    else:
+        case = many_body_case(N, S=S_RIRF, dt_rirf=DT, n_exc=N_EXC, dt_exc=DT, seed=20251031 + rank)
+        gpu = HydroForces.from_case(case, device=local_rank)
+        motion = PrescribedMotion(N, rest_positions(case), seed=20251031 + rank)
+        exchange = ForceExchange(N * world, world, rank, device="cuda")  # farms concatenated
+    waves = dict(WAVES, num_bodies=N)
+    gpu.add_waves_irregular(**waves)
+    D_local = gpu.D_local
 
     nhist = S_RIRF + 5
     t_hist = T0 - DT * np.arange(1, nhist + 1)
@@ -118,15 +138,17 @@ def main():
 
     total = args.warmup + args.steps
     states = torch.tensor(np.stack([motion.packed(T0 + k * DT) for k in range(total)]), device="cuda")
-    forces = torch.zeros(total, D, dtype=torch.float64, device="cuda")
-    gathered = torch.zeros(world * D, dtype=torch.float64, device="cuda") if world > 1 else None
+    forces = torch.zeros(total, D_local, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def run(k0, k1):
         for k in range(k0, k1):
-            gpu.step_device(T0 + k * DT, states[k].data_ptr(), forces[k].data_ptr(), stream)
             if world > 1:
-                dist.all_gather_into_tensor(gathered, forces[k])
+                # kernels write straight into the exchange's send buffer; every rank ends up with the full vector
+                gpu.step_device(T0 + k * DT, states[k].data_ptr(), exchange.send.data_ptr(), stream)
+                exchange.gather()
+            else:
+                gpu.step_device(T0 + k * DT, states[k].data_ptr(), forces[k].data_ptr(), stream)
 
     run(0, args.warmup)
     torch.cuda.synchronize()
@@ -161,23 +183,27 @@ def main():
                 traffic = None
         out = {
             "metric": "hydro-force evals/sec (all bodies)",
-            "value": world * args.steps / elapsed,
+            "value": (1 if strong else world) * args.steps / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"C3: synthetic {N}-body array per GPU, {S_RIRF} radiation-IRF samples, irregular JONSWAP "
+                "workload": (f"C4-style: ONE coupled synthetic {N}-body array row-sharded over {world} GPU(s), " if strong else
+                             f"C3: synthetic {N}-body array per GPU, ") +
+                            f"{S_RIRF} radiation-IRF samples, irregular JONSWAP "
                             f"waves with {WAVES['nfrequencies']} components (excitation-IRF convolution, L={gpu.sizes()['L']}), "
                             "prescribed motion, dt = dt_rirf = 0.01 s, steady-state history",
-                "bodies_per_gpu": N, "irf_samples": S_RIRF, "wave_components": WAVES["nfrequencies"],
-                "sharding": "one independent farm per GPU + RCCL all-gather of forces" if world > 1 else "single GPU",
+                "bodies": N, "bodies_per_gpu": (N / world if strong else N), "irf_samples": S_RIRF,
+                "wave_components": WAVES["nfrequencies"],
+                "sharding": ("body-row shards of one coupled array + RCCL all-gather of forces" if strong else
+                             "one independent farm per GPU + RCCL all-gather of forces") if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "kernel": "hc::conv_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -186,7 +212,7 @@ def main():
                 "launches_timed": prof["conv_kernel_launches"],
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and case is not None:
             base, f_cpu = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds)
             f_gpu = forces[0].cpu().numpy()  # step k = 0 is t = T0 on both sides
             out["cpu_baseline"] = base

@@ -86,6 +86,16 @@ SIGNATURES = {
     "hc_synth_fill": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_int, C.c_double, C.c_int, C.c_double]),
 }
 
+# include/hydrochrono_amd_host.h
+SIGNATURES.update({
+    "hc_host_linspaced": (None, [C.c_int, C.c_double, C.c_double, c_double_p]),
+    "hc_host_trapezoid_widths": (None, [c_double_p, C.c_int, c_double_p]),
+    "hc_host_jonswap_spectrum_hz": (None, [c_double_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, c_double_p]),
+    "hc_host_random_phases": (None, [C.c_int, C.c_int, c_double_p]),
+    "hc_host_wave_number": (C.c_double, [C.c_double, C.c_double, C.c_double]),
+    "hc_host_resample_irf": (C.c_int, [c_double_p, C.c_int, C.c_int, c_double_p]),
+})
+
 _lib = None
 
 

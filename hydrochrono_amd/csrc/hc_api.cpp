@@ -1188,3 +1188,45 @@ int hc_synth_fill(hc_ctx* c, unsigned long long seed, int S, double dt_rirf, int
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// include/hydrochrono_amd_host.h
+// =================================================================================================
+#include "../../include/hydrochrono_amd_host.h"
+
+extern "C" {
+
+void hc_host_linspaced(int n, double lo, double hi, double* out) {
+    const auto v = hc::linspaced(n, lo, hi);
+    std::copy(v.begin(), v.end(), out);
+}
+void hc_host_trapezoid_widths(const double* grid, int n, double* out) {
+    const auto v = hc::trapezoid_widths(std::vector<double>(grid, grid + n));
+    std::copy(v.begin(), v.end(), out);
+}
+void hc_host_jonswap_spectrum_hz(const double* f, int n, double Hs, double Tp, double gamma, int is_normalized, double* out) {
+    const auto v = hc::jonswap_spectrum_hz(std::vector<double>(f, f + n), Hs, Tp, gamma, is_normalized != 0);
+    std::copy(v.begin(), v.end(), out);
+}
+void hc_host_random_phases(int n, int seed, double* out) {
+    const auto v = hc::random_phases(n, seed);
+    std::copy(v.begin(), v.end(), out);
+}
+double hc_host_wave_number(double omega, double water_depth, double g) {
+    try {
+        return hc::wave_number(omega, water_depth, g);
+    } catch (...) {
+        return std::numeric_limits<double>::quiet_NaN();
+    }
+}
+int hc_host_resample_irf(const double* vals, int n_old, int n_new, double* out) {
+    try {
+        const auto v = hc::resample_cubic_bspline6(std::vector<double>(vals, vals + static_cast<size_t>(6) * n_old), n_old, n_new);
+        std::copy(v.begin(), v.end(), out);
+    } catch (...) {
+        return HC_ERR_RUNTIME;
+    }
+    return HC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,439 @@
+// hydro_forces_amd.hpp -- C++ host-side mirror of the reference's plugin surface over the C ABI
+// (include/hydrochrono_amd.h).  Header-only; link with libhydrochrono_amd.so.
+//
+// Same names, argument meaning and error behaviour as the reference for the hot path:
+//   WaveBase / NoWave / RegularWave / IrregularWaves(IrregularWaveParams)   include/hydroc/wave_types.h:52-467
+//   TestHydro(bodies, h5_file, waves), AddWaves, ComputeForce*, CoordinateFuncForBody, SetRadiationConvolutionMode,
+//   SetTaperedDirectOptions, GetProfileStats                               include/hydroc/hydro_forces.h:164-285
+//   ChLoadAddedMass::{ComputeJacobian, LoadIntLoadResidual_Mv}             include/hydroc/chloadaddedmass.h:22-90
+// C status codes are rethrown as the exception types the reference throws (std::runtime_error / std::out_of_range).
+//
+// Bodies are seen through the small `HydroBody` interface (name, time, pose, velocities) -- exactly the ChBody getters
+// the reference calls (src/hydro_forces.cpp:106-107,279-280,550,567-568).  `MockBody` implements it with plain fields
+// for drivers without Chrono; with Project Chrono on the include path (HYDROCHRONO_AMD_WITH_CHRONO or auto-detected)
+// `ChronoBody` wraps a chrono::ChBody and the ChFunction / ChForce / ChLoadCustomMultiple adapters at the bottom of
+// this file wire everything into a ChSystem the way the reference's ForceFunc6d / ChLoadAddedMass do.
+#pragma once
+
+#include <array>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/hydrochrono_amd.h"
+
+#if !defined(HYDROCHRONO_AMD_WITH_CHRONO) && defined(__has_include)
+#if __has_include(<chrono/physics/ChBody.h>)
+#define HYDROCHRONO_AMD_WITH_CHRONO 1
+#endif
+#endif
+
+namespace hydroc_amd {
+
+inline void check(hc_ctx* ctx, int rc) {
+    if (rc == HC_OK) return;
+    const std::string msg = hc_last_error(ctx);
+    if (rc == HC_ERR_OUT_OF_RANGE) throw std::out_of_range(msg);
+    throw std::runtime_error(msg);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Body view
+// ---------------------------------------------------------------------------------------------------------------
+struct HydroBody {
+    virtual ~HydroBody()                                   = default;
+    virtual std::string GetName() const                    = 0;  // "body<k>", 1-based (src/hydro_forces.cpp:106-107)
+    virtual double GetChTime() const                       = 0;
+    virtual std::array<double, 3> GetPos() const           = 0;
+    virtual std::array<double, 3> GetCardanAnglesXYZ() const = 0;  // GetRot().GetCardanAnglesXYZ()
+    virtual std::array<double, 3> GetPosDt() const         = 0;
+    virtual std::array<double, 3> GetAngVelParent() const  = 0;
+};
+
+struct MockBody : HydroBody {
+    std::string name;
+    double time = 0.0;
+    std::array<double, 3> pos{0, 0, 0}, rpy{0, 0, 0}, linvel{0, 0, 0}, angvel{0, 0, 0};
+    explicit MockBody(std::string n) : name(std::move(n)) {}
+    std::string GetName() const override { return name; }
+    double GetChTime() const override { return time; }
+    std::array<double, 3> GetPos() const override { return pos; }
+    std::array<double, 3> GetCardanAnglesXYZ() const override { return rpy; }
+    std::array<double, 3> GetPosDt() const override { return linvel; }
+    std::array<double, 3> GetAngVelParent() const override { return angvel; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave models (configuration holders; the arithmetic lives behind hc_set_wave_*)
+// ---------------------------------------------------------------------------------------------------------------
+enum class WaveMode { noWaveCIC = 0, regular = 1, irregular = 2 };
+
+class WaveBase {
+  public:
+    virtual ~WaveBase()             = default;
+    virtual WaveMode GetWaveMode()  = 0;
+    virtual void Attach(hc_ctx* ctx) = 0;  // AddH5Data + Initialize of the reference, executed by the library
+};
+
+class NoWave : public WaveBase {
+  public:
+    NoWave() : num_bodies_(1) {}
+    explicit NoWave(unsigned num_b) : num_bodies_(num_b) {}
+    WaveMode GetWaveMode() override { return WaveMode::noWaveCIC; }
+    void Attach(hc_ctx* ctx) override { check(ctx, hc_set_wave_none(ctx, static_cast<int>(num_bodies_))); }
+
+  private:
+    unsigned num_bodies_;
+};
+
+class RegularWave : public WaveBase {
+  public:
+    RegularWave() : num_bodies_(1) {}
+    explicit RegularWave(unsigned num_b) : num_bodies_(num_b) {}
+    WaveMode GetWaveMode() override { return WaveMode::regular; }
+    void Attach(hc_ctx* ctx) override {
+        check(ctx, hc_set_wave_regular(ctx, static_cast<int>(num_bodies_), regular_wave_amplitude_, regular_wave_omega_));
+    }
+    double regular_wave_amplitude_ = 0.0;
+    double regular_wave_omega_     = 0.0;
+    double regular_wave_phase_     = 0.0;  // unused by the force, as in the reference
+
+  private:
+    unsigned num_bodies_;
+};
+
+struct IrregularWaveParams {  // include/hydroc/wave_types.h:277-292
+    unsigned int num_bodies_        = 1;
+    double simulation_dt_           = 0.0;
+    double simulation_duration_     = 0.0;
+    double ramp_duration_           = 0.0;
+    std::string eta_file_path_;     // not supported (undefined behaviour in the reference)
+    double wave_height_             = 0.0;
+    double wave_period_             = 0.0;
+    double frequency_min_           = 0.001;
+    double frequency_max_           = 1.0;
+    double nfrequencies_            = 0;
+    double peak_enhancement_factor_ = 1.0;
+    bool is_normalized_             = false;
+    int seed_                       = 1;
+    bool wave_stretching_           = true;
+};
+
+class IrregularWaves : public WaveBase {
+  public:
+    explicit IrregularWaves(const IrregularWaveParams& params) : params_(params) {}
+    WaveMode GetWaveMode() override { return WaveMode::irregular; }
+    void Attach(hc_ctx* ctx) override {
+        if (!params_.eta_file_path_.empty()) throw std::runtime_error("eta_file_path_ is not supported by the GPU path");
+        hc_irregular_wave_params p;
+        hc_irregular_wave_params_default(&p);
+        p.num_bodies              = static_cast<int>(params_.num_bodies_);
+        p.simulation_dt           = params_.simulation_dt_;
+        p.simulation_duration     = params_.simulation_duration_;
+        p.ramp_duration           = params_.ramp_duration_;
+        p.wave_height             = params_.wave_height_;
+        p.wave_period             = params_.wave_period_;
+        p.frequency_min           = params_.frequency_min_;
+        p.frequency_max           = params_.frequency_max_;
+        p.nfrequencies            = params_.nfrequencies_;
+        p.peak_enhancement_factor = params_.peak_enhancement_factor_;
+        p.is_normalized           = params_.is_normalized_ ? 1 : 0;
+        p.seed                    = params_.seed_;
+        check(ctx, hc_set_wave_irregular(ctx, &p));
+        ctx_ = ctx;
+    }
+    // exporter inputs (src/wave_types.cpp:461-478)
+    std::vector<double> GetFreeSurfaceTime() const { return table(true); }
+    std::vector<double> GetFreeSurfaceElevation() const { return table(false); }
+    std::vector<double> GetFrequenciesHz() const {
+        int nf = 0;
+        check(ctx_, hc_get_sizes(ctx_, nullptr, nullptr, nullptr, nullptr, &nf, nullptr, nullptr, nullptr));
+        std::vector<double> f(nf);
+        check(ctx_, hc_get_spectrum(ctx_, f.data(), nullptr, nullptr, nullptr, nullptr));
+        return f;
+    }
+
+  private:
+    std::vector<double> table(bool time) const {
+        int nt = 0;
+        check(ctx_, hc_get_sizes(ctx_, nullptr, nullptr, nullptr, nullptr, nullptr, &nt, nullptr, nullptr));
+        std::vector<double> v(nt);
+        check(ctx_, time ? hc_get_eta_table(ctx_, v.data(), nullptr) : hc_get_eta_table(ctx_, nullptr, v.data()));
+        return v;
+    }
+    IrregularWaveParams params_;
+    hc_ctx* ctx_ = nullptr;
+};
+
+struct HydroProfileStats {  // include/hydroc/hydro_forces.h:153-160
+    double hydrostatics_seconds = 0.0, radiation_seconds = 0.0, waves_seconds = 0.0;
+    int hydrostatics_calls = 0, radiation_calls = 0, waves_calls = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// TestHydro
+// ---------------------------------------------------------------------------------------------------------------
+class TestHydro {
+  public:
+    TestHydro()                                = delete;
+    TestHydro(const TestHydro&)                = delete;
+    TestHydro& operator=(const TestHydro&)     = delete;
+
+    TestHydro(std::vector<std::shared_ptr<HydroBody>> user_bodies, const std::string& h5_file_name,
+              std::shared_ptr<WaveBase> waves = std::make_shared<NoWave>(), int device_id = 0)
+        : bodies_(std::move(user_bodies)), num_bodies_(static_cast<int>(bodies_.size())) {
+        if (bodies_.empty()) throw std::runtime_error("TestHydro needs at least one body");
+        // body numbers come from the names "body<k>", 1-based (ForceFunc6d ctor, src/hydro_forces.cpp:104-108)
+        for (auto& b : bodies_) {
+            std::string temp = b->GetName();
+            body_numbers_.push_back(std::stoi(temp.erase(0, 4)));
+        }
+        int rc = hc_create(num_bodies_, device_id, &ctx_);
+        if (rc != HC_OK) throw std::runtime_error(hc_last_error(nullptr));
+        try {
+            check(ctx_, hc_load_bemio_h5(ctx_, h5_file_name.c_str()));
+            check(ctx_, hc_finalize(ctx_));
+            AddWaves(std::move(waves));
+        } catch (...) {
+            hc_destroy(ctx_);
+            throw;
+        }
+        total_force_.assign(6 * num_bodies_, 0.0);
+    }
+    ~TestHydro() { hc_destroy(ctx_); }
+
+    void AddWaves(std::shared_ptr<WaveBase> waves) {  // src/hydro_forces.cpp:244-261
+        user_waves_ = std::move(waves);
+        user_waves_->Attach(ctx_);
+    }
+    std::shared_ptr<WaveBase> GetWave() const { return user_waves_; }
+    void SetGravitationalAcceleration(double gx, double gy, double gz) {  // ChSystem setting read at :268
+        const double g[3] = {gx, gy, gz};
+        check(ctx_, hc_set_gravity(ctx_, g));
+    }
+
+    enum class RadiationConvolutionMode { Baseline, TaperedDirect };
+    void SetRadiationConvolutionMode(RadiationConvolutionMode mode) {
+        check(ctx_, hc_set_convolution_mode(ctx_, mode == RadiationConvolutionMode::TaperedDirect ? 1 : 0));
+    }
+    struct TaperedDirectOptions {
+        std::string smoothing        = "sg";
+        int window_length            = 5;
+        double rirf_end_time         = -1.0;
+        double taper_start_percent   = 0.8;
+        double taper_end_percent     = 1.0;
+        double taper_final_amplitude = 0.0;
+        bool export_plot_csv         = false;  // diagnostics CSV is not produced by the GPU path
+    };
+    void SetTaperedDirectOptions(const TaperedDirectOptions& o) {
+        hc_tapered_direct_options c;
+        hc_tapered_direct_options_default(&c);
+        c.smoothing             = (o.smoothing == "moving_average") ? 1 : 0;
+        c.window_length         = o.window_length;
+        c.rirf_end_time         = o.rirf_end_time;
+        c.taper_start_percent   = o.taper_start_percent;
+        c.taper_end_percent     = o.taper_end_percent;
+        c.taper_final_amplitude = o.taper_final_amplitude;
+        check(ctx_, hc_set_tapered_direct_options(ctx_, &c));
+    }
+
+    std::vector<double> ComputeForceHydrostatics() {
+        gather_state();
+        std::vector<double> out(6 * num_bodies_);
+        check(ctx_, hc_compute_hydrostatics(ctx_, pos_.data(), rpy_.data(), out.data()));
+        return out;
+    }
+    std::vector<double> ComputeForceRadiationDampingConv() {
+        gather_state();
+        std::vector<double> out(6 * num_bodies_);
+        check(ctx_, hc_compute_radiation(ctx_, bodies_[0]->GetChTime(), lin_.data(), ang_.data(), out.data()));
+        return out;
+    }
+    std::vector<double> ComputeForceWaves() {
+        std::vector<double> out(6 * num_bodies_);
+        check(ctx_, hc_compute_waves(ctx_, bodies_[0]->GetChTime(), out.data()));
+        return out;
+    }
+
+    // src/hydro_forces.cpp:727-767.  b is 1-based.  All 6N callbacks of one Chrono update share one evaluation.
+    double CoordinateFuncForBody(int b, int dof_index) {
+        if (dof_index < 0 || dof_index >= 6 || b < 1 || b > num_bodies_) throw std::out_of_range("Invalid index in CoordinateFuncForBody");
+        const double t = bodies_[0]->GetChTime();
+        if (!(have_time_ && t == prev_time_)) {
+            prev_time_ = t;
+            have_time_ = true;
+            gather_state();
+            check(ctx_, hc_step(ctx_, t, pos_.data(), rpy_.data(), lin_.data(), ang_.data(), total_force_.data()));
+        }
+        return total_force_[6 * (b - 1) + dof_index];
+    }
+
+    HydroProfileStats GetProfileStats() const {
+        hc_profile_stats p;
+        check(ctx_, hc_get_profile(ctx_, &p));
+        HydroProfileStats s;
+        s.hydrostatics_seconds = p.hydrostatics_seconds;
+        s.radiation_seconds    = p.radiation_seconds;
+        s.waves_seconds        = p.waves_seconds;
+        s.hydrostatics_calls   = p.hydrostatics_calls;
+        s.radiation_calls      = p.radiation_calls;
+        s.waves_calls          = p.waves_calls;
+        return s;
+    }
+
+    // ChLoadAddedMass data (src/chloadaddedmass.cpp)
+    std::vector<double> GetAddedMassMatrix() const {
+        std::vector<double> M(static_cast<size_t>(36) * num_bodies_ * num_bodies_);
+        check(ctx_, hc_added_mass_matrix(ctx_, M.data()));
+        return M;
+    }
+    void AddedMassMv(double* R, const double* w, double c, int n_sys) const { check(ctx_, hc_added_mass_mv(ctx_, w, c, R, n_sys)); }
+
+    hc_ctx* context() const { return ctx_; }
+    int body_number(int i) const { return body_numbers_[i]; }
+    int num_bodies() const { return num_bodies_; }
+
+  private:
+    void gather_state() {
+        const size_t n = static_cast<size_t>(3) * num_bodies_;
+        pos_.resize(n); rpy_.resize(n); lin_.resize(n); ang_.resize(n);
+        for (int b = 0; b < num_bodies_; ++b) {
+            const auto p = bodies_[b]->GetPos(), r = bodies_[b]->GetCardanAnglesXYZ(), v = bodies_[b]->GetPosDt(),
+                       w = bodies_[b]->GetAngVelParent();
+            for (int k = 0; k < 3; ++k) {
+                pos_[3 * b + k] = p[k]; rpy_[3 * b + k] = r[k]; lin_[3 * b + k] = v[k]; ang_[3 * b + k] = w[k];
+            }
+        }
+    }
+    std::vector<std::shared_ptr<HydroBody>> bodies_;
+    int num_bodies_;
+    std::vector<int> body_numbers_;
+    hc_ctx* ctx_ = nullptr;
+    std::shared_ptr<WaveBase> user_waves_;
+    std::vector<double> total_force_, pos_, rpy_, lin_, ang_;
+    bool have_time_   = false;
+    double prev_time_ = -1.0;
+};
+
+}  // namespace hydroc_amd
+
+// =================================================================================================================
+// Project Chrono adapters (compiled only when Chrono headers are available; untestable in the build container)
+// =================================================================================================================
+#ifdef HYDROCHRONO_AMD_WITH_CHRONO
+#include <chrono/functions/ChFunction.h>
+#include <chrono/physics/ChBody.h>
+#include <chrono/physics/ChForce.h>
+#include <chrono/physics/ChLoad.h>
+#include <chrono/physics/ChLoadContainer.h>
+#include <chrono/physics/ChSystem.h>
+
+namespace hydroc_amd {
+
+struct ChronoBody : HydroBody {
+    std::shared_ptr<chrono::ChBody> body;
+    explicit ChronoBody(std::shared_ptr<chrono::ChBody> b) : body(std::move(b)) {}
+    std::string GetName() const override { return body->GetName(); }
+    double GetChTime() const override { return body->GetChTime(); }
+    std::array<double, 3> GetPos() const override { auto v = body->GetPos(); return {v.x(), v.y(), v.z()}; }
+    std::array<double, 3> GetCardanAnglesXYZ() const override { auto v = body->GetRot().GetCardanAnglesXYZ(); return {v.x(), v.y(), v.z()}; }
+    std::array<double, 3> GetPosDt() const override { auto v = body->GetPosDt(); return {v.x(), v.y(), v.z()}; }
+    std::array<double, 3> GetAngVelParent() const override { auto v = body->GetAngVelParent(); return {v.x(), v.y(), v.z()}; }
+};
+
+// ComponentFunc (include/hydroc/hydro_forces.h:45-86): GetVal's argument is ignored, time comes from body 0.
+class ComponentFunc : public chrono::ChFunction {
+  public:
+    ComponentFunc(TestHydro* hydro, int body_1based, int dof) : hydro_(hydro), b_(body_1based), i_(dof) {}
+    ComponentFunc* Clone() const override { return new ComponentFunc(*this); }
+    double GetVal(double) const override { return hydro_->CoordinateFuncForBody(b_, i_); }
+
+  private:
+    TestHydro* hydro_;
+    int b_, i_;
+};
+
+// ChLoadAddedMass (include/hydroc/chloadaddedmass.h:22-90)
+class ChLoadAddedMass : public chrono::ChLoadCustomMultiple {
+  public:
+    ChLoadAddedMass(TestHydro* hydro, std::vector<std::shared_ptr<chrono::ChLoadable>>& bodies, chrono::ChSystem* system)
+        : chrono::ChLoadCustomMultiple(bodies), hydro_(hydro), system_(system) {
+        const int D = 6 * hydro_->num_bodies();
+        const auto M = hydro_->GetAddedMassMatrix();
+        infinite_added_mass_.setZero(D, D);
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) infinite_added_mass_(i, j) = M[static_cast<size_t>(i) * D + j];
+        infinite_added_mass_system_ = infinite_added_mass_;
+    }
+    ChLoadAddedMass* Clone() const override { return new ChLoadAddedMass(*this); }
+    void ComputeQ(chrono::ChState*, chrono::ChStateDelta*) override {}
+    void ComputeJacobian(chrono::ChState*, chrono::ChStateDelta*) override {  // src/chloadaddedmass.cpp:27-53
+        auto mmrows = system_->GetNumCoordsVelLevel();
+        if (mmrows != infinite_added_mass_system_.rows() && mmrows > 0) {
+            infinite_added_mass_system_.setZero(mmrows, mmrows);
+            auto amrows = infinite_added_mass_.rows();
+            infinite_added_mass_system_.block(0, 0, amrows, amrows) = infinite_added_mass_;
+        }
+        m_jacobians->M = infinite_added_mass_system_;
+        m_jacobians->R.setZero();
+        m_jacobians->K.setZero();
+    }
+    void LoadIntLoadResidual_Mv(chrono::ChVectorDynamic<>& R, const chrono::ChVectorDynamic<>& w, const double c) override {
+        if (!this->m_jacobians) return;
+        hydro_->AddedMassMv(R.data(), w.data(), c, static_cast<int>(R.size()));  // R += c*M*w on the GPU (:55-70)
+    }
+
+  private:
+    bool IsStiff() override { return true; }
+    TestHydro* hydro_;
+    chrono::ChSystem* system_;
+    chrono::ChMatrixDynamic<double> infinite_added_mass_, infinite_added_mass_system_;
+};
+
+// Wires a TestHydro into a ChSystem exactly as the reference's constructor does (src/hydro_forces.cpp:146-168,218-234):
+// per body two WORLD_DIR ChForce objects ("hydroforce", "hydrotorque") fed by six ComponentFunc, plus the added-mass load.
+class ChronoHydroSystem {
+  public:
+    ChronoHydroSystem(std::vector<std::shared_ptr<chrono::ChBody>> bodies, const std::string& h5, std::shared_ptr<WaveBase> waves)
+        : chbodies_(std::move(bodies)) {
+        std::vector<std::shared_ptr<HydroBody>> views;
+        for (auto& b : chbodies_) views.push_back(std::make_shared<ChronoBody>(b));
+        hydro_ = std::make_unique<TestHydro>(views, h5, std::move(waves));
+        auto g = chbodies_[0]->GetSystem()->GetGravitationalAcceleration();
+        hydro_->SetGravitationalAcceleration(g.x(), g.y(), g.z());
+        for (size_t k = 0; k < chbodies_.size(); ++k) {
+            const int bnum = hydro_->body_number(static_cast<int>(k));
+            auto force = chrono_types::make_shared<chrono::ChForce>();
+            auto torque = chrono_types::make_shared<chrono::ChForce>();
+            force->SetAlign(chrono::ChForce::AlignmentFrame::WORLD_DIR);
+            torque->SetAlign(chrono::ChForce::AlignmentFrame::WORLD_DIR);
+            force->SetName("hydroforce");
+            torque->SetName("hydrotorque");
+            force->SetF_x(chrono_types::make_shared<ComponentFunc>(hydro_.get(), bnum, 0));
+            force->SetF_y(chrono_types::make_shared<ComponentFunc>(hydro_.get(), bnum, 1));
+            force->SetF_z(chrono_types::make_shared<ComponentFunc>(hydro_.get(), bnum, 2));
+            torque->SetF_x(chrono_types::make_shared<ComponentFunc>(hydro_.get(), bnum, 3));
+            torque->SetF_y(chrono_types::make_shared<ComponentFunc>(hydro_.get(), bnum, 4));
+            torque->SetF_z(chrono_types::make_shared<ComponentFunc>(hydro_.get(), bnum, 5));
+            torque->SetMode(chrono::ChForce::ForceType::TORQUE);
+            chbodies_[k]->AddForce(force);
+            chbodies_[k]->AddForce(torque);
+        }
+        std::vector<std::shared_ptr<chrono::ChLoadable>> loadables(chbodies_.begin(), chbodies_.end());
+        container_ = chrono_types::make_shared<chrono::ChLoadContainer>();
+        load_      = chrono_types::make_shared<ChLoadAddedMass>(hydro_.get(), loadables, chbodies_[0]->GetSystem());
+        chbodies_[0]->GetSystem()->Add(container_);
+        container_->Add(load_);
+    }
+    TestHydro& hydro() { return *hydro_; }
+
+  private:
+    std::vector<std::shared_ptr<chrono::ChBody>> chbodies_;
+    std::unique_ptr<TestHydro> hydro_;
+    std::shared_ptr<chrono::ChLoadContainer> container_;
+    std::shared_ptr<ChLoadAddedMass> load_;
+};
+
+}  // namespace hydroc_amd
+#endif  // HYDROCHRONO_AMD_WITH_CHRONO

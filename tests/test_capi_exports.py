@@ -1,0 +1,49 @@
+"""The C-ABI library must load without a GPU and export every symbol the public headers declare."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for hdr in ("hydrochrono_amd.h", "hydrochrono_amd_host.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(hc_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from hydrochrono_amd import capi
+    lib = capi.load()
+    decl = declared_symbols()
+    assert len(decl) >= 45
+    for name in sorted(decl):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert decl == set(capi.SIGNATURES), (decl ^ set(capi.SIGNATURES))
+    assert b"gfx950" in lib.hc_version()
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a GPU, creating a context must fail loudly (HC_ERR_DEVICE), not fall back."""
+    from hydrochrono_amd import capi
+    lib = capi.load()
+    if lib.hc_device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is present")
+    ctx = ctypes.c_void_p()
+    rc = lib.hc_create(1, 0, ctypes.byref(ctx))
+    assert rc == capi.HC_ERR_DEVICE and not ctx.value
+    assert b"no CPU fallback" in lib.hc_last_error(None)
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under hydrochrono_amd/ may import, link or load anything under oracle/."""
+    pkg = os.path.join(ROOT, "hydrochrono_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "hc_oracle" not in text and "oracle/" not in text and "import oracle" not in text, f

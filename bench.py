@@ -57,32 +57,54 @@ def parse():
 
 
 def cpu_baseline(case, motion, t_hist, v_hist, budget_s):
-    """Times the oracle in its reference-faithful OpenMP form on all host cores; returns (dict, forces at T0)."""
+    """Times the CPU oracle on this box's host cores on a bounded sample of the same workload.
+
+    Two variants: the reference-faithful restatement (OpenMP over IRF steps, per-element
+    accessor, nested-vector history -- `value`, thread count chosen by a short sweep because the reference's
+    `schedule(static)` over 1024 steps does not scale to every core count) and an optimised flat-array CPU variant
+    (`optimized_port`) so that the GPU speed-up is not flattered by reference overheads.  Returns (dict, forces at T0)."""
     import oracle as orc_mod
     from cases import load_into_oracle
     cores = os.cpu_count() or 1
-    orc_mod.set_num_threads(cores)
     orc = load_into_oracle(case)
     orc.add_waves_irregular(**WAVES)
     orc.prefill_history(t_hist, v_hist)
-    durations, first = [], None
+    k = [0]
+
+    def timed(fn, nsteps):
+        d, f0 = [], None
+        for _ in range(nsteps):
+            t = T0 + k[0] * DT
+            st = motion.state(t)
+            a = time.perf_counter()
+            f = fn(t, *st)
+            d.append(time.perf_counter() - a)
+            f0 = f if f0 is None else f0
+            k[0] += 1
+        return d, f0
+
     t_begin = time.perf_counter()
-    n = 0
-    while True:
-        t = T0 + n * DT
-        st = motion.state(t)
-        a = time.perf_counter()
-        f = orc.step(t, *st)
-        durations.append(time.perf_counter() - a)
-        if first is None:
-            first = f.copy()
-        n += 1
-        if n >= 3 and (time.perf_counter() - t_begin > budget_s or n >= 100):
-            break
-    med = float(np.median(durations))
-    info = {"value": 1.0 / med, "unit": "evals/s", "cores": cores, "kind": "port", "ms_per_step": med * 1e3,
-            "sample": f"{n} consecutive steady-state steps of the same workload (median), oracle -O2 -fopenmp, "
-                      f"OMP threads = {orc_mod.num_threads()}"}
+    sweep, first = {}, None
+    for th in sorted({cores, max(1, cores // 2), min(cores, 64), min(cores, 16)}, reverse=True):
+        orc_mod.set_num_threads(th)
+        d, f0 = timed(orc.step, 3)
+        first = f0 if first is None else first
+        sweep[th] = float(np.median(d))
+    best = min(sweep, key=sweep.get)
+    orc_mod.set_num_threads(best)
+    n_more = int(max(3, min(40, (0.5 * budget_s - (time.perf_counter() - t_begin)) / sweep[best])))
+    d, _ = timed(orc.step, n_more)
+    med = float(np.median(d))
+    orc_mod.set_num_threads(cores)
+    orc.flat_prepare()
+    d_flat, _ = timed(orc.flat_step, 12)
+    med_flat = float(np.median(d_flat[2:]))
+    info = {"value": 1.0 / med, "unit": "evals/s", "cores": best, "kind": "port", "ms_per_step": med * 1e3,
+            "sample": f"{n_more} consecutive steady-state steps of the same workload (median), reference-faithful oracle "
+                      f"-O2 -fopenmp, OMP threads = {best} (best of sweep); box has {cores} logical cores",
+            "threads_sweep_ms": {str(th): v * 1e3 for th, v in sweep.items()},
+            "optimized_port": {"value": 1.0 / med_flat, "unit": "evals/s", "cores": cores, "ms_per_step": med_flat * 1e3,
+                               "sample": "10 steps (median), flat-array OpenMP-over-rows CPU variant of the same math"}}
     return info, first
 
 
@@ -218,6 +240,7 @@ def main():
             out["cpu_baseline"] = base
             out["parity_max_rel_err_vs_oracle"] = float(np.max(np.abs(f_gpu - f_cpu)) / np.max(np.abs(f_cpu)))
             out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
+            out["speedup_vs_optimized_cpu"] = out["value"] / base["optimized_port"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

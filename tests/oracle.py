@@ -216,6 +216,16 @@ class Oracle:
         self._chk(self.L.orc_added_mass_mv(self.ctx, _p(R), _p(w), C.c_double(c), C.c_int(R.size)))
         return R
 
+    # ---- optimised CPU variant (bench cpu_baseline only) ----
+    def flat_prepare(self):
+        self._chk(self.L.orc_flat_prepare(self.ctx))
+
+    def flat_step(self, t, pos, rpy, linvel, angvel):
+        out = np.empty(self.D)
+        a = [np.ascontiguousarray(x, dtype=np.float64).reshape(-1) for x in (pos, rpy, linvel, angvel)]
+        self._chk(self.L.orc_flat_step(self.ctx, C.c_double(t), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(out)))
+        return out
+
     def run_heave_1dof(self, mass, g, pto_damping, z0, dt, nsteps, want_force=False):
         z = np.empty(nsteps)
         fz = np.empty(nsteps) if want_force else None

@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--bodies", type=int, default=N_BODIES, help="bodies per GPU (default: the C3 configuration)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--profile-stride", type=int, default=8, help="HIP-event sampling stride for the roofline kernel time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline time budget")
     return ap.parse_args()
@@ -174,7 +175,7 @@ def main():
 
     run(0, args.warmup)
     torch.cuda.synchronize()
-    gpu.enable_profiling(True)
+    gpu.enable_profiling(args.profile_stride)  # HIP events around the conv kernel of every n-th timed step
     gpu.reset_profile()
     if world > 1:
         dist.barrier()

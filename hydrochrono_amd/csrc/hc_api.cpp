@@ -110,13 +110,14 @@ void profile_drain(hc_ctx* c) {
     if (c->events_used == 0) return;
     HC_HIP(hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < c->events_used; ++i) {
-        float ms01 = 0, ms12 = 0, ms23 = 0;
+        float ms01 = 0, ms12 = 0;
         HC_HIP(hipEventElapsedTime(&ms01, c->events[i].e[0], c->events[i].e[1]));
         HC_HIP(hipEventElapsedTime(&ms12, c->events[i].e[1], c->events[i].e[2]));
-        HC_HIP(hipEventElapsedTime(&ms23, c->events[i].e[2], c->events[i].e[3]));
-        c->prof.radiation_seconds += (ms01 + ms12) * 1e-3;
-        c->prof.hydrostatics_seconds += ms23 * 1e-3;
-        c->prof.conv_kernel_seconds += ms12 * 1e-3;
+        // the convolution launch carries radiation and (irregular waves) excitation; the finalize launch carries
+        // hydrostatics, the regular-wave term and the reduction
+        c->prof.radiation_seconds += ms01 * 1e-3;
+        c->prof.hydrostatics_seconds += ms12 * 1e-3;
+        c->prof.conv_kernel_seconds += ms01 * 1e-3;
         c->prof.conv_kernel_launches += 1;
     }
     c->events_used = 0;
@@ -124,6 +125,7 @@ void profile_drain(hc_ctx* c) {
 
 hc::EventSet* profile_next(hc_ctx* c) {
     if (!c->profiling) return nullptr;
+    if ((c->profile_counter++ % c->profile_stride) != 0) return nullptr;  // sampled: events perturb the launch stream
     if (c->events_used == c->events.size()) {
         if (c->events.size() < 4096) {
             hc::EventSet es;
@@ -231,7 +233,7 @@ void check_wave_ready(hc_ctx* c, double t) {
     }
 }
 
-// Enqueue prep -> conv -> finalize for time t. d_state: device pointer to the 12N state. user_out may be null.
+// Enqueue conv -> finalize for time t. d_state: device pointer to the 12N state. user_out may be null.
 void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f) {
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     const bool irregular = c->wave_kind == hc::kWaveIrregular;
@@ -241,62 +243,49 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         ensure_processed(c);
         H = history_push(c, t);
     }
-    hc::EventSet* ev = profile_next(c);
-    if (ev) HC_HIP(hipEventRecord(ev->e[0], stream));
-
     const bool run_rad = f.rad && H >= 2;  // "Nothing to convolve with if we don't yet have at least 2 time points" (:580)
-    hc::PrepArgs p{};
-    p.state         = d_state;
-    p.N             = c->N;
-    p.D             = c->D;
-    p.t             = t;
-    p.S             = c->S;
-    p.tau           = c->d_tau.p;
-    p.width         = c->d_width.p;
-    p.ring_t        = c->d_ring_t.p;
-    p.ring_v        = c->d_ring_v.p;
-    p.head          = c->head;
-    p.H             = H;
-    p.Hcap          = c->Hcap;
-    p.dt_hint       = (H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
-    p.u             = c->d_u.p;
-    p.do_radiation  = f.rad ? 1 : 0;
-    p.L             = c->L;
-    p.Lpad          = c->Lpad;
-    p.ex_tau        = c->d_ex_tau.p;
-    p.ex_width      = c->d_ex_width.p;
-    p.eta_t         = c->d_eta_t.p;
-    p.eta           = c->d_eta.p;
-    p.nt            = c->nt;
-    p.eta_dt        = irregular ? c->irr.simulation_dt : 1.0;
-    p.e             = c->d_e.p;
-    p.do_excitation = (f.waves && irregular) ? 1 : 0;
-    p.error_flag    = c->d_err.p;
-    if (f.rad && !run_rad) {
-        // first sample: only the ring push is needed; u is not consumed
-        p.S = 0;
-    }
-    hc::launch_prep(p, stream);
-    if (ev) HC_HIP(hipEventRecord(ev->e[1], stream));
+    const bool run_exc = f.waves && irregular;
+    hc::EventSet* ev = profile_next(c);
 
     hc::ConvArgs a{};
-    a.K             = (c->conv_mode == 1) ? c->dKproc.p : c->dK.p;
-    a.ldk           = c->ldk;
-    a.u             = c->d_u.p;
-    a.F             = c->S * c->D;
-    a.chunk_cols    = c->chunk_cols;
-    a.nchunks_rad   = run_rad ? c->nchunks_rad : 0;
-    a.Kex           = c->d_kex.p;
-    a.ldkex         = static_cast<size_t>(c->Lpad);
-    a.e             = c->d_e.p;
-    a.Lpad          = c->Lpad;
-    a.chunk_cols_ex = c->chunk_cols_ex;
-    a.nchunks_ex    = p.do_excitation ? c->nchunks_ex : 0;
-    a.partials      = c->d_partials.p;
-    a.Dloc          = c->Dloc;
-    a.nrowtiles     = c->nrowtiles;
+    a.K                   = (c->conv_mode == 1) ? c->dKproc.p : c->dK.p;
+    a.ldk                 = c->ldk;
+    a.F                   = c->S * c->D;
+    a.chunk_cols          = c->chunk_cols;
+    a.nchunks_rad         = run_rad ? c->nchunks_rad : 0;
+    a.max_steps_per_chunk = c->chunk_cols / c->D + 2;
+    a.hist.state          = d_state;
+    a.hist.N              = c->N;
+    a.hist.D              = c->D;
+    a.hist.t              = t;
+    a.hist.ring_t         = c->d_ring_t.p;
+    a.hist.ring_v         = c->d_ring_v.p;
+    a.hist.head           = c->head;
+    a.hist.H              = H;
+    a.hist.Hcap           = c->Hcap;
+    a.hist.dt_hint        = (H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
+    a.S                   = c->S;
+    a.tau                 = c->d_tau.p;
+    a.width               = c->d_width.p;
+    a.Kex                 = c->d_kex.p;
+    a.ldkex               = static_cast<size_t>(c->Lpad);
+    a.L                   = c->L;
+    a.Lpad                = c->Lpad;
+    a.chunk_cols_ex       = c->chunk_cols_ex;
+    a.nchunks_ex          = run_exc ? c->nchunks_ex : 0;
+    a.ex_tau              = c->d_ex_tau.p;
+    a.ex_width            = c->d_ex_width.p;
+    a.eta_t               = c->d_eta_t.p;
+    a.eta                 = c->d_eta.p;
+    a.nt                  = c->nt;
+    a.eta_dt              = irregular ? c->irr.simulation_dt : 1.0;
+    a.partials            = c->d_partials.p;
+    a.Dloc                = c->Dloc;
+    a.nrowtiles           = c->nrowtiles;
+    a.error_flag          = c->d_err.p;
+    if (ev) HC_HIP(hipEventRecord(ev->e[0], stream));
     hc::launch_conv(a, c->rows_per_tile, stream);
-    if (ev) HC_HIP(hipEventRecord(ev->e[2], stream));
+    if (ev) HC_HIP(hipEventRecord(ev->e[1], stream));
 
     hc::FinalizeArgs z{};
     z.partials    = c->d_partials.p;
@@ -328,8 +317,13 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     z.waves         = c->d_waves.p;
     z.total         = c->d_total.p;
     z.user_out      = d_user_out;
+    z.do_push       = f.rad ? 1 : 0;
+    z.head          = c->head;
+    z.D             = c->D;
+    z.ring_t        = c->d_ring_t.p;
+    z.ring_v        = c->d_ring_v.p;
     hc::launch_finalize(z, stream);
-    if (ev) HC_HIP(hipEventRecord(ev->e[3], stream));
+    if (ev) HC_HIP(hipEventRecord(ev->e[2], stream));
     HC_HIP(hipGetLastError());
 
     if (f.hs) c->prof.hydrostatics_calls++;
@@ -600,8 +594,6 @@ int hc_finalize(hc_ctx* c) {
     c->prev_time = -1.0;
     // GEMV scratch
     choose_conv_config(c);
-    c->d_u.alloc(static_cast<size_t>(c->S) * c->D);
-    HC_HIP(hipMemsetAsync(c->d_u.p, 0, c->d_u.n * sizeof(double), c->stream));
     // step I/O
     c->d_state.alloc(static_cast<size_t>(12) * c->N);
     c->d_hs.alloc(c->Dloc);
@@ -1019,7 +1011,9 @@ int hc_added_mass_mv(hc_ctx* c, const double* w, double cc, double* R, int n_sys
 int hc_enable_profiling(hc_ctx* c, int on) {
     HC_API_BEGIN(c)
     if (!on) profile_drain(c);
-    c->profiling = on != 0;
+    c->profiling       = on != 0;
+    c->profile_stride  = on > 1 ? on : 1;
+    c->profile_counter = 0;
     HC_API_END(c)
 }
 

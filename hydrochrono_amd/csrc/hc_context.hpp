@@ -88,7 +88,7 @@ struct BodyHost {
 enum WaveKind { kWaveNone = 0, kWaveRegular = 1, kWaveIrregular = 2 };
 
 struct EventSet {
-    hipEvent_t e[4];
+    hipEvent_t e[3];
 };
 
 }  // namespace hc
@@ -140,7 +140,7 @@ struct hc_ctx {
     // GEMV configuration + scratch
     int rows_per_tile = 6, nrowtiles = 0;
     int chunk_cols = 0, nchunks_rad = 0, chunk_cols_ex = 0, nchunks_ex = 0;
-    hc::DeviceBuffer<double> d_u, d_partials;
+    hc::DeviceBuffer<double> d_partials;
 
     // step I/O
     hc::DeviceBuffer<double> d_state, d_hs, d_rad, d_waves, d_total;
@@ -150,6 +150,8 @@ struct hc_ctx {
 
     // profiling
     bool profiling = false;
+    int profile_stride = 1;
+    long long profile_counter = 0;
     std::vector<hc::EventSet> events;
     size_t events_used = 0;
     hc_profile_stats prof{};

@@ -1,16 +1,18 @@
 // hc_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the hydro-force path.
 //
-// Per step three launches run back to back on one stream:
-//   prep_kernel      velocity-ring push, bracket search + linear interpolation of the velocity history at
-//                    t - tau_s (-> u[S*D], trapezoid width folded in), eta(t - tau_j) lookup (-> e[L])
+// Per step two launches run back to back on one stream:
 //   conv_kernel      the Cummins convolution as a streamed FP64 GEMV  partial[chunk][row] = K[row, chunk] . u[chunk]
-//                    (HBM-bound: K is read exactly once, 16 B per lane, fully coalesced; u comes from L2)
+//                    (HBM-bound: K is read exactly once, 16 B per lane, fully coalesced).  u[s][col] -- the body
+//                    velocity history interpolated at t - tau_s, times the trapezoid width -- is formed in registers
+//                    from the velocity ring via a per-workgroup bracket table in LDS; the irregular-wave excitation
+//                    Kex . eta(t - tau_j) rides in the same launch as extra column chunks.
 //   finalize_kernel  fixed-order reduction of the partials, hydrostatics, regular-wave term,
-//                    total = hydrostatic - radiation + waves
+//                    total = hydrostatic - radiation + waves, velocity-ring push of this step's sample
 // Reference semantics: src/hydro_forces.cpp:263-322,537-691,727-767; src/wave_types.cpp:315-327,776-844.
 #include "hc_kernels.hpp"
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace hc {
 
@@ -65,126 +67,23 @@ void launch_unrelayout(const double* d_K, size_t ldk, int Dloc, int D, int S, do
     hipLaunchKernelGGL(unrelayout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_K, ldk, Dloc, D, S, d_out);
 }
 
-// ------------------------------------------------------------------------------------------------
-// prep_kernel.  Block roles by blockIdx.x:
-//   [0, S)                 radiation sample s: bracket search in the time ring, interpolate all D columns
-//   [S, S + nexc)          excitation samples, one thread per tau_j
-//   S + nexc               ring push of the current sample
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double state_velocity(const double* __restrict__ state, int N, int col) {
     const int b = col / 6, d = col - 6 * b;
     return d < 3 ? state[6 * N + 3 * b + d] : state[9 * N + 3 * b + (d - 3)];
-}
-
-__global__ void __launch_bounds__(256) prep_kernel(PrepArgs a) {
-    const int nrad  = a.do_radiation ? a.S : 0;
-    const int nexc  = a.do_excitation ? (a.L + 255) / 256 : 0;
-    const int bid   = blockIdx.x;
-    const int tid   = threadIdx.x;
-
-    if (bid < nrad) {
-        // ---- AdvanceToBracket + InterpolateVelocity6D (src/hydro_forces.cpp:343-381,600-636) ----
-        const int s    = bid;
-        const double q = a.t - a.tau[s];
-        auto hist_time = [&](int k) -> double { return k == 0 ? a.t : a.ring_t[(a.head - k + a.Hcap) % a.Hcap]; };
-        // smallest i in [0, H-2] with time(i+1) <= q ; none (i == H-1) -> no older sample -> contributes nothing.
-        // Histories are close to uniformly spaced, so first try the index the previous step size predicts
-        // (2-3 dependent loads); any miss falls back to the full binary search.
-        int lo = 0, hi = a.H - 1;
-        if (a.H >= 3) {
-            int gi = (int)((a.t - q) / a.dt_hint) - 1;
-            gi     = max(0, min(gi, a.H - 2));
-#pragma unroll 1
-            for (int k = 0; k < 3; ++k, ++gi) {
-                if (gi > a.H - 2) break;
-                if (hist_time(gi + 1) <= q && (gi == 0 || hist_time(gi) > q)) { lo = hi = gi; break; }
-            }
-        }
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (hist_time(mid + 1) <= q) hi = mid; else lo = mid + 1;
-        }
-        double* __restrict__ urow = a.u + (size_t)s * a.D;
-        if (lo >= a.H - 1) {
-            for (int c = tid; c < a.D; c += blockDim.x) urow[c] = 0.0;
-            return;
-        }
-        const double newer = hist_time(lo), older = hist_time(lo + 1);
-        double wo, wn;
-        if (q == older) { wo = 1.0; wn = 0.0; }
-        else if (q == newer) { wo = 0.0; wn = 1.0; }
-        else if (q > older && q < newer) {
-            const double td = newer - older;
-            wo = (td != 0.0) ? ((newer - q) / td) : 0.0;
-            wn = 1.0 - wo;
-        } else {
-            if (tid == 0) *a.error_flag = 1;  // "query_time not bracketed by history" (:370)
-            wo = 0.0; wn = 0.0;
-        }
-        const double w        = a.width[s];
-        const int slot_older  = (a.head - (lo + 1) + a.Hcap) % a.Hcap;
-        const int slot_newer  = (a.head - lo + a.Hcap) % a.Hcap;
-        const double* v_older = a.ring_v + (size_t)slot_older * a.D;
-        const double* v_newer = a.ring_v + (size_t)slot_newer * a.D;
-        for (int c = tid; c < a.D; c += blockDim.x) {
-            const double vn = (lo == 0) ? state_velocity(a.state, a.N, c) : v_newer[c];
-            const double vo = v_older[c];
-            double v;
-            if (wn == 0.0) v = vo;           // exact copies, as the reference's early returns
-            else if (wo == 0.0) v = vn;
-            else v = wo * vo + wn * vn;
-            urow[c] = v * w;
-        }
-        return;
-    }
-    if (bid < nrad + nexc) {
-        // ---- eta(t - tau_j), linear interpolation in the precomputed table (src/wave_types.cpp:797-831) ----
-        const int j = (bid - nrad) * 256 + tid;
-        if (j >= a.Lpad) return;
-        if (j >= a.L) { a.e[j] = 0.0; return; }
-        const double q    = a.t - a.ex_tau[j];
-        const double tmin = a.eta_t[0];
-        int idx = (int)floor((q - tmin) / a.eta_dt);
-        idx     = max(0, min(idx, a.nt - 2));
-        while (idx > 0 && a.eta_t[idx] > q) --idx;
-        while (idx < a.nt - 2 && a.eta_t[idx + 1] <= q) ++idx;
-        const double t1 = a.eta_t[idx], t2 = a.eta_t[idx + 1];
-        double val;
-        if (q == t1) val = a.eta[idx];
-        else if (q == t2) val = a.eta[idx + 1];
-        else if (q > t1 && q < t2) {
-            const double w1 = (t2 - q) / (t2 - t1);
-            const double w2 = 1.0 - w1;
-            val = w1 * a.eta[idx] + w2 * a.eta[idx + 1];
-        } else {
-            *a.error_flag = 2;  // outside the table: the host has already refused the step (:833-840)
-            val = 0.0;
-        }
-        a.e[j] = val * a.ex_width[j];
-        if (j + 1 == a.L && a.Lpad > a.L) a.e[a.L] = 0.0;
-        return;
-    }
-    // ---- ring push (src/hydro_forces.cpp:559-574) ----
-    if (a.do_radiation) {
-        if (tid == 0) a.ring_t[a.head] = a.t;
-        double* slot = a.ring_v + (size_t)a.head * a.D;
-        for (int c = tid; c < a.D; c += blockDim.x) slot[c] = state_velocity(a.state, a.N, c);
-    }
-}
-
-void launch_prep(const PrepArgs& a, hipStream_t stream) {
-    const int nrad = a.do_radiation ? a.S : 0;
-    const int nexc = a.do_excitation ? (a.L + 255) / 256 : 0;
-    hipLaunchKernelGGL(prep_kernel, dim3(nrad + nexc + 1), dim3(256), 0, stream, a);
 }
 
 // ------------------------------------------------------------------------------------------------
 // conv_kernel<R>: the dominant kernel.  HBM-bound FP64 GEMV, 0.25 flop/B.
 //   grid   = nrowtiles * (nchunks_rad + nchunks_ex) workgroups of 4 waves
 //   each lane streams 16-byte pieces of R rows (R independent global_load_dwordx4 in flight per column block,
-//   straight to VGPRs -- no LDS round trip for data that is used once), multiplies with the matching pair of u
-//   (L2-resident, re-used by all row tiles) and keeps R FP64 accumulators; a wave64 xor-shuffle tree and a
-//   4-entry LDS step reduce them in a FIXED order, so results are bitwise reproducible run to run.
+//   straight to VGPRs -- no LDS round trip for data that is used once), multiplies with the matching pair of the
+//   right-hand side and keeps R FP64 accumulators; a wave64 xor-shuffle tree and a 4-entry LDS step reduce them in
+//   a FIXED order, so results are bitwise reproducible run to run.
+//   Right-hand side of a radiation chunk: for every IRF sample s the chunk touches, one thread finds the history
+//   bracket (AdvanceToBracket) and the interpolation weights (InterpolateVelocity6D, src/hydro_forces.cpp:343-381)
+//   into an LDS table; each lane then forms u = (w_older*v_older + w_newer*v_newer) * width_s for its two columns
+//   from two 16-byte ring loads (L2 hits).  Right-hand side of an excitation chunk: eta(t - tau_j), linearly
+//   interpolated in the precomputed table (src/wave_types.cpp:797-831), times width_j.
 // ------------------------------------------------------------------------------------------------
 typedef double dvec2 __attribute__((ext_vector_type(2)));
 
@@ -194,47 +93,148 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int R>
+struct Bracket {
+    double wo, wn, width;  // weights of the older / newer sample, trapezoid width
+    int slot_older;        // ring slot of the older sample
+    int slot_newer;        // ring slot of the newer sample, -1: the newer sample is the current state
+};
+
+__device__ __forceinline__ double hist_time(const HistoryView& h, int k) {
+    return k == 0 ? h.t : h.ring_t[(h.head - k + h.Hcap) % h.Hcap];
+}
+
+// smallest i in [0, H-2] with time(i+1) <= q ; i == H-1 means "no older sample" (the step contributes nothing).
+__device__ Bracket find_bracket(const HistoryView& h, double tau_s, double width_s, int* error_flag) {
+    const double q = h.t - tau_s;
+    int lo = 0, hi = h.H - 1;
+    if (h.H >= 3) {
+        // histories are close to uniformly spaced: try the index the previous step size predicts first
+        int gi = (int)(tau_s / h.dt_hint) - 1;
+        gi     = max(0, min(gi, h.H - 2));
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k, ++gi) {
+            if (gi > h.H - 2) break;
+            if (hist_time(h, gi + 1) <= q && (gi == 0 || hist_time(h, gi) > q)) { lo = hi = gi; break; }
+        }
+    }
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (hist_time(h, mid + 1) <= q) hi = mid; else lo = mid + 1;
+    }
+    Bracket b;
+    b.width = width_s;
+    if (lo >= h.H - 1) {  // not enough older history (src/hydro_forces.cpp:604-606)
+        b.wo = 0.0; b.wn = 0.0; b.slot_older = 0; b.slot_newer = 0;
+        return b;
+    }
+    const double newer = hist_time(h, lo), older = hist_time(h, lo + 1);
+    if (q == older) { b.wo = 1.0; b.wn = 0.0; }
+    else if (q == newer) { b.wo = 0.0; b.wn = 1.0; }
+    else if (q > older && q < newer) {
+        const double td = newer - older;
+        b.wo = (td != 0.0) ? ((newer - q) / td) : 0.0;
+        b.wn = 1.0 - b.wo;
+    } else {
+        *error_flag = 1;  // "query_time not bracketed by history" (:370)
+        b.wo = 0.0; b.wn = 0.0;
+    }
+    b.slot_older = (h.head - (lo + 1) + h.Hcap) % h.Hcap;
+    b.slot_newer = (lo == 0) ? -1 : (h.head - lo + h.Hcap) % h.Hcap;
+    return b;
+}
+
+__device__ __forceinline__ double eta_at(const ConvArgs& a, int j) {
+    if (j >= a.L) return 0.0;
+    const double q    = a.hist.t - a.ex_tau[j];
+    const double tmin = a.eta_t[0];
+    int idx = (int)floor((q - tmin) / a.eta_dt);
+    idx     = max(0, min(idx, a.nt - 2));
+    while (idx > 0 && a.eta_t[idx] > q) --idx;
+    while (idx < a.nt - 2 && a.eta_t[idx + 1] <= q) ++idx;
+    const double t1 = a.eta_t[idx], t2 = a.eta_t[idx + 1];
+    double val;
+    if (q == t1) val = a.eta[idx];
+    else if (q == t2) val = a.eta[idx + 1];
+    else if (q > t1 && q < t2) {
+        const double w1 = (t2 - q) / (t2 - t1);
+        const double w2 = 1.0 - w1;
+        val = w1 * a.eta[idx] + w2 * a.eta[idx + 1];
+    } else {
+        *a.error_flag = 2;  // outside the table: the host has already refused the step (:833-840)
+        val = 0.0;
+    }
+    return val * a.ex_width[j];
+}
+
+template <int R, int U>
 __global__ void __launch_bounds__(kConvThreads) conv_kernel(ConvArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Bracket* tab = reinterpret_cast<Bracket*>(smem_raw);
+    __shared__ double red[kConvThreads / kWave][R];
+
     const int nct   = a.nchunks_rad + a.nchunks_ex;
     const int chunk = blockIdx.x % nct;
     const int rt    = blockIdx.x / nct;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    const double* __restrict__ M;
-    const double* __restrict__ x;
-    size_t ld;
-    int c0, c1;
-    if (chunk < a.nchunks_rad) {
-        M = a.K; x = a.u; ld = a.ldk;
-        c0 = chunk * a.chunk_cols;
-        c1 = min(a.F, c0 + a.chunk_cols);
-    } else {
-        M = a.Kex; x = a.e; ld = a.ldkex;
-        c0 = (chunk - a.nchunks_rad) * a.chunk_cols_ex;
-        c1 = min(a.Lpad, c0 + a.chunk_cols_ex);
-    }
-    const double* __restrict__ rows = M + (size_t)(rt * R) * ld;
+    const bool radiation = chunk < a.nchunks_rad;
 
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
 
-#pragma unroll 2
-    for (int col = c0 + 2 * tid; col < c1; col += 2 * kConvThreads) {
-        const dvec2 xv = *reinterpret_cast<const dvec2*>(x + col);
-        dvec2 kv[R];
-        // K is streamed exactly once per step: non-temporal loads keep it from evicting u / the ring from L2
+    if (radiation) {
+        const int D  = a.hist.D;
+        const int c0 = chunk * a.chunk_cols;
+        const int c1 = min(a.F, c0 + a.chunk_cols);
+        const int s0 = c0 / D;
+        const int ns = (c1 - 1) / D - s0 + 1;
+        for (int k = tid; k < ns; k += kConvThreads) tab[k] = find_bracket(a.hist, a.tau[s0 + k], a.width[s0 + k], a.error_flag);
+        __syncthreads();
+        const double* __restrict__ rows = a.K + (size_t)(rt * R) * a.ldk;
+        const double* __restrict__ ring = a.hist.ring_v;
+#pragma unroll U
+        for (int f = c0 + 2 * tid; f < c1; f += 2 * kConvThreads) {
+            dvec2 kv[R];
+            // K is streamed exactly once per step: non-temporal loads keep it from evicting the ring from L2
 #pragma unroll
-        for (int r = 0; r < R; ++r) kv[r] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(rows + (size_t)r * ld + col));
+            for (int r = 0; r < R; ++r) kv[r] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(rows + (size_t)r * a.ldk + f));
+            const int s   = f / D;
+            const int col = f - s * D;  // even; f and f+1 share s because D is even
+            const Bracket b = tab[s - s0];
+            const dvec2 vo  = *reinterpret_cast<const dvec2*>(ring + (size_t)b.slot_older * D + col);
+            dvec2 vn;
+            if (b.slot_newer >= 0) vn = *reinterpret_cast<const dvec2*>(ring + (size_t)b.slot_newer * D + col);
+            else { vn.x = state_velocity(a.hist.state, a.hist.N, col); vn.y = state_velocity(a.hist.state, a.hist.N, col + 1); }
+            dvec2 u;
+            if (b.wn == 0.0) u = vo;          // exact copies, as the reference's early returns
+            else if (b.wo == 0.0) u = vn;
+            else { u.x = b.wo * vo.x + b.wn * vn.x; u.y = b.wo * vo.y + b.wn * vn.y; }
+            if (b.wo == 0.0 && b.wn == 0.0) { u.x = 0.0; u.y = 0.0; }
+            u.x *= b.width;
+            u.y *= b.width;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            acc[r] = fma(kv[r].x, xv.x, acc[r]);
-            acc[r] = fma(kv[r].y, xv.y, acc[r]);
+            for (int r = 0; r < R; ++r) {
+                acc[r] = fma(kv[r].x, u.x, acc[r]);
+                acc[r] = fma(kv[r].y, u.y, acc[r]);
+            }
+        }
+    } else {
+        const int c0 = (chunk - a.nchunks_rad) * a.chunk_cols_ex;
+        const int c1 = min(a.Lpad, c0 + a.chunk_cols_ex);
+        const double* __restrict__ rows = a.Kex + (size_t)(rt * R) * a.ldkex;
+        for (int j = c0 + 2 * tid; j < c1; j += 2 * kConvThreads) {
+            dvec2 kv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) kv[r] = *reinterpret_cast<const dvec2*>(rows + (size_t)r * a.ldkex + j);
+            const double e0 = eta_at(a, j), e1 = eta_at(a, j + 1);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r] = fma(kv[r].x, e0, acc[r]);
+                acc[r] = fma(kv[r].y, e1, acc[r]);
+            }
         }
     }
 
-    __shared__ double red[kConvThreads / kWave][R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const double s = wave_sum(acc[r]);
@@ -247,10 +247,18 @@ __global__ void __launch_bounds__(kConvThreads) conv_kernel(ConvArgs a) {
 void launch_conv(const ConvArgs& a, int rows_per_tile, hipStream_t stream) {
     const int nblocks = a.nrowtiles * (a.nchunks_rad + a.nchunks_ex);
     if (nblocks <= 0) return;
-    if (rows_per_tile == 12)
-        hipLaunchKernelGGL(conv_kernel<12>, dim3(nblocks), dim3(kConvThreads), 0, stream, a);
-    else
-        hipLaunchKernelGGL(conv_kernel<6>, dim3(nblocks), dim3(kConvThreads), 0, stream, a);
+    const size_t smem = (size_t)max(1, a.max_steps_per_chunk) * sizeof(Bracket);
+    static const int unroll = [] {
+        const char* e = std::getenv("HC_CONV_UNROLL");  // tuning experiments only
+        return e ? std::atoi(e) : 1;
+    }();
+    if (rows_per_tile == 12) {
+        if (unroll == 2) hipLaunchKernelGGL((conv_kernel<12, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+        else hipLaunchKernelGGL((conv_kernel<12, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    } else {
+        if (unroll == 1) hipLaunchKernelGGL((conv_kernel<6, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+        else hipLaunchKernelGGL((conv_kernel<6, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    }
 }
 
 const char* conv_kernel_name() { return "conv_kernel"; }
@@ -267,6 +275,13 @@ __device__ __forceinline__ double lane16_sum(double v) {
 }
 
 __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
+    if (a.do_push && blockIdx.x == gridDim.x - 1) {
+        // the extra last workgroup stores this step's sample into ring slot `head`; nobody reads that slot this step
+        if (threadIdx.x == 0) a.ring_t[a.head] = a.t;
+        double* slot = a.ring_v + (size_t)a.head * a.D;
+        for (int c = threadIdx.x; c < a.D; c += blockDim.x) slot[c] = state_velocity(a.state, a.N, c);
+        return;
+    }
     const int sub = threadIdx.x & 15;
     const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool live = row < a.Dloc;
@@ -327,7 +342,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 }
 
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(finalize_kernel, dim3((a.Dloc + 15) / 16), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(finalize_kernel, dim3((a.Dloc + 15) / 16 + (a.do_push ? 1 : 0)), dim3(256), 0, stream, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -10,54 +10,48 @@ namespace hc {
 
 // Velocity-history ring in HBM: ring_v[Hcap][D], ring_t[Hcap]; sample k (0 = newest) lives in slot
 // (head - k + Hcap) % Hcap.  The sample of the CURRENT step (k = 0) is read from `state`, never from the
-// ring, so the block that stores it into slot `head` races with nobody.
-struct PrepArgs {
-    // state of this step: pos[3N] | rpy[3N] | linvel[3N] | angvel[3N]
-    const double* state;
+// ring, so the workgroup that stores it into slot `head` (finalize_kernel) races with nobody.
+struct HistoryView {
+    const double* state;  // this step: pos[3N] | rpy[3N] | linvel[3N] | angvel[3N]
     int N, D;
     double t;
-    // radiation side
+    const double* ring_t;
+    const double* ring_v;
+    int head, H, Hcap;    // H counts the current sample
+    double dt_hint;       // t - previous sample time (bracket-search hint only, > 0)
+};
+
+// One launch per step covers the radiation matrix K[D_local x S*D] and, for irregular waves, the excitation
+// matrix Kex[D_local x Lpad]; a workgroup owns R consecutive rows x one column chunk of one of them and leaves one
+// partial sum per row in `partials[chunk][D_local]`.  The right-hand sides are never materialised: the
+// interpolated, width-scaled velocity history u[s][col] and the free-surface samples e[j] are formed in registers
+// from the ring / the eta table (both L2-resident) while K streams from HBM.
+struct ConvArgs {
+    const double* K;
+    size_t ldk;       // row stride of K in doubles (even)
+    int F;            // S*D
+    int chunk_cols;   // multiple of 512
+    int nchunks_rad;
+    int max_steps_per_chunk;  // size of the per-workgroup bracket table: chunk_cols / D + 2
+    HistoryView hist;
     int S;
     const double* tau;    // [S] radiation IRF sample times
     const double* width;  // [S] trapezoid widths
-    double* ring_t;
-    double* ring_v;
-    int head, H, Hcap;    // H counts the current sample
-    double dt_hint;       // t - previous sample time (search hint only, > 0)
-    double* u;            // [S*D] out: interpolated velocity * width  (0 where no bracket exists)
-    int do_radiation;
-    // excitation side (irregular waves)
+    const double* Kex;
+    size_t ldkex;     // Lpad
     int L, Lpad;
+    int chunk_cols_ex;
+    int nchunks_ex;
     const double* ex_tau;    // [L]
     const double* ex_width;  // [L]
     const double* eta_t;     // [nt]
     const double* eta;       // [nt]
     int nt;
     double eta_dt;           // nominal spacing of eta_t (search hint only)
-    double* e;               // [Lpad] out: eta(t - tau_j) * width_j
-    int do_excitation;
-    int* error_flag;         // set to 1 if a query time is not bracketed (reference: runtime_error)
-};
-
-// One GEMV launch covers the radiation matrix K[D_local x S*D] and, for irregular waves, the excitation
-// matrix Kex[D_local x Lpad]; a workgroup owns R consecutive rows x one column chunk of one of them and
-// leaves one partial sum per row in `partials[chunk][D_local]`.
-struct ConvArgs {
-    const double* K;
-    size_t ldk;       // row stride of K in doubles (even)
-    const double* u;
-    int F;            // S*D
-    int chunk_cols;   // even
-    int nchunks_rad;
-    const double* Kex;
-    size_t ldkex;     // Lpad
-    const double* e;
-    int Lpad;
-    int chunk_cols_ex;
-    int nchunks_ex;
     double* partials;  // [(nchunks_rad + nchunks_ex)][Dloc]
     int Dloc;
     int nrowtiles;
+    int* error_flag;   // set to 1 / 2 if a query time is not bracketed (reference: runtime_error)
 };
 
 struct FinalizeArgs {
@@ -84,6 +78,10 @@ struct FinalizeArgs {
     double* waves;
     double* total;
     double* user_out;  // may be null
+    // history push of this step's sample into ring slot `head` (src/hydro_forces.cpp:559-574)
+    int do_push, head, D;
+    double* ring_t;
+    double* ring_v;
 };
 
 struct TaperArgs {
@@ -100,7 +98,6 @@ struct TaperArgs {
 
 // ---- launchers (all asynchronous on `stream`) ----
 void launch_relayout_rirf(const double* d_Kb_6xDxS, double* d_K, int D, int S, size_t ldk, int row0, double rho, hipStream_t stream);
-void launch_prep(const PrepArgs& a, hipStream_t stream);
 // rows_per_tile is 6 or 12 (Dloc % rows_per_tile == 0)
 void launch_conv(const ConvArgs& a, int rows_per_tile, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);

@@ -205,7 +205,8 @@ class HydroForces:
         self._chk(self.lib.hc_get_sizes(self.ctx, *[C.byref(x) for x in v]))
         return dict(zip(("N", "n_local", "S", "L", "nf", "nt", "H", "Hcap"), (x.value for x in v)))
 
-    def enable_profiling(self, on=True):
+    def enable_profiling(self, on=1):
+        """on = n > 0: HIP events around the kernels of every n-th step; 0/False: off."""
         self._chk(self.lib.hc_enable_profiling(self.ctx, int(on)))
 
     def reset_profile(self):

@@ -183,7 +183,9 @@ typedef struct hc_profile_stats {
     long long conv_kernel_launches;
     double conv_kernel_bytes;   /* algorithmic bytes one launch streams (8*D_local*D*S + vectors) */
 } hc_profile_stats;
-int hc_enable_profiling(hc_ctx* ctx, int on); /* HIP events around each kernel; off by default */
+/* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default).  Event records
+ * perturb the launch stream by a few microseconds, so throughput runs should sample (e.g. on = 8). */
+int hc_enable_profiling(hc_ctx* ctx, int on);
 int hc_get_profile(hc_ctx* ctx, hc_profile_stats* out);
 int hc_reset_profile(hc_ctx* ctx);
 

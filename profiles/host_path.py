@@ -1,0 +1,62 @@
+"""Host-boundary (PCIe-inclusive) rate of hc_step and small-N latency, beside the CPU oracle on the same box.
+Writes profiles-style JSON to stdout.  Usage: python profiles/host_path.py > gpurun_out/host_path.json"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402,F401
+import oracle as orc_mod  # noqa: E402
+from cases import load_into_oracle, sphere_case  # noqa: E402
+from hydrochrono_amd.hydro import HydroForces  # noqa: E402
+from hydrochrono_amd.mock_chrono import PrescribedMotion  # noqa: E402
+from hydrochrono_amd.synthetic import many_body_case, rest_positions  # noqa: E402
+
+
+def time_steps(obj, motion, t0, dt, n, warm):
+    for k in range(warm):
+        obj.step(t0 + k * dt, *motion.state(t0 + k * dt))
+    states = [motion.state(t0 + (warm + k) * dt) for k in range(n)]
+    a = time.perf_counter()
+    for k in range(n):
+        obj.step(t0 + (warm + k) * dt, *states[k])
+    return (time.perf_counter() - a) / n
+
+
+out = {}
+# C1-like: sphere, regular wave, dt = 0.015 (N = 1: launch/PCIe latency dominates, the CPU is expected to win)
+case = sphere_case()
+gpu, orc = HydroForces.from_case(case), load_into_oracle(case)
+gpu.add_waves_regular(0.177, 2.094395102)
+orc.add_waves_regular(0.177, 2.094395102)
+m = PrescribedMotion(1, [[0, 0, -2.0]], seed=1)
+orc_mod.set_num_threads(1)
+out["sphere_N1_S1001"] = {"gpu_hc_step_us": 1e6 * time_steps(gpu, m, 0.0, 0.015, 3000, 1200),
+                          "cpu_oracle_1thread_us": 1e6 * time_steps(orc, m, 0.0, 0.015, 3000, 1200)}
+# C2-like: two bodies, irregular waves, dt = 0.01
+case = many_body_case(2, S=1001, dt_rirf=0.015, n_exc=1001, dt_exc=0.125, seed=2)
+gpu, orc = HydroForces.from_case(case), load_into_oracle(case)
+kw = dict(simulation_dt=0.01, simulation_duration=100.0, wave_height=2.5, wave_period=8.0, nfrequencies=512,
+          frequency_min=0.02, frequency_max=0.5, peak_enhancement_factor=3.3)
+gpu.add_waves_irregular(**kw)
+orc.add_waves_irregular(**kw)
+m = PrescribedMotion(2, rest_positions(case), seed=2)
+orc_mod.set_num_threads(8)
+out["two_body_irregular_S1001_L12500"] = {"gpu_hc_step_us": 1e6 * time_steps(gpu, m, 0.0, 0.01, 2000, 1600),
+                                          "cpu_oracle_8threads_us": 1e6 * time_steps(orc, m, 0.0, 0.01, 300, 1600)}
+# C3 through the host boundary (pageable pointers in, forces out, synchronous)
+case = many_body_case(64, S=1024, dt_rirf=0.01, n_exc=1024, dt_exc=0.01)
+gpu = HydroForces.from_case(case)
+gpu.add_waves_irregular(simulation_dt=0.01, simulation_duration=60.0, wave_height=2.0, wave_period=8.0, frequency_min=0.02,
+                        frequency_max=0.5, nfrequencies=512, peak_enhancement_factor=3.3)
+m = PrescribedMotion(64, rest_positions(case))
+t_hist = 20.0 - 0.01 * np.arange(1, 1030)
+gpu.set_history(t_hist, np.stack([m.velocity6(t) for t in t_hist]))
+out["c3_host_boundary"] = {"gpu_hc_step_us": 1e6 * time_steps(gpu, m, 20.0, 0.01, 400, 20),
+                           "note": "hc_step: 4 host arrays staged to pinned memory, H2D, 2 kernels, D2H, stream sync per step"}
+print(json.dumps(out, indent=1))

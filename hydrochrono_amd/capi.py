@@ -34,7 +34,9 @@ class ProfileStats(C.Structure):
     _fields_ = [("hydrostatics_seconds", C.c_double), ("radiation_seconds", C.c_double), ("waves_seconds", C.c_double),
                 ("hydrostatics_calls", C.c_int), ("radiation_calls", C.c_int), ("waves_calls", C.c_int),
                 ("conv_kernel_seconds", C.c_double), ("conv_kernel_launches", C.c_longlong),
-                ("conv_kernel_bytes", C.c_double)]
+                ("conv_kernel_bytes", C.c_double), ("block_kernel_seconds", C.c_double),
+                ("block_kernel_launches", C.c_longlong), ("block_kernel_bytes", C.c_double),
+                ("rem_kernel_seconds", C.c_double), ("rem_kernel_launches", C.c_longlong)]
 
 
 # name -> (restype, argtypes); every symbol include/hydrochrono_amd.h declares
@@ -68,6 +70,7 @@ SIGNATURES = {
     "hc_compute_radiation": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p, c_double_p]),
     "hc_compute_hydrostatics": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "hc_compute_waves": (C.c_int, [C.c_void_p, C.c_double, c_double_p]),
+    "hc_set_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
     "hc_reset_history": (C.c_int, [C.c_void_p]),
     "hc_set_history": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p]),
     "hc_get_history": (C.c_int, [C.c_void_p, c_int_p, c_double_p, c_double_p]),

@@ -117,8 +117,16 @@ void profile_drain(hc_ctx* c) {
         // hydrostatics, the regular-wave term and the reduction
         c->prof.radiation_seconds += ms01 * 1e-3;
         c->prof.hydrostatics_seconds += ms12 * 1e-3;
-        c->prof.conv_kernel_seconds += ms01 * 1e-3;
-        c->prof.conv_kernel_launches += 1;
+        if (c->events[i].kind == 1) {  // look-ahead pass (+ its reduction + the excitation chunks of this step)
+            c->prof.block_kernel_seconds += ms01 * 1e-3;
+            c->prof.block_kernel_launches += 1;
+        } else if (c->events[i].kind == 2) {
+            c->prof.rem_kernel_seconds += ms01 * 1e-3;
+            c->prof.rem_kernel_launches += 1;
+        } else {
+            c->prof.conv_kernel_seconds += ms01 * 1e-3;
+            c->prof.conv_kernel_launches += 1;
+        }
     }
     c->events_used = 0;
 }
@@ -138,42 +146,66 @@ hc::EventSet* profile_next(hc_ctx* c) {
     return &c->events[c->events_used++];
 }
 
-// ---- GEMV tiling ------------------------------------------------------------------------------
+// ---- panel geometry and launch tiling ---------------------------------------------------------
+int env_int(const char* name, int fallback) {
+    const char* e = std::getenv(name);  // HC_* variables are tuning knobs for experiments only
+    return e ? std::atoi(e) : fallback;
+}
+
+void setup_panel_geometry(hc_ctx* c) {
+    c->ntiles = (c->Dloc + 15) / 16;
+    c->Dpad   = c->ntiles * 16;
+    c->ngp    = static_cast<int>((static_cast<long long>(c->S) * c->D + 7) / 8);
+    c->mt     = (c->ntiles % 4 == 0) ? 4 : ((c->ntiles % 2 == 0) ? 2 : 1);
+    const int want = env_int("HC_CONV_MT", 0);
+    if ((want == 1 || want == 2 || want == 4) && c->ntiles % want == 0) c->mt = want;
+    c->ngroups = c->ntiles / c->mt;
+}
+
+hc::Panel rad_panel(const hc_ctx* c) {
+    hc::Panel p;
+    p.base   = (c->conv_mode == 1) ? c->dKproc.p : c->dK.p;
+    p.ntiles = c->ntiles;
+    p.ngp    = c->ngp;
+    return p;
+}
+
 void choose_conv_config(hc_ctx* c) {
-    c->rows_per_tile = (c->Dloc % 12 == 0) ? 12 : 6;
-    c->nrowtiles     = c->Dloc / c->rows_per_tile;
-    const long long F = static_cast<long long>(c->S) * c->D;
-    // aim for >= 8 workgroups per CU (256 CUs); a chunk is a multiple of 512 columns (one pass of 256 lanes x 2)
-    int target_wgs = 4096;
-    if (const char* e = std::getenv("HC_CONV_TARGET_WGS")) target_wgs = std::max(1, std::atoi(e));  // tuning experiments only
-    if (const char* e = std::getenv("HC_CONV_ROWS")) {
-        const int r = std::atoi(e);
-        if ((r == 6 || r == 12) && c->Dloc % r == 0) {
-            c->rows_per_tile = r;
-            c->nrowtiles     = c->Dloc / r;
-        }
-    }
-    long long nch        = std::max<long long>(1, target_wgs / std::max(1, c->nrowtiles));
-    long long cols       = (F + nch - 1) / nch;
-    cols                 = std::max<long long>(512, ((cols + 511) / 512) * 512);
-    c->chunk_cols        = static_cast<int>(cols);
-    c->nchunks_rad       = static_cast<int>((F + cols - 1) / cols);
+    // plain per-step kernel: aim for >= 16 workgroups per CU (256 CUs); a chunk is a whole number of 8-column groups
+    const int target_wgs = std::max(1, env_int("HC_CONV_TARGET_WGS", 4096));
+    long long nch        = std::max<long long>(1, target_wgs / std::max(1, c->ngroups));
+    long long gps        = (c->ngp + nch - 1) / nch;
+    gps                  = std::max<long long>(16, ((gps + 3) / 4) * 4);  // every wave of the workgroup gets work
+    c->chunk_gp          = static_cast<int>(gps);
+    c->nchunks_rad       = static_cast<int>((c->ngp + gps - 1) / gps);
+    // look-ahead pass: fewer, longer chunks (its partials are 16x larger); bracket table [samples][16] must fit in LDS
+    long long bgps = std::max(8, env_int("HC_BLOCK_CHUNK_GP", 192));
+    const long long cap = std::max<long long>(8, (64LL * c->D) / 8);
+    bgps                = std::min(bgps, cap);
+    bgps                = ((bgps + 3) / 4) * 4;
+    c->chunk_gp_block   = static_cast<int>(bgps);
+    c->nchunks_block    = static_cast<int>((c->ngp + bgps - 1) / bgps);
+    // remainder of a look-ahead step: at most 16 samples wide
+    c->chunk_gp_rem = std::max(4, env_int("HC_REM_CHUNK_GP", 64));
 }
 
 void choose_exc_config(hc_ctx* c) {
     if (c->wave_kind != hc::kWaveIrregular || c->L == 0) {
-        c->nchunks_ex = 0;
-        c->chunk_cols_ex = 512;
+        c->nchunks_ex  = 0;
+        c->chunk_gp_ex = 64;
         return;
     }
-    long long cols   = 2048;
-    c->chunk_cols_ex = static_cast<int>(cols);
-    c->nchunks_ex    = static_cast<int>((c->Lpad + cols - 1) / cols);
+    c->chunk_gp_ex = 256;
+    c->nchunks_ex  = (c->ngp_ex + c->chunk_gp_ex - 1) / c->chunk_gp_ex;
 }
 
 void alloc_partials(hc_ctx* c) {
-    const size_t n = static_cast<size_t>(c->nchunks_rad + c->nchunks_ex) * c->Dloc;
+    const int rem_chunks = (c->ngp + c->chunk_gp_rem - 1) / c->chunk_gp_rem + 1;  // worst case: remainder spans all of K
+    const size_t n = static_cast<size_t>(std::max(c->nchunks_rad, rem_chunks) + c->nchunks_ex) * c->Dpad;
     if (c->d_partials.n < n) c->d_partials.alloc(n);
+    const size_t nb = static_cast<size_t>(c->nchunks_block) * hc::kLookahead * c->Dpad;
+    if (c->d_partials_block.n < nb) c->d_partials_block.alloc(nb);
+    if (c->d_P.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_P.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
 }
 
 // ---- TaperedDirect ----------------------------------------------------------------------------
@@ -191,11 +223,16 @@ void ensure_processed(hc_ctx* c) {
     int tc_end   = static_cast<int>(std::floor(c->taper.taper_end_percent * static_cast<double>(effective)));
     tc_index     = std::max(0, std::min(tc_index, effective));
     tc_end       = std::max(tc_index, std::min(tc_end, effective));
-    if (c->dKproc.n != c->dK.n) c->dKproc.alloc(c->dK.n);
+    HC_HIP(hipDeviceSynchronize());  // once per option change; orders against steps on a caller's stream
+    if (c->dKproc.n != c->dK.n) {
+        c->dKproc.alloc(c->dK.n);
+        HC_HIP(hipMemsetAsync(c->dKproc.p, 0, c->dKproc.n * sizeof(double), c->stream));
+    }
     hc::TaperArgs a{};
-    a.Kraw            = c->dK.p;
+    a.Kraw.base       = c->dK.p;
+    a.Kraw.ntiles     = c->ntiles;
+    a.Kraw.ngp        = c->ngp;
     a.Kproc           = c->dKproc.p;
-    a.ldk             = c->ldk;
     a.Dloc            = c->Dloc;
     a.D               = c->D;
     a.S               = c->S;
@@ -205,11 +242,11 @@ void ensure_processed(hc_ctx* c) {
     a.tc_index        = tc_index;
     a.tc_end          = tc_end;
     a.final_amplitude = c->taper.taper_final_amplitude;
-    HC_HIP(hipDeviceSynchronize());  // once per option change; orders against steps on a caller's stream
     hc::launch_taper(a, c->stream);
     HC_HIP(hipGetLastError());
     HC_HIP(hipStreamSynchronize(c->stream));
     c->proc_ready = true;
+    c->plan.valid = false;
 }
 
 // ---- the step ---------------------------------------------------------------------------------
@@ -233,45 +270,133 @@ void check_wave_ready(hc_ctx* c, double t) {
     }
 }
 
-// Enqueue conv -> finalize for time t. d_state: device pointer to the 12N state. user_out may be null.
+// Look-ahead bookkeeping.  Decides how the radiation term of the step at time t is evaluated:
+//   0 = plain (whole K this step), 1 = boundary (blocked pass over K covering this and the next 15 predicted steps),
+//   2 = inside a block (precomputed part P[j] + remainder over the newest samples).
+int plan_step(hc_ctx* c, double t, int H) {
+    auto& pl = c->plan;
+    if (H < 2) return 0;
+    if (c->lookahead <= 0) return 0;
+    if (pl.cooldown > 0) {
+        --pl.cooldown;
+        return 0;
+    }
+    if (pl.valid && pl.j_next < hc::kLookahead) {
+        if (std::fabs(t - pl.tpred[pl.j_next]) <= 1e-9 * pl.dt) return 2;
+        // the caller left the predicted time grid (variable step): drop the block
+        pl.valid = false;
+        if (++pl.misses >= 2) {
+            pl.misses   = 0;
+            pl.cooldown = 64;  // irregular stepping: plain steps for a while, then try again
+            return 0;
+        }
+    } else if (pl.valid) {
+        pl.misses = 0;  // a block was consumed completely
+    }
+    const double dt = c->times[0] - c->times[1];
+    if (!(dt > 0.0)) return 0;
+    pl.valid  = true;
+    pl.t0     = t;
+    pl.dt     = dt;
+    pl.j_next = 1;
+    for (int j = 0; j < hc::kLookahead; ++j) {
+        pl.tpred[j] = (j == 0) ? t : t + j * dt;
+        // samples s >= s_cut[j] of step j need only history known now: tpred[j] - tau_s <= t (same expression as the kernel)
+        int sc = 0;
+        while (sc < c->S && !(pl.tpred[j] - c->tau[sc] <= t)) ++sc;
+        pl.s_cut[j] = sc;
+    }
+    if (pl.s_cut[hc::kLookahead - 1] > c->S / 4) {
+        // step size comparable to the IRF window: the remainder would re-read most of K every step, so blocking cannot pay
+        pl.valid    = false;
+        pl.cooldown = 256;
+        return 0;
+    }
+    return 1;
+}
+
+// Enqueue the kernels of one evaluation at time t. d_state: device pointer to the 12N state. user_out may be null.
 void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f) {
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     const bool irregular = c->wave_kind == hc::kWaveIrregular;
     if (f.waves) check_wave_ready(c, t);
-    int H = 0;
+    int H = 0, mode = 0;
     if (f.rad) {
         ensure_processed(c);
-        H = history_push(c, t);
+        H    = history_push(c, t);
+        mode = plan_step(c, t, H);
     }
     const bool run_rad = f.rad && H >= 2;  // "Nothing to convolve with if we don't yet have at least 2 time points" (:580)
     const bool run_exc = f.waves && irregular;
     hc::EventSet* ev = profile_next(c);
+    if (ev) ev->kind = mode;
 
-    hc::ConvArgs a{};
-    a.K                   = (c->conv_mode == 1) ? c->dKproc.p : c->dK.p;
-    a.ldk                 = c->ldk;
-    a.F                   = c->S * c->D;
-    a.chunk_cols          = c->chunk_cols;
-    a.nchunks_rad         = run_rad ? c->nchunks_rad : 0;
-    a.max_steps_per_chunk = c->chunk_cols / c->D + 2;
-    a.hist.state          = d_state;
-    a.hist.N              = c->N;
-    a.hist.D              = c->D;
-    a.hist.t              = t;
-    a.hist.ring_t         = c->d_ring_t.p;
-    a.hist.ring_v         = c->d_ring_v.p;
-    a.hist.head           = c->head;
-    a.hist.H              = H;
-    a.hist.Hcap           = c->Hcap;
-    a.hist.dt_hint        = (H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
-    a.S                   = c->S;
+    hc::HistoryView hv{};
+    hv.state   = d_state;
+    hv.N       = c->N;
+    hv.D       = c->D;
+    hv.t       = t;
+    hv.ring_t  = c->d_ring_t.p;
+    hv.ring_v  = c->d_ring_v.p;
+    hv.head    = c->head;
+    hv.H       = H;
+    hv.Hcap    = c->Hcap;
+    hv.dt_hint = (H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
+
+    if (ev) HC_HIP(hipEventRecord(ev->e[0], stream));
+    const double* P_row = nullptr;
+    int j_block = 0;
+    if (run_rad && mode == 1) {
+        hc::BlockArgs b{};
+        b.K                   = rad_panel(c);
+        b.F                   = c->S * c->D;
+        b.chunk_gp            = c->chunk_gp_block;
+        b.nchunks             = c->nchunks_block;
+        b.max_steps_per_chunk = (c->chunk_gp_block * 8) / c->D + 2;
+        b.hist                = hv;
+        for (int j = 0; j < hc::kLookahead; ++j) {
+            b.tpred[j] = c->plan.tpred[j];
+            b.s_cut[j] = c->plan.s_cut[j];
+        }
+        b.tau        = c->d_tau.p;
+        b.width      = c->d_width.p;
+        b.partials   = c->d_partials_block.p;
+        b.Dpad       = c->Dpad;
+        b.ngroups    = c->ngroups;
+        b.error_flag = c->d_err.p;
+        hc::launch_conv_block(b, c->mt, stream);
+        hc::launch_reduce_block(c->d_partials_block.p, c->nchunks_block, c->Dpad, c->d_P.p, stream);
+        P_row = c->d_P.p;
+    } else if (run_rad && mode == 2) {
+        j_block = c->plan.j_next++;
+        P_row   = c->d_P.p + static_cast<size_t>(j_block) * c->Dpad;
+    }
+
+    // per-step kernel: radiation columns still to do this step + excitation chunks
+    int F_limit = 0, chunk_gp = c->chunk_gp, nchunks_rad = 0;
+    if (run_rad && mode == 0) {
+        F_limit     = c->S * c->D;
+        nchunks_rad = c->nchunks_rad;
+    } else if (run_rad && mode == 2) {
+        F_limit           = c->plan.s_cut[j_block] * c->D;
+        chunk_gp          = c->chunk_gp_rem;
+        const int ngp_lim = (F_limit + 7) / 8;
+        nchunks_rad       = (ngp_lim + chunk_gp - 1) / chunk_gp;
+    }
+    hc::StepArgs a{};
+    a.K                   = rad_panel(c);
+    a.F_limit             = F_limit;
+    a.chunk_gp            = chunk_gp;
+    a.nchunks_rad         = nchunks_rad;
+    a.max_steps_per_chunk = (chunk_gp * 8) / c->D + 2;
+    a.hist                = hv;
     a.tau                 = c->d_tau.p;
     a.width               = c->d_width.p;
-    a.Kex                 = c->d_kex.p;
-    a.ldkex               = static_cast<size_t>(c->Lpad);
+    a.Kex.base            = c->d_kex.p;
+    a.Kex.ntiles          = c->ntiles;
+    a.Kex.ngp             = c->ngp_ex;
     a.L                   = c->L;
-    a.Lpad                = c->Lpad;
-    a.chunk_cols_ex       = c->chunk_cols_ex;
+    a.chunk_gp_ex         = c->chunk_gp_ex;
     a.nchunks_ex          = run_exc ? c->nchunks_ex : 0;
     a.ex_tau              = c->d_ex_tau.p;
     a.ex_width            = c->d_ex_width.p;
@@ -280,18 +405,19 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     a.nt                  = c->nt;
     a.eta_dt              = irregular ? c->irr.simulation_dt : 1.0;
     a.partials            = c->d_partials.p;
-    a.Dloc                = c->Dloc;
-    a.nrowtiles           = c->nrowtiles;
+    a.Dpad                = c->Dpad;
+    a.ngroups             = c->ngroups;
     a.error_flag          = c->d_err.p;
-    if (ev) HC_HIP(hipEventRecord(ev->e[0], stream));
-    hc::launch_conv(a, c->rows_per_tile, stream);
+    hc::launch_conv_step(a, c->mt, stream);
     if (ev) HC_HIP(hipEventRecord(ev->e[1], stream));
 
     hc::FinalizeArgs z{};
     z.partials    = c->d_partials.p;
     z.nchunks_rad = a.nchunks_rad;
     z.nchunks_ex  = a.nchunks_ex;
+    z.P           = P_row;
     z.Dloc        = c->Dloc;
+    z.Dpad        = c->Dpad;
     z.N           = c->N;
     z.b0          = c->b0;
     z.state       = d_state;
@@ -473,8 +599,9 @@ int hc_set_rirf(hc_ctx* c, int body, const double* t, int S, const double* K) {
     if (c->S == 0) {
         c->S = S;
         c->tau.assign(t, t + S);
-        c->ldk = static_cast<size_t>(S) * c->D;
-        c->dK.alloc(static_cast<size_t>(c->Dloc) * c->ldk);
+        setup_panel_geometry(c);
+        c->dK.alloc(hc::panel_doubles(c->ntiles, c->ngp));
+        HC_HIP(hipMemsetAsync(c->dK.p, 0, c->dK.n * sizeof(double), c->stream));  // padding rows / columns stay zero
         c->d_stage.alloc(static_cast<size_t>(6) * c->D * S);
     } else {
         require(S == c->S, HC_ERR_RUNTIME, "RIRF time vectors have to be exactly the same for all bodies (length differs)");
@@ -485,7 +612,7 @@ int hc_set_rirf(hc_ctx* c, int body, const double* t, int S, const double* K) {
     c->bodies[body].have_rirf = true;
     if (is_local(c, body)) {
         HC_HIP(hipMemcpyAsync(c->d_stage.p, K, static_cast<size_t>(6) * c->D * S * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        hc::launch_relayout_rirf(c->d_stage.p, c->dK.p, c->D, S, c->ldk, 6 * (body - c->b0), c->rho, c->stream);
+        hc::launch_relayout_rirf(c->d_stage.p, c->dK.p, c->ngp, c->D, S, 6 * (body - c->b0), c->rho, c->stream);
         HC_HIP(hipGetLastError());
         HC_HIP(hipStreamSynchronize(c->stream));
         c->proc_ready = false;
@@ -612,7 +739,10 @@ int hc_finalize(hc_ctx* c) {
     c->wave_nb_arg = c->N;
     choose_exc_config(c);
     alloc_partials(c);
-    c->prof.conv_kernel_bytes = 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
+    c->prof.conv_kernel_bytes  = 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
+    c->prof.block_kernel_bytes = hc::kLookahead * c->prof.conv_kernel_bytes;
+    c->lookahead               = env_int("HC_LOOKAHEAD", hc::kLookahead) > 0 ? hc::kLookahead : 0;
+    c->plan                    = hc::Plan{};
     HC_HIP(hipStreamSynchronize(c->stream));
     c->finalized = true;
     HC_API_END(c)
@@ -717,17 +847,13 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     require(L >= 2, HC_ERR_INVALID, "excitation IRF resamples to fewer than two points");
     std::vector<double> ex_tau   = hc::linspaced(L, t0, t1);
     std::vector<double> ex_width = hc::trapezoid_widths(ex_tau);
-    const int Lpad = (L + 1) & ~1;
+    const int Lpad = (L + 7) & ~7;
     std::vector<double> vals(static_cast<size_t>(c->Dloc) * L);
-    std::vector<double> kex(static_cast<size_t>(c->Dloc) * Lpad, 0.0);
     for (int bl = 0; bl < c->nloc; ++bl) {
         const auto r = hc::resample_cubic_bspline6(c->bodies[c->b0 + bl].exirf_f, n_old, L);
-        for (int d = 0; d < 6; ++d) {
+        for (int d = 0; d < 6; ++d)
             std::copy(r.begin() + static_cast<size_t>(d) * L, r.begin() + static_cast<size_t>(d + 1) * L,
                       vals.begin() + static_cast<size_t>(6 * bl + d) * L);
-            std::copy(r.begin() + static_cast<size_t>(d) * L, r.begin() + static_cast<size_t>(d + 1) * L,
-                      kex.begin() + static_cast<size_t>(6 * bl + d) * Lpad);
-        }
     }
     // CreateSpectrum (:643-676)
     int nf;
@@ -775,7 +901,16 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     HC_HIP(hipMemcpyAsync(eta.data(), c->d_eta.p, nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));
 
-    c->d_kex.upload(kex, c->stream);
+    {   // excitation IRF into the same panel layout as K (row tiles of 16, column groups of 8)
+        hc::DeviceBuffer<double> d_rowmajor;
+        d_rowmajor.upload(vals, c->stream);
+        c->ngp_ex = Lpad / 8;
+        c->d_kex.alloc(hc::panel_doubles(c->ntiles, c->ngp_ex));
+        HC_HIP(hipMemsetAsync(c->d_kex.p, 0, c->d_kex.n * sizeof(double), c->stream));
+        hc::launch_relayout_rowmajor(d_rowmajor.p, c->Dloc, L, c->d_kex.p, c->ngp_ex, 0, c->stream);
+        HC_HIP(hipGetLastError());
+        HC_HIP(hipStreamSynchronize(c->stream));
+    }
     c->d_ex_tau.upload(ex_tau, c->stream);
     c->d_ex_width.upload(ex_width, c->stream);
     c->d_e.alloc(Lpad);
@@ -801,6 +936,7 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     alloc_partials(c);
     c->prof.conv_kernel_bytes = 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D +
                                        static_cast<double>(c->Dloc) * L + L);
+    c->prof.block_kernel_bytes = hc::kLookahead * 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
     HC_HIP(hipStreamSynchronize(c->stream));
     HC_API_END(c)
 }
@@ -808,7 +944,8 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
 int hc_set_convolution_mode(hc_ctx* c, int mode) {
     HC_API_BEGIN(c)
     require(mode == 0 || mode == 1, HC_ERR_INVALID, "mode must be 0 (Baseline) or 1 (TaperedDirect)");
-    c->conv_mode = mode;
+    c->conv_mode  = mode;
+    c->plan.valid = false;
     HC_API_END(c)
 }
 
@@ -828,6 +965,7 @@ int hc_set_tapered_direct_options(hc_ctx* c, const hc_tapered_direct_options* o)
     require(o->smoothing == 0 || o->smoothing == 1, HC_ERR_INVALID, "smoothing must be 0 (sg) or 1 (moving_average)");
     c->taper      = *o;
     c->proc_ready = false;
+    c->plan.valid = false;
     HC_API_END(c)
 }
 
@@ -928,6 +1066,13 @@ int hc_compute_waves(hc_ctx* c, double t, double* waves_out) {
     HC_API_END(c)
 }
 
+int hc_set_lookahead(hc_ctx* c, int steps) {
+    HC_API_BEGIN(c)
+    c->lookahead = steps > 0 ? hc::kLookahead : 0;
+    c->plan      = hc::Plan{};
+    HC_API_END(c)
+}
+
 int hc_reset_history(hc_ctx* c) {
     HC_API_BEGIN(c)
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
@@ -936,6 +1081,7 @@ int hc_reset_history(hc_ctx* c) {
     c->head = -1;
     c->have_prev = false;
     c->prev_time = -1.0;
+    c->plan = hc::Plan{};
     HC_API_END(c)
 }
 
@@ -958,6 +1104,7 @@ int hc_set_history(hc_ctx* c, int n, const double* times, const double* vel) {
         HC_HIP(hipMemcpy(c->d_ring_v.p, vv.data(), vv.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     c->head      = n - 1;
+    c->plan      = hc::Plan{};
     c->have_prev = n > 0;
     c->prev_time = n > 0 ? times[0] : -1.0;
     HC_API_END(c)
@@ -1028,9 +1175,10 @@ int hc_get_profile(hc_ctx* c, hc_profile_stats* out) {
 int hc_reset_profile(hc_ctx* c) {
     HC_API_BEGIN(c)
     profile_drain(c);
-    const double bytes = c->prof.conv_kernel_bytes;
+    const double bytes = c->prof.conv_kernel_bytes, bbytes = c->prof.block_kernel_bytes;
     c->prof = hc_profile_stats{};
-    c->prof.conv_kernel_bytes = bytes;
+    c->prof.conv_kernel_bytes  = bytes;
+    c->prof.block_kernel_bytes = bbytes;
     HC_API_END(c)
 }
 
@@ -1061,7 +1209,7 @@ int hc_get_rirf_effective(hc_ctx* c, double* out) {
     const size_t n = static_cast<size_t>(c->Dloc) * c->D * c->S;
     hc::DeviceBuffer<double> tmp;
     tmp.alloc(n);
-    hc::launch_unrelayout(c->conv_mode == 1 ? c->dKproc.p : c->dK.p, c->ldk, c->Dloc, c->D, c->S, tmp.p, c->stream);
+    hc::launch_unrelayout(rad_panel(c), c->Dloc, c->D, c->S, tmp.p, c->stream);
     HC_HIP(hipGetLastError());
     HC_HIP(hipMemcpyAsync(out, tmp.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));
@@ -1124,9 +1272,9 @@ int hc_synth_fill(hc_ctx* c, unsigned long long seed, int S, double dt_rirf, int
     c->S = S;
     c->tau.resize(S);
     for (int s = 0; s < S; ++s) c->tau[s] = s * dt_rirf;
-    c->ldk = static_cast<size_t>(S) * c->D;
-    c->dK.alloc(static_cast<size_t>(c->Dloc) * c->ldk);
-    hc::launch_synth_rirf(c->dK.p, c->ldk, c->Dloc, c->D, S, 6 * c->b0, dt_rirf, seed, c->rho, c->stream);
+    setup_panel_geometry(c);
+    c->dK.alloc(hc::panel_doubles(c->ntiles, c->ngp));
+    hc::launch_synth_rirf(c->dK.p, c->ntiles, c->ngp, c->Dloc, c->D, S, 6 * c->b0, dt_rirf, seed, c->rho, c->stream);
     HC_HIP(hipGetLastError());
     // small per-body tables from the same counter-based stream, on the host
     auto mix = [](uint64_t x) {

@@ -89,6 +89,18 @@ enum WaveKind { kWaveNone = 0, kWaveRegular = 1, kWaveIrregular = 2 };
 
 struct EventSet {
     hipEvent_t e[3];
+    int kind = 0;  // 0 plain step, 1 look-ahead boundary step, 2 step inside a look-ahead block
+};
+
+// Look-ahead plan: a blocked pass at time t0 has precomputed, for the predicted steps tpred[j] = t0 + j*dt, the part of
+// the radiation sum that only needs history known at t0 (IRF samples s >= s_cut[j]).
+struct Plan {
+    bool valid = false;
+    double t0 = 0.0, dt = 0.0;
+    int j_next = 0;
+    double tpred[kLookahead] = {0};
+    int s_cut[kLookahead]    = {0};
+    int misses = 0, cooldown = 0;
 };
 
 }  // namespace hc
@@ -107,7 +119,7 @@ struct hc_ctx {
     int S = 0;
     std::vector<double> tau, width;
     hc::DeviceBuffer<double> dK, dKproc, d_tau, d_width, d_stage;
-    size_t ldk = 0;
+    int ntiles = 0, Dpad = 0, ngp = 0, mt = 1, ngroups = 0;  // panel geometry (hc_kernels.hpp)
     int conv_mode = 0;
     bool proc_ready = false;
     hc_tapered_direct_options taper{};
@@ -138,9 +150,11 @@ struct hc_ctx {
     hc::DeviceBuffer<double> d_kex, d_ex_tau, d_ex_width, d_eta_t, d_eta, d_e;
 
     // GEMV configuration + scratch
-    int rows_per_tile = 6, nrowtiles = 0;
-    int chunk_cols = 0, nchunks_rad = 0, chunk_cols_ex = 0, nchunks_ex = 0;
-    hc::DeviceBuffer<double> d_partials;
+    int chunk_gp = 0, nchunks_rad = 0, chunk_gp_ex = 0, nchunks_ex = 0, ngp_ex = 0;
+    int chunk_gp_block = 0, nchunks_block = 0, chunk_gp_rem = 64;
+    hc::DeviceBuffer<double> d_partials, d_partials_block, d_P;
+    int lookahead = 0;  // 0: off, else kLookahead
+    hc::Plan plan;
 
     // step I/O
     hc::DeviceBuffer<double> d_state, d_hs, d_rad, d_waves, d_total;

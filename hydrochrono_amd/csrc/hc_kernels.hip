@@ -1,13 +1,15 @@
 // hc_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the hydro-force path.
 //
-// Per step two launches run back to back on one stream:
-//   conv_kernel      the Cummins convolution as a streamed FP64 GEMV  partial[chunk][row] = K[row, chunk] . u[chunk]
-//                    (HBM-bound: K is read exactly once, 16 B per lane, fully coalesced).  u[s][col] -- the body
-//                    velocity history interpolated at t - tau_s, times the trapezoid width -- is formed in registers
-//                    from the velocity ring via a per-workgroup bracket table in LDS; the irregular-wave excitation
-//                    Kex . eta(t - tau_j) rides in the same launch as extra column chunks.
-//   finalize_kernel  fixed-order reduction of the partials, hydrostatics, regular-wave term,
-//                    total = hydrostatic - radiation + waves, velocity-ring push of this step's sample
+// Steady state, per step:
+//   plain step      conv_step_kernel (all of K, streamed FP64 GEMV)            -> finalize_kernel
+//   look-ahead      every 16th step: conv_block_kernel (K read ONCE for 16 steps, FP64 MFMA GEMM) -> reduce_block_kernel,
+//                   every step:      conv_step_kernel over the few newest IRF samples only        -> finalize_kernel
+// conv_step_kernel  partial[chunk][row] = K[row, chunk] . u[chunk]; u[s][col] -- the body velocity history interpolated
+//                   at t - tau_s, times the trapezoid width -- is formed in registers from the velocity ring via a
+//                   per-workgroup bracket table in LDS; the irregular-wave excitation Kex . eta(t - tau_j) rides in the
+//                   same launch as extra column chunks.  HBM-bound: K is read exactly once, 16 B per lane, coalesced.
+// finalize_kernel   fixed-order reduction of the partials (+ the look-ahead part), hydrostatics, regular-wave term,
+//                   total = hydrostatic - radiation + waves, velocity-ring push of this step's sample.
 // Reference semantics: src/hydro_forces.cpp:263-322,537-691,727-767; src/wave_types.cpp:315-327,776-844.
 #include "hc_kernels.hpp"
 
@@ -19,97 +21,88 @@ namespace hc {
 static constexpr int kConvThreads = 256;  // 4 waves of 64
 static constexpr int kWave        = 64;
 
-// ------------------------------------------------------------------------------------------------
-// K re-layout at ingest: file order [i][col][s] (s fastest) -> HBM order [row][s][col] (col fastest) so that
-// the (s,col) axis the per-step GEMV contracts over is contiguous.  32x32 LDS-tiled transpose; rho folded in
-// (HydroData::GetRIRFVal, src/h5fileinfo.cpp:321-323).
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) relayout_rirf_kernel(const double* __restrict__ Kb, double* __restrict__ K, int D, int S,
-                                                             size_t ldk, int row0, double rho) {
-    __shared__ double tile[32][33];
-    const int i    = blockIdx.z;          // DoF row of this body, 0..5
-    const int col0 = blockIdx.x * 32;
-    const int s0   = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    const double* src = Kb + (size_t)i * D * S;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = col0 + ty + 8 * k, s = s0 + tx;
-        if (c < D && s < S) tile[ty + 8 * k][tx] = src[(size_t)c * S + s];
-    }
-    __syncthreads();
-    double* dst = K + (size_t)(row0 + i) * ldk;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int s = s0 + ty + 8 * k, c = col0 + tx;
-        if (c < D && s < S) dst[(size_t)s * D + c] = tile[tx][ty + 8 * k] * rho;
-    }
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+typedef double dvec4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline size_t panel_offset(int ngp, int row, int f) {
+    const int rt = row >> 4, ri = row & 15, gp = f >> 3, j = (f >> 2) & 1, kk = f & 3;
+    return ((static_cast<size_t>(rt) * ngp + gp) * 64 + (kk * 16 + ri)) * 2 + j;
 }
 
-void launch_relayout_rirf(const double* d_Kb, double* d_K, int D, int S, size_t ldk, int row0, double rho, hipStream_t stream) {
-    dim3 grid((D + 31) / 32, (S + 31) / 32, 6);
-    hipLaunchKernelGGL(relayout_rirf_kernel, grid, dim3(256), 0, stream, d_Kb, d_K, D, S, ldk, row0, rho);
+// ------------------------------------------------------------------------------------------------
+// Ingest re-layout: BEMIO file order [i][col][s] (s fastest) -> panel order, rho folded in
+// (HydroData::GetRIRFVal, src/h5fileinfo.cpp:321-323).  Init-time; one thread per element of the body's 6 rows.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) relayout_rirf_kernel(const double* __restrict__ Kb, double* __restrict__ K, int ngp, int D, int S,
+                                                             int row0, double scale) {
+    const size_t F   = (size_t)S * D;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 6 * F) return;
+    const int i   = (int)(gid / F);
+    const int f   = (int)(gid % F);
+    const int s   = f / D, col = f - s * D;
+    K[panel_offset(ngp, row0 + i, f)] = Kb[((size_t)i * D + col) * S + s] * scale;
 }
 
-__global__ void __launch_bounds__(256) unrelayout_kernel(const double* __restrict__ K, size_t ldk, int Dloc, int D, int S,
-                                                          double* __restrict__ out) {
+void launch_relayout_rirf(const double* d_Kb, double* d_K, int ngp, int D, int S, int row0, double scale, hipStream_t stream) {
+    const size_t n = (size_t)6 * S * D;
+    hipLaunchKernelGGL(relayout_rirf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_Kb, d_K, ngp, D, S, row0, scale);
+}
+
+__global__ void __launch_bounds__(256) relayout_rowmajor_kernel(const double* __restrict__ src, int rows, int cols, double* __restrict__ dst,
+                                                                 int ngp, int row0) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)rows * cols) return;
+    const int r = (int)(gid / cols), c = (int)(gid % cols);
+    dst[panel_offset(ngp, row0 + r, c)] = src[gid];
+}
+
+void launch_relayout_rowmajor(const double* d_src, int rows, int cols, double* d_panel, int ngp, int row0, hipStream_t stream) {
+    const size_t n = (size_t)rows * cols;
+    hipLaunchKernelGGL(relayout_rowmajor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_src, rows, cols, d_panel, ngp, row0);
+}
+
+__global__ void __launch_bounds__(256) unrelayout_kernel(Panel K, int Dloc, int D, int S, double* __restrict__ out) {
     const size_t n   = (size_t)Dloc * D * S;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n) return;
     const int s   = (int)(gid % S);
     const int col = (int)((gid / S) % D);
     const int row = (int)(gid / ((size_t)S * D));
-    out[gid]      = K[(size_t)row * ldk + (size_t)s * D + col];
+    out[gid]      = K.base[panel_offset(K.ngp, row, s * D + col)];
 }
 
-void launch_unrelayout(const double* d_K, size_t ldk, int Dloc, int D, int S, double* d_out, hipStream_t stream) {
+void launch_unrelayout(const Panel& K, int Dloc, int D, int S, double* d_out, hipStream_t stream) {
     const size_t n = (size_t)Dloc * D * S;
-    hipLaunchKernelGGL(unrelayout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_K, ldk, Dloc, D, S, d_out);
+    hipLaunchKernelGGL(unrelayout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, K, Dloc, D, S, d_out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// History access and the bracket search shared by both convolution kernels.
+// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double state_velocity(const double* __restrict__ state, int N, int col) {
     const int b = col / 6, d = col - 6 * b;
     return d < 3 ? state[6 * N + 3 * b + d] : state[9 * N + 3 * b + (d - 3)];
 }
 
-// ------------------------------------------------------------------------------------------------
-// conv_kernel<R>: the dominant kernel.  HBM-bound FP64 GEMV, 0.25 flop/B.
-//   grid   = nrowtiles * (nchunks_rad + nchunks_ex) workgroups of 4 waves
-//   each lane streams 16-byte pieces of R rows (R independent global_load_dwordx4 in flight per column block,
-//   straight to VGPRs -- no LDS round trip for data that is used once), multiplies with the matching pair of the
-//   right-hand side and keeps R FP64 accumulators; a wave64 xor-shuffle tree and a 4-entry LDS step reduce them in
-//   a FIXED order, so results are bitwise reproducible run to run.
-//   Right-hand side of a radiation chunk: for every IRF sample s the chunk touches, one thread finds the history
-//   bracket (AdvanceToBracket) and the interpolation weights (InterpolateVelocity6D, src/hydro_forces.cpp:343-381)
-//   into an LDS table; each lane then forms u = (w_older*v_older + w_newer*v_newer) * width_s for its two columns
-//   from two 16-byte ring loads (L2 hits).  Right-hand side of an excitation chunk: eta(t - tau_j), linearly
-//   interpolated in the precomputed table (src/wave_types.cpp:797-831), times width_j.
-// ------------------------------------------------------------------------------------------------
-typedef double dvec2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
-}
-
-struct Bracket {
-    double wo, wn, width;  // weights of the older / newer sample, trapezoid width
-    int slot_older;        // ring slot of the older sample
-    int slot_newer;        // ring slot of the newer sample, -1: the newer sample is the current state
-};
-
 __device__ __forceinline__ double hist_time(const HistoryView& h, int k) {
     return k == 0 ? h.t : h.ring_t[(h.head - k + h.Hcap) % h.Hcap];
 }
 
-// smallest i in [0, H-2] with time(i+1) <= q ; i == H-1 means "no older sample" (the step contributes nothing).
-__device__ Bracket find_bracket(const HistoryView& h, double tau_s, double width_s, int* error_flag) {
-    const double q = h.t - tau_s;
+struct Bracket {
+    double wo, wn;   // weights of the older / newer sample (both 0: the sample contributes nothing)
+    int slot_older;  // ring slot of the older sample
+    int slot_newer;  // ring slot of the newer sample, -1: the newer sample is the current state
+};
+
+// AdvanceToBracket + InterpolateVelocity6D weights (src/hydro_forces.cpp:343-381) for a query time q <= h.t against
+// the history whose newest sample (k = 0) is the current state at h.t.  Finds the smallest i in [0, H-2] with
+// time(i+1) <= q; i == H-1 means "no older sample" and the IRF step contributes nothing (:604-606).
+__device__ Bracket find_bracket(const HistoryView& h, double q, int* error_flag) {
     int lo = 0, hi = h.H - 1;
     if (h.H >= 3) {
-        // histories are close to uniformly spaced: try the index the previous step size predicts first
-        int gi = (int)(tau_s / h.dt_hint) - 1;
+        // histories are close to uniformly spaced: try the index the last step size predicts, then fall back
+        int gi = (int)((h.t - q) / h.dt_hint) - 1;
         gi     = max(0, min(gi, h.H - 2));
 #pragma unroll 1
         for (int k = 0; k < 3; ++k, ++gi) {
@@ -122,11 +115,8 @@ __device__ Bracket find_bracket(const HistoryView& h, double tau_s, double width
         if (hist_time(h, mid + 1) <= q) hi = mid; else lo = mid + 1;
     }
     Bracket b;
-    b.width = width_s;
-    if (lo >= h.H - 1) {  // not enough older history (src/hydro_forces.cpp:604-606)
-        b.wo = 0.0; b.wn = 0.0; b.slot_older = 0; b.slot_newer = 0;
-        return b;
-    }
+    b.wo = 0.0; b.wn = 0.0; b.slot_older = 0; b.slot_newer = 0;
+    if (lo >= h.H - 1) return b;
     const double newer = hist_time(h, lo), older = hist_time(h, lo + 1);
     if (q == older) { b.wo = 1.0; b.wn = 0.0; }
     else if (q == newer) { b.wo = 0.0; b.wn = 1.0; }
@@ -136,14 +126,24 @@ __device__ Bracket find_bracket(const HistoryView& h, double tau_s, double width
         b.wn = 1.0 - b.wo;
     } else {
         *error_flag = 1;  // "query_time not bracketed by history" (:370)
-        b.wo = 0.0; b.wn = 0.0;
+        return b;
     }
     b.slot_older = (h.head - (lo + 1) + h.Hcap) % h.Hcap;
     b.slot_newer = (lo == 0) ? -1 : (h.head - lo + h.Hcap) % h.Hcap;
     return b;
 }
 
-__device__ __forceinline__ double eta_at(const ConvArgs& a, int j) {
+// interpolated velocity of column `col` for bracket b (exact copies where the reference returns early)
+__device__ __forceinline__ double interp_velocity(const HistoryView& h, const Bracket& b, int col) {
+    if (b.wo == 0.0 && b.wn == 0.0) return 0.0;
+    const double vo = h.ring_v[(size_t)b.slot_older * h.D + col];
+    if (b.wn == 0.0) return vo;
+    const double vn = (b.slot_newer >= 0) ? h.ring_v[(size_t)b.slot_newer * h.D + col] : state_velocity(h.state, h.N, col);
+    if (b.wo == 0.0) return vn;
+    return b.wo * vo + b.wn * vn;
+}
+
+__device__ __forceinline__ double eta_at(const StepArgs& a, int j) {
     if (j >= a.L) return 0.0;
     const double q    = a.hist.t - a.ex_tau[j];
     const double tmin = a.eta_t[0];
@@ -160,123 +160,251 @@ __device__ __forceinline__ double eta_at(const ConvArgs& a, int j) {
         const double w2 = 1.0 - w1;
         val = w1 * a.eta[idx] + w2 * a.eta[idx + 1];
     } else {
-        *a.error_flag = 2;  // outside the table: the host has already refused the step (:833-840)
+        *a.error_flag = 2;  // outside the table: the host has already refused the step (src/wave_types.cpp:833-840)
         val = 0.0;
     }
     return val * a.ex_width[j];
 }
 
-template <int R, int U>
-__global__ void __launch_bounds__(kConvThreads) conv_kernel(ConvArgs a) {
+// ------------------------------------------------------------------------------------------------
+// conv_step_kernel<MT,U>: streamed FP64 GEMV over panel-layout K.  HBM-bound, 0.25 flop/B.
+//   grid = ngroups * (nchunks_rad + nchunks_ex) workgroups of 4 waves; a workgroup owns MT row tiles (16 rows each)
+//   x one chunk of column groups; wave w takes column groups gp0+w, gp0+w+4, ...  Per column group a lane issues MT
+//   non-temporal global_load_dwordx4 (1 KiB coalesced per wave and tile, straight to VGPRs -- K is used once), forms the
+//   right-hand side for its two columns and keeps MT FP64 accumulators.  Reduction: two xor-shuffles over the 4 column
+//   lanes of a row, then a 4-entry LDS step over the waves -- a FIXED order, bitwise reproducible.
+//   Right-hand side of a radiation chunk: one thread per IRF sample the chunk touches writes the history bracket and
+//   weights to an LDS table; a lane forms u = interp(v) * width_s from two 8-byte ring loads (L2 hits).  Excitation
+//   chunk: eta(t - tau_j), linearly interpolated in the precomputed table (src/wave_types.cpp:797-831), times width_j.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int U>
+__global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    Bracket* tab = reinterpret_cast<Bracket*>(smem_raw);
-    __shared__ double red[kConvThreads / kWave][R];
+    Bracket* tab  = reinterpret_cast<Bracket*>(smem_raw);
+    double* wtab  = reinterpret_cast<double*>(tab + a.max_steps_per_chunk);
+    __shared__ double red[kConvThreads / kWave][MT][16];
 
     const int nct   = a.nchunks_rad + a.nchunks_ex;
     const int chunk = blockIdx.x % nct;
-    const int rt    = blockIdx.x / nct;
+    const int grp   = blockIdx.x / nct;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool radiation = chunk < a.nchunks_rad;
+    const int kk = lane >> 4;
 
-    double acc[R];
+    double acc[MT];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    for (int m = 0; m < MT; ++m) acc[m] = 0.0;
 
-    if (radiation) {
-        const int D  = a.hist.D;
-        const int c0 = chunk * a.chunk_cols;
-        const int c1 = min(a.F, c0 + a.chunk_cols);
+    if (chunk < a.nchunks_rad) {
+        const int D   = a.hist.D;
+        const int gp0 = chunk * a.chunk_gp;
+        const int gp1 = min((a.F_limit + 7) >> 3, gp0 + a.chunk_gp);
+        const int c0 = gp0 * 8, c1 = min(a.F_limit, gp1 * 8);
         const int s0 = c0 / D;
         const int ns = (c1 - 1) / D - s0 + 1;
-        for (int k = tid; k < ns; k += kConvThreads) tab[k] = find_bracket(a.hist, a.tau[s0 + k], a.width[s0 + k], a.error_flag);
+        for (int k = tid; k < ns; k += kConvThreads) {
+            tab[k]  = find_bracket(a.hist, a.hist.t - a.tau[s0 + k], a.error_flag);
+            wtab[k] = a.width[s0 + k];
+        }
         __syncthreads();
-        const double* __restrict__ rows = a.K + (size_t)(rt * R) * a.ldk;
-        const double* __restrict__ ring = a.hist.ring_v;
+        const double* __restrict__ kbase = a.K.base + ((size_t)(grp * MT) * a.K.ngp) * 128 + lane * 2;
+        const size_t tile_stride = (size_t)a.K.ngp * 128;
 #pragma unroll U
-        for (int f = c0 + 2 * tid; f < c1; f += 2 * kConvThreads) {
-            dvec2 kv[R];
+        for (int gp = gp0 + wave; gp < gp1; gp += 4) {
+            dvec2 kv[MT];
             // K is streamed exactly once per step: non-temporal loads keep it from evicting the ring from L2
 #pragma unroll
-            for (int r = 0; r < R; ++r) kv[r] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(rows + (size_t)r * a.ldk + f));
-            const int s   = f / D;
-            const int col = f - s * D;  // even; f and f+1 share s because D is even
-            const Bracket b = tab[s - s0];
-            const dvec2 vo  = *reinterpret_cast<const dvec2*>(ring + (size_t)b.slot_older * D + col);
-            dvec2 vn;
-            if (b.slot_newer >= 0) vn = *reinterpret_cast<const dvec2*>(ring + (size_t)b.slot_newer * D + col);
-            else { vn.x = state_velocity(a.hist.state, a.hist.N, col); vn.y = state_velocity(a.hist.state, a.hist.N, col + 1); }
-            dvec2 u;
-            if (b.wn == 0.0) u = vo;          // exact copies, as the reference's early returns
-            else if (b.wo == 0.0) u = vn;
-            else { u.x = b.wo * vo.x + b.wn * vn.x; u.y = b.wo * vo.y + b.wn * vn.y; }
-            if (b.wo == 0.0 && b.wn == 0.0) { u.x = 0.0; u.y = 0.0; }
-            u.x *= b.width;
-            u.y *= b.width;
+            for (int m = 0; m < MT; ++m)
+                kv[m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128));
+            double u[2];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                acc[r] = fma(kv[r].x, u.x, acc[r]);
-                acc[r] = fma(kv[r].y, u.y, acc[r]);
+            for (int h = 0; h < 2; ++h) {
+                const int f = gp * 8 + 4 * h + kk;
+                if (f < c1) {
+                    const int s   = f / D;
+                    const int col = f - s * D;
+                    u[h] = interp_velocity(a.hist, tab[s - s0], col) * wtab[s - s0];
+                } else {
+                    u[h] = 0.0;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = fma(kv[m].x, u[0], acc[m]);
+                acc[m] = fma(kv[m].y, u[1], acc[m]);
             }
         }
     } else {
-        const int c0 = (chunk - a.nchunks_rad) * a.chunk_cols_ex;
-        const int c1 = min(a.Lpad, c0 + a.chunk_cols_ex);
-        const double* __restrict__ rows = a.Kex + (size_t)(rt * R) * a.ldkex;
-        for (int j = c0 + 2 * tid; j < c1; j += 2 * kConvThreads) {
-            dvec2 kv[R];
+        const int gp0 = (chunk - a.nchunks_rad) * a.chunk_gp_ex;
+        const int gp1 = min(a.Kex.ngp, gp0 + a.chunk_gp_ex);
+        const double* __restrict__ kbase = a.Kex.base + ((size_t)(grp * MT) * a.Kex.ngp) * 128 + lane * 2;
+        const size_t tile_stride = (size_t)a.Kex.ngp * 128;
+        for (int gp = gp0 + wave; gp < gp1; gp += 4) {
+            dvec2 kv[MT];
 #pragma unroll
-            for (int r = 0; r < R; ++r) kv[r] = *reinterpret_cast<const dvec2*>(rows + (size_t)r * a.ldkex + j);
-            const double e0 = eta_at(a, j), e1 = eta_at(a, j + 1);
+            for (int m = 0; m < MT; ++m) kv[m] = *reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128);
+            const double e0 = eta_at(a, gp * 8 + kk), e1 = eta_at(a, gp * 8 + 4 + kk);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                acc[r] = fma(kv[r].x, e0, acc[r]);
-                acc[r] = fma(kv[r].y, e1, acc[r]);
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = fma(kv[m].x, e0, acc[m]);
+                acc[m] = fma(kv[m].y, e1, acc[m]);
             }
         }
     }
 
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const double s = wave_sum(acc[r]);
-        if (lane == 0) red[wave][r] = s;
+    for (int m = 0; m < MT; ++m) {
+        double v = acc[m];
+        v += __shfl_xor(v, 16, kWave);
+        v += __shfl_xor(v, 32, kWave);
+        if (lane < 16) red[wave][m][lane] = v;
     }
     __syncthreads();
-    if (tid < R) a.partials[(size_t)chunk * a.Dloc + rt * R + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-}
-
-void launch_conv(const ConvArgs& a, int rows_per_tile, hipStream_t stream) {
-    const int nblocks = a.nrowtiles * (a.nchunks_rad + a.nchunks_ex);
-    if (nblocks <= 0) return;
-    const size_t smem = (size_t)max(1, a.max_steps_per_chunk) * sizeof(Bracket);
-    static const int unroll = [] {
-        const char* e = std::getenv("HC_CONV_UNROLL");  // tuning experiments only
-        return e ? std::atoi(e) : 1;
-    }();
-    if (rows_per_tile == 12) {
-        if (unroll == 2) hipLaunchKernelGGL((conv_kernel<12, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-        else hipLaunchKernelGGL((conv_kernel<12, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-    } else {
-        if (unroll == 1) hipLaunchKernelGGL((conv_kernel<6, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-        else hipLaunchKernelGGL((conv_kernel<6, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    if (tid < MT * 16) {
+        const int m = tid >> 4, r = tid & 15;
+        a.partials[(size_t)chunk * a.Dpad + (grp * MT + m) * 16 + r] = ((red[0][m][r] + red[1][m][r]) + red[2][m][r]) + red[3][m][r];
     }
 }
 
-const char* conv_kernel_name() { return "conv_kernel"; }
+template <int MT>
+static void launch_conv_step_mt(const StepArgs& a, int unroll, int nblocks, size_t smem, hipStream_t stream) {
+    if (unroll == 1) hipLaunchKernelGGL((conv_step_kernel<MT, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    else if (unroll == 3) hipLaunchKernelGGL((conv_step_kernel<MT, 3>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    else hipLaunchKernelGGL((conv_step_kernel<MT, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+}
+
+void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
+    const int nblocks = a.ngroups * (a.nchunks_rad + a.nchunks_ex);
+    if (nblocks <= 0) return;
+    static const int unroll = [] {
+        const char* e = std::getenv("HC_CONV_UNROLL");  // tuning experiments only
+        return e ? std::atoi(e) : 2;
+    }();
+    const size_t smem = (size_t)max(1, a.max_steps_per_chunk) * (sizeof(Bracket) + sizeof(double));
+    if (mt == 4) launch_conv_step_mt<4>(a, unroll, nblocks, smem, stream);
+    else if (mt == 2) launch_conv_step_mt<2>(a, unroll, nblocks, smem, stream);
+    else launch_conv_step_mt<1>(a, unroll, nblocks, smem, stream);
+}
 
 // ------------------------------------------------------------------------------------------------
-// finalize_kernel: 16 lanes per owned output row (16 rows per 256-thread workgroup).  Lane l adds the partials of
-// chunks l, l+16, ... in ascending order, a 4-step xor-shuffle tree adds the 16 lane sums -- a fixed order, so the
-// result is bitwise reproducible -- then lane 0 of the row adds hydrostatics / the regular-wave term and writes.
+// conv_block_kernel<MT>: the look-ahead pass.  C[row, j] = sum_f K[row, f] * U[f, j], j = 0..15, with
+//   U[(s,col), j] = interp(v_col)(tpred[j] - tau_s) * width_s   for s >= s_cut[j], else 0
+// on v_mfma_f64_16x16x4_f64: the 16-byte word a lane streams from a K panel is the A operand of two MFMAs, the lane
+// forms its B operand (one column, step j = lane & 15) from the LDS bracket table [sample][j] and two ring loads.
+// Same grid / chunk mapping as conv_step_kernel; K is read once for 16 steps, so the pass stays HBM-bound
+// (32 flop/B, FP64 MFMA ~ 1/3 busy).  Partials [chunk][j][row], reduced in fixed order by reduce_block_kernel.
 // ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Bracket* tab = reinterpret_cast<Bracket*>(smem_raw);                                   // [ns][16]
+    double* wtab = reinterpret_cast<double*>(tab + (size_t)a.max_steps_per_chunk * kLookahead);  // [ns]
+    __shared__ double red[kConvThreads / kWave][MT][256];
+
+    const int chunk = blockIdx.x % a.nchunks;
+    const int grp   = blockIdx.x / a.nchunks;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kk = lane >> 4, jstep = lane & 15;
+    const int D = a.hist.D;
+
+    const int gp0 = chunk * a.chunk_gp;
+    const int gp1 = min((a.F + 7) >> 3, gp0 + a.chunk_gp);
+    const int c0 = gp0 * 8, c1 = min(a.F, gp1 * 8);
+    const int s0 = c0 / D;
+    const int ns = (c1 - 1) / D - s0 + 1;
+    for (int idx = tid; idx < ns * kLookahead; idx += kConvThreads) {
+        const int k = idx >> 4, j = idx & 15, s = s0 + k;
+        Bracket b;
+        b.wo = 0.0; b.wn = 0.0; b.slot_older = 0; b.slot_newer = 0;
+        if (s >= a.s_cut[j]) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
+        tab[idx] = b;
+        if (j == 0) wtab[k] = a.width[s];
+    }
+    __syncthreads();
+
+    dvec4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = dvec4{0.0, 0.0, 0.0, 0.0};
+
+    const double* __restrict__ kbase = a.K.base + ((size_t)(grp * MT) * a.K.ngp) * 128 + lane * 2;
+    const size_t tile_stride = (size_t)a.K.ngp * 128;
+#pragma unroll 2
+    for (int gp = gp0 + wave; gp < gp1; gp += 4) {
+        dvec2 kv[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            kv[m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128));
+        double u[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int f = gp * 8 + 4 * h + kk;
+            if (f < c1) {
+                const int s   = f / D;
+                const int col = f - s * D;
+                u[h] = interp_velocity(a.hist, tab[(s - s0) * kLookahead + jstep], col) * wtab[s - s0];
+            } else {
+                u[h] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[m].x, u[0], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[m].y, u[1], acc[m], 0, 0, 0);
+        }
+    }
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][m][(kk + 4 * r) * 16 + jstep] = acc[m][r];
+    __syncthreads();
+    for (int idx = tid; idx < MT * 256; idx += kConvThreads) {
+        const int m = idx >> 8, e = idx & 255, row = e >> 4, j = e & 15;
+        const double v = ((red[0][m][e] + red[1][m][e]) + red[2][m][e]) + red[3][m][e];
+        a.partials[((size_t)chunk * kLookahead + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
+    }
+}
+
+void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
+    const int nblocks = a.ngroups * a.nchunks;
+    if (nblocks <= 0) return;
+    const size_t smem = (size_t)max(1, a.max_steps_per_chunk) * (kLookahead * sizeof(Bracket) + sizeof(double));
+    if (mt == 4) hipLaunchKernelGGL((conv_block_kernel<4>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    else if (mt == 2) hipLaunchKernelGGL((conv_block_kernel<2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    else hipLaunchKernelGGL((conv_block_kernel<1>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+}
+
 __device__ __forceinline__ double lane16_sum(double v) {
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 16);
     return v;
 }
 
+// P[j][row] = sum_c partials[c][j][row]; 16 lanes per output, chunks c = l, l+16, ... then a 4-step xor tree.
+__global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restrict__ partials, int nchunks, int Dpad, double* __restrict__ P) {
+    const int sub = threadIdx.x & 15;
+    const int out = blockIdx.x * 16 + (threadIdx.x >> 4);  // j*Dpad + row
+    const int n   = kLookahead * Dpad;
+    const int o   = out < n ? out : 0;
+    double v = 0.0;
+    for (int c = sub; c < nchunks; c += 16) v += partials[(size_t)c * n + o];
+    v = lane16_sum(v);
+    if (out < n && sub == 0) P[out] = v;
+}
+
+void launch_reduce_block(const double* d_partials, int nchunks, int Dpad, double* d_P, hipStream_t stream) {
+    const int n = kLookahead * Dpad;
+    hipLaunchKernelGGL(reduce_block_kernel, dim3((n + 15) / 16), dim3(256), 0, stream, d_partials, nchunks, Dpad, d_P);
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize_kernel: 16 lanes per owned output row (16 rows per 256-thread workgroup).  Lane l adds the partials of
+// chunks l, l+16, ... in ascending order, a 4-step xor-shuffle tree adds the 16 lane sums -- a fixed order, so the
+// result is bitwise reproducible -- then lane 0 of the row adds the look-ahead part, hydrostatics / the regular-wave
+// term and writes.  One extra workgroup stores this step's sample into the ring.
+// ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     if (a.do_push && blockIdx.x == gridDim.x - 1) {
-        // the extra last workgroup stores this step's sample into ring slot `head`; nobody reads that slot this step
+        // nobody reads ring slot `head` during this step (the current sample is always taken from `state`)
         if (threadIdx.x == 0) a.ring_t[a.head] = a.t;
         double* slot = a.ring_v + (size_t)a.head * a.D;
         for (int c = threadIdx.x; c < a.D; c += blockDim.x) slot[c] = state_velocity(a.state, a.N, c);
@@ -289,11 +417,12 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 
     double rad = 0.0, wav = 0.0;
     if (a.do_rad) {
-        for (int c = sub; c < a.nchunks_rad; c += 16) rad += a.partials[(size_t)c * a.Dloc + rrow];
+        for (int c = sub; c < a.nchunks_rad; c += 16) rad += a.partials[(size_t)c * a.Dpad + rrow];
         rad = lane16_sum(rad);
+        if (a.P) rad = a.P[rrow] + rad;
     }
     if (a.do_waves && a.wave_mode == 2) {
-        for (int c = sub; c < a.nchunks_ex; c += 16) wav += a.partials[(size_t)(a.nchunks_rad + c) * a.Dloc + rrow];
+        for (int c = sub; c < a.nchunks_ex; c += 16) wav += a.partials[(size_t)(a.nchunks_rad + c) * a.Dpad + rrow];
         wav = lane16_sum(wav);
     }
     if (!live || sub != 0) return;
@@ -348,16 +477,14 @@ void launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // TaperedDirect preprocessing (TestHydro::EnsureProcessedRIRF, src/hydro_forces.cpp:385-535), once per
 // option change: per (row, col) series along s -> truncate, smooth (SG-5 / moving average), half-cosine taper.
-// Thread = one (row, col) series; consecutive threads = consecutive col -> coalesced for every s.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) taper_kernel(TaperArgs a) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)a.Dloc * a.D) return;
     const int row = (int)(gid / a.D), col = (int)(gid % a.D);
-    const double* __restrict__ in = a.Kraw + (size_t)row * a.ldk + col;
-    double* __restrict__ out      = a.Kproc + (size_t)row * a.ldk + col;
+    const int ngp = a.Kraw.ngp;
+    auto in = [&](int s) -> double { return a.Kraw.base[panel_offset(ngp, row, s * a.D + col)]; };
     const int E = a.effective_steps;
-    const size_t st = (size_t)a.D;  // stride between consecutive s
     const double sg0 = -3.0 / 35.0, sg1 = 12.0 / 35.0, sg2 = 17.0 / 35.0;
     const int taper_len = a.tc_end - a.tc_index;
     for (int s = 0; s < E; ++s) {
@@ -366,14 +493,13 @@ __global__ void __launch_bounds__(256) taper_kernel(TaperArgs a) {
             const int half = a.window / 2;
             const int lo = max(0, s - half), hi = min(E - 1, s + half);
             double sum = 0.0;
-            for (int k = lo; k <= hi; ++k) sum += in[(size_t)k * st];
+            for (int k = lo; k <= hi; ++k) sum += in(k);
             const int cnt = hi - lo + 1;
-            v = (cnt > 0) ? (sum / cnt) : in[(size_t)s * st];
+            v = (cnt > 0) ? (sum / cnt) : in(s);
         } else if (E >= 5 && s >= 2 && s <= E - 3) {
-            v = sg0 * in[(size_t)(s - 2) * st] + sg1 * in[(size_t)(s - 1) * st] + sg2 * in[(size_t)s * st] +
-                sg1 * in[(size_t)(s + 1) * st] + sg0 * in[(size_t)(s + 2) * st];
+            v = sg0 * in(s - 2) + sg1 * in(s - 1) + sg2 * in(s) + sg1 * in(s + 1) + sg0 * in(s + 2);
         } else {
-            v = in[(size_t)s * st];
+            v = in(s);
         }
         if (s < a.tc_index) {
         } else if (s < a.tc_end && taper_len > 0) {
@@ -383,9 +509,9 @@ __global__ void __launch_bounds__(256) taper_kernel(TaperArgs a) {
         } else {
             v = 0.0;
         }
-        out[(size_t)s * st] = v;
+        a.Kproc[panel_offset(ngp, row, s * a.D + col)] = v;
     }
-    for (int s = max(E, 0); s < a.S; ++s) out[(size_t)s * st] = 0.0;
+    for (int s = max(E, 0); s < a.S; ++s) a.Kproc[panel_offset(ngp, row, s * a.D + col)] = 0.0;
 }
 
 void launch_taper(const TaperArgs& a, hipStream_t stream) {
@@ -396,7 +522,6 @@ void launch_taper(const TaperArgs& a, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // eta(t) synthesis at init (GetEtaIrregularTimeSeries, src/wave_types.cpp:14-59 with x = 0, then the ramp of
 // :759-769).  Thread = one time sample; components are summed in index order like the reference loop.
-// amp/omega/phase are wave-uniform reads (scalar loads).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) eta_kernel(const double* __restrict__ t, int nt, const double* __restrict__ amp,
                                                    const double* __restrict__ omega, const double* __restrict__ phase, int nf,
@@ -422,6 +547,12 @@ void launch_eta_synthesis(const double* d_t, int nt, const double* d_amp, const 
 // ------------------------------------------------------------------------------------------------
 // Added-mass product (ChLoadAddedMass::LoadIntLoadResidual_Mv, src/chloadaddedmass.cpp:55-70): one wave per row.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
 __global__ void __launch_bounds__(256) added_mass_mv_kernel(const double* __restrict__ M, int rows, int cols,
                                                              const double* __restrict__ w, double c, double* __restrict__ R) {
     const int row  = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -442,7 +573,8 @@ void launch_added_mass_mv(const double* d_M, int rows, int cols, const double* d
 // Synthetic radiation kernels generated in HBM (benchmark inputs):
 //   K[row][col][s] = a * exp(-tau_s / tau_d) * cos(om * tau_s),  tau_s = s*dt,
 //   (a, tau_d, om) = per-(row,col) draws of a counter-based splitmix64 stream; same-body blocks x10.
-// hydrochrono_amd/synthetic.py holds the identical formula for host-side generation.
+// hydrochrono_amd/synthetic.py holds the identical formula for host-side generation.  Thread = one panel element
+// (coalesced stores); padding rows / columns are written as zero.
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -452,29 +584,37 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
 }
 __host__ __device__ inline double u01(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
 
-__global__ void __launch_bounds__(256) synth_rirf_kernel(double* __restrict__ K, size_t ldk, int Dloc, int D, int S, int row0, double dt,
+__global__ void __launch_bounds__(256) synth_rirf_kernel(double* __restrict__ K, int ntiles, int ngp, int Dloc, int D, int S, int row0, double dt,
                                                           unsigned long long seed, double rho) {
-    const size_t n   = (size_t)Dloc * S * D;
+    const size_t n   = (size_t)ntiles * ngp * 128;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n) return;
-    const int col = (int)(gid % D);
-    const int s   = (int)((gid / D) % S);
-    const int row = (int)(gid / ((size_t)D * S));
-    const int grow = row0 + row;
-    const uint64_t base = splitmix64(seed ^ (((uint64_t)grow << 32) | (uint64_t)col));
-    const double ua = u01(splitmix64(base + 1)), ud = u01(splitmix64(base + 2)), uo = u01(splitmix64(base + 3));
-    double amp   = (2.0 * ua - 1.0);
-    if (grow / 6 == col / 6) amp *= 10.0;
-    const double tau_d = 1.0 + 3.0 * ud;
-    const double om    = 0.5 + 2.5 * uo;
-    const double tau   = s * dt;
-    K[(size_t)row * ldk + (size_t)s * D + col] = (amp * exp(-tau / tau_d) * cos(om * tau)) * rho;
+    const int j    = (int)(gid & 1);
+    const int lane = (int)((gid >> 1) & 63);
+    const size_t blk = gid >> 7;
+    const int gp = (int)(blk % ngp), rt = (int)(blk / ngp);
+    const int row = rt * 16 + (lane & 15);
+    const size_t f = (size_t)gp * 8 + 4 * j + (lane >> 4);
+    double val = 0.0;
+    if (row < Dloc && f < (size_t)S * D) {
+        const int s = (int)(f / D), col = (int)(f - (size_t)s * D);
+        const int grow = row0 + row;
+        const uint64_t base = splitmix64(seed ^ (((uint64_t)grow << 32) | (uint64_t)col));
+        const double ua = u01(splitmix64(base + 1)), ud = u01(splitmix64(base + 2)), uo = u01(splitmix64(base + 3));
+        double amp = (2.0 * ua - 1.0);
+        if (grow / 6 == col / 6) amp *= 10.0;
+        const double tau_d = 1.0 + 3.0 * ud;
+        const double om    = 0.5 + 2.5 * uo;
+        const double tau   = s * dt;
+        val = (amp * exp(-tau / tau_d) * cos(om * tau)) * rho;
+    }
+    K[gid] = val;
 }
 
-void launch_synth_rirf(double* d_K, size_t ldk, int Dloc, int D, int S, int row0, double dt, unsigned long long seed, double rho,
+void launch_synth_rirf(double* d_K, int ntiles, int ngp, int Dloc, int D, int S, int row0, double dt, unsigned long long seed, double rho,
                        hipStream_t stream) {
-    const size_t n = (size_t)Dloc * S * D;
-    hipLaunchKernelGGL(synth_rirf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_K, ldk, Dloc, D, S, row0, dt, seed, rho);
+    const size_t n = (size_t)ntiles * ngp * 128;
+    hipLaunchKernelGGL(synth_rirf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_K, ntiles, ngp, Dloc, D, S, row0, dt, seed, rho);
 }
 
 }  // namespace hc

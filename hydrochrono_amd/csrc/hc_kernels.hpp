@@ -6,7 +6,23 @@
 
 namespace hc {
 
-// ---- per-step argument blocks (passed by value as kernel arguments; no per-step H2D descriptor copies) ----
+constexpr int kLookahead = 16;  // future steps covered by one blocked pass (= N dimension of v_mfma_f64_16x16x4_f64)
+
+// ------------------------------------------------------------------------------------------------------------------
+// Panel layout of the convolution matrices in HBM (radiation K[D_loc x S*D], excitation Kex[D_loc x L]).
+// Rows are grouped in tiles of 16, columns in groups of 8 ("gp").  One 16 x 8 block is 128 consecutive doubles:
+//     element (row, f):  rt = row/16, ri = row%16, gp = f/8, j = (f%8)/4, kk = f%4
+//     offset = ((rt*ngp + gp)*64 + (kk*16 + ri))*2 + j
+// so that lane l = kk*16 + ri of a wave reads ONE 16-byte word per 16 x 8 block (a 1 KiB fully coalesced wave load) and
+// holds exactly the A operands of two v_mfma_f64_16x16x4_f64 (A[row = l&15][k = l>>4]) for columns 8gp+kk and 8gp+4+kk.
+// Rows >= D_loc and columns >= F are zero padding.
+// ------------------------------------------------------------------------------------------------------------------
+struct Panel {
+    const double* base;
+    int ntiles;  // ceil(D_loc / 16)
+    int ngp;     // ceil(F / 8)
+};
+inline size_t panel_doubles(int ntiles, int ngp) { return static_cast<size_t>(ntiles) * ngp * 128; }
 
 // Velocity-history ring in HBM: ring_v[Hcap][D], ring_t[Hcap]; sample k (0 = newest) lives in slot
 // (head - k + Hcap) % Hcap.  The sample of the CURRENT step (k = 0) is read from `state`, never from the
@@ -21,26 +37,21 @@ struct HistoryView {
     double dt_hint;       // t - previous sample time (bracket-search hint only, > 0)
 };
 
-// One launch per step covers the radiation matrix K[D_local x S*D] and, for irregular waves, the excitation
-// matrix Kex[D_local x Lpad]; a workgroup owns R consecutive rows x one column chunk of one of them and leaves one
-// partial sum per row in `partials[chunk][D_local]`.  The right-hand sides are never materialised: the
-// interpolated, width-scaled velocity history u[s][col] and the free-surface samples e[j] are formed in registers
-// from the ring / the eta table (both L2-resident) while K streams from HBM.
-struct ConvArgs {
-    const double* K;
-    size_t ldk;       // row stride of K in doubles (even)
-    int F;            // S*D
-    int chunk_cols;   // multiple of 512
+// Per-step launch: radiation columns [0, F_limit) of K (F_limit = S*D for a plain step, s_cut*D for the remainder of a
+// look-ahead step) and, for irregular waves, the excitation matrix, both as column chunks of a streamed FP64 GEMV.
+// A workgroup owns MT row tiles x one chunk and leaves one partial per row in partials[chunk][Dpad].
+struct StepArgs {
+    Panel K;
+    int F_limit;          // radiation columns to contract (multiple of D)
+    int chunk_gp;         // column groups per radiation chunk
     int nchunks_rad;
-    int max_steps_per_chunk;  // size of the per-workgroup bracket table: chunk_cols / D + 2
+    int max_steps_per_chunk;  // LDS bracket table entries
     HistoryView hist;
-    int S;
     const double* tau;    // [S] radiation IRF sample times
     const double* width;  // [S] trapezoid widths
-    const double* Kex;
-    size_t ldkex;     // Lpad
-    int L, Lpad;
-    int chunk_cols_ex;
+    Panel Kex;
+    int L;                // excitation samples (columns of Kex)
+    int chunk_gp_ex;
     int nchunks_ex;
     const double* ex_tau;    // [L]
     const double* ex_width;  // [L]
@@ -48,16 +59,37 @@ struct ConvArgs {
     const double* eta;       // [nt]
     int nt;
     double eta_dt;           // nominal spacing of eta_t (search hint only)
-    double* partials;  // [(nchunks_rad + nchunks_ex)][Dloc]
-    int Dloc;
-    int nrowtiles;
-    int* error_flag;   // set to 1 / 2 if a query time is not bracketed (reference: runtime_error)
+    double* partials;        // [(nchunks_rad + nchunks_ex)][Dpad]
+    int Dpad;
+    int ngroups;             // ntiles / MT
+    int* error_flag;         // 1 / 2: a query time is not bracketed (reference: runtime_error)
+};
+
+// Look-ahead pass: for j = 0..15 the part of step (n+j)'s radiation sum that depends only on history known at step n,
+//   P_j[row] = sum over s >= s_cut[j], col of K[row, s, col] * u_{n+j}(s, col),   t_{n+j} = t + j*dt,
+// as one [D_loc x F] x [F x 16] FP64 GEMM on the matrix cores; K is read once for 16 steps.
+struct BlockArgs {
+    Panel K;
+    int F;                // S*D
+    int chunk_gp;
+    int nchunks;
+    int max_steps_per_chunk;
+    HistoryView hist;
+    double tpred[kLookahead];  // predicted step times, tpred[0] = hist.t
+    int s_cut[kLookahead];
+    const double* tau;
+    const double* width;
+    double* partials;     // [nchunks][16][Dpad]
+    int Dpad;
+    int ngroups;
+    int* error_flag;
 };
 
 struct FinalizeArgs {
     const double* partials;
     int nchunks_rad, nchunks_ex;
-    int Dloc, N, b0;
+    const double* P;         // look-ahead part of this step's radiation sum, [Dpad] (may be null)
+    int Dloc, Dpad, N, b0;
     const double* state;
     // hydrostatics
     const double* lin;       // [nloc][36]
@@ -85,9 +117,8 @@ struct FinalizeArgs {
 };
 
 struct TaperArgs {
-    const double* Kraw;
-    double* Kproc;
-    size_t ldk;
+    Panel Kraw;
+    double* Kproc;  // same panel geometry
     int Dloc, D, S;
     int effective_steps;
     int smoothing;  // 0 sg5, 1 moving average
@@ -97,9 +128,15 @@ struct TaperArgs {
 };
 
 // ---- launchers (all asynchronous on `stream`) ----
-void launch_relayout_rirf(const double* d_Kb_6xDxS, double* d_K, int D, int S, size_t ldk, int row0, double rho, hipStream_t stream);
-// rows_per_tile is 6 or 12 (Dloc % rows_per_tile == 0)
-void launch_conv(const ConvArgs& a, int rows_per_tile, hipStream_t stream);
+// staging Kb[6][D][S] (file order, unscaled) -> rows row0..row0+5 of the panel matrix, times `scale`
+void launch_relayout_rirf(const double* d_Kb_6xDxS, double* d_K, int ngp, int D, int S, int row0, double scale, hipStream_t stream);
+// row-major src[rows][cols] -> panel rows row0.. (used for the excitation IRF)
+void launch_relayout_rowmajor(const double* d_src, int rows, int cols, double* d_panel, int ngp, int row0, hipStream_t stream);
+// mt = row tiles per workgroup (1, 2 or 4; ngroups*mt == ntiles)
+void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream);
+void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream);
+// P[j][row] = sum_c partials[c][j][row]  (fixed order)
+void launch_reduce_block(const double* d_partials, int nchunks, int Dpad, double* d_P, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 void launch_taper(const TaperArgs& a, hipStream_t stream);
 // eta[j] = sum_i amp[i] * cos(-omega[i]*t[j] + phase[i]), then the ramp rule of src/wave_types.cpp:759-769
@@ -108,11 +145,9 @@ void launch_eta_synthesis(const double* d_t, int nt, const double* d_amp, const 
 // R[i] += c * sum_j M[i][j] * w[j]   (i < rows)
 void launch_added_mass_mv(const double* d_M, int rows, int cols, const double* d_w, double c, double* d_R, hipStream_t stream);
 // out[(row*D + col)*S + s] = K[row][s*D + col]  (reference indexing; diagnostics)
-void launch_unrelayout(const double* d_K, size_t ldk, int Dloc, int D, int S, double* d_out, hipStream_t stream);
-// synthetic many-body coefficient generator
-void launch_synth_rirf(double* d_K, size_t ldk, int Dloc, int D, int S, int row0, double dt, unsigned long long seed, double rho,
+void launch_unrelayout(const Panel& K, int Dloc, int D, int S, double* d_out, hipStream_t stream);
+// synthetic many-body coefficient generator: fills the whole panel matrix (padding = 0)
+void launch_synth_rirf(double* d_K, int ntiles, int ngp, int Dloc, int D, int S, int row0, double dt, unsigned long long seed, double rho,
                        hipStream_t stream);
-
-const char* conv_kernel_name();
 
 }  // namespace hc

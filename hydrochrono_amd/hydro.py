@@ -172,6 +172,10 @@ class HydroForces:
         self._chk(self.lib.hc_compute_waves(self.ctx, float(t), _dp(out)))
         return out
 
+    def set_lookahead(self, steps):
+        """0 = plain per-step evaluation; > 0 = 16-step look-ahead blocking (the default)."""
+        self._chk(self.lib.hc_set_lookahead(self.ctx, int(steps)))
+
     def reset_history(self):
         self._chk(self.lib.hc_reset_history(self.ctx))
 

@@ -154,6 +154,12 @@ int hc_compute_radiation(hc_ctx* ctx, double t, const double* linvel, const doub
 /* TestHydro::ComputeForceHydrostatics (:263-322) and ComputeForceWaves (:713-725) on their own. */
 int hc_compute_hydrostatics(hc_ctx* ctx, const double* pos, const double* rpy, double* hs_out);
 int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
+/* Multi-step look-ahead (on by default): when the caller steps on a uniform time grid, one blocked pass over K
+ * precomputes, for the next 16 predicted step times, the part of the radiation sum that only needs history already
+ * known, so K leaves HBM once per 16 steps; each step then adds the few newest samples.  A step whose time deviates from
+ * the prediction (> 1e-9 of the step size) silently falls back to the plain per-step evaluation, so results never
+ * depend on the prediction being right.  steps = 0 disables it (every step streams K), any other value enables it. */
+int hc_set_lookahead(hc_ctx* ctx, int steps);
 /* Forget the velocity history and the per-time cache (fresh TestHydro state). */
 int hc_reset_history(hc_ctx* ctx);
 /* Injects a history as if those steps had been evaluated (times newest first, vel [n][D]); used to start
@@ -179,9 +185,14 @@ int hc_added_mass_mv(hc_ctx* ctx, const double* w, double c, double* R_inout, in
 typedef struct hc_profile_stats {
     double hydrostatics_seconds, radiation_seconds, waves_seconds;
     int hydrostatics_calls, radiation_calls, waves_calls;
-    double conv_kernel_seconds; /* sum of HIP-event durations of the convolution kernel */
+    double conv_kernel_seconds; /* sum of HIP-event durations of the plain per-step convolution launches */
     long long conv_kernel_launches;
-    double conv_kernel_bytes;   /* algorithmic bytes one launch streams (8*D_local*D*S + vectors) */
+    double conv_kernel_bytes;   /* algorithmic bytes of one step (8*D_local*D*S + vectors) */
+    double block_kernel_seconds; /* look-ahead passes (one covers 16 steps) incl. their reduction */
+    long long block_kernel_launches;
+    double block_kernel_bytes;  /* algorithmic bytes of the 16 steps one pass covers */
+    double rem_kernel_seconds;  /* per-step remainder launches inside a look-ahead block */
+    long long rem_kernel_launches;
 } hc_profile_stats;
 /* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default).  Event records
  * perturb the launch stream by a few microseconds, so throughput runs should sample (e.g. on = 8). */

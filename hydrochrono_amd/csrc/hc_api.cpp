@@ -295,6 +295,11 @@ int plan_step(hc_ctx* c, double t, int H) {
     }
     const double dt = c->times[0] - c->times[1];
     if (!(dt > 0.0)) return 0;
+    // Blocks are planned only once the history spans the whole IRF window.  While it is shorter, the reference's
+    // "no older sample -> the IRF step contributes nothing" rule (src/hydro_forces.cpp:604-606) makes the sum
+    // discontinuous in t at q == oldest sample time, and a predicted time that differs from the caller's by one ulp
+    // could flip that decision; with full coverage every query of every predicted step lies strictly inside the history.
+    if (!(c->times.back() <= t - c->tau.back())) return 0;
     pl.valid  = true;
     pl.t0     = t;
     pl.dt     = dt;

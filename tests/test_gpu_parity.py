@@ -145,7 +145,8 @@ def test_sphere_prescribed_motion_all_terms(HF):
         gpu.add_waves_irregular(**kw)
         orc.add_waves_irregular(**kw)
         motion = PrescribedMotion(1, [[0, 0, -2.0]], seed=3)
-        drive_both(gpu, orc, motion, dt * np.arange(1300))  # beyond the 15 s IRF window at dt=0.015: exercises pruning
+        # beyond the 15 s IRF window: exercises pruning and (past the window) the look-ahead blocks
+        drive_both(gpu, orc, motion, dt * np.arange(1300 if dt == 0.015 else 1750))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -180,6 +181,35 @@ def test_multibody_regular_wave_phase_indexing(HF):
     t = 0.37
     expect = mag * 0.8 * np.cos(1.3 * t + np.tile(ph[:6], 3))
     assert_close(gpu.compute_waves(t), expect, 1e-13, "regular wave with body-0 phases")
+
+
+@pytest.mark.parametrize("N", [1, 2, 4])
+def test_lookahead_matches_plain_and_survives_irregular_steps(HF, N):
+    """16-step look-ahead blocking vs plain per-step evaluation on the same inputs: uniform steps (blocks in use),
+    then a change of step size, jittered steps (every prediction misses -> fallback), then uniform again."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    case = many_body_case(N, S=100, dt_rirf=0.01, n_exc=33, seed=200 + N)
+    a, b = HF.from_case(case), HF.from_case(case)
+    a.set_lookahead(16)
+    b.set_lookahead(0)
+    orc = load_into_oracle(case)
+    for h in (a, b, orc):
+        h.add_waves_none()
+    rng = np.random.default_rng(N)
+    dts = np.concatenate([np.full(180, 0.01), np.full(90, 0.004), rng.uniform(0.003, 0.012, 60), np.full(120, 0.01),
+                          np.full(40, 0.05)])
+    times = np.concatenate([[0.0], np.cumsum(dts)])
+    motion = PrescribedMotion(N, rest_positions(case), seed=3)
+    a.enable_profiling(1)
+    for t in times:
+        st = motion.state(t)
+        fa, fb, fo = a.step(t, *st), b.step(t, *st), orc.step(t, *st)
+        assert_close(fa, fb, 1e-11, f"look-ahead vs plain at t={t}")
+        assert_close(fa, fo, TIGHT_TOL, f"look-ahead vs oracle at t={t}")
+    prof = a.profile()
+    assert prof["block_kernel_launches"] >= 10 and prof["rem_kernel_launches"] >= 100  # blocks really were used
+    assert prof["conv_kernel_launches"] >= 100                                         # and the fallback too
 
 
 def test_row_sharded_contexts_concatenate(HF):
@@ -387,13 +417,13 @@ def test_c3_full_size_against_oracle(c3):
     v_hist = np.stack([motion.velocity6(t) for t in t_hist])
     gpu.set_history(t_hist, v_hist)
     orc.prefill_history(t_hist, v_hist)
-    for n in range(2):
+    for n in range(19):  # boundary step, a full 16-step look-ahead block, the next boundary and one more
         t = 20.0 + n * dt
         st = motion.state(t)
         fg, fo = gpu.step(t, *st), orc.step(t, *st)
-        assert_close(fg, fo, TIGHT_TOL, "C3 total force")
+        assert_close(fg, fo, TIGHT_TOL, f"C3 total force, step {n}")
         for g, o in zip(gpu.components(), orc.components()):
-            assert_close(g, o, TIGHT_TOL, "C3 component")
+            assert_close(g, o, TIGHT_TOL, f"C3 component, step {n}")
 
 
 def test_c3_linearity_and_delta_kernel_properties(c3):

@@ -195,7 +195,7 @@ void choose_exc_config(hc_ctx* c) {
         c->chunk_gp_ex = 64;
         return;
     }
-    c->chunk_gp_ex = 256;
+    c->chunk_gp_ex = std::max(4, env_int("HC_EXC_CHUNK_GP", 32));  // short chunks: the excitation side is latency-bound
     c->nchunks_ex  = (c->ngp_ex + c->chunk_gp_ex - 1) / c->chunk_gp_ex;
 }
 
@@ -394,6 +394,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     a.chunk_gp            = chunk_gp;
     a.nchunks_rad         = nchunks_rad;
     a.max_steps_per_chunk = (chunk_gp * 8) / c->D + 2;
+    a.rhs_capacity        = 8 * std::max(chunk_gp, c->chunk_gp_ex);
     a.hist                = hv;
     a.tau                 = c->d_tau.p;
     a.width               = c->d_width.p;

@@ -173,15 +173,18 @@ __device__ __forceinline__ double eta_at(const StepArgs& a, int j) {
 //   non-temporal global_load_dwordx4 (1 KiB coalesced per wave and tile, straight to VGPRs -- K is used once), forms the
 //   right-hand side for its two columns and keeps MT FP64 accumulators.  Reduction: two xor-shuffles over the 4 column
 //   lanes of a row, then a 4-entry LDS step over the waves -- a FIXED order, bitwise reproducible.
-//   Right-hand side of a radiation chunk: one thread per IRF sample the chunk touches writes the history bracket and
-//   weights to an LDS table; a lane forms u = interp(v) * width_s from two 8-byte ring loads (L2 hits).  Excitation
-//   chunk: eta(t - tau_j), linearly interpolated in the precomputed table (src/wave_types.cpp:797-831), times width_j.
+//   The right-hand side of the chunk is staged in LDS first (a few KB): radiation -- one thread per IRF sample the chunk
+//   touches finds the history bracket and weights, then every thread forms u = interp(v) * width_s for a few columns
+//   from two ring loads (L2 hits); excitation -- eta(t - tau_j), linearly interpolated in the precomputed table
+//   (src/wave_types.cpp:797-831), times width_j.  The streaming loop then only reads K and two LDS words per 16 bytes.
 // ------------------------------------------------------------------------------------------------
 template <int MT, int U>
 __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
+    // dynamic LDS: right-hand side of the chunk [chunk columns], then the bracket table [samples] + widths
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    Bracket* tab  = reinterpret_cast<Bracket*>(smem_raw);
-    double* wtab  = reinterpret_cast<double*>(tab + a.max_steps_per_chunk);
+    double* rhs  = reinterpret_cast<double*>(smem_raw);
+    Bracket* tab = reinterpret_cast<Bracket*>(rhs + a.rhs_capacity);
+    double* wtab = reinterpret_cast<double*>(tab + a.max_steps_per_chunk);
     __shared__ double red[kConvThreads / kWave][MT][16];
 
     const int nct   = a.nchunks_rad + a.nchunks_ex;
@@ -190,14 +193,14 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kk = lane >> 4;
 
-    double acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = 0.0;
-
-    if (chunk < a.nchunks_rad) {
-        const int D   = a.hist.D;
-        const int gp0 = chunk * a.chunk_gp;
-        const int gp1 = min((a.F_limit + 7) >> 3, gp0 + a.chunk_gp);
+    const bool radiation = chunk < a.nchunks_rad;
+    const Panel& M = radiation ? a.K : a.Kex;
+    int gp0, gp1;
+    if (radiation) {
+        // ---- stage u[f] = interp(v_col)(t - tau_s) * width_s for the chunk's columns ----
+        const int D = a.hist.D;
+        gp0 = chunk * a.chunk_gp;
+        gp1 = min((a.F_limit + 7) >> 3, gp0 + a.chunk_gp);
         const int c0 = gp0 * 8, c1 = min(a.F_limit, gp1 * 8);
         const int s0 = c0 / D;
         const int ns = (c1 - 1) / D - s0 + 1;
@@ -206,48 +209,39 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
             wtab[k] = a.width[s0 + k];
         }
         __syncthreads();
-        const double* __restrict__ kbase = a.K.base + ((size_t)(grp * MT) * a.K.ngp) * 128 + lane * 2;
-        const size_t tile_stride = (size_t)a.K.ngp * 128;
-#pragma unroll U
-        for (int gp = gp0 + wave; gp < gp1; gp += 4) {
-            dvec2 kv[MT];
-            // K is streamed exactly once per step: non-temporal loads keep it from evicting the ring from L2
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                kv[m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128));
-            double u[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int f = gp * 8 + 4 * h + kk;
-                if (f < c1) {
-                    const int s   = f / D;
-                    const int col = f - s * D;
-                    u[h] = interp_velocity(a.hist, tab[s - s0], col) * wtab[s - s0];
-                } else {
-                    u[h] = 0.0;
-                }
+        for (int f = c0 + tid; f < gp1 * 8; f += kConvThreads) {
+            double u = 0.0;
+            if (f < c1) {
+                const int s = f / D, col = f - s * D;
+                u = interp_velocity(a.hist, tab[s - s0], col) * wtab[s - s0];
             }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                acc[m] = fma(kv[m].x, u[0], acc[m]);
-                acc[m] = fma(kv[m].y, u[1], acc[m]);
-            }
+            rhs[f - c0] = u;
         }
     } else {
-        const int gp0 = (chunk - a.nchunks_rad) * a.chunk_gp_ex;
-        const int gp1 = min(a.Kex.ngp, gp0 + a.chunk_gp_ex);
-        const double* __restrict__ kbase = a.Kex.base + ((size_t)(grp * MT) * a.Kex.ngp) * 128 + lane * 2;
-        const size_t tile_stride = (size_t)a.Kex.ngp * 128;
-        for (int gp = gp0 + wave; gp < gp1; gp += 4) {
-            dvec2 kv[MT];
+        // ---- stage e[j] = eta(t - tau_j) * width_j ----
+        gp0 = (chunk - a.nchunks_rad) * a.chunk_gp_ex;
+        gp1 = min(a.Kex.ngp, gp0 + a.chunk_gp_ex);
+        for (int j = gp0 * 8 + tid; j < gp1 * 8; j += kConvThreads) rhs[j - gp0 * 8] = eta_at(a, j);
+    }
+    __syncthreads();
+
+    double acc[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) kv[m] = *reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128);
-            const double e0 = eta_at(a, gp * 8 + kk), e1 = eta_at(a, gp * 8 + 4 + kk);
+    for (int m = 0; m < MT; ++m) acc[m] = 0.0;
+    const double* __restrict__ kbase = M.base + ((size_t)(grp * MT) * M.ngp) * 128 + lane * 2;
+    const size_t tile_stride = (size_t)M.ngp * 128;
+#pragma unroll U
+    for (int gp = gp0 + wave; gp < gp1; gp += 4) {
+        dvec2 kv[MT];
+        // the matrix is streamed exactly once per step: non-temporal loads keep it from evicting the ring from L2
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                acc[m] = fma(kv[m].x, e0, acc[m]);
-                acc[m] = fma(kv[m].y, e1, acc[m]);
-            }
+        for (int m = 0; m < MT; ++m)
+            kv[m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128));
+        const double u0 = rhs[(gp - gp0) * 8 + kk], u1 = rhs[(gp - gp0) * 8 + 4 + kk];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = fma(kv[m].x, u0, acc[m]);
+            acc[m] = fma(kv[m].y, u1, acc[m]);
         }
     }
 
@@ -279,7 +273,7 @@ void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
         const char* e = std::getenv("HC_CONV_UNROLL");  // tuning experiments only
         return e ? std::atoi(e) : 2;
     }();
-    const size_t smem = (size_t)max(1, a.max_steps_per_chunk) * (sizeof(Bracket) + sizeof(double));
+    const size_t smem = (size_t)a.rhs_capacity * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * (sizeof(Bracket) + sizeof(double));
     if (mt == 4) launch_conv_step_mt<4>(a, unroll, nblocks, smem, stream);
     else if (mt == 2) launch_conv_step_mt<2>(a, unroll, nblocks, smem, stream);
     else launch_conv_step_mt<1>(a, unroll, nblocks, smem, stream);

@@ -46,6 +46,7 @@ struct StepArgs {
     int chunk_gp;         // column groups per radiation chunk
     int nchunks_rad;
     int max_steps_per_chunk;  // LDS bracket table entries
+    int rhs_capacity;         // LDS right-hand-side entries: 8 * max(chunk_gp, chunk_gp_ex)
     HistoryView hist;
     const double* tau;    // [S] radiation IRF sample times
     const double* width;  // [S] trapezoid widths

@@ -282,17 +282,25 @@ void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // conv_block_kernel<MT>: the look-ahead pass.  C[row, j] = sum_f K[row, f] * U[f, j], j = 0..15, with
 //   U[(s,col), j] = interp(v_col)(tpred[j] - tau_s) * width_s   for s >= s_cut[j], else 0
-// on v_mfma_f64_16x16x4_f64: the 16-byte word a lane streams from a K panel is the A operand of two MFMAs, the lane
-// forms its B operand (one column, step j = lane & 15) from the LDS bracket table [sample][j] and two ring loads.
-// Same grid / chunk mapping as conv_step_kernel; K is read once for 16 steps, so the pass stays HBM-bound
-// (32 flop/B, FP64 MFMA ~ 1/3 busy).  Partials [chunk][j][row], reduced in fixed order by reduce_block_kernel.
+// on v_mfma_f64_16x16x4_f64: the 16-byte word a lane streams from a K panel is the A operand of two MFMAs.  The chunk is
+// walked in sub-tiles of 128 columns: the wave first issues its K loads of the sub-tile, then the workgroup stages
+// U[16 steps][128 columns] in LDS (bracket table [sample][j] in LDS + two coalesced ring loads per value) while those
+// loads are in flight, then each lane reads its B operand (one column, step j = lane & 15) from LDS (padded rows:
+// conflict-free ds_read_b64).  Same grid / chunk mapping as conv_step_kernel; K is read once for 16 steps, so the pass
+// stays HBM-bound (32 flop/B).  Partials [chunk][j][row], reduced in fixed order by reduce_block_kernel.
 // ------------------------------------------------------------------------------------------------
+static constexpr int kSubGp     = 16;                 // column groups per staged sub-tile (4 per wave)
+static constexpr int kSubCols   = kSubGp * 8;         // 128 columns
+static constexpr int kUStride   = kSubCols + 2;       // LDS row stride of U[j][col] in doubles: conflict-free ds_read_b64 for the B operand
+static constexpr int kUDoubles  = kLookahead * kUStride;
+
 template <int MT>
 __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
+    // dynamic LDS: U sub-tile [16][130] (re-used as the cross-wave reduction buffer at the end), bracket table [ns][16], widths [ns]
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    Bracket* tab = reinterpret_cast<Bracket*>(smem_raw);                                   // [ns][16]
-    double* wtab = reinterpret_cast<double*>(tab + (size_t)a.max_steps_per_chunk * kLookahead);  // [ns]
-    __shared__ double red[kConvThreads / kWave][MT][256];
+    double* Us   = reinterpret_cast<double*>(smem_raw);
+    Bracket* tab = reinterpret_cast<Bracket*>(Us + a.lds_front_doubles);
+    double* wtab = reinterpret_cast<double*>(tab + (size_t)a.max_steps_per_chunk * kLookahead);
 
     const int chunk = blockIdx.x % a.nchunks;
     const int grp   = blockIdx.x / a.nchunks;
@@ -313,7 +321,6 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
         tab[idx] = b;
         if (j == 0) wtab[k] = a.width[s];
     }
-    __syncthreads();
 
     dvec4 acc[MT];
 #pragma unroll
@@ -321,39 +328,66 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
 
     const double* __restrict__ kbase = a.K.base + ((size_t)(grp * MT) * a.K.ngp) * 128 + lane * 2;
     const size_t tile_stride = (size_t)a.K.ngp * 128;
-#pragma unroll 2
-    for (int gp = gp0 + wave; gp < gp1; gp += 4) {
-        dvec2 kv[MT];
+    const int fl = tid & (kSubCols - 1);   // column of the sub-tile this thread stages
+    const int jh = tid >> 7;               // it stages steps jh, jh+2, ..., jh+14
+
+    for (int sub0 = gp0; sub0 < gp1; sub0 += kSubGp) {
+        // 1. put this wave's K fragments of the sub-tile in flight (HBM latency overlaps the staging below)
+        dvec2 kv[kSubGp / 4][MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-            kv[m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128));
-        double u[2];
+        for (int it = 0; it < kSubGp / 4; ++it) {
+            const int gp = sub0 + wave + 4 * it;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int f = gp * 8 + 4 * h + kk;
-            if (f < c1) {
-                const int s   = f / D;
-                const int col = f - s * D;
-                u[h] = interp_velocity(a.hist, tab[(s - s0) * kLookahead + jstep], col) * wtab[s - s0];
-            } else {
-                u[h] = 0.0;
+            for (int m = 0; m < MT; ++m) {
+                if (gp < gp1)
+                    kv[it][m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128));
+                else
+                    kv[it][m] = dvec2{0.0, 0.0};
             }
         }
+        __syncthreads();  // previous sub-tile's U fully consumed (also orders the bracket table on the first pass)
+        // 2. stage U[j][col] = interp(v_col)(tpred[j] - tau_s) * width_s for 128 columns x 16 steps
+        {
+            const int f = sub0 * 8 + fl;
+            if (f < c1) {
+                const int s = f / D, col = f - s * D;
+                const double w = wtab[s - s0];
+                const Bracket* __restrict__ row = tab + (size_t)(s - s0) * kLookahead;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[m].x, u[0], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[m].y, u[1], acc[m], 0, 0, 0);
+                for (int q = 0; q < kLookahead / 2; ++q) {
+                    const int j = jh + 2 * q;
+                    Us[j * kUStride + fl] = interp_velocity(a.hist, row[j], col) * w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + fl] = 0.0;
+            }
+        }
+        __syncthreads();
+        // 3. 2 MFMAs per streamed 16-byte word and row tile
+#pragma unroll
+        for (int it = 0; it < kSubGp / 4; ++it) {
+            const int gl = wave + 4 * it;  // column group inside the sub-tile
+            const double u0 = Us[jstep * kUStride + gl * 8 + kk];
+            const double u1 = Us[jstep * kUStride + gl * 8 + 4 + kk];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].x, u0, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].y, u1, acc[m], 0, 0, 0);
+            }
         }
     }
-    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
+    __syncthreads();
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg.  red[wave][m][row*16 + j] aliases Us.
+    double* red = Us;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][m][(kk + 4 * r) * 16 + jstep] = acc[m][r];
+        for (int r = 0; r < 4; ++r) red[((size_t)wave * MT + m) * 256 + (kk + 4 * r) * 16 + jstep] = acc[m][r];
     __syncthreads();
     for (int idx = tid; idx < MT * 256; idx += kConvThreads) {
         const int m = idx >> 8, e = idx & 255, row = e >> 4, j = e & 15;
-        const double v = ((red[0][m][e] + red[1][m][e]) + red[2][m][e]) + red[3][m][e];
+        const double v = ((red[(0 * MT + m) * 256 + e] + red[(1 * MT + m) * 256 + e]) + red[(2 * MT + m) * 256 + e]) + red[(3 * MT + m) * 256 + e];
         a.partials[((size_t)chunk * kLookahead + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
     }
 }
@@ -361,10 +395,13 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
 void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
     const int nblocks = a.ngroups * a.nchunks;
     if (nblocks <= 0) return;
-    const size_t smem = (size_t)max(1, a.max_steps_per_chunk) * (kLookahead * sizeof(Bracket) + sizeof(double));
-    if (mt == 4) hipLaunchKernelGGL((conv_block_kernel<4>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-    else if (mt == 2) hipLaunchKernelGGL((conv_block_kernel<2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-    else hipLaunchKernelGGL((conv_block_kernel<1>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    BlockArgs b = a;
+    b.lds_front_doubles = max(kUDoubles, 4 * mt * 256);  // U sub-tile, later the [wave][tile][16x16] reduction buffer
+    const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) +
+                        (size_t)max(1, a.max_steps_per_chunk) * (kLookahead * sizeof(Bracket) + sizeof(double));
+    if (mt == 4) hipLaunchKernelGGL((conv_block_kernel<4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    else if (mt == 2) hipLaunchKernelGGL((conv_block_kernel<2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    else hipLaunchKernelGGL((conv_block_kernel<1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
 }
 
 __device__ __forceinline__ double lane16_sum(double v) {

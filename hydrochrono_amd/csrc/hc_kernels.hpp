@@ -75,6 +75,7 @@ struct BlockArgs {
     int chunk_gp;
     int nchunks;
     int max_steps_per_chunk;
+    int lds_front_doubles;  // set by the launcher
     HistoryView hist;
     double tpred[kLookahead];  // predicted step times, tpred[0] = hist.t
     int s_cut[kLookahead];

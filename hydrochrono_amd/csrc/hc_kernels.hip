@@ -331,9 +331,10 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
     const int fl = tid & (kSubCols - 1);   // column of the sub-tile this thread stages
     const int jh = tid >> 7;               // it stages steps jh, jh+2, ..., jh+14
 
-    for (int sub0 = gp0; sub0 < gp1; sub0 += kSubGp) {
-        // 1. put this wave's K fragments of the sub-tile in flight (HBM latency overlaps the staging below)
-        dvec2 kv[kSubGp / 4][MT];
+    // LDS-only barrier: unlike __syncthreads() it does not drain the vector-memory counter, so the K loads of the
+    // next sub-tile stay in flight across it
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto load_sub = [&](int sub0, dvec2 (&kv)[kSubGp / 4][MT]) {
 #pragma unroll
         for (int it = 0; it < kSubGp / 4; ++it) {
             const int gp = sub0 + wave + 4 * it;
@@ -345,8 +346,13 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
                     kv[it][m] = dvec2{0.0, 0.0};
             }
         }
-        __syncthreads();  // previous sub-tile's U fully consumed (also orders the bracket table on the first pass)
-        // 2. stage U[j][col] = interp(v_col)(tpred[j] - tau_s) * width_s for 128 columns x 16 steps
+    };
+
+    dvec2 kv[kSubGp / 4][MT], kv_next[kSubGp / 4][MT];
+    load_sub(gp0, kv);
+    __syncthreads();  // bracket table complete
+    for (int sub0 = gp0; sub0 < gp1; sub0 += kSubGp) {
+        // 1. stage U[j][col] = interp(v_col)(tpred[j] - tau_s) * width_s for 128 columns x 16 steps
         {
             const int f = sub0 * 8 + fl;
             if (f < c1) {
@@ -363,19 +369,25 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
                 for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + fl] = 0.0;
             }
         }
-        __syncthreads();
-        // 3. 2 MFMAs per streamed 16-byte word and row tile
+        lds_barrier();
+        // 2. put the NEXT sub-tile's K fragments in flight: their HBM latency overlaps the MFMA phase below
+        if (sub0 + kSubGp < gp1) load_sub(sub0 + kSubGp, kv_next);
+        // 3. 2 MFMAs per streamed 16-byte word and row tile; consecutive MFMAs use different accumulators
 #pragma unroll
         for (int it = 0; it < kSubGp / 4; ++it) {
             const int gl = wave + 4 * it;  // column group inside the sub-tile
             const double u0 = Us[jstep * kUStride + gl * 8 + kk];
             const double u1 = Us[jstep * kUStride + gl * 8 + 4 + kk];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].x, u0, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].y, u1, acc[m], 0, 0, 0);
-            }
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].x, u0, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].y, u1, acc[m], 0, 0, 0);
         }
+        lds_barrier();  // U consumed
+#pragma unroll
+        for (int it = 0; it < kSubGp / 4; ++it)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) kv[it][m] = kv_next[it][m];
     }
     __syncthreads();
     // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg.  red[wave][m][row*16 + j] aliases Us.

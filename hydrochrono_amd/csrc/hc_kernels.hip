@@ -282,24 +282,25 @@ void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // conv_block_kernel<MT>: the look-ahead pass.  C[row, j] = sum_f K[row, f] * U[f, j], j = 0..15, with
 //   U[(s,col), j] = interp(v_col)(tpred[j] - tau_s) * width_s   for s >= s_cut[j], else 0
-// on v_mfma_f64_16x16x4_f64: the 16-byte word a lane streams from a K panel is the A operand of two MFMAs.  The chunk is
-// walked in sub-tiles of 128 columns: the wave first issues its K loads of the sub-tile, then the workgroup stages
-// U[16 steps][128 columns] in LDS (bracket table [sample][j] in LDS + two coalesced ring loads per value) while those
-// loads are in flight, then each lane reads its B operand (one column, step j = lane & 15) from LDS (padded rows:
-// conflict-free ds_read_b64).  Same grid / chunk mapping as conv_step_kernel; K is read once for 16 steps, so the pass
-// stays HBM-bound (32 flop/B).  Partials [chunk][j][row], reduced in fixed order by reduce_block_kernel.
+// on v_mfma_f64_16x16x4_f64: the 16-byte word a lane streams from a K panel is the A operand of two MFMAs.  Each wave
+// walks its share of the chunk in sub-tiles of 32 columns: it issues the K loads of the sub-tile, stages
+// U[16 steps][32 columns] in a wave-private LDS tile (bracket table [sample][j] in LDS + two ring loads per value) while
+// those loads are in flight, then every lane reads its B operand (one column, step j = lane & 15) back from LDS (padded
+// rows: conflict-free ds_read_b64).  No workgroup barrier inside the loop, so waves drift out of phase and some wave is
+// always loading.  Same grid / chunk mapping as conv_step_kernel; K is read once for 16 steps, so the pass stays
+// HBM-bound (32 flop/B).  Partials [chunk][j][row], reduced in fixed order by reduce_block_kernel.
 // ------------------------------------------------------------------------------------------------
-static constexpr int kSubGp     = 16;                 // column groups per staged sub-tile (4 per wave)
-static constexpr int kSubCols   = kSubGp * 8;         // 128 columns
-static constexpr int kUStride   = kSubCols + 2;       // LDS row stride of U[j][col] in doubles: conflict-free ds_read_b64 for the B operand
-static constexpr int kUDoubles  = kLookahead * kUStride;
+static constexpr int kWaveGp    = 4;                  // column groups a wave handles per sub-tile (32 columns)
+static constexpr int kUStride   = kWaveGp * 8 + 2;    // LDS row stride of a wave's U[j][col] in doubles: conflict-free ds_read_b64 of the B operand
+static constexpr int kUWave     = kLookahead * kUStride;  // doubles per wave
 
 template <int MT>
 __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
-    // dynamic LDS: U sub-tile [16][130] (re-used as the cross-wave reduction buffer at the end), bracket table [ns][16], widths [ns]
+    // dynamic LDS: per-wave U sub-tiles [4][16][34] (re-used as the cross-wave reduction buffer at the end),
+    // bracket table [ns][16], widths [ns]
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    double* Us   = reinterpret_cast<double*>(smem_raw);
-    Bracket* tab = reinterpret_cast<Bracket*>(Us + a.lds_front_doubles);
+    double* Uall = reinterpret_cast<double*>(smem_raw);
+    Bracket* tab = reinterpret_cast<Bracket*>(Uall + a.lds_front_doubles);
     double* wtab = reinterpret_cast<double*>(tab + (size_t)a.max_steps_per_chunk * kLookahead);
 
     const int chunk = blockIdx.x % a.nchunks;
@@ -321,6 +322,8 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
         tab[idx] = b;
         if (j == 0) wtab[k] = a.width[s];
     }
+    __syncthreads();  // the only workgroup barrier before the epilogue: from here on the four waves run independently,
+                      // so their load / stage / MFMA phases drift apart and HBM stays busy
 
     dvec4 acc[MT];
 #pragma unroll
@@ -328,15 +331,15 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
 
     const double* __restrict__ kbase = a.K.base + ((size_t)(grp * MT) * a.K.ngp) * 128 + lane * 2;
     const size_t tile_stride = (size_t)a.K.ngp * 128;
-    const int fl = tid & (kSubCols - 1);   // column of the sub-tile this thread stages
-    const int jh = tid >> 7;               // it stages steps jh, jh+2, ..., jh+14
+    double* Us = Uall + wave * kUWave;
+    // staging role of this lane: column c8 of column group `sit` of the wave's sub-tile, steps jh, jh+2, ..., jh+14
+    const int c8 = lane & 7, sit = (lane >> 3) & 3, jh = lane >> 5;
 
-    // LDS-only barrier: unlike __syncthreads() it does not drain the vector-memory counter, so the K loads of the
-    // next sub-tile stay in flight across it
-    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto load_sub = [&](int sub0, dvec2 (&kv)[kSubGp / 4][MT]) {
+    for (int sub0 = gp0; sub0 < gp1; sub0 += 4 * kWaveGp) {
+        // 1. put this wave's K fragments of the sub-tile in flight
+        dvec2 kv[kWaveGp][MT];
 #pragma unroll
-        for (int it = 0; it < kSubGp / 4; ++it) {
+        for (int it = 0; it < kWaveGp; ++it) {
             const int gp = sub0 + wave + 4 * it;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -346,15 +349,9 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
                     kv[it][m] = dvec2{0.0, 0.0};
             }
         }
-    };
-
-    dvec2 kv[kSubGp / 4][MT], kv_next[kSubGp / 4][MT];
-    load_sub(gp0, kv);
-    __syncthreads();  // bracket table complete
-    for (int sub0 = gp0; sub0 < gp1; sub0 += kSubGp) {
-        // 1. stage U[j][col] = interp(v_col)(tpred[j] - tau_s) * width_s for 128 columns x 16 steps
+        // 2. stage U[j][col] = interp(v_col)(tpred[j] - tau_s) * width_s for the wave's 32 columns x 16 steps
         {
-            const int f = sub0 * 8 + fl;
+            const int f = (sub0 + wave + 4 * sit) * 8 + c8;
             if (f < c1) {
                 const int s = f / D, col = f - s * D;
                 const double w = wtab[s - s0];
@@ -362,36 +359,29 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
 #pragma unroll
                 for (int q = 0; q < kLookahead / 2; ++q) {
                     const int j = jh + 2 * q;
-                    Us[j * kUStride + fl] = interp_velocity(a.hist, row[j], col) * w;
+                    Us[j * kUStride + sit * 8 + c8] = interp_velocity(a.hist, row[j], col) * w;
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + fl] = 0.0;
+                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = 0.0;
             }
         }
-        lds_barrier();
-        // 2. put the NEXT sub-tile's K fragments in flight: their HBM latency overlaps the MFMA phase below
-        if (sub0 + kSubGp < gp1) load_sub(sub0 + kSubGp, kv_next);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private LDS tile: no barrier needed
         // 3. 2 MFMAs per streamed 16-byte word and row tile; consecutive MFMAs use different accumulators
 #pragma unroll
-        for (int it = 0; it < kSubGp / 4; ++it) {
-            const int gl = wave + 4 * it;  // column group inside the sub-tile
-            const double u0 = Us[jstep * kUStride + gl * 8 + kk];
-            const double u1 = Us[jstep * kUStride + gl * 8 + 4 + kk];
+        for (int it = 0; it < kWaveGp; ++it) {
+            const double u0 = Us[jstep * kUStride + it * 8 + kk];
+            const double u1 = Us[jstep * kUStride + it * 8 + 4 + kk];
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].x, u0, acc[m], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].y, u1, acc[m], 0, 0, 0);
         }
-        lds_barrier();  // U consumed
-#pragma unroll
-        for (int it = 0; it < kSubGp / 4; ++it)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) kv[it][m] = kv_next[it][m];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // U reads done before the next sub-tile overwrites it
     }
     __syncthreads();
-    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg.  red[wave][m][row*16 + j] aliases Us.
-    double* red = Us;
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg.  red[wave][m][row*16 + j] aliases U.
+    double* red = Uall;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -408,7 +398,7 @@ void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
     const int nblocks = a.ngroups * a.nchunks;
     if (nblocks <= 0) return;
     BlockArgs b = a;
-    b.lds_front_doubles = max(kUDoubles, 4 * mt * 256);  // U sub-tile, later the [wave][tile][16x16] reduction buffer
+    b.lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // per-wave U sub-tiles, later the [wave][tile][16x16] reduction buffer
     const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) +
                         (size_t)max(1, a.max_steps_per_chunk) * (kLookahead * sizeof(Bracket) + sizeof(double));
     if (mt == 4) hipLaunchKernelGGL((conv_block_kernel<4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);

@@ -133,14 +133,19 @@ __device__ Bracket find_bracket(const HistoryView& h, double q, int* error_flag)
     return b;
 }
 
-// interpolated velocity of column `col` for bracket b (exact copies where the reference returns early)
-__device__ __forceinline__ double interp_velocity(const HistoryView& h, const Bracket& b, int col) {
-    if (b.wo == 0.0 && b.wn == 0.0) return 0.0;
-    const double vo = h.ring_v[(size_t)b.slot_older * h.D + col];
-    if (b.wn == 0.0) return vo;
-    const double vn = (b.slot_newer >= 0) ? h.ring_v[(size_t)b.slot_newer * h.D + col] : state_velocity(h.state, h.N, col);
-    if (b.wo == 0.0) return vn;
-    return b.wo * vo + b.wn * vn;
+// interpolated velocity of column `col` for bracket b (exact copies where the reference returns early).  Branch-free:
+// both ring loads are issued unconditionally (slots of masked brackets are 0, a valid row), so a caller that stages
+// several values gets all its loads in flight at once instead of one dependent round trip per branch.
+// vstate = velocity of `col` in the current state (used when the newer sample is the current one).
+__device__ __forceinline__ double interp_velocity(const HistoryView& h, const Bracket& b, int col, double vstate) {
+    const double vo  = h.ring_v[(size_t)b.slot_older * h.D + col];
+    const double vnr = h.ring_v[(size_t)max(b.slot_newer, 0) * h.D + col];
+    const double vn  = (b.slot_newer >= 0) ? vnr : vstate;
+    double v = b.wo * vo + b.wn * vn;
+    v = (b.wo == 0.0) ? vn : v;
+    v = (b.wn == 0.0) ? vo : v;
+    v = (b.wo == 0.0 && b.wn == 0.0) ? 0.0 : v;
+    return v;
 }
 
 __device__ __forceinline__ double eta_at(const StepArgs& a, int j) {
@@ -213,7 +218,7 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
             double u = 0.0;
             if (f < c1) {
                 const int s = f / D, col = f - s * D;
-                u = interp_velocity(a.hist, tab[s - s0], col) * wtab[s - s0];
+                u = interp_velocity(a.hist, tab[s - s0], col, state_velocity(a.hist.state, a.hist.N, col)) * wtab[s - s0];
             }
             rhs[f - c0] = u;
         }
@@ -354,13 +359,14 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
             const int f = (sub0 + wave + 4 * sit) * 8 + c8;
             if (f < c1) {
                 const int s = f / D, col = f - s * D;
-                const double w = wtab[s - s0];
+                const double w      = wtab[s - s0];
+                const double vstate = state_velocity(a.hist.state, a.hist.N, col);
                 const Bracket* __restrict__ row = tab + (size_t)(s - s0) * kLookahead;
+                double uq[kLookahead / 2];
 #pragma unroll
-                for (int q = 0; q < kLookahead / 2; ++q) {
-                    const int j = jh + 2 * q;
-                    Us[j * kUStride + sit * 8 + c8] = interp_velocity(a.hist, row[j], col) * w;
-                }
+                for (int q = 0; q < kLookahead / 2; ++q) uq[q] = interp_velocity(a.hist, row[jh + 2 * q], col, vstate) * w;
+#pragma unroll
+                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = uq[q];
             } else {
 #pragma unroll
                 for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = 0.0;

@@ -180,7 +180,8 @@ void choose_conv_config(hc_ctx* c) {
     c->nchunks_rad       = static_cast<int>((c->ngp + gps - 1) / gps);
     // look-ahead pass: fewer, longer chunks (its partials are 16x larger); bracket table [samples][16] must fit in LDS
     long long bgps = std::max(8, env_int("HC_BLOCK_CHUNK_GP", 192));
-    const long long cap = std::max<long long>(8, (64LL * c->D) / 8);
+    bgps           = std::max<long long>(bgps, (c->ngp + 255) / 256);  // at most 256 chunks: partials stay ~1 % of K
+    const long long cap = std::max<long long>(8, (64LL * c->D) / 8);   // bracket table [samples][16] must fit in LDS
     bgps                = std::min(bgps, cap);
     bgps                = std::max<long long>(16, ((bgps + 15) / 16) * 16);  // whole 16-group sub-tiles
     c->chunk_gp_block   = static_cast<int>(bgps);

@@ -176,6 +176,7 @@ void choose_conv_config(hc_ctx* c) {
     long long nch        = std::max<long long>(1, target_wgs / std::max(1, c->ngroups));
     long long gps        = (c->ngp + nch - 1) / nch;
     gps                  = std::max<long long>(16, ((gps + 3) / 4) * 4);  // every wave of the workgroup gets work
+    gps                  = std::min<long long>(gps, 512);                 // the chunk's right-hand side is staged in LDS (<= 32 KB)
     c->chunk_gp          = static_cast<int>(gps);
     c->nchunks_rad       = static_cast<int>((c->ngp + gps - 1) / gps);
     // look-ahead pass: fewer, longer chunks (its partials are 16x larger); bracket table [samples][16] must fit in LDS

@@ -618,6 +618,8 @@ int hc_set_rirf(hc_ctx* c, int body, const double* t, int S, const double* K) {
                 throw Error(HC_ERR_RUNTIME, "RIRF time vectors have to be exactly the same for all bodies.");
     }
     c->bodies[body].have_rirf = true;
+    for (int j = 0; j < S; ++j)
+        if (t[j] < 0.0) c->device_errors_possible = true;  // a query t - tau could then exceed t (reference: throws at :370)
     if (is_local(c, body)) {
         HC_HIP(hipMemcpyAsync(c->d_stage.p, K, static_cast<size_t>(6) * c->D * S * sizeof(double), hipMemcpyHostToDevice, c->stream));
         hc::launch_relayout_rirf(c->d_stage.p, c->dK.p, c->ngp, c->D, S, 6 * (body - c->b0), c->rho, c->stream);
@@ -988,14 +990,19 @@ int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const dou
     }
     c->prev_time = t;  // :747 (set before the terms are computed, so a throwing step is not retried)
     c->have_prev = true;
-    stage_state(c, pos, rpy, linvel, angvel);
-    enqueue_step(c, t, c->d_state.p, nullptr, c->stream, StepFlags{});
-    const size_t nb = c->Dloc * sizeof(double);
-    HC_HIP(hipMemcpyAsync(c->h_out.p + 3 * c->Dloc, c->d_total.p, nb, hipMemcpyDeviceToHost, c->stream));
-    HC_HIP(hipMemcpyAsync(c->h_err.p, c->d_err.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // Zero-copy boundary: the 12N state doubles are written into mapped pinned memory the kernels read directly, and
+    // finalize_kernel stores the totals (and the error flag is polled) in mapped pinned memory as well -- no memcpy
+    // launches on the critical path of a small-N step, just two kernels and one stream synchronisation.
+    const int n3 = 3 * c->N;
+    double* h    = c->h_state.p;
+    std::memcpy(h, pos, n3 * sizeof(double));
+    std::memcpy(h + n3, rpy, n3 * sizeof(double));
+    std::memcpy(h + 2 * n3, linvel, n3 * sizeof(double));
+    std::memcpy(h + 3 * n3, angvel, n3 * sizeof(double));
+    enqueue_step(c, t, c->h_state.dp, c->h_out.dp + 3 * c->Dloc, c->stream, StepFlags{});
     HC_HIP(hipStreamSynchronize(c->stream));
-    if (*c->h_err.p != 0) check_device_flag(c);
-    std::memcpy(force_out, c->h_out.p + 3 * c->Dloc, nb);
+    if (c->device_errors_possible) check_device_flag(c);
+    std::memcpy(force_out, c->h_out.p + 3 * c->Dloc, c->Dloc * sizeof(double));
     HC_API_END(c)
 }
 

@@ -55,7 +55,8 @@ struct DeviceBuffer {
 
 template <class T>
 struct PinnedBuffer {
-    T* p     = nullptr;
+    T* p     = nullptr;  // host address
+    T* dp    = nullptr;  // the same memory as seen by the GPU (zero-copy)
     size_t n = 0;
     PinnedBuffer() = default;
     PinnedBuffer(const PinnedBuffer&)            = delete;
@@ -68,7 +69,8 @@ struct PinnedBuffer {
         p = nullptr;
         n = 0;
         if (count == 0) return;
-        HC_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocDefault));
+        HC_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocMapped));
+        HC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dp), p, 0));
         n = count;
     }
 };
@@ -161,6 +163,7 @@ struct hc_ctx {
     hc::DeviceBuffer<int> d_err;
     hc::PinnedBuffer<double> h_state, h_out;
     hc::PinnedBuffer<int> h_err;
+    bool device_errors_possible = false;  // radiation IRF times < 0 (the only way a per-step query can leave its bracket)
 
     // profiling
     bool profiling = false;

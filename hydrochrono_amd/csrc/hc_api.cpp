@@ -990,16 +990,21 @@ int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const dou
     }
     c->prev_time = t;  // :747 (set before the terms are computed, so a throwing step is not retried)
     c->have_prev = true;
-    // Zero-copy boundary: the 12N state doubles are written into mapped pinned memory the kernels read directly, and
-    // finalize_kernel stores the totals (and the error flag is polled) in mapped pinned memory as well -- no memcpy
-    // launches on the critical path of a small-N step, just two kernels and one stream synchronisation.
+    // Zero-copy boundary: finalize_kernel stores the totals straight into mapped pinned memory, and for small systems the
+    // kernels read the 12N state doubles from mapped pinned memory too -- no memcpy launches on the critical path of a
+    // small-N step, just two kernels and one stream synchronisation.
     const int n3 = 3 * c->N;
     double* h    = c->h_state.p;
     std::memcpy(h, pos, n3 * sizeof(double));
     std::memcpy(h + n3, rpy, n3 * sizeof(double));
     std::memcpy(h + 2 * n3, linvel, n3 * sizeof(double));
     std::memcpy(h + 3 * n3, angvel, n3 * sizeof(double));
-    enqueue_step(c, t, c->h_state.dp, c->h_out.dp + 3 * c->Dloc, c->stream, StepFlags{});
+    const double* d_state = c->h_state.dp;
+    if (c->N > 8) {  // many workgroups re-read the state: one small H2D copy beats thousands of PCIe reads
+        HC_HIP(hipMemcpyAsync(c->d_state.p, h, 4 * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        d_state = c->d_state.p;
+    }
+    enqueue_step(c, t, d_state, c->h_out.dp + 3 * c->Dloc, c->stream, StepFlags{});
     HC_HIP(hipStreamSynchronize(c->stream));
     if (c->device_errors_possible) check_device_flag(c);
     std::memcpy(force_out, c->h_out.p + 3 * c->Dloc, c->Dloc * sizeof(double));

@@ -397,6 +397,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     a.nchunks_rad         = nchunks_rad;
     a.max_steps_per_chunk = (chunk_gp * 8) / c->D + 2;
     a.rhs_capacity        = 8 * std::max(chunk_gp, c->chunk_gp_ex);
+    a.stream_once         = (mode == 2 && env_int("HC_REM_NT", 0) == 0) ? 0 : 1;
     a.hist                = hv;
     a.tau                 = c->d_tau.p;
     a.width               = c->d_width.p;

@@ -238,10 +238,16 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
 #pragma unroll U
     for (int gp = gp0 + wave; gp < gp1; gp += 4) {
         dvec2 kv[MT];
-        // the matrix is streamed exactly once per step: non-temporal loads keep it from evicting the ring from L2
+        // a matrix streamed exactly once per step uses non-temporal loads (keeps the ring in L2); the short remainder
+        // of a look-ahead step re-reads the same newest-sample columns every step, so it uses normal loads and stays cached
+        if (a.stream_once) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-            kv[m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128));
+            for (int m = 0; m < MT; ++m)
+                kv[m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128));
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) kv[m] = *reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128);
+        }
         const double u0 = rhs[(gp - gp0) * 8 + kk], u1 = rhs[(gp - gp0) * 8 + 4 + kk];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {

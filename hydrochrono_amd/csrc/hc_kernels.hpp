@@ -47,6 +47,7 @@ struct StepArgs {
     int nchunks_rad;
     int max_steps_per_chunk;  // LDS bracket table entries
     int rhs_capacity;         // LDS right-hand-side entries: 8 * max(chunk_gp, chunk_gp_ex)
+    int stream_once;          // 1: non-temporal K loads (plain step); 0: cacheable (remainder of a look-ahead step)
     HistoryView hist;
     const double* tau;    // [S] radiation IRF sample times
     const double* width;  // [S] trapezoid widths

@@ -129,10 +129,18 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hydro-force path has no CPU fallback")
+    # HC_BENCH_SHARE_GPU=1 (functional test of the N > 1 code path on a one-GPU box): all ranks use device 0 and the
+    # force all-gather goes over gloo instead of RCCL.  Never used for reported numbers.
+    share_gpu = os.environ.get("HC_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from hydrochrono_amd.parallel import ForceExchange, body_shard
     strong = args.scaling == "strong"
@@ -192,7 +200,7 @@ def main():
     prof = gpu.profile()
     gpu.enable_profiling(False)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -9,10 +9,9 @@ sea state with 512 wave components, prescribed body motion with dt = dt_rirf = 0
 pre-filled over the whole 10.23 s IRF window).  A "step" = one evaluation of all 6N hydrodynamic forces
 (hydrostatic - radiation + waves) through hc_step_device, body states already resident in HBM.
 
-Multi-GPU, default (weak scaling): every rank owns one independent 64-body farm (a block-diagonal 64*G-body array
-whose cross-farm coupling blocks are structurally zero); after each step the per-farm force vectors are all-gathered
-over RCCL so every rank holds the full 6*64*G vector a host integrator needs -- the single exchange step of the
-path.  value = farms * K / max-over-ranks time.
+Multi-GPU, default (weak scaling): every rank owns one independent 64-body farm (independent simulations, e.g. the
+iterations of a design exploration); the farms share nothing, so there is no data-path collective -- only the
+barriers around the timed region.  value = farms * K / max-over-ranks time.
 
 --scaling strong --bodies 512 is configuration C4: ONE coupled 512-body array (K = 77.3 GB FP64, generated in HBM by
 hc_synth_fill) row-sharded over the ranks (hydrochrono_amd.parallel.body_shard), forces all-gathered every step;
@@ -159,7 +158,7 @@ def main():
         case = many_body_case(N, S=S_RIRF, dt_rirf=DT, n_exc=N_EXC, dt_exc=DT, seed=20251031 + rank)
         gpu = HydroForces.from_case(case, device=local_rank)
         motion = PrescribedMotion(N, rest_positions(case), seed=20251031 + rank)
-        exchange = ForceExchange(N * world, world, rank, device="cuda")  # farms concatenated
+        exchange = None  # independent farms: nothing to exchange
     waves = dict(WAVES, num_bodies=N)
     gpu.add_waves_irregular(**waves)
     gpu.set_lookahead(args.lookahead)
@@ -177,8 +176,9 @@ def main():
 
     def run(k0, k1):
         for k in range(k0, k1):
-            if world > 1:
-                # kernels write straight into the exchange's send buffer; every rank ends up with the full vector
+            if exchange is not None and world > 1:
+                # coupled array: kernels write straight into the exchange's send buffer; the RCCL all-gather leaves the
+                # full 6N force vector on every rank (the one exchange step of the path)
                 gpu.step_device(T0 + k * DT, states[k].data_ptr(), exchange.send.data_ptr(), stream)
                 exchange.gather()
             else:
@@ -249,7 +249,7 @@ def main():
                 "bodies": N, "bodies_per_gpu": (N / world if strong else N), "irf_samples": S_RIRF,
                 "wave_components": WAVES["nfrequencies"],
                 "sharding": ("body-row shards of one coupled array + RCCL all-gather of forces" if strong else
-                             "one independent farm per GPU + RCCL all-gather of forces") if world > 1 else "single GPU",
+                             "one independent farm per GPU, no data-path collective") if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -188,7 +188,7 @@ void choose_conv_config(hc_ctx* c) {
     c->chunk_gp_block   = static_cast<int>(bgps);
     c->nchunks_block    = static_cast<int>((c->ngp + bgps - 1) / bgps);
     // remainder of a look-ahead step: at most 16 samples wide
-    c->chunk_gp_rem = std::max(4, env_int("HC_REM_CHUNK_GP", 16));  // short chunks: these launches are latency-bound
+    c->chunk_gp_rem = std::max(4, env_int("HC_REM_CHUNK_GP", 8));  // short chunks: these launches are latency-bound
 }
 
 void choose_exc_config(hc_ctx* c) {
@@ -197,7 +197,7 @@ void choose_exc_config(hc_ctx* c) {
         c->chunk_gp_ex = 64;
         return;
     }
-    c->chunk_gp_ex = std::max(4, env_int("HC_EXC_CHUNK_GP", 16));  // short chunks: the excitation side is latency-bound
+    c->chunk_gp_ex = std::max(4, env_int("HC_EXC_CHUNK_GP", 8));  // short chunks: the excitation side is latency-bound
     c->nchunks_ex  = (c->ngp_ex + c->chunk_gp_ex - 1) / c->chunk_gp_ex;
 }
 

@@ -208,7 +208,7 @@ def main():
         ms = elapsed / args.steps * 1e3
         # dominant kernel: the look-ahead pass when blocking is on (one launch covers 16 steps), else the per-step kernel
         if prof["block_kernel_launches"] > 0:
-            kname, steps_per_launch = "hc::conv_block_kernel (+reduce_block_kernel)", (32 if args.lookahead >= 32 else 16)
+            kname, steps_per_launch = "hc::conv_block_kernel (+reduce_block_kernel)", 16
             conv_s = prof["block_kernel_seconds"] / prof["block_kernel_launches"]
             alg_bytes = prof["block_kernel_bytes"]
             n_timed = prof["block_kernel_launches"]
@@ -224,7 +224,7 @@ def main():
         if os.path.exists(tpath) and N == N_BODIES:
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("block_hbm_bytes_per_launch" if steps_per_launch > 1 else "hbm_bytes_per_launch")
+                traffic = tj.get("block_hbm_bytes_per_launch" if steps_per_launch == 16 else "hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -257,9 +257,9 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "steps_per_launch": steps_per_launch,
                 "mean_kernel_us": conv_s * 1e6, "launches_timed": n_timed,
                 "in_block_step_kernel_us": rem_us,
-                "note": (f"one look-ahead launch covers {steps_per_launch} steps: algorithmic bytes = {steps_per_launch} x the per-step "
-                         "figure of SURVEY 8d, while K leaves HBM once (see traffic), so frac > 1 measures the reuse, not a faster memory")
-                        if steps_per_launch > 1 else "one launch = one step",
+                "note": ("one look-ahead launch covers 16 steps: algorithmic bytes = 16 x the per-step figure of SURVEY 8d, "
+                         "while K leaves HBM once (see traffic), so frac > 1 measures the reuse, not a faster memory")
+                        if steps_per_launch == 16 else "one launch = one step",
             },
         }
         if world == 1 and not args.no_cpu_baseline and case is not None:

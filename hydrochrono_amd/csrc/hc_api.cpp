@@ -152,8 +152,6 @@ int env_int(const char* name, int fallback) {
     return e ? std::atoi(e) : fallback;
 }
 
-int normalize_lookahead(int steps) { return steps <= 0 ? 0 : (steps >= 32 ? 32 : 16); }
-
 void setup_panel_geometry(hc_ctx* c) {
     c->ntiles = (c->Dloc + 15) / 16;
     c->Dpad   = c->ntiles * 16;
@@ -207,9 +205,9 @@ void alloc_partials(hc_ctx* c) {
     const int rem_chunks = (c->ngp + c->chunk_gp_rem - 1) / c->chunk_gp_rem + 1;  // worst case: remainder spans all of K
     const size_t n = static_cast<size_t>(std::max(c->nchunks_rad, rem_chunks) + c->nchunks_ex) * c->Dpad;
     if (c->d_partials.n < n) c->d_partials.alloc(n);
-    const size_t nb = static_cast<size_t>(c->nchunks_block) * hc::kLookaheadMax * c->Dpad;
+    const size_t nb = static_cast<size_t>(c->nchunks_block) * hc::kLookahead * c->Dpad;
     if (c->d_partials_block.n < nb) c->d_partials_block.alloc(nb);
-    if (c->d_P.n < static_cast<size_t>(hc::kLookaheadMax) * c->Dpad) c->d_P.alloc(static_cast<size_t>(hc::kLookaheadMax) * c->Dpad);
+    if (c->d_P.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_P.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
 }
 
 // ---- TaperedDirect ----------------------------------------------------------------------------
@@ -285,7 +283,7 @@ int plan_step(hc_ctx* c, double t, int H) {
         --pl.cooldown;
         return 0;
     }
-    if (pl.valid && pl.j_next < pl.T) {
+    if (pl.valid && pl.j_next < hc::kLookahead) {
         if (std::fabs(t - pl.tpred[pl.j_next]) <= 1e-9 * pl.dt) return 2;
         // the caller left the predicted time grid (variable step): drop the block
         pl.valid = false;
@@ -308,15 +306,14 @@ int plan_step(hc_ctx* c, double t, int H) {
     pl.t0     = t;
     pl.dt     = dt;
     pl.j_next = 1;
-    pl.T      = c->lookahead;
-    for (int j = 0; j < pl.T; ++j) {
+    for (int j = 0; j < hc::kLookahead; ++j) {
         pl.tpred[j] = (j == 0) ? t : t + j * dt;
         // samples s >= s_cut[j] of step j need only history known now: tpred[j] - tau_s <= t (same expression as the kernel)
         int sc = 0;
         while (sc < c->S && !(pl.tpred[j] - c->tau[sc] <= t)) ++sc;
         pl.s_cut[j] = sc;
     }
-    if (pl.s_cut[pl.T - 1] > c->S / 4) {
+    if (pl.s_cut[hc::kLookahead - 1] > c->S / 4) {
         // step size comparable to the IRF window: the remainder would re-read most of K every step, so blocking cannot pay
         pl.valid    = false;
         pl.cooldown = 256;
@@ -364,8 +361,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         b.nchunks             = c->nchunks_block;
         b.max_steps_per_chunk = (c->chunk_gp_block * 8) / c->D + 2;
         b.hist                = hv;
-        b.T = c->plan.T;
-        for (int j = 0; j < c->plan.T; ++j) {
+        for (int j = 0; j < hc::kLookahead; ++j) {
             b.tpred[j] = c->plan.tpred[j];
             b.s_cut[j] = c->plan.s_cut[j];
         }
@@ -376,7 +372,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         b.ngroups    = c->ngroups;
         b.error_flag = c->d_err.p;
         hc::launch_conv_block(b, c->mt, stream);
-        hc::launch_reduce_block(c->d_partials_block.p, c->nchunks_block, c->plan.T, c->Dpad, c->d_P.p, stream);
+        hc::launch_reduce_block(c->d_partials_block.p, c->nchunks_block, c->Dpad, c->d_P.p, stream);
         P_row = c->d_P.p;
     } else if (run_rad && mode == 2) {
         j_block = c->plan.j_next++;
@@ -755,8 +751,8 @@ int hc_finalize(hc_ctx* c) {
     choose_exc_config(c);
     alloc_partials(c);
     c->prof.conv_kernel_bytes  = 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
-    c->lookahead               = normalize_lookahead(env_int("HC_LOOKAHEAD", 16));
-    c->prof.block_kernel_bytes = c->lookahead * c->prof.conv_kernel_bytes;
+    c->prof.block_kernel_bytes = hc::kLookahead * c->prof.conv_kernel_bytes;
+    c->lookahead               = env_int("HC_LOOKAHEAD", hc::kLookahead) > 0 ? hc::kLookahead : 0;
     c->plan                    = hc::Plan{};
     HC_HIP(hipStreamSynchronize(c->stream));
     c->finalized = true;
@@ -951,7 +947,7 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     alloc_partials(c);
     c->prof.conv_kernel_bytes = 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D +
                                        static_cast<double>(c->Dloc) * L + L);
-    c->prof.block_kernel_bytes = c->lookahead * 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
+    c->prof.block_kernel_bytes = hc::kLookahead * 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
     HC_HIP(hipStreamSynchronize(c->stream));
     HC_API_END(c)
 }
@@ -1093,9 +1089,8 @@ int hc_compute_waves(hc_ctx* c, double t, double* waves_out) {
 
 int hc_set_lookahead(hc_ctx* c, int steps) {
     HC_API_BEGIN(c)
-    c->lookahead = normalize_lookahead(steps);
+    c->lookahead = steps > 0 ? hc::kLookahead : 0;
     c->plan      = hc::Plan{};
-    c->prof.block_kernel_bytes = c->lookahead * 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
     HC_API_END(c)
 }
 

@@ -100,9 +100,8 @@ struct Plan {
     bool valid = false;
     double t0 = 0.0, dt = 0.0;
     int j_next = 0;
-    int T = 16;  // steps covered by the block
-    double tpred[kLookaheadMax] = {0};
-    int s_cut[kLookaheadMax]    = {0};
+    double tpred[kLookahead] = {0};
+    int s_cut[kLookahead]    = {0};
     int misses = 0, cooldown = 0;
 };
 
@@ -156,7 +155,7 @@ struct hc_ctx {
     int chunk_gp = 0, nchunks_rad = 0, chunk_gp_ex = 0, nchunks_ex = 0, ngp_ex = 0;
     int chunk_gp_block = 0, nchunks_block = 0, chunk_gp_rem = 64;
     hc::DeviceBuffer<double> d_partials, d_partials_block, d_P;
-    int lookahead = 0;  // 0: off, else 16 or 32 future steps per blocked pass
+    int lookahead = 0;  // 0: off, else kLookahead
     hc::Plan plan;
 
     // step I/O

@@ -303,17 +303,16 @@ void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 static constexpr int kWaveGp    = 4;                  // column groups a wave handles per sub-tile (32 columns)
 static constexpr int kUStride   = kWaveGp * 8 + 2;    // LDS row stride of a wave's U[j][col] in doubles: conflict-free ds_read_b64 of the B operand
+static constexpr int kUWave     = kLookahead * kUStride;  // doubles per wave
 
-// NB = number of 16-step MFMA N-blocks: look-ahead T = 16*NB
-template <int MT, int NB>
+template <int MT>
 __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
-    constexpr int T = 16 * NB;
-    // dynamic LDS: per-wave U sub-tiles [4][T][34] (re-used as the cross-wave reduction buffer at the end),
-    // bracket table [ns][T], widths [ns]
+    // dynamic LDS: per-wave U sub-tiles [4][16][34] (re-used as the cross-wave reduction buffer at the end),
+    // bracket table [ns][16], widths [ns]
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double* Uall = reinterpret_cast<double*>(smem_raw);
     Bracket* tab = reinterpret_cast<Bracket*>(Uall + a.lds_front_doubles);
-    double* wtab = reinterpret_cast<double*>(tab + (size_t)a.max_steps_per_chunk * T);
+    double* wtab = reinterpret_cast<double*>(tab + (size_t)a.max_steps_per_chunk * kLookahead);
 
     const int chunk = blockIdx.x % a.nchunks;
     const int grp   = blockIdx.x / a.nchunks;
@@ -326,8 +325,8 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
     const int c0 = gp0 * 8, c1 = min(a.F, gp1 * 8);
     const int s0 = c0 / D;
     const int ns = (c1 - 1) / D - s0 + 1;
-    for (int idx = tid; idx < ns * T; idx += kConvThreads) {
-        const int k = idx / T, j = idx - k * T, s = s0 + k;
+    for (int idx = tid; idx < ns * kLookahead; idx += kConvThreads) {
+        const int k = idx >> 4, j = idx & 15, s = s0 + k;
         Bracket b;
         b.wo = 0.0; b.wn = 0.0; b.slot_older = 0; b.slot_newer = 0;
         if (s >= a.s_cut[j]) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
@@ -337,16 +336,14 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
     __syncthreads();  // the only workgroup barrier before the epilogue: from here on the four waves run independently,
                       // so their load / stage / MFMA phases drift apart and HBM stays busy
 
-    dvec4 acc[NB][MT];
+    dvec4 acc[MT];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[nb][m] = dvec4{0.0, 0.0, 0.0, 0.0};
+    for (int m = 0; m < MT; ++m) acc[m] = dvec4{0.0, 0.0, 0.0, 0.0};
 
     const double* __restrict__ kbase = a.K.base + ((size_t)(grp * MT) * a.K.ngp) * 128 + lane * 2;
     const size_t tile_stride = (size_t)a.K.ngp * 128;
-    double* Us = Uall + wave * (T * kUStride);
-    // staging role of this lane: column c8 of column group `sit` of the wave's sub-tile, steps jh, jh+2, ..., jh+T-2
+    double* Us = Uall + wave * kUWave;
+    // staging role of this lane: column c8 of column group `sit` of the wave's sub-tile, steps jh, jh+2, ..., jh+14
     const int c8 = lane & 7, sit = (lane >> 3) & 3, jh = lane >> 5;
 
     for (int sub0 = gp0; sub0 < gp1; sub0 += 4 * kWaveGp) {
@@ -363,77 +360,62 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
                     kv[it][m] = dvec2{0.0, 0.0};
             }
         }
-        // 2. stage U[j][col] = interp(v_col)(tpred[j] - tau_s) * width_s for the wave's 32 columns x T steps
+        // 2. stage U[j][col] = interp(v_col)(tpred[j] - tau_s) * width_s for the wave's 32 columns x 16 steps
         {
             const int f = (sub0 + wave + 4 * sit) * 8 + c8;
             if (f < c1) {
                 const int s = f / D, col = f - s * D;
                 const double w      = wtab[s - s0];
                 const double vstate = state_velocity(a.hist.state, a.hist.N, col);
-                const Bracket* __restrict__ row = tab + (size_t)(s - s0) * T;
+                const Bracket* __restrict__ row = tab + (size_t)(s - s0) * kLookahead;
+                double uq[kLookahead / 2];
 #pragma unroll
-                for (int half = 0; half < NB; ++half) {
-                    double uq[8];
+                for (int q = 0; q < kLookahead / 2; ++q) uq[q] = interp_velocity(a.hist, row[jh + 2 * q], col, vstate) * w;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) uq[q] = interp_velocity(a.hist, row[jh + 2 * (q + 8 * half)], col, vstate) * w;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) Us[(jh + 2 * (q + 8 * half)) * kUStride + sit * 8 + c8] = uq[q];
-                }
+                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = uq[q];
             } else {
 #pragma unroll
-                for (int q = 0; q < T / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = 0.0;
+                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = 0.0;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private LDS tile: no barrier needed
-        // 3. 2*NB MFMAs per streamed 16-byte word and row tile; consecutive MFMAs use different accumulators
+        // 3. 2 MFMAs per streamed 16-byte word and row tile; consecutive MFMAs use different accumulators
 #pragma unroll
         for (int it = 0; it < kWaveGp; ++it) {
+            const double u0 = Us[jstep * kUStride + it * 8 + kk];
+            const double u1 = Us[jstep * kUStride + it * 8 + 4 + kk];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const double u0 = Us[(16 * nb + jstep) * kUStride + it * 8 + kk];
-                const double u1 = Us[(16 * nb + jstep) * kUStride + it * 8 + 4 + kk];
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].x, u0, acc[m], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[nb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].x, u0, acc[nb][m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[nb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].y, u1, acc[nb][m], 0, 0, 0);
-            }
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[it][m].y, u1, acc[m], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // U reads done before the next sub-tile overwrites it
     }
-    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg.  red[wave][m][row*16 + j16] aliases U.
+    __syncthreads();
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg.  red[wave][m][row*16 + j] aliases U.
     double* red = Uall;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        __syncthreads();
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[((size_t)wave * MT + m) * 256 + (kk + 4 * r) * 16 + jstep] = acc[nb][m][r];
-        __syncthreads();
-        for (int idx = tid; idx < MT * 256; idx += kConvThreads) {
-            const int m = idx >> 8, e = idx & 255, row = e >> 4, j = 16 * nb + (e & 15);
-            const double v = ((red[(0 * MT + m) * 256 + e] + red[(1 * MT + m) * 256 + e]) + red[(2 * MT + m) * 256 + e]) + red[(3 * MT + m) * 256 + e];
-            a.partials[((size_t)chunk * T + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
-        }
+        for (int r = 0; r < 4; ++r) red[((size_t)wave * MT + m) * 256 + (kk + 4 * r) * 16 + jstep] = acc[m][r];
+    __syncthreads();
+    for (int idx = tid; idx < MT * 256; idx += kConvThreads) {
+        const int m = idx >> 8, e = idx & 255, row = e >> 4, j = e & 15;
+        const double v = ((red[(0 * MT + m) * 256 + e] + red[(1 * MT + m) * 256 + e]) + red[(2 * MT + m) * 256 + e]) + red[(3 * MT + m) * 256 + e];
+        a.partials[((size_t)chunk * kLookahead + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
     }
-}
-
-template <int NB>
-static void launch_conv_block_nb(const BlockArgs& b, int mt, int nblocks, size_t smem, hipStream_t stream) {
-    if (mt == 4) hipLaunchKernelGGL((conv_block_kernel<4, NB>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-    else if (mt == 2) hipLaunchKernelGGL((conv_block_kernel<2, NB>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-    else hipLaunchKernelGGL((conv_block_kernel<1, NB>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
 }
 
 void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
     const int nblocks = a.ngroups * a.nchunks;
     if (nblocks <= 0) return;
     BlockArgs b = a;
-    b.lds_front_doubles = max(4 * a.T * kUStride, 4 * mt * 256);  // per-wave U sub-tiles, later the [wave][tile][16x16] reduction buffer
+    b.lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // per-wave U sub-tiles, later the [wave][tile][16x16] reduction buffer
     const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) +
-                        (size_t)max(1, a.max_steps_per_chunk) * (a.T * sizeof(Bracket) + sizeof(double));
-    if (a.T == 32) launch_conv_block_nb<2>(b, mt, nblocks, smem, stream);
-    else launch_conv_block_nb<1>(b, mt, nblocks, smem, stream);
+                        (size_t)max(1, a.max_steps_per_chunk) * (kLookahead * sizeof(Bracket) + sizeof(double));
+    if (mt == 4) hipLaunchKernelGGL((conv_block_kernel<4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    else if (mt == 2) hipLaunchKernelGGL((conv_block_kernel<2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    else hipLaunchKernelGGL((conv_block_kernel<1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
 }
 
 __device__ __forceinline__ double lane16_sum(double v) {
@@ -443,9 +425,10 @@ __device__ __forceinline__ double lane16_sum(double v) {
 }
 
 // P[j][row] = sum_c partials[c][j][row]; 16 lanes per output, chunks c = l, l+16, ... then a 4-step xor tree.
-__global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restrict__ partials, int nchunks, int n, double* __restrict__ P) {
+__global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restrict__ partials, int nchunks, int Dpad, double* __restrict__ P) {
     const int sub = threadIdx.x & 15;
     const int out = blockIdx.x * 16 + (threadIdx.x >> 4);  // j*Dpad + row
+    const int n   = kLookahead * Dpad;
     const int o   = out < n ? out : 0;
     double v = 0.0;
     for (int c = sub; c < nchunks; c += 16) v += partials[(size_t)c * n + o];
@@ -453,9 +436,9 @@ __global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restr
     if (out < n && sub == 0) P[out] = v;
 }
 
-void launch_reduce_block(const double* d_partials, int nchunks, int T, int Dpad, double* d_P, hipStream_t stream) {
-    const int n = T * Dpad;
-    hipLaunchKernelGGL(reduce_block_kernel, dim3((n + 15) / 16), dim3(256), 0, stream, d_partials, nchunks, n, d_P);
+void launch_reduce_block(const double* d_partials, int nchunks, int Dpad, double* d_P, hipStream_t stream) {
+    const int n = kLookahead * Dpad;
+    hipLaunchKernelGGL(reduce_block_kernel, dim3((n + 15) / 16), dim3(256), 0, stream, d_partials, nchunks, Dpad, d_P);
 }
 
 // ------------------------------------------------------------------------------------------------

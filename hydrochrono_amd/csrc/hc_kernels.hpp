@@ -6,7 +6,7 @@
 
 namespace hc {
 
-constexpr int kLookaheadMax = 32;  // most future steps one blocked pass can cover (2 N-blocks of v_mfma_f64_16x16x4_f64)
+constexpr int kLookahead = 16;  // future steps covered by one blocked pass (= N dimension of v_mfma_f64_16x16x4_f64)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Panel layout of the convolution matrices in HBM (radiation K[D_loc x S*D], excitation Kex[D_loc x L]).
@@ -67,10 +67,9 @@ struct StepArgs {
     int* error_flag;         // 1 / 2: a query time is not bracketed (reference: runtime_error)
 };
 
-// Look-ahead pass: for j = 0..T-1 (T = 16 or 32) the part of step (n+j)'s radiation sum that depends only on history
-// known at step n,
+// Look-ahead pass: for j = 0..15 the part of step (n+j)'s radiation sum that depends only on history known at step n,
 //   P_j[row] = sum over s >= s_cut[j], col of K[row, s, col] * u_{n+j}(s, col),   t_{n+j} = t + j*dt,
-// as one [D_loc x F] x [F x T] FP64 GEMM on the matrix cores; K is read once for T steps.
+// as one [D_loc x F] x [F x 16] FP64 GEMM on the matrix cores; K is read once for 16 steps.
 struct BlockArgs {
     Panel K;
     int F;                // S*D
@@ -79,12 +78,11 @@ struct BlockArgs {
     int max_steps_per_chunk;
     int lds_front_doubles;  // set by the launcher
     HistoryView hist;
-    int T;                         // 16 or 32
-    double tpred[kLookaheadMax];   // predicted step times, tpred[0] = hist.t
-    int s_cut[kLookaheadMax];
+    double tpred[kLookahead];  // predicted step times, tpred[0] = hist.t
+    int s_cut[kLookahead];
     const double* tau;
     const double* width;
-    double* partials;     // [nchunks][T][Dpad]
+    double* partials;     // [nchunks][16][Dpad]
     int Dpad;
     int ngroups;
     int* error_flag;
@@ -141,7 +139,7 @@ void launch_relayout_rowmajor(const double* d_src, int rows, int cols, double* d
 void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream);
 void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream);
 // P[j][row] = sum_c partials[c][j][row]  (fixed order)
-void launch_reduce_block(const double* d_partials, int nchunks, int T, int Dpad, double* d_P, hipStream_t stream);
+void launch_reduce_block(const double* d_partials, int nchunks, int Dpad, double* d_P, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 void launch_taper(const TaperArgs& a, hipStream_t stream);
 // eta[j] = sum_i amp[i] * cos(-omega[i]*t[j] + phase[i]), then the ramp rule of src/wave_types.cpp:759-769

@@ -158,8 +158,7 @@ int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
  * precomputes, for the next 16 predicted step times, the part of the radiation sum that only needs history already
  * known, so K leaves HBM once per 16 steps; each step then adds the few newest samples.  A step whose time deviates from
  * the prediction (> 1e-9 of the step size) silently falls back to the plain per-step evaluation, so results never
- * depend on the prediction being right.  steps = 0 disables it (every step streams K); 1..31 selects 16-step blocks
- * (the default), >= 32 selects 32-step blocks (K leaves HBM once per 32 steps, the per-step remainder doubles). */
+ * depend on the prediction being right.  steps = 0 disables it (every step streams K), any other value enables it. */
 int hc_set_lookahead(hc_ctx* ctx, int steps);
 /* Forget the velocity history and the per-time cache (fresh TestHydro state). */
 int hc_reset_history(hc_ctx* ctx);

@@ -183,15 +183,15 @@ def test_multibody_regular_wave_phase_indexing(HF):
     assert_close(gpu.compute_waves(t), expect, 1e-13, "regular wave with body-0 phases")
 
 
-@pytest.mark.parametrize("N,T", [(1, 16), (2, 16), (4, 16), (2, 32), (4, 32)])
-def test_lookahead_matches_plain_and_survives_irregular_steps(HF, N, T):
+@pytest.mark.parametrize("N", [1, 2, 4])
+def test_lookahead_matches_plain_and_survives_irregular_steps(HF, N):
     """16-step look-ahead blocking vs plain per-step evaluation on the same inputs: uniform steps (blocks in use),
     then a change of step size, jittered steps (every prediction misses -> fallback), then uniform again."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     from hydrochrono_amd.synthetic import many_body_case, rest_positions
     case = many_body_case(N, S=100, dt_rirf=0.01, n_exc=33, seed=200 + N)
     a, b = HF.from_case(case), HF.from_case(case)
-    a.set_lookahead(T)
+    a.set_lookahead(16)
     b.set_lookahead(0)
     orc = load_into_oracle(case)
     for h in (a, b, orc):
@@ -208,7 +208,7 @@ def test_lookahead_matches_plain_and_survives_irregular_steps(HF, N, T):
         assert_close(fa, fb, 1e-11, f"look-ahead vs plain at t={t}")
         assert_close(fa, fo, TIGHT_TOL, f"look-ahead vs oracle at t={t}")
     prof = a.profile()
-    assert prof["block_kernel_launches"] >= 160 // T and prof["rem_kernel_launches"] >= 100  # blocks really were used
+    assert prof["block_kernel_launches"] >= 10 and prof["rem_kernel_launches"] >= 100  # blocks really were used
     assert prof["conv_kernel_launches"] >= 100                                         # and the fallback too
 
 

@@ -91,8 +91,8 @@ __device__ __forceinline__ double hist_time(const HistoryView& h, int k) {
 
 struct Bracket {
     double wo, wn;   // weights of the older / newer sample (both 0: the sample contributes nothing)
-    int slot_older;  // ring slot of the older sample
-    int slot_newer;  // ring slot of the newer sample, -1: the newer sample is the current state
+    int off_older;   // element offset (slot * D) of the older sample's ring row
+    int off_newer;   // element offset of the newer sample's ring row, -1: the newer sample is the current state
 };
 
 // AdvanceToBracket + InterpolateVelocity6D weights (src/hydro_forces.cpp:343-381) for a query time q <= h.t against
@@ -115,7 +115,7 @@ __device__ Bracket find_bracket(const HistoryView& h, double q, int* error_flag)
         if (hist_time(h, mid + 1) <= q) hi = mid; else lo = mid + 1;
     }
     Bracket b;
-    b.wo = 0.0; b.wn = 0.0; b.slot_older = 0; b.slot_newer = 0;
+    b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
     if (lo >= h.H - 1) return b;
     const double newer = hist_time(h, lo), older = hist_time(h, lo + 1);
     if (q == older) { b.wo = 1.0; b.wn = 0.0; }
@@ -128,8 +128,8 @@ __device__ Bracket find_bracket(const HistoryView& h, double q, int* error_flag)
         *error_flag = 1;  // "query_time not bracketed by history" (:370)
         return b;
     }
-    b.slot_older = (h.head - (lo + 1) + h.Hcap) % h.Hcap;
-    b.slot_newer = (lo == 0) ? -1 : (h.head - lo + h.Hcap) % h.Hcap;
+    b.off_older = ((h.head - (lo + 1) + h.Hcap) % h.Hcap) * h.D;
+    b.off_newer = (lo == 0) ? -1 : ((h.head - lo + h.Hcap) % h.Hcap) * h.D;
     return b;
 }
 
@@ -138,14 +138,24 @@ __device__ Bracket find_bracket(const HistoryView& h, double q, int* error_flag)
 // several values gets all its loads in flight at once instead of one dependent round trip per branch.
 // vstate = velocity of `col` in the current state (used when the newer sample is the current one).
 __device__ __forceinline__ double interp_velocity(const HistoryView& h, const Bracket& b, int col, double vstate) {
-    const double vo  = h.ring_v[(size_t)b.slot_older * h.D + col];
-    const double vnr = h.ring_v[(size_t)max(b.slot_newer, 0) * h.D + col];
-    const double vn  = (b.slot_newer >= 0) ? vnr : vstate;
+    const double vo  = h.ring_v[b.off_older + col];
+    const double vnr = h.ring_v[max(b.off_newer, 0) + col];
+    const double vn  = (b.off_newer >= 0) ? vnr : vstate;
     double v = b.wo * vo + b.wn * vn;
     v = (b.wo == 0.0) ? vn : v;
     v = (b.wn == 0.0) ? vo : v;
     v = (b.wo == 0.0 && b.wn == 0.0) ? 0.0 : v;
     return v;
+}
+
+// Same value for finite history data without the exact-copy selects: a weight of exactly 0 or 1 already reproduces the
+// copied sample (1*v + 0*w == v), and a masked bracket (both weights 0) gives 0.  Used by the look-ahead pass, whose
+// staging loop is instruction-bound.
+__device__ __forceinline__ double interp_velocity_lean(const HistoryView& h, const Bracket& b, int col, double vstate) {
+    const double vo  = h.ring_v[b.off_older + col];
+    const double vnr = h.ring_v[max(b.off_newer, 0) + col];
+    const double vn  = (b.off_newer >= 0) ? vnr : vstate;
+    return b.wo * vo + b.wn * vn;
 }
 
 __device__ __forceinline__ double eta_at(const StepArgs& a, int j) {
@@ -328,7 +338,7 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
     for (int idx = tid; idx < ns * kLookahead; idx += kConvThreads) {
         const int k = idx >> 4, j = idx & 15, s = s0 + k;
         Bracket b;
-        b.wo = 0.0; b.wn = 0.0; b.slot_older = 0; b.slot_newer = 0;
+        b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
         if (s >= a.s_cut[j]) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
         tab[idx] = b;
         if (j == 0) wtab[k] = a.width[s];
@@ -370,7 +380,7 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
                 const Bracket* __restrict__ row = tab + (size_t)(s - s0) * kLookahead;
                 double uq[kLookahead / 2];
 #pragma unroll
-                for (int q = 0; q < kLookahead / 2; ++q) uq[q] = interp_velocity(a.hist, row[jh + 2 * q], col, vstate) * w;
+                for (int q = 0; q < kLookahead / 2; ++q) uq[q] = interp_velocity_lean(a.hist, row[jh + 2 * q], col, vstate) * w;
 #pragma unroll
                 for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = uq[q];
             } else {

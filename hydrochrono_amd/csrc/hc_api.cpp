@@ -284,7 +284,10 @@ int plan_step(hc_ctx* c, double t, int H) {
         return 0;
     }
     if (pl.valid && pl.j_next < hc::kLookahead) {
-        if (std::fabs(t - pl.tpred[pl.j_next]) <= 1e-9 * pl.dt) return 2;
+        // accept the caller's time if it is the predicted one up to accumulated rounding (t += dt in the caller vs
+        // t0 + j*dt here); the interpolation weights then differ by <= tol/dt relative, far inside the 1e-6 contract
+        const double tol = std::max(1e-9 * pl.dt, 64.0 * std::numeric_limits<double>::epsilon() * std::fabs(t));
+        if (std::fabs(t - pl.tpred[pl.j_next]) <= tol) return 2;
         // the caller left the predicted time grid (variable step): drop the block
         pl.valid = false;
         if (++pl.misses >= 2) {
@@ -924,8 +927,6 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     }
     c->d_ex_tau.upload(ex_tau, c->stream);
     c->d_ex_width.upload(ex_width, c->stream);
-    c->d_e.alloc(Lpad);
-    HC_HIP(hipMemsetAsync(c->d_e.p, 0, Lpad * sizeof(double), c->stream));
     c->irr = p;
     c->L = L;
     c->Lpad = Lpad;

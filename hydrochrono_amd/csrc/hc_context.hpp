@@ -149,7 +149,7 @@ struct hc_ctx {
     std::vector<double> ex_tau, ex_width, ex_vals;  // ex_vals [Dloc][L]
     std::vector<double> spec_f, spec_S, spec_df, spec_phase, spec_k;
     std::vector<double> eta_t, eta;
-    hc::DeviceBuffer<double> d_kex, d_ex_tau, d_ex_width, d_eta_t, d_eta, d_e;
+    hc::DeviceBuffer<double> d_kex, d_ex_tau, d_ex_width, d_eta_t, d_eta;
 
     // GEMV configuration + scratch
     int chunk_gp = 0, nchunks_rad = 0, chunk_gp_ex = 0, nchunks_ex = 0, ngp_ex = 0;

@@ -373,7 +373,10 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
         // 2. stage U[j][col] = interp(v_col)(tpred[j] - tau_s) * width_s for the wave's 32 columns x 16 steps
         {
             const int f = (sub0 + wave + 4 * sit) * 8 + c8;
-            if (f < c1) {
+            if (a.ablate == 1) {  // diagnostic build path only (HC_BLOCK_ABLATE): no staging loads
+#pragma unroll
+                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = 1.0;
+            } else if (f < c1) {
                 const int s = f / D, col = f - s * D;
                 const double w      = wtab[s - s0];
                 const double vstate = state_velocity(a.hist.state, a.hist.N, col);
@@ -390,6 +393,13 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private LDS tile: no barrier needed
         // 3. 2 MFMAs per streamed 16-byte word and row tile; consecutive MFMAs use different accumulators
+        if (a.ablate == 2) {  // diagnostic: keep the loads, skip the matrix work
+#pragma unroll
+            for (int it = 0; it < kWaveGp; ++it)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(kv[it][m].x), "v"(kv[it][m].y));
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < kWaveGp; ++it) {
             const double u0 = Us[jstep * kUStride + it * 8 + kk];
@@ -420,6 +430,8 @@ void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
     const int nblocks = a.ngroups * a.nchunks;
     if (nblocks <= 0) return;
     BlockArgs b = a;
+    static const int ablate = [] { const char* e = std::getenv("HC_BLOCK_ABLATE"); return e ? std::atoi(e) : 0; }();
+    b.ablate = ablate;
     b.lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // per-wave U sub-tiles, later the [wave][tile][16x16] reduction buffer
     const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) +
                         (size_t)max(1, a.max_steps_per_chunk) * (kLookahead * sizeof(Bracket) + sizeof(double));

@@ -77,6 +77,7 @@ struct BlockArgs {
     int nchunks;
     int max_steps_per_chunk;
     int lds_front_doubles;  // set by the launcher
+    int ablate;             // diagnostics only (HC_BLOCK_ABLATE): 1 = no staging loads, 2 = no MFMAs
     HistoryView hist;
     double tpred[kLookahead];  // predicted step times, tpred[0] = hist.t
     int s_cut[kLookahead];

@@ -99,6 +99,20 @@ SIGNATURES.update({
     "hc_host_resample_irf": (C.c_int, [c_double_p, C.c_int, C.c_int, c_double_p]),
 })
 
+# include/hydrochrono_amd_yaml.h
+SIGNATURES.update({
+    "hc_yaml_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "hc_yaml_free": (None, [C.c_void_p]),
+    "hc_yaml_num_bodies": (C.c_int, [C.c_void_p]),
+    "hc_yaml_body_string": (C.c_char_p, [C.c_void_p, C.c_int, C.c_char_p]),
+    "hc_yaml_body_number": (C.c_double, [C.c_void_p, C.c_int, C.c_char_p]),
+    "hc_yaml_string": (C.c_char_p, [C.c_void_p, C.c_char_p]),
+    "hc_yaml_number": (C.c_double, [C.c_void_p, C.c_char_p]),
+    "hc_yaml_period_values": (C.c_int, [C.c_void_p, c_double_p, C.c_int]),
+    "hc_create_from_hydro_yaml": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                                            C.POINTER(C.c_void_p), c_int_p, c_int_p, C.c_char_p, C.c_size_t]),
+})
+
 _lib = None
 
 

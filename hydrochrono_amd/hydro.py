@@ -105,6 +105,34 @@ class HydroForces:
             h.set_gravity(case["g_sys"])
         return h
 
+    @classmethod
+    def from_hydro_yaml(cls, yaml_path, system_body_names, timestep, sim_duration, ramp_duration=0.0, device=0):
+        """ReadHydroYAML + SetupHydroFromYAML (src/hydro_yaml_parser.cpp, src/setup_hydro_from_yaml.cpp:126-193).
+        Returns (HydroForces, matched_index) where matched_index[k] is the position of hydro body k in system_body_names."""
+        lib = capi.load()
+        cfg = C.c_void_p()
+        err = C.create_string_buffer(2048)
+        rc = lib.hc_yaml_read(str(yaml_path).encode(), C.byref(cfg), err, 2048)
+        if rc != capi.HC_OK:
+            raise HydroError(rc, err.value.decode())
+        try:
+            names = (C.c_char_p * len(system_body_names))(*[n.encode() for n in system_body_names])
+            matched = (C.c_int * max(1, len(system_body_names)))()
+            nm = C.c_int()
+            ctx = C.c_void_p()
+            rc = lib.hc_create_from_hydro_yaml(cfg, names, len(system_body_names), timestep, sim_duration, ramp_duration, int(device),
+                                               C.byref(ctx), matched, C.byref(nm), err, 2048)
+            if rc != capi.HC_OK:
+                raise HydroError(rc, err.value.decode())
+        finally:
+            lib.hc_yaml_free(cfg)
+        self = cls.__new__(cls)
+        self.lib, self.ctx = lib, ctx
+        self.N = nm.value
+        self.D = 6 * self.N
+        self.b0, self.b1, self.n_local, self.D_local = 0, self.N, self.N, self.D
+        return self, list(matched[: nm.value])
+
     # -- configuration --
     def set_gravity(self, g3):
         g3 = _arr(g3, 3)

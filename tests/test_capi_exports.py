@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for hdr in ("hydrochrono_amd.h", "hydrochrono_amd_host.h"):
+    for hdr in ("hydrochrono_amd.h", "hydrochrono_amd_host.h", "hydrochrono_amd_yaml.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(hc_[a-z0-9_]+)\s*\(", text))

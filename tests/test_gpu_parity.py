@@ -500,3 +500,40 @@ def test_config_c5_single_body_2048_components(HF):
     assert np.max(np.abs(eg - eo)) <= 1e-9 * np.max(np.abs(eo))
     motion = PrescribedMotion(1, [case["bodies"][0]["cg"]], seed=7)
     drive_both(gpu, orc, motion, 0.08 * np.arange(600))
+
+
+def test_create_from_hydro_yaml(HF, tmp_path):
+    """hydro.yaml + BEMIO h5 -> context (ReadHydroYAML + SetupHydroFromYAML): same forces as wiring the same inputs by hand."""
+    from hydrochrono_amd.hydro import HydroError
+    cfgdir = tmp_path / "case"
+    cfgdir.mkdir()
+    h5 = os.path.join(GOLDEN_DIR, "sphere.h5")
+    (cfgdir / "sphere.hydro.yaml").write_text(
+        "hydrodynamics:\n  bodies:\n    - name: body1\n      h5_file: " + h5 + "\n"
+        "  waves:\n    type: regular\n    height: 0.354   # 2 x 0.177\n    period: 3.0\n"
+        "  convolution:\n    mode: TaperedDirect\n    taper:\n      start_percent: 0.7\n")
+    try:
+        a, matched = HF.from_hydro_yaml(cfgdir / "sphere.hydro.yaml", ["ground", "body1"], 0.015, 40.0)
+    except HydroError as e:
+        if e.status == 5:
+            pytest.skip("libhdf5 not available: " + str(e))
+        raise
+    assert matched == [1] and a.N == 1
+    b = HF.from_case(sphere_case())
+    b.add_waves_regular(0.354 / 2.0, 2.0 * np.pi / 3.0)
+    b.set_convolution_mode(1)
+    b.set_tapered_direct_options(taper_start_percent=0.7)
+    z = np.zeros(3)
+    for n in range(40):
+        st = (np.array([0, 0, -2.0 + 0.01 * n]), z, np.array([0, 0, 0.1 * np.sin(0.3 * n)]), z)
+        assert np.array_equal(a.step(0.015 * n, *st), b.step(0.015 * n, *st))
+    # irregular: YAML path = Pierson-Moskowitz defaults, seed <= 0 -> 1 (src/setup_hydro_from_yaml.cpp:52-60)
+    (cfgdir / "irr.hydro.yaml").write_text(
+        "hydrodynamics:\n  bodies:\n    - name: body1\n      h5_file: " + h5 + "\n  waves:\n    type: irregular\n    height: 2.0\n    period: 12.0\n")
+    c, _ = HF.from_hydro_yaml(cfgdir / "irr.hydro.yaml", ["body1"], 0.015, 60.0, ramp_duration=0.0)
+    d = HF.from_case(sphere_case())
+    d.add_waves_irregular(0.015, 60.0, wave_height=2.0, wave_period=12.0, seed=1)
+    assert c.sizes()["nf"] == d.sizes()["nf"] == 60  # ceil((1.0 - 0.001) * 60)
+    assert np.array_equal(c.irreg_eta()[1], d.irreg_eta()[1])
+    with pytest.raises(HydroError):
+        HF.from_hydro_yaml(cfgdir / "irr.hydro.yaml", ["someone_else"], 0.015, 60.0)

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/hydrochrono_amd.h"
+#include "../../include/hydrochrono_amd_yaml.h"
 
 #if !defined(HYDROCHRONO_AMD_WITH_CHRONO) && defined(__has_include)
 #if __has_include(<chrono/physics/ChBody.h>)
@@ -201,6 +202,15 @@ class TestHydro {
         }
         total_force_.assign(6 * num_bodies_, 0.0);
     }
+    // Adopts a context that is already configured (used by SetupHydroFromYAML below).
+    TestHydro(std::vector<std::shared_ptr<HydroBody>> user_bodies, hc_ctx* configured_ctx)
+        : bodies_(std::move(user_bodies)), num_bodies_(static_cast<int>(bodies_.size())), ctx_(configured_ctx) {
+        for (auto& b : bodies_) {
+            std::string temp = b->GetName();
+            body_numbers_.push_back(std::stoi(temp.erase(0, 4)));
+        }
+        total_force_.assign(6 * num_bodies_, 0.0);
+    }
     ~TestHydro() { hc_destroy(ctx_); }
 
     void AddWaves(std::shared_ptr<WaveBase> waves) {  // src/hydro_forces.cpp:244-261
@@ -315,6 +325,31 @@ class TestHydro {
     bool have_time_   = false;
     double prev_time_ = -1.0;
 };
+
+// SetupHydroFromYAML(hydro_data, bodies, timestep, sim_duration, ramp_duration) of the reference
+// (src/setup_hydro_from_yaml.cpp:126-193) with ReadHydroYAML folded in: bodies are matched to the YAML entries by name
+// (YAML order), the first body's h5 file is read, waves and convolution options come from the YAML.
+inline std::unique_ptr<TestHydro> SetupHydroFromYAML(const std::string& hydro_yaml_path,
+                                                     const std::vector<std::shared_ptr<HydroBody>>& bodies, double timestep,
+                                                     double sim_duration, double ramp_duration, int device_id = 0) {
+    char err[1024] = {0};
+    hc_yaml* cfg   = nullptr;
+    if (hc_yaml_read(hydro_yaml_path.c_str(), &cfg, err, sizeof err) != HC_OK) throw std::runtime_error(err);
+    std::vector<std::string> names;
+    for (auto& b : bodies) names.push_back(b->GetName());
+    std::vector<const char*> cnames;
+    for (auto& n : names) cnames.push_back(n.c_str());
+    std::vector<int> matched(bodies.size() + 1);
+    int n_matched = 0;
+    hc_ctx* ctx   = nullptr;
+    const int rc  = hc_create_from_hydro_yaml(cfg, cnames.data(), static_cast<int>(cnames.size()), timestep, sim_duration, ramp_duration,
+                                              device_id, &ctx, matched.data(), &n_matched, err, sizeof err);
+    hc_yaml_free(cfg);
+    if (rc != HC_OK) throw std::runtime_error(err);
+    std::vector<std::shared_ptr<HydroBody>> hydro_bodies;
+    for (int k = 0; k < n_matched; ++k) hydro_bodies.push_back(bodies[matched[k]]);
+    return std::make_unique<TestHydro>(std::move(hydro_bodies), ctx);
+}
 
 }  // namespace hydroc_amd
 

@@ -446,6 +446,13 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     for (int i = 0; i < 6; ++i) z.reg_phase[i] = c->reg_phase.size() >= 6 ? c->reg_phase[i] : 0.0;
     z.reg_amplitude = c->reg_amp;
     z.reg_omega     = c->reg_omega;
+    z.spec_nf       = c->nf;
+    z.spec_mag      = c->d_spec_mag.p;
+    z.spec_phase    = c->d_spec_phase.p;
+    z.spec_amp      = c->d_spec_amp.p;
+    z.spec_omega    = c->d_spec_omega.p;
+    z.spec_phi      = c->d_spec_phi.p;
+    z.spec_ramp     = c->irr.ramp_duration;
     z.t             = t;
     z.do_hs         = f.hs;
     z.do_rad        = run_rad;
@@ -467,6 +474,39 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     if (f.hs) c->prof.hydrostatics_calls++;
     if (f.rad) c->prof.radiation_calls++;
     if (f.waves) c->prof.waves_calls++;
+}
+
+// CreateSpectrum (src/wave_types.cpp:643-676): frequencies, PM/JONSWAP densities, trapezoid widths, mt19937 phases,
+// wavenumbers, plus the component amplitude sqrt(2 S df) and angular frequency of GetEtaIrregular (:39-40).
+struct Spectrum {
+    int nf = 0;
+    std::vector<double> f, S, df, phase, k, amp, omega;
+};
+
+Spectrum build_spectrum(const hc_ctx* c, const hc_irregular_wave_params& p) {
+    Spectrum sp;
+    if (p.nfrequencies == 0) {
+        const double df = 1.0 / p.simulation_duration;
+        sp.nf           = static_cast<int>(std::ceil((p.frequency_max - p.frequency_min) / df));
+    } else {
+        sp.nf = static_cast<int>(p.nfrequencies);
+    }
+    require(sp.nf >= 1, HC_ERR_INVALID, "no wave components");
+    sp.f = hc::linspaced(sp.nf, p.frequency_min, p.frequency_max);
+    std::sort(sp.f.begin(), sp.f.end());  // PiersonMoskowitzSpectrumHz sorts its argument in place (:681)
+    sp.S     = hc::jonswap_spectrum_hz(sp.f, p.wave_height, p.wave_period, p.peak_enhancement_factor, p.is_normalized != 0);
+    sp.df    = hc::trapezoid_widths(sp.f);
+    sp.phase = hc::random_phases(sp.nf, p.seed);
+    sp.k.resize(sp.nf);
+    sp.amp.resize(sp.nf);
+    sp.omega.resize(sp.nf);
+    const double two_pi = 2 * M_PI;
+    for (int i = 0; i < sp.nf; ++i) {
+        sp.k[i]     = hc::wave_number(two_pi * sp.f[i], c->depth, c->g);
+        sp.amp[i]   = std::sqrt(2 * sp.S[i] * sp.df[i]);
+        sp.omega[i] = two_pi * sp.f[i];
+    }
+    return sp;
 }
 
 void check_device_flag(hc_ctx* c) {
@@ -870,26 +910,9 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
                       vals.begin() + static_cast<size_t>(6 * bl + d) * L);
     }
     // CreateSpectrum (:643-676)
-    int nf;
-    if (p.nfrequencies == 0) {
-        const double df = 1.0 / p.simulation_duration;
-        nf              = static_cast<int>(std::ceil((p.frequency_max - p.frequency_min) / df));
-    } else {
-        nf = static_cast<int>(p.nfrequencies);
-    }
-    require(nf >= 1, HC_ERR_INVALID, "no wave components");
-    std::vector<double> f = hc::linspaced(nf, p.frequency_min, p.frequency_max);
-    std::sort(f.begin(), f.end());  // PiersonMoskowitzSpectrumHz sorts its argument in place (:681)
-    std::vector<double> Sd    = hc::jonswap_spectrum_hz(f, p.wave_height, p.wave_period, p.peak_enhancement_factor, p.is_normalized != 0);
-    std::vector<double> dfv   = hc::trapezoid_widths(f);
-    std::vector<double> phase = hc::random_phases(nf, p.seed);
-    std::vector<double> kk(nf), amp(nf), omg(nf);
-    const double two_pi = 2 * M_PI;
-    for (int i = 0; i < nf; ++i) {
-        kk[i]  = hc::wave_number(two_pi * f[i], c->depth, c->g);
-        amp[i] = std::sqrt(2 * Sd[i] * dfv[i]);  // GetEtaIrregular (:39-40)
-        omg[i] = two_pi * f[i];
-    }
+    Spectrum sp = build_spectrum(c, p);
+    const int nf = sp.nf;
+    std::vector<double>&f = sp.f, &Sd = sp.S, &dfv = sp.df, &phase = sp.phase, &kk = sp.k, &amp = sp.amp, &omg = sp.omega;
     // CreateFreeSurfaceElevation (:717-774); all bodies share ex_tau, so the min/max scan reduces to its ends
     double t_irf_min = 0.0, t_irf_max = 0.0;
     if (ex_tau.front() < t_irf_min) t_irf_min = ex_tau.front();
@@ -950,6 +973,55 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
                                        static_cast<double>(c->Dloc) * L + L);
     c->prof.block_kernel_bytes = hc::kLookahead * 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
     HC_HIP(hipStreamSynchronize(c->stream));
+    HC_API_END(c)
+}
+
+int hc_set_wave_irregular_spectral(hc_ctx* c, const hc_irregular_wave_params* pp) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(pp, HC_ERR_INVALID, "null parameters");
+    const hc_irregular_wave_params p = *pp;
+    require(p.num_bodies == c->N, HC_ERR_INVALID, "IrregularWaveParams.num_bodies_ must equal the number of hydro bodies");
+    require(p.wave_height != 0.0 && p.wave_period != 0.0, HC_ERR_INVALID, "wave_height and wave_period must be non-zero");
+    for (int b = c->b0; b < c->b1; ++b) require(c->bodies[b].have_rao, HC_ERR_INVALID, "excitation RAO missing for a local body");
+    Spectrum sp = build_spectrum(c, p);
+    // per-component excitation RAO: RegularWave's interpolator (src/wave_types.cpp:329-352: uniform list starting at
+    // d_omega, index = omega/d_omega - 1, linear between neighbours), held constant outside the BEM frequency range
+    std::vector<double> mag(static_cast<size_t>(c->Dloc) * sp.nf), ph(static_cast<size_t>(c->Dloc) * sp.nf);
+    for (int bl = 0; bl < c->nloc; ++bl) {
+        const auto& bd  = c->bodies[c->b0 + bl];
+        const int nw    = static_cast<int>(bd.rao_w.size());
+        const double dw = bd.rao_w.back() / static_cast<double>(nw);
+        for (int i = 0; i < sp.nf; ++i) {
+            double idx = sp.omega[i] / dw - 1;
+            idx        = std::min(std::max(idx, 0.0), static_cast<double>(nw - 1));
+            const int k0 = std::min(static_cast<int>(std::floor(idx)), nw - 2 >= 0 ? nw - 2 : 0);
+            const int k1 = std::min(k0 + 1, nw - 1);
+            const double fr = idx - k0;
+            for (int r = 0; r < 6; ++r) {
+                const double m0 = bd.rao_mag[static_cast<size_t>(r) * nw + k0], m1 = bd.rao_mag[static_cast<size_t>(r) * nw + k1];
+                const double p0 = bd.rao_phase[static_cast<size_t>(r) * nw + k0], p1 = bd.rao_phase[static_cast<size_t>(r) * nw + k1];
+                mag[static_cast<size_t>(6 * bl + r) * sp.nf + i] = (fr * (m1 - m0)) + m0;
+                ph[static_cast<size_t>(6 * bl + r) * sp.nf + i]  = (fr * (p1 - p0)) + p0;
+            }
+        }
+    }
+    c->d_spec_mag.upload(mag, c->stream);
+    c->d_spec_phase.upload(ph, c->stream);
+    c->d_spec_amp.upload(sp.amp, c->stream);
+    c->d_spec_omega.upload(sp.omega, c->stream);
+    c->d_spec_phi.upload(sp.phase, c->stream);
+    c->irr = p;
+    c->nf  = sp.nf;
+    c->L = c->Lpad = c->nt = 0;
+    c->spec_f.swap(sp.f);
+    c->spec_S.swap(sp.S);
+    c->spec_df.swap(sp.df);
+    c->spec_phase.swap(sp.phase);
+    c->spec_k.swap(sp.k);
+    c->wave_kind   = hc::kWaveSpectral;
+    c->wave_nb_arg = p.num_bodies;
+    choose_exc_config(c);
     HC_API_END(c)
 }
 
@@ -1254,7 +1326,7 @@ int hc_get_excitation_irf_resampled(hc_ctx* c, int body, double* t, double* widt
 
 int hc_get_spectrum(hc_ctx* c, double* f, double* S, double* df, double* phase, double* k) {
     HC_API_BEGIN(c)
-    require(c->wave_kind == hc::kWaveIrregular, HC_ERR_INVALID, "no irregular wave model attached");
+    require(c->wave_kind == hc::kWaveIrregular || c->wave_kind == hc::kWaveSpectral, HC_ERR_INVALID, "no irregular wave model attached");
     if (f) std::copy(c->spec_f.begin(), c->spec_f.end(), f);
     if (S) std::copy(c->spec_S.begin(), c->spec_S.end(), S);
     if (df) std::copy(c->spec_df.begin(), c->spec_df.end(), df);

@@ -87,7 +87,7 @@ struct BodyHost {
     std::vector<double> exirf_f;    // [6][n] rho*g-scaled (local bodies only)
 };
 
-enum WaveKind { kWaveNone = 0, kWaveRegular = 1, kWaveIrregular = 2 };
+enum WaveKind { kWaveNone = 0, kWaveRegular = 1, kWaveIrregular = 2, kWaveSpectral = 3 };
 
 struct EventSet {
     hipEvent_t e[3];
@@ -150,6 +150,7 @@ struct hc_ctx {
     std::vector<double> spec_f, spec_S, spec_df, spec_phase, spec_k;
     std::vector<double> eta_t, eta;
     hc::DeviceBuffer<double> d_kex, d_ex_tau, d_ex_width, d_eta_t, d_eta;
+    hc::DeviceBuffer<double> d_spec_mag, d_spec_phase, d_spec_amp, d_spec_omega, d_spec_phi;  // spectral (component-sum) mode
 
     // GEMV configuration + scratch
     int chunk_gp = 0, nchunks_rad = 0, chunk_gp_ex = 0, nchunks_ex = 0, ngp_ex = 0;

@@ -492,6 +492,15 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         for (int c = sub; c < a.nchunks_ex; c += 16) wav += a.partials[(size_t)(a.nchunks_rad + c) * a.Dpad + rrow];
         wav = lane16_sum(wav);
     }
+    if (a.do_waves && a.wave_mode == 3) {
+        // component sum over the spectrum (the north_star's literal wording; not the reference's IRF convolution):
+        // eta(t) = sum a_i cos(w_i t - phi_i)  ->  f = sum |X(w_i)| a_i cos(w_i t - phi_i + arg X(w_i)); 16 lanes per row
+        const double* __restrict__ mg = a.spec_mag + (size_t)rrow * a.spec_nf;
+        const double* __restrict__ pg = a.spec_phase + (size_t)rrow * a.spec_nf;
+        for (int k = sub; k < a.spec_nf; k += 16) wav += mg[k] * a.spec_amp[k] * cos(a.spec_omega[k] * a.t - a.spec_phi[k] + pg[k]);
+        wav = lane16_sum(wav);
+        if (a.spec_ramp > 0.0 && a.t < a.spec_ramp) wav *= (a.t <= 0.0) ? 0.0 : a.t / a.spec_ramp;
+    }
     if (!live || sub != 0) return;
 
     const int bl = row / 6, i = row - 6 * bl;  // local body, DoF

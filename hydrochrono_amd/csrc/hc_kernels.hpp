@@ -103,10 +103,18 @@ struct FinalizeArgs {
     double rho;
     double gx, gy, gz;
     // waves
-    int wave_mode;            // 0 none, 1 regular, 2 irregular
+    int wave_mode;            // 0 none, 1 regular, 2 irregular (excitation-IRF convolution), 3 irregular (spectral component sum)
     const double* reg_mag;    // [Dloc]
     double reg_phase[6];      // body-0 phases (reference indexes the phase by DoF only, src/wave_types.cpp:323)
     double reg_amplitude, reg_omega, t;
+    // spectral mode: f[row] = ramp(t) * sum_i |X_row(w_i)| a_i cos(w_i t - phi_i + arg X_row(w_i))
+    int spec_nf;
+    const double* spec_mag;    // [Dloc][nf]
+    const double* spec_phase;  // [Dloc][nf]
+    const double* spec_amp;    // [nf] sqrt(2 S df)
+    const double* spec_omega;  // [nf]
+    const double* spec_phi;    // [nf] random phases
+    double spec_ramp;
     int do_hs, do_rad, do_waves;
     // outputs
     double* hs;

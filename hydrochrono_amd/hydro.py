@@ -146,7 +146,7 @@ class HydroForces:
 
     def add_waves_irregular(self, simulation_dt, simulation_duration, ramp_duration=0.0, wave_height=0.0, wave_period=0.0,
                             frequency_min=0.001, frequency_max=1.0, nfrequencies=0, peak_enhancement_factor=1.0,
-                            is_normalized=False, seed=1, num_bodies=None):
+                            is_normalized=False, seed=1, num_bodies=None, spectral=False):
         p = capi.IrregularWaveParams()
         self.lib.hc_irregular_wave_params_default(C.byref(p))
         p.num_bodies = self.N if num_bodies is None else int(num_bodies)
@@ -154,7 +154,8 @@ class HydroForces:
         p.wave_height, p.wave_period = wave_height, wave_period
         p.frequency_min, p.frequency_max, p.nfrequencies = frequency_min, frequency_max, nfrequencies
         p.peak_enhancement_factor, p.is_normalized, p.seed = peak_enhancement_factor, int(is_normalized), int(seed)
-        self._chk(self.lib.hc_set_wave_irregular(self.ctx, C.byref(p)))
+        fn = self.lib.hc_set_wave_irregular_spectral if spectral else self.lib.hc_set_wave_irregular
+        self._chk(fn(self.ctx, C.byref(p)))
 
     def set_convolution_mode(self, mode):
         self._chk(self.lib.hc_set_convolution_mode(self.ctx, int(mode)))

@@ -112,6 +112,14 @@ void hc_irregular_wave_params_default(hc_irregular_wave_params* p);
  * (src/wave_types.cpp:432-459,572-606,643-676,717-774). */
 int hc_set_wave_irregular(hc_ctx* ctx, const hc_irregular_wave_params* params);
 
+/* Spectral (component-sum) excitation -- NOT in the reference (whose irregular waves are the excitation-IRF convolution
+ * above); it is the mode BASELINE.json's north_star words literally: the same spectrum / phases as hc_set_wave_irregular,
+ *   f[row](t) = ramp(t) * sum_i |X_row(w_i)| * a_i * cos(w_i t - phi_i + arg X_row(w_i)),   a_i = sqrt(2 S_i df_i),
+ * with the excitation RAO interpolated per component by RegularWave's interpolator (src/wave_types.cpp:329-352, held
+ * constant outside the BEM frequency range) and per-body phases.  Agrees with the IRF convolution up to the IRF's
+ * truncation / resampling error (a few per cent on the sphere data), so it is validated at a looser tolerance. */
+int hc_set_wave_irregular_spectral(hc_ctx* ctx, const hc_irregular_wave_params* params);
+
 /* TestHydro::SetRadiationConvolutionMode: 0 = Baseline, 1 = TaperedDirect (include/hydroc/hydro_forces.h:234-243) */
 int hc_set_convolution_mode(hc_ctx* ctx, int mode);
 /* TestHydro::TaperedDirectOptions (include/hydroc/hydro_forces.h:246-259) */

@@ -86,6 +86,7 @@ SIGNATURES = {
     "hc_get_excitation_irf_resampled": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
     "hc_get_spectrum": (C.c_int, [C.c_void_p] + [c_double_p] * 5),
     "hc_get_eta_table": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "hc_export_irregular_inputs_h5": (C.c_int, [C.c_void_p, C.c_char_p]),
     "hc_get_regular_coeffs": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "hc_synth_fill": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_int, C.c_double, C.c_int, C.c_double]),
 }

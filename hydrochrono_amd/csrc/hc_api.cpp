@@ -705,10 +705,10 @@ int hc_set_excitation_irf(hc_ctx* c, int body, const double* t, int n, const dou
     HC_API_END(c)
 }
 
-int hc_load_bemio_h5(hc_ctx* c, const char* path) {
-    HC_API_BEGIN(c)
-    require(path, HC_ERR_INVALID, "null path");
-    // The HDF5 reader lives in libhc_bemio.so (built only where libhdf5 exists) next to this library.
+namespace {
+// The HDF5 code lives in libhc_bemio.so (built only where libhdf5 exists) next to this library.
+using bemio_fn_t = int (*)(hc_ctx*, const char*, char*, size_t);
+bemio_fn_t bemio_symbol(const char* name) {
     Dl_info info;
     std::string dir = ".";
     if (dladdr(reinterpret_cast<void*>(&hc_version), &info) && info.dli_fname) {
@@ -718,12 +718,28 @@ int hc_load_bemio_h5(hc_ctx* c, const char* path) {
     }
     const std::string lib = dir + "/libhc_bemio.so";
     void* h = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (!h) throw Error(HC_ERR_UNSUPPORTED, std::string("BEMIO HDF5 reader not available: ") + dlerror());
-    using fn_t = int (*)(hc_ctx*, const char*, char*, size_t);
-    fn_t fn = reinterpret_cast<fn_t>(dlsym(h, "hc_bemio_load"));
-    if (!fn) throw Error(HC_ERR_UNSUPPORTED, "libhc_bemio.so lacks hc_bemio_load");
+    if (!h) throw Error(HC_ERR_UNSUPPORTED, std::string("HDF5 support not available: ") + dlerror());
+    bemio_fn_t fn = reinterpret_cast<bemio_fn_t>(dlsym(h, name));
+    if (!fn) throw Error(HC_ERR_UNSUPPORTED, std::string("libhc_bemio.so lacks ") + name);
+    return fn;
+}
+}  // namespace
+
+int hc_load_bemio_h5(hc_ctx* c, const char* path) {
+    HC_API_BEGIN(c)
+    require(path, HC_ERR_INVALID, "null path");
     char msg[1024] = {0};
-    const int rc = fn(c, path, msg, sizeof msg);
+    const int rc = bemio_symbol("hc_bemio_load")(c, path, msg, sizeof msg);
+    if (rc != HC_OK) throw Error(rc, msg[0] ? std::string(msg) : c->err);
+    HC_API_END(c)
+}
+
+int hc_export_irregular_inputs_h5(hc_ctx* c, const char* path) {
+    HC_API_BEGIN(c)
+    require(path, HC_ERR_INVALID, "null path");
+    require(c->wave_kind == hc::kWaveIrregular || c->wave_kind == hc::kWaveSpectral, HC_ERR_INVALID, "no irregular wave model attached");
+    char msg[1024] = {0};
+    const int rc = bemio_symbol("hc_bemio_export_irregular")(c, path, msg, sizeof msg);
     if (rc != HC_OK) throw Error(rc, msg[0] ? std::string(msg) : c->err);
     HC_API_END(c)
 }
@@ -1337,7 +1353,7 @@ int hc_get_spectrum(hc_ctx* c, double* f, double* S, double* df, double* phase, 
 
 int hc_get_eta_table(hc_ctx* c, double* t, double* eta) {
     HC_API_BEGIN(c)
-    require(c->wave_kind == hc::kWaveIrregular, HC_ERR_INVALID, "no irregular wave model attached");
+    require(c->wave_kind == hc::kWaveIrregular || c->wave_kind == hc::kWaveSpectral, HC_ERR_INVALID, "no irregular wave model attached");
     if (t) std::copy(c->eta_t.begin(), c->eta_t.end(), t);
     if (eta) std::copy(c->eta.begin(), c->eta.end(), eta);
     HC_API_END(c)

@@ -133,3 +133,88 @@ extern "C" int hc_bemio_load(hc_ctx* ctx, const char* path, char* err, size_t er
     }
     return HC_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Result-file side: SimulationExporter::WriteIrregularInputs (src/simulation_exporter.cpp:365-393) -- the spectrum and the
+// free-surface table of the attached irregular wave model under /inputs/simulation/waves/irregular, same dataset and
+// attribute names, so the reference's comparison tooling can read the new path's outputs.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+hid_t require_group(hid_t parent, const char* name) {
+    if (H5Lexists(parent, name, H5P_DEFAULT) > 0) return H5Gopen2(parent, name, H5P_DEFAULT);
+    return H5Gcreate2(parent, name, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+}
+
+void write_string_attr(hid_t obj, const char* name, const char* value) {
+    hid_t type = H5Tcopy(H5T_C_S1);
+    H5Tset_size(type, std::strlen(value) + 1);
+    hid_t space = H5Screate(H5S_SCALAR);
+    if (H5Aexists(obj, name) > 0) H5Adelete(obj, name);
+    hid_t attr = H5Acreate2(obj, name, type, space, H5P_DEFAULT, H5P_DEFAULT);
+    if (attr >= 0) {
+        H5Awrite(attr, type, value);
+        H5Aclose(attr);
+    }
+    H5Sclose(space);
+    H5Tclose(type);
+}
+
+void write_vector(hid_t group, const char* name, const std::vector<double>& v) {
+    if (v.empty()) return;  // the reference skips empty vectors
+    if (H5Lexists(group, name, H5P_DEFAULT) > 0) H5Ldelete(group, name, H5P_DEFAULT);
+    hsize_t dims[1] = {static_cast<hsize_t>(v.size())};
+    hid_t space     = H5Screate_simple(1, dims, nullptr);
+    hid_t ds        = H5Dcreate2(group, name, H5T_NATIVE_DOUBLE, space, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    if (ds < 0) {
+        H5Sclose(space);
+        throw H5Error(std::string("cannot create dataset ") + name);
+    }
+    H5Dwrite(ds, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, v.data());
+    H5Dclose(ds);
+    H5Sclose(space);
+}
+
+}  // namespace
+
+extern "C" int hc_bemio_export_irregular(hc_ctx* ctx, const char* path, char* err, size_t errlen) {
+    try {
+        int nf = 0, nt = 0;
+        ok(ctx, hc_get_sizes(ctx, nullptr, nullptr, nullptr, nullptr, &nf, &nt, nullptr, nullptr));
+        std::vector<double> f(nf), S(nf), t(nt), eta(nt);
+        if (nf) ok(ctx, hc_get_spectrum(ctx, f.data(), S.data(), nullptr, nullptr, nullptr));
+        if (nt) ok(ctx, hc_get_eta_table(ctx, t.data(), eta.data()));
+        H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);
+        hid_t file = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
+        if (file < 0) file = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+        if (file < 0) throw H5Error(std::string("cannot open or create ") + path);
+        hid_t g1 = require_group(file, "inputs");
+        hid_t g2 = require_group(g1, "simulation");
+        hid_t g3 = require_group(g2, "waves");
+        hid_t g  = require_group(g3, "irregular");
+        write_vector(g, "frequencies_hz", f);
+        if (nf) write_string_attr(g, "frequencies_hz.units", "Hz");
+        write_vector(g, "spectral_densities", S);
+        if (nf) {
+            write_string_attr(g, "spectral_densities.units", "m^2/Hz");
+            write_string_attr(g, "spectral_densities.convention", "JONSWAP (if gamma>1), else PM");
+        }
+        write_vector(g, "free_surface_time", t);
+        if (nt) write_string_attr(g, "free_surface_time.units", "s");
+        write_vector(g, "free_surface_eta", eta);
+        if (nt) {
+            write_string_attr(g, "free_surface_eta.units", "m");
+            write_string_attr(g, "free_surface_eta.location", "x=0,y=0,z=0 (assumed)");
+        }
+        H5Gclose(g);
+        H5Gclose(g3);
+        H5Gclose(g2);
+        H5Gclose(g1);
+        H5Fclose(file);
+    } catch (const std::exception& e) {
+        if (err && errlen) std::snprintf(err, errlen, "%s", e.what());
+        return HC_ERR_RUNTIME;
+    }
+    return HC_OK;
+}

@@ -279,6 +279,9 @@ class HydroForces:
         self._chk(self.lib.hc_get_eta_table(self.ctx, _dp(t), _dp(e)))
         return t, e
 
+    def export_irregular_inputs_h5(self, path):
+        self._chk(self.lib.hc_export_irregular_inputs_h5(self.ctx, str(path).encode()))
+
     def regular_coeffs(self):
         mag, ph, k = np.empty(self.D), np.empty(self.D), C.c_double()
         self._chk(self.lib.hc_get_regular_coeffs(self.ctx, _dp(mag), _dp(ph), C.byref(k)))

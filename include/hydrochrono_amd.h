@@ -223,6 +223,10 @@ int hc_get_excitation_irf_resampled(hc_ctx* ctx, int body, double* t_L, double* 
 int hc_get_spectrum(hc_ctx* ctx, double* f, double* S, double* df, double* phase, double* k);
 /* free_surface_time_sampled_ / free_surface_elevation_sampled_ (:717-774; exporter: runner:668-679) */
 int hc_get_eta_table(hc_ctx* ctx, double* t_nt, double* eta_nt);
+/* SimulationExporter::WriteIrregularInputs (src/simulation_exporter.cpp:365-393): writes frequencies_hz, spectral_densities,
+ * free_surface_time, free_surface_eta (+ the reference's attributes) under /inputs/simulation/waves/irregular of an HDF5
+ * result file (created if absent).  Needs libhdf5 (HC_ERR_UNSUPPORTED otherwise). */
+int hc_export_irregular_inputs_h5(hc_ctx* ctx, const char* path);
 /* RegularWave::excitation_force_mag_/phase_ and wavenumber_ (:278-299) */
 int hc_get_regular_coeffs(hc_ctx* ctx, double* mag_D, double* phase_D, double* wavenumber);
 

@@ -568,3 +568,34 @@ def test_spectral_component_sum_mode_agrees_with_irf_convolution(HF):
     t = 123.4
     expect = np.sum(X * np.sqrt(2 * sp["S"] * sp["df"]) * np.cos(om * t - sp["phase"] + P))
     assert abs(b.compute_waves(t)[2] - expect) <= 1e-10 * abs(expect)
+
+
+def test_export_irregular_inputs_h5(HF, tmp_path):
+    """SURVEY.md 8f-4: spectrum and eta(t) table written like SimulationExporter::WriteIrregularInputs."""
+    import shutil
+    import subprocess
+    from hydrochrono_amd.hydro import HydroError
+    gpu = HF.from_case(sphere_case())
+    gpu.add_waves_irregular(simulation_dt=0.1, simulation_duration=50.0, wave_height=2.0, wave_period=9.0, nfrequencies=40,
+                            frequency_min=0.03, frequency_max=0.4)
+    out = tmp_path / "results.h5"
+    try:
+        gpu.export_irregular_inputs_h5(out)
+    except HydroError as e:
+        if e.status == 5:
+            pytest.skip("libhdf5 not available: " + str(e))
+        raise
+    assert out.exists() and out.stat().st_size > 0
+    gpu.export_irregular_inputs_h5(out)  # idempotent on an existing file
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
+    if h5dump is None:
+        pytest.skip("h5dump not available to read the file back")
+    sp, (tt, eta) = gpu.irreg_spectrum(), gpu.irreg_eta()
+    for name, ref in (("frequencies_hz", sp["f"]), ("spectral_densities", sp["S"]), ("free_surface_time", tt), ("free_surface_eta", eta)):
+        binfile = tmp_path / (name + ".bin")
+        subprocess.run([h5dump, "-d", f"/inputs/simulation/waves/irregular/{name}", "-b", "LE", "-o", str(binfile), str(out)],
+                       check=True, stdout=subprocess.DEVNULL)
+        assert np.array_equal(np.fromfile(binfile, dtype="<f8"), ref), name
+    hdr = subprocess.run([h5dump, "-A", str(out)], check=True, capture_output=True, text=True).stdout
+    for attr in ("frequencies_hz.units", "spectral_densities.convention", "free_surface_eta.location"):
+        assert attr in hdr

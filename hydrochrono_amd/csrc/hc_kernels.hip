@@ -193,7 +193,7 @@ __device__ __forceinline__ double eta_at(const StepArgs& a, int j) {
 //   from two ring loads (L2 hits); excitation -- eta(t - tau_j), linearly interpolated in the precomputed table
 //   (src/wave_types.cpp:797-831), times width_j.  The streaming loop then only reads K and two LDS words per 16 bytes.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int U>
+template <int MT, int U, bool NT>
 __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     // dynamic LDS: right-hand side of the chunk [chunk columns], then the bracket table [samples] + widths
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -250,13 +250,11 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
         dvec2 kv[MT];
         // a matrix streamed exactly once per step uses non-temporal loads (keeps the ring in L2); the short remainder
         // of a look-ahead step re-reads the same newest-sample columns every step, so it uses normal loads and stays cached
-        if (a.stream_once) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                kv[m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128));
-        } else {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) kv[m] = *reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128);
+        for (int m = 0; m < MT; ++m) {
+            const dvec2* src = reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128);
+            if constexpr (NT) kv[m] = __builtin_nontemporal_load(src);
+            else kv[m] = *src;
         }
         const double u0 = rhs[(gp - gp0) * 8 + kk], u1 = rhs[(gp - gp0) * 8 + 4 + kk];
 #pragma unroll
@@ -282,9 +280,13 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
 
 template <int MT>
 static void launch_conv_step_mt(const StepArgs& a, int unroll, int nblocks, size_t smem, hipStream_t stream) {
-    if (unroll == 1) hipLaunchKernelGGL((conv_step_kernel<MT, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-    else if (unroll == 3) hipLaunchKernelGGL((conv_step_kernel<MT, 3>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-    else hipLaunchKernelGGL((conv_step_kernel<MT, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    if (!a.stream_once) {  // remainder of a look-ahead step: cacheable loads, latency-bound, no unroll variants needed
+        hipLaunchKernelGGL((conv_step_kernel<MT, 2, false>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+        return;
+    }
+    if (unroll == 1) hipLaunchKernelGGL((conv_step_kernel<MT, 1, true>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    else if (unroll == 3) hipLaunchKernelGGL((conv_step_kernel<MT, 3, true>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    else hipLaunchKernelGGL((conv_step_kernel<MT, 2, true>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
 }
 
 void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
@@ -482,16 +484,27 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const bool live = row < a.Dloc;
     const int rrow  = live ? row : 0;
 
+    // lane `sub` adds chunks sub, sub+16, ... in ascending order; loads are issued 8 at a time so that a long chunk list
+    // (plain steps use several hundred chunks) costs a few round trips, not one per chunk -- the order of the adds is unchanged
+    auto lane_sum = [&](int first, int count) {
+        double acc = 0.0;
+        int c = sub;
+        for (; c + 7 * 16 < count; c += 8 * 16) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = a.partials[(size_t)(first + c + 16 * k) * a.Dpad + rrow];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        }
+        for (; c < count; c += 16) acc += a.partials[(size_t)(first + c) * a.Dpad + rrow];
+        return acc;
+    };
     double rad = 0.0, wav = 0.0;
     if (a.do_rad) {
-        for (int c = sub; c < a.nchunks_rad; c += 16) rad += a.partials[(size_t)c * a.Dpad + rrow];
-        rad = lane16_sum(rad);
+        rad = lane16_sum(lane_sum(0, a.nchunks_rad));
         if (a.P) rad = a.P[rrow] + rad;
     }
-    if (a.do_waves && a.wave_mode == 2) {
-        for (int c = sub; c < a.nchunks_ex; c += 16) wav += a.partials[(size_t)(a.nchunks_rad + c) * a.Dpad + rrow];
-        wav = lane16_sum(wav);
-    }
+    if (a.do_waves && a.wave_mode == 2) wav = lane16_sum(lane_sum(a.nchunks_rad, a.nchunks_ex));
     if (a.do_waves && a.wave_mode == 3) {
         // component sum over the spectrum (the north_star's literal wording; not the reference's IRF convolution):
         // eta(t) = sum a_i cos(w_i t - phi_i)  ->  f = sum |X(w_i)| a_i cos(w_i t - phi_i + arg X(w_i)); 16 lanes per row

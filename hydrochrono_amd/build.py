@@ -15,7 +15,7 @@ LIBDIR = os.path.join(PKG, "lib")
 MAIN_LIB = os.path.join(LIBDIR, "libhydrochrono_amd.so")
 BEMIO_LIB = os.path.join(LIBDIR, "libhc_bemio.so")
 
-SOURCES = ["hc_kernels.hip", "hc_api.cpp", "hc_host_math.cpp", "hc_yaml.cpp"]
+SOURCES = ["hc_kernels.hip", "hc_api.cpp", "hc_host_math.cpp", "hc_yaml.cpp", "hc_eta_fft.cpp"]
 HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_host_math.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h"),
            os.path.join(ROOT, "include", "hydrochrono_amd_host.h"), os.path.join(ROOT, "include", "hydrochrono_amd_yaml.h")]
 
@@ -52,7 +52,7 @@ def build(force=False, verbose=False):
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     if force or _newer(MAIN_LIB, deps):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-               "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")] + srcs + ["-o", MAIN_LIB, "-ldl"]
+               "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")] + srcs + ["-o", MAIN_LIB, "-ldl", "-lrocfft"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "hc_set_wave_regular": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double]),
     "hc_irregular_wave_params_default": (None, [C.POINTER(IrregularWaveParams)]),
     "hc_set_wave_irregular": (C.c_int, [C.c_void_p, C.POINTER(IrregularWaveParams)]),
+    "hc_set_eta_synthesis": (C.c_int, [C.c_void_p, C.c_int]),
     "hc_set_wave_irregular_spectral": (C.c_int, [C.c_void_p, C.POINTER(IrregularWaveParams)]),
     "hc_set_convolution_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "hc_tapered_direct_options_default": (None, [C.POINTER(TaperedDirectOptions)]),

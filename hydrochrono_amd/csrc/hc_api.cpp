@@ -17,6 +17,11 @@
 
 using hc::Error;
 
+namespace hc {
+void eta_synthesis_fft(const std::vector<double>& t, const std::vector<double>& amp, const std::vector<double>& omega,
+                       const std::vector<double>& phase, double ramp, const double* d_t, double* d_eta, hipStream_t stream);
+}
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -948,7 +953,11 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     d_ph.upload(phase, c->stream);
     c->d_eta_t.upload(eta_t, c->stream);
     c->d_eta.alloc(nt);
-    hc::launch_eta_synthesis(c->d_eta_t.p, nt, d_amp.p, d_omg.p, d_ph.p, nf, p.ramp_duration, c->d_eta.p, c->stream);
+    if (c->eta_mode == 1 && nf >= 2) {
+        hc::eta_synthesis_fft(eta_t, amp, omg, phase, p.ramp_duration, c->d_eta_t.p, c->d_eta.p, c->stream);  // rocFFT chirp-z
+    } else {
+        hc::launch_eta_synthesis(c->d_eta_t.p, nt, d_amp.p, d_omg.p, d_ph.p, nf, p.ramp_duration, c->d_eta.p, c->stream);
+    }
     HC_HIP(hipGetLastError());
     std::vector<double> eta(nt);
     HC_HIP(hipMemcpyAsync(eta.data(), c->d_eta.p, nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1038,6 +1047,13 @@ int hc_set_wave_irregular_spectral(hc_ctx* c, const hc_irregular_wave_params* pp
     c->wave_kind   = hc::kWaveSpectral;
     c->wave_nb_arg = p.num_bodies;
     choose_exc_config(c);
+    HC_API_END(c)
+}
+
+int hc_set_eta_synthesis(hc_ctx* c, int mode) {
+    HC_API_BEGIN(c)
+    require(mode == 0 || mode == 1, HC_ERR_INVALID, "mode must be 0 (direct FP64 sum) or 1 (rocFFT chirp-z)");
+    c->eta_mode = mode;
     HC_API_END(c)
 }
 

@@ -145,6 +145,7 @@ struct hc_ctx {
     std::vector<double> reg_mag, reg_phase;  // [D] each (all bodies)
     hc::DeviceBuffer<double> d_reg_mag;      // [Dloc]
     hc_irregular_wave_params irr{};
+    int eta_mode = 0;  // 0: direct FP64 sum (eta_kernel), 1: rocFFT chirp-z (hc_eta_fft.cpp)
     int L = 0, Lpad = 0, nf = 0, nt = 0;
     std::vector<double> ex_tau, ex_width, ex_vals;  // ex_vals [Dloc][L]
     std::vector<double> spec_f, spec_S, spec_df, spec_phase, spec_k;

@@ -157,6 +157,10 @@ class HydroForces:
         fn = self.lib.hc_set_wave_irregular_spectral if spectral else self.lib.hc_set_wave_irregular
         self._chk(fn(self.ctx, C.byref(p)))
 
+    def set_eta_synthesis(self, mode):
+        """0 = direct FP64 sum (default), 1 = rocFFT chirp-z."""
+        self._chk(self.lib.hc_set_eta_synthesis(self.ctx, int(mode)))
+
     def set_convolution_mode(self, mode):
         self._chk(self.lib.hc_set_convolution_mode(self.ctx, int(mode)))
 

@@ -112,6 +112,11 @@ void hc_irregular_wave_params_default(hc_irregular_wave_params* p);
  * (src/wave_types.cpp:432-459,572-606,643-676,717-774). */
 int hc_set_wave_irregular(hc_ctx* ctx, const hc_irregular_wave_params* params);
 
+/* How hc_set_wave_irregular builds the free-surface table eta(t) (GetEtaIrregularTimeSeries, src/wave_types.cpp:27-59):
+ * 0 = direct FP64 sum of the Nf cosines per time sample on the GPU (default; same summation order as the reference),
+ * 1 = chirp-z transform on rocFFT (three FFTs of length >= nt + nf - 1; agrees with the direct sum to ~1e-12 of max|eta|). */
+int hc_set_eta_synthesis(hc_ctx* ctx, int mode);
+
 /* Spectral (component-sum) excitation -- NOT in the reference (whose irregular waves are the excitation-IRF convolution
  * above); it is the mode BASELINE.json's north_star words literally: the same spectrum / phases as hc_set_wave_irregular,
  *   f[row](t) = ramp(t) * sum_i |X_row(w_i)| * a_i * cos(w_i t - phi_i + arg X_row(w_i)),   a_i = sqrt(2 S_i df_i),

@@ -486,7 +486,7 @@ def test_config_c2_two_body_irregular_jonswap(HF):
 
 def test_config_c5_single_body_2048_components(HF):
     """C5: DeepCWind-like single body, dt = 0.08, 1000 s, 2048 wave components: eta(t) table (direct FP64 sum on the GPU)
-    against the oracle's libm sum, then force parity."""
+    against the oracle's libm sum, then force parity; then the same through the rocFFT chirp-z synthesis."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     from hydrochrono_amd.synthetic import many_body_case
     case = many_body_case(1, S=401, dt_rirf=0.05, n_exc=401, dt_exc=0.25, seed=5)
@@ -500,6 +500,17 @@ def test_config_c5_single_body_2048_components(HF):
     assert np.max(np.abs(eg - eo)) <= 1e-9 * np.max(np.abs(eo))
     motion = PrescribedMotion(1, [case["bodies"][0]["cg"]], seed=7)
     drive_both(gpu, orc, motion, 0.08 * np.arange(600))
+    # the rocFFT (chirp-z / Bluestein) synthesis of the same table: <= 1e-9 relative to the direct FP64 sum,
+    # then force parity with the oracle through that table
+    fft = HF.from_case(case)
+    fft.set_eta_synthesis(1)
+    fft.add_waves_irregular(**kw)
+    tf, ef = fft.irreg_eta()
+    assert np.array_equal(tf, tg)
+    assert np.max(np.abs(ef - eg)) <= 1e-9 * np.max(np.abs(eg)), np.max(np.abs(ef - eg)) / np.max(np.abs(eg))
+    orc2 = load_into_oracle(case)
+    orc2.add_waves_irregular(**kw)
+    drive_both(fft, orc2, motion, 0.08 * np.arange(200), tol=1e-8)
 
 
 def test_create_from_hydro_yaml(HF, tmp_path):

@@ -305,11 +305,6 @@ int plan_step(hc_ctx* c, double t, int H) {
     }
     const double dt = c->times[0] - c->times[1];
     if (!(dt > 0.0)) return 0;
-    // Blocks are planned only once the history spans the whole IRF window.  While it is shorter, the reference's
-    // "no older sample -> the IRF step contributes nothing" rule (src/hydro_forces.cpp:604-606) makes the sum
-    // discontinuous in t at q == oldest sample time, and a predicted time that differs from the caller's by one ulp
-    // could flip that decision; with full coverage every query of every predicted step lies strictly inside the history.
-    if (!(c->times.back() <= t - c->tau.back())) return 0;
     pl.valid  = true;
     pl.t0     = t;
     pl.dt     = dt;
@@ -320,6 +315,18 @@ int plan_step(hc_ctx* c, double t, int H) {
         int sc = 0;
         while (sc < c->S && !(pl.tpred[j] - c->tau[sc] <= t)) ++sc;
         pl.s_cut[j] = sc;
+        // While the history is shorter than the IRF window the reference's "no older sample -> the IRF step contributes
+        // nothing" rule (src/hydro_forces.cpp:604-606) makes the sum discontinuous in t where t - tau_s crosses the oldest
+        // sample time; a predicted time that differs from the caller's by an ulp could flip that decision.  The one sample
+        // per step for which the test is too close to call is left out of the pass and evaluated by the step itself.
+        pl.s_defer[j]       = -1;
+        const double oldest = c->times.back();
+        const double margin = 8.0 * std::max(1e-9 * dt, 64.0 * std::numeric_limits<double>::epsilon() * std::fabs(pl.tpred[j]));
+        const double target = pl.tpred[j] - oldest;  // tau of the sample that lands on the oldest history time
+        if (target <= c->tau.back() + margin) {
+            const auto it = std::lower_bound(c->tau.begin(), c->tau.end(), target - margin);
+            if (it != c->tau.end() && std::fabs(*it - target) <= margin) pl.s_defer[j] = static_cast<int>(it - c->tau.begin());
+        }
     }
     if (pl.s_cut[hc::kLookahead - 1] > c->S / 4) {
         // step size comparable to the IRF window: the remainder would re-read most of K every step, so blocking cannot pay
@@ -370,8 +377,9 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         b.max_steps_per_chunk = (c->chunk_gp_block * 8) / c->D + 2;
         b.hist                = hv;
         for (int j = 0; j < hc::kLookahead; ++j) {
-            b.tpred[j] = c->plan.tpred[j];
-            b.s_cut[j] = c->plan.s_cut[j];
+            b.tpred[j]   = c->plan.tpred[j];
+            b.s_cut[j]   = c->plan.s_cut[j];
+            b.s_defer[j] = c->plan.s_defer[j];
         }
         b.tau        = c->d_tau.p;
         b.width      = c->d_width.p;
@@ -388,21 +396,32 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     }
 
     // per-step kernel: radiation columns still to do this step + excitation chunks
-    int F_limit = 0, chunk_gp = c->chunk_gp, nchunks_rad = 0;
+    int F_limit = 0, chunk_gp = c->chunk_gp, nchunks_rad1 = 0, nchunks_rad2 = 0, F2_lo = 0, F2_hi = 0;
     if (run_rad && mode == 0) {
-        F_limit     = c->S * c->D;
-        nchunks_rad = c->nchunks_rad;
-    } else if (run_rad && mode == 2) {
+        F_limit      = c->S * c->D;
+        nchunks_rad1 = c->nchunks_rad;
+    } else if (run_rad && mode != 0) {
+        // remainder of a look-ahead step: the newest samples, plus the deferred sample if it is not among them
         F_limit           = c->plan.s_cut[j_block] * c->D;
         chunk_gp          = c->chunk_gp_rem;
         const int ngp_lim = (F_limit + 7) / 8;
-        nchunks_rad       = (ngp_lim + chunk_gp - 1) / chunk_gp;
+        nchunks_rad1      = (ngp_lim + chunk_gp - 1) / chunk_gp;
+        const int sd      = c->plan.s_defer[j_block];
+        if (sd >= c->plan.s_cut[j_block]) {
+            F2_lo        = sd * c->D;
+            F2_hi        = (sd + 1) * c->D;
+            nchunks_rad2 = ((F2_hi + 7) / 8 - F2_lo / 8 + chunk_gp - 1) / chunk_gp;
+        }
     }
+    const int nchunks_rad = nchunks_rad1 + nchunks_rad2;
     hc::StepArgs a{};
     a.K                   = rad_panel(c);
     a.F_limit             = F_limit;
     a.chunk_gp            = chunk_gp;
     a.nchunks_rad         = nchunks_rad;
+    a.nchunks_rad1        = nchunks_rad1;
+    a.F2_lo               = F2_lo;
+    a.F2_hi               = F2_hi;
     a.max_steps_per_chunk = (chunk_gp * 8) / c->D + 2;
     a.rhs_capacity        = 8 * std::max(chunk_gp, c->chunk_gp_ex);
     a.stream_once         = (mode == 2 && env_int("HC_REM_NT", 0) == 0) ? 0 : 1;

@@ -102,6 +102,7 @@ struct Plan {
     int j_next = 0;
     double tpred[kLookahead] = {0};
     int s_cut[kLookahead]    = {0};
+    int s_defer[kLookahead]  = {0};  // sample whose "is there an older history sample" test is too close to call ahead of time (-1: none)
     int misses = 0, cooldown = 0;
 };
 

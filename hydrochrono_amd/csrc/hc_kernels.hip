@@ -214,9 +214,18 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     if (radiation) {
         // ---- stage u[f] = interp(v_col)(t - tau_s) * width_s for the chunk's columns ----
         const int D = a.hist.D;
-        gp0 = chunk * a.chunk_gp;
-        gp1 = min((a.F_limit + 7) >> 3, gp0 + a.chunk_gp);
-        const int c0 = gp0 * 8, c1 = min(a.F_limit, gp1 * 8);
+        int lo, hi;  // valid columns of this chunk's range
+        if (chunk < a.nchunks_rad1) {
+            lo  = 0;
+            hi  = a.F_limit;
+            gp0 = chunk * a.chunk_gp;
+        } else {
+            lo  = a.F2_lo;
+            hi  = a.F2_hi;
+            gp0 = (a.F2_lo >> 3) + (chunk - a.nchunks_rad1) * a.chunk_gp;
+        }
+        gp1 = min((hi + 7) >> 3, gp0 + a.chunk_gp);
+        const int c0 = max(lo, gp0 * 8), c1 = min(hi, gp1 * 8);
         const int s0 = c0 / D;
         const int ns = (c1 - 1) / D - s0 + 1;
         for (int k = tid; k < ns; k += kConvThreads) {
@@ -224,13 +233,13 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
             wtab[k] = a.width[s0 + k];
         }
         __syncthreads();
-        for (int f = c0 + tid; f < gp1 * 8; f += kConvThreads) {
+        for (int f = gp0 * 8 + tid; f < gp1 * 8; f += kConvThreads) {
             double u = 0.0;
-            if (f < c1) {
+            if (f >= c0 && f < c1) {
                 const int s = f / D, col = f - s * D;
                 u = interp_velocity(a.hist, tab[s - s0], col, state_velocity(a.hist.state, a.hist.N, col)) * wtab[s - s0];
             }
-            rhs[f - c0] = u;
+            rhs[f - gp0 * 8] = u;
         }
     } else {
         // ---- stage e[j] = eta(t - tau_j) * width_j ----
@@ -341,7 +350,7 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
         const int k = idx >> 4, j = idx & 15, s = s0 + k;
         Bracket b;
         b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
-        if (s >= a.s_cut[j]) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
+        if (s >= a.s_cut[j] && s != a.s_defer[j]) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
         tab[idx] = b;
         if (j == 0) wtab[k] = a.width[s];
     }

@@ -42,9 +42,12 @@ struct HistoryView {
 // A workgroup owns MT row tiles x one chunk and leaves one partial per row in partials[chunk][Dpad].
 struct StepArgs {
     Panel K;
-    int F_limit;          // radiation columns to contract (multiple of D)
+    int F_limit;          // radiation columns [0, F_limit) to contract (multiple of D)
     int chunk_gp;         // column groups per radiation chunk
-    int nchunks_rad;
+    int nchunks_rad;      // chunks covering [0, F_limit) plus the chunks of the extra range below
+    // extra column range [F2_lo, F2_hi) (one IRF sample deferred by the look-ahead pass), chunks nchunks_rad1 .. nchunks_rad-1
+    int nchunks_rad1;     // chunks of the first range
+    int F2_lo, F2_hi;
     int max_steps_per_chunk;  // LDS bracket table entries
     int rhs_capacity;         // LDS right-hand-side entries: 8 * max(chunk_gp, chunk_gp_ex)
     int stream_once;          // 1: non-temporal K loads (plain step); 0: cacheable (remainder of a look-ahead step)
@@ -81,6 +84,7 @@ struct BlockArgs {
     HistoryView hist;
     double tpred[kLookahead];  // predicted step times, tpred[0] = hist.t
     int s_cut[kLookahead];
+    int s_defer[kLookahead];   // IRF sample left to the step itself although it is >= s_cut (-1: none), see plan_step
     const double* tau;
     const double* width;
     double* partials;     // [nchunks][16][Dpad]

@@ -337,32 +337,6 @@ int plan_step(hc_ctx* c, double t, int H) {
     return 1;
 }
 
-// Host-side twin of the device bracket search (hc_kernels.hip: find_bracket) for IRF sample s at time t, using the host's
-// mirror of the history times (times[0] == t is the current sample).  Same comparisons and the same weight expressions,
-// so the result is the one the device would compute.
-hc::Bracket host_bracket(const hc_ctx* c, double t, int s, bool* ok) {
-    hc::Bracket b{0.0, 0.0, 0, 0};
-    const double q = t - c->tau[s];
-    const int H    = static_cast<int>(c->times.size());
-    int lo = 0;
-    while (lo < H - 1 && !(c->times[lo + 1] <= q)) ++lo;  // smallest i with time(i+1) <= q
-    if (lo >= H - 1) return b;                             // no older sample: contributes nothing
-    const double newer = c->times[lo], older = c->times[lo + 1];
-    if (q == older) { b.wo = 1.0; b.wn = 0.0; }
-    else if (q == newer) { b.wo = 0.0; b.wn = 1.0; }
-    else if (q > older && q < newer) {
-        const double td = newer - older;
-        b.wo = (td != 0.0) ? ((newer - q) / td) : 0.0;
-        b.wn = 1.0 - b.wo;
-    } else {
-        *ok = false;  // let the device path raise the reference's error
-        return b;
-    }
-    b.off_older = (((c->head - (lo + 1)) % c->Hcap + c->Hcap) % c->Hcap) * c->D;
-    b.off_newer = (lo == 0) ? -1 : (((c->head - lo) % c->Hcap + c->Hcap) % c->Hcap) * c->D;
-    return b;
-}
-
 // Enqueue the kernels of one evaluation at time t. d_state: device pointer to the 12N state. user_out may be null.
 void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f) {
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
@@ -448,24 +422,6 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     a.nchunks_rad1        = nchunks_rad1;
     a.F2_lo               = F2_lo;
     a.F2_hi               = F2_hi;
-    a.n_host = 0;
-    if (run_rad && mode != 0) {
-        // few samples: find their brackets here instead of on the device (the host knows all history times)
-        const int sc = c->plan.s_cut[j_block], sd = c->plan.s_defer[j_block];
-        const int need = sc + ((sd >= sc) ? 1 : 0);
-        if (need <= hc::kHostBrackets) {
-            bool ok = true;
-            for (int s = 0; s < sc && ok; ++s) {
-                a.host_s[a.n_host]     = s;
-                a.host_tab[a.n_host++] = host_bracket(c, t, s, &ok);
-            }
-            if (ok && sd >= sc) {
-                a.host_s[a.n_host]     = sd;
-                a.host_tab[a.n_host++] = host_bracket(c, t, sd, &ok);
-            }
-            if (!ok) a.n_host = 0;
-        }
-    }
     a.max_steps_per_chunk = (chunk_gp * 8) / c->D + 2;
     a.rhs_capacity        = 8 * std::max(chunk_gp, c->chunk_gp_ex);
     a.stream_once         = (mode == 2 && env_int("HC_REM_NT", 0) == 0) ? 0 : 1;

@@ -89,6 +89,12 @@ __device__ __forceinline__ double hist_time(const HistoryView& h, int k) {
     return k == 0 ? h.t : h.ring_t[(h.head - k + h.Hcap) % h.Hcap];
 }
 
+struct Bracket {
+    double wo, wn;   // weights of the older / newer sample (both 0: the sample contributes nothing)
+    int off_older;   // element offset (slot * D) of the older sample's ring row
+    int off_newer;   // element offset of the newer sample's ring row, -1: the newer sample is the current state
+};
+
 // AdvanceToBracket + InterpolateVelocity6D weights (src/hydro_forces.cpp:343-381) for a query time q <= h.t against
 // the history whose newest sample (k = 0) is the current state at h.t.  Finds the smallest i in [0, H-2] with
 // time(i+1) <= q; i == H-1 means "no older sample" and the IRF step contributes nothing (:604-606).
@@ -223,12 +229,8 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
         const int s0 = c0 / D;
         const int ns = (c1 - 1) / D - s0 + 1;
         for (int k = tid; k < ns; k += kConvThreads) {
-            const int s = s0 + k;
-            int hit = -1;
-            for (int q = 0; q < a.n_host; ++q)
-                if (a.host_s[q] == s) hit = q;
-            tab[k]  = hit >= 0 ? a.host_tab[hit] : find_bracket(a.hist, a.hist.t - a.tau[s], a.error_flag);
-            wtab[k] = a.width[s];
+            tab[k]  = find_bracket(a.hist, a.hist.t - a.tau[s0 + k], a.error_flag);
+            wtab[k] = a.width[s0 + k];
         }
         __syncthreads();
         for (int f = gp0 * 8 + tid; f < gp1 * 8; f += kConvThreads) {
@@ -506,11 +508,10 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         for (; c < count; c += 16) acc += a.partials[(size_t)(first + c) * a.Dpad + rrow];
         return acc;
     };
-    const double p_ahead = (a.do_rad && a.P) ? a.P[rrow] : 0.0;  // issued before the partial sums: independent load
     double rad = 0.0, wav = 0.0;
     if (a.do_rad) {
         rad = lane16_sum(lane_sum(0, a.nchunks_rad));
-        if (a.P) rad = p_ahead + rad;
+        if (a.P) rad = a.P[rrow] + rad;
     }
     if (a.do_waves && a.wave_mode == 2) wav = lane16_sum(lane_sum(a.nchunks_rad, a.nchunks_ex));
     if (a.do_waves && a.wave_mode == 3) {

@@ -37,15 +37,6 @@ struct HistoryView {
     double dt_hint;       // t - previous sample time (bracket-search hint only, > 0)
 };
 
-// History bracket of one IRF sample: the two samples around the query time t - tau_s and their interpolation weights
-// (AdvanceToBracket + InterpolateVelocity6D, src/hydro_forces.cpp:343-381).
-struct Bracket {
-    double wo, wn;   // weights of the older / newer sample (both 0: the sample contributes nothing)
-    int off_older;   // element offset (slot * D) of the older sample's ring row
-    int off_newer;   // element offset of the newer sample's ring row, -1: the newer sample is the current state
-};
-constexpr int kHostBrackets = 18;  // brackets the host may hand to a remainder launch (16 newest samples + deferred one + spare)
-
 // Per-step launch: radiation columns [0, F_limit) of K (F_limit = S*D for a plain step, s_cut*D for the remainder of a
 // look-ahead step) and, for irregular waves, the excitation matrix, both as column chunks of a streamed FP64 GEMV.
 // A workgroup owns MT row tiles x one chunk and leaves one partial per row in partials[chunk][Dpad].
@@ -57,11 +48,6 @@ struct StepArgs {
     // extra column range [F2_lo, F2_hi) (one IRF sample deferred by the look-ahead pass), chunks nchunks_rad1 .. nchunks_rad-1
     int nchunks_rad1;     // chunks of the first range
     int F2_lo, F2_hi;
-    // Brackets found on the host (it mirrors the history times) for the few samples of a look-ahead remainder: saves the
-    // launch two to three dependent global-memory round trips.  n_host = 0: search on the device.
-    int n_host;
-    int host_s[kHostBrackets];       // IRF sample index of each entry
-    Bracket host_tab[kHostBrackets];
     int max_steps_per_chunk;  // LDS bracket table entries
     int rhs_capacity;         // LDS right-hand-side entries: 8 * max(chunk_gp, chunk_gp_ex)
     int stream_once;          // 1: non-temporal K loads (plain step); 0: cacheable (remainder of a look-ahead step)

@@ -204,6 +204,31 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # Secondary figure (not `value`): the same workload with look-ahead off, i.e. K streamed from HBM every step -- the
+    # conventional form of the path, whose kernel is the one the per-step HBM roofline applies to.
+    plain = None
+    if args.lookahead > 0 and world == 1:
+        n_plain = max(20, args.steps // 4)
+        gpu.set_lookahead(0)
+        extra_states = torch.tensor(np.stack([motion.packed(T0 + (total + k) * DT) for k in range(n_plain + 4)]), device="cuda")
+        extra_out = torch.zeros(n_plain + 4, D_local, dtype=torch.float64, device="cuda")
+        for k in range(4):
+            gpu.step_device(T0 + (total + k) * DT, extra_states[k].data_ptr(), extra_out[k].data_ptr(), stream)
+        torch.cuda.synchronize()
+        gpu.enable_profiling(args.profile_stride)
+        gpu.reset_profile()
+        tp = time.perf_counter()
+        for k in range(4, n_plain + 4):
+            gpu.step_device(T0 + (total + k) * DT, extra_states[k].data_ptr(), extra_out[k].data_ptr(), stream)
+        torch.cuda.synchronize()
+        tp = time.perf_counter() - tp
+        pp = gpu.profile()
+        gpu.enable_profiling(False)
+        kus = 1e6 * pp["conv_kernel_seconds"] / max(1, pp["conv_kernel_launches"])
+        plain = {"evals_per_s": n_plain / tp, "ms_per_step": tp / n_plain * 1e3, "steps": n_plain, "kernel": "hc::conv_step_kernel",
+                 "mean_kernel_us": kus, "achieved_GBps": pp["conv_kernel_bytes"] / (kus * 1e-6) / 1e9 if kus > 0 else 0.0,
+                 "frac_of_hbm_peak": (pp["conv_kernel_bytes"] / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS) if kus > 0 else 0.0}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         # dominant kernel: the look-ahead pass when blocking is on (one launch covers 16 steps), else the per-step kernel
@@ -262,6 +287,8 @@ def main():
                         if steps_per_launch == 16 else "one launch = one step",
             },
         }
+        if plain is not None:
+            out["plain_per_step_mode"] = plain
         if world == 1 and not args.no_cpu_baseline and case is not None:
             base, f_cpu = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds)
             f_gpu = forces[0].cpu().numpy()  # step k = 0 is t = T0 on both sides

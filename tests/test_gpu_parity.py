@@ -481,7 +481,8 @@ def test_config_c2_two_body_irregular_jonswap(HF):
     drive_both(gpu, orc, motion, 0.01 * np.arange(1650), check_components=False)
     gpu.enable_profiling(1)
     drive_both(gpu, orc, motion, 0.01 * np.arange(1650, 1700))
-    assert gpu.profile()["rem_kernel_launches"] > 0
+    if os.environ.get("HC_LOOKAHEAD", "16") != "0":
+        assert gpu.profile()["rem_kernel_launches"] > 0
 
 
 def test_config_c5_single_body_2048_components(HF):

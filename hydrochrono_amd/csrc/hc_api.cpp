@@ -337,6 +337,17 @@ int plan_step(hc_ctx* c, double t, int H) {
     return 1;
 }
 
+// Number of leading IRF samples that can contribute at query time t_query: samples whose t_query - tau_s lies before the
+// oldest history sample have no older bracket and contribute nothing (src/hydro_forces.cpp:604-606), so while the history
+// is shorter than the IRF window the kernels need not stream the tail of K at all.  Conservative by a small margin.
+int live_samples(const hc_ctx* c, double t_query) {
+    if (c->times.empty()) return 0;
+    const double span   = t_query - c->times.back();
+    const double margin = 1e-6 * std::max(1.0, std::fabs(span));
+    const auto it       = std::upper_bound(c->tau.begin(), c->tau.end(), span + margin);
+    return static_cast<int>(it - c->tau.begin());
+}
+
 // Enqueue the kernels of one evaluation at time t. d_state: device pointer to the 12N state. user_out may be null.
 void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f) {
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
@@ -371,9 +382,9 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     if (run_rad && mode == 1) {
         hc::BlockArgs b{};
         b.K                   = rad_panel(c);
-        b.F                   = c->S * c->D;
+        b.F                   = std::min(c->S, live_samples(c, c->plan.tpred[hc::kLookahead - 1])) * c->D;
         b.chunk_gp            = c->chunk_gp_block;
-        b.nchunks             = c->nchunks_block;
+        b.nchunks             = std::max(1, ((b.F + 7) / 8 + c->chunk_gp_block - 1) / c->chunk_gp_block);
         b.max_steps_per_chunk = (c->chunk_gp_block * 8) / c->D + 2;
         b.hist                = hv;
         for (int j = 0; j < hc::kLookahead; ++j) {
@@ -388,7 +399,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         b.ngroups    = c->ngroups;
         b.error_flag = c->d_err.p;
         hc::launch_conv_block(b, c->mt, stream);
-        hc::launch_reduce_block(c->d_partials_block.p, c->nchunks_block, c->Dpad, c->d_P.p, stream);
+        hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, c->Dpad, c->d_P.p, stream);
         P_row = c->d_P.p;
     } else if (run_rad && mode == 2) {
         j_block = c->plan.j_next++;
@@ -398,8 +409,8 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     // per-step kernel: radiation columns still to do this step + excitation chunks
     int F_limit = 0, chunk_gp = c->chunk_gp, nchunks_rad1 = 0, nchunks_rad2 = 0, F2_lo = 0, F2_hi = 0;
     if (run_rad && mode == 0) {
-        F_limit      = c->S * c->D;
-        nchunks_rad1 = c->nchunks_rad;
+        F_limit      = std::min(c->S, live_samples(c, t)) * c->D;
+        nchunks_rad1 = ((F_limit + 7) / 8 + chunk_gp - 1) / chunk_gp;
     } else if (run_rad && mode != 0) {
         // remainder of a look-ahead step: the newest samples, plus the deferred sample if it is not among them
         F_limit           = c->plan.s_cut[j_block] * c->D;

@@ -43,6 +43,9 @@ def lib():
         _lib.orc_wave_number.restype = C.c_double
         _lib.orc_last_error.argtypes = [C.c_void_p]
         _lib.orc_destroy.argtypes = [C.c_void_p]
+        # the reference's static schedule over IRF steps gets slower beyond a few dozen threads (see bench.py's sweep);
+        # tests pin a small count, bench.py's cpu_baseline sets its own
+        _lib.orc_set_num_threads(C.c_int(min(8, os.cpu_count() or 1)))
     return _lib
 
 

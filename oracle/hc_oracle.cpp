@@ -1377,7 +1377,8 @@ double orc_wave_number(double omega, double depth, double g) {
 // =================================================================================================
 struct orc_flat {
     int N = 0, D = 0, S = 0, L = 0;
-    std::vector<double> K;    // [D][S*D]
+    std::unique_ptr<double[]> Kbuf;
+    double* K = nullptr;      // [D][S*D]
     std::vector<double> Kex;  // [D][L]
     std::vector<double> u, e;
     std::vector<double> times;                // newest first
@@ -1393,7 +1394,8 @@ int orc_flat_prepare(orc_ctx* c) {
     f->D = 6 * f->N;
     f->S = h.file_info_.GetRIRFDims(2);
     const size_t F = size_t(f->S) * f->D;
-    f->K.resize(size_t(f->D) * F);
+    f->Kbuf.reset(new double[size_t(f->D) * F]);  // no value-initialisation: pages are first touched by the thread that
+    f->K = f->Kbuf.get();                         // later streams them (NUMA placement), same static schedule as the GEMV
     if (h.convolution_mode_ == 1) h.EnsureProcessedRIRF();
 #pragma omp parallel for schedule(static)
     for (int row = 0; row < f->D; ++row)

@@ -455,11 +455,6 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     a.Dpad                = c->Dpad;
     a.ngroups             = c->ngroups;
     a.error_flag          = c->d_err.p;
-    // the ring push rides in this launch when it has any work, else in the finalize launch
-    const bool conv_has_work = c->ngroups * (a.nchunks_rad + a.nchunks_ex) > 0;
-    a.do_push                = (f.rad && conv_has_work) ? 1 : 0;
-    a.ring_t_w               = c->d_ring_t.p;
-    a.ring_v_w               = c->d_ring_v.p;
     hc::launch_conv_step(a, c->mt, stream);
     if (ev) HC_HIP(hipEventRecord(ev->e[1], stream));
 
@@ -502,7 +497,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     z.waves         = c->d_waves.p;
     z.total         = c->d_total.p;
     z.user_out      = d_user_out;
-    z.do_push       = (f.rad && !conv_has_work) ? 1 : 0;
+    z.do_push       = f.rad ? 1 : 0;
     z.head          = c->head;
     z.D             = c->D;
     z.ring_t        = c->d_ring_t.p;

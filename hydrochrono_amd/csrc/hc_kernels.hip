@@ -203,16 +203,9 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     __shared__ double red[kConvThreads / kWave][MT][16];
 
     const int nct   = a.nchunks_rad + a.nchunks_ex;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (a.do_push && blockIdx.x == gridDim.x - 1) {
-        // extra workgroup: store this step's sample into the ring (off the critical path of the step)
-        if (tid == 0) a.ring_t_w[a.hist.head] = a.hist.t;
-        double* slot = a.ring_v_w + (size_t)a.hist.head * a.hist.D;
-        for (int c = tid; c < a.hist.D; c += kConvThreads) slot[c] = state_velocity(a.hist.state, a.hist.N, c);
-        return;
-    }
     const int chunk = blockIdx.x % nct;
     const int grp   = blockIdx.x / nct;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kk = lane >> 4;
 
     const bool radiation = chunk < a.nchunks_rad;
@@ -295,8 +288,7 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
 }
 
 template <int MT>
-static void launch_conv_step_mt(const StepArgs& a, int unroll, int nblocks_work, size_t smem, hipStream_t stream) {
-    const int nblocks = nblocks_work + (a.do_push ? 1 : 0);
+static void launch_conv_step_mt(const StepArgs& a, int unroll, int nblocks, size_t smem, hipStream_t stream) {
     if (!a.stream_once) {  // remainder of a look-ahead step: cacheable loads, latency-bound, no unroll variants needed
         hipLaunchKernelGGL((conv_step_kernel<MT, 2, false>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
         return;

@@ -68,11 +68,6 @@ struct StepArgs {
     int Dpad;
     int ngroups;             // ntiles / MT
     int* error_flag;         // 1 / 2: a query time is not bracketed (reference: runtime_error)
-    // history push of this step's sample into ring slot `head` (src/hydro_forces.cpp:559-574) by one extra workgroup;
-    // nobody reads that slot during the step (the current sample is always taken from `state`)
-    int do_push;
-    double* ring_t_w;
-    double* ring_v_w;
 };
 
 // Look-ahead pass: for j = 0..15 the part of step (n+j)'s radiation sum that depends only on history known at step n,

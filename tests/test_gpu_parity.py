@@ -698,3 +698,56 @@ def test_lookahead_random_step_patterns(HF, seed):
     assert worst <= 1e-10, worst
     prof = a.profile()
     assert prof["block_kernel_launches"] > 5 and prof["conv_kernel_launches"] > 5  # both paths were exercised
+
+
+def test_edge_cases_and_argument_errors(HF):
+    """Smallest sizes, ragged inputs and misuse: statuses instead of undefined behaviour."""
+    from hydrochrono_amd.hydro import HydroError
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    # smallest useful kernel: two IRF samples, one body, four excitation samples
+    case = many_body_case(1, S=2, dt_rirf=0.05, n_exc=4, dt_exc=0.1, seed=1)
+    gpu, orc = make_pair(HF, case)
+    kw = dict(simulation_dt=0.05, simulation_duration=2.0, wave_height=1.0, wave_period=4.0, nfrequencies=4, frequency_min=0.1, frequency_max=0.4)
+    gpu.add_waves_irregular(**kw)
+    orc.add_waves_irregular(**kw)
+    drive_both(gpu, orc, PrescribedMotion(1, rest_positions(case), seed=1), 0.05 * np.arange(30))
+    # stepping before finalize, bad body index
+    h = HF(2)
+    h.set_simulation_parameters(1000.0, 9.81, 50.0)
+    z6 = np.zeros(6)
+    with pytest.raises(HydroError) as ei:
+        h.step(0.0, z6, z6, z6, z6)
+    assert ei.value.status == 3
+    with pytest.raises(HydroError) as ei:
+        h.set_body_excitation_irf(2, np.arange(4.0), np.zeros((6, 1, 4)))
+    assert ei.value.status == 2
+    with pytest.raises(HydroError) as ei:
+        h.finalize()  # nothing ingested
+    assert ei.value.status == 3
+    # RIRF time vectors must agree across bodies (HydroData::GetRIRFTimeVector, src/h5fileinfo.cpp:329-343)
+    case2 = many_body_case(2, S=8, n_exc=9, seed=2)
+    h = HF(2)
+    h.set_simulation_parameters(case2["rho"], case2["g"], case2["water_depth"])
+    b0, b1 = case2["bodies"]
+    h.set_body(0, b0["disp_vol"], b0["cg"], b0["cb"], b0["lin"], b0["added_mass_inf"], b0["rirf_t"], b0["rirf_K"])
+    with pytest.raises(HydroError) as ei:
+        h.set_body(1, b1["disp_vol"], b1["cg"], b1["cb"], b1["lin"], b1["added_mass_inf"], b1["rirf_t"] * 1.01, b1["rirf_K"])
+    assert ei.value.status == 1 and "exactly the same for all bodies" in str(ei.value)
+    # ragged excitation-IRF grids across bodies are refused (BEMIO writes one grid per file)
+    g = HF.from_case(case2)
+    g.set_body_excitation_irf(1, b1["ex_irf_t"] * 1.5, b1["ex_irf_f"])
+    with pytest.raises(HydroError) as ei:
+        g.add_waves_irregular(**kw, num_bodies=2)
+    assert ei.value.status == 5
+    # wave model for the wrong number of bodies / zero sea state / time going backwards
+    g = HF.from_case(case2)
+    with pytest.raises(HydroError):
+        g.add_waves_irregular(**kw, num_bodies=1)
+    with pytest.raises(HydroError):
+        g.add_waves_irregular(simulation_dt=0.05, simulation_duration=2.0, wave_height=0.0, wave_period=4.0)
+    z12 = np.zeros(6)
+    g.step(1.0, z12, z12, z12, z12)
+    with pytest.raises(HydroError) as ei:
+        g.step(0.5, z12, z12, z12, z12)
+    assert ei.value.status == 3 and "must not decrease" in str(ei.value)

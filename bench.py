@@ -238,7 +238,7 @@ def main():
         ms = elapsed / args.steps * 1e3
         # dominant kernel: the look-ahead pass when blocking is on (one launch covers 16 steps), else the per-step kernel
         if prof["block_kernel_launches"] > 0:
-            kname, steps_per_launch = "hc::conv_block_kernel (+reduce_block_kernel)", 16
+            kname, steps_per_launch = "hc::conv_block_kernel", 16
             conv_s = prof["block_kernel_seconds"] / prof["block_kernel_launches"]
             alg_bytes = prof["block_kernel_bytes"]
             n_timed = prof["block_kernel_launches"]

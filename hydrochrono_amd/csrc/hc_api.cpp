@@ -122,8 +122,10 @@ void profile_drain(hc_ctx* c) {
         // hydrostatics, the regular-wave term and the reduction
         c->prof.radiation_seconds += ms01 * 1e-3;
         c->prof.hydrostatics_seconds += ms12 * 1e-3;
-        if (c->events[i].kind == 1) {  // look-ahead pass (+ its reduction + the excitation chunks of this step)
-            c->prof.block_kernel_seconds += ms01 * 1e-3;
+        if (c->events[i].kind == 1) {  // boundary step: time the look-ahead kernel alone (event 3 follows it directly)
+            float msb = 0;
+            HC_HIP(hipEventElapsedTime(&msb, c->events[i].e[0], c->events[i].e[3]));
+            c->prof.block_kernel_seconds += msb * 1e-3;
             c->prof.block_kernel_launches += 1;
         } else if (c->events[i].kind == 2) {
             c->prof.rem_kernel_seconds += ms01 * 1e-3;
@@ -399,6 +401,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         b.ngroups    = c->ngroups;
         b.error_flag = c->d_err.p;
         hc::launch_conv_block(b, c->mt, stream);
+        if (ev) HC_HIP(hipEventRecord(ev->e[3], stream));
         hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, c->Dpad, c->d_P.p, stream);
         P_row = c->d_P.p;
     } else if (run_rad && mode == 2) {

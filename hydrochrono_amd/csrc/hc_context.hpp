@@ -90,7 +90,7 @@ struct BodyHost {
 enum WaveKind { kWaveNone = 0, kWaveRegular = 1, kWaveIrregular = 2, kWaveSpectral = 3 };
 
 struct EventSet {
-    hipEvent_t e[3];
+    hipEvent_t e[4];  // 0 start, 1 after the per-step convolution launch, 2 after finalize, 3 right after the look-ahead kernel
     int kind = 0;  // 0 plain step, 1 look-ahead boundary step, 2 step inside a look-ahead block
 };
 

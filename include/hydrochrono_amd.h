@@ -201,7 +201,7 @@ typedef struct hc_profile_stats {
     double conv_kernel_seconds; /* sum of HIP-event durations of the plain per-step convolution launches */
     long long conv_kernel_launches;
     double conv_kernel_bytes;   /* algorithmic bytes of one step (8*D_local*D*S + vectors) */
-    double block_kernel_seconds; /* look-ahead passes (one covers 16 steps) incl. their reduction */
+    double block_kernel_seconds; /* look-ahead kernel launches (one covers 16 steps) */
     long long block_kernel_launches;
     double block_kernel_bytes;  /* algorithmic bytes of the 16 steps one pass covers */
     double rem_kernel_seconds;  /* per-step remainder launches inside a look-ahead block */

@@ -287,6 +287,12 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "steps_per_launch": steps_per_launch,
                 "mean_kernel_us": conv_s * 1e6, "launches_timed": n_timed,
                 "in_block_step_kernel_us": rem_us,
+                # what the launch really moves / computes: PMC-measured HBM bytes over the live duration, and the FP64 MFMA
+                # rate of the [D x F] x [F x 16] product against the 78.6 TFLOP/s dense FP64 peak
+                "traffic_GBps": (traffic / conv_s / 1e9) if (traffic and conv_s > 0) else None,
+                "traffic_frac_of_hbm_peak": (traffic / conv_s / 1e9 / HBM_PEAK_GBS) if (traffic and conv_s > 0) else None,
+                "fp64_TFLOPs": (2.0 * (alg_bytes / 8.0) / conv_s / 1e12) if conv_s > 0 else None,
+                "fp64_frac_of_mfma_peak": (2.0 * (alg_bytes / 8.0) / conv_s / 1e12 / 78.6) if conv_s > 0 else None,
                 "note": ("one look-ahead launch covers 16 steps: algorithmic bytes = 16 x the per-step figure of SURVEY 8d, "
                          "while K leaves HBM once (see traffic), so frac > 1 measures the reuse, not a faster memory")
                         if steps_per_launch == 16 else "one launch = one step",

@@ -50,8 +50,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--bodies", type=int, default=N_BODIES, help="bodies per GPU (default: the C3 configuration)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--profile-stride", type=int, default=5, help="HIP-event sampling stride for the roofline kernel time "
-                    "(co-prime with the 16-step look-ahead period so boundary and in-block steps are both sampled)")
+    ap.add_argument("--profile-stride", type=int, default=17, help="HIP-event sampling stride for the per-step launches (co-prime "
+                    "with the 16-step look-ahead period); every look-ahead pass, the roofline kernel, is timed regardless")
     ap.add_argument("--lookahead", type=int, default=16, help="0: plain per-step evaluation (K streamed every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline time budget")
@@ -179,15 +179,23 @@ def main():
     forces = torch.zeros(total, D_local, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
+    # device addresses of each step's state / force row, so that the timed loop is the C-ABI call and nothing else
+    state_ptrs = [states.data_ptr() + k * states.stride(0) * 8 for k in range(total)]
+    force_ptrs = [forces.data_ptr() + k * forces.stride(0) * 8 for k in range(total)]
+    times = [T0 + k * DT for k in range(total)]
+    step_device = gpu.step_device
+
     def run(k0, k1):
-        for k in range(k0, k1):
-            if exchange is not None and world > 1:
-                # coupled array: kernels write straight into the exchange's send buffer; the RCCL all-gather leaves the
-                # full 6N force vector on every rank (the one exchange step of the path)
-                gpu.step_device(T0 + k * DT, states[k].data_ptr(), exchange.send.data_ptr(), stream)
+        if exchange is not None and world > 1:
+            # coupled array: kernels write straight into the exchange's send buffer; the RCCL all-gather leaves the
+            # full 6N force vector on every rank (the one exchange step of the path)
+            send_ptr = exchange.send.data_ptr()
+            for k in range(k0, k1):
+                step_device(times[k], state_ptrs[k], send_ptr, stream)
                 exchange.gather()
-            else:
-                gpu.step_device(T0 + k * DT, states[k].data_ptr(), forces[k].data_ptr(), stream)
+        else:
+            for k in range(k0, k1):
+                step_device(times[k], state_ptrs[k], force_ptrs[k], stream)
 
     run(0, args.warmup)
     torch.cuda.synchronize()
@@ -198,6 +206,7 @@ def main():
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     run(args.warmup, total)
+    enqueue_s = time.perf_counter() - t_start  # host time to enqueue every step (the GPU runs behind it)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -265,6 +274,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
+            "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,

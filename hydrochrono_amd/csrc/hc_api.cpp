@@ -138,9 +138,12 @@ void profile_drain(hc_ctx* c) {
     c->events_used = 0;
 }
 
-hc::EventSet* profile_next(hc_ctx* c) {
+// Event set for this step, or null.  Sampled (events perturb the launch stream): every stride-th step, plus every look-ahead
+// boundary step -- its pass over K is the launch the roofline is quoted on and costs one event set per 16 steps.
+hc::EventSet* profile_next(hc_ctx* c, int mode) {
     if (!c->profiling) return nullptr;
-    if ((c->profile_counter++ % c->profile_stride) != 0) return nullptr;  // sampled: events perturb the launch stream
+    const bool strided = (c->profile_counter++ % c->profile_stride) == 0;
+    if (!strided && mode != 1) return nullptr;
     if (c->events_used == c->events.size()) {
         if (c->events.size() < 4096) {
             hc::EventSet es;
@@ -363,7 +366,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     }
     const bool run_rad = f.rad && H >= 2;  // "Nothing to convolve with if we don't yet have at least 2 time points" (:580)
     const bool run_exc = f.waves && irregular;
-    hc::EventSet* ev = profile_next(c);
+    hc::EventSet* ev = profile_next(c, mode);
     if (ev) ev->kind = mode;
 
     hc::HistoryView hv{};

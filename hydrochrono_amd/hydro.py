@@ -180,8 +180,10 @@ class HydroForces:
 
     def step_device(self, t, state_ptr, out_ptr, stream_ptr=None):
         """state_ptr / out_ptr: integer device addresses (e.g. torch.Tensor.data_ptr())."""
-        self._chk(self.lib.hc_step_device(self.ctx, float(t), C.c_void_p(state_ptr), C.c_void_p(out_ptr),
-                                          C.c_void_p(stream_ptr) if stream_ptr else None))
+        # plain ints go straight through the declared c_void_p argtypes (this call sits in per-step loops)
+        rc = self.lib.hc_step_device(self.ctx, t, state_ptr, out_ptr, stream_ptr or None)
+        if rc:
+            self._chk(rc)
 
     def components(self):
         hs, rad, wv = (np.empty(self.D_local) for _ in range(3))

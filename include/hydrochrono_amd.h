@@ -207,8 +207,9 @@ typedef struct hc_profile_stats {
     double rem_kernel_seconds;  /* per-step remainder launches inside a look-ahead block */
     long long rem_kernel_launches;
 } hc_profile_stats;
-/* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default).  Event records
- * perturb the launch stream by a few microseconds, so throughput runs should sample (e.g. on = 8). */
+/* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default), and around every
+ * look-ahead pass (one per 16 steps) whatever the stride.  Event records perturb the launch stream by a few
+ * microseconds, so throughput runs should sample (e.g. on = 17). */
 int hc_enable_profiling(hc_ctx* ctx, int on);
 int hc_get_profile(hc_ctx* ctx, hc_profile_stats* out);
 int hc_reset_profile(hc_ctx* ctx);

@@ -29,6 +29,24 @@ def goldens():
     return np.load(os.path.join(GOLDEN_DIR, "sphere_goldens.npz"))
 
 
+def iea_sphere_decay():
+    """The YAML-runner regression case tests/regression/run_hydrochrono/iea_sphere/decay (reference's expected
+    results.still.h5): recorded heave position / velocity / acceleration at dt = 0.01 (!= dt_rirf = 0.015), gravity 9.8,
+    HHT integrator; its BEMIO file is byte-identical to the sphere's."""
+    return dict(np.load(os.path.join(GOLDEN_DIR, "iea_sphere_decay.npz")))
+
+
+def iea_sphere_residual(forces_z, rec, case):
+    """Soft check of the true-interpolation branch: Newton's law of the recorded motion,
+    (m + rho*Ainf_33) a_z + m g, against hs_z - rad_z recomputed from the recorded position and velocity columns.
+    Returns max |difference| as an acceleration.  HHT's alpha-weighting and the reference evaluating the force at each
+    step's predictor state limit the agreement to ~7.4e-3 m/s^2 (3.8e-3 of max |a|); a wrong gravity source, sign
+    or interpolation is 10x-1000x worse."""
+    m, g = float(rec["mass"]), -float(rec["gravity_z"])
+    a33 = case["rho"] * np.asarray(case["bodies"][0]["added_mass_inf"]).reshape(6, 6)[2, 2]
+    return float(np.max(np.abs(rec["acceleration_z"] - (np.asarray(forces_z) - m * g) / (m + a33))))
+
+
 def load_into_oracle(case, oracle_cls=None):
     from oracle import Oracle
     o = (oracle_cls or Oracle)(case["N"])

@@ -8,6 +8,10 @@ Produces (committed, small, data only -- no reference source text):
   tests/golden/sphere_goldens.npz   heave trajectories of the reference regression suite
                                     (tests/regression/reference_data/sphere/**/hc_ref_*.txt),
                                     stored as int32 micro-metres (the files print 6 decimals).
+  tests/golden/iea_sphere_decay.npz time / heave position, velocity, acceleration of the YAML-runner regression case
+                                    tests/regression/run_hydrochrono/iea_sphere/decay/expected/results.still.h5
+                                    (dt = 0.01 != dt_rirf = 0.015, gravity 9.8, HHT; its iea_sphere.h5 is byte-identical
+                                    to demos/sphere/hydroData/sphere.h5, i.e. sphere_bemio.npz).
 
 Needs h5dump (HDF5 1.10 tools, /opt/conda/bin) and /root/reference; neither exists on the GPU box,
 which only ever reads the .npz files.
@@ -53,6 +57,30 @@ def dump(path, shape):
     return arr.reshape(shape)
 
 
+def dump_file(h5file, path, shape):
+    with tempfile.NamedTemporaryFile(suffix=".bin") as tmp:
+        subprocess.run([H5DUMP, "-d", path, "-b", "LE", "-o", tmp.name, h5file], check=True, stdout=subprocess.DEVNULL)
+        arr = np.fromfile(tmp.name, dtype="<f8")
+    assert arr.size == int(np.prod(shape)), (path, arr.size, shape)
+    return arr.reshape(shape)
+
+
+def iea_sphere_decay():
+    base = os.path.join(REF, "tests/regression/run_hydrochrono/iea_sphere")
+    with open(os.path.join(base, "assets/hydroData/iea_sphere.h5"), "rb") as a, open(H5, "rb") as b:
+        assert a.read() == b.read(), "iea_sphere.h5 is expected to be the sphere BEMIO file"
+    res = os.path.join(base, "decay/expected/results.still.h5")
+    n = 4000
+    out = {"time": dump_file(res, "/results/time/time", (n,))}
+    for name in ("position", "velocity", "acceleration"):
+        a = dump_file(res, f"/results/model/bodies/body1/{name}", (n, 3))
+        assert np.all(a[:, :2] == 0.0)  # prismatic heave joint
+        out[name + "_z"] = a[:, 2].copy()
+    # case parameters, transcribed as data from the case's model / simulation yaml
+    out["mass"], out["gravity_z"], out["time_step"] = np.array(261800.0), np.array(-9.8), np.array(0.01)
+    np.savez_compressed(os.path.join(HERE, "iea_sphere_decay.npz"), **out)
+
+
 def read_heave(relpath, skip):
     rows = []
     with open(os.path.join(REF, relpath)) as fh:
@@ -93,7 +121,8 @@ def main():
     gold["reg_wave_pto_damping"] = np.array([398736.034, 118149.758, 90080.857, 161048.558, 322292.419,
                                              479668.979, 633979.761, 784083.286, 932117.647, 1077123.445])
     np.savez_compressed(os.path.join(HERE, "sphere_goldens.npz"), **gold)
-    for f in ("sphere_bemio.npz", "sphere_goldens.npz"):
+    iea_sphere_decay()
+    for f in ("sphere_bemio.npz", "sphere_goldens.npz", "iea_sphere_decay.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

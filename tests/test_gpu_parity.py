@@ -10,7 +10,8 @@ import os
 import numpy as np
 import pytest
 
-from cases import GOLDEN_DIR, SPHERE_DT, SPHERE_G, SPHERE_MASS, goldens, load_into_oracle, sphere_case
+from cases import (GOLDEN_DIR, SPHERE_DT, SPHERE_G, SPHERE_MASS, goldens, iea_sphere_decay, iea_sphere_residual,
+                   load_into_oracle, sphere_case)
 
 pytestmark = pytest.mark.gpu
 
@@ -104,6 +105,32 @@ def test_sphere_decay_forces_and_golden(HF):
     assert np.max(np.abs(z - ref)) <= 5.1e-7  # reference golden, 6 printed decimals
     zo, fo = orc.run_heave_1dof(SPHERE_MASS, SPHERE_G, 0.0, -1.0, SPHERE_DT, len(ref), want_force=True)
     assert np.max(np.abs(z - zo)) <= 1e-12
+
+
+@pytest.mark.parametrize("lookahead", [16, 0])
+def test_iea_sphere_decay_recorded_motion(HF, lookahead):
+    """Reference YAML-runner case iea_sphere/decay (expected/results.still.h5): 4000 recorded steps at dt = 0.01 against
+    an IRF grid of 0.015 -- every IRF sample is a true interpolation -- with system gravity 9.8 (the BEMIO file says 9.81).
+    Forces along the recorded motion: HIP path == oracle, and Newton's law of the recorded accelerations holds to the
+    HHT-limited residual documented in tests/cases.py."""
+    import oracle as oracle_mod
+    oracle_mod.set_num_threads(1)
+    rec, case = iea_sphere_decay(), sphere_case()
+    gpu, orc = make_pair(HF, case)
+    for h in (gpu, orc):
+        h.add_waves_none()
+        h.set_gravity([0.0, 0.0, float(rec["gravity_z"])])
+    gpu.set_lookahead(lookahead)
+    fz, worst = [], 0.0
+    for t, z, v in zip(rec["time"], rec["position_z"], rec["velocity_z"]):
+        st = ([[0, 0, z]], [[0, 0, 0]], [[0, 0, v]], [[0, 0, 0]])
+        fg, fo = gpu.step(float(t), *st), orc.step(float(t), *st)
+        worst = max(worst, relerr(fg, fo))
+        fz.append(fg[2])
+    oracle_mod.set_num_threads(8)
+    assert worst <= TIGHT_TOL
+    res = iea_sphere_residual(fz, rec, case)
+    assert res <= 1.0e-2 and res <= 5e-3 * np.max(np.abs(rec["acceleration_z"]))
 
 
 @pytest.mark.parametrize("k", [1, 10])

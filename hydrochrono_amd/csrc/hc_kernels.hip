@@ -210,11 +210,10 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
 
     const bool radiation = chunk < a.nchunks_rad;
     const Panel& M = radiation ? a.K : a.Kex;
-    int gp0, gp1;
+    // column groups [gp0, gp1) of this chunk and, for radiation, its valid column range [c0, c1)
+    int gp0, gp1, c0 = 0, c1 = 0;
     if (radiation) {
-        // ---- stage u[f] = interp(v_col)(t - tau_s) * width_s for the chunk's columns ----
-        const int D = a.hist.D;
-        int lo, hi;  // valid columns of this chunk's range
+        int lo, hi;
         if (chunk < a.nchunks_rad1) {
             lo  = 0;
             hi  = a.F_limit;
@@ -225,7 +224,32 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
             gp0 = (a.F2_lo >> 3) + (chunk - a.nchunks_rad1) * a.chunk_gp;
         }
         gp1 = min((hi + 7) >> 3, gp0 + a.chunk_gp);
-        const int c0 = max(lo, gp0 * 8), c1 = min(hi, gp1 * 8);
+        c0  = max(lo, gp0 * 8);
+        c1  = min(hi, gp1 * 8);
+    } else {
+        gp0 = (chunk - a.nchunks_rad) * a.chunk_gp_ex;
+        gp1 = min(a.Kex.ngp, gp0 + a.chunk_gp_ex);
+    }
+    const double* __restrict__ kbase = M.base + ((size_t)(grp * MT) * M.ngp) * 128 + lane * 2;
+    const size_t tile_stride = (size_t)M.ngp * 128;
+
+    // Latency-bound variant (short chunks of a look-ahead step): put the wave's first K words in flight before the
+    // right-hand side is staged, so the two round trips overlap instead of adding up.
+    constexpr int PRE = NT ? 0 : 2;
+    dvec2 pre[PRE > 0 ? PRE : 1][MT];
+    if constexpr (PRE > 0) {
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int gp = gp0 + wave + 4 * i;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                pre[i][m] = gp < gp1 ? *reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128) : dvec2{0.0, 0.0};
+        }
+    }
+
+    if (radiation) {
+        // ---- stage u[f] = interp(v_col)(t - tau_s) * width_s for the chunk's columns ----
+        const int D = a.hist.D;
         const int s0 = c0 / D;
         const int ns = (c1 - 1) / D - s0 + 1;
         for (int k = tid; k < ns; k += kConvThreads) {
@@ -243,8 +267,6 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
         }
     } else {
         // ---- stage e[j] = eta(t - tau_j) * width_j ----
-        gp0 = (chunk - a.nchunks_rad) * a.chunk_gp_ex;
-        gp1 = min(a.Kex.ngp, gp0 + a.chunk_gp_ex);
         for (int j = gp0 * 8 + tid; j < gp1 * 8; j += kConvThreads) rhs[j - gp0 * 8] = eta_at(a, j);
     }
     __syncthreads();
@@ -252,10 +274,22 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     double acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = 0.0;
-    const double* __restrict__ kbase = M.base + ((size_t)(grp * MT) * M.ngp) * 128 + lane * 2;
-    const size_t tile_stride = (size_t)M.ngp * 128;
+    if constexpr (PRE > 0) {
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int gp = gp0 + wave + 4 * i;
+            if (gp < gp1) {
+                const double u0 = rhs[(gp - gp0) * 8 + kk], u1 = rhs[(gp - gp0) * 8 + 4 + kk];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m] = fma(pre[i][m].x, u0, acc[m]);
+                    acc[m] = fma(pre[i][m].y, u1, acc[m]);
+                }
+            }
+        }
+    }
 #pragma unroll U
-    for (int gp = gp0 + wave; gp < gp1; gp += 4) {
+    for (int gp = gp0 + wave + 4 * PRE; gp < gp1; gp += 4) {
         dvec2 kv[MT];
         // a matrix streamed exactly once per step uses non-temporal loads (keeps the ring in L2); the short remainder
         // of a look-ahead step re-reads the same newest-sample columns every step, so it uses normal loads and stays cached
@@ -508,10 +542,34 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         for (; c < count; c += 16) acc += a.partials[(size_t)(first + c) * a.Dpad + rrow];
         return acc;
     };
+    // what lane 0 of the row needs besides the partial sums is requested first, so that those loads are in flight
+    // together with the partials instead of after them
+    const int bl = rrow / 6, i = rrow - 6 * bl;  // local body, DoF
+    const int b  = a.b0 + bl;                    // global body
+    const bool finisher = live && sub == 0;
+    double p_row = 0.0, dq[6] = {0, 0, 0, 0, 0, 0}, krow[6] = {0, 0, 0, 0, 0, 0}, V = 0.0, r[3] = {0, 0, 0};
+    if (finisher) {
+        if (a.do_rad && a.P) p_row = a.P[rrow];
+        if (a.do_hs) {
+            const double* pos = a.state + 3 * b;
+            const double* rpy = a.state + 3 * a.N + 3 * b;
+            const double* cg  = a.cg + 3 * bl;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                dq[j]     = pos[j] - cg[j];
+                dq[3 + j] = rpy[j] - 0.0;  // equilibrium rotations are zero (src/hydro_forces.cpp:208-216)
+                r[j]      = a.cb_m_cg[3 * bl + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) krow[j] = a.lin[36 * bl + 6 * i + j];
+            V = a.disp_vol[bl];
+        }
+    }
+
     double rad = 0.0, wav = 0.0;
     if (a.do_rad) {
         rad = lane16_sum(lane_sum(0, a.nchunks_rad));
-        if (a.P) rad = a.P[rrow] + rad;
+        if (a.P) rad = p_row + rad;
     }
     if (a.do_waves && a.wave_mode == 2) wav = lane16_sum(lane_sum(a.nchunks_rad, a.nchunks_ex));
     if (a.do_waves && a.wave_mode == 3) {
@@ -523,10 +581,8 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         wav = lane16_sum(wav);
         if (a.spec_ramp > 0.0 && a.t < a.spec_ramp) wav *= (a.t <= 0.0) ? 0.0 : a.t / a.spec_ramp;
     }
-    if (!live || sub != 0) return;
+    if (!finisher) return;
 
-    const int bl = row / 6, i = row - 6 * bl;  // local body, DoF
-    const int b  = a.b0 + bl;                  // global body
     double hs = 0.0;
     if (a.do_waves && a.wave_mode == 1) {
         // RegularWave::GetForceAtTime (src/wave_types.cpp:315-327)
@@ -534,21 +590,12 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     }
     if (a.do_hs) {
         // ComputeForceHydrostatics (src/hydro_forces.cpp:263-322)
-        const double* pos = a.state + 3 * b;
-        const double* rpy = a.state + 3 * a.N + 3 * b;
-        const double* cg  = a.cg + 3 * bl;
-        double dq[6];
-        dq[0] = pos[0] - cg[0]; dq[1] = pos[1] - cg[1]; dq[2] = pos[2] - cg[2];
-        dq[3] = rpy[0] - 0.0;   dq[4] = rpy[1] - 0.0;   dq[5] = rpy[2] - 0.0;  // equilibrium rotations are zero (:208-216)
-        const double* Krow = a.lin + 36 * bl + 6 * i;
         double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) s += Krow[j] * dq[j];
+        for (int j = 0; j < 6; ++j) s += krow[j] * dq[j];
         const double glen = sqrt(a.gx * a.gx + a.gy * a.gy + a.gz * a.gz);
         hs                = -(a.rho * glen) * s;
-        const double V    = a.disp_vol[bl];
         const double fbx = a.rho * (-a.gx) * V, fby = a.rho * (-a.gy) * V, fbz = a.rho * (-a.gz) * V;
-        const double* r  = a.cb_m_cg + 3 * bl;
         double add;
         switch (i) {
             case 0: add = fbx; break;

@@ -1,5 +1,6 @@
 # Final round-1 measurements: bench lines, rocprofv3 kernel stats, PMC traffic (separate passes).
 R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/final
 mkdir -p $R/gpurun_out/final
 python $R/bench.py > $R/gpurun_out/final/bench_c3.log 2>&1; tail -1 $R/gpurun_out/final/bench_c3.log > $R/gpurun_out/final/bench_c3.json
 python $R/bench.py --lookahead 0 --no-cpu-baseline > $R/gpurun_out/final/bench_c3_plain.log 2>&1; tail -1 $R/gpurun_out/final/bench_c3_plain.log > $R/gpurun_out/final/bench_c3_plain.json

@@ -47,3 +47,16 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "hc_oracle" not in text and "oracle/" not in text and "import oracle" not in text, f
+
+
+def test_cpp_mirror_header_and_example_compile_and_link(tmp_path):
+    """The header-only C++ mirror of the reference's plugin surface (hydro_forces_amd.hpp, Chrono-free part) and the
+    example driver build with plain g++ against the C-ABI library.  Running them needs a GPU (tests/test_gpu_cpp_mirror.py)."""
+    import subprocess
+    from hydrochrono_amd import build as hb
+    hb.build()
+    libdir = os.path.join(ROOT, "hydrochrono_amd", "lib")
+    out = str(tmp_path / "sphere_mock_chrono")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "examples", "sphere_mock_chrono.cpp"), "-o", out,
+                    "-L", libdir, "-lhydrochrono_amd", f"-Wl,-rpath,{libdir}"], check=True)
+    assert os.path.exists(out)

@@ -43,6 +43,12 @@ def stats_file(subdir):
 os.makedirs(DST, exist_ok=True)
 shutil.copy(stats_file("stats"), os.path.join(DST, "final_c3_lookahead_kernel_stats.csv"))
 shutil.copy(stats_file("stats_plain"), os.path.join(DST, "final_c3_plain_kernel_stats.csv"))
+if os.path.isdir(os.path.join(SRC, "stats_default")):  # rocprofv3 around the default command line, `python3 bench.py`
+    shutil.copy(stats_file("stats_default"), os.path.join(DST, "final_c3_default_cmd_kernel_stats.csv"))
+    with open(os.path.join(SRC, "stats_default.log")) as fh:
+        lines = [ln for ln in fh if ln.startswith("{")]
+    if lines:
+        open(os.path.join(DST, "final_bench_c3_default_cmd_under_rocprof.json"), "w").write(lines[-1])
 for src, dst in (("bench_c3.json", "final_bench_c3_lookahead.json"), ("bench_c3_plain.json", "final_bench_c3_plain.json"),
                  ("bench_c4_1gpu.json", "final_bench_c4_1gpu_lookahead.json"), ("host_path.json", "host_path.json")):
     shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))

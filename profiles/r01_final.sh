@@ -8,6 +8,7 @@ python $R/bench.py --scaling strong --bodies 512 --steps 64 --warmup 16 > $R/gpu
 python $R/profiles/host_path.py > $R/gpurun_out/final/host_path.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/stats -- python3 $R/bench.py --steps 320 --warmup 32 --no-cpu-baseline --profile-stride 1000000 > $R/gpurun_out/final/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/stats_default -- python3 $R/bench.py > $R/gpurun_out/final/stats_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/stats_plain -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --lookahead 0 --profile-stride 1000000 > $R/gpurun_out/final/stats_plain.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/fetch -- python3 $R/bench.py --steps 48 --warmup 4 --no-cpu-baseline --profile-stride 1000000 > $R/gpurun_out/final/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/write -- python3 $R/bench.py --steps 48 --warmup 4 --no-cpu-baseline --profile-stride 1000000 > $R/gpurun_out/final/write.log 2>&1

@@ -53,12 +53,14 @@ def parse():
     ap.add_argument("--profile-stride", type=int, default=17, help="HIP-event sampling stride for the per-step launches (co-prime "
                     "with the 16-step look-ahead period); every look-ahead pass, the roofline kernel, is timed regardless")
     ap.add_argument("--lookahead", type=int, default=16, help="0: plain per-step evaluation (K streamed every step)")
+    ap.add_argument("--step-dt", type=float, default=DT, help="caller's step size (default = the IRF grid spacing, the common "
+                    "case; e.g. 0.007 makes every IRF sample a true interpolation, SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline time budget")
     return ap.parse_args()
 
 
-def cpu_baseline(case, motion, t_hist, v_hist, budget_s):
+def cpu_baseline(case, motion, t_hist, v_hist, budget_s, step_dt=DT):
     """Times the CPU oracle on this box's host cores on a bounded sample of the same workload.
 
     Two variants: the reference-faithful restatement (OpenMP over IRF steps, per-element
@@ -69,14 +71,14 @@ def cpu_baseline(case, motion, t_hist, v_hist, budget_s):
     from cases import load_into_oracle
     cores = os.cpu_count() or 1
     orc = load_into_oracle(case)
-    orc.add_waves_irregular(**WAVES)
+    orc.add_waves_irregular(**dict(WAVES, simulation_dt=step_dt))
     orc.prefill_history(t_hist, v_hist)
     k = [0]
 
     def timed(fn, nsteps):
         d, f0 = [], None
         for _ in range(nsteps):
-            t = T0 + k[0] * DT
+            t = T0 + k[0] * step_dt
             st = motion.state(t)
             a = time.perf_counter()
             f = fn(t, *st)
@@ -164,25 +166,26 @@ def main():
         gpu = HydroForces.from_case(case, device=local_rank)
         motion = PrescribedMotion(N, rest_positions(case), seed=20251031 + rank)
         exchange = None  # independent farms: nothing to exchange
-    waves = dict(WAVES, num_bodies=N)
+    waves = dict(WAVES, num_bodies=N, simulation_dt=args.step_dt)  # the wave model is built for the caller's step size
     gpu.add_waves_irregular(**waves)
     gpu.set_lookahead(args.lookahead)
     D_local = gpu.D_local
 
-    nhist = S_RIRF + 5
-    t_hist = T0 - DT * np.arange(1, nhist + 1)
+    sdt = args.step_dt
+    nhist = int(np.ceil(S_RIRF * DT / sdt)) + 5
+    t_hist = T0 - sdt * np.arange(1, nhist + 1)
     v_hist = np.stack([motion.velocity6(t) for t in t_hist])
     gpu.set_history(t_hist, v_hist)
 
     total = args.warmup + args.steps
-    states = torch.tensor(np.stack([motion.packed(T0 + k * DT) for k in range(total)]), device="cuda")
+    states = torch.tensor(np.stack([motion.packed(T0 + k * sdt) for k in range(total)]), device="cuda")
     forces = torch.zeros(total, D_local, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     # device addresses of each step's state / force row, so that the timed loop is the C-ABI call and nothing else
     state_ptrs = [states.data_ptr() + k * states.stride(0) * 8 for k in range(total)]
     force_ptrs = [forces.data_ptr() + k * forces.stride(0) * 8 for k in range(total)]
-    times = [T0 + k * DT for k in range(total)]
+    times = [T0 + k * sdt for k in range(total)]
     step_device = gpu.step_device
 
     def run(k0, k1):
@@ -224,16 +227,16 @@ def main():
     if args.lookahead > 0 and world == 1:
         n_plain = max(20, args.steps // 4)
         gpu.set_lookahead(0)
-        extra_states = torch.tensor(np.stack([motion.packed(T0 + (total + k) * DT) for k in range(n_plain + 4)]), device="cuda")
+        extra_states = torch.tensor(np.stack([motion.packed(T0 + (total + k) * sdt) for k in range(n_plain + 4)]), device="cuda")
         extra_out = torch.zeros(n_plain + 4, D_local, dtype=torch.float64, device="cuda")
         for k in range(4):
-            gpu.step_device(T0 + (total + k) * DT, extra_states[k].data_ptr(), extra_out[k].data_ptr(), stream)
+            gpu.step_device(T0 + (total + k) * sdt, extra_states[k].data_ptr(), extra_out[k].data_ptr(), stream)
         torch.cuda.synchronize()
         gpu.enable_profiling(args.profile_stride)
         gpu.reset_profile()
         tp = time.perf_counter()
         for k in range(4, n_plain + 4):
-            gpu.step_device(T0 + (total + k) * DT, extra_states[k].data_ptr(), extra_out[k].data_ptr(), stream)
+            gpu.step_device(T0 + (total + k) * sdt, extra_states[k].data_ptr(), extra_out[k].data_ptr(), stream)
         torch.cuda.synchronize()
         tp = time.perf_counter() - tp
         pp = gpu.profile()
@@ -285,7 +288,7 @@ def main():
                              f"C3: synthetic {N}-body array per GPU, ") +
                             f"{S_RIRF} radiation-IRF samples, irregular JONSWAP "
                             f"waves with {WAVES['nfrequencies']} components (excitation-IRF convolution, L={gpu.sizes()['L']}), "
-                            "prescribed motion, dt = dt_rirf = 0.01 s, steady-state history",
+                            f"prescribed motion, step dt = {sdt} s, dt_rirf = {DT} s, steady-state history",
                 "bodies": N, "bodies_per_gpu": (N / world if strong else N), "irf_samples": S_RIRF,
                 "wave_components": WAVES["nfrequencies"],
                 "sharding": ("body-row shards of one coupled array + RCCL all-gather of forces" if strong else
@@ -311,7 +314,7 @@ def main():
         if plain is not None:
             out["plain_per_step_mode"] = plain
         if world == 1 and not args.no_cpu_baseline and case is not None:
-            base, f_cpu = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds)
+            base, f_cpu = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds, sdt)
             f_gpu = forces[0].cpu().numpy()  # step k = 0 is t = T0 on both sides
             out["cpu_baseline"] = base
             out["parity_max_rel_err_vs_oracle"] = float(np.max(np.abs(f_gpu - f_cpu)) / np.max(np.abs(f_cpu)))

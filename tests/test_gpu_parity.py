@@ -432,15 +432,16 @@ def c3(HF):
     return case, gpu, motion
 
 
-def test_c3_full_size_against_oracle(c3):
+@pytest.mark.parametrize("dt", [0.01, 0.007])  # the common dt = dt_rirf and a step that makes every sample interpolate
+def test_c3_full_size_against_oracle(c3, dt):
     case, gpu, motion = c3
     orc = load_into_oracle(case)
-    kw = dict(simulation_dt=0.01, simulation_duration=60.0, wave_height=2.0, wave_period=8.0, frequency_min=0.02,
+    kw = dict(simulation_dt=dt, simulation_duration=60.0, wave_height=2.0, wave_period=8.0, frequency_min=0.02,
               frequency_max=0.5, nfrequencies=512, peak_enhancement_factor=3.3, seed=1)
+    gpu.reset_history()
     gpu.add_waves_irregular(**kw)
     orc.add_waves_irregular(**kw)
-    dt = 0.01
-    t_hist = 20.0 - dt * np.arange(1, 1030)  # newest first, covers the whole 10.23 s window
+    t_hist = 20.0 - dt * np.arange(1, int(np.ceil(10.24 / dt)) + 6)  # newest first, covers the whole 10.23 s window
     v_hist = np.stack([motion.velocity6(t) for t in t_hist])
     gpu.set_history(t_hist, v_hist)
     orc.prefill_history(t_hist, v_hist)

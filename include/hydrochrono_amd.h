@@ -155,7 +155,9 @@ int hc_step(hc_ctx* ctx, double t, const double* pos, const double* rpy, const d
 /* Same evaluation with the body state already in HBM and the result left in HBM:
  *   d_state     device pointer, 12N doubles = pos[3N] | rpy[3N] | linvel[3N] | angvel[3N]
  *   d_force_out device pointer, D_local doubles
- *   stream      hipStream_t (NULL = the context's own stream).  Asynchronous: returns after enqueue. */
+ *   stream      hipStream_t (NULL = the context's own stream).  Asynchronous: returns after enqueue; d_state and
+ *               d_force_out must stay valid until the work enqueued for this step has run, and every step of one
+ *               context must go to the same stream (the velocity ring is updated in stream order). */
 int hc_step_device(hc_ctx* ctx, double t, const double* d_state, double* d_force_out, void* stream);
 /* force_hydrostatic_, force_radiation_damping_, force_waves_ of the last evaluated step (D_local each;
  * any pointer may be NULL).  Synchronises the context's stream. */

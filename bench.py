@@ -306,8 +306,9 @@ def main():
                 "traffic_frac_of_hbm_peak": (traffic / conv_s / 1e9 / HBM_PEAK_GBS) if (traffic and conv_s > 0) else None,
                 "fp64_TFLOPs": (2.0 * (alg_bytes / 8.0) / conv_s / 1e12) if conv_s > 0 else None,
                 "fp64_frac_of_mfma_peak": (2.0 * (alg_bytes / 8.0) / conv_s / 1e12 / 78.6) if conv_s > 0 else None,
-                "note": ("one look-ahead launch covers 16 steps: algorithmic bytes = 16 x the per-step figure of SURVEY 8d, "
-                         "while K leaves HBM once (see traffic), so frac > 1 measures the reuse, not a faster memory")
+                "note": ("one look-ahead launch covers 16 steps: algorithmic bytes = the SURVEY 8d per-step figure summed over those "
+                         "steps (less the newest-sample share each step adds itself), while K leaves HBM once (see traffic), so "
+                         "frac > 1 measures the reuse, not a faster memory")
                         if steps_per_launch == 16 else "one launch = one step",
             },
         }

@@ -403,6 +403,11 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         b.Dpad       = c->Dpad;
         b.ngroups    = c->ngroups;
         b.error_flag = c->d_err.p;
+        {  // algorithmic bytes of this pass: step j's share of K (and of the velocity vector) from s_cut[j] on
+            double samples = 0.0;
+            for (int j = 0; j < hc::kLookahead; ++j) samples += std::max(0, b.F / c->D - c->plan.s_cut[j]);
+            c->prof.block_kernel_bytes = 8.0 * samples * (static_cast<double>(c->Dloc) * c->D + c->D);
+        }
         hc::launch_conv_block(b, c->mt, stream);
         if (ev) HC_HIP(hipEventRecord(ev->e[3], stream));
         hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, c->Dpad, c->d_P.p, stream);

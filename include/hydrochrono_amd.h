@@ -205,7 +205,8 @@ typedef struct hc_profile_stats {
     double conv_kernel_bytes;   /* algorithmic bytes of one step (8*D_local*D*S + vectors) */
     double block_kernel_seconds; /* look-ahead kernel launches (one covers 16 steps) */
     long long block_kernel_launches;
-    double block_kernel_bytes;  /* algorithmic bytes of the 16 steps one pass covers */
+    double block_kernel_bytes;  /* algorithmic bytes of the last pass: sum over its 16 steps of the share of K (and of the
+                                   velocity vector) that the pass computes for that step, i.e. IRF samples s >= s_cut[j] */
     double rem_kernel_seconds;  /* per-step remainder launches inside a look-ahead block */
     long long rem_kernel_launches;
 } hc_profile_stats;

@@ -498,7 +498,13 @@ __global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restr
     const int n   = kLookahead * Dpad;
     const int o   = out < n ? out : 0;
     double v = 0.0;
-    for (int c = sub; c < nchunks; c += 16) v += partials[(size_t)c * n + o];
+    for (int c = sub; c < nchunks; c += 8 * 16) {  // 8 loads in flight per lane, adds in ascending chunk order
+        double w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = (c + 16 * k) < nchunks ? partials[(size_t)(c + 16 * k) * n + o] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += w[k];
+    }
     v = lane16_sum(v);
     if (out < n && sub == 0) P[out] = v;
 }
@@ -527,19 +533,21 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const bool live = row < a.Dloc;
     const int rrow  = live ? row : 0;
 
-    // lane `sub` adds chunks sub, sub+16, ... in ascending order; loads are issued 8 at a time so that a long chunk list
-    // (plain steps use several hundred chunks) costs a few round trips, not one per chunk -- the order of the adds is unchanged
+    // lane `sub` adds chunks sub, sub+16, ... in ascending order.  The loads are issued 8 at a time, the tail batch too
+    // (masked slots load nothing and add +0.0): a chunk list costs one round trip per 8 entries instead of one per entry
+    // through the loop-carried add, and the order of the adds is unchanged.
     auto lane_sum = [&](int first, int count) {
         double acc = 0.0;
-        int c = sub;
-        for (; c + 7 * 16 < count; c += 8 * 16) {
+        for (int c = sub; c < count; c += 8 * 16) {
             double v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = a.partials[(size_t)(first + c + 16 * k) * a.Dpad + rrow];
+            for (int k = 0; k < 8; ++k) {
+                const int idx = c + 16 * k;
+                v[k] = idx < count ? a.partials[(size_t)(first + idx) * a.Dpad + rrow] : 0.0;
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc += v[k];
         }
-        for (; c < count; c += 16) acc += a.partials[(size_t)(first + c) * a.Dpad + rrow];
         return acc;
     };
     // what lane 0 of the row needs besides the partial sums is requested first, so that those loads are in flight

@@ -353,6 +353,37 @@ int live_samples(const hc_ctx* c, double t_query) {
     return static_cast<int>(it - c->tau.begin());
 }
 
+// find_bracket of hc_kernels.hip on the host copy of the history (times[0] = t is the current sample, times[k] = ring slot
+// head - k): the same comparisons and the same divisions on the same doubles, so the weights are the kernel's bit for bit.
+// Returns false where the kernel would raise its "not bracketed" flag (the launch then searches itself and reports).
+bool host_bracket(const hc_ctx* c, double q, int H, hc::Bracket* out) {
+    auto time_at = [&](int k) { return c->times[static_cast<size_t>(k)]; };
+    int lo = 0, hi = H - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (time_at(mid + 1) <= q) hi = mid; else lo = mid + 1;
+    }
+    hc::Bracket b{0.0, 0.0, 0, 0};
+    if (lo >= H - 1) {
+        *out = b;
+        return true;
+    }
+    const double newer = time_at(lo), older = time_at(lo + 1);
+    if (q == older) { b.wo = 1.0; b.wn = 0.0; }
+    else if (q == newer) { b.wo = 0.0; b.wn = 1.0; }
+    else if (q > older && q < newer) {
+        const double td = newer - older;
+        b.wo = (td != 0.0) ? ((newer - q) / td) : 0.0;
+        b.wn = 1.0 - b.wo;
+    } else {
+        return false;
+    }
+    b.off_older = ((c->head - (lo + 1) + c->Hcap) % c->Hcap) * c->D;
+    b.off_newer = (lo == 0) ? -1 : ((c->head - lo + c->Hcap) % c->Hcap) * c->D;
+    *out = b;
+    return true;
+}
+
 // Enqueue the kernels of one evaluation at time t. d_state: device pointer to the 12N state. user_out may be null.
 void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f) {
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
@@ -462,10 +493,18 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     a.eta                 = c->d_eta.p;
     a.nt                  = c->nt;
     a.eta_dt              = irregular ? c->irr.simulation_dt : 1.0;
+    a.eta_t0              = (irregular && !c->eta_t.empty()) ? c->eta_t.front() : 0.0;
     a.partials            = c->d_partials.p;
     a.Dpad                = c->Dpad;
     a.ngroups             = c->ngroups;
     a.error_flag          = c->d_err.p;
+    if (run_rad && mode != 0) {
+        const int n = std::min({F_limit / c->D, hc::kHostBrackets, c->S});
+        bool ok = true;
+        for (int s_ = 0; s_ < n && ok; ++s_) ok = host_bracket(c, t - c->tau[s_], H, &a.hb[s_]);
+        a.hb_n = ok ? n : 0;
+        if (nchunks_rad2 > 0) a.hb_defer_valid = host_bracket(c, t - c->tau[c->plan.s_defer[j_block]], H, &a.hb_defer) ? 1 : 0;
+    }
     hc::launch_conv_step(a, c->mt, stream);
     if (ev) HC_HIP(hipEventRecord(ev->e[1], stream));
 

@@ -89,11 +89,6 @@ __device__ __forceinline__ double hist_time(const HistoryView& h, int k) {
     return k == 0 ? h.t : h.ring_t[(h.head - k + h.Hcap) % h.Hcap];
 }
 
-struct Bracket {
-    double wo, wn;   // weights of the older / newer sample (both 0: the sample contributes nothing)
-    int off_older;   // element offset (slot * D) of the older sample's ring row
-    int off_newer;   // element offset of the newer sample's ring row, -1: the newer sample is the current state
-};
 
 // AdvanceToBracket + InterpolateVelocity6D weights (src/hydro_forces.cpp:343-381) for a query time q <= h.t against
 // the history whose newest sample (k = 0) is the current state at h.t.  Finds the smallest i in [0, H-2] with
@@ -160,20 +155,24 @@ __device__ __forceinline__ double interp_velocity_lean(const HistoryView& h, con
 
 __device__ __forceinline__ double eta_at(const StepArgs& a, int j) {
     if (j >= a.L) return 0.0;
-    const double q    = a.hist.t - a.ex_tau[j];
-    const double tmin = a.eta_t[0];
-    int idx = (int)floor((q - tmin) / a.eta_dt);
+    const double q = a.hist.t - a.ex_tau[j];
+    int idx = (int)floor((q - a.eta_t0) / a.eta_dt);  // eta_t0 = eta_t[0], passed by value: no load before the index is known
     idx     = max(0, min(idx, a.nt - 2));
-    while (idx > 0 && a.eta_t[idx] > q) --idx;
-    while (idx < a.nt - 2 && a.eta_t[idx + 1] <= q) ++idx;
-    const double t1 = a.eta_t[idx], t2 = a.eta_t[idx + 1];
+    // the table is close to uniform, so the guessed interval is almost always the right one: request times and values of
+    // the guess together (one round trip) and search only if the guess fails the test the search would end on
+    double t1 = a.eta_t[idx], t2 = a.eta_t[idx + 1], e1 = a.eta[idx], e2 = a.eta[idx + 1];
+    if (!((idx == 0 || t1 <= q) && (idx == a.nt - 2 || t2 > q))) {
+        while (idx > 0 && a.eta_t[idx] > q) --idx;
+        while (idx < a.nt - 2 && a.eta_t[idx + 1] <= q) ++idx;
+        t1 = a.eta_t[idx]; t2 = a.eta_t[idx + 1]; e1 = a.eta[idx]; e2 = a.eta[idx + 1];
+    }
     double val;
-    if (q == t1) val = a.eta[idx];
-    else if (q == t2) val = a.eta[idx + 1];
+    if (q == t1) val = e1;
+    else if (q == t2) val = e2;
     else if (q > t1 && q < t2) {
         const double w1 = (t2 - q) / (t2 - t1);
         const double w2 = 1.0 - w1;
-        val = w1 * a.eta[idx] + w2 * a.eta[idx + 1];
+        val = w1 * e1 + w2 * e2;
     } else {
         *a.error_flag = 2;  // outside the table: the host has already refused the step (src/wave_types.cpp:833-840)
         val = 0.0;
@@ -252,8 +251,11 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
         const int D = a.hist.D;
         const int s0 = c0 / D;
         const int ns = (c1 - 1) / D - s0 + 1;
+        const bool first_range = chunk < a.nchunks_rad1;
         for (int k = tid; k < ns; k += kConvThreads) {
-            tab[k]  = find_bracket(a.hist, a.hist.t - a.tau[s0 + k], a.error_flag);
+            if (first_range && s0 + k < a.hb_n) tab[k] = a.hb[s0 + k];
+            else if (!first_range && a.hb_defer_valid) tab[k] = a.hb_defer;
+            else tab[k] = find_bracket(a.hist, a.hist.t - a.tau[s0 + k], a.error_flag);
             wtab[k] = a.width[s0 + k];
         }
         __syncthreads();

@@ -37,6 +37,15 @@ struct HistoryView {
     double dt_hint;       // t - previous sample time (bracket-search hint only, > 0)
 };
 
+// Interpolation bracket of one IRF sample's query time in the history (AdvanceToBracket + InterpolateVelocity6D weights,
+// src/hydro_forces.cpp:343-381).
+struct Bracket {
+    double wo, wn;   // weights of the older / newer sample (both 0: the sample contributes nothing)
+    int off_older;   // element offset (slot * D) of the older sample's ring row
+    int off_newer;   // element offset of the newer sample's ring row, -1: the newer sample is the current state
+};
+constexpr int kHostBrackets = 24;
+
 // Per-step launch: radiation columns [0, F_limit) of K (F_limit = S*D for a plain step, s_cut*D for the remainder of a
 // look-ahead step) and, for irregular waves, the excitation matrix, both as column chunks of a streamed FP64 GEMV.
 // A workgroup owns MT row tiles x one chunk and leaves one partial per row in partials[chunk][Dpad].
@@ -64,10 +73,16 @@ struct StepArgs {
     const double* eta;       // [nt]
     int nt;
     double eta_dt;           // nominal spacing of eta_t (search hint only)
+    double eta_t0;           // eta_t[0]
     double* partials;        // [(nchunks_rad + nchunks_ex)][Dpad]
     int Dpad;
     int ngroups;             // ntiles / MT
     int* error_flag;         // 1 / 2: a query time is not bracketed (reference: runtime_error)
+    // brackets of the first hb_n IRF samples and of the deferred sample, found on the host (same arithmetic on the same
+    // doubles) for the short remainder of a look-ahead step: saves the launch two dependent round trips to the ring times
+    int hb_n, hb_defer_valid;
+    Bracket hb[kHostBrackets];
+    Bracket hb_defer;
 };
 
 // Look-ahead pass: for j = 0..15 the part of step (n+j)'s radiation sum that depends only on history known at step n,

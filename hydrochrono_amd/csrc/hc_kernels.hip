@@ -252,20 +252,36 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
         const int s0 = c0 / D;
         const int ns = (c1 - 1) / D - s0 + 1;
         const bool first_range = chunk < a.nchunks_rad1;
-        for (int k = tid; k < ns; k += kConvThreads) {
-            if (first_range && s0 + k < a.hb_n) tab[k] = a.hb[s0 + k];
-            else if (!first_range && a.hb_defer_valid) tab[k] = a.hb_defer;
-            else tab[k] = find_bracket(a.hist, a.hist.t - a.tau[s0 + k], a.error_flag);
-            wtab[k] = a.width[s0 + k];
-        }
-        __syncthreads();
-        for (int f = gp0 * 8 + tid; f < gp1 * 8; f += kConvThreads) {
-            double u = 0.0;
-            if (f >= c0 && f < c1) {
-                const int s = f / D, col = f - s * D;
-                u = interp_velocity(a.hist, tab[s - s0], col, state_velocity(a.hist.state, a.hist.N, col)) * wtab[s - s0];
+        const bool from_host   = first_range ? (s0 + ns <= a.hb_n) : (a.hb_defer_valid != 0);
+        if (!NT && ns == 1 && from_host) {
+            // short chunk inside one IRF sample whose bracket came with the launch: the bracket is workgroup-uniform
+            // (scalar loads from the argument block), so no table, no barrier -- the ring loads go out at once
+            const Bracket b = first_range ? a.hb[s0] : a.hb_defer;
+            const double w  = a.width[s0];
+            for (int f = gp0 * 8 + tid; f < gp1 * 8; f += kConvThreads) {
+                double u = 0.0;
+                if (f >= c0 && f < c1) {
+                    const int col = f - s0 * D;
+                    u = interp_velocity(a.hist, b, col, state_velocity(a.hist.state, a.hist.N, col)) * w;
+                }
+                rhs[f - gp0 * 8] = u;
             }
-            rhs[f - gp0 * 8] = u;
+        } else {
+            for (int k = tid; k < ns; k += kConvThreads) {
+                if (first_range && s0 + k < a.hb_n) tab[k] = a.hb[s0 + k];
+                else if (!first_range && a.hb_defer_valid) tab[k] = a.hb_defer;
+                else tab[k] = find_bracket(a.hist, a.hist.t - a.tau[s0 + k], a.error_flag);
+                wtab[k] = a.width[s0 + k];
+            }
+            __syncthreads();
+            for (int f = gp0 * 8 + tid; f < gp1 * 8; f += kConvThreads) {
+                double u = 0.0;
+                if (f >= c0 && f < c1) {
+                    const int s = f / D, col = f - s * D;
+                    u = interp_velocity(a.hist, tab[s - s0], col, state_velocity(a.hist.state, a.hist.N, col)) * wtab[s - s0];
+                }
+                rhs[f - gp0 * 8] = u;
+            }
         }
     } else {
         // ---- stage e[j] = eta(t - tau_j) * width_j ----

@@ -205,19 +205,23 @@ void choose_exc_config(hc_ctx* c) {
     if (c->wave_kind != hc::kWaveIrregular || c->L == 0) {
         c->nchunks_ex  = 0;
         c->chunk_gp_ex = 64;
+        c->nchunks_ex_block = 0;
         return;
     }
     c->chunk_gp_ex = std::max(4, env_int("HC_EXC_CHUNK_GP", 8));  // short chunks: the excitation side is latency-bound
     c->nchunks_ex  = (c->ngp_ex + c->chunk_gp_ex - 1) / c->chunk_gp_ex;
+    c->chunk_gp_ex_block = 32;  // whole 16-group sub-tiles of the look-ahead kernel
+    c->nchunks_ex_block  = (c->ngp_ex + c->chunk_gp_ex_block - 1) / c->chunk_gp_ex_block;
 }
 
 void alloc_partials(hc_ctx* c) {
     const int rem_chunks = (c->ngp + c->chunk_gp_rem - 1) / c->chunk_gp_rem + 1;  // worst case: remainder spans all of K
     const size_t n = static_cast<size_t>(std::max(c->nchunks_rad, rem_chunks) + c->nchunks_ex) * c->Dpad;
     if (c->d_partials.n < n) c->d_partials.alloc(n);
-    const size_t nb = static_cast<size_t>(c->nchunks_block) * hc::kLookahead * c->Dpad;
+    const size_t nb = static_cast<size_t>(c->nchunks_block + c->nchunks_ex_block) * hc::kLookahead * c->Dpad;
     if (c->d_partials_block.n < nb) c->d_partials_block.alloc(nb);
     if (c->d_P.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_P.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
+    if (c->d_E.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_E.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
 }
 
 // ---- TaperedDirect ----------------------------------------------------------------------------
@@ -265,6 +269,16 @@ void ensure_processed(hc_ctx* c) {
 struct StepFlags {
     bool hs = true, rad = true, waves = true;
 };
+
+// the excitation-window tests of check_wave_ready as a predicate (for predicted step times)
+bool wave_window_ok(const hc_ctx* c, double t) {
+    if (c->wave_kind != hc::kWaveIrregular || c->eta_t.size() < 2 || c->ex_tau.empty()) return false;
+    const double tmin = c->eta_t.front(), tmax = c->eta_t.back();
+    const double q0 = t - c->ex_tau.front(), q1 = t - c->ex_tau.back();
+    if (!(tmin <= q0 && q0 <= tmax) || !(tmin <= q1 && q1 <= tmax)) return false;
+    if (q0 > tmin && q0 < tmax && q0 <= c->eta_t[1]) return false;
+    return true;
+}
 
 void check_wave_ready(hc_ctx* c, double t) {
     if (c->wave_nb_arg < c->N)
@@ -412,6 +426,20 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     hv.Hcap    = c->Hcap;
     hv.dt_hint = (H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
 
+    hc::Panel kex{};
+    kex.base   = c->d_kex.p;
+    kex.ntiles = c->ntiles;
+    kex.ngp    = c->ngp_ex;
+    hc::EtaTable ex{};
+    ex.L        = c->L;
+    ex.ex_tau   = c->d_ex_tau.p;
+    ex.ex_width = c->d_ex_width.p;
+    ex.eta_t    = c->d_eta_t.p;
+    ex.eta      = c->d_eta.p;
+    ex.nt       = c->nt;
+    ex.eta_dt   = irregular ? c->irr.simulation_dt : 1.0;
+    ex.eta_t0   = (irregular && !c->eta_t.empty()) ? c->eta_t.front() : 0.0;
+
     if (ev) HC_HIP(hipEventRecord(ev->e[0], stream));
     const double* P_row = nullptr;
     int j_block = 0;
@@ -430,6 +458,16 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         }
         b.tau        = c->d_tau.p;
         b.width      = c->d_width.p;
+        // The excitation force depends on time only, so the pass also evaluates it for the 16 predicted times (extra chunks
+        // over Kex in the same launch) -- provided every predicted time passes the window tests a real step would have to pass.
+        static const bool exc_in_block = env_int("HC_EXC_IN_BLOCK", 1) != 0;
+        bool exc_block = exc_in_block && run_exc && c->nchunks_ex_block > 0;
+        for (int j = 0; j < hc::kLookahead && exc_block; ++j) exc_block = wave_window_ok(c, c->plan.tpred[j]);
+        c->plan.has_exc = exc_block;
+        b.Kex           = kex;
+        b.ex            = ex;
+        b.chunk_gp_ex   = c->chunk_gp_ex_block;
+        b.nchunks_ex    = exc_block ? c->nchunks_ex_block : 0;
         b.partials   = c->d_partials_block.p;
         b.Dpad       = c->Dpad;
         b.ngroups    = c->ngroups;
@@ -438,15 +476,18 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
             double samples = 0.0;
             for (int j = 0; j < hc::kLookahead; ++j) samples += std::max(0, b.F / c->D - c->plan.s_cut[j]);
             c->prof.block_kernel_bytes = 8.0 * samples * (static_cast<double>(c->Dloc) * c->D + c->D);
+            if (exc_block) c->prof.block_kernel_bytes += 8.0 * hc::kLookahead * (static_cast<double>(c->Dloc) * c->L + c->L);
         }
         hc::launch_conv_block(b, c->mt, stream);
         if (ev) HC_HIP(hipEventRecord(ev->e[3], stream));
-        hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, c->Dpad, c->d_P.p, stream);
+        hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, c->d_P.p, c->d_E.p, stream);
         P_row = c->d_P.p;
     } else if (run_rad && mode == 2) {
         j_block = c->plan.j_next++;
         P_row   = c->d_P.p + static_cast<size_t>(j_block) * c->Dpad;
     }
+
+    const double* E_row = (run_exc && run_rad && mode != 0 && c->plan.has_exc) ? c->d_E.p + static_cast<size_t>(j_block) * c->Dpad : nullptr;
 
     // per-step kernel: radiation columns still to do this step + excitation chunks
     int F_limit = 0, chunk_gp = c->chunk_gp, nchunks_rad1 = 0, nchunks_rad2 = 0, F2_lo = 0, F2_hi = 0;
@@ -481,19 +522,10 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     a.hist                = hv;
     a.tau                 = c->d_tau.p;
     a.width               = c->d_width.p;
-    a.Kex.base            = c->d_kex.p;
-    a.Kex.ntiles          = c->ntiles;
-    a.Kex.ngp             = c->ngp_ex;
-    a.L                   = c->L;
+    a.Kex                 = kex;
+    a.ex                  = ex;
     a.chunk_gp_ex         = c->chunk_gp_ex;
-    a.nchunks_ex          = run_exc ? c->nchunks_ex : 0;
-    a.ex_tau              = c->d_ex_tau.p;
-    a.ex_width            = c->d_ex_width.p;
-    a.eta_t               = c->d_eta_t.p;
-    a.eta                 = c->d_eta.p;
-    a.nt                  = c->nt;
-    a.eta_dt              = irregular ? c->irr.simulation_dt : 1.0;
-    a.eta_t0              = (irregular && !c->eta_t.empty()) ? c->eta_t.front() : 0.0;
+    a.nchunks_ex          = (run_exc && !E_row) ? c->nchunks_ex : 0;
     a.partials            = c->d_partials.p;
     a.Dpad                = c->Dpad;
     a.ngroups             = c->ngroups;
@@ -513,6 +545,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     z.nchunks_rad = a.nchunks_rad;
     z.nchunks_ex  = a.nchunks_ex;
     z.P           = P_row;
+    z.E           = E_row;
     z.Dloc        = c->Dloc;
     z.Dpad        = c->Dpad;
     z.N           = c->N;
@@ -913,6 +946,7 @@ int hc_set_gravity(hc_ctx* c, const double g[3]) {
 
 int hc_set_wave_none(hc_ctx* c, int num_bodies_arg) {
     HC_API_BEGIN(c)
+    c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(num_bodies_arg >= 0, HC_ERR_INVALID, "negative body count");
     c->wave_kind   = hc::kWaveNone;
@@ -923,6 +957,7 @@ int hc_set_wave_none(hc_ctx* c, int num_bodies_arg) {
 
 int hc_set_wave_regular(hc_ctx* c, int num_bodies_arg, double amplitude, double omega) {
     HC_API_BEGIN(c)
+    c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(num_bodies_arg >= 1 && num_bodies_arg <= c->N, HC_ERR_OUT_OF_RANGE, "regular wave created for more bodies than the hydro data holds");
     for (int b = 0; b < num_bodies_arg; ++b) require(c->bodies[b].have_rao, HC_ERR_INVALID, "excitation RAO missing for a body");
@@ -977,6 +1012,7 @@ void hc_irregular_wave_params_default(hc_irregular_wave_params* p) {
 
 int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     HC_API_BEGIN(c)
+    c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(pp, HC_ERR_INVALID, "null parameters");
     const hc_irregular_wave_params p = *pp;
@@ -1083,6 +1119,7 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
 
 int hc_set_wave_irregular_spectral(hc_ctx* c, const hc_irregular_wave_params* pp) {
     HC_API_BEGIN(c)
+    c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(pp, HC_ERR_INVALID, "null parameters");
     const hc_irregular_wave_params p = *pp;

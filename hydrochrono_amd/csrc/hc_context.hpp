@@ -104,6 +104,7 @@ struct Plan {
     int s_cut[kLookahead]    = {0};
     int s_defer[kLookahead]  = {0};  // sample whose "is there an older history sample" test is too close to call ahead of time (-1: none)
     int misses = 0, cooldown = 0;
+    bool has_exc = false;  // the pass also left the excitation force of the 16 predicted times (E rows)
 };
 
 }  // namespace hc
@@ -157,7 +158,8 @@ struct hc_ctx {
     // GEMV configuration + scratch
     int chunk_gp = 0, nchunks_rad = 0, chunk_gp_ex = 0, nchunks_ex = 0, ngp_ex = 0;
     int chunk_gp_block = 0, nchunks_block = 0, chunk_gp_rem = 64;
-    hc::DeviceBuffer<double> d_partials, d_partials_block, d_P;
+    hc::DeviceBuffer<double> d_partials, d_partials_block, d_P, d_E;
+    int chunk_gp_ex_block = 32, nchunks_ex_block = 0;  // excitation chunks of the look-ahead launch
     int lookahead = 0;  // 0: off, else kLookahead
     hc::Plan plan;
 

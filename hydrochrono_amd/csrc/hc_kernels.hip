@@ -153,9 +153,9 @@ __device__ __forceinline__ double interp_velocity_lean(const HistoryView& h, con
     return b.wo * vo + b.wn * vn;
 }
 
-__device__ __forceinline__ double eta_at(const StepArgs& a, int j) {
+__device__ __forceinline__ double eta_at(const EtaTable& a, double t, int j, int* error_flag) {
     if (j >= a.L) return 0.0;
-    const double q = a.hist.t - a.ex_tau[j];
+    const double q = t - a.ex_tau[j];
     int idx = (int)floor((q - a.eta_t0) / a.eta_dt);  // eta_t0 = eta_t[0], passed by value: no load before the index is known
     idx     = max(0, min(idx, a.nt - 2));
     // the table is close to uniform, so the guessed interval is almost always the right one: request times and values of
@@ -174,7 +174,7 @@ __device__ __forceinline__ double eta_at(const StepArgs& a, int j) {
         const double w2 = 1.0 - w1;
         val = w1 * e1 + w2 * e2;
     } else {
-        *a.error_flag = 2;  // outside the table: the host has already refused the step (src/wave_types.cpp:833-840)
+        *error_flag = 2;  // outside the table: the host has already refused the step (src/wave_types.cpp:833-840)
         val = 0.0;
     }
     return val * a.ex_width[j];
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
         }
     } else {
         // ---- stage e[j] = eta(t - tau_j) * width_j ----
-        for (int j = gp0 * 8 + tid; j < gp1 * 8; j += kConvThreads) rhs[j - gp0 * 8] = eta_at(a, j);
+        for (int j = gp0 * 8 + tid; j < gp1 * 8; j += kConvThreads) rhs[j - gp0 * 8] = eta_at(a.ex, a.hist.t, j, a.error_flag);
     }
     __syncthreads();
 
@@ -378,33 +378,33 @@ static constexpr int kWaveGp    = 4;                  // column groups a wave ha
 static constexpr int kUStride   = kWaveGp * 8 + 2;    // LDS row stride of a wave's U[j][col] in doubles: conflict-free ds_read_b64 of the B operand
 static constexpr int kUWave     = kLookahead * kUStride;  // doubles per wave
 
-template <int MT>
-__global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
-    // dynamic LDS: per-wave U sub-tiles [4][16][34] (re-used as the cross-wave reduction buffer at the end),
-    // bracket table [ns][16], widths [ns]
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    double* Uall = reinterpret_cast<double*>(smem_raw);
-    Bracket* tab = reinterpret_cast<Bracket*>(Uall + a.lds_front_doubles);
-    double* wtab = reinterpret_cast<double*>(tab + (size_t)a.max_steps_per_chunk * kLookahead);
-
-    const int chunk = blockIdx.x % a.nchunks;
-    const int grp   = blockIdx.x / a.nchunks;
+// One work item of a look-ahead workgroup: RAD = its radiation chunk of K, !RAD = excitation chunk `e` of Kex.
+template <int MT, bool RAD>
+__device__ __forceinline__ void block_work(const BlockArgs& a, const int chunk, const int grp, const int e, double* Uall, Bracket* tab,
+                                           double* wtab) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kk = lane >> 4, jstep = lane & 15;
     const int D = a.hist.D;
-
-    const int gp0 = chunk * a.chunk_gp;
-    const int gp1 = min((a.F + 7) >> 3, gp0 + a.chunk_gp);
-    const int c0 = gp0 * 8, c1 = min(a.F, gp1 * 8);
-    const int s0 = c0 / D;
-    const int ns = (c1 - 1) / D - s0 + 1;
-    for (int idx = tid; idx < ns * kLookahead; idx += kConvThreads) {
-        const int k = idx >> 4, j = idx & 15, s = s0 + k;
-        Bracket b;
-        b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
-        if (s >= a.s_cut[j] && s != a.s_defer[j]) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
-        tab[idx] = b;
-        if (j == 0) wtab[k] = a.width[s];
+    const Panel& M = RAD ? a.K : a.Kex;
+    int gp0, gp1, c1, s0 = 0;
+    if constexpr (RAD) {
+        gp0 = chunk * a.chunk_gp;
+        gp1 = min((a.F + 7) >> 3, gp0 + a.chunk_gp);
+        c1  = min(a.F, gp1 * 8);
+        s0  = (gp0 * 8) / D;
+        const int ns = (c1 - 1) / D - s0 + 1;
+        for (int idx = tid; idx < ns * kLookahead; idx += kConvThreads) {
+            const int k = idx >> 4, j = idx & 15, s = s0 + k;
+            Bracket b;
+            b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
+            if (s >= a.s_cut[j] && s != a.s_defer[j]) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
+            tab[idx] = b;
+            if (j == 0) wtab[k] = a.width[s];
+        }
+    } else {
+        gp0 = e * a.chunk_gp_ex;
+        gp1 = min(a.Kex.ngp, gp0 + a.chunk_gp_ex);
+        c1  = min(a.ex.L, gp1 * 8);
     }
     __syncthreads();  // the only workgroup barrier before the epilogue: from here on the four waves run independently,
                       // so their load / stage / MFMA phases drift apart and HBM stays busy
@@ -413,8 +413,8 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = dvec4{0.0, 0.0, 0.0, 0.0};
 
-    const double* __restrict__ kbase = a.K.base + ((size_t)(grp * MT) * a.K.ngp) * 128 + lane * 2;
-    const size_t tile_stride = (size_t)a.K.ngp * 128;
+    const double* __restrict__ kbase = M.base + ((size_t)(grp * MT) * M.ngp) * 128 + lane * 2;
+    const size_t tile_stride = (size_t)M.ngp * 128;
     double* Us = Uall + wave * kUWave;
     // staging role of this lane: column c8 of column group `sit` of the wave's sub-tile, steps jh, jh+2, ..., jh+14
     const int c8 = lane & 7, sit = (lane >> 3) & 3, jh = lane >> 5;
@@ -433,13 +433,21 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
                     kv[it][m] = dvec2{0.0, 0.0};
             }
         }
-        // 2. stage U[j][col] = interp(v_col)(tpred[j] - tau_s) * width_s for the wave's 32 columns x 16 steps
+        // 2. stage U[j][col] for the wave's 32 columns x 16 steps
         {
             const int f = (sub0 + wave + 4 * sit) * 8 + c8;
             if (a.ablate == 1) {  // diagnostic build path only (HC_BLOCK_ABLATE): no staging loads
 #pragma unroll
                 for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = 1.0;
+            } else if (!RAD) {
+                // excitation: U[j][l] = eta(tpred[j] - ex_tau[l]) * ex_width[l]  (0 for l >= L)
+                double uq[kLookahead / 2];
+#pragma unroll
+                for (int q = 0; q < kLookahead / 2; ++q) uq[q] = eta_at(a.ex, a.tpred[jh + 2 * q], f, a.error_flag);
+#pragma unroll
+                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = uq[q];
             } else if (f < c1) {
+                // radiation: U[j][(s,col)] = interp(v_col)(tpred[j] - tau_s) * width_s
                 const int s = f / D, col = f - s * D;
                 const double w      = wtab[s - s0];
                 const double vstate = state_velocity(a.hist.state, a.hist.N, col);
@@ -482,15 +490,42 @@ __global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[((size_t)wave * MT + m) * 256 + (kk + 4 * r) * 16 + jstep] = acc[m][r];
     __syncthreads();
+    const int out_chunk = RAD ? chunk : a.nchunks + e;
     for (int idx = tid; idx < MT * 256; idx += kConvThreads) {
-        const int m = idx >> 8, e = idx & 255, row = e >> 4, j = e & 15;
-        const double v = ((red[(0 * MT + m) * 256 + e] + red[(1 * MT + m) * 256 + e]) + red[(2 * MT + m) * 256 + e]) + red[(3 * MT + m) * 256 + e];
-        a.partials[((size_t)chunk * kLookahead + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
+        const int m = idx >> 8, el = idx & 255, row = el >> 4, j = el & 15;
+        const double v = ((red[(0 * MT + m) * 256 + el] + red[(1 * MT + m) * 256 + el]) + red[(2 * MT + m) * 256 + el]) + red[(3 * MT + m) * 256 + el];
+        a.partials[((size_t)out_chunk * kLookahead + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
+    }
+}
+
+template <int MT>
+__global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
+    // dynamic LDS: per-wave U sub-tiles [4][16][34] (re-used as the cross-wave reduction buffer at the end),
+    // bracket table [ns][16], widths [ns]
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double* Uall = reinterpret_cast<double*>(smem_raw);
+    Bracket* tab = reinterpret_cast<Bracket*>(Uall + a.lds_front_doubles);
+    double* wtab = reinterpret_cast<double*>(tab + (size_t)a.max_steps_per_chunk * kLookahead);
+
+    // Block index -> (chunk, row group).  Workgroups are dealt to the 8 XCDs round-robin by block index, and the row groups
+    // of one chunk stage the same ring rows, so they get block indices that are congruent mod 8 and close together
+    // ([octet of chunks][row group][chunk % 8]): the staging loads of all but the first then hit that XCD's L2.
+    const int r     = (int)blockIdx.x % (8 * a.ngroups);
+    const int chunk = ((int)blockIdx.x / (8 * a.ngroups)) * 8 + (r & 7);
+    const int grp   = r >> 3;
+    if (chunk >= a.nchunks) return;
+
+    block_work<MT, true>(a, chunk, grp, 0, Uall, tab, wtab);
+    // The excitation force depends on time only: its chunks over Kex (a fraction of a percent of K) for the 16 predicted
+    // times ride at the end of radiation workgroups, so the launch keeps its number of workgroups (grid rounds on the chip).
+    for (int e = chunk; e < a.nchunks_ex; e += a.nchunks) {
+        __syncthreads();  // the reduction buffer of the previous work item aliases the U tiles of this one
+        block_work<MT, false>(a, chunk, grp, e, Uall, tab, wtab);
     }
 }
 
 void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
-    const int nblocks = a.ngroups * a.nchunks;
+    const int nblocks = ((a.nchunks + 7) >> 3) * 8 * a.ngroups;  // octets of chunks, see the kernel's block mapping
     if (nblocks <= 0) return;
     BlockArgs b = a;
     static const int ablate = [] { const char* e = std::getenv("HC_BLOCK_ABLATE"); return e ? std::atoi(e) : 0; }();
@@ -509,27 +544,35 @@ __device__ __forceinline__ double lane16_sum(double v) {
     return v;
 }
 
-// P[j][row] = sum_c partials[c][j][row]; 16 lanes per output, chunks c = l, l+16, ... then a 4-step xor tree.
-__global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restrict__ partials, int nchunks, int Dpad, double* __restrict__ P) {
+// P[j][row] = sum over radiation chunks c of partials[c][j][row]; E[j][row] = the same over the excitation chunks.
+// 16 lanes per output, chunks c = l, l+16, ... (8 loads in flight per lane, adds in ascending chunk order), then a 4-step
+// xor tree.
+__global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restrict__ partials, int nchunks_rad, int nchunks_ex, int Dpad,
+                                                           double* __restrict__ P, double* __restrict__ E) {
     const int sub = threadIdx.x & 15;
-    const int out = blockIdx.x * 16 + (threadIdx.x >> 4);  // j*Dpad + row
     const int n   = kLookahead * Dpad;
-    const int o   = out < n ? out : 0;
+    int out       = blockIdx.x * 16 + (threadIdx.x >> 4);  // [segment][j*Dpad + row]
+    const bool exc = out >= n;
+    if (exc) out -= n;
+    const int first = exc ? nchunks_rad : 0, count = exc ? nchunks_ex : nchunks_rad;
+    const int o     = out < n ? out : 0;
     double v = 0.0;
-    for (int c = sub; c < nchunks; c += 8 * 16) {  // 8 loads in flight per lane, adds in ascending chunk order
+    for (int c = sub; c < count; c += 8 * 16) {
         double w[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] = (c + 16 * k) < nchunks ? partials[(size_t)(c + 16 * k) * n + o] : 0.0;
+        for (int k = 0; k < 8; ++k) w[k] = (c + 16 * k) < count ? partials[(size_t)(first + c + 16 * k) * n + o] : 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) v += w[k];
     }
     v = lane16_sum(v);
-    if (out < n && sub == 0) P[out] = v;
+    if (out < n && sub == 0) (exc ? E : P)[out] = v;
 }
 
-void launch_reduce_block(const double* d_partials, int nchunks, int Dpad, double* d_P, hipStream_t stream) {
-    const int n = kLookahead * Dpad;
-    hipLaunchKernelGGL(reduce_block_kernel, dim3((n + 15) / 16), dim3(256), 0, stream, d_partials, nchunks, Dpad, d_P);
+void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_ex, int Dpad, double* d_P, double* d_E, hipStream_t stream) {
+    const int n    = kLookahead * Dpad;
+    const int nblk = (n + 15) / 16;  // n is a multiple of 16, so the excitation segment starts on a workgroup boundary
+    hipLaunchKernelGGL(reduce_block_kernel, dim3(nchunks_ex > 0 ? 2 * nblk : nblk), dim3(256), 0, stream, d_partials, nchunks_rad, nchunks_ex,
+                       Dpad, d_P, d_E);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -573,9 +616,10 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const int bl = rrow / 6, i = rrow - 6 * bl;  // local body, DoF
     const int b  = a.b0 + bl;                    // global body
     const bool finisher = live && sub == 0;
-    double p_row = 0.0, dq[6] = {0, 0, 0, 0, 0, 0}, krow[6] = {0, 0, 0, 0, 0, 0}, V = 0.0, r[3] = {0, 0, 0};
+    double p_row = 0.0, e_row = 0.0, dq[6] = {0, 0, 0, 0, 0, 0}, krow[6] = {0, 0, 0, 0, 0, 0}, V = 0.0, r[3] = {0, 0, 0};
     if (finisher) {
         if (a.do_rad && a.P) p_row = a.P[rrow];
+        if (a.do_waves && a.wave_mode == 2 && a.E) e_row = a.E[rrow];
         if (a.do_hs) {
             const double* pos = a.state + 3 * b;
             const double* rpy = a.state + 3 * a.N + 3 * b;
@@ -597,7 +641,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         rad = lane16_sum(lane_sum(0, a.nchunks_rad));
         if (a.P) rad = p_row + rad;
     }
-    if (a.do_waves && a.wave_mode == 2) wav = lane16_sum(lane_sum(a.nchunks_rad, a.nchunks_ex));
+    if (a.do_waves && a.wave_mode == 2) wav = a.E ? e_row : lane16_sum(lane_sum(a.nchunks_rad, a.nchunks_ex));
     if (a.do_waves && a.wave_mode == 3) {
         // component sum over the spectrum (the north_star's literal wording; not the reference's IRF convolution):
         // eta(t) = sum a_i cos(w_i t - phi_i)  ->  f = sum |X(w_i)| a_i cos(w_i t - phi_i + arg X(w_i)); 16 lanes per row

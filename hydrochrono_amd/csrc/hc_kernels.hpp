@@ -46,6 +46,19 @@ struct Bracket {
 };
 constexpr int kHostBrackets = 24;
 
+// Excitation side shared by the per-step and the look-ahead launch: e[j] = eta(t - ex_tau[j]) * ex_width[j], eta linearly
+// interpolated in the precomputed free-surface table (src/wave_types.cpp:797-831).
+struct EtaTable {
+    int L;                   // excitation samples (columns of Kex)
+    const double* ex_tau;    // [L]
+    const double* ex_width;  // [L]
+    const double* eta_t;     // [nt]
+    const double* eta;       // [nt]
+    int nt;
+    double eta_dt;           // nominal spacing of eta_t (search hint only)
+    double eta_t0;           // eta_t[0]
+};
+
 // Per-step launch: radiation columns [0, F_limit) of K (F_limit = S*D for a plain step, s_cut*D for the remainder of a
 // look-ahead step) and, for irregular waves, the excitation matrix, both as column chunks of a streamed FP64 GEMV.
 // A workgroup owns MT row tiles x one chunk and leaves one partial per row in partials[chunk][Dpad].
@@ -64,16 +77,9 @@ struct StepArgs {
     const double* tau;    // [S] radiation IRF sample times
     const double* width;  // [S] trapezoid widths
     Panel Kex;
-    int L;                // excitation samples (columns of Kex)
+    EtaTable ex;
     int chunk_gp_ex;
     int nchunks_ex;
-    const double* ex_tau;    // [L]
-    const double* ex_width;  // [L]
-    const double* eta_t;     // [nt]
-    const double* eta;       // [nt]
-    int nt;
-    double eta_dt;           // nominal spacing of eta_t (search hint only)
-    double eta_t0;           // eta_t[0]
     double* partials;        // [(nchunks_rad + nchunks_ex)][Dpad]
     int Dpad;
     int ngroups;             // ntiles / MT
@@ -102,7 +108,13 @@ struct BlockArgs {
     int s_defer[kLookahead];   // IRF sample left to the step itself although it is >= s_cut (-1: none), see plan_step
     const double* tau;
     const double* width;
-    double* partials;     // [nchunks][16][Dpad]
+    // excitation for the 16 predicted times rides in the same launch as extra chunks (nchunks_ex may be 0):
+    // E_j[row] = sum_l Kex[row, l] * eta(tpred[j] - ex_tau[l]) * ex_width[l]
+    Panel Kex;
+    EtaTable ex;
+    int chunk_gp_ex;
+    int nchunks_ex;
+    double* partials;     // [nchunks + nchunks_ex][16][Dpad]
     int Dpad;
     int ngroups;
     int* error_flag;
@@ -112,6 +124,7 @@ struct FinalizeArgs {
     const double* partials;
     int nchunks_rad, nchunks_ex;
     const double* P;         // look-ahead part of this step's radiation sum, [Dpad] (may be null)
+    const double* E;         // excitation force of this step precomputed by the look-ahead pass, [Dpad] (may be null)
     int Dloc, Dpad, N, b0;
     const double* state;
     // hydrostatics
@@ -166,8 +179,9 @@ void launch_relayout_rowmajor(const double* d_src, int rows, int cols, double* d
 // mt = row tiles per workgroup (1, 2 or 4; ngroups*mt == ntiles)
 void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream);
 void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream);
-// P[j][row] = sum_c partials[c][j][row]  (fixed order)
-void launch_reduce_block(const double* d_partials, int nchunks, int Dpad, double* d_P, hipStream_t stream);
+// P[j][row] = sum over the radiation chunks c of partials[c][j][row], E[j][row] = the same over the excitation chunks
+// (fixed order; nchunks_ex may be 0)
+void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_ex, int Dpad, double* d_P, double* d_E, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 void launch_taper(const TaperArgs& a, hipStream_t stream);
 // eta[j] = sum_i amp[i] * cos(-omega[i]*t[j] + phase[i]), then the ramp rule of src/wave_types.cpp:759-769

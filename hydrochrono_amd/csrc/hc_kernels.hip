@@ -201,9 +201,13 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     double* wtab = reinterpret_cast<double*>(tab + a.max_steps_per_chunk);
     __shared__ double red[kConvThreads / kWave][MT][16];
 
+    // block index -> (chunk, row group): the row groups of one chunk stage the same right-hand side, so they get block
+    // indices congruent mod 8 (same XCD under round-robin placement) and close together: [octet of chunks][group][chunk % 8]
     const int nct   = a.nchunks_rad + a.nchunks_ex;
-    const int chunk = blockIdx.x % nct;
-    const int grp   = blockIdx.x / nct;
+    const int r8    = (int)blockIdx.x % (8 * a.ngroups);
+    const int chunk = ((int)blockIdx.x / (8 * a.ngroups)) * 8 + (r8 & 7);
+    const int grp   = r8 >> 3;
+    if (chunk >= nct) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kk = lane >> 4;
 
@@ -351,7 +355,7 @@ static void launch_conv_step_mt(const StepArgs& a, int unroll, int nblocks, size
 }
 
 void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
-    const int nblocks = a.ngroups * (a.nchunks_rad + a.nchunks_ex);
+    const int nblocks = ((a.nchunks_rad + a.nchunks_ex + 7) >> 3) * 8 * a.ngroups;  // octets of chunks (kernel's block mapping)
     if (nblocks <= 0) return;
     static const int unroll = [] {
         const char* e = std::getenv("HC_CONV_UNROLL");  // tuning experiments only

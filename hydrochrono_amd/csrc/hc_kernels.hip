@@ -153,30 +153,41 @@ __device__ __forceinline__ double interp_velocity_lean(const HistoryView& h, con
     return b.wo * vo + b.wn * vn;
 }
 
-__device__ __forceinline__ double eta_at(const EtaTable& a, double t, int j, int* error_flag) {
-    if (j >= a.L) return 0.0;
-    const double q = t - a.ex_tau[j];
-    int idx = (int)floor((q - a.eta_t0) / a.eta_dt);  // eta_t0 = eta_t[0], passed by value: no load before the index is known
-    idx     = max(0, min(idx, a.nt - 2));
-    // the table is close to uniform, so the guessed interval is almost always the right one: request times and values of
-    // the guess together (one round trip) and search only if the guess fails the test the search would end on
-    double t1 = a.eta_t[idx], t2 = a.eta_t[idx + 1], e1 = a.eta[idx], e2 = a.eta[idx + 1];
-    if (!((idx == 0 || t1 <= q) && (idx == a.nt - 2 || t2 > q))) {
-        while (idx > 0 && a.eta_t[idx] > q) --idx;
-        while (idx < a.nt - 2 && a.eta_t[idx + 1] <= q) ++idx;
-        t1 = a.eta_t[idx]; t2 = a.eta_t[idx + 1]; e1 = a.eta[idx]; e2 = a.eta[idx + 1];
-    }
-    double val;
-    if (q == t1) val = e1;
-    else if (q == t2) val = e2;
-    else if (q > t1 && q < t2) {
+// eta(q) by linear interpolation in the free-surface table (src/wave_types.cpp:797-831), in pieces so that a caller can
+// put the loads of several query times in flight together.
+__device__ __forceinline__ int eta_guess(const EtaTable& a, double q) {
+    const int idx = (int)floor((q - a.eta_t0) / a.eta_dt);  // eta_t0 = eta_t[0], passed by value: no load before the index is known
+    return max(0, min(idx, a.nt - 2));
+}
+// does interval idx (times t1, t2) end the reference's search for q?
+__device__ __forceinline__ bool eta_guess_ok(const EtaTable& a, int idx, double q, double t1, double t2) {
+    return (idx == 0 || t1 <= q) && (idx == a.nt - 2 || t2 > q);
+}
+__device__ __forceinline__ double eta_interp(double q, double t1, double t2, double e1, double e2, int* error_flag) {
+    if (q == t1) return e1;
+    if (q == t2) return e2;
+    if (q > t1 && q < t2) {
         const double w1 = (t2 - q) / (t2 - t1);
         const double w2 = 1.0 - w1;
-        val = w1 * e1 + w2 * e2;
-    } else {
-        *error_flag = 2;  // outside the table: the host has already refused the step (src/wave_types.cpp:833-840)
-        val = 0.0;
+        return w1 * e1 + w2 * e2;
     }
+    *error_flag = 2;  // outside the table: the host has already refused the step (src/wave_types.cpp:833-840)
+    return 0.0;
+}
+// the search itself, from a starting index (rarely needed: the table is close to uniform)
+__device__ __forceinline__ double eta_search(const EtaTable& a, int idx, double q, int* error_flag) {
+    while (idx > 0 && a.eta_t[idx] > q) --idx;
+    while (idx < a.nt - 2 && a.eta_t[idx + 1] <= q) ++idx;
+    return eta_interp(q, a.eta_t[idx], a.eta_t[idx + 1], a.eta[idx], a.eta[idx + 1], error_flag);
+}
+
+// e[j] = eta(t - ex_tau[j]) * ex_width[j]: times and values of the guessed interval are requested together (one round trip)
+__device__ __forceinline__ double eta_at(const EtaTable& a, double t, int j, int* error_flag) {
+    if (j >= a.L) return 0.0;
+    const double q   = t - a.ex_tau[j];
+    const int idx    = eta_guess(a, q);
+    const double t1 = a.eta_t[idx], t2 = a.eta_t[idx + 1], e1 = a.eta[idx], e2 = a.eta[idx + 1];
+    const double val = eta_guess_ok(a, idx, q, t1, t2) ? eta_interp(q, t1, t2, e1, e2, error_flag) : eta_search(a, idx, q, error_flag);
     return val * a.ex_width[j];
 }
 
@@ -445,11 +456,36 @@ __device__ __forceinline__ void block_work(const BlockArgs& a, const int chunk, 
                 for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = 1.0;
             } else if (!RAD) {
                 // excitation: U[j][l] = eta(tpred[j] - ex_tau[l]) * ex_width[l]  (0 for l >= L)
-                double uq[kLookahead / 2];
+                // (same arithmetic as eta_at; the table loads of 4 steps go out together -- more would raise the register
+                // count of the whole kernel past two waves per SIMD)
+                constexpr int NB = 4;
+                const bool in   = f < a.ex.L;
+                const int fl    = in ? f : 0;
+                const double tf = a.ex.ex_tau[fl], wf = a.ex.ex_width[fl];
+#pragma unroll 1
+                for (int q0 = 0; q0 < kLookahead / 2; q0 += NB) {
+                    double qv[NB], t1[NB], t2[NB], e1[NB], e2[NB];
+                    int ix[NB];
 #pragma unroll
-                for (int q = 0; q < kLookahead / 2; ++q) uq[q] = eta_at(a.ex, a.tpred[jh + 2 * q], f, a.error_flag);
+                    for (int q = 0; q < NB; ++q) {
+                        qv[q] = a.tpred[jh + 2 * (q0 + q)] - tf;
+                        ix[q] = eta_guess(a.ex, qv[q]);
+                    }
 #pragma unroll
-                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = uq[q];
+                    for (int q = 0; q < NB; ++q) {
+                        t1[q] = a.ex.eta_t[ix[q]];
+                        t2[q] = a.ex.eta_t[ix[q] + 1];
+                        e1[q] = a.ex.eta[ix[q]];
+                        e2[q] = a.ex.eta[ix[q] + 1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        double val = 0.0;
+                        if (in) val = eta_guess_ok(a.ex, ix[q], qv[q], t1[q], t2[q]) ? eta_interp(qv[q], t1[q], t2[q], e1[q], e2[q], a.error_flag)
+                                                                                      : eta_search(a.ex, ix[q], qv[q], a.error_flag);
+                        Us[(jh + 2 * (q0 + q)) * kUStride + sit * 8 + c8] = val * wf;
+                    }
+                }
             } else if (f < c1) {
                 // radiation: U[j][(s,col)] = interp(v_col)(tpred[j] - tau_s) * width_s
                 const int s = f / D, col = f - s * D;

@@ -339,6 +339,63 @@ def test_wave_model_errors(HF):
         gpu.add_waves_regular(1.0, 1e3)  # far outside the BEM frequency list
 
 
+def test_wave_model_changes_inside_a_lookahead_block_and_table_end(HF):
+    """The look-ahead pass also leaves the excitation force of its 16 predicted times.  Those rows must be dropped when the
+    wave model changes in the middle of a block, and must not be produced (nor an error raised early) when a predicted time
+    lies beyond the free-surface table although the steps actually taken stay inside it."""
+    from hydrochrono_amd.hydro import HydroError
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    case = many_body_case(3, S=96, dt_rirf=0.02, n_exc=81, dt_exc=0.05, seed=11)
+    gpu, orc = make_pair(HF, case)
+    motion = PrescribedMotion(3, rest_positions(case), seed=4)
+    dt = 0.02
+    kw1 = dict(simulation_dt=dt, simulation_duration=3.0, wave_height=1.5, wave_period=5.0, nfrequencies=32, seed=1)
+    kw2 = dict(simulation_dt=dt, simulation_duration=3.0, wave_height=0.7, wave_period=3.0, nfrequencies=24, seed=5)
+    for h in (gpu, orc):
+        h.add_waves_irregular(**kw1)
+    gpu.set_lookahead(16)
+    n = 0
+
+    def run(steps):
+        nonlocal n
+        for _ in range(steps):
+            t = n * dt
+            st = motion.state(t)
+            assert_close(gpu.step(t, *st), orc.step(t, *st), TIGHT_TOL, f"step {n}")
+            for g, o in zip(gpu.components(), orc.components()):
+                assert_close(g, o, TIGHT_TOL, f"components, step {n}")
+            n += 1
+
+    run(23)                      # well inside the second look-ahead block
+    for h in (gpu, orc):
+        h.add_waves_irregular(**kw2)
+    run(9)
+    for h in (gpu, orc):
+        h.add_waves_regular(0.4, 1.3)
+    run(7)
+    for h in (gpu, orc):
+        h.add_waves_irregular(**kw1)
+    # walk to the end of the table: the last blocks predict times beyond it; both sides must fail at the same step
+    failed_gpu = failed_orc = None
+    for _ in range(400):
+        t = n * dt
+        st = motion.state(t)
+        try:
+            fo = orc.step(t, *st)
+        except Exception:  # noqa: BLE001  (the oracle wrapper's own error type)
+            failed_orc = n
+        try:
+            fg = gpu.step(t, *st)
+        except HydroError:
+            failed_gpu = n
+        if failed_gpu is not None or failed_orc is not None:
+            break
+        assert_close(fg, fo, TIGHT_TOL, f"step {n} near the table end")
+        n += 1
+    assert failed_gpu is not None and failed_gpu == failed_orc
+
+
 def test_history_pruning_and_ring_growth(HF):
     """Variable step sizes, including many tiny steps that overflow the initial ring capacity."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion

@@ -537,13 +537,25 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         a.hb_n = ok ? n : 0;
         if (nchunks_rad2 > 0) a.hb_defer_valid = host_bracket(c, t - c->tau[c->plan.s_defer[j_block]], H, &a.hb_defer) ? 1 : 0;
     }
-    hc::launch_conv_step(a, c->mt, stream);
+    // Small system inside a look-ahead block: the remainder is a few hundred columns, which finalize_kernel contracts
+    // itself (16 lanes per row) -- the step is then ONE launch.  Needs every bracket from the host and no other chunk work.
+    static const int fin_rem_cols = env_int("HC_FIN_REM_COLS", 512);
+    const bool rem_in_finalize = run_rad && mode == 2 && nchunks_rad2 == 0 && a.nchunks_ex == 0 && F_limit > 0 &&
+                                 F_limit <= fin_rem_cols && a.hb_n * c->D == F_limit;
+    if (!rem_in_finalize) hc::launch_conv_step(a, c->mt, stream);
     if (ev) HC_HIP(hipEventRecord(ev->e[1], stream));
 
     hc::FinalizeArgs z{};
     z.partials    = c->d_partials.p;
-    z.nchunks_rad = a.nchunks_rad;
+    z.nchunks_rad = rem_in_finalize ? 0 : a.nchunks_rad;
     z.nchunks_ex  = a.nchunks_ex;
+    if (rem_in_finalize) {
+        z.rem_F = F_limit;
+        z.remK  = a.K;
+        z.hist  = hv;
+        z.width = c->d_width.p;
+        for (int s_ = 0; s_ < a.hb_n; ++s_) z.hb[s_] = a.hb[s_];
+    }
     z.P           = P_row;
     z.E           = E_row;
     z.Dloc        = c->Dloc;

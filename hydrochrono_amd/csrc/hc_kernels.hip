@@ -678,7 +678,23 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 
     double rad = 0.0, wav = 0.0;
     if (a.do_rad) {
-        rad = lane16_sum(lane_sum(0, a.nchunks_rad));
+        if (a.rem_F > 0) {
+            // small system inside a look-ahead block: the few newest-sample columns are contracted right here (lane `sub`
+            // takes columns sub, sub+16, ...), so the step is this one launch
+            const int Dh = a.hist.D;
+            const double* __restrict__ krow = a.remK.base + ((size_t)(rrow >> 4) * a.remK.ngp) * 128 + (rrow & 15) * 2;
+            double acc = 0.0;
+#pragma unroll 4
+            for (int f = sub; f < a.rem_F; f += 16) {
+                const int s_ = f / Dh, col = f - s_ * Dh;
+                const double u = interp_velocity(a.hist, a.hb[s_], col, state_velocity(a.hist.state, a.hist.N, col)) * a.width[s_];
+                const double k = krow[(size_t)(f >> 3) * 128 + (f & 3) * 32 + ((f & 7) >> 2)];
+                acc = fma(k, u, acc);
+            }
+            rad = lane16_sum(acc);
+        } else {
+            rad = lane16_sum(lane_sum(0, a.nchunks_rad));
+        }
         if (a.P) rad = p_row + rad;
     }
     if (a.do_waves && a.wave_mode == 2) wav = a.E ? e_row : lane16_sum(lane_sum(a.nchunks_rad, a.nchunks_ex));

@@ -154,6 +154,13 @@ struct FinalizeArgs {
     double* waves;
     double* total;
     double* user_out;  // may be null
+    // Tiny remainder of a look-ahead step (small systems): radiation columns [0, rem_F) are contracted here, 16 lanes per
+    // row, instead of in a launch of their own; hb[s] = bracket of IRF sample s (found on the host).  rem_F = 0: off.
+    int rem_F;
+    Panel remK;
+    HistoryView hist;
+    const double* width;
+    Bracket hb[kHostBrackets];
     // history push of this step's sample into ring slot `head` (src/hydro_forces.cpp:559-574)
     int do_push, head, D;
     double* ring_t;

@@ -107,7 +107,7 @@ def main():
     t, z = read_heave(f"{base}/decay/hc_ref_sphere_decay.txt", 1)
     gold["decay_t0"], gold["decay_dt"], gold["decay_z_um"] = t[0], 0.015, z
     assert np.allclose(t, 0.015 * np.arange(1, len(t) + 1), atol=1e-9)
-    for k in (1, 5, 10):
+    for k in range(1, 11):
         t, z = read_heave(f"{base}/reg_waves/hc_ref_sphere_reg_waves_{k}.txt", 5)
         assert np.allclose(t, 0.015 * np.arange(1, len(t) + 1), atol=1e-9), k
         gold[f"reg_waves_{k}_z_um"] = z

@@ -133,7 +133,7 @@ def test_iea_sphere_decay_recorded_motion(HF, lookahead):
     assert res <= 1.0e-2 and res <= 5e-3 * np.max(np.abs(rec["acceleration_z"]))
 
 
-@pytest.mark.parametrize("k", [1, 10])
+@pytest.mark.parametrize("k", list(range(1, 11)))  # every regular-wave golden of the reference suite
 def test_sphere_regular_waves_golden(HF, k):
     from hydrochrono_amd.mock_chrono import run_heave_1dof
     g = goldens()

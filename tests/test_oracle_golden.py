@@ -21,7 +21,7 @@ def test_sphere_decay_golden():
     assert np.max(np.abs(z - ref)) <= 5.1e-7
 
 
-@pytest.mark.parametrize("k", [1, 5, 10])
+@pytest.mark.parametrize("k", list(range(1, 11)))  # every regular-wave golden of the reference suite
 def test_sphere_regular_waves_golden(k):
     g = goldens()
     o = load_into_oracle(sphere_case())

@@ -539,7 +539,7 @@ __device__ __forceinline__ void block_work(const BlockArgs& a, const int chunk, 
 }
 
 template <int MT>
-__global__ void __launch_bounds__(kConvThreads) conv_block_kernel(BlockArgs a) {
+__global__ void __launch_bounds__(kConvThreads, 2) conv_block_kernel(BlockArgs a) {
     // dynamic LDS: per-wave U sub-tiles [4][16][34] (re-used as the cross-wave reduction buffer at the end),
     // bracket table [ns][16], widths [ns]
     extern __shared__ __align__(16) unsigned char smem_raw[];

@@ -160,6 +160,7 @@ struct hc_ctx {
     int chunk_gp_block = 0, nchunks_block = 0, chunk_gp_rem = 64;
     hc::DeviceBuffer<double> d_partials, d_partials_block, d_P, d_E;
     int chunk_gp_ex_block = 32, nchunks_ex_block = 0;  // excitation chunks of the look-ahead launch
+    int mt_block = 4;                                   // row tiles per workgroup of the look-ahead launch (1, 2, 4 or 6)
     int lookahead = 0;  // 0: off, else kLookahead
     hc::Plan plan;
 

@@ -573,7 +573,8 @@ void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
     b.lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // per-wave U sub-tiles, later the [wave][tile][16x16] reduction buffer
     const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) +
                         (size_t)max(1, a.max_steps_per_chunk) * (kLookahead * sizeof(Bracket) + sizeof(double));
-    if (mt == 4) hipLaunchKernelGGL((conv_block_kernel<4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    if (mt == 6) hipLaunchKernelGGL((conv_block_kernel<6>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    else if (mt == 4) hipLaunchKernelGGL((conv_block_kernel<4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
     else if (mt == 2) hipLaunchKernelGGL((conv_block_kernel<2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
     else hipLaunchKernelGGL((conv_block_kernel<1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
 }

@@ -183,7 +183,7 @@ struct TaperArgs {
 void launch_relayout_rirf(const double* d_Kb_6xDxS, double* d_K, int ngp, int D, int S, int row0, double scale, hipStream_t stream);
 // row-major src[rows][cols] -> panel rows row0.. (used for the excitation IRF)
 void launch_relayout_rowmajor(const double* d_src, int rows, int cols, double* d_panel, int ngp, int row0, hipStream_t stream);
-// mt = row tiles per workgroup (1, 2 or 4; ngroups*mt == ntiles)
+// mt = row tiles per workgroup (1, 2 or 4 -- the look-ahead launch also 6; ngroups*mt == ntiles)
 void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream);
 void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream);
 // P[j][row] = sum over the radiation chunks c of partials[c][j][row], E[j][row] = the same over the excitation chunks

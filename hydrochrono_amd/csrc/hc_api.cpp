@@ -725,7 +725,7 @@ int hc_create(int num_bodies, int device_id, hc_ctx** out) { return hc_create_sh
 void hc_destroy(hc_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();  // steps may still be running on a caller's stream; the buffers go away below
     for (auto& es : ctx->events)
         for (auto& e : es.e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -965,6 +965,7 @@ int hc_set_gravity(hc_ctx* c, const double g[3]) {
 int hc_set_wave_none(hc_ctx* c, int num_bodies_arg) {
     HC_API_BEGIN(c)
     c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
+    HC_HIP(hipDeviceSynchronize());  // the tables replaced below may be in use by steps on a caller's stream
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(num_bodies_arg >= 0, HC_ERR_INVALID, "negative body count");
     c->wave_kind   = hc::kWaveNone;
@@ -976,6 +977,7 @@ int hc_set_wave_none(hc_ctx* c, int num_bodies_arg) {
 int hc_set_wave_regular(hc_ctx* c, int num_bodies_arg, double amplitude, double omega) {
     HC_API_BEGIN(c)
     c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
+    HC_HIP(hipDeviceSynchronize());  // the tables replaced below may be in use by steps on a caller's stream
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(num_bodies_arg >= 1 && num_bodies_arg <= c->N, HC_ERR_OUT_OF_RANGE, "regular wave created for more bodies than the hydro data holds");
     for (int b = 0; b < num_bodies_arg; ++b) require(c->bodies[b].have_rao, HC_ERR_INVALID, "excitation RAO missing for a body");
@@ -1031,6 +1033,7 @@ void hc_irregular_wave_params_default(hc_irregular_wave_params* p) {
 int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     HC_API_BEGIN(c)
     c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
+    HC_HIP(hipDeviceSynchronize());  // the tables replaced below may be in use by steps on a caller's stream
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(pp, HC_ERR_INVALID, "null parameters");
     const hc_irregular_wave_params p = *pp;
@@ -1138,6 +1141,7 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
 int hc_set_wave_irregular_spectral(hc_ctx* c, const hc_irregular_wave_params* pp) {
     HC_API_BEGIN(c)
     c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
+    HC_HIP(hipDeviceSynchronize());  // the tables replaced below may be in use by steps on a caller's stream
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(pp, HC_ERR_INVALID, "null parameters");
     const hc_irregular_wave_params p = *pp;
@@ -1337,7 +1341,7 @@ int hc_set_lookahead(hc_ctx* c, int steps) {
 int hc_reset_history(hc_ctx* c) {
     HC_API_BEGIN(c)
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
-    HC_HIP(hipStreamSynchronize(c->stream));
+    HC_HIP(hipDeviceSynchronize());  // steps may still be running on a caller's stream (hc_step_device)
     c->times.clear();
     c->head = -1;
     c->have_prev = false;
@@ -1351,7 +1355,7 @@ int hc_set_history(hc_ctx* c, int n, const double* times, const double* vel) {
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(n >= 0 && (n == 0 || (times && vel)), HC_ERR_INVALID, "bad history arguments");
     for (int k = 1; k < n; ++k) require(times[k] < times[k - 1], HC_ERR_INVALID, "history times must be strictly decreasing (newest first)");
-    HC_HIP(hipStreamSynchronize(c->stream));
+    HC_HIP(hipDeviceSynchronize());  // steps may still be running on a caller's stream (hc_step_device)
     if (n > c->Hcap) ring_alloc(c, n + 16);
     c->times.assign(times, times + n);
     // sample k -> slot n-1-k, head = n-1

@@ -194,9 +194,21 @@ void choose_conv_config(hc_ctx* c) {
     gps                  = std::min<long long>(gps, 512);                 // the chunk's right-hand side is staged in LDS (<= 32 KB)
     c->chunk_gp          = static_cast<int>(gps);
     c->nchunks_rad       = static_cast<int>((c->ngp + gps - 1) / gps);
-    // look-ahead pass: fewer, longer chunks (its partials are 16x larger); bracket table [samples][16] must fit in LDS
-    long long bgps = std::max(8, env_int("HC_BLOCK_CHUNK_GP", 192));
-    bgps           = std::max<long long>(bgps, (c->ngp + 255) / 256);  // at most 256 chunks: partials stay ~1 % of K
+    // Look-ahead pass.  Its workgroups live long (tens of microseconds) and two fit on a CU, so the launch runs in "rounds" of
+    // 2 * CUs workgroups and is fastest when row groups x chunks fills whole rounds: C3 has 4 row groups (6 tiles each), so
+    // CUs / 2 = 128 chunks make exactly one round (207 us per pass against 221 us at three rounds and 249 us at one and a
+    // half).  The chunk length depends on the column count only -- never on how many rows this context owns -- so that
+    // row-sharded contexts add their partial sums in the same order as the unsharded one (bitwise equal results).
+    long long bgps;
+    const int forced = env_int("HC_BLOCK_CHUNK_GP", 0);
+    if (forced > 0) {
+        bgps = std::max(8, forced);
+        bgps = std::max<long long>(bgps, (c->ngp + 255) / 256);
+    } else {
+        const long long nch_target = std::max(1, c->num_cus / 2);
+        bgps                       = (c->ngp + nch_target - 1) / nch_target;
+        bgps                       = std::min<long long>(bgps, std::max<long long>(16, (16LL * c->D) / 8));  // <= 16 IRF samples per chunk
+    }
     const long long cap = std::max<long long>(8, (64LL * c->D) / 8);   // bracket table [samples][16] must fit in LDS
     bgps                = std::min(bgps, cap);
     bgps                = std::max<long long>(16, ((bgps + 15) / 16) * 16);  // whole 16-group sub-tiles
@@ -704,7 +716,8 @@ int hc_create_sharded(int num_bodies, int body_begin, int body_end, int device_i
         c->nloc   = body_end - body_begin;
         c->D      = 6 * num_bodies;
         c->Dloc   = 6 * c->nloc;
-        c->device = device_id;
+        c->device  = device_id;
+        c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         c->bodies.resize(num_bodies);
         HC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         hc_tapered_direct_options_default(&c->taper);

@@ -161,6 +161,7 @@ struct hc_ctx {
     hc::DeviceBuffer<double> d_partials, d_partials_block, d_P, d_E;
     int chunk_gp_ex_block = 32, nchunks_ex_block = 0;  // excitation chunks of the look-ahead launch
     int mt_block = 4;                                   // row tiles per workgroup of the look-ahead launch (1, 2, 4 or 6)
+    int num_cus  = 256;                                 // compute units of the device (grid rounds of the look-ahead launch)
     int lookahead = 0;  // 0: off, else kLookahead
     hc::Plan plan;
 

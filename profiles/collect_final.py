@@ -58,7 +58,8 @@ pmc = {"fetch": counter_means("fetch", "FETCH_SIZE"), "write": counter_means("wr
        "units": "KB as reported by rocprofv3 (raw); gfx950 correction for wide streaming reads: FETCH_SIZE x2"}
 json.dump(pmc, open(os.path.join(DST, "final_pmc.json"), "w"), indent=1)
 
-blk, stp = "void hc::conv_block_kernel<4>", "void hc::conv_step_kernel<4, 2, true>"
+stp = "void hc::conv_step_kernel<4, 2, true>"
+blk = next(k for k in pmc["fetch"] if k.startswith("void hc::conv_block_kernel<"))  # <6> at C3 (6 row tiles per workgroup)
 bench = json.loads(open(os.path.join(SRC, "bench_c3.json")).read())
 plain = json.loads(open(os.path.join(SRC, "bench_c3_plain.json")).read())
 traffic = {
@@ -69,7 +70,7 @@ traffic = {
     "WRITE_SIZE_KB": pmc["write_plain"][stp]["mean_KB"],
     "hbm_bytes_per_launch": 1024.0 * (2 * pmc["fetch_plain"][stp]["mean_KB"] + pmc["write_plain"][stp]["mean_KB"]),
     "algorithmic_bytes_per_launch": plain["roofline"]["algorithmic_bytes_per_launch"],
-    "block_kernel": "hc::conv_block_kernel<4> (look-ahead pass, one launch per 16 steps)",
+    "block_kernel": blk.replace("void ", "") + " (look-ahead pass, one launch per 16 steps)",
     "block_FETCH_SIZE_KB_raw": pmc["fetch"][blk]["mean_KB"],
     "block_WRITE_SIZE_KB": pmc["write"][blk]["mean_KB"],
     "block_hbm_bytes_per_launch": 1024.0 * (2 * pmc["fetch"][blk]["mean_KB"] + pmc["write"][blk]["mean_KB"]),

@@ -205,7 +205,9 @@ void choose_conv_config(hc_ctx* c) {
         bgps = std::max(8, forced);
         bgps = std::max<long long>(bgps, (c->ngp + 255) / 256);
     } else {
-        const long long nch_target = std::max(1, c->num_cus / 2);
+        // row groups of the UNSHARDED system (6 tiles each): few of them (small systems) need more chunks to fill a round
+        const long long groups_full = std::max<long long>(1, ((c->D + 15) / 16 + 5) / 6);
+        const long long nch_target  = std::max<long long>(c->num_cus / 2, (2LL * c->num_cus + groups_full - 1) / groups_full);
         bgps                       = (c->ngp + nch_target - 1) / nch_target;
         bgps                       = std::min<long long>(bgps, std::max<long long>(16, (16LL * c->D) / 8));  // <= 16 IRF samples per chunk
     }

@@ -559,7 +559,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     }
     // Small system inside a look-ahead block: the remainder is a few hundred columns, which finalize_kernel contracts
     // itself (16 lanes per row) -- the step is then ONE launch.  Needs every bracket from the host and no other chunk work.
-    static const int fin_rem_cols = env_int("HC_FIN_REM_COLS", 512);
+    static const int fin_rem_cols = env_int("HC_FIN_REM_COLS", 256);  // <= 16 columns per lane; beyond that the chunked launch wins (measured N = 2..12)
     const bool rem_in_finalize = run_rad && mode == 2 && nchunks_rad2 == 0 && a.nchunks_ex == 0 && F_limit > 0 &&
                                  F_limit <= fin_rem_cols && a.hb_n * c->D == F_limit;
     if (!rem_in_finalize) hc::launch_conv_step(a, c->mt, stream);

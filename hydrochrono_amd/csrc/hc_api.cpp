@@ -186,8 +186,9 @@ hc::Panel rad_panel(const hc_ctx* c) {
 }
 
 void choose_conv_config(hc_ctx* c) {
-    // plain per-step kernel: aim for >= 16 workgroups per CU (256 CUs); a chunk is a whole number of 8-column groups
-    const int target_wgs = std::max(1, env_int("HC_CONV_TARGET_WGS", 4096));
+    // plain per-step kernel: 8 workgroups per CU (one resident set; 184.6 us against 187.2 us with twice as many, and
+    // finalize_kernel has half as many partials to add); a chunk is a whole number of 8-column groups
+    const int target_wgs = std::max(1, env_int("HC_CONV_TARGET_WGS", 8 * c->num_cus));
     long long nch        = std::max<long long>(1, target_wgs / std::max(1, c->ngroups));
     long long gps        = (c->ngp + nch - 1) / nch;
     gps                  = std::max<long long>(16, ((gps + 3) / 4) * 4);  // every wave of the workgroup gets work

@@ -1,28 +1,34 @@
 #!/usr/bin/env python3
-"""Headline benchmark of the hydro-force path: all-body force evaluations per second.
+"""Headline benchmark of the hydro-force path: all-body force evaluations per second (SURVEY.md 8d).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[2], "C3"): synthetic 64-body array, 1024 radiation-IRF samples, irregular JONSWAP
-sea state with 512 wave components, prescribed body motion with dt = dt_rirf = 0.01 s, steady state (velocity history
-pre-filled over the whole 10.23 s IRF window).  A "step" = one evaluation of all 6N hydrodynamic forces
-(hydrostatic - radiation + waves) through hc_step_device, body states already resident in HBM.
+N = 1 (default) -- configuration C3 (BASELINE.json configs[2]): synthetic 64-body array, 1024 radiation-IRF samples,
+irregular JONSWAP sea state with 512 wave components, prescribed body motion with dt = dt_rirf = 0.01 s, steady state
+(velocity history pre-filled over the whole 10.23 s IRF window).  A "step" = one SYNCHRONOUS hc_step: host pointers to
+the body state in, all 6N hydrodynamic forces (hydrostatic - radiation + waves) out on the host -- what one Chrono
+update costs through ComponentFunc::GetVal (src/hydro_forces.cpp:79-85,727-767): the next state depends on these forces,
+so nothing is pipelined across steps.  value = K / wall time of K consecutive calls (the look-ahead passes included);
+the median call is reported next to it.  Secondary figures in the same line: `device_pipelined` (hc_step_device with
+states resident in HBM, enqueued ahead -- an upper bound no Chrono loop can use) and `plain_per_step_mode`
+(look-ahead off: K streamed from HBM every step).
 
-Multi-GPU, default (weak scaling): every rank owns one independent 64-body farm (independent simulations, e.g. the
-iterations of a design exploration); the farms share nothing, so there is no data-path collective -- only the
-barriers around the timed region.  value = farms * K / max-over-ranks time.
-
---scaling strong --bodies 512 is configuration C4: ONE coupled 512-body array (K = 77.3 GB FP64, generated in HBM by
-hc_synth_fill) row-sharded over the ranks (hydrochrono_amd.parallel.body_shard), forces all-gathered every step;
-value = K / time.  It also runs on one GPU (77 GB fits in 288 GB).
+N > 1 (default: --scaling strong --bodies 512) -- configuration C4: ONE coupled 512-body array (K = 77.3 GB FP64,
+generated in HBM by hc_synth_fill) row-sharded over the ranks (hydrochrono_amd.parallel.body_shard), each rank's force
+rows all-gathered over RCCL every step and the stream synchronised (every rank holds the full 6N vector before the next
+step starts); value = K / max-over-ranks time.  `--scaling weak` runs independent 64-body farms instead (replicas, no
+data-path collective).  `--scaling strong` also runs on one GPU (77 GB fits in 288 GB).
 
 The JSON line also carries
-  roofline      HBM roofline of the convolution kernel: algorithmic bytes per launch / mean HIP-event duration
+  roofline      HBM roofline of the dominant kernel (the look-ahead pass): bytes the launch has to move ONCE / mean
+                HIP-event duration / 8 TB/s -- a fraction; the reuse over 16 steps is reported separately
   cpu_baseline  the CPU oracle (reference-faithful OpenMP restatement, oracle/) timed on this box's host cores on a
-                bounded sample of the same workload (rank 0, N=1 only); it is also used to check the GPU forces.
+                bounded sample of the same workload (rank 0, N=1 only)
+  parity        every timed step compared with the CPU oracle (flat-array variant; the faithful one on its sample)
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -36,37 +42,41 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+FP64_MFMA_PEAK_TF = 78.6
 
 WAVES = dict(simulation_dt=0.01, simulation_duration=60.0, ramp_duration=0.0, wave_height=2.0, wave_period=8.0,
              frequency_min=0.02, frequency_max=0.5, nfrequencies=512, peak_enhancement_factor=3.3, seed=1)
-N_BODIES, S_RIRF, N_EXC, DT = 64, 1024, 1024, 0.01
+N_BODIES, N_BODIES_C4, S_RIRF, N_EXC, DT = 64, 512, 1024, 1024, 0.01
 T0 = 20.0  # start of the timed window (history covers [T0 - 10.29, T0))
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)  # 2000 steps = 125 look-ahead blocks, about 50 ms of GPU time
+    ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--bodies", type=int, default=N_BODIES, help="bodies per GPU (default: the C3 configuration)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--bodies", type=int, default=None, help="default: 64 (C3) for independent farms, 512 (C4) for --scaling strong")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong (one coupled array sharded over the ranks) when N > 1, else the single-GPU C3 case")
     ap.add_argument("--profile-stride", type=int, default=17, help="HIP-event sampling stride for the per-step launches (co-prime "
                     "with the 16-step look-ahead period); every look-ahead pass, the roofline kernel, is timed regardless")
     ap.add_argument("--lookahead", type=int, default=16, help="0: plain per-step evaluation (K streamed every step)")
     ap.add_argument("--step-dt", type=float, default=DT, help="caller's step size (default = the IRF grid spacing, the common "
                     "case; e.g. 0.007 makes every IRF sample a true interpolation, SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the device_pipelined / plain_per_step_mode measurements")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline time budget")
     return ap.parse_args()
 
 
-def cpu_baseline(case, motion, t_hist, v_hist, budget_s, step_dt=DT, duration=60.0):
+def cpu_baseline(case, motion, t_hist, v_hist, budget_s, step_dt, duration):
     """Times the CPU oracle on this box's host cores on a bounded sample of the same workload.
 
     Two variants: the reference-faithful restatement (OpenMP over IRF steps, per-element
     accessor, nested-vector history -- `value`, thread count chosen by a short sweep because the reference's
     `schedule(static)` over 1024 steps does not scale to every core count) and an optimised flat-array CPU variant
-    (`optimized_port`) so that the GPU speed-up is not flattered by reference overheads.  Returns (dict, forces at T0)."""
+    (`optimized_port`) so that the GPU speed-up is not flattered by reference overheads.
+    Returns (dict, [forces of the first steps from T0 on, faithful oracle])."""
     import oracle as orc_mod
     from cases import load_into_oracle
     cores = os.cpu_count() or 1
@@ -74,37 +84,35 @@ def cpu_baseline(case, motion, t_hist, v_hist, budget_s, step_dt=DT, duration=60
     orc.add_waves_irregular(**dict(WAVES, simulation_dt=step_dt, simulation_duration=duration))
     orc.prefill_history(t_hist, v_hist)
     k = [0]
+    forces = []
 
-    def timed(fn, nsteps):
-        d, f0 = [], None
+    def timed(fn, nsteps, keep):
+        d = []
         for _ in range(nsteps):
             t = T0 + k[0] * step_dt
             st = motion.state(t)
             a = time.perf_counter()
             f = fn(t, *st)
             d.append(time.perf_counter() - a)
-            f0 = f if f0 is None else f0
+            if keep:
+                forces.append(f)
             k[0] += 1
-        return d, f0
+        return d
 
     t_begin = time.perf_counter()
-    sweep, first = {}, None
+    sweep = {}
     for th in sorted({cores, max(1, cores // 2), min(cores, 64), min(cores, 16)}, reverse=True):
         orc_mod.set_num_threads(th)
-        d, f0 = timed(orc.step, 3)
-        first = f0 if first is None else first
-        sweep[th] = float(np.median(d))
+        sweep[th] = float(np.median(timed(orc.step, 3, True)))
     best = min(sweep, key=sweep.get)
     orc_mod.set_num_threads(best)
     n_more = int(max(3, min(40, (0.5 * budget_s - (time.perf_counter() - t_begin)) / sweep[best])))
-    d, _ = timed(orc.step, n_more)
-    med = float(np.median(d))
+    med = float(np.median(timed(orc.step, n_more, True)))
     flat_sweep = {}
     for th in sorted({cores, min(cores, 64), min(cores, 16)}, reverse=True):
         orc_mod.set_num_threads(th)
         orc.flat_prepare()  # re-laid out (first touch) with this thread count
-        d_flat, _ = timed(orc.flat_step, 8)
-        flat_sweep[th] = float(np.median(d_flat[2:]))
+        flat_sweep[th] = float(np.median(timed(orc.flat_step, 8, False)[2:]))
     best_flat = min(flat_sweep, key=flat_sweep.get)
     med_flat = flat_sweep[best_flat]
     info = {"value": 1.0 / med, "unit": "evals/s", "cores": best, "kind": "port", "ms_per_step": med * 1e3,
@@ -114,7 +122,30 @@ def cpu_baseline(case, motion, t_hist, v_hist, budget_s, step_dt=DT, duration=60
             "optimized_port": {"value": 1.0 / med_flat, "unit": "evals/s", "cores": best_flat, "ms_per_step": med_flat * 1e3,
                                "threads_sweep_ms": {str(th): v * 1e3 for th, v in flat_sweep.items()},
                                "sample": "6 steps per thread count (median), flat-array OpenMP-over-rows CPU variant of the same math"}}
-    return info, first
+    return info, forces, best_flat
+
+
+def oracle_all_steps(case, motion, t_hist, v_hist, step_dt, duration, nsteps, threads):
+    """Forces of steps T0 + k*dt, k < nsteps, from the flat-array variant of the CPU oracle (checked against the faithful
+    restatement in tests/test_oracle_flat.py and, below, on the faithful oracle's own sample)."""
+    import oracle as orc_mod
+    from cases import load_into_oracle
+    orc_mod.set_num_threads(threads)
+    orc = load_into_oracle(case)
+    orc.add_waves_irregular(**dict(WAVES, simulation_dt=step_dt, simulation_duration=duration))
+    orc.prefill_history(t_hist, v_hist)
+    orc.flat_prepare()
+    out = np.empty((nsteps, 6 * case["N"]))
+    for k in range(nsteps):
+        t = T0 + k * step_dt
+        out[k] = orc.flat_step(t, *motion.state(t))
+    return out
+
+
+def max_rel_err(a, b):
+    """Largest per-step error, each relative to the largest force component of that step (the tests' vector-relative norm)."""
+    a, b = np.atleast_2d(a), np.atleast_2d(b)
+    return float(np.max(np.max(np.abs(a - b), axis=1) / np.maximum(np.max(np.abs(b), axis=1), 1e-300)))
 
 
 def main():
@@ -126,9 +157,15 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
+    strong = args.scaling == "strong"
+    if args.bodies is None:
+        args.bodies = N_BODIES_C4 if strong else N_BODIES
 
     import torch
     import torch.distributed as dist
+    from hydrochrono_amd import capi
     from hydrochrono_amd.hydro import HydroForces
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     from hydrochrono_amd.synthetic import many_body_case, rest_positions
@@ -149,9 +186,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from hydrochrono_amd.parallel import ForceExchange, body_shard
-    strong = args.scaling == "strong"
     N = args.bodies
-    D = 6 * N
     case = None
     if strong:
         # one coupled N-body array, this rank owns the output rows of bodies [b0, b1); inputs generated in HBM
@@ -160,60 +195,85 @@ def main():
         gpu.synth_fill(20251031, S_RIRF, DT, N_EXC, DT)
         gpu.finalize()
         motion = PrescribedMotion(N, np.zeros((N, 3)), seed=20251031)
-        exchange = ForceExchange(N, world, rank, device="cuda")
+        exchange = ForceExchange(N, world, rank, device="cpu" if share_gpu else "cuda") if world > 1 else None
     else:
         case = many_body_case(N, S=S_RIRF, dt_rirf=DT, n_exc=N_EXC, dt_exc=DT, seed=20251031 + rank)
         gpu = HydroForces.from_case(case, device=local_rank)
         motion = PrescribedMotion(N, rest_positions(case), seed=20251031 + rank)
         exchange = None  # independent farms: nothing to exchange
+    sdt = args.step_dt
+    n_pipe = 0 if (args.no_secondary or world > 1) else args.steps
+    n_plain = 0 if (args.no_secondary or world > 1 or args.lookahead == 0) else max(20, args.steps // 8)
+    total = args.warmup + args.steps
+    n_all = total + n_pipe + n_plain + 16
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
-    # (timed + warm-up + the plain-mode secondary measurement), so long runs extend the 60 s of the C3 definition
-    n_all = args.warmup + args.steps + max(20, args.steps // 4) + 8
-    duration = max(WAVES["simulation_duration"], T0 + n_all * args.step_dt + 5.0)
-    waves = dict(WAVES, num_bodies=N, simulation_dt=args.step_dt, simulation_duration=duration)
-    gpu.add_waves_irregular(**waves)
+    duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
+    gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
     gpu.set_lookahead(args.lookahead)
     D_local = gpu.D_local
 
-    sdt = args.step_dt
     nhist = int(np.ceil(S_RIRF * DT / sdt)) + 5
     t_hist = T0 - sdt * np.arange(1, nhist + 1)
     v_hist = np.stack([motion.velocity6(t) for t in t_hist])
     gpu.set_history(t_hist, v_hist)
 
-    total = args.warmup + args.steps
-    states = torch.tensor(np.stack([motion.packed(T0 + k * sdt) for k in range(total)]), device="cuda")
-    forces = torch.zeros(total, D_local, dtype=torch.float64, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    times = [T0 + k * sdt for k in range(n_all)]
+    states = np.ascontiguousarray(np.stack([motion.packed(t) for t in times]))  # [n_all][12N] = pos | rpy | linvel | angvel
+    forces = np.zeros((n_all, D_local))
+    n3 = 3 * N
+    # raw entry point: integer addresses straight through (the timed loop is the C-ABI call and nothing else)
+    hc_step = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(
+        ("hc_step", capi.load()))
+    ctx = gpu.ctx
+    sp = [states.ctypes.data + k * states.strides[0] for k in range(n_all)]
+    fp = [forces.ctypes.data + k * forces.strides[0] for k in range(n_all)]
+    per_step = np.zeros(n_all)
 
-    # device addresses of each step's state / force row, so that the timed loop is the C-ABI call and nothing else
-    state_ptrs = [states.data_ptr() + k * states.stride(0) * 8 for k in range(total)]
-    force_ptrs = [forces.data_ptr() + k * forces.stride(0) * 8 for k in range(total)]
-    times = [T0 + k * sdt for k in range(total)]
-    step_device = gpu.step_device
+    stream = torch.cuda.current_stream()
+    if exchange is not None:
+        d_states = torch.tensor(states[:total], device="cuda")
+        state_ptrs = [d_states.data_ptr() + k * d_states.stride(0) * 8 for k in range(total)]
+        d_send = exchange.send if not share_gpu else torch.zeros(exchange.max_rows, dtype=torch.float64, device="cuda")
+        gathered = torch.zeros(total, 6 * N, dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+        torch.cuda.synchronize()
 
-    def run(k0, k1):
-        if exchange is not None and world > 1:
-            # coupled array: kernels write straight into the exchange's send buffer; the RCCL all-gather leaves the
-            # full 6N force vector on every rank (the one exchange step of the path)
-            send_ptr = exchange.send.data_ptr()
+    def run_sync(k0, k1):
+        """K synchronous evaluations: state from host memory in, forces in host memory out, one call after the other."""
+        if exchange is None:
+            pc = time.perf_counter
             for k in range(k0, k1):
-                step_device(times[k], state_ptrs[k], send_ptr, stream)
-                exchange.gather()
+                a = pc()
+                rc = hc_step(ctx, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
+                per_step[k] = pc() - a
+                if rc:
+                    gpu._chk(rc)
         else:
+            # coupled array over several ranks: kernels write this rank's rows into the exchange's send buffer, the RCCL
+            # all-gather leaves the full 6N force vector on every rank (the one exchange step of the path, SURVEY.md 8e),
+            # and the stream is synchronised: the next step starts only when every rank holds all forces of this one
+            pc = time.perf_counter
             for k in range(k0, k1):
-                step_device(times[k], state_ptrs[k], force_ptrs[k], stream)
+                a = pc()
+                gpu.step_device(times[k], state_ptrs[k], d_send.data_ptr(), stream.cuda_stream)
+                if share_gpu:
+                    stream.synchronize()
+                    full = exchange.gather(d_send[: exchange.rows].cpu())
+                    gathered[k].copy_(full)
+                else:
+                    full = exchange.gather()
+                    gathered[k].copy_(full, non_blocking=True)
+                    stream.synchronize()
+                per_step[k] = pc() - a
 
-    run(0, args.warmup)
+    run_sync(0, args.warmup)
     torch.cuda.synchronize()
-    gpu.enable_profiling(args.profile_stride)  # HIP events around the conv kernel of every n-th timed step
+    gpu.enable_profiling(args.profile_stride)
     gpu.reset_profile()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    run(args.warmup, total)
-    enqueue_s = time.perf_counter() - t_start  # host time to enqueue every step (the GPU runs behind it)
+    run_sync(args.warmup, total)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -225,54 +285,72 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # Secondary figure (not `value`): the same workload with look-ahead off, i.e. K streamed from HBM every step -- the
-    # conventional form of the path, whose kernel is the one the per-step HBM roofline applies to.
-    plain = None
-    if args.lookahead > 0 and world == 1:
-        n_plain = max(20, args.steps // 4)
-        gpu.set_lookahead(0)
-        extra_states = torch.tensor(np.stack([motion.packed(T0 + (total + k) * sdt) for k in range(n_plain + 4)]), device="cuda")
-        extra_out = torch.zeros(n_plain + 4, D_local, dtype=torch.float64, device="cuda")
-        for k in range(4):
-            gpu.step_device(T0 + (total + k) * sdt, extra_states[k].data_ptr(), extra_out[k].data_ptr(), stream)
+    # ---- secondary figures (not `value`) ----
+    pipelined = plain = None
+    k_next = total
+    if n_pipe > 0:
+        # hc_step_device, states resident in HBM, every step enqueued without waiting for the previous one's forces
+        d_states = torch.tensor(states[k_next:k_next + n_pipe], device="cuda")
+        d_out = torch.zeros(n_pipe, D_local, dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
+        s_ptr, o_ptr, sb, ob = d_states.data_ptr(), d_out.data_ptr(), d_states.stride(0) * 8, d_out.stride(0) * 8
+        tp = time.perf_counter()
+        for k in range(n_pipe):
+            gpu.step_device(times[k_next + k], s_ptr + k * sb, o_ptr + k * ob, stream.cuda_stream)
+        torch.cuda.synchronize()
+        tp = time.perf_counter() - tp
+        forces[k_next:k_next + n_pipe] = d_out.cpu().numpy()
+        pipelined = {"evals_per_s": n_pipe / tp, "ms_per_step": tp / n_pipe * 1e3, "steps": n_pipe,
+                     "note": "hc_step_device enqueued ahead of the GPU, states and forces resident in HBM; not usable by a Chrono "
+                             "loop (its next state needs these forces on the host)"}
+        k_next += n_pipe
+    if n_plain > 0:
+        gpu.set_lookahead(0)
+        for k in range(k_next, k_next + 4):
+            hc_step(ctx, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
         gpu.enable_profiling(args.profile_stride)
         gpu.reset_profile()
         tp = time.perf_counter()
-        for k in range(4, n_plain + 4):
-            gpu.step_device(T0 + (total + k) * sdt, extra_states[k].data_ptr(), extra_out[k].data_ptr(), stream)
-        torch.cuda.synchronize()
+        for k in range(k_next + 4, k_next + 4 + n_plain):
+            hc_step(ctx, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
         tp = time.perf_counter() - tp
         pp = gpu.profile()
         gpu.enable_profiling(False)
         kus = 1e6 * pp["conv_kernel_seconds"] / max(1, pp["conv_kernel_launches"])
         plain = {"evals_per_s": n_plain / tp, "ms_per_step": tp / n_plain * 1e3, "steps": n_plain, "kernel": "hc::conv_step_kernel",
-                 "mean_kernel_us": kus, "achieved_GBps": pp["conv_kernel_bytes"] / (kus * 1e-6) / 1e9 if kus > 0 else 0.0,
-                 "frac_of_hbm_peak": (pp["conv_kernel_bytes"] / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS) if kus > 0 else 0.0}
+                 "mean_kernel_us": kus, "algorithmic_bytes_per_launch": pp["conv_kernel_bytes"],
+                 "achieved_GBps": pp["conv_kernel_bytes"] / (kus * 1e-6) / 1e9 if kus > 0 else 0.0,
+                 "frac_of_hbm_peak": (pp["conv_kernel_bytes"] / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS) if kus > 0 else 0.0,
+                 "note": "synchronous hc_step with look-ahead off: one launch streams all of K per step"}
+        k_next += 4 + n_plain
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        timed = per_step[args.warmup:total] * 1e3
         # dominant kernel: the look-ahead pass when blocking is on (one launch covers 16 steps), else the per-step kernel
         if prof["block_kernel_launches"] > 0:
-            kname, steps_per_launch = "hc::conv_block_kernel", 16
+            kname, units = "hc::conv_block_kernel", 16
             conv_s = prof["block_kernel_seconds"] / prof["block_kernel_launches"]
-            alg_bytes = prof["block_kernel_bytes"]
+            bytes_once = prof["block_kernel_bytes_once"]
+            bytes_units = prof["block_kernel_bytes"]
             n_timed = prof["block_kernel_launches"]
         else:
-            kname, steps_per_launch = "hc::conv_step_kernel", 1
+            kname, units = "hc::conv_step_kernel", 1
             conv_s = prof["conv_kernel_seconds"] / max(1, prof["conv_kernel_launches"])
-            alg_bytes = prof["conv_kernel_bytes"]
+            bytes_once = bytes_units = prof["conv_kernel_bytes"]
             n_timed = prof["conv_kernel_launches"]
-        achieved = alg_bytes / conv_s / 1e9 if conv_s > 0 else 0.0
-        rem_us = 1e6 * prof["rem_kernel_seconds"] / max(1, prof["rem_kernel_launches"])
-        traffic = None
+        achieved = bytes_once / conv_s / 1e9 if conv_s > 0 else 0.0
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")
-        if os.path.exists(tpath) and N == N_BODIES:
+        if os.path.exists(tpath) and N == N_BODIES and not strong:
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("block_hbm_bytes_per_launch" if steps_per_launch == 16 else "hbm_bytes_per_launch")
+                traffic = tj.get("block_hbm_bytes_per_launch" if units == 16 else "hbm_bytes_per_launch")
+                traffic_src = "profiles/conv_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                              "gfx950 x2 read correction; not collected in this run)"
             except Exception:
                 traffic = None
+        us = lambda sec, n: 1e6 * sec / max(1, n)  # noqa: E731
         out = {
             "metric": "hydro-force evals/sec (all bodies)",
             "value": (1 if strong else world) * args.steps / elapsed,
@@ -281,9 +359,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
-            # wall time of the enqueue loop; in long runs the host runs ahead until the launch queue is full and then waits
-            # on the GPU, so this approaches ms_per_step -- the host's own cost per step is about 0.007 ms (short runs)
-            "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
+            "median_ms_per_step": float(np.median(timed)),
+            "p10_ms_per_step": float(np.percentile(timed, 10)),
+            "p90_ms_per_step": float(np.percentile(timed, 90)),
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -294,39 +372,55 @@ def main():
                              f"C3: synthetic {N}-body array per GPU, ") +
                             f"{S_RIRF} radiation-IRF samples, irregular JONSWAP "
                             f"waves with {WAVES['nfrequencies']} components (excitation-IRF convolution, L={gpu.sizes()['L']}), "
-                            f"prescribed motion, step dt = {sdt} s, dt_rirf = {DT} s, steady-state history",
+                            f"prescribed motion, step dt = {sdt} s, dt_rirf = {DT} s, steady-state history; "
+                            "synchronous steps (forces of step n are on the host before step n+1 is issued)",
                 "bodies": N, "bodies_per_gpu": (N / world if strong else N), "irf_samples": S_RIRF,
-                "wave_components": WAVES["nfrequencies"],
-                "sharding": ("body-row shards of one coupled array + RCCL all-gather of forces" if strong else
+                "wave_components": WAVES["nfrequencies"], "lookahead": args.lookahead,
+                "sharding": ("body-row shards of one coupled array + RCCL all-gather of forces every step" if strong else
                              "one independent farm per GPU, no data-path collective") if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes, "steps_per_launch": steps_per_launch,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": bytes_once, "units_per_launch": units,
+                "reuse_factor": bytes_units / bytes_once if bytes_once else None,
+                "algorithmic_bytes_of_the_units": bytes_units,
                 "mean_kernel_us": conv_s * 1e6, "launches_timed": n_timed,
-                "in_block_step_kernel_us": rem_us,
-                # what the launch really moves / computes: PMC-measured HBM bytes over the live duration, and the FP64 MFMA
-                # rate of the [D x F] x [F x 16] product against the 78.6 TFLOP/s dense FP64 peak
-                "traffic_GBps": (traffic / conv_s / 1e9) if (traffic and conv_s > 0) else None,
-                "traffic_frac_of_hbm_peak": (traffic / conv_s / 1e9 / HBM_PEAK_GBS) if (traffic and conv_s > 0) else None,
-                "fp64_TFLOPs": (2.0 * (alg_bytes / 8.0) / conv_s / 1e12) if conv_s > 0 else None,
-                "fp64_frac_of_mfma_peak": (2.0 * (alg_bytes / 8.0) / conv_s / 1e12 / 78.6) if conv_s > 0 else None,
-                "note": ("one look-ahead launch covers 16 steps: algorithmic bytes = the SURVEY 8d per-step figure summed over those "
-                         "steps (less the newest-sample share each step adds itself), while K leaves HBM once (see traffic), so "
-                         "frac > 1 measures the reuse, not a faster memory")
-                        if steps_per_launch == 16 else "one launch = one step",
+                "step_kernel_us": us(prof["step_kernel_seconds"], prof["step_kernel_launches"]),
+                "scatter_kernel_us": us(prof["scatter_kernel_seconds"], prof["scatter_kernel_launches"]),
+                "fp64_TFLOPs": (2.0 * (bytes_units / 8.0) / conv_s / 1e12) if conv_s > 0 else None,
+                "fp64_frac_of_mfma_peak": (2.0 * (bytes_units / 8.0) / conv_s / 1e12 / FP64_MFMA_PEAK_TF) if conv_s > 0 else None,
+                "note": ("achieved = bytes one launch must move once (live K + Kex + staged vectors) / mean HIP-event duration; the "
+                         "launch serves 16 steps (SURVEY 8d bytes of those steps = algorithmic_bytes_of_the_units, reuse_factor x)")
+                        if units == 16 else "one launch = one step",
             },
+            "term_seconds": {k: prof[k] for k in ("hydrostatics_seconds", "radiation_seconds", "waves_seconds")},
         }
+        if pipelined is not None:
+            out["device_pipelined"] = pipelined
         if plain is not None:
             out["plain_per_step_mode"] = plain
         if world == 1 and not args.no_cpu_baseline and case is not None:
-            base, f_cpu = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds, sdt, duration)
-            f_gpu = forces[0].cpu().numpy()  # step k = 0 is t = T0 on both sides
+            base, f_faithful, flat_threads = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds, sdt, duration)
+            n_chk = k_next
+            f_flat = oracle_all_steps(case, motion, t_hist, v_hist, sdt, duration, n_chk, flat_threads)
+            nf = min(len(f_faithful), n_chk)
             out["cpu_baseline"] = base
-            out["parity_max_rel_err_vs_oracle"] = float(np.max(np.abs(f_gpu - f_cpu)) / np.max(np.abs(f_cpu)))
+            out["parity"] = {
+                "timed_steps_max_rel_err": max_rel_err(forces[args.warmup:total], f_flat[args.warmup:total]),
+                "all_steps_checked": n_chk,
+                "all_steps_max_rel_err": max_rel_err(forces[:n_chk], f_flat[:n_chk]),
+                "oracle": "flat-array variant of the CPU oracle on every step",
+                "faithful_oracle_steps": nf,
+                "faithful_oracle_max_rel_err": max_rel_err(forces[:nf], np.stack(f_faithful[:nf])),
+                "tolerance": 1e-6,
+            }
+            out["parity_max_rel_err_vs_oracle"] = out["parity"]["all_steps_max_rel_err"]
             out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
             out["speedup_vs_optimized_cpu"] = out["value"] / base["optimized_port"]["value"]
+        elif exchange is not None:
+            # coupled array: every rank must hold the same gathered vector; spot-check rank 0's own rows against its kernels' output
+            out["gathered_rows_finite"] = bool(torch.isfinite(gathered[args.warmup:total]).all().item())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -36,7 +36,9 @@ class ProfileStats(C.Structure):
                 ("conv_kernel_seconds", C.c_double), ("conv_kernel_launches", C.c_longlong),
                 ("conv_kernel_bytes", C.c_double), ("block_kernel_seconds", C.c_double),
                 ("block_kernel_launches", C.c_longlong), ("block_kernel_bytes", C.c_double),
-                ("rem_kernel_seconds", C.c_double), ("rem_kernel_launches", C.c_longlong)]
+                ("block_kernel_bytes_once", C.c_double),
+                ("step_kernel_seconds", C.c_double), ("step_kernel_launches", C.c_longlong),
+                ("scatter_kernel_seconds", C.c_double), ("scatter_kernel_launches", C.c_longlong)]
 
 
 # name -> (restype, argtypes); every symbol include/hydrochrono_amd.h declares

@@ -111,49 +111,76 @@ int history_push(hc_ctx* c, double t) {
 }
 
 // ---- profiling --------------------------------------------------------------------------------
+// Timed launches carry their own pair of HIP events, recorded on the stream the launch went to (a caller's stream in
+// hc_step_device), so the drain waits on the events themselves, not on a particular stream.
 void profile_drain(hc_ctx* c) {
-    if (c->events_used == 0) return;
-    HC_HIP(hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < c->events_used; ++i) {
-        float ms01 = 0, ms12 = 0;
-        HC_HIP(hipEventElapsedTime(&ms01, c->events[i].e[0], c->events[i].e[1]));
-        HC_HIP(hipEventElapsedTime(&ms12, c->events[i].e[1], c->events[i].e[2]));
-        // the convolution launch carries radiation and (irregular waves) excitation; the finalize launch carries
-        // hydrostatics, the regular-wave term and the reduction
-        c->prof.radiation_seconds += ms01 * 1e-3;
-        c->prof.hydrostatics_seconds += ms12 * 1e-3;
-        if (c->events[i].kind == 1) {  // boundary step: time the look-ahead kernel alone (event 3 follows it directly)
-            float msb = 0;
-            HC_HIP(hipEventElapsedTime(&msb, c->events[i].e[0], c->events[i].e[3]));
-            c->prof.block_kernel_seconds += msb * 1e-3;
-            c->prof.block_kernel_launches += 1;
-        } else if (c->events[i].kind == 2) {
-            c->prof.rem_kernel_seconds += ms01 * 1e-3;
-            c->prof.rem_kernel_launches += 1;
-        } else {
-            c->prof.conv_kernel_seconds += ms01 * 1e-3;
-            c->prof.conv_kernel_launches += 1;
+        hc::EventPair& ev = c->events[i];
+        HC_HIP(hipEventSynchronize(ev.b));
+        float ms = 0;
+        HC_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
+        const double sec = ms * 1e-3;
+        switch (ev.kind) {
+            case hc::kEvConvPlain:  // radiation (+ irregular-wave excitation chunks) of a plain step
+                c->prof.conv_kernel_seconds += sec;
+                c->prof.conv_kernel_launches += 1;
+                c->prof.radiation_seconds += sec * (1.0 - ev.waves_share);
+                c->prof.waves_seconds += sec * ev.waves_share;
+                break;
+            case hc::kEvPass:  // look-ahead pass: radiation part of 16 steps (+ their excitation force)
+                c->prof.block_kernel_seconds += sec;
+                c->prof.block_kernel_launches += 1;
+                c->prof.radiation_seconds += sec * (1.0 - ev.waves_share);
+                c->prof.waves_seconds += sec * ev.waves_share;
+                break;
+            case hc::kEvStep:  // the step kernel: reduction, own-sample part, hydrostatics, regular / spectral wave term
+                c->prof.step_kernel_seconds += sec;
+                c->prof.step_kernel_launches += 1;
+                c->prof.hydrostatics_seconds += sec;
+                break;
+            case hc::kEvScatter:
+                c->prof.scatter_kernel_seconds += sec;
+                c->prof.scatter_kernel_launches += 1;
+                c->prof.radiation_seconds += sec;
+                break;
+            default:  // excitation-only convolution launch
+                c->prof.waves_seconds += sec;
+                break;
         }
     }
     c->events_used = 0;
 }
 
-// Event set for this step, or null.  Sampled (events perturb the launch stream): every stride-th step, plus every look-ahead
-// boundary step -- its pass over K is the launch the roofline is quoted on and costs one event set per 16 steps.
-hc::EventSet* profile_next(hc_ctx* c, int mode) {
-    if (!c->profiling) return nullptr;
-    const bool strided = (c->profile_counter++ % c->profile_stride) == 0;
-    if (!strided && mode != 1) return nullptr;
+constexpr size_t kEventPoolMax = 4096;
+
+// Called at the top of a step, before anything is enqueued or the history is touched: decides whether this step's launches
+// are timed (every stride-th step) and makes room in the event pool (draining synchronises, so it must not happen between
+// the history push and the launches).
+void profile_begin_step(hc_ctx* c) {
+    c->sample_this_step = false;
+    if (!c->profiling) return;
+    if (c->events_used + 8 > kEventPoolMax) profile_drain(c);
+    c->sample_this_step = (c->profile_counter++ % c->profile_stride) == 0;
+}
+
+// Event pair around one launch, or null.  The look-ahead pass (one per 16 steps) is timed whatever the stride.
+hc::EventPair* ev_begin(hc_ctx* c, int kind, hipStream_t stream, double waves_share = 0.0) {
+    if (!c->profiling || !(c->sample_this_step || kind == hc::kEvPass)) return nullptr;
     if (c->events_used == c->events.size()) {
-        if (c->events.size() < 4096) {
-            hc::EventSet es;
-            for (auto& e : es.e) HC_HIP(hipEventCreate(&e));
-            c->events.push_back(es);
-        } else {
-            profile_drain(c);
-        }
+        if (c->events.size() >= kEventPoolMax) return nullptr;
+        hc::EventPair ev;
+        HC_HIP(hipEventCreate(&ev.a));
+        HC_HIP(hipEventCreate(&ev.b));
+        c->events.push_back(ev);
     }
-    return &c->events[c->events_used++];
+    hc::EventPair* ev = &c->events[c->events_used++];
+    ev->kind        = kind;
+    ev->waves_share = waves_share;
+    HC_HIP(hipEventRecord(ev->a, stream));
+    return ev;
+}
+void ev_end(hc::EventPair* ev, hipStream_t stream) {
+    if (ev) HC_HIP(hipEventRecord(ev->b, stream));
 }
 
 // ---- panel geometry and launch tiling ---------------------------------------------------------
@@ -187,9 +214,12 @@ hc::Panel rad_panel(const hc_ctx* c) {
 
 void choose_conv_config(hc_ctx* c) {
     // plain per-step kernel: 8 workgroups per CU (one resident set; 184.6 us against 187.2 us with twice as many, and
-    // finalize_kernel has half as many partials to add); a chunk is a whole number of 8-column groups
-    const int target_wgs = std::max(1, env_int("HC_CONV_TARGET_WGS", 8 * c->num_cus));
-    long long nch        = std::max<long long>(1, target_wgs / std::max(1, c->ngroups));
+    // finalize_kernel has half as many partials to add); a chunk is a whole number of 8-column groups.  Like the pass
+    // below, the chunk length is a function of the column count only (row groups of the UNSHARDED system), so row-sharded
+    // contexts add their partial sums in the same order as the unsharded one (bitwise equal results).
+    const int target_wgs       = std::max(1, env_int("HC_CONV_TARGET_WGS", 8 * c->num_cus));
+    const long long rows_full  = std::max<long long>(1, (((c->D + 15) / 16) + 3) / 4);
+    long long nch              = std::max<long long>({1, target_wgs / rows_full, c->num_cus / 2});
     long long gps        = (c->ngp + nch - 1) / nch;
     gps                  = std::max<long long>(16, ((gps + 3) / 4) * 4);  // every wave of the workgroup gets work
     gps                  = std::min<long long>(gps, 512);                 // the chunk's right-hand side is staged in LDS (<= 32 KB)
@@ -217,8 +247,6 @@ void choose_conv_config(hc_ctx* c) {
     bgps                = std::max<long long>(16, ((bgps + 15) / 16) * 16);  // whole 16-group sub-tiles
     c->chunk_gp_block   = static_cast<int>(bgps);
     c->nchunks_block    = static_cast<int>((c->ngp + bgps - 1) / bgps);
-    // remainder of a look-ahead step: at most 16 samples wide
-    c->chunk_gp_rem = std::max(4, env_int("HC_REM_CHUNK_GP", 8));  // short chunks: these launches are latency-bound
 }
 
 void choose_exc_config(hc_ctx* c) {
@@ -235,13 +263,14 @@ void choose_exc_config(hc_ctx* c) {
 }
 
 void alloc_partials(hc_ctx* c) {
-    const int rem_chunks = (c->ngp + c->chunk_gp_rem - 1) / c->chunk_gp_rem + 1;  // worst case: remainder spans all of K
-    const size_t n = static_cast<size_t>(std::max(c->nchunks_rad, rem_chunks) + c->nchunks_ex) * c->Dpad;
+    const size_t n = static_cast<size_t>(c->nchunks_rad + c->nchunks_ex) * c->Dpad;
     if (c->d_partials.n < n) c->d_partials.alloc(n);
     const size_t nb = static_cast<size_t>(c->nchunks_block + c->nchunks_ex_block) * hc::kLookahead * c->Dpad;
     if (c->d_partials_block.n < nb) c->d_partials_block.alloc(nb);
     if (c->d_P.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_P.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
     if (c->d_E.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_E.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
+    const size_t ny = static_cast<size_t>(hc::kLookahead) * hc::kScatterSamples * c->Dpad;
+    if (c->d_Y.n < ny) c->d_Y.alloc(ny);
 }
 
 // ---- TaperedDirect ----------------------------------------------------------------------------
@@ -288,6 +317,7 @@ void ensure_processed(hc_ctx* c) {
 // ---- the step ---------------------------------------------------------------------------------
 struct StepFlags {
     bool hs = true, rad = true, waves = true;
+    bool scratch_out = false;  // term-only entry points: outputs go to scratch buffers, the last step's components stay
 };
 
 // the excitation-window tests of check_wave_ready as a predicate (for predicted step times)
@@ -316,66 +346,6 @@ void check_wave_ready(hc_ctx* c, double t) {
     }
 }
 
-// Look-ahead bookkeeping.  Decides how the radiation term of the step at time t is evaluated:
-//   0 = plain (whole K this step), 1 = boundary (blocked pass over K covering this and the next 15 predicted steps),
-//   2 = inside a block (precomputed part P[j] + remainder over the newest samples).
-int plan_step(hc_ctx* c, double t, int H) {
-    auto& pl = c->plan;
-    if (H < 2) return 0;
-    if (c->lookahead <= 0) return 0;
-    if (pl.cooldown > 0) {
-        --pl.cooldown;
-        return 0;
-    }
-    if (pl.valid && pl.j_next < hc::kLookahead) {
-        // accept the caller's time if it is the predicted one up to accumulated rounding (t += dt in the caller vs
-        // t0 + j*dt here); the interpolation weights then differ by <= tol/dt relative, far inside the 1e-6 contract
-        const double tol = std::max(1e-9 * pl.dt, 64.0 * std::numeric_limits<double>::epsilon() * std::fabs(t));
-        if (std::fabs(t - pl.tpred[pl.j_next]) <= tol) return 2;
-        // the caller left the predicted time grid (variable step): drop the block
-        pl.valid = false;
-        if (++pl.misses >= 2) {
-            pl.misses   = 0;
-            pl.cooldown = 64;  // irregular stepping: plain steps for a while, then try again
-            return 0;
-        }
-    } else if (pl.valid) {
-        pl.misses = 0;  // a block was consumed completely
-    }
-    const double dt = c->times[0] - c->times[1];
-    if (!(dt > 0.0)) return 0;
-    pl.valid  = true;
-    pl.t0     = t;
-    pl.dt     = dt;
-    pl.j_next = 1;
-    for (int j = 0; j < hc::kLookahead; ++j) {
-        pl.tpred[j] = (j == 0) ? t : t + j * dt;
-        // samples s >= s_cut[j] of step j need only history known now: tpred[j] - tau_s <= t (same expression as the kernel)
-        int sc = 0;
-        while (sc < c->S && !(pl.tpred[j] - c->tau[sc] <= t)) ++sc;
-        pl.s_cut[j] = sc;
-        // While the history is shorter than the IRF window the reference's "no older sample -> the IRF step contributes
-        // nothing" rule (src/hydro_forces.cpp:604-606) makes the sum discontinuous in t where t - tau_s crosses the oldest
-        // sample time; a predicted time that differs from the caller's by an ulp could flip that decision.  The one sample
-        // per step for which the test is too close to call is left out of the pass and evaluated by the step itself.
-        pl.s_defer[j]       = -1;
-        const double oldest = c->times.back();
-        const double margin = 8.0 * std::max(1e-9 * dt, 64.0 * std::numeric_limits<double>::epsilon() * std::fabs(pl.tpred[j]));
-        const double target = pl.tpred[j] - oldest;  // tau of the sample that lands on the oldest history time
-        if (target <= c->tau.back() + margin) {
-            const auto it = std::lower_bound(c->tau.begin(), c->tau.end(), target - margin);
-            if (it != c->tau.end() && std::fabs(*it - target) <= margin) pl.s_defer[j] = static_cast<int>(it - c->tau.begin());
-        }
-    }
-    if (pl.s_cut[hc::kLookahead - 1] > c->S / 4) {
-        // step size comparable to the IRF window: the remainder would re-read most of K every step, so blocking cannot pay
-        pl.valid    = false;
-        pl.cooldown = 256;
-        return 0;
-    }
-    return 1;
-}
-
 // Number of leading IRF samples that can contribute at query time t_query: samples whose t_query - tau_s lies before the
 // oldest history sample have no older bracket and contribute nothing (src/hydro_forces.cpp:604-606), so while the history
 // is shorter than the IRF window the kernels need not stream the tail of K at all.  Conservative by a small margin.
@@ -389,7 +359,7 @@ int live_samples(const hc_ctx* c, double t_query) {
 
 // find_bracket of hc_kernels.hip on the host copy of the history (times[0] = t is the current sample, times[k] = ring slot
 // head - k): the same comparisons and the same divisions on the same doubles, so the weights are the kernel's bit for bit.
-// Returns false where the kernel would raise its "not bracketed" flag (the launch then searches itself and reports).
+// Returns false where the kernel would raise its "not bracketed" flag.
 bool host_bracket(const hc_ctx* c, double q, int H, hc::Bracket* out) {
     auto time_at = [&](int k) { return c->times[static_cast<size_t>(k)]; };
     int lo = 0, hi = H - 1;
@@ -418,167 +388,312 @@ bool host_bracket(const hc_ctx* c, double q, int H, hc::Bracket* out) {
     return true;
 }
 
-// Enqueue the kernels of one evaluation at time t. d_state: device pointer to the 12N state. user_out may be null.
-void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f) {
+// Look-ahead bookkeeping at the start of a step: 0 = plain (whole K this step), j = 1..16: the step is block step j of the
+// current plan (its time is the predicted one).
+int plan_step(hc_ctx* c, double t, int H) {
+    auto& pl = c->plan;
+    if (pl.cooldown > 0) --pl.cooldown;
+    if (H < 2 || c->lookahead <= 0 || !pl.valid) return 0;
+    if (pl.j_next <= hc::kLookahead) {
+        // accept the caller's time if it is the predicted one up to accumulated rounding (t += dt in the caller vs
+        // t0 + j*dt here); the radiation term is evaluated on the predicted grid, whose interpolation weights then differ
+        // from the caller's by <= tol/dt relative, far inside the 1e-6 contract
+        const double tol = std::max(1e-9 * pl.dt, 64.0 * std::numeric_limits<double>::epsilon() * std::fabs(t));
+        if (std::fabs(t - pl.tgrid[pl.j_next]) <= tol) return pl.j_next++;
+    }
+    // the caller left the predicted time grid (variable step): drop the block
+    pl.valid = false;
+    if (++pl.misses >= 2) {
+        pl.misses   = 0;
+        pl.cooldown = 64;  // irregular stepping: plain steps for a while, then try again
+    }
+    return 0;
+}
+
+// Plans the block that follows the step just pushed (times[0]).  On the predicted time grid it classifies, for every block
+// step m and IRF sample s, the interpolation bracket of the query time tgrid[m] - tau_s by who owns its two samples:
+// samples known now (the pass), earlier block steps (scatter terms), step m itself (own entries).  The comparisons and the
+// weight arithmetic are those of find_bracket / InterpolateVelocity6D (src/hydro_forces.cpp:343-381).
+bool make_plan(hc_ctx* c) {
+    auto& pl       = c->plan;
+    const int keep_misses = pl.misses, keep_cool = pl.cooldown;
+    pl             = hc::Plan{};
+    pl.misses      = keep_misses;
+    pl.cooldown    = keep_cool;
+    const int H    = static_cast<int>(c->times.size());
+    if (c->lookahead <= 0 || H < 2 || pl.cooldown > 0 || c->S < 2 || c->tau.front() < 0.0) return false;
+    const double t0 = c->times[0], dt = c->times[0] - c->times[1];
+    if (!(dt > 0.0)) return false;
+    if (dt * hc::kLookahead > 0.25 * (c->tau.back() - c->tau.front())) {
+        pl.cooldown = 256;  // step size comparable to the IRF window: blocking cannot pay
+        return false;
+    }
+    pl.dt = dt;
+    for (int j = 0; j <= hc::kLookahead; ++j) pl.tgrid[j] = (j == 0) ? t0 : t0 + j * dt;
+    auto G = [&](int idx) { return idx >= 1 ? pl.tgrid[idx] : c->times[static_cast<size_t>(-idx)]; };  // idx > -H
+    for (int i = 0; i <= hc::kLookahead; ++i) {
+        pl.scat_lo[i] = c->S;
+        pl.scat_hi[i] = -1;
+    }
+    const double oldest = c->times.back();
+    for (int m = 1; m <= hc::kLookahead; ++m) {
+        const int j = m - 1;
+        // pass: samples s >= s_cut[j] of block step m need only history known now and the (zero) not-yet-known sample at
+        // tgrid[1]: tgrid[m] - tau_s <= tgrid[1] (same expression as the kernel)
+        int sc = 0;
+        while (sc < c->S && !(pl.tgrid[m] - c->tau[sc] <= pl.tgrid[1])) ++sc;
+        pl.s_cut[j] = sc;
+        // While the history is shorter than the IRF window the reference's "no older sample -> the IRF step contributes
+        // nothing" rule (src/hydro_forces.cpp:604-606) makes the sum discontinuous in t where t - tau_s crosses the oldest
+        // sample time; a predicted time that differs from the caller's by an ulp could flip that decision.  The one sample
+        // per step for which the test is too close to call is left out of the pass and evaluated by the step itself.
+        pl.s_defer[j]       = -1;
+        const double margin = 8.0 * std::max(1e-9 * dt, 64.0 * std::numeric_limits<double>::epsilon() * std::fabs(pl.tgrid[m]));
+        const double target = pl.tgrid[m] - oldest;  // tau of the sample that lands on the oldest history time
+        if (target <= c->tau.back() + margin) {
+            const auto it = std::lower_bound(c->tau.begin(), c->tau.end(), target - margin);
+            if (it != c->tau.end() && std::fabs(*it - target) <= margin) pl.s_defer[j] = static_cast<int>(it - c->tau.begin());
+        }
+        // brackets that touch a block sample (grid index >= 1)
+        for (int s = 0; s < c->S; ++s) {
+            const double q = pl.tgrid[m] - c->tau[s];
+            int lo = 0;  // smallest lo with G(m - lo - 1) <= q
+            while (m - lo - 1 > -H && G(m - lo - 1) > q) ++lo;
+            const int nm = m - lo, om = nm - 1;
+            if (nm <= 0) break;  // both samples known now: the pass has it, and so it has every later s
+            if (om <= -H) break; // (cannot happen for nm >= 1)
+            if (s >= hc::kScatterSamples || s == pl.s_defer[j]) return false;
+            const double newer = G(nm), older = G(om);
+            double wo = 0.0, wn = 0.0;
+            if (q == older) { wo = 1.0; wn = 0.0; }
+            else if (q == newer) { wo = 0.0; wn = 1.0; }
+            else if (q > older && q < newer) {
+                const double td = newer - older;
+                wo = (td != 0.0) ? ((newer - q) / td) : 0.0;
+                wn = 1.0 - wo;
+            } else {
+                return false;
+            }
+            const int idx[2]     = {nm, om};
+            const double wgt[2]  = {wn, wo};
+            for (int e = 0; e < 2; ++e) {
+                if (wgt[e] == 0.0 || idx[e] < 1) continue;
+                if (idx[e] == m) {
+                    if (pl.n_own[m] >= hc::kNearMax - 1) return false;  // one entry stays free for the deferred sample
+                    pl.own_s[m][pl.n_own[m]] = s;
+                    pl.own_a[m][pl.n_own[m]] = wgt[e] * c->width[s];
+                    pl.n_own[m]++;
+                } else {
+                    if (pl.n_terms[m] >= hc::kTermMax) return false;
+                    const int k = pl.n_terms[m]++;
+                    pl.term_slot[m][k] = idx[e];
+                    pl.term_s[m][k]    = s;
+                    pl.term_coef[m][k] = wgt[e];
+                    pl.scat_lo[idx[e]] = std::min(pl.scat_lo[idx[e]], s);
+                    pl.scat_hi[idx[e]] = std::max(pl.scat_hi[idx[e]], s);
+                }
+            }
+        }
+    }
+    pl.j_next = 1;
+    pl.valid  = true;
+    return true;
+}
+
+struct StepViews {
+    hc::Panel kex;
+    hc::EtaTable ex;
+};
+
+StepViews make_views(const hc_ctx* c) {
+    StepViews v{};
+    const bool irregular = c->wave_kind == hc::kWaveIrregular;
+    v.kex.base   = c->d_kex.p;
+    v.kex.ntiles = c->ntiles;
+    v.kex.ngp    = c->ngp_ex;
+    v.ex.L        = c->L;
+    v.ex.ex_tau   = c->d_ex_tau.p;
+    v.ex.ex_width = c->d_ex_width.p;
+    v.ex.eta_t    = c->d_eta_t.p;
+    v.ex.eta      = c->d_eta.p;
+    v.ex.nt       = c->nt;
+    v.ex.eta_dt   = irregular ? c->irr.simulation_dt : 1.0;
+    v.ex.eta_t0   = (irregular && !c->eta_t.empty()) ? c->eta_t.front() : 0.0;
+    return v;
+}
+
+// The look-ahead pass of the plan just made: for the 16 predicted steps, what the samples known now contribute.  It runs as
+// the plain pass of a (virtual) step at tgrid[1] whose own sample is zero -- that sample's share is added later by the
+// step itself and by its scatter.  Enqueued behind the step that has just been evaluated (its ring push included).
+void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
+    auto& pl = c->plan;
+    const int H = static_cast<int>(c->times.size());
+    // history length the virtual step would see after its own push + prune (PruneHistory, src/hydro_forces.cpp:327-340)
+    const double hmin = pl.tgrid[1] - (c->tau.empty() ? 0.0 : c->tau.back());
+    int Hv = H + 1;
+    auto vtime = [&](int k) { return k == 0 ? pl.tgrid[1] : c->times[static_cast<size_t>(k - 1)]; };
+    while (Hv > 1 && vtime(Hv - 2) < hmin) --Hv;
+
+    hc::HistoryView hv{};
+    hv.state   = c->d_zero_state.p;
+    hv.N       = c->N;
+    hv.D       = c->D;
+    hv.t       = pl.tgrid[1];
+    hv.ring_t  = c->d_ring_t.p;
+    hv.ring_v  = c->d_ring_v.p;
+    hv.head    = (c->head + 1) % c->Hcap;  // slot of the virtual sample (never read: time and velocity come from t / state)
+    hv.H       = Hv;
+    hv.Hcap    = c->Hcap;
+    hv.dt_hint = pl.dt;
+
+    const StepViews vw = make_views(c);
+    hc::BlockArgs b{};
+    b.K                   = rad_panel(c);
+    b.F                   = std::min(c->S, live_samples(c, pl.tgrid[hc::kLookahead])) * c->D;
+    b.chunk_gp            = c->chunk_gp_block;
+    b.nchunks             = std::max(1, ((b.F + 7) / 8 + c->chunk_gp_block - 1) / c->chunk_gp_block);
+    b.max_steps_per_chunk = (c->chunk_gp_block * 8) / c->D + 2;
+    b.hist                = hv;
+    for (int j = 0; j < hc::kLookahead; ++j) {
+        b.tpred[j]   = pl.tgrid[j + 1];
+        b.s_cut[j]   = pl.s_cut[j];
+        b.s_defer[j] = pl.s_defer[j];
+    }
+    b.tau   = c->d_tau.p;
+    b.width = c->d_width.p;
+    // The excitation force depends on time only, so the pass also evaluates it for the 16 predicted times (extra chunks
+    // over Kex in the same launch) -- provided every predicted time passes the window tests a real step would have to pass.
+    static const bool exc_in_block = env_int("HC_EXC_IN_BLOCK", 1) != 0;
+    bool exc_block = exc_in_block && with_exc && c->wave_kind == hc::kWaveIrregular && c->nchunks_ex_block > 0;
+    for (int j = 1; j <= hc::kLookahead && exc_block; ++j) exc_block = wave_window_ok(c, pl.tgrid[j]);
+    pl.has_exc    = exc_block;
+    b.Kex         = vw.kex;
+    b.ex          = vw.ex;
+    b.chunk_gp_ex = c->chunk_gp_ex_block;
+    b.nchunks_ex  = exc_block ? c->nchunks_ex_block : 0;
+    b.partials    = c->d_partials_block.p;
+    b.Dpad        = c->Dpad;
+    b.error_flag  = c->d_err.p;
+    b.ngroups     = c->ntiles / c->mt_block;
+    // algorithmic bytes: summed over the 16 steps, step j's share of K and of the velocity vector from s_cut[j]
+    // on ...; what the launch has to move once: the live part of K, Kex and the staged vectors
+    double samples = 0.0;
+    for (int j = 0; j < hc::kLookahead; ++j) samples += std::max(0, b.F / c->D - pl.s_cut[j]);
+    const double rad_16 = 8.0 * samples * (static_cast<double>(c->Dloc) * c->D + c->D);
+    const double exc_16 = exc_block ? 8.0 * hc::kLookahead * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
+    c->prof.block_kernel_bytes      = rad_16 + exc_16;
+    const double rad_once = 8.0 * (static_cast<double>(c->Dloc) * b.F + b.F);
+    const double exc_once = exc_block ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
+    c->prof.block_kernel_bytes_once = rad_once + exc_once;
+    hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_once / std::max(1.0, rad_once + exc_once));
+    hc::launch_conv_block(b, c->mt_block, stream);
+    ev_end(ev, stream);
+    hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, c->d_P.p, c->d_E.p, stream);
+}
+
+// Enqueue the kernels of one evaluation at time t.  d_state: device-visible pointer to the 12N state.  d_user_out
+// (device) and host_tagged (mapped pinned granules) may be null.
+void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f,
+                  unsigned long long* host_tagged = nullptr, unsigned long long seq = 0) {
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     const bool irregular = c->wave_kind == hc::kWaveIrregular;
     if (f.waves) check_wave_ready(c, t);
-    int H = 0, mode = 0;
+    profile_begin_step(c);
+    int H = 0, m = 0;
     if (f.rad) {
         ensure_processed(c);
-        H    = history_push(c, t);
-        mode = plan_step(c, t, H);
+        H = history_push(c, t);
+        m = plan_step(c, t, H);
     }
     const bool run_rad = f.rad && H >= 2;  // "Nothing to convolve with if we don't yet have at least 2 time points" (:580)
     const bool run_exc = f.waves && irregular;
-    hc::EventSet* ev = profile_next(c, mode);
-    if (ev) ev->kind = mode;
+    const StepViews vw = make_views(c);
+    const bool block   = run_rad && m > 0;
+    const double* P_row = block ? c->d_P.p + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
+    const double* E_row = (block && run_exc && c->plan.has_exc) ? c->d_E.p + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
 
-    hc::HistoryView hv{};
-    hv.state   = d_state;
-    hv.N       = c->N;
-    hv.D       = c->D;
-    hv.t       = t;
-    hv.ring_t  = c->d_ring_t.p;
-    hv.ring_v  = c->d_ring_v.p;
-    hv.head    = c->head;
-    hv.H       = H;
-    hv.Hcap    = c->Hcap;
-    hv.dt_hint = (H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
-
-    hc::Panel kex{};
-    kex.base   = c->d_kex.p;
-    kex.ntiles = c->ntiles;
-    kex.ngp    = c->ngp_ex;
-    hc::EtaTable ex{};
-    ex.L        = c->L;
-    ex.ex_tau   = c->d_ex_tau.p;
-    ex.ex_width = c->d_ex_width.p;
-    ex.eta_t    = c->d_eta_t.p;
-    ex.eta      = c->d_eta.p;
-    ex.nt       = c->nt;
-    ex.eta_dt   = irregular ? c->irr.simulation_dt : 1.0;
-    ex.eta_t0   = (irregular && !c->eta_t.empty()) ? c->eta_t.front() : 0.0;
-
-    if (ev) HC_HIP(hipEventRecord(ev->e[0], stream));
-    const double* P_row = nullptr;
-    int j_block = 0;
-    if (run_rad && mode == 1) {
-        hc::BlockArgs b{};
-        b.K                   = rad_panel(c);
-        b.F                   = std::min(c->S, live_samples(c, c->plan.tpred[hc::kLookahead - 1])) * c->D;
-        b.chunk_gp            = c->chunk_gp_block;
-        b.nchunks             = std::max(1, ((b.F + 7) / 8 + c->chunk_gp_block - 1) / c->chunk_gp_block);
-        b.max_steps_per_chunk = (c->chunk_gp_block * 8) / c->D + 2;
-        b.hist                = hv;
-        for (int j = 0; j < hc::kLookahead; ++j) {
-            b.tpred[j]   = c->plan.tpred[j];
-            b.s_cut[j]   = c->plan.s_cut[j];
-            b.s_defer[j] = c->plan.s_defer[j];
-        }
-        b.tau        = c->d_tau.p;
-        b.width      = c->d_width.p;
-        // The excitation force depends on time only, so the pass also evaluates it for the 16 predicted times (extra chunks
-        // over Kex in the same launch) -- provided every predicted time passes the window tests a real step would have to pass.
-        static const bool exc_in_block = env_int("HC_EXC_IN_BLOCK", 1) != 0;
-        bool exc_block = exc_in_block && run_exc && c->nchunks_ex_block > 0;
-        for (int j = 0; j < hc::kLookahead && exc_block; ++j) exc_block = wave_window_ok(c, c->plan.tpred[j]);
-        c->plan.has_exc = exc_block;
-        b.Kex           = kex;
-        b.ex            = ex;
-        b.chunk_gp_ex   = c->chunk_gp_ex_block;
-        b.nchunks_ex    = exc_block ? c->nchunks_ex_block : 0;
-        b.partials   = c->d_partials_block.p;
-        b.Dpad       = c->Dpad;
-        b.ngroups    = c->ngroups;
-        b.error_flag = c->d_err.p;
-        {  // algorithmic bytes of this pass: step j's share of K (and of the velocity vector) from s_cut[j] on
-            double samples = 0.0;
-            for (int j = 0; j < hc::kLookahead; ++j) samples += std::max(0, b.F / c->D - c->plan.s_cut[j]);
-            c->prof.block_kernel_bytes = 8.0 * samples * (static_cast<double>(c->Dloc) * c->D + c->D);
-            if (exc_block) c->prof.block_kernel_bytes += 8.0 * hc::kLookahead * (static_cast<double>(c->Dloc) * c->L + c->L);
-        }
-        b.ngroups = c->ntiles / c->mt_block;
-        hc::launch_conv_block(b, c->mt_block, stream);
-        if (ev) HC_HIP(hipEventRecord(ev->e[3], stream));
-        hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, c->d_P.p, c->d_E.p, stream);
-        P_row = c->d_P.p;
-    } else if (run_rad && mode == 2) {
-        j_block = c->plan.j_next++;
-        P_row   = c->d_P.p + static_cast<size_t>(j_block) * c->Dpad;
+    // plain step: all live columns of K, plus the excitation chunks unless a pass has left the excitation force
+    int nchunks_rad = 0, nchunks_ex = (run_exc && !E_row) ? c->nchunks_ex : 0;
+    if ((run_rad && !block) || nchunks_ex > 0) {
+        hc::HistoryView hv{};
+        hv.state   = d_state;
+        hv.N       = c->N;
+        hv.D       = c->D;
+        hv.t       = t;
+        hv.ring_t  = c->d_ring_t.p;
+        hv.ring_v  = c->d_ring_v.p;
+        hv.head    = c->head;
+        hv.H       = H;
+        hv.Hcap    = c->Hcap;
+        hv.dt_hint = (H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
+        hc::StepArgs a{};
+        a.K       = rad_panel(c);
+        a.F_limit = (run_rad && !block) ? std::min(c->S, live_samples(c, t)) * c->D : 0;
+        a.chunk_gp = c->chunk_gp;
+        nchunks_rad           = ((a.F_limit + 7) / 8 + a.chunk_gp - 1) / a.chunk_gp;
+        a.nchunks_rad         = nchunks_rad;
+        a.max_steps_per_chunk = (a.chunk_gp * 8) / c->D + 2;
+        a.rhs_capacity        = 8 * std::max(a.chunk_gp, c->chunk_gp_ex);
+        a.hist                = hv;
+        a.tau                 = c->d_tau.p;
+        a.width               = c->d_width.p;
+        a.Kex                 = vw.kex;
+        a.ex                  = vw.ex;
+        a.chunk_gp_ex         = c->chunk_gp_ex;
+        a.nchunks_ex          = nchunks_ex;
+        a.partials            = c->d_partials.p;
+        a.Dpad                = c->Dpad;
+        a.ngroups             = c->ngroups;
+        a.error_flag          = c->d_err.p;
+        const double rad_b = 8.0 * (static_cast<double>(c->Dloc) * a.F_limit + a.F_limit);
+        const double exc_b = nchunks_ex > 0 ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
+        hc::EventPair* ev = ev_begin(c, nchunks_rad > 0 ? hc::kEvConvPlain : hc::kEvConvExc, stream, exc_b / std::max(1.0, rad_b + exc_b));
+        hc::launch_conv_step(a, c->mt, stream);
+        ev_end(ev, stream);
     }
-
-    const double* E_row = (run_exc && run_rad && mode != 0 && c->plan.has_exc) ? c->d_E.p + static_cast<size_t>(j_block) * c->Dpad : nullptr;
-
-    // per-step kernel: radiation columns still to do this step + excitation chunks
-    int F_limit = 0, chunk_gp = c->chunk_gp, nchunks_rad1 = 0, nchunks_rad2 = 0, F2_lo = 0, F2_hi = 0;
-    if (run_rad && mode == 0) {
-        F_limit      = std::min(c->S, live_samples(c, t)) * c->D;
-        nchunks_rad1 = ((F_limit + 7) / 8 + chunk_gp - 1) / chunk_gp;
-    } else if (run_rad && mode != 0) {
-        // remainder of a look-ahead step: the newest samples, plus the deferred sample if it is not among them
-        F_limit           = c->plan.s_cut[j_block] * c->D;
-        chunk_gp          = c->chunk_gp_rem;
-        const int ngp_lim = (F_limit + 7) / 8;
-        nchunks_rad1      = (ngp_lim + chunk_gp - 1) / chunk_gp;
-        const int sd      = c->plan.s_defer[j_block];
-        if (sd >= c->plan.s_cut[j_block]) {
-            F2_lo        = sd * c->D;
-            F2_hi        = (sd + 1) * c->D;
-            nchunks_rad2 = ((F2_hi + 7) / 8 - F2_lo / 8 + chunk_gp - 1) / chunk_gp;
-        }
-    }
-    const int nchunks_rad = nchunks_rad1 + nchunks_rad2;
-    hc::StepArgs a{};
-    a.K                   = rad_panel(c);
-    a.F_limit             = F_limit;
-    a.chunk_gp            = chunk_gp;
-    a.nchunks_rad         = nchunks_rad;
-    a.nchunks_rad1        = nchunks_rad1;
-    a.F2_lo               = F2_lo;
-    a.F2_hi               = F2_hi;
-    a.max_steps_per_chunk = (chunk_gp * 8) / c->D + 2;
-    a.rhs_capacity        = 8 * std::max(chunk_gp, c->chunk_gp_ex);
-    a.stream_once         = (mode == 2 && env_int("HC_REM_NT", 0) == 0) ? 0 : 1;
-    a.hist                = hv;
-    a.tau                 = c->d_tau.p;
-    a.width               = c->d_width.p;
-    a.Kex                 = kex;
-    a.ex                  = ex;
-    a.chunk_gp_ex         = c->chunk_gp_ex;
-    a.nchunks_ex          = (run_exc && !E_row) ? c->nchunks_ex : 0;
-    a.partials            = c->d_partials.p;
-    a.Dpad                = c->Dpad;
-    a.ngroups             = c->ngroups;
-    a.error_flag          = c->d_err.p;
-    if (run_rad && mode != 0) {
-        const int n = std::min({F_limit / c->D, hc::kHostBrackets, c->S});
-        bool ok = true;
-        for (int s_ = 0; s_ < n && ok; ++s_) ok = host_bracket(c, t - c->tau[s_], H, &a.hb[s_]);
-        a.hb_n = ok ? n : 0;
-        if (nchunks_rad2 > 0) a.hb_defer_valid = host_bracket(c, t - c->tau[c->plan.s_defer[j_block]], H, &a.hb_defer) ? 1 : 0;
-    }
-    // Small system inside a look-ahead block: the remainder is a few hundred columns, which finalize_kernel contracts
-    // itself (16 lanes per row) -- the step is then ONE launch.  Needs every bracket from the host and no other chunk work.
-    static const int fin_rem_cols = env_int("HC_FIN_REM_COLS", 256);  // <= 16 columns per lane; beyond that the chunked launch wins (measured N = 2..12)
-    const bool rem_in_finalize = run_rad && mode == 2 && nchunks_rad2 == 0 && a.nchunks_ex == 0 && F_limit > 0 &&
-                                 F_limit <= fin_rem_cols && a.hb_n * c->D == F_limit;
-    if (!rem_in_finalize) hc::launch_conv_step(a, c->mt, stream);
-    if (ev) HC_HIP(hipEventRecord(ev->e[1], stream));
 
     hc::FinalizeArgs z{};
     z.partials    = c->d_partials.p;
-    z.nchunks_rad = rem_in_finalize ? 0 : a.nchunks_rad;
-    z.nchunks_ex  = a.nchunks_ex;
-    if (rem_in_finalize) {
-        z.rem_F = F_limit;
-        z.remK  = a.K;
-        z.hist  = hv;
-        z.width = c->d_width.p;
-        for (int s_ = 0; s_ < a.hb_n; ++s_) z.hb[s_] = a.hb[s_];
-    }
+    z.nchunks_rad = nchunks_rad;
+    z.nchunks_ex  = nchunks_ex;
     z.P           = P_row;
     z.E           = E_row;
+    if (block) {
+        const auto& pl = c->plan;
+        z.nearK     = rad_panel(c);
+        z.ring_v_ro = c->d_ring_v.p;
+        for (int e = 0; e < pl.n_own[m]; ++e) {
+            hc::NearEntry& ne = z.near[z.n_near++];
+            ne   = hc::NearEntry{};
+            ne.s = pl.own_s[m][e];
+            ne.a = pl.own_a[m][e];
+        }
+        const int sd = pl.s_defer[m - 1];
+        if (sd >= 0) {
+            // the IRF sample the pass left to this step: its whole bracket, with the caller's time and the history as it is
+            hc::Bracket br{};
+            if (host_bracket(c, t - c->tau[sd], H, &br) && (br.wo != 0.0 || br.wn != 0.0)) {
+                hc::NearEntry& ne = z.near[z.n_near++];
+                ne       = hc::NearEntry{};
+                ne.s     = sd;
+                ne.off_b = br.off_older;
+                ne.b     = br.wo * c->width[sd];
+                if (br.off_newer < 0) ne.a = br.wn * c->width[sd];
+                else {
+                    ne.off_c = br.off_newer;
+                    ne.c     = br.wn * c->width[sd];
+                }
+            }
+        }
+        z.n_terms = pl.n_terms[m];
+        z.Y       = c->d_Y.p;
+        for (int k = 0; k < pl.n_terms[m]; ++k) {
+            z.term_off[k]  = (pl.term_slot[m][k] * hc::kScatterSamples + pl.term_s[m][k]) * c->Dpad;
+            z.term_coef[k] = pl.term_coef[m][k];
+        }
+    }
+    z.host_tagged = host_tagged;
+    z.seq         = seq;
     z.Dloc        = c->Dloc;
     z.Dpad        = c->Dpad;
     z.N           = c->N;
@@ -608,18 +723,46 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     z.do_hs         = f.hs;
     z.do_rad        = run_rad;
     z.do_waves      = f.waves;
-    z.hs            = c->d_hs.p;
-    z.rad           = c->d_rad.p;
-    z.waves         = c->d_waves.p;
-    z.total         = c->d_total.p;
+    double* out4    = f.scratch_out ? c->d_scratch.p : nullptr;
+    z.hs            = out4 ? out4 : c->d_hs.p;
+    z.rad           = out4 ? out4 + c->Dloc : c->d_rad.p;
+    z.waves         = out4 ? out4 + 2 * c->Dloc : c->d_waves.p;
+    z.total         = out4 ? out4 + 3 * c->Dloc : c->d_total.p;
     z.user_out      = d_user_out;
     z.do_push       = f.rad ? 1 : 0;
     z.head          = c->head;
     z.D             = c->D;
     z.ring_t        = c->d_ring_t.p;
     z.ring_v        = c->d_ring_v.p;
-    hc::launch_finalize(z, stream);
-    if (ev) HC_HIP(hipEventRecord(ev->e[2], stream));
+    {
+        hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
+        hc::launch_finalize(z, stream);
+        ev_end(ev, stream);
+    }
+
+    // ---- off the caller's critical path: everything below is needed by later steps only ----
+    if (f.rad && c->lookahead > 0) {
+        if (block && m < hc::kLookahead) {
+            const auto& pl = c->plan;
+            if (pl.scat_hi[m] >= pl.scat_lo[m]) {
+                hc::ScatterArgs sa{};
+                sa.K     = rad_panel(c);
+                sa.D     = c->D;
+                sa.Dpad  = c->Dpad;
+                sa.s_lo  = pl.scat_lo[m];
+                sa.ns    = pl.scat_hi[m] - pl.scat_lo[m] + 1;
+                sa.v     = c->d_ring_v.p + static_cast<size_t>(c->head) * c->D;  // this step's sample, pushed by finalize_kernel
+                sa.width = c->d_width.p;
+                sa.Y     = c->d_Y.p + (static_cast<size_t>(m) * hc::kScatterSamples + sa.s_lo) * c->Dpad;
+                hc::EventPair* ev = ev_begin(c, hc::kEvScatter, stream);
+                hc::launch_scatter(sa, stream);
+                ev_end(ev, stream);
+            }
+        } else if (!block || m == hc::kLookahead) {
+            if (block) c->plan.misses = 0;  // a block was consumed completely
+            if (H >= 2 && make_plan(c)) launch_pass(c, stream, f.waves);
+        }
+    }
     HC_HIP(hipGetLastError());
 
     if (f.hs) c->prof.hydrostatics_calls++;
@@ -672,6 +815,7 @@ void check_device_flag(hc_ctx* c) {
 }
 
 void stage_state(hc_ctx* c, const double* pos, const double* rpy, const double* linvel, const double* angvel) {
+    HC_HIP(hipStreamSynchronize(c->stream));  // kernels of the last hc_step may still be reading the pinned state (zero-copy)
     const int n3 = 3 * c->N;
     double* h    = c->h_state.p;
     const double* src[4] = {pos, rpy, linvel, angvel};
@@ -723,6 +867,7 @@ int hc_create_sharded(int num_bodies, int body_begin, int body_end, int device_i
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         c->bodies.resize(num_bodies);
         HC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HC_HIP(hipStreamCreateWithFlags(&c->stream_am, hipStreamNonBlocking));
         hc_tapered_direct_options_default(&c->taper);
         hc_irregular_wave_params_default(&c->irr);
         *out = c.release();
@@ -742,9 +887,12 @@ void hc_destroy(hc_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();  // steps may still be running on a caller's stream; the buffers go away below
-    for (auto& es : ctx->events)
-        for (auto& e : es.e) (void)hipEventDestroy(e);
+    for (auto& ev : ctx->events) {
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream_am) (void)hipStreamDestroy(ctx->stream_am);
     delete ctx;
 }
 
@@ -939,8 +1087,8 @@ int hc_finalize(hc_ctx* c) {
     // history ring
     ring_alloc(c, std::max(64, c->S + 2));
     c->times.clear();
-    c->have_prev = false;
-    c->prev_time = -1.0;
+    c->have_prev = c->have_prev_device = false;
+    c->prev_time = c->prev_time_device = -1.0;
     // GEMV scratch
     choose_conv_config(c);
     // step I/O
@@ -952,9 +1100,18 @@ int hc_finalize(hc_ctx* c) {
     for (auto* b : {&c->d_hs, &c->d_rad, &c->d_waves, &c->d_total}) HC_HIP(hipMemsetAsync(b->p, 0, b->n * sizeof(double), c->stream));
     c->d_err.alloc(1);
     HC_HIP(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
-    c->h_state.alloc(static_cast<size_t>(12) * c->N);
+    c->h_state.alloc(static_cast<size_t>(2) * 12 * c->N);  // two halves used alternately by hc_step, see there
     c->h_out.alloc(static_cast<size_t>(4) * c->Dloc);
     c->h_err.alloc(1);
+    c->h_am.alloc(static_cast<size_t>(c->D) + c->Dloc);
+    c->h_tag.alloc(static_cast<size_t>(2) * c->Dloc);
+    std::memset(c->h_tag.p, 0, c->h_tag.n * sizeof(unsigned long long));
+    c->seq = 0;
+    c->last_total.assign(c->Dloc, 0.0);
+    c->d_scratch.alloc(static_cast<size_t>(4) * c->Dloc);
+    c->d_zero_state.alloc(static_cast<size_t>(12) * c->N);
+    HC_HIP(hipMemsetAsync(c->d_zero_state.p, 0, c->d_zero_state.n * sizeof(double), c->stream));
+    c->zero_copy_max_bodies = env_int("HC_ZERO_COPY_BODIES", 64);
     // default wave model: NoWave for all bodies (the reference's default NoWave() covers one body only and is
     // read out of bounds for N > 1, src/hydro_forces.cpp:758-760; that overread is deliberately not reproduced)
     c->wave_kind   = hc::kWaveNone;
@@ -1241,34 +1398,69 @@ int hc_set_tapered_direct_options(hc_ctx* c, const hc_tapered_direct_options* o)
 }
 
 // ---- per-step ---------------------------------------------------------------------------------
+namespace {
+// Wait until finalize_kernel's {total, sequence} granules of step `seq` have all arrived in mapped pinned memory, then
+// copy the totals out.  Each granule is one 16-byte store, so its value is valid as soon as its sequence number is.  This
+// replaces hipStreamSynchronize on the per-step path (14 -> 9 us for an empty launch, profiles/r02/latency_probe_v1.txt);
+// the stream is queried from time to time so that a failed launch ends the wait with an error instead of hanging.
+void wait_tagged(hc_ctx* c, unsigned long long seq, hipStream_t stream, double* out) {
+    const volatile unsigned long long* g = c->h_tag.p;
+    unsigned long long spins = 0;
+    for (int r = c->Dloc - 1; r >= 0; --r) {
+        while (g[2 * r + 1] != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0x3FFFF) == 0) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q == hipSuccess) {
+                    if (g[2 * r + 1] != seq) throw Error(HC_ERR_DEVICE, "hc_step: the stream drained but the step's results did not arrive");
+                } else if (q != hipErrorNotReady) {
+                    throw Error(HC_ERR_DEVICE, std::string("hc_step: ") + hipGetErrorString(q));
+                }
+            }
+        }
+    }
+    for (int r = 0; r < c->Dloc; ++r) {
+        const unsigned long long bits = g[2 * r];
+        std::memcpy(out + r, &bits, sizeof(double));
+    }
+}
+}  // namespace
+
 int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel, double* force_out) {
     HC_API_BEGIN(c)
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(pos && rpy && linvel && angvel && force_out, HC_ERR_INVALID, "null pointer");
     if (c->have_prev && t == c->prev_time) {  // src/hydro_forces.cpp:742-744
-        std::memcpy(force_out, c->h_out.p + 3 * c->Dloc, c->Dloc * sizeof(double));
+        std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
         return HC_OK;
     }
     c->prev_time = t;  // :747 (set before the terms are computed, so a throwing step is not retried)
     c->have_prev = true;
-    // Zero-copy boundary: finalize_kernel stores the totals straight into mapped pinned memory, and for small systems the
-    // kernels read the 12N state doubles from mapped pinned memory too -- no memcpy launches on the critical path of a
-    // small-N step, just two kernels and one stream synchronisation.
-    const int n3 = 3 * c->N;
-    double* h    = c->h_state.p;
+    std::fill(c->last_total.begin(), c->last_total.end(), 0.0);  // the reference zero-fills total_force_ before the terms (:749-751)
+    // Zero-copy boundary: the kernels read the 12N state doubles from mapped pinned memory (up to a few dozen bodies) and
+    // finalize_kernel stores the totals straight into mapped pinned memory, tagged with this step's sequence number -- no
+    // copy launches and no stream synchronisation on the critical path, one kernel launch for a step inside a block.
+    // The state buffer has two halves used alternately: this call returns as soon as the totals have arrived, while the
+    // workgroup that stores the step's sample into the ring may still be reading the state -- the next call must not
+    // overwrite it.  (The kernels of step n+1 run after those of step n, and step n+2 starts only after the totals of
+    // step n+1 have arrived, so two halves are enough.)
+    const int n3   = 3 * c->N;
+    const size_t o = (c->seq & 1) ? static_cast<size_t>(12) * c->N : 0;
+    double* h      = c->h_state.p + o;
     std::memcpy(h, pos, n3 * sizeof(double));
     std::memcpy(h + n3, rpy, n3 * sizeof(double));
     std::memcpy(h + 2 * n3, linvel, n3 * sizeof(double));
     std::memcpy(h + 3 * n3, angvel, n3 * sizeof(double));
-    const double* d_state = c->h_state.dp;
-    if (c->N > 8) {  // many workgroups re-read the state: one small H2D copy beats thousands of PCIe reads
+    const double* d_state = c->h_state.dp + o;
+    if (c->N > c->zero_copy_max_bodies) {  // many workgroups re-read the state: one small H2D copy beats their PCIe reads
         HC_HIP(hipMemcpyAsync(c->d_state.p, h, 4 * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
         d_state = c->d_state.p;
     }
-    enqueue_step(c, t, d_state, c->h_out.dp + 3 * c->Dloc, c->stream, StepFlags{});
-    HC_HIP(hipStreamSynchronize(c->stream));
+    const unsigned long long seq = ++c->seq;
+    enqueue_step(c, t, d_state, nullptr, c->stream, StepFlags{}, c->h_tag.dp, seq);
+    wait_tagged(c, seq, c->stream, c->last_total.data());
     if (c->device_errors_possible) check_device_flag(c);
-    std::memcpy(force_out, c->h_out.p + 3 * c->Dloc, c->Dloc * sizeof(double));
+    std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
     HC_API_END(c)
 }
 
@@ -1277,13 +1469,14 @@ int hc_step_device(hc_ctx* c, double t, const double* d_state, double* d_force_o
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(d_state && d_force_out, HC_ERR_INVALID, "null pointer");
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    if (c->have_prev && t == c->prev_time) {
+    if (c->have_prev_device && t == c->prev_time_device) {
         HC_HIP(hipMemcpyAsync(d_force_out, c->d_total.p, c->Dloc * sizeof(double), hipMemcpyDeviceToDevice, s));
         return HC_OK;
     }
-    c->prev_time = t;
-    c->have_prev = true;
+    c->have_prev = false;  // the host-side cache of hc_step does not hold this step
     enqueue_step(c, t, d_state, d_force_out, s, StepFlags{});
+    c->prev_time_device = t;
+    c->have_prev_device = true;
     HC_API_END(c)
 }
 
@@ -1302,6 +1495,8 @@ int hc_get_force_components(hc_ctx* c, double* hs, double* rad, double* waves) {
     HC_API_END(c)
 }
 
+// The three term-only entry points write to scratch outputs: the components and the cached total of the last full step
+// (hc_get_force_components, the duplicate-time cache) stay what that step left.
 int hc_compute_radiation(hc_ctx* c, double t, const double* linvel, const double* angvel, double* rad_out) {
     HC_API_BEGIN(c)
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
@@ -1310,8 +1505,9 @@ int hc_compute_radiation(hc_ctx* c, double t, const double* linvel, const double
     StepFlags f;
     f.hs = false;
     f.waves = false;
+    f.scratch_out = true;
     enqueue_step(c, t, c->d_state.p, nullptr, c->stream, f);
-    HC_HIP(hipMemcpyAsync(c->h_out.p + c->Dloc, c->d_rad.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipMemcpyAsync(c->h_out.p + c->Dloc, c->d_scratch.p + c->Dloc, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     check_device_flag(c);
     std::memcpy(rad_out, c->h_out.p + c->Dloc, c->Dloc * sizeof(double));
     HC_API_END(c)
@@ -1325,8 +1521,9 @@ int hc_compute_hydrostatics(hc_ctx* c, const double* pos, const double* rpy, dou
     StepFlags f;
     f.rad = false;
     f.waves = false;
+    f.scratch_out = true;
     enqueue_step(c, 0.0, c->d_state.p, nullptr, c->stream, f);
-    HC_HIP(hipMemcpyAsync(c->h_out.p, c->d_hs.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipMemcpyAsync(c->h_out.p, c->d_scratch.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));
     std::memcpy(hs_out, c->h_out.p, c->Dloc * sizeof(double));
     HC_API_END(c)
@@ -1340,8 +1537,9 @@ int hc_compute_waves(hc_ctx* c, double t, double* waves_out) {
     StepFlags f;
     f.hs = false;
     f.rad = false;
+    f.scratch_out = true;
     enqueue_step(c, t, c->d_state.p, nullptr, c->stream, f);
-    HC_HIP(hipMemcpyAsync(c->h_out.p + 2 * c->Dloc, c->d_waves.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipMemcpyAsync(c->h_out.p + 2 * c->Dloc, c->d_scratch.p + 2 * c->Dloc, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     check_device_flag(c);
     std::memcpy(waves_out, c->h_out.p + 2 * c->Dloc, c->Dloc * sizeof(double));
     HC_API_END(c)
@@ -1360,8 +1558,8 @@ int hc_reset_history(hc_ctx* c) {
     HC_HIP(hipDeviceSynchronize());  // steps may still be running on a caller's stream (hc_step_device)
     c->times.clear();
     c->head = -1;
-    c->have_prev = false;
-    c->prev_time = -1.0;
+    c->have_prev = c->have_prev_device = false;
+    c->prev_time = c->prev_time_device = -1.0;
     c->plan = hc::Plan{};
     HC_API_END(c)
 }
@@ -1389,8 +1587,10 @@ int hc_set_history(hc_ctx* c, int n, const double* times, const double* vel) {
     HC_HIP(hipStreamSynchronize(c->stream));  // tt / vv are released on return
     c->head      = n - 1;
     c->plan      = hc::Plan{};
-    c->have_prev = n > 0;
-    c->prev_time = n > 0 ? times[0] : -1.0;
+    // No step has been evaluated at times[0], so the per-time cache holds nothing (a step at exactly that time is the
+    // reference's duplicate-time error, raised by the history push).
+    c->have_prev = c->have_prev_device = false;
+    c->prev_time = c->prev_time_device = -1.0;
     HC_API_END(c)
 }
 
@@ -1426,15 +1626,20 @@ int hc_added_mass_mv(hc_ctx* c, const double* w, double cc, double* R, int n_sys
     require(w && R, HC_ERR_INVALID, "null pointer");
     require(n_sys >= c->D, HC_ERR_INVALID, "system has fewer coordinates than the added-mass block");
     const int row0 = 6 * c->b0;
-    std::memcpy(c->h_state.p, w, c->D * sizeof(double));
-    std::memcpy(c->h_out.p, R + row0, c->Dloc * sizeof(double));
-    HC_HIP(hipMemcpyAsync(c->d_vec_w.p, c->h_state.p, c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HC_HIP(hipMemcpyAsync(c->d_vec_R.p, c->h_out.p, c->Dloc * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    hc::launch_added_mass_mv(c->d_ainf.p, c->Dloc, c->D, c->d_vec_w.p, cc, c->d_vec_R.p, c->stream);
+    // Staging buffers and a stream of its own: Chrono's integrator calls this between force evaluations, while kernels of the
+    // last hc_step may still be reading the pinned state buffer and the work that step left for later steps (scatter,
+    // look-ahead pass) is still running on the context's stream -- the product does not wait for it.
+    double* hw = c->h_am.p;
+    double* hr = c->h_am.p + c->D;
+    std::memcpy(hw, w, c->D * sizeof(double));
+    std::memcpy(hr, R + row0, c->Dloc * sizeof(double));
+    HC_HIP(hipMemcpyAsync(c->d_vec_w.p, hw, c->D * sizeof(double), hipMemcpyHostToDevice, c->stream_am));
+    HC_HIP(hipMemcpyAsync(c->d_vec_R.p, hr, c->Dloc * sizeof(double), hipMemcpyHostToDevice, c->stream_am));
+    hc::launch_added_mass_mv(c->d_ainf.p, c->Dloc, c->D, c->d_vec_w.p, cc, c->d_vec_R.p, c->stream_am);
     HC_HIP(hipGetLastError());
-    HC_HIP(hipMemcpyAsync(c->h_out.p, c->d_vec_R.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HC_HIP(hipStreamSynchronize(c->stream));
-    std::memcpy(R + row0, c->h_out.p, c->Dloc * sizeof(double));
+    HC_HIP(hipMemcpyAsync(hr, c->d_vec_R.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream_am));
+    HC_HIP(hipStreamSynchronize(c->stream_am));
+    std::memcpy(R + row0, hr, c->Dloc * sizeof(double));
     HC_API_END(c)
 }
 
@@ -1459,10 +1664,11 @@ int hc_get_profile(hc_ctx* c, hc_profile_stats* out) {
 int hc_reset_profile(hc_ctx* c) {
     HC_API_BEGIN(c)
     profile_drain(c);
-    const double bytes = c->prof.conv_kernel_bytes, bbytes = c->prof.block_kernel_bytes;
+    const double bytes = c->prof.conv_kernel_bytes, bbytes = c->prof.block_kernel_bytes, obytes = c->prof.block_kernel_bytes_once;
     c->prof = hc_profile_stats{};
-    c->prof.conv_kernel_bytes  = bytes;
-    c->prof.block_kernel_bytes = bbytes;
+    c->prof.conv_kernel_bytes       = bytes;
+    c->prof.block_kernel_bytes      = bbytes;
+    c->prof.block_kernel_bytes_once = obytes;
     HC_API_END(c)
 }
 

@@ -69,7 +69,7 @@ struct PinnedBuffer {
         p = nullptr;
         n = 0;
         if (count == 0) return;
-        HC_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocMapped));
+        HC_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent));
         HC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dp), p, 0));
         n = count;
     }
@@ -89,20 +89,35 @@ struct BodyHost {
 
 enum WaveKind { kWaveNone = 0, kWaveRegular = 1, kWaveIrregular = 2, kWaveSpectral = 3 };
 
-struct EventSet {
-    hipEvent_t e[4];  // 0 start, 1 after the per-step convolution launch, 2 after finalize, 3 right after the look-ahead kernel
-    int kind = 0;  // 0 plain step, 1 look-ahead boundary step, 2 step inside a look-ahead block
+// One timed kernel launch (HIP events before / after it on the stream it was launched on).
+enum EventKind { kEvConvPlain = 0, kEvPass = 1, kEvStep = 2, kEvScatter = 3, kEvConvExc = 4 };
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind = 0;
+    double waves_share = 0.0;  // share of the launch that is excitation work (by algorithmic bytes)
 };
 
-// Look-ahead plan: a blocked pass at time t0 has precomputed, for the predicted steps tpred[j] = t0 + j*dt, the part of
-// the radiation sum that only needs history known at t0 (IRF samples s >= s_cut[j]).
+// Look-ahead plan (scatter form, see hc_kernels.hpp).  Made right after a step at time tgrid[0] has been enqueued: the
+// block covers the next 16 predicted steps tgrid[j] = tgrid[0] + j*dt.  The pass launched with the plan has computed, for
+// each block step, what the samples known at planning time contribute; the tables below say what each block step adds.
 struct Plan {
     bool valid = false;
-    double t0 = 0.0, dt = 0.0;
-    int j_next = 0;
-    double tpred[kLookahead] = {0};
-    int s_cut[kLookahead]    = {0};
-    int s_defer[kLookahead]  = {0};  // sample whose "is there an older history sample" test is too close to call ahead of time (-1: none)
+    double dt = 0.0;
+    int j_next = 1;                       // next block step, 1..16
+    double tgrid[kLookahead + 1] = {0};
+    int s_cut[kLookahead]    = {0};       // pass: block step j+1 takes IRF samples s >= s_cut[j]
+    int s_defer[kLookahead]  = {0};       // IRF sample whose "is there an older history sample" test is too close to call ahead of time (-1: none)
+    // block step m = 1..16 (index m): IRF samples involving the step's own sample (weight x width) ...
+    int n_own[kLookahead + 1] = {0};
+    int own_s[kLookahead + 1][kNearMax];
+    double own_a[kLookahead + 1][kNearMax];
+    // ... and the scatter results of earlier block steps it adds: coef * Y[slot][s]
+    int n_terms[kLookahead + 1] = {0};
+    int term_slot[kLookahead + 1][kTermMax];
+    int term_s[kLookahead + 1][kTermMax];
+    double term_coef[kLookahead + 1][kTermMax];
+    // scatter launched after block step i covers IRF samples [scat_lo[i], scat_hi[i]] (hi < lo: nothing)
+    int scat_lo[kLookahead + 1] = {0}, scat_hi[kLookahead + 1] = {0};
     int misses = 0, cooldown = 0;
     bool has_exc = false;  // the pass also left the excitation force of the 16 predicted times (E rows)
 };
@@ -112,6 +127,7 @@ struct Plan {
 struct hc_ctx {
     int N = 0, b0 = 0, b1 = 0, nloc = 0, D = 0, Dloc = 0, device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_am = nullptr;  // added-mass products (independent of the step kernels)
     std::string err;
 
     bool have_sim = false;
@@ -133,8 +149,8 @@ struct hc_ctx {
     std::deque<double> times;
     int head = -1, Hcap = 0;
     hc::DeviceBuffer<double> d_ring_t, d_ring_v;
-    bool have_prev = false;
-    double prev_time = -1.0;
+    bool have_prev = false, have_prev_device = false;  // per-time cache of hc_step (host totals) / hc_step_device (d_total)
+    double prev_time = -1.0, prev_time_device = -1.0;
 
     // hydrostatics / added mass
     hc::DeviceBuffer<double> d_lin, d_cg, d_cbmcg, d_vol, d_ainf, d_vec_w, d_vec_R;
@@ -157,8 +173,10 @@ struct hc_ctx {
 
     // GEMV configuration + scratch
     int chunk_gp = 0, nchunks_rad = 0, chunk_gp_ex = 0, nchunks_ex = 0, ngp_ex = 0;
-    int chunk_gp_block = 0, nchunks_block = 0, chunk_gp_rem = 64;
+    int chunk_gp_block = 0, nchunks_block = 0;
     hc::DeviceBuffer<double> d_partials, d_partials_block, d_P, d_E;
+    hc::DeviceBuffer<double> d_Y;           // scatter results [kLookahead][kScatterSamples][Dpad]
+    hc::DeviceBuffer<double> d_zero_state;  // 12N zeros: the not-yet-known sample of the look-ahead pass
     int chunk_gp_ex_block = 32, nchunks_ex_block = 0;  // excitation chunks of the look-ahead launch
     int mt_block = 4;                                   // row tiles per workgroup of the look-ahead launch (1, 2, 4 or 6)
     int num_cus  = 256;                                 // compute units of the device (grid rounds of the look-ahead launch)
@@ -167,8 +185,13 @@ struct hc_ctx {
 
     // step I/O
     hc::DeviceBuffer<double> d_state, d_hs, d_rad, d_waves, d_total;
+    hc::DeviceBuffer<double> d_scratch;  // [4][Dloc] outputs of the term-only entry points (they must not clobber the last step)
     hc::DeviceBuffer<int> d_err;
-    hc::PinnedBuffer<double> h_state, h_out;
+    hc::PinnedBuffer<double> h_state, h_out, h_am;
+    hc::PinnedBuffer<unsigned long long> h_tag;  // [Dloc][2] {total, sequence number} granules written by finalize_kernel
+    unsigned long long seq = 0;
+    std::vector<double> last_total;               // totals of the last evaluated step (duplicate-time cache of hc_step)
+    int zero_copy_max_bodies = 64;                // hc_step: kernels read the state from mapped pinned memory up to this size
     hc::PinnedBuffer<int> h_err;
     bool device_errors_possible = false;  // radiation IRF times < 0 (the only way a per-step query can leave its bracket)
 
@@ -176,7 +199,8 @@ struct hc_ctx {
     bool profiling = false;
     int profile_stride = 1;
     long long profile_counter = 0;
-    std::vector<hc::EventSet> events;
+    std::vector<hc::EventPair> events;
     size_t events_used = 0;
+    bool sample_this_step = false;
     hc_profile_stats prof{};
 };

@@ -203,7 +203,7 @@ __device__ __forceinline__ double eta_at(const EtaTable& a, double t, int j, int
 //   from two ring loads (L2 hits); excitation -- eta(t - tau_j), linearly interpolated in the precomputed table
 //   (src/wave_types.cpp:797-831), times width_j.  The streaming loop then only reads K and two LDS words per 16 bytes.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int U, bool NT>
+template <int MT, int U>
 __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     // dynamic LDS: right-hand side of the chunk [chunk columns], then the bracket table [samples] + widths
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -227,19 +227,10 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     // column groups [gp0, gp1) of this chunk and, for radiation, its valid column range [c0, c1)
     int gp0, gp1, c0 = 0, c1 = 0;
     if (radiation) {
-        int lo, hi;
-        if (chunk < a.nchunks_rad1) {
-            lo  = 0;
-            hi  = a.F_limit;
-            gp0 = chunk * a.chunk_gp;
-        } else {
-            lo  = a.F2_lo;
-            hi  = a.F2_hi;
-            gp0 = (a.F2_lo >> 3) + (chunk - a.nchunks_rad1) * a.chunk_gp;
-        }
-        gp1 = min((hi + 7) >> 3, gp0 + a.chunk_gp);
-        c0  = max(lo, gp0 * 8);
-        c1  = min(hi, gp1 * 8);
+        gp0 = chunk * a.chunk_gp;
+        gp1 = min((a.F_limit + 7) >> 3, gp0 + a.chunk_gp);
+        c0  = gp0 * 8;
+        c1  = min(a.F_limit, gp1 * 8);
     } else {
         gp0 = (chunk - a.nchunks_rad) * a.chunk_gp_ex;
         gp1 = min(a.Kex.ngp, gp0 + a.chunk_gp_ex);
@@ -247,56 +238,23 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     const double* __restrict__ kbase = M.base + ((size_t)(grp * MT) * M.ngp) * 128 + lane * 2;
     const size_t tile_stride = (size_t)M.ngp * 128;
 
-    // Latency-bound variant (short chunks of a look-ahead step): put the wave's first K words in flight before the
-    // right-hand side is staged, so the two round trips overlap instead of adding up.
-    constexpr int PRE = NT ? 0 : 2;
-    dvec2 pre[PRE > 0 ? PRE : 1][MT];
-    if constexpr (PRE > 0) {
-#pragma unroll
-        for (int i = 0; i < PRE; ++i) {
-            const int gp = gp0 + wave + 4 * i;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                pre[i][m] = gp < gp1 ? *reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128) : dvec2{0.0, 0.0};
-        }
-    }
-
     if (radiation) {
         // ---- stage u[f] = interp(v_col)(t - tau_s) * width_s for the chunk's columns ----
         const int D = a.hist.D;
         const int s0 = c0 / D;
         const int ns = (c1 - 1) / D - s0 + 1;
-        const bool first_range = chunk < a.nchunks_rad1;
-        const bool from_host   = first_range ? (s0 + ns <= a.hb_n) : (a.hb_defer_valid != 0);
-        if (!NT && ns == 1 && from_host) {
-            // short chunk inside one IRF sample whose bracket came with the launch: the bracket is workgroup-uniform
-            // (scalar loads from the argument block), so no table, no barrier -- the ring loads go out at once
-            const Bracket b = first_range ? a.hb[s0] : a.hb_defer;
-            const double w  = a.width[s0];
-            for (int f = gp0 * 8 + tid; f < gp1 * 8; f += kConvThreads) {
-                double u = 0.0;
-                if (f >= c0 && f < c1) {
-                    const int col = f - s0 * D;
-                    u = interp_velocity(a.hist, b, col, state_velocity(a.hist.state, a.hist.N, col)) * w;
-                }
-                rhs[f - gp0 * 8] = u;
+        for (int k = tid; k < ns; k += kConvThreads) {
+            tab[k]  = find_bracket(a.hist, a.hist.t - a.tau[s0 + k], a.error_flag);
+            wtab[k] = a.width[s0 + k];
+        }
+        __syncthreads();
+        for (int f = gp0 * 8 + tid; f < gp1 * 8; f += kConvThreads) {
+            double u = 0.0;
+            if (f >= c0 && f < c1) {
+                const int s = f / D, col = f - s * D;
+                u = interp_velocity(a.hist, tab[s - s0], col, state_velocity(a.hist.state, a.hist.N, col)) * wtab[s - s0];
             }
-        } else {
-            for (int k = tid; k < ns; k += kConvThreads) {
-                if (first_range && s0 + k < a.hb_n) tab[k] = a.hb[s0 + k];
-                else if (!first_range && a.hb_defer_valid) tab[k] = a.hb_defer;
-                else tab[k] = find_bracket(a.hist, a.hist.t - a.tau[s0 + k], a.error_flag);
-                wtab[k] = a.width[s0 + k];
-            }
-            __syncthreads();
-            for (int f = gp0 * 8 + tid; f < gp1 * 8; f += kConvThreads) {
-                double u = 0.0;
-                if (f >= c0 && f < c1) {
-                    const int s = f / D, col = f - s * D;
-                    u = interp_velocity(a.hist, tab[s - s0], col, state_velocity(a.hist.state, a.hist.N, col)) * wtab[s - s0];
-                }
-                rhs[f - gp0 * 8] = u;
-            }
+            rhs[f - gp0 * 8] = u;
         }
     } else {
         // ---- stage e[j] = eta(t - tau_j) * width_j ----
@@ -307,31 +265,13 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     double acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = 0.0;
-    if constexpr (PRE > 0) {
-#pragma unroll
-        for (int i = 0; i < PRE; ++i) {
-            const int gp = gp0 + wave + 4 * i;
-            if (gp < gp1) {
-                const double u0 = rhs[(gp - gp0) * 8 + kk], u1 = rhs[(gp - gp0) * 8 + 4 + kk];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    acc[m] = fma(pre[i][m].x, u0, acc[m]);
-                    acc[m] = fma(pre[i][m].y, u1, acc[m]);
-                }
-            }
-        }
-    }
 #pragma unroll U
-    for (int gp = gp0 + wave + 4 * PRE; gp < gp1; gp += 4) {
+    for (int gp = gp0 + wave; gp < gp1; gp += 4) {
         dvec2 kv[MT];
-        // a matrix streamed exactly once per step uses non-temporal loads (keeps the ring in L2); the short remainder
-        // of a look-ahead step re-reads the same newest-sample columns every step, so it uses normal loads and stays cached
+        // a matrix streamed exactly once per step uses non-temporal loads (keeps the ring in L2)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const dvec2* src = reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128);
-            if constexpr (NT) kv[m] = __builtin_nontemporal_load(src);
-            else kv[m] = *src;
-        }
+        for (int m = 0; m < MT; ++m)
+            kv[m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gp * 128));
         const double u0 = rhs[(gp - gp0) * 8 + kk], u1 = rhs[(gp - gp0) * 8 + 4 + kk];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -356,13 +296,9 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
 
 template <int MT>
 static void launch_conv_step_mt(const StepArgs& a, int unroll, int nblocks, size_t smem, hipStream_t stream) {
-    if (!a.stream_once) {  // remainder of a look-ahead step: cacheable loads, latency-bound, no unroll variants needed
-        hipLaunchKernelGGL((conv_step_kernel<MT, 2, false>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-        return;
-    }
-    if (unroll == 1) hipLaunchKernelGGL((conv_step_kernel<MT, 1, true>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-    else if (unroll == 3) hipLaunchKernelGGL((conv_step_kernel<MT, 3, true>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-    else hipLaunchKernelGGL((conv_step_kernel<MT, 2, true>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    if (unroll == 1) hipLaunchKernelGGL((conv_step_kernel<MT, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    else if (unroll == 3) hipLaunchKernelGGL((conv_step_kernel<MT, 3>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+    else hipLaunchKernelGGL((conv_step_kernel<MT, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
 }
 
 void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
@@ -538,6 +474,184 @@ __device__ __forceinline__ void block_work(const BlockArgs& a, const int chunk, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Radiation work item of the look-ahead pass as a rolling software pipeline (round 2).  The wave keeps R column groups
+// ("fragments": MT 16-byte K words + the four ring values of its two B operands) in flight at all times: in every step
+// of the loop it waits for the oldest fragment only (a counted vmcnt), forms the two B operands in registers
+//     u = wo' * ring[off_older + col] + wn' * ring[off_newer + col]        (wo', wn' = weights x trapezoid width),
+// issues 2*MT MFMAs and immediately re-fills the freed registers with the fragment R groups ahead -- so the wave has
+// loads outstanding while its MFMAs run, and nothing of the right-hand side goes through LDS inside the loop.  Each lane
+// gathers exactly its own B operands (column 8gp + kk (+4), step j = lane & 15); the bracket of (IRF sample, step) comes
+// from a table in LDS built once per workgroup.  The not-yet-known sample of the pass is zero (hc_api.cpp: launch_pass),
+// so a bracket whose newer end is that sample simply gets wn' = 0.
+//   UNI: D % 8 == 0 -- a column group never straddles two IRF samples, the sample index is wave-uniform and the bracket
+//        registers are reloaded only when it changes.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int R, bool UNI>
+__device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int chunk, const int grp, double* red, double* t_wo, double* t_wn,
+                                                 int* t_oo, int* t_on) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kk = lane >> 4, jstep = lane & 15;
+    const int D = a.hist.D;
+    const int gp0 = chunk * a.chunk_gp;
+    const int gp1 = min((a.F + 7) >> 3, gp0 + a.chunk_gp);
+    const int s0  = (gp0 * 8) / D;
+    const int ns  = (min(a.F, gp1 * 8) - 1) / D - s0 + 1;
+    const int s_live = a.F / D;  // F is a whole number of samples
+    for (int idx = tid; idx < ns * kLookahead; idx += kConvThreads) {
+        const int k = idx >> 4, j = idx & 15, s = s0 + k;
+        Bracket b;
+        b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
+        if (s >= a.s_cut[j] && s != a.s_defer[j] && s < s_live) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
+        const double w = a.width[s < s_live ? s : 0];
+        t_wo[idx] = b.wo * w;
+        t_wn[idx] = (b.off_newer >= 0) ? b.wn * w : 0.0;
+        t_oo[idx] = b.off_older;
+        t_on[idx] = max(b.off_newer, 0);
+    }
+    __syncthreads();
+
+    dvec4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = dvec4{0.0, 0.0, 0.0, 0.0};
+    const double* __restrict__ kbase = a.K.base + ((size_t)(grp * MT) * a.K.ngp) * 128 + lane * 2;
+    const size_t tile_stride         = (size_t)a.K.ngp * 128;
+    const double* __restrict__ ring  = a.hist.ring_v;
+
+    // pipeline registers
+    dvec2 kv[R][MT];
+    double vo[R][2], vn[R][2], wo_[R][2], wn_[R][2];
+    // issue-side position: column group gp_i of this wave and the (sample, column) of its first column per half
+    int gp_i = gp0 + wave;
+    // trackers of the two columns of a lane (half 0: 8gp + kk, half 1: 8gp + 4 + kk): IRF sample and column inside it.
+    // UNI: both halves of all lanes are in sample s_u, the group's first column is column cb_u of it (wave-uniform).
+    int s_t[2], c_t[2];
+    int s_u = (gp_i * 8) / D, cb_u = gp_i * 8 - s_u * D;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int f = gp_i * 8 + 4 * h + kk;
+        s_t[h] = UNI ? s_u : f / D;
+        c_t[h] = f - s_t[h] * D;
+    }
+    double bwo[2], bwn[2];
+    int boo[2], bon[2];
+    auto load_bracket = [&](int h) {
+        const int k = min(max(s_t[h] - s0, 0), ns - 1) * kLookahead + jstep;
+        bwo[h] = t_wo[k];
+        bwn[h] = t_wn[k];
+        boo[h] = t_oo[k];
+        bon[h] = t_on[k];
+    };
+    load_bracket(0);
+    if constexpr (UNI) {
+        bwo[1] = bwo[0]; bwn[1] = bwn[0]; boo[1] = boo[0]; bon[1] = bon[0];
+    } else {
+        load_bracket(1);
+    }
+
+    auto issue = [&](const int slot) {
+        // Unconditional: every call issues the same MT + 4 loads, so the compiler's vmcnt bookkeeping stays exact (a
+        // branch around the loads degrades every wait in the loop to "all but a few").  Past the end of the chunk the
+        // wave re-reads its last column group with zero weights.
+        const bool live = gp_i < gp1;
+        const int gpc   = live ? gp_i : gp1 - 1;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            kv[slot][m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gpc * 128));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            vo[slot][h]  = ring[boo[h] + c_t[h]];
+            vn[slot][h]  = ring[bon[h] + c_t[h]];
+            wo_[slot][h] = live ? bwo[h] : 0.0;
+            wn_[slot][h] = live ? bwn[h] : 0.0;
+        }
+        // advance to this wave's next column group (32 columns on)
+        gp_i += 4;
+        if constexpr (UNI) {
+            cb_u += 32;
+            if (cb_u >= D) {  // scalar branch
+                do {
+                    cb_u -= D;
+                    ++s_u;
+                } while (cb_u >= D);
+                s_t[0] = s_u;
+                load_bracket(0);
+                bwo[1] = bwo[0]; bwn[1] = bwn[0]; boo[1] = boo[0]; bon[1] = bon[0];
+            }
+            c_t[0] = cb_u + kk;
+            c_t[1] = cb_u + 4 + kk;
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                c_t[h] += 32;
+                while (c_t[h] >= D) {
+                    c_t[h] -= D;
+                    ++s_t[h];
+                }
+                load_bracket(h);
+            }
+        }
+    };
+    auto consume = [&](const int slot) {
+        const double u0 = wo_[slot][0] * vo[slot][0] + wn_[slot][0] * vn[slot][0];
+        const double u1 = wo_[slot][1] * vo[slot][1] + wn_[slot][1] * vn[slot][1];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[slot][m].x, u0, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[slot][m].y, u1, acc[m], 0, 0, 0);
+    };
+
+    const int nfrag = (gp1 - gp0 - wave + 3) / 4;  // column groups of this wave
+#pragma unroll
+    for (int r = 0; r < R; ++r) issue(r);
+    for (int i = 0; i < nfrag; i += R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            consume(r);
+            issue(r);
+        }
+    }
+
+    __syncthreads();
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg.  red[wave][m][row*16 + j].
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((size_t)wave * MT + m) * 256 + (kk + 4 * r) * 16 + jstep] = acc[m][r];
+    __syncthreads();
+    for (int idx = tid; idx < MT * 256; idx += kConvThreads) {
+        const int m = idx >> 8, el = idx & 255, row = el >> 4, j = el & 15;
+        const double v = ((red[(0 * MT + m) * 256 + el] + red[(1 * MT + m) * 256 + el]) + red[(2 * MT + m) * 256 + el]) + red[(3 * MT + m) * 256 + el];
+        a.partials[((size_t)chunk * kLookahead + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
+    }
+}
+
+template <int MT, int R>
+__global__ void __launch_bounds__(kConvThreads, 2) conv_block_kernel2(BlockArgs a) {
+    // dynamic LDS: [front: cross-wave reduction buffer / U tiles of the excitation items][bracket table, SoA: wo', wn', off_older, off_newer]
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double* front = reinterpret_cast<double*>(smem_raw);
+    const int nt  = a.max_steps_per_chunk * kLookahead;
+    double* t_wo  = front + a.lds_front_doubles;
+    double* t_wn  = t_wo + nt;
+    int* t_oo     = reinterpret_cast<int*>(t_wn + nt);
+    int* t_on     = t_oo + nt;
+
+    const int r     = (int)blockIdx.x % (8 * a.ngroups);
+    const int chunk = ((int)blockIdx.x / (8 * a.ngroups)) * 8 + (r & 7);
+    const int grp   = r >> 3;
+    if (chunk >= a.nchunks) return;
+
+    if ((a.hist.D & 7) == 0) block_rad_stream<MT, R, true>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+    else block_rad_stream<MT, R, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+    // excitation chunks for the 16 predicted times ride at the end of radiation workgroups (old LDS-staged form; 0.3 % of the work)
+    for (int e = chunk; e < a.nchunks_ex; e += a.nchunks) {
+        __syncthreads();
+        block_work<MT, false>(a, chunk, grp, e, front, nullptr, nullptr);
+    }
+}
+
 template <int MT>
 __global__ void __launch_bounds__(kConvThreads, 2) conv_block_kernel(BlockArgs a) {
     // dynamic LDS: per-wave U sub-tiles [4][16][34] (re-used as the cross-wave reduction buffer at the end),
@@ -568,15 +682,28 @@ void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
     const int nblocks = ((a.nchunks + 7) >> 3) * 8 * a.ngroups;  // octets of chunks, see the kernel's block mapping
     if (nblocks <= 0) return;
     BlockArgs b = a;
-    static const int ablate = [] { const char* e = std::getenv("HC_BLOCK_ABLATE"); return e ? std::atoi(e) : 0; }();
+    static const int ablate  = [] { const char* e = std::getenv("HC_BLOCK_ABLATE"); return e ? std::atoi(e) : 0; }();
+    static const int version = [] { const char* e = std::getenv("HC_BLOCK_KERNEL"); return e ? std::atoi(e) : 2; }();  // 1: round-1 kernel (A/B runs)
     b.ablate = ablate;
     b.lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // per-wave U sub-tiles, later the [wave][tile][16x16] reduction buffer
-    const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) +
-                        (size_t)max(1, a.max_steps_per_chunk) * (kLookahead * sizeof(Bracket) + sizeof(double));
-    if (mt == 6) hipLaunchKernelGGL((conv_block_kernel<6>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-    else if (mt == 4) hipLaunchKernelGGL((conv_block_kernel<4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-    else if (mt == 2) hipLaunchKernelGGL((conv_block_kernel<2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-    else hipLaunchKernelGGL((conv_block_kernel<1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    if (version == 1) {
+        const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) +
+                            (size_t)max(1, a.max_steps_per_chunk) * (kLookahead * sizeof(Bracket) + sizeof(double));
+        if (mt == 6) hipLaunchKernelGGL((conv_block_kernel<6>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+        else if (mt == 4) hipLaunchKernelGGL((conv_block_kernel<4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+        else if (mt == 2) hipLaunchKernelGGL((conv_block_kernel<2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+        else hipLaunchKernelGGL((conv_block_kernel<1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+        return;
+    }
+    const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * kLookahead * 24;
+    static const int depth = [] { const char* e = std::getenv("HC_BLOCK_DEPTH"); return e ? std::atoi(e) : 3; }();  // fragments in flight per wave
+    if (mt == 6) {
+        if (depth == 2) hipLaunchKernelGGL((conv_block_kernel2<6, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+        else if (depth == 4) hipLaunchKernelGGL((conv_block_kernel2<6, 4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+        else hipLaunchKernelGGL((conv_block_kernel2<6, 3>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    } else if (mt == 4) hipLaunchKernelGGL((conv_block_kernel2<4, 4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    else if (mt == 2) hipLaunchKernelGGL((conv_block_kernel2<2, 4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    else hipLaunchKernelGGL((conv_block_kernel2<1, 4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
 }
 
 __device__ __forceinline__ double lane16_sum(double v) {
@@ -617,12 +744,23 @@ void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_
 }
 
 // ------------------------------------------------------------------------------------------------
-// finalize_kernel: 16 lanes per owned output row (16 rows per 256-thread workgroup).  Lane l adds the partials of
-// chunks l, l+16, ... in ascending order, a 4-step xor-shuffle tree adds the 16 lane sums -- a fixed order, so the
-// result is bitwise reproducible -- then lane 0 of the row adds the look-ahead part, hydrostatics / the regular-wave
-// term and writes.  One extra workgroup stores this step's sample into the ring.
+// finalize_kernel (the "step kernel"): one workgroup per tile of 16 owned output rows (+ one that stores this step's
+// sample into the ring).  It finishes a step whichever way its radiation term was prepared:
+//   plain step          16 lanes per row add the chunk partials of conv_step_kernel in a fixed order;
+//   step inside a block the workgroup contracts the few IRF samples that involve this step's own sample itself (its 16
+//                       rows x n_near * D columns of K, right-hand side staged in LDS once -- row-owned, so nothing is
+//                       left to reduce across workgroups), adds the look-ahead part P and the scatter results of the
+//                       earlier steps of the block: the step is this ONE launch;
+// then hydrostatics / the regular-wave or spectral term, total = hydrostatic - radiation + waves (src/hydro_forces.cpp:
+// 263-322,758-760; src/wave_types.cpp:315-327).  All sums run in a fixed order (bitwise reproducible).  For the host
+// boundary the totals also leave as 16-byte {value, sequence} granules in mapped pinned memory.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double* U = reinterpret_cast<double*>(smem_raw);  // [n_near][D] right-hand sides of the near samples
+    __shared__ double red_near[4][16];
+    __shared__ double red_term[4][16];
+
     if (a.do_push && blockIdx.x == gridDim.x - 1) {
         // nobody reads ring slot `head` during this step (the current sample is always taken from `state`)
         if (threadIdx.x == 0) a.ring_t[a.head] = a.t;
@@ -630,8 +768,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         for (int c = threadIdx.x; c < a.D; c += blockDim.x) slot[c] = state_velocity(a.state, a.N, c);
         return;
     }
-    const int sub = threadIdx.x & 15;
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub  = tid & 15;
+    const int rit  = tid >> 4;  // row inside the tile
+    const int row  = blockIdx.x * 16 + rit;
     const bool live = row < a.Dloc;
     const int rrow  = live ? row : 0;
 
@@ -652,8 +793,8 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         }
         return acc;
     };
-    // what lane 0 of the row needs besides the partial sums is requested first, so that those loads are in flight
-    // together with the partials instead of after them
+    // what lane 0 of the row needs besides the sums is requested first, so that those loads are in flight together with
+    // everything else instead of after it
     const int bl = rrow / 6, i = rrow - 6 * bl;  // local body, DoF
     const int b  = a.b0 + bl;                    // global body
     const bool finisher = live && sub == 0;
@@ -677,26 +818,81 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         }
     }
 
+    const bool near_on = a.do_rad && a.n_near > 0, term_on = a.do_rad && a.n_terms > 0;
+    if (near_on) {
+        // ---- the IRF samples this step contracts itself: rows of this tile x [s*D, (s+1)*D) ----
+        const int D  = a.D;
+        const int kk = lane >> 4;
+        const double* __restrict__ kbase = a.nearK.base + ((size_t)blockIdx.x * a.nearK.ngp) * 128 + lane * 2;
+        // the first K words are requested before the right-hand side is staged: the two round trips overlap
+        constexpr int PRE = 4;
+        const int f0_0 = a.near[0].s * D, g0_0 = f0_0 >> 3, g1_0 = (f0_0 + D + 7) >> 3;
+        dvec2 pre[PRE];
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+            const int gp = g0_0 + wave + 4 * q;
+            pre[q] = gp < g1_0 ? *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128) : dvec2{0.0, 0.0};
+        }
+        for (int e = 0; e < a.n_near; ++e) {
+            const NearEntry& ne = a.near[e];
+            for (int col = tid; col < D; col += 256) {
+                double u = 0.0;
+                if (ne.a != 0.0) u = ne.a * state_velocity(a.state, a.N, col);
+                if (ne.b != 0.0) u = fma(ne.b, a.ring_v_ro[ne.off_b + col], u);
+                if (ne.c != 0.0) u = fma(ne.c, a.ring_v_ro[ne.off_c + col], u);
+                U[e * D + col] = u;
+            }
+        }
+        __syncthreads();
+        double acc = 0.0;
+        for (int e = 0; e < a.n_near; ++e) {
+            const int f0 = a.near[e].s * D, f1 = f0 + D;
+            const int g0 = f0 >> 3, g1 = (f1 + 7) >> 3;
+            const double* __restrict__ u = U + e * D - f0;
+            int gp = g0 + wave;
+            if (e == 0) {
+#pragma unroll
+                for (int q = 0; q < PRE; ++q, gp += 4) {
+                    if (gp < g1) {
+                        const int fa = gp * 8 + kk, fb = fa + 4;
+                        const double u0 = (fa >= f0 && fa < f1) ? u[fa] : 0.0, u1 = (fb >= f0 && fb < f1) ? u[fb] : 0.0;
+                        acc = fma(pre[q].x, u0, acc);
+                        acc = fma(pre[q].y, u1, acc);
+                    }
+                }
+            }
+#pragma unroll 4
+            for (; gp < g1; gp += 4) {
+                const dvec2 kv = *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128);
+                const int fa = gp * 8 + kk, fb = fa + 4;
+                const double u0 = (fa >= f0 && fa < f1) ? u[fa] : 0.0, u1 = (fb >= f0 && fb < f1) ? u[fb] : 0.0;
+                acc = fma(kv.x, u0, acc);
+                acc = fma(kv.y, u1, acc);
+            }
+        }
+        acc += __shfl_xor(acc, 16, kWave);
+        acc += __shfl_xor(acc, 32, kWave);
+        if (lane < 16) red_near[wave][lane] = acc;
+    }
+    if (term_on) {
+        // ---- scatter results of the earlier steps of the block: wave w adds terms w, w+4, ... (wave-uniform table reads
+        //      from the argument block), lanes 0..15 = the rows of the tile ----
+        double tacc = 0.0;
+        if (lane < 16) {
+            const double* __restrict__ y = a.Y + blockIdx.x * 16 + lane;
+#pragma unroll 4
+            for (int k = wave; k < a.n_terms; k += 4) tacc = fma(a.term_coef[k], y[a.term_off[k]], tacc);
+            red_term[wave][lane] = tacc;
+        }
+    }
+    if (near_on || term_on) __syncthreads();
+
     double rad = 0.0, wav = 0.0;
     if (a.do_rad) {
-        if (a.rem_F > 0) {
-            // small system inside a look-ahead block: the few newest-sample columns are contracted right here (lane `sub`
-            // takes columns sub, sub+16, ...), so the step is this one launch
-            const int Dh = a.hist.D;
-            const double* __restrict__ krow = a.remK.base + ((size_t)(rrow >> 4) * a.remK.ngp) * 128 + (rrow & 15) * 2;
-            double acc = 0.0;
-#pragma unroll 4
-            for (int f = sub; f < a.rem_F; f += 16) {
-                const int s_ = f / Dh, col = f - s_ * Dh;
-                const double u = interp_velocity(a.hist, a.hb[s_], col, state_velocity(a.hist.state, a.hist.N, col)) * a.width[s_];
-                const double k = krow[(size_t)(f >> 3) * 128 + (f & 3) * 32 + ((f & 7) >> 2)];
-                acc = fma(k, u, acc);
-            }
-            rad = lane16_sum(acc);
-        } else {
-            rad = lane16_sum(lane_sum(0, a.nchunks_rad));
-        }
+        if (a.nchunks_rad > 0) rad = lane16_sum(lane_sum(0, a.nchunks_rad));
         if (a.P) rad = p_row + rad;
+        if (term_on) rad += ((red_term[0][rit] + red_term[1][rit]) + red_term[2][rit]) + red_term[3][rit];
+        if (near_on) rad += ((red_near[0][rit] + red_near[1][rit]) + red_near[2][rit]) + red_near[3][rit];
     }
     if (a.do_waves && a.wave_mode == 2) wav = a.E ? e_row : lane16_sum(lane_sum(a.nchunks_rad, a.nchunks_ex));
     if (a.do_waves && a.wave_mode == 3) {
@@ -740,10 +936,87 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     a.waves[row] = wav;
     a.total[row] = total;
     if (a.user_out) a.user_out[row] = total;
+    if (a.host_tagged) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u64x2*>(a.host_tagged + 2 * (size_t)row) = u64x2{(unsigned long long)__double_as_longlong(total), a.seq};
+    }
 }
 
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(finalize_kernel, dim3((a.Dloc + 15) / 16 + (a.do_push ? 1 : 0)), dim3(256), 0, stream, a);
+    const size_t smem = (size_t)max(0, a.n_near) * a.D * sizeof(double);
+    if (smem > 64 * 1024) {
+        static size_t granted = 0;
+        if (smem > granted) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            granted = smem;
+        }
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3((a.Dloc + 15) / 16 + (a.do_push ? 1 : 0)), dim3(256), smem, stream, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scatter_kernel: what the sample that has just arrived contributes to the later steps of the look-ahead block.  For each
+// IRF sample s in [s_lo, s_lo + ns):  Y[s - s_lo][row] = width_s * sum_col K[row, s*D + col] * v[col]; the steps that use
+// it apply the interpolation weight of the sample (FinalizeArgs::term_coef).  One workgroup per (row tile, s): row-owned,
+// no partials.  Runs after the step has delivered its forces -- off the caller's critical path.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) scatter_kernel(ScatterArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double* vs = reinterpret_cast<double*>(smem_raw);  // [D]
+    __shared__ double red[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4;
+    const int rt = (int)blockIdx.x % a.K.ntiles, si = (int)blockIdx.x / a.K.ntiles;
+    const int s  = a.s_lo + si;
+    const int D  = a.D;
+    const int f0 = s * D, f1 = f0 + D, g0 = f0 >> 3, g1 = (f1 + 7) >> 3;
+    const double* __restrict__ kbase = a.K.base + ((size_t)rt * a.K.ngp) * 128 + lane * 2;
+    constexpr int PRE = 4;
+    dvec2 pre[PRE];
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+        const int gp = g0 + wave + 4 * q;
+        pre[q] = gp < g1 ? *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128) : dvec2{0.0, 0.0};
+    }
+    for (int col = tid; col < D; col += 256) vs[col] = a.v[col];
+    __syncthreads();
+    const double* __restrict__ u = vs - f0;
+    double acc = 0.0;
+    int gp = g0 + wave;
+#pragma unroll
+    for (int q = 0; q < PRE; ++q, gp += 4) {
+        if (gp < g1) {
+            const int fa = gp * 8 + kk, fb = fa + 4;
+            const double u0 = (fa >= f0 && fa < f1) ? u[fa] : 0.0, u1 = (fb >= f0 && fb < f1) ? u[fb] : 0.0;
+            acc = fma(pre[q].x, u0, acc);
+            acc = fma(pre[q].y, u1, acc);
+        }
+    }
+#pragma unroll 4
+    for (; gp < g1; gp += 4) {
+        const dvec2 kv = *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128);
+        const int fa = gp * 8 + kk, fb = fa + 4;
+        const double u0 = (fa >= f0 && fa < f1) ? u[fa] : 0.0, u1 = (fb >= f0 && fb < f1) ? u[fb] : 0.0;
+        acc = fma(kv.x, u0, acc);
+        acc = fma(kv.y, u1, acc);
+    }
+    acc += __shfl_xor(acc, 16, kWave);
+    acc += __shfl_xor(acc, 32, kWave);
+    if (lane < 16) red[wave][lane] = acc;
+    __syncthreads();
+    if (tid < 16) a.Y[(size_t)si * a.Dpad + rt * 16 + tid] = (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]) * a.width[s];
+}
+
+void launch_scatter(const ScatterArgs& a, hipStream_t stream) {
+    if (a.ns <= 0) return;
+    const size_t smem = (size_t)a.D * sizeof(double);
+    if (smem > 64 * 1024) {
+        static size_t granted = 0;
+        if (smem > granted) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            granted = smem;
+        }
+    }
+    hipLaunchKernelGGL(scatter_kernel, dim3(a.K.ntiles * a.ns), dim3(256), smem, stream, a);
 }
 
 // ------------------------------------------------------------------------------------------------

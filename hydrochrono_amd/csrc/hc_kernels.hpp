@@ -44,7 +44,28 @@ struct Bracket {
     int off_older;   // element offset (slot * D) of the older sample's ring row
     int off_newer;   // element offset of the newer sample's ring row, -1: the newer sample is the current state
 };
-constexpr int kHostBrackets = 24;
+
+// ------------------------------------------------------------------------------------------------------------------
+// Scatter-form look-ahead (hc_api.cpp: make_plan).  The interpolated history is linear in its samples,
+//     v~(q) = sum_k phi_k(q) v_k      (phi_k = the reference's two interpolation weights of sample k, src/hydro_forces.cpp:343-371),
+// so the radiation sum of a future step m splits by history sample: what the samples known when the block was planned
+// contribute (the look-ahead pass, K read once for 16 steps), what a sample that arrives at block step i < m contributes
+// (scatter_kernel right after step i has delivered its forces, off the caller's critical path), and what step m's own
+// sample contributes (the few IRF samples tau_s < dt, contracted by step_kernel itself).  A step inside a block is then
+// ONE launch on the caller's critical path.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kNearMax        = 8;   // IRF samples a step contracts itself (own sample + a deferred one)
+constexpr int kTermMax        = 96;  // scatter results a step adds
+constexpr int kScatterSamples = 64;  // IRF samples s < kScatterSamples can be targets of a scatter
+
+// One IRF sample s contracted by the step itself: columns [s*D, (s+1)*D) of K against
+//     u[col] = a * v_state[col] + b * ring_v[off_b + col] + c * ring_v[off_c + col]
+// (a: this step's own sample, weight x trapezoid width; b, c: a complete bracket of stored samples, used for the one IRF
+// sample per step whose "is there an older sample" test the pass could not decide ahead of time).
+struct NearEntry {
+    int s, off_b, off_c, pad;
+    double a, b, c;
+};
 
 // Excitation side shared by the per-step and the look-ahead launch: e[j] = eta(t - ex_tau[j]) * ex_width[j], eta linearly
 // interpolated in the precomputed free-surface table (src/wave_types.cpp:797-831).
@@ -59,20 +80,16 @@ struct EtaTable {
     double eta_t0;           // eta_t[0]
 };
 
-// Per-step launch: radiation columns [0, F_limit) of K (F_limit = S*D for a plain step, s_cut*D for the remainder of a
-// look-ahead step) and, for irregular waves, the excitation matrix, both as column chunks of a streamed FP64 GEMV.
-// A workgroup owns MT row tiles x one chunk and leaves one partial per row in partials[chunk][Dpad].
+// Plain per-step launch: radiation columns [0, F_limit) of K (F_limit = live samples * D) and, for irregular waves, the
+// excitation matrix, both as column chunks of a streamed FP64 GEMV.  A workgroup owns MT row tiles x one chunk and leaves
+// one partial per row in partials[chunk][Dpad].
 struct StepArgs {
     Panel K;
     int F_limit;          // radiation columns [0, F_limit) to contract (multiple of D)
     int chunk_gp;         // column groups per radiation chunk
-    int nchunks_rad;      // chunks covering [0, F_limit) plus the chunks of the extra range below
-    // extra column range [F2_lo, F2_hi) (one IRF sample deferred by the look-ahead pass), chunks nchunks_rad1 .. nchunks_rad-1
-    int nchunks_rad1;     // chunks of the first range
-    int F2_lo, F2_hi;
+    int nchunks_rad;      // chunks covering [0, F_limit)
     int max_steps_per_chunk;  // LDS bracket table entries
     int rhs_capacity;         // LDS right-hand-side entries: 8 * max(chunk_gp, chunk_gp_ex)
-    int stream_once;          // 1: non-temporal K loads (plain step); 0: cacheable (remainder of a look-ahead step)
     HistoryView hist;
     const double* tau;    // [S] radiation IRF sample times
     const double* width;  // [S] trapezoid widths
@@ -84,11 +101,6 @@ struct StepArgs {
     int Dpad;
     int ngroups;             // ntiles / MT
     int* error_flag;         // 1 / 2: a query time is not bracketed (reference: runtime_error)
-    // brackets of the first hb_n IRF samples and of the deferred sample, found on the host (same arithmetic on the same
-    // doubles) for the short remainder of a look-ahead step: saves the launch two dependent round trips to the ring times
-    int hb_n, hb_defer_valid;
-    Bracket hb[kHostBrackets];
-    Bracket hb_defer;
 };
 
 // Look-ahead pass: for j = 0..15 the part of step (n+j)'s radiation sum that depends only on history known at step n,
@@ -154,17 +166,35 @@ struct FinalizeArgs {
     double* waves;
     double* total;
     double* user_out;  // may be null
-    // Tiny remainder of a look-ahead step (small systems): radiation columns [0, rem_F) are contracted here, 16 lanes per
-    // row, instead of in a launch of their own; hb[s] = bracket of IRF sample s (found on the host).  rem_F = 0: off.
-    int rem_F;
-    Panel remK;
-    HistoryView hist;
-    const double* width;
-    Bracket hb[kHostBrackets];
+    // Step inside a look-ahead block: the IRF samples this step contracts itself (row-owned, no partials) ...
+    int n_near;
+    NearEntry near[kNearMax];
+    Panel nearK;
+    const double* ring_v_ro;   // velocity ring (read side)
+    // ... and the scatter results of the earlier steps of the block: rad += sum_i term_coef[i] * Y[term_off[i] + row]
+    int n_terms;
+    const double* Y;
+    int term_off[kTermMax];
+    double term_coef[kTermMax];
+    // Host boundary: the totals also go to mapped pinned host memory as 16-byte granules {total, seq}; the host spins on
+    // seq instead of synchronising the stream (one store carries value and sequence number, so no ordering is assumed).
+    unsigned long long* host_tagged;  // [Dloc][2] or null
+    unsigned long long seq;
     // history push of this step's sample into ring slot `head` (src/hydro_forces.cpp:559-574)
     int do_push, head, D;
     double* ring_t;
     double* ring_v;
+};
+
+// scatter_kernel: Y[(s - s_lo)][row] = width[s] * sum_col K[row, s*D + col] * v[col] for s in [s_lo, s_lo + ns); one
+// workgroup per (row tile, sample), so nothing is left to reduce across workgroups.
+struct ScatterArgs {
+    Panel K;
+    int D, Dpad;
+    int s_lo, ns;
+    const double* v;      // [D] the sample's velocities (its ring row)
+    const double* width;  // [S]
+    double* Y;            // [ns][Dpad], row s - s_lo
 };
 
 struct TaperArgs {
@@ -190,6 +220,7 @@ void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream);
 // (fixed order; nchunks_ex may be 0)
 void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_ex, int Dpad, double* d_P, double* d_E, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
+void launch_scatter(const ScatterArgs& a, hipStream_t stream);
 void launch_taper(const TaperArgs& a, hipStream_t stream);
 // eta[j] = sum_i amp[i] * cos(-omega[i]*t[j] + phase[i]), then the ramp rule of src/wave_types.cpp:759-769
 void launch_eta_synthesis(const double* d_t, int nt, const double* d_amp, const double* d_omega, const double* d_phase, int nf,

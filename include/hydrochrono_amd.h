@@ -198,6 +198,9 @@ int hc_added_mass_mv(hc_ctx* ctx, const double* w, double c, double* R_inout, in
 /* HydroProfileStats (include/hydroc/hydro_forces.h:153-160), filled from HIP events; *_seconds are GPU
  * time of the kernels of each term.  conv_kernel_* describe the radiation GEMV kernel alone. */
 typedef struct hc_profile_stats {
+    /* HydroProfileStats: GPU seconds per term.  A launch that carries two terms (the convolution kernels stream K and,
+     * for irregular waves, Kex) is apportioned by algorithmic bytes; hydrostatics_seconds is the step kernel (reduction,
+     * the step's own newest-sample part, hydrostatics, regular / spectral wave term, total). */
     double hydrostatics_seconds, radiation_seconds, waves_seconds;
     int hydrostatics_calls, radiation_calls, waves_calls;
     double conv_kernel_seconds; /* sum of HIP-event durations of the plain per-step convolution launches */
@@ -207,8 +210,11 @@ typedef struct hc_profile_stats {
     long long block_kernel_launches;
     double block_kernel_bytes;  /* algorithmic bytes of the last pass: sum over its 16 steps of the share of K (and of the
                                    velocity vector) that the pass computes for that step, i.e. IRF samples s >= s_cut[j] */
-    double rem_kernel_seconds;  /* per-step remainder launches inside a look-ahead block */
-    long long rem_kernel_launches;
+    double block_kernel_bytes_once; /* bytes the last pass has to move once: live part of K, Kex, staged vectors */
+    double step_kernel_seconds;  /* the step kernel (finalize_kernel): the one launch on the critical path of a block step */
+    long long step_kernel_launches;
+    double scatter_kernel_seconds; /* scatter launches (after a block step has delivered its forces) */
+    long long scatter_kernel_launches;
 } hc_profile_stats;
 /* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default), and around every
  * look-ahead pass (one per 16 steps) whatever the stride.  Event records perturb the launch stream by a few

@@ -235,7 +235,7 @@ def test_lookahead_matches_plain_and_survives_irregular_steps(HF, N):
         assert_close(fa, fb, 1e-11, f"look-ahead vs plain at t={t}")
         assert_close(fa, fo, TIGHT_TOL, f"look-ahead vs oracle at t={t}")
     prof = a.profile()
-    assert prof["block_kernel_launches"] >= 10 and prof["rem_kernel_launches"] >= 100  # blocks really were used
+    assert prof["block_kernel_launches"] >= 10 and prof["scatter_kernel_launches"] >= 100  # blocks really were used
     assert prof["conv_kernel_launches"] >= 100                                         # and the fallback too
 
 
@@ -567,7 +567,7 @@ def test_config_c2_two_body_irregular_jonswap(HF):
     gpu.enable_profiling(1)
     drive_both(gpu, orc, motion, 0.01 * np.arange(1650, 1700))
     if os.environ.get("HC_LOOKAHEAD", "16") != "0":
-        assert gpu.profile()["rem_kernel_launches"] > 0
+        assert gpu.profile()["scatter_kernel_launches"] > 0
 
 
 def test_config_c5_single_body_2048_components(HF):

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -424,8 +425,8 @@ bool make_plan(hc_ctx* c) {
     if (c->lookahead <= 0 || H < 2 || pl.cooldown > 0 || c->S < 2 || c->tau.front() < 0.0) return false;
     const double t0 = c->times[0], dt = c->times[0] - c->times[1];
     if (!(dt > 0.0)) return false;
-    if (dt * hc::kLookahead > 0.25 * (c->tau.back() - c->tau.front())) {
-        pl.cooldown = 256;  // step size comparable to the IRF window: blocking cannot pay
+    if (dt * hc::kLookahead > 0.5 * (c->tau.back() - c->tau.front())) {
+        pl.cooldown = 64;  // a block would span most of the IRF window: the scatter launches would re-read most of K every step
         return false;
     }
     pl.dt = dt;
@@ -585,6 +586,15 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
     const double rad_once = 8.0 * (static_cast<double>(c->Dloc) * b.F + b.F);
     const double exc_once = exc_block ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
     c->prof.block_kernel_bytes_once = rad_once + exc_once;
+    if (env_int("HC_DEBUG_PLAN", 0) != 0) {
+        std::fprintf(stderr, "[hc] pass t0=%.6f dt=%.17g Hv=%d F/D=%d nchunks=%d exc=%d\n     s_cut:", pl.tgrid[0], pl.dt, Hv, b.F / c->D, b.nchunks, (int)exc_block);
+        for (int j = 0; j < hc::kLookahead; ++j) std::fprintf(stderr, " %d", pl.s_cut[j]);
+        std::fprintf(stderr, "\n     s_defer:");
+        for (int j = 0; j < hc::kLookahead; ++j) std::fprintf(stderr, " %d", pl.s_defer[j]);
+        std::fprintf(stderr, "\n     scat:");
+        for (int i = 1; i <= hc::kLookahead; ++i) std::fprintf(stderr, " [%d,%d]", pl.scat_lo[i], pl.scat_hi[i]);
+        std::fprintf(stderr, "\n");
+    }
     hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_once / std::max(1.0, rad_once + exc_once));
     hc::launch_conv_block(b, c->mt_block, stream);
     ev_end(ev, stream);
@@ -691,6 +701,16 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
             z.term_off[k]  = (pl.term_slot[m][k] * hc::kScatterSamples + pl.term_s[m][k]) * c->Dpad;
             z.term_coef[k] = pl.term_coef[m][k];
         }
+    }
+    static const bool dbg = env_int("HC_DEBUG_PLAN", 0) != 0;
+    if (dbg) {
+        std::fprintf(stderr, "[hc] t=%.6f H=%d m=%d n_near=%d n_terms=%d sd=%d nchunks_rad=%d nchunks_ex=%d head=%d\n", t, H, m, z.n_near, z.n_terms,
+                     block ? c->plan.s_defer[m - 1] : -2, nchunks_rad, nchunks_ex, c->head);
+        for (int e = 0; e < z.n_near; ++e)
+            std::fprintf(stderr, "     near s=%d a=%.6g b=%.6g c=%.6g offb=%d offc=%d\n", z.near[e].s, z.near[e].a, z.near[e].b, z.near[e].c, z.near[e].off_b, z.near[e].off_c);
+        if (block)
+            for (int k = 0; k < z.n_terms; ++k)
+                std::fprintf(stderr, "     term slot=%d s=%d coef=%.17g\n", c->plan.term_slot[m][k], c->plan.term_s[m][k], z.term_coef[k]);
     }
     z.host_tagged = host_tagged;
     z.seq         = seq;
@@ -1816,6 +1836,17 @@ int hc_synth_fill(hc_ctx* c, unsigned long long seed, int S, double dt_rirf, int
         }
     }
     HC_HIP(hipStreamSynchronize(c->stream));
+    HC_API_END(c)
+}
+
+// Diagnostics (not part of the public header): copies an internal device buffer to the host.  which: 0 = P [16][Dpad],
+// 1 = E [16][Dpad], 2 = Y [16][kScatterSamples][Dpad].
+int hc_debug_read(hc_ctx* c, int which, double* out, long long n) {
+    HC_API_BEGIN(c)
+    HC_HIP(hipDeviceSynchronize());
+    const hc::DeviceBuffer<double>& b = which == 0 ? c->d_P : (which == 1 ? c->d_E : c->d_Y);
+    require(n >= 0 && static_cast<size_t>(n) <= b.n, HC_ERR_INVALID, "bad size");
+    HC_HIP(hipMemcpy(out, b.p, static_cast<size_t>(n) * sizeof(double), hipMemcpyDeviceToHost));
     HC_API_END(c)
 }
 

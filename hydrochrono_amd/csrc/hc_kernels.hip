@@ -537,11 +537,15 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
     double bwo[2], bwn[2];
     int boo[2], bon[2];
     auto load_bracket = [&](int h) {
-        const int k = min(max(s_t[h] - s0, 0), ns - 1) * kLookahead + jstep;
-        bwo[h] = t_wo[k];
-        bwn[h] = t_wn[k];
-        boo[h] = t_oo[k];
-        bon[h] = t_on[k];
+        // columns past the chunk's last live sample (the rest of its last column group, or the groups the wave re-reads
+        // past the end) get zero weights
+        const int ks = s_t[h] - s0;
+        const bool in = ks >= 0 && ks < ns;
+        const int k  = (in ? ks : 0) * kLookahead + jstep;
+        bwo[h] = in ? t_wo[k] : 0.0;
+        bwn[h] = in ? t_wn[k] : 0.0;
+        boo[h] = in ? t_oo[k] : 0;
+        bon[h] = in ? t_on[k] : 0;
     };
     load_bracket(0);
     if constexpr (UNI) {

@@ -424,7 +424,9 @@ def test_history_injection_matches_stepping(HF):
     t, v = a.get_history()
     b.set_history(t, v)
     st = motion.state(0.6)
-    assert np.array_equal(a.step(0.6, *st), b.step(0.6, *st))
+    # a is inside a look-ahead block (pass + scatter terms + own sample), b starts from the injected history with a plain
+    # step: same mathematics, different summation order
+    assert_close(a.step(0.6, *st), b.step(0.6, *st), 1e-13, "stepped vs injected history")
 
 
 def test_step_device_matches_host_step(HF):

@@ -4,6 +4,9 @@
 // src/hydro_forces.cpp:327-340,549-584), error rules of the reference, and the three kernel launches per step.
 // All arithmetic of the per-step force path runs in hc_kernels.hip on the GPU; there is no CPU fallback.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <xmmintrin.h>
 
 #include <algorithm>
 #include <cmath>
@@ -17,6 +20,34 @@
 #include "hc_host_math.hpp"
 
 using hc::Error;
+
+// Fine-grained device allocation + a fault-free test of whether the CPU can address it: read(2) from /dev/zero INTO the
+// buffer and write(2) FROM it fail with EFAULT instead of raising SIGSEGV when the range is not mapped for the host.
+template <class T>
+void hc::BarBuffer<T>::alloc(size_t count) {
+    if (p) (void)hipFree(p);
+    p       = nullptr;
+    n       = 0;
+    host_ok = false;
+    if (count == 0) return;
+    static const bool disabled = [] { const char* e = std::getenv("HC_NO_BAR_STATE"); return e && std::atoi(e) != 0; }();
+    if (disabled) return;
+    void* q = nullptr;
+    if (hipExtMallocWithFlags(&q, count * sizeof(T), hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    p = static_cast<T*>(q);
+    n = count;
+    const int fz = open("/dev/zero", O_RDONLY), fn = open("/dev/null", O_WRONLY);
+    if (fz >= 0 && fn >= 0) {
+        const size_t bytes = count * sizeof(T);
+        host_ok = read(fz, p, bytes) == static_cast<ssize_t>(bytes) && write(fn, p, bytes) == static_cast<ssize_t>(bytes);
+    }
+    if (fz >= 0) close(fz);
+    if (fn >= 0) close(fn);
+}
+template struct hc::BarBuffer<double>;
 
 namespace hc {
 void eta_synthesis_fft(const std::vector<double>& t, const std::vector<double>& amp, const std::vector<double>& omega,
@@ -1121,6 +1152,20 @@ int hc_finalize(hc_ctx* c) {
     c->d_err.alloc(1);
     HC_HIP(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
     c->h_state.alloc(static_cast<size_t>(2) * 12 * c->N);  // two halves used alternately by hc_step, see there
+    c->bar_state.alloc(static_cast<size_t>(2) * 12 * c->N);
+    if (c->bar_state.host_ok) {
+        // trust, but verify: what the host stores through the BAR must be what a device-side copy sees
+        const size_t nb = c->bar_state.n;
+        for (size_t k = 0; k < nb; ++k) c->bar_state.p[k] = 0.5 + static_cast<double>(k);
+        _mm_sfence();
+        hc::DeviceBuffer<double> tmp;
+        tmp.alloc(nb);
+        std::vector<double> back(nb);
+        HC_HIP(hipMemcpyAsync(tmp.p, c->bar_state.p, nb * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HC_HIP(hipMemcpyAsync(back.data(), tmp.p, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HC_HIP(hipStreamSynchronize(c->stream));
+        for (size_t k = 0; k < nb && c->bar_state.host_ok; ++k) c->bar_state.host_ok = back[k] == 0.5 + static_cast<double>(k);
+    }
     c->h_out.alloc(static_cast<size_t>(4) * c->Dloc);
     c->h_err.alloc(1);
     c->h_am.alloc(static_cast<size_t>(c->D) + c->Dloc);
@@ -1457,24 +1502,37 @@ int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const dou
     c->prev_time = t;  // :747 (set before the terms are computed, so a throwing step is not retried)
     c->have_prev = true;
     std::fill(c->last_total.begin(), c->last_total.end(), 0.0);  // the reference zero-fills total_force_ before the terms (:749-751)
-    // Zero-copy boundary: the kernels read the 12N state doubles from mapped pinned memory (up to a few dozen bodies) and
-    // finalize_kernel stores the totals straight into mapped pinned memory, tagged with this step's sequence number -- no
-    // copy launches and no stream synchronisation on the critical path, one kernel launch for a step inside a block.
+    // Boundary without copy launches or stream synchronisation: the host stores the 12N state doubles straight into device
+    // memory through the PCIe BAR (fallback: mapped pinned memory the kernels read over PCIe), finalize_kernel stores the
+    // totals straight into mapped pinned memory, tagged with this step's sequence number; one kernel launch for a step
+    // inside a block.
     // The state buffer has two halves used alternately: this call returns as soon as the totals have arrived, while the
     // workgroup that stores the step's sample into the ring may still be reading the state -- the next call must not
     // overwrite it.  (The kernels of step n+1 run after those of step n, and step n+2 starts only after the totals of
     // step n+1 have arrived, so two halves are enough.)
     const int n3   = 3 * c->N;
     const size_t o = (c->seq & 1) ? static_cast<size_t>(12) * c->N : 0;
-    double* h      = c->h_state.p + o;
-    std::memcpy(h, pos, n3 * sizeof(double));
-    std::memcpy(h + n3, rpy, n3 * sizeof(double));
-    std::memcpy(h + 2 * n3, linvel, n3 * sizeof(double));
-    std::memcpy(h + 3 * n3, angvel, n3 * sizeof(double));
-    const double* d_state = c->h_state.dp + o;
-    if (c->N > c->zero_copy_max_bodies) {  // many workgroups re-read the state: one small H2D copy beats their PCIe reads
-        HC_HIP(hipMemcpyAsync(c->d_state.p, h, 4 * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        d_state = c->d_state.p;
+    const double* d_state;
+    if (c->bar_state.host_ok) {
+        // device memory written through the PCIe BAR: the kernels read the state locally (no PCIe read on the critical path)
+        double* h = c->bar_state.p + o;
+        std::memcpy(h, pos, n3 * sizeof(double));
+        std::memcpy(h + n3, rpy, n3 * sizeof(double));
+        std::memcpy(h + 2 * n3, linvel, n3 * sizeof(double));
+        std::memcpy(h + 3 * n3, angvel, n3 * sizeof(double));
+        _mm_sfence();  // write-combined stores are globally visible before the doorbell of the launch
+        d_state = h;
+    } else {
+        double* h = c->h_state.p + o;
+        std::memcpy(h, pos, n3 * sizeof(double));
+        std::memcpy(h + n3, rpy, n3 * sizeof(double));
+        std::memcpy(h + 2 * n3, linvel, n3 * sizeof(double));
+        std::memcpy(h + 3 * n3, angvel, n3 * sizeof(double));
+        d_state = c->h_state.dp + o;
+        if (c->N > c->zero_copy_max_bodies) {  // many workgroups re-read the state: one small H2D copy beats their PCIe reads
+            HC_HIP(hipMemcpyAsync(c->d_state.p, h, 4 * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            d_state = c->d_state.p;
+        }
     }
     const unsigned long long seq = ++c->seq;
     enqueue_step(c, t, d_state, nullptr, c->stream, StepFlags{}, c->h_tag.dp, seq);

@@ -75,6 +75,24 @@ struct PinnedBuffer {
     }
 };
 
+// Device memory the host can write directly through the PCIe BAR (fine-grained allocation; host-visible where the whole
+// VRAM is BAR-mapped, as on MI355X servers).  hc_step puts the body state there: the step kernel then reads it locally
+// instead of fetching it from pinned host memory over PCIe (10.1 vs 12.9 us launch-to-result for the same kernel,
+// profiles/r02/latency_probe2.txt).  host_ok == false: not host-visible here, the caller falls back to pinned memory.
+template <class T>
+struct BarBuffer {
+    T* p         = nullptr;  // device address == host address when host_ok
+    size_t n     = 0;
+    bool host_ok = false;
+    BarBuffer() = default;
+    BarBuffer(const BarBuffer&)            = delete;
+    BarBuffer& operator=(const BarBuffer&) = delete;
+    ~BarBuffer() {
+        if (p) (void)hipFree(p);
+    }
+    void alloc(size_t count);  // hc_api.cpp (probes host visibility without faulting)
+};
+
 struct BodyHost {
     bool have_props = false, have_lin = false, have_ainf = false, have_rirf = false, have_rao = false, have_exirf = false;
     double disp_vol = 0.0, cg[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
@@ -188,6 +206,7 @@ struct hc_ctx {
     hc::DeviceBuffer<double> d_scratch;  // [4][Dloc] outputs of the term-only entry points (they must not clobber the last step)
     hc::DeviceBuffer<int> d_err;
     hc::PinnedBuffer<double> h_state, h_out, h_am;
+    hc::BarBuffer<double> bar_state;  // [2][12N] body state written by the host through the BAR (hc_step)
     hc::PinnedBuffer<unsigned long long> h_tag;  // [Dloc][2] {total, sequence number} granules written by finalize_kernel
     unsigned long long seq = 0;
     std::vector<double> last_total;               // totals of the last evaluated step (duplicate-time cache of hc_step)

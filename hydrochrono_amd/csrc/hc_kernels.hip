@@ -823,20 +823,36 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     }
 
     const bool near_on = a.do_rad && a.n_near > 0, term_on = a.do_rad && a.n_terms > 0;
+    // Loads first, uses later: the step is a chain of dependent round trips (state -> LDS -> K x u; table -> Y), so everything
+    // that can be requested up front is -- the first K words of the wave, the scatter results it will add -- before the
+    // first wait.
+    const int kk = lane >> 4;
+    constexpr int PRE = 12;  // C3: all 12 column groups a wave owns of one IRF sample
+    dvec2 pre[PRE];
+    const double* __restrict__ kbase = a.nearK.base + ((size_t)blockIdx.x * a.nearK.ngp) * 128 + lane * 2;
     if (near_on) {
-        // ---- the IRF samples this step contracts itself: rows of this tile x [s*D, (s+1)*D) ----
-        const int D  = a.D;
-        const int kk = lane >> 4;
-        const double* __restrict__ kbase = a.nearK.base + ((size_t)blockIdx.x * a.nearK.ngp) * 128 + lane * 2;
-        // the first K words are requested before the right-hand side is staged: the two round trips overlap
-        constexpr int PRE = 4;
-        const int f0_0 = a.near[0].s * D, g0_0 = f0_0 >> 3, g1_0 = (f0_0 + D + 7) >> 3;
-        dvec2 pre[PRE];
+        const int f0_0 = a.near[0].s * a.D, g0_0 = f0_0 >> 3, g1_0 = (f0_0 + a.D + 7) >> 3;
 #pragma unroll
         for (int q = 0; q < PRE; ++q) {
             const int gp = g0_0 + wave + 4 * q;
             pre[q] = gp < g1_0 ? *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128) : dvec2{0.0, 0.0};
         }
+    }
+    // scatter results of the earlier steps of the block: wave w adds terms w, w+4, ... (wave-uniform table reads from the
+    // argument block), lanes 0..15 = the rows of the tile; the first 8 are requested here
+    constexpr int TPRE = 8;
+    double ypre[TPRE];
+    const double* __restrict__ ybase = a.Y + blockIdx.x * 16 + (lane & 15);
+    if (term_on) {
+#pragma unroll
+        for (int q = 0; q < TPRE; ++q) {
+            const int k = wave + 4 * q;
+            ypre[q] = (k < a.n_terms && lane < 16) ? ybase[a.term_off[k]] : 0.0;
+        }
+    }
+    if (near_on) {
+        // ---- the IRF samples this step contracts itself: rows of this tile x [s*D, (s+1)*D) ----
+        const int D = a.D;
         for (int e = 0; e < a.n_near; ++e) {
             const NearEntry& ne = a.near[e];
             for (int col = tid; col < D; col += 256) {
@@ -879,13 +895,15 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         if (lane < 16) red_near[wave][lane] = acc;
     }
     if (term_on) {
-        // ---- scatter results of the earlier steps of the block: wave w adds terms w, w+4, ... (wave-uniform table reads
-        //      from the argument block), lanes 0..15 = the rows of the tile ----
         double tacc = 0.0;
         if (lane < 16) {
-            const double* __restrict__ y = a.Y + blockIdx.x * 16 + lane;
+#pragma unroll
+            for (int q = 0; q < TPRE; ++q) {
+                const int k = wave + 4 * q;
+                if (k < a.n_terms) tacc = fma(a.term_coef[k], ypre[q], tacc);
+            }
 #pragma unroll 4
-            for (int k = wave; k < a.n_terms; k += 4) tacc = fma(a.term_coef[k], y[a.term_off[k]], tacc);
+            for (int k = wave + 4 * TPRE; k < a.n_terms; k += 4) tacc = fma(a.term_coef[k], ybase[a.term_off[k]], tacc);
             red_term[wave][lane] = tacc;
         }
     }

@@ -13,6 +13,7 @@
 // Reference semantics: src/hydro_forces.cpp:263-322,537-691,727-767; src/wave_types.cpp:315-327,776-844.
 #include "hc_kernels.hpp"
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
@@ -63,18 +64,20 @@ void launch_relayout_rowmajor(const double* d_src, int rows, int cols, double* d
 }
 
 __global__ void __launch_bounds__(256) unrelayout_kernel(Panel K, int Dloc, int D, int S, double* __restrict__ out) {
-    const size_t n   = (size_t)Dloc * D * S;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n) return;
-    const int s   = (int)(gid % S);
-    const int col = (int)((gid / S) % D);
-    const int row = (int)(gid / ((size_t)S * D));
-    out[gid]      = K.base[panel_offset(K.ngp, row, s * D + col)];
+    const size_t n      = (size_t)Dloc * D * S;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gid < n; gid += stride) {
+        const int s   = (int)(gid % S);
+        const int col = (int)((gid / S) % D);
+        const int row = (int)(gid / ((size_t)S * D));
+        out[gid]      = K.base[panel_offset(K.ngp, row, s * D + col)];
+    }
 }
 
 void launch_unrelayout(const Panel& K, int Dloc, int D, int S, double* d_out, hipStream_t stream) {
-    const size_t n = (size_t)Dloc * D * S;
-    hipLaunchKernelGGL(unrelayout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, K, Dloc, D, S, d_out);
+    const size_t n      = (size_t)Dloc * D * S;
+    const size_t blocks = std::min<size_t>((n + 255) / 256, (size_t)1 << 22);
+    hipLaunchKernelGGL(unrelayout_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, K, Dloc, D, S, d_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1153,35 +1156,38 @@ __host__ __device__ inline double u01(uint64_t h) { return (double)(h >> 11) * (
 
 __global__ void __launch_bounds__(256) synth_rirf_kernel(double* __restrict__ K, int ntiles, int ngp, int Dloc, int D, int S, int row0, double dt,
                                                           unsigned long long seed, double rho) {
-    const size_t n   = (size_t)ntiles * ngp * 128;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n) return;
-    const int j    = (int)(gid & 1);
-    const int lane = (int)((gid >> 1) & 63);
-    const size_t blk = gid >> 7;
-    const int gp = (int)(blk % ngp), rt = (int)(blk / ngp);
-    const int row = rt * 16 + (lane & 15);
-    const size_t f = (size_t)gp * 8 + 4 * j + (lane >> 4);
-    double val = 0.0;
-    if (row < Dloc && f < (size_t)S * D) {
-        const int s = (int)(f / D), col = (int)(f - (size_t)s * D);
-        const int grow = row0 + row;
-        const uint64_t base = splitmix64(seed ^ (((uint64_t)grow << 32) | (uint64_t)col));
-        const double ua = u01(splitmix64(base + 1)), ud = u01(splitmix64(base + 2)), uo = u01(splitmix64(base + 3));
-        double amp = (2.0 * ua - 1.0);
-        if (grow / 6 == col / 6) amp *= 10.0;
-        const double tau_d = 1.0 + 3.0 * ud;
-        const double om    = 0.5 + 2.5 * uo;
-        const double tau   = s * dt;
-        val = (amp * exp(-tau / tau_d) * cos(om * tau)) * rho;
+    // grid-stride: a C4-size matrix has more elements (9.7e9) than a launch can have work-items (2^32)
+    const size_t n      = (size_t)ntiles * ngp * 128;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gid < n; gid += stride) {
+        const int j    = (int)(gid & 1);
+        const int lane = (int)((gid >> 1) & 63);
+        const size_t blk = gid >> 7;
+        const int gp = (int)(blk % ngp), rt = (int)(blk / ngp);
+        const int row = rt * 16 + (lane & 15);
+        const size_t f = (size_t)gp * 8 + 4 * j + (lane >> 4);
+        double val = 0.0;
+        if (row < Dloc && f < (size_t)S * D) {
+            const int s = (int)(f / D), col = (int)(f - (size_t)s * D);
+            const int grow = row0 + row;
+            const uint64_t base = splitmix64(seed ^ (((uint64_t)grow << 32) | (uint64_t)col));
+            const double ua = u01(splitmix64(base + 1)), ud = u01(splitmix64(base + 2)), uo = u01(splitmix64(base + 3));
+            double amp = (2.0 * ua - 1.0);
+            if (grow / 6 == col / 6) amp *= 10.0;
+            const double tau_d = 1.0 + 3.0 * ud;
+            const double om    = 0.5 + 2.5 * uo;
+            const double tau   = s * dt;
+            val = (amp * exp(-tau / tau_d) * cos(om * tau)) * rho;
+        }
+        K[gid] = val;
     }
-    K[gid] = val;
 }
 
 void launch_synth_rirf(double* d_K, int ntiles, int ngp, int Dloc, int D, int S, int row0, double dt, unsigned long long seed, double rho,
                        hipStream_t stream) {
-    const size_t n = (size_t)ntiles * ngp * 128;
-    hipLaunchKernelGGL(synth_rirf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_K, ntiles, ngp, Dloc, D, S, row0, dt, seed, rho);
+    const size_t n      = (size_t)ntiles * ngp * 128;
+    const size_t blocks = std::min<size_t>((n + 255) / 256, (size_t)1 << 22);  // <= 2^30 work-items per launch
+    hipLaunchKernelGGL(synth_rirf_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_K, ntiles, ngp, Dloc, D, S, row0, dt, seed, rho);
 }
 
 }  // namespace hc

@@ -59,3 +59,60 @@ def test_force_all_gather_world2_gloo(N):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), N, 5, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ------------------------------------------------------------------------------------------------
+# real contexts: two processes, each with a row-sharded hc_ctx (hc_create_sharded) on the one GPU of the box, forces
+# all-gathered over gloo (on an 8-GPU node the same code runs one rank per GPU over RCCL, bench.py --gpus N)
+# ------------------------------------------------------------------------------------------------
+def _ctx_worker(rank, world, port, N, steps, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        if here not in sys.path:
+            sys.path.insert(0, here)
+        from cases import load_into_oracle
+        from hydrochrono_amd.hydro import HydroForces
+        from hydrochrono_amd.mock_chrono import PrescribedMotion
+        from hydrochrono_amd.synthetic import many_body_case, rest_positions
+        case = many_body_case(N, S=96, dt_rirf=0.01, n_exc=65, dt_exc=0.02, seed=4100 + N)
+        kw = dict(simulation_dt=0.01, simulation_duration=4.0, ramp_duration=0.5, wave_height=2.0, wave_period=6.0,
+                  frequency_min=0.05, frequency_max=0.6, nfrequencies=48, peak_enhancement_factor=3.3)
+        b0, b1 = body_shard(N, world, rank)
+        mine = HydroForces.from_case(case, device=0, body_range=(b0, b1))
+        mine.add_waves_irregular(**kw)
+        ex = ForceExchange(N, world, rank, device="cpu")
+        motion = PrescribedMotion(N, rest_positions(case), seed=5)
+        full = orc = None
+        if rank == 0:  # the unsharded context and the CPU oracle as checkers
+            full = HydroForces.from_case(case, device=0)
+            full.add_waves_irregular(**kw)
+            orc = load_into_oracle(case)
+            orc.add_waves_irregular(**kw)
+        ok, worst = True, 0.0
+        for n in range(steps):
+            t = 0.01 * n
+            st = motion.state(t)
+            gathered = ex.gather(torch.from_numpy(mine.step(t, *st))).numpy().copy()
+            ok &= gathered.shape == (6 * N,)
+            if rank == 0:
+                ok &= bool(np.array_equal(gathered, full.step(t, *st)))  # row shards add in the same order: bitwise
+                fo = orc.step(t, *st)
+                worst = max(worst, float(np.max(np.abs(gathered - fo)) / np.max(np.abs(fo))))
+        ret[rank] = (bool(ok), worst)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [6, 5])  # even and uneven shards
+def test_row_sharded_contexts_two_ranks_one_gpu(N):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ctx_worker, args=(world, _free_port(), N, 70, ret), nprocs=world, join=True)
+    res = dict(ret)
+    assert res[0][0] and res[1][0]
+    assert res[0][1] <= 1e-10  # gathered forces vs the CPU oracle (contract 1e-6)

@@ -25,6 +25,25 @@ def sphere_case():
     return dict(N=1, rho=float(z["rho"][0]), g=float(z["g"][0]), water_depth=float(z["water_depth"][0]), bodies=[body])
 
 
+def three_body_case():
+    """The generated three-body BEMIO fixture (tests/golden/make_multibody_bemio.py): dataset shapes of a multi-body BEMIO
+    file (added_mass/inf_freq {6,18}, impulse_response_fun/K {6,18,S}) and water_depth = "infinite"."""
+    z = np.load(os.path.join(GOLDEN_DIR, "three_body_bemio.npz"))
+    bodies = []
+    for b in (1, 2, 3):
+        p = f"body{b}/"
+        bodies.append(dict(
+            disp_vol=float(z[p + "properties/disp_vol"]), cg=z[p + "properties/cg"], cb=z[p + "properties/cb"],
+            lin=z[p + "hydro_coeffs/linear_restoring_stiffness"], added_mass_inf=z[p + "hydro_coeffs/added_mass/inf_freq"],
+            rirf_t=z[p + "hydro_coeffs/radiation_damping/impulse_response_fun/t"],
+            rirf_K=z[p + "hydro_coeffs/radiation_damping/impulse_response_fun/K"], w=z["simulation_parameters/w"],
+            ex_mag=z[p + "hydro_coeffs/excitation/mag"], ex_phase=z[p + "hydro_coeffs/excitation/phase"],
+            ex_irf_t=z[p + "hydro_coeffs/excitation/impulse_response_fun/t"],
+            ex_irf_f=z[p + "hydro_coeffs/excitation/impulse_response_fun/f"]))
+    return dict(N=3, rho=float(z["simulation_parameters/rho"]), g=float(z["simulation_parameters/g"]), water_depth=float("inf"),
+                bodies=bodies)
+
+
 def goldens():
     return np.load(os.path.join(GOLDEN_DIR, "sphere_goldens.npz"))
 

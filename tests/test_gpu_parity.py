@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from cases import (GOLDEN_DIR, SPHERE_DT, SPHERE_G, SPHERE_MASS, goldens, iea_sphere_decay, iea_sphere_residual,
-                   load_into_oracle, sphere_case)
+                   load_into_oracle, sphere_case, three_body_case)
 
 pytestmark = pytest.mark.gpu
 
@@ -475,6 +475,47 @@ def test_bemio_h5_ingest_matches_flat_fixture(HF):
     for n in range(5):
         st = (np.array([0, 0, -1.0 - 0.1 * n]), z, np.array([0, 0, 0.2 * n]), z)
         assert np.array_equal(a.step(0.015 * n, *st), b.step(0.015 * n, *st))
+
+
+@pytest.mark.parametrize("fname", ["three_body.h5", "three_body_vlen.h5"])  # water_depth as fixed- / variable-length string
+def test_bemio_h5_multibody_ingest(HF, fname):
+    """Multi-body BEMIO layout (H5FileInfo::ReadH5Data, src/h5fileinfo.cpp:41-90: K {6,6N,S}, A_inf {6,6N} for body1..N)
+    and the string-valued water depth "infinite" (:207-220) through hc_load_bemio_h5: identical to the raw-array setters
+    bit for bit, forces identical to the oracle's.  The file is generated (tests/golden/make_multibody_bemio.py): the
+    reference snapshot ships no multi-body BEMIO blob."""
+    from hydrochrono_amd.hydro import HydroError
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import rest_positions
+    case = three_body_case()
+    a = HF(3)
+    try:
+        a.load_bemio_h5(os.path.join(GOLDEN_DIR, fname))
+    except HydroError as e:
+        if e.status == 5:
+            pytest.skip("libhdf5 not available on this box: " + str(e))
+        raise
+    a.finalize()
+    b, orc = make_pair(HF, case)
+    assert np.array_equal(a.rirf_effective(), b.rirf_effective())
+    assert np.array_equal(a.added_mass_matrix(), b.added_mass_matrix())
+    assert np.array_equal(a.added_mass_matrix(), orc.added_mass_matrix())
+    # infinite depth -> deep-water wave numbers (src/wave_types.cpp:178-255), irregular waves, all three bodies coupled
+    kw = dict(simulation_dt=0.02, simulation_duration=6.0, ramp_duration=1.0, wave_height=2.0, wave_period=7.0,
+              frequency_min=0.05, frequency_max=0.5, nfrequencies=40, peak_enhancement_factor=3.3)
+    for h in (a, b, orc):
+        h.add_waves_irregular(**kw)
+    assert np.array_equal(a.irreg_spectrum()["k"], orc.irreg_spectrum()["k"])
+    motion = PrescribedMotion(3, rest_positions(case), seed=33)
+    for n in range(80):
+        st = motion.state(0.02 * n)
+        fa, fb, fo = a.step(0.02 * n, *st), b.step(0.02 * n, *st), orc.step(0.02 * n, *st)
+        assert np.array_equal(fa, fb)
+        assert_close(fa, fo, TIGHT_TOL, f"three-body BEMIO file vs oracle, step {n}")
+    # regular waves: per-body excitation coefficients read from {6,1,nw} datasets
+    for h in (a, orc):
+        h.add_waves_regular(0.5, 0.62)
+    for x, y in zip(a.regular_coeffs(), orc.regular_coeffs()):
+        assert_close(x, y, 1e-15, "regular-wave coefficients of the three-body file")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -268,9 +268,11 @@ void choose_conv_config(hc_ctx* c) {
         bgps = std::max(8, forced);
         bgps = std::max<long long>(bgps, (c->ngp + 255) / 256);
     } else {
-        // row groups of the UNSHARDED system (6 tiles each): few of them (small systems) need more chunks to fill a round
+        // row groups of the UNSHARDED system (6 tiles each): few of them (small systems) need more chunks to fill a round.
+        // Two workgroups fit on a CU at depth 16, one at depth 32 (twice the accumulators).
         const long long groups_full = std::max<long long>(1, ((c->D + 15) / 16 + 5) / 6);
-        const long long nch_target  = std::max<long long>(c->num_cus / 2, (2LL * c->num_cus + groups_full - 1) / groups_full);
+        const long long slots       = (c->lookahead > 16 ? 1LL : 2LL) * c->num_cus;
+        const long long nch_target  = std::max<long long>(slots / 4, (slots + groups_full - 1) / groups_full);
         bgps                       = (c->ngp + nch_target - 1) / nch_target;
         bgps                       = std::min<long long>(bgps, std::max<long long>(16, (16LL * c->D) / 8));  // <= 16 IRF samples per chunk
     }
@@ -426,7 +428,7 @@ int plan_step(hc_ctx* c, double t, int H) {
     auto& pl = c->plan;
     if (pl.cooldown > 0) --pl.cooldown;
     if (H < 2 || c->lookahead <= 0 || !pl.valid) return 0;
-    if (pl.j_next <= hc::kLookahead) {
+    if (pl.j_next <= c->lookahead) {
         // accept the caller's time if it is the predicted one up to accumulated rounding (t += dt in the caller vs
         // t0 + j*dt here); the radiation term is evaluated on the predicted grid, whose interpolation weights then differ
         // from the caller's by <= tol/dt relative, far inside the 1e-6 contract
@@ -456,19 +458,20 @@ bool make_plan(hc_ctx* c) {
     if (c->lookahead <= 0 || H < 2 || pl.cooldown > 0 || c->S < 2 || c->tau.front() < 0.0) return false;
     const double t0 = c->times[0], dt = c->times[0] - c->times[1];
     if (!(dt > 0.0)) return false;
-    if (dt * hc::kLookahead > 0.5 * (c->tau.back() - c->tau.front())) {
+    const int L = c->lookahead;  // steps per block: 16 or 32
+    if (dt * L > 0.5 * (c->tau.back() - c->tau.front())) {
         pl.cooldown = 64;  // a block would span most of the IRF window: the scatter launches would re-read most of K every step
         return false;
     }
     pl.dt = dt;
-    for (int j = 0; j <= hc::kLookahead; ++j) pl.tgrid[j] = (j == 0) ? t0 : t0 + j * dt;
+    for (int j = 0; j <= L; ++j) pl.tgrid[j] = (j == 0) ? t0 : t0 + j * dt;
     auto G = [&](int idx) { return idx >= 1 ? pl.tgrid[idx] : c->times[static_cast<size_t>(-idx)]; };  // idx > -H
-    for (int i = 0; i <= hc::kLookahead; ++i) {
+    for (int i = 0; i <= L; ++i) {
         pl.scat_lo[i] = c->S;
         pl.scat_hi[i] = -1;
     }
     const double oldest = c->times.back();
-    for (int m = 1; m <= hc::kLookahead; ++m) {
+    for (int m = 1; m <= L; ++m) {
         const int j = m - 1;
         // pass: samples s >= s_cut[j] of block step m need only history known now and the (zero) not-yet-known sample at
         // tgrid[1]: tgrid[m] - tau_s <= tgrid[1] (same expression as the kernel)
@@ -559,6 +562,7 @@ StepViews make_views(const hc_ctx* c) {
 // step itself and by its scatter.  Enqueued behind the step that has just been evaluated (its ring push included).
 void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
     auto& pl = c->plan;
+    const int L = c->lookahead;
     const int H = static_cast<int>(c->times.size());
     // history length the virtual step would see after its own push + prune (PruneHistory, src/hydro_forces.cpp:327-340)
     const double hmin = pl.tgrid[1] - (c->tau.empty() ? 0.0 : c->tau.back());
@@ -581,12 +585,13 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
     const StepViews vw = make_views(c);
     hc::BlockArgs b{};
     b.K                   = rad_panel(c);
-    b.F                   = std::min(c->S, live_samples(c, pl.tgrid[hc::kLookahead])) * c->D;
+    b.F                   = std::min(c->S, live_samples(c, pl.tgrid[L])) * c->D;
+    b.depth               = L;
     b.chunk_gp            = c->chunk_gp_block;
     b.nchunks             = std::max(1, ((b.F + 7) / 8 + c->chunk_gp_block - 1) / c->chunk_gp_block);
     b.max_steps_per_chunk = (c->chunk_gp_block * 8) / c->D + 2;
     b.hist                = hv;
-    for (int j = 0; j < hc::kLookahead; ++j) {
+    for (int j = 0; j < L; ++j) {
         b.tpred[j]   = pl.tgrid[j + 1];
         b.s_cut[j]   = pl.s_cut[j];
         b.s_defer[j] = pl.s_defer[j];
@@ -597,7 +602,7 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
     // over Kex in the same launch) -- provided every predicted time passes the window tests a real step would have to pass.
     static const bool exc_in_block = env_int("HC_EXC_IN_BLOCK", 1) != 0;
     bool exc_block = exc_in_block && with_exc && c->wave_kind == hc::kWaveIrregular && c->nchunks_ex_block > 0;
-    for (int j = 1; j <= hc::kLookahead && exc_block; ++j) exc_block = wave_window_ok(c, pl.tgrid[j]);
+    for (int j = 1; j <= L && exc_block; ++j) exc_block = wave_window_ok(c, pl.tgrid[j]);
     pl.has_exc    = exc_block;
     b.Kex         = vw.kex;
     b.ex          = vw.ex;
@@ -610,26 +615,26 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
     // algorithmic bytes: summed over the 16 steps, step j's share of K and of the velocity vector from s_cut[j]
     // on ...; what the launch has to move once: the live part of K, Kex and the staged vectors
     double samples = 0.0;
-    for (int j = 0; j < hc::kLookahead; ++j) samples += std::max(0, b.F / c->D - pl.s_cut[j]);
+    for (int j = 0; j < L; ++j) samples += std::max(0, b.F / c->D - pl.s_cut[j]);
     const double rad_16 = 8.0 * samples * (static_cast<double>(c->Dloc) * c->D + c->D);
-    const double exc_16 = exc_block ? 8.0 * hc::kLookahead * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
+    const double exc_16 = exc_block ? 8.0 * L * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
     c->prof.block_kernel_bytes      = rad_16 + exc_16;
     const double rad_once = 8.0 * (static_cast<double>(c->Dloc) * b.F + b.F);
     const double exc_once = exc_block ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
     c->prof.block_kernel_bytes_once = rad_once + exc_once;
     if (env_int("HC_DEBUG_PLAN", 0) != 0) {
         std::fprintf(stderr, "[hc] pass t0=%.6f dt=%.17g Hv=%d F/D=%d nchunks=%d exc=%d\n     s_cut:", pl.tgrid[0], pl.dt, Hv, b.F / c->D, b.nchunks, (int)exc_block);
-        for (int j = 0; j < hc::kLookahead; ++j) std::fprintf(stderr, " %d", pl.s_cut[j]);
+        for (int j = 0; j < L; ++j) std::fprintf(stderr, " %d", pl.s_cut[j]);
         std::fprintf(stderr, "\n     s_defer:");
-        for (int j = 0; j < hc::kLookahead; ++j) std::fprintf(stderr, " %d", pl.s_defer[j]);
+        for (int j = 0; j < L; ++j) std::fprintf(stderr, " %d", pl.s_defer[j]);
         std::fprintf(stderr, "\n     scat:");
-        for (int i = 1; i <= hc::kLookahead; ++i) std::fprintf(stderr, " [%d,%d]", pl.scat_lo[i], pl.scat_hi[i]);
+        for (int i = 1; i <= L; ++i) std::fprintf(stderr, " [%d,%d]", pl.scat_lo[i], pl.scat_hi[i]);
         std::fprintf(stderr, "\n");
     }
     hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_once / std::max(1.0, rad_once + exc_once));
     hc::launch_conv_block(b, c->mt_block, stream);
     ev_end(ev, stream);
-    hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, c->d_P.p, c->d_E.p, stream);
+    hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, stream);
 }
 
 // Enqueue the kernels of one evaluation at time t.  d_state: device-visible pointer to the 12N state.  d_user_out
@@ -793,7 +798,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
 
     // ---- off the caller's critical path: everything below is needed by later steps only ----
     if (f.rad && c->lookahead > 0) {
-        if (block && m < hc::kLookahead) {
+        if (block && m < c->lookahead) {
             const auto& pl = c->plan;
             if (pl.scat_hi[m] >= pl.scat_lo[m]) {
                 hc::ScatterArgs sa{};
@@ -809,7 +814,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
                 hc::launch_scatter(sa, stream);
                 ev_end(ev, stream);
             }
-        } else if (!block || m == hc::kLookahead) {
+        } else if (!block || m == c->lookahead) {
             if (block) c->plan.misses = 0;  // a block was consumed completely
             if (H >= 2 && make_plan(c)) launch_pass(c, stream, f.waves);
         }
@@ -1140,6 +1145,10 @@ int hc_finalize(hc_ctx* c) {
     c->times.clear();
     c->have_prev = c->have_prev_device = false;
     c->prev_time = c->prev_time_device = -1.0;
+    {
+        const int want = env_int("HC_LOOKAHEAD", 16);
+        c->lookahead   = want <= 0 ? 0 : (want <= 16 ? 16 : hc::kLookahead);
+    }
     // GEMV scratch
     choose_conv_config(c);
     // step I/O
@@ -1185,7 +1194,6 @@ int hc_finalize(hc_ctx* c) {
     alloc_partials(c);
     c->prof.conv_kernel_bytes  = 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
     c->prof.block_kernel_bytes = hc::kLookahead * c->prof.conv_kernel_bytes;
-    c->lookahead               = env_int("HC_LOOKAHEAD", hc::kLookahead) > 0 ? hc::kLookahead : 0;
     c->plan                    = hc::Plan{};
     HC_HIP(hipStreamSynchronize(c->stream));
     c->finalized = true;
@@ -1625,7 +1633,11 @@ int hc_compute_waves(hc_ctx* c, double t, double* waves_out) {
 
 int hc_set_lookahead(hc_ctx* c, int steps) {
     HC_API_BEGIN(c)
-    c->lookahead = steps > 0 ? hc::kLookahead : 0;
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    HC_HIP(hipDeviceSynchronize());  // a pass of the previous depth may still be running
+    c->lookahead = steps <= 0 ? 0 : (steps <= 16 ? 16 : hc::kLookahead);
+    choose_conv_config(c);  // the pass chunking depends on the depth
+    alloc_partials(c);
     c->plan      = hc::Plan{};
     HC_API_END(c)
 }

@@ -318,50 +318,37 @@ void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv_block_kernel<MT>: the look-ahead pass.  C[row, j] = sum_f K[row, f] * U[f, j], j = 0..15, with
+// conv_block_kernel<MT, R, NB>: the look-ahead pass.  C[row, j] = sum_f K[row, f] * U[f, j], j = 0 .. 16*NB - 1, with
 //   U[(s,col), j] = interp(v_col)(tpred[j] - tau_s) * width_s   for s >= s_cut[j], else 0
-// on v_mfma_f64_16x16x4_f64: the 16-byte word a lane streams from a K panel is the A operand of two MFMAs.  Each wave
-// walks its share of the chunk in sub-tiles of 32 columns: it issues the K loads of the sub-tile, stages
-// U[16 steps][32 columns] in a wave-private LDS tile (bracket table [sample][j] in LDS + two ring loads per value) while
-// those loads are in flight, then every lane reads its B operand (one column, step j = lane & 15) back from LDS (padded
-// rows: conflict-free ds_read_b64).  No workgroup barrier inside the loop, so waves drift out of phase and some wave is
-// always loading.  Same grid / chunk mapping as conv_step_kernel; K is read once for 16 steps, so the pass stays
-// HBM-bound (32 flop/B).  Partials [chunk][j][row], reduced in fixed order by reduce_block_kernel.
+// on v_mfma_f64_16x16x4_f64: the 16-byte word a lane streams from a K panel is the A operand of two MFMAs per block of 16
+// steps, so K leaves HBM ONCE for 16 (NB = 1) or 32 (NB = 2) steps.  Same grid / chunk mapping as conv_step_kernel;
+// partials [chunk][j][row], reduced in fixed order by reduce_block_kernel.
+//
+// Radiation work item = a rolling software pipeline.  The wave keeps R column groups ("fragments": MT 16-byte K words +
+// the ring values of its B operands) in flight at all times: in every step of the loop it waits for the oldest fragment
+// only (a counted vmcnt), forms the B operands in registers
+//     u = wo' * ring[off_older + col] + wn' * ring[off_newer + col]        (wo', wn' = weights x trapezoid width),
+// issues 2*MT*NB MFMAs and immediately re-fills the freed registers with the fragment R groups ahead -- so the wave has
+// loads outstanding while its MFMAs run, and nothing of the right-hand side goes through LDS inside the loop.  Each lane
+// gathers exactly its own B operands (column 8gp + kk (+4), step j = 16*tb + (lane & 15)); the bracket of (IRF sample, step)
+// comes from a table in LDS built once per workgroup.  The not-yet-known sample of the pass is zero (hc_api.cpp:
+// launch_pass), so a bracket whose newer end is that sample simply gets wn' = 0.
+//   UNI: D % 8 == 0 -- a column group never straddles two IRF samples, the sample index is wave-uniform and the bracket
+//        registers are reloaded only when it changes.
+// Excitation work items (Kex x eta(tpred[j] - tau_l), 0.3 % of the bytes) keep the LDS-staged form of round 1.
 // ------------------------------------------------------------------------------------------------
-static constexpr int kWaveGp    = 4;                  // column groups a wave handles per sub-tile (32 columns)
+static constexpr int kWaveGp    = 4;                  // column groups a wave handles per sub-tile of an excitation item (32 columns)
 static constexpr int kUStride   = kWaveGp * 8 + 2;    // LDS row stride of a wave's U[j][col] in doubles: conflict-free ds_read_b64 of the B operand
-static constexpr int kUWave     = kLookahead * kUStride;  // doubles per wave
+static constexpr int kUWave     = 16 * kUStride;      // doubles per wave
 
-// One work item of a look-ahead workgroup: RAD = its radiation chunk of K, !RAD = excitation chunk `e` of Kex.
-template <int MT, bool RAD>
-__device__ __forceinline__ void block_work(const BlockArgs& a, const int chunk, const int grp, const int e, double* Uall, Bracket* tab,
-                                           double* wtab) {
+// Excitation chunk `e` of Kex for the 16 predicted times tpred[j0 .. j0+15].
+template <int MT>
+__device__ __forceinline__ void block_exc_work(const BlockArgs& a, const int grp, const int e, const int j0, double* Uall) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kk = lane >> 4, jstep = lane & 15;
-    const int D = a.hist.D;
-    const Panel& M = RAD ? a.K : a.Kex;
-    int gp0, gp1, c1, s0 = 0;
-    if constexpr (RAD) {
-        gp0 = chunk * a.chunk_gp;
-        gp1 = min((a.F + 7) >> 3, gp0 + a.chunk_gp);
-        c1  = min(a.F, gp1 * 8);
-        s0  = (gp0 * 8) / D;
-        const int ns = (c1 - 1) / D - s0 + 1;
-        for (int idx = tid; idx < ns * kLookahead; idx += kConvThreads) {
-            const int k = idx >> 4, j = idx & 15, s = s0 + k;
-            Bracket b;
-            b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
-            if (s >= a.s_cut[j] && s != a.s_defer[j]) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
-            tab[idx] = b;
-            if (j == 0) wtab[k] = a.width[s];
-        }
-    } else {
-        gp0 = e * a.chunk_gp_ex;
-        gp1 = min(a.Kex.ngp, gp0 + a.chunk_gp_ex);
-        c1  = min(a.ex.L, gp1 * 8);
-    }
-    __syncthreads();  // the only workgroup barrier before the epilogue: from here on the four waves run independently,
-                      // so their load / stage / MFMA phases drift apart and HBM stays busy
+    const Panel& M = a.Kex;
+    const int gp0 = e * a.chunk_gp_ex;
+    const int gp1 = min(a.Kex.ngp, gp0 + a.chunk_gp_ex);
 
     dvec4 acc[MT];
 #pragma unroll
@@ -387,69 +374,41 @@ __device__ __forceinline__ void block_work(const BlockArgs& a, const int chunk, 
                     kv[it][m] = dvec2{0.0, 0.0};
             }
         }
-        // 2. stage U[j][col] for the wave's 32 columns x 16 steps
+        // 2. stage U[j][l] = eta(tpred[j0 + j] - ex_tau[l]) * ex_width[l]  (0 for l >= L) for the wave's 32 columns x 16 steps
+        //    (same arithmetic as eta_at; the table loads of 4 steps go out together)
         {
             const int f = (sub0 + wave + 4 * sit) * 8 + c8;
-            if (a.ablate == 1) {  // diagnostic build path only (HC_BLOCK_ABLATE): no staging loads
-#pragma unroll
-                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = 1.0;
-            } else if (!RAD) {
-                // excitation: U[j][l] = eta(tpred[j] - ex_tau[l]) * ex_width[l]  (0 for l >= L)
-                // (same arithmetic as eta_at; the table loads of 4 steps go out together -- more would raise the register
-                // count of the whole kernel past two waves per SIMD)
-                constexpr int NB = 4;
-                const bool in   = f < a.ex.L;
-                const int fl    = in ? f : 0;
-                const double tf = a.ex.ex_tau[fl], wf = a.ex.ex_width[fl];
+            constexpr int NQ = 4;
+            const bool in   = f < a.ex.L;
+            const int fl    = in ? f : 0;
+            const double tf = a.ex.ex_tau[fl], wf = a.ex.ex_width[fl];
 #pragma unroll 1
-                for (int q0 = 0; q0 < kLookahead / 2; q0 += NB) {
-                    double qv[NB], t1[NB], t2[NB], e1[NB], e2[NB];
-                    int ix[NB];
+            for (int q0 = 0; q0 < 8; q0 += NQ) {
+                double qv[NQ], t1[NQ], t2[NQ], e1[NQ], e2[NQ];
+                int ix[NQ];
 #pragma unroll
-                    for (int q = 0; q < NB; ++q) {
-                        qv[q] = a.tpred[jh + 2 * (q0 + q)] - tf;
-                        ix[q] = eta_guess(a.ex, qv[q]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < NB; ++q) {
-                        t1[q] = a.ex.eta_t[ix[q]];
-                        t2[q] = a.ex.eta_t[ix[q] + 1];
-                        e1[q] = a.ex.eta[ix[q]];
-                        e2[q] = a.ex.eta[ix[q] + 1];
-                    }
-#pragma unroll
-                    for (int q = 0; q < NB; ++q) {
-                        double val = 0.0;
-                        if (in) val = eta_guess_ok(a.ex, ix[q], qv[q], t1[q], t2[q]) ? eta_interp(qv[q], t1[q], t2[q], e1[q], e2[q], a.error_flag)
-                                                                                      : eta_search(a.ex, ix[q], qv[q], a.error_flag);
-                        Us[(jh + 2 * (q0 + q)) * kUStride + sit * 8 + c8] = val * wf;
-                    }
+                for (int q = 0; q < NQ; ++q) {
+                    qv[q] = a.tpred[j0 + jh + 2 * (q0 + q)] - tf;
+                    ix[q] = eta_guess(a.ex, qv[q]);
                 }
-            } else if (f < c1) {
-                // radiation: U[j][(s,col)] = interp(v_col)(tpred[j] - tau_s) * width_s
-                const int s = f / D, col = f - s * D;
-                const double w      = wtab[s - s0];
-                const double vstate = state_velocity(a.hist.state, a.hist.N, col);
-                const Bracket* __restrict__ row = tab + (size_t)(s - s0) * kLookahead;
-                double uq[kLookahead / 2];
 #pragma unroll
-                for (int q = 0; q < kLookahead / 2; ++q) uq[q] = interp_velocity_lean(a.hist, row[jh + 2 * q], col, vstate) * w;
+                for (int q = 0; q < NQ; ++q) {
+                    t1[q] = a.ex.eta_t[ix[q]];
+                    t2[q] = a.ex.eta_t[ix[q] + 1];
+                    e1[q] = a.ex.eta[ix[q]];
+                    e2[q] = a.ex.eta[ix[q] + 1];
+                }
 #pragma unroll
-                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = uq[q];
-            } else {
-#pragma unroll
-                for (int q = 0; q < kLookahead / 2; ++q) Us[(jh + 2 * q) * kUStride + sit * 8 + c8] = 0.0;
+                for (int q = 0; q < NQ; ++q) {
+                    double val = 0.0;
+                    if (in) val = eta_guess_ok(a.ex, ix[q], qv[q], t1[q], t2[q]) ? eta_interp(qv[q], t1[q], t2[q], e1[q], e2[q], a.error_flag)
+                                                                                  : eta_search(a.ex, ix[q], qv[q], a.error_flag);
+                    Us[(jh + 2 * (q0 + q)) * kUStride + sit * 8 + c8] = val * wf;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private LDS tile: no barrier needed
         // 3. 2 MFMAs per streamed 16-byte word and row tile; consecutive MFMAs use different accumulators
-        if (a.ablate == 2) {  // diagnostic: keep the loads, skip the matrix work
-#pragma unroll
-            for (int it = 0; it < kWaveGp; ++it)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(kv[it][m].x), "v"(kv[it][m].y));
-            continue;
-        }
 #pragma unroll
         for (int it = 0; it < kWaveGp; ++it) {
             const double u0 = Us[jstep * kUStride + it * 8 + kk];
@@ -469,30 +428,18 @@ __device__ __forceinline__ void block_work(const BlockArgs& a, const int chunk, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[((size_t)wave * MT + m) * 256 + (kk + 4 * r) * 16 + jstep] = acc[m][r];
     __syncthreads();
-    const int out_chunk = RAD ? chunk : a.nchunks + e;
+    const int out_chunk = a.nchunks + e;
     for (int idx = tid; idx < MT * 256; idx += kConvThreads) {
         const int m = idx >> 8, el = idx & 255, row = el >> 4, j = el & 15;
         const double v = ((red[(0 * MT + m) * 256 + el] + red[(1 * MT + m) * 256 + el]) + red[(2 * MT + m) * 256 + el]) + red[(3 * MT + m) * 256 + el];
-        a.partials[((size_t)out_chunk * kLookahead + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
+        a.partials[((size_t)out_chunk * a.depth + j0 + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Radiation work item of the look-ahead pass as a rolling software pipeline (round 2).  The wave keeps R column groups
-// ("fragments": MT 16-byte K words + the four ring values of its two B operands) in flight at all times: in every step
-// of the loop it waits for the oldest fragment only (a counted vmcnt), forms the two B operands in registers
-//     u = wo' * ring[off_older + col] + wn' * ring[off_newer + col]        (wo', wn' = weights x trapezoid width),
-// issues 2*MT MFMAs and immediately re-fills the freed registers with the fragment R groups ahead -- so the wave has
-// loads outstanding while its MFMAs run, and nothing of the right-hand side goes through LDS inside the loop.  Each lane
-// gathers exactly its own B operands (column 8gp + kk (+4), step j = lane & 15); the bracket of (IRF sample, step) comes
-// from a table in LDS built once per workgroup.  The not-yet-known sample of the pass is zero (hc_api.cpp: launch_pass),
-// so a bracket whose newer end is that sample simply gets wn' = 0.
-//   UNI: D % 8 == 0 -- a column group never straddles two IRF samples, the sample index is wave-uniform and the bracket
-//        registers are reloaded only when it changes.
-// ------------------------------------------------------------------------------------------------
-template <int MT, int R, bool UNI>
+template <int MT, int R, int NB, bool UNI>
 __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int chunk, const int grp, double* red, double* t_wo, double* t_wn,
                                                  int* t_oo, int* t_on) {
+    constexpr int L = 16 * NB;  // steps of the pass
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 4, jstep = lane & 15;
@@ -502,8 +449,8 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
     const int s0  = (gp0 * 8) / D;
     const int ns  = (min(a.F, gp1 * 8) - 1) / D - s0 + 1;
     const int s_live = a.F / D;  // F is a whole number of samples
-    for (int idx = tid; idx < ns * kLookahead; idx += kConvThreads) {
-        const int k = idx >> 4, j = idx & 15, s = s0 + k;
+    for (int idx = tid; idx < ns * L; idx += kConvThreads) {
+        const int k = idx / L, j = idx - k * L, s = s0 + k;
         Bracket b;
         b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
         if (s >= a.s_cut[j] && s != a.s_defer[j] && s < s_live) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
@@ -515,17 +462,19 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
     }
     __syncthreads();
 
-    dvec4 acc[MT];
+    dvec4 acc[NB][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = dvec4{0.0, 0.0, 0.0, 0.0};
+    for (int tb = 0; tb < NB; ++tb)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[tb][m] = dvec4{0.0, 0.0, 0.0, 0.0};
     const double* __restrict__ kbase = a.K.base + ((size_t)(grp * MT) * a.K.ngp) * 128 + lane * 2;
     const size_t tile_stride         = (size_t)a.K.ngp * 128;
     const double* __restrict__ ring  = a.hist.ring_v;
 
     // pipeline registers
     dvec2 kv[R][MT];
-    double vo[R][2], vn[R][2], wo_[R][2], wn_[R][2];
-    // issue-side position: column group gp_i of this wave and the (sample, column) of its first column per half
+    double vo[R][2][NB], vn[R][2][NB], wo_[R][2][NB], wn_[R][2][NB];
+    // issue-side position: column group gp_i of this wave
     int gp_i = gp0 + wave;
     // trackers of the two columns of a lane (half 0: 8gp + kk, half 1: 8gp + 4 + kk): IRF sample and column inside it.
     // UNI: both halves of all lanes are in sample s_u, the group's first column is column cb_u of it (wave-uniform).
@@ -537,28 +486,32 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
         s_t[h] = UNI ? s_u : f / D;
         c_t[h] = f - s_t[h] * D;
     }
-    double bwo[2], bwn[2];
-    int boo[2], bon[2];
+    double bwo[2][NB], bwn[2][NB];
+    int boo[2][NB], bon[2][NB];
     auto load_bracket = [&](int h) {
         // columns past the chunk's last live sample (the rest of its last column group, or the groups the wave re-reads
         // past the end) get zero weights
         const int ks = s_t[h] - s0;
         const bool in = ks >= 0 && ks < ns;
-        const int k  = (in ? ks : 0) * kLookahead + jstep;
-        bwo[h] = in ? t_wo[k] : 0.0;
-        bwn[h] = in ? t_wn[k] : 0.0;
-        boo[h] = in ? t_oo[k] : 0;
-        bon[h] = in ? t_on[k] : 0;
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) {
+            const int k = (in ? ks : 0) * L + 16 * tb + jstep;
+            bwo[h][tb] = in ? t_wo[k] : 0.0;
+            bwn[h][tb] = in ? t_wn[k] : 0.0;
+            boo[h][tb] = in ? t_oo[k] : 0;
+            bon[h][tb] = in ? t_on[k] : 0;
+        }
+    };
+    auto copy_bracket = [&]() {
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) { bwo[1][tb] = bwo[0][tb]; bwn[1][tb] = bwn[0][tb]; boo[1][tb] = boo[0][tb]; bon[1][tb] = bon[0][tb]; }
     };
     load_bracket(0);
-    if constexpr (UNI) {
-        bwo[1] = bwo[0]; bwn[1] = bwn[0]; boo[1] = boo[0]; bon[1] = bon[0];
-    } else {
-        load_bracket(1);
-    }
+    if constexpr (UNI) copy_bracket();
+    else load_bracket(1);
 
     auto issue = [&](const int slot) {
-        // Unconditional: every call issues the same MT + 4 loads, so the compiler's vmcnt bookkeeping stays exact (a
+        // Unconditional: every call issues the same MT + 4*NB loads, so the compiler's vmcnt bookkeeping stays exact (a
         // branch around the loads degrades every wait in the loop to "all but a few").  Past the end of the chunk the
         // wave re-reads its last column group with zero weights.
         const bool live = gp_i < gp1;
@@ -567,12 +520,14 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
         for (int m = 0; m < MT; ++m)
             kv[slot][m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kbase + (size_t)m * tile_stride + (size_t)gpc * 128));
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            vo[slot][h]  = ring[boo[h] + c_t[h]];
-            vn[slot][h]  = ring[bon[h] + c_t[h]];
-            wo_[slot][h] = live ? bwo[h] : 0.0;
-            wn_[slot][h] = live ? bwn[h] : 0.0;
-        }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int tb = 0; tb < NB; ++tb) {
+                vo[slot][h][tb]  = ring[boo[h][tb] + c_t[h]];
+                vn[slot][h][tb]  = ring[bon[h][tb] + c_t[h]];
+                wo_[slot][h][tb] = live ? bwo[h][tb] : 0.0;
+                wn_[slot][h][tb] = live ? bwn[h][tb] : 0.0;
+            }
         // advance to this wave's next column group (32 columns on)
         gp_i += 4;
         if constexpr (UNI) {
@@ -584,7 +539,7 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
                 } while (cb_u >= D);
                 s_t[0] = s_u;
                 load_bracket(0);
-                bwo[1] = bwo[0]; bwn[1] = bwn[0]; boo[1] = boo[0]; bon[1] = bon[0];
+                copy_bracket();
             }
             c_t[0] = cb_u + kk;
             c_t[1] = cb_u + 4 + kk;
@@ -601,12 +556,20 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
         }
     };
     auto consume = [&](const int slot) {
-        const double u0 = wo_[slot][0] * vo[slot][0] + wn_[slot][0] * vn[slot][0];
-        const double u1 = wo_[slot][1] * vo[slot][1] + wn_[slot][1] * vn[slot][1];
+        double u[2][NB];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[slot][m].x, u0, acc[m], 0, 0, 0);
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[slot][m].y, u1, acc[m], 0, 0, 0);
+            for (int tb = 0; tb < NB; ++tb) u[h][tb] = wo_[slot][h][tb] * vo[slot][h][tb] + wn_[slot][h][tb] * vn[slot][h][tb];
+        // consecutive MFMAs use different accumulators
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[tb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[slot][m].x, u[0][tb], acc[tb][m], 0, 0, 0);
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[tb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[slot][m].y, u[1][tb], acc[tb][m], 0, 0, 0);
     };
 
     const int nfrag = (gp1 - gp0 - wave + 3) / 4;  // column groups of this wave
@@ -620,68 +583,77 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
         }
     }
 
-    __syncthreads();
-    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg.  red[wave][m][row*16 + j].
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg.  red[wave][m][row*16 + j], one block of
+    // 16 steps at a time (the buffer holds one).
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int tb = 0; tb < NB; ++tb) {
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[((size_t)wave * MT + m) * 256 + (kk + 4 * r) * 16 + jstep] = acc[m][r];
-    __syncthreads();
-    for (int idx = tid; idx < MT * 256; idx += kConvThreads) {
-        const int m = idx >> 8, el = idx & 255, row = el >> 4, j = el & 15;
-        const double v = ((red[(0 * MT + m) * 256 + el] + red[(1 * MT + m) * 256 + el]) + red[(2 * MT + m) * 256 + el]) + red[(3 * MT + m) * 256 + el];
-        a.partials[((size_t)chunk * kLookahead + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((size_t)wave * MT + m) * 256 + (kk + 4 * r) * 16 + jstep] = acc[tb][m][r];
+        __syncthreads();
+        for (int idx = tid; idx < MT * 256; idx += kConvThreads) {
+            const int m = idx >> 8, el = idx & 255, row = el >> 4, j = el & 15;
+            const double v = ((red[(0 * MT + m) * 256 + el] + red[(1 * MT + m) * 256 + el]) + red[(2 * MT + m) * 256 + el]) + red[(3 * MT + m) * 256 + el];
+            a.partials[((size_t)chunk * L + 16 * tb + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
+        }
     }
 }
 
-template <int MT, int R>
-__global__ void __launch_bounds__(kConvThreads, 2) conv_block_kernel2(BlockArgs a) {
+template <int MT, int R, int NB>
+__global__ void __launch_bounds__(kConvThreads, NB == 1 ? 2 : 1) conv_block_kernel(BlockArgs a) {
     // dynamic LDS: [front: cross-wave reduction buffer / U tiles of the excitation items][bracket table, SoA: wo', wn', off_older, off_newer]
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double* front = reinterpret_cast<double*>(smem_raw);
-    const int nt  = a.max_steps_per_chunk * kLookahead;
+    const int nt  = a.max_steps_per_chunk * 16 * NB;
     double* t_wo  = front + a.lds_front_doubles;
     double* t_wn  = t_wo + nt;
     int* t_oo     = reinterpret_cast<int*>(t_wn + nt);
     int* t_on     = t_oo + nt;
 
+    // Block index -> (chunk, row group).  Workgroups are dealt to the 8 XCDs round-robin by block index, and the row groups
+    // of one chunk gather the same ring rows, so they get block indices that are congruent mod 8 and close together
+    // ([octet of chunks][row group][chunk % 8]): the gathers of all but the first then hit that XCD's L2.
     const int r     = (int)blockIdx.x % (8 * a.ngroups);
     const int chunk = ((int)blockIdx.x / (8 * a.ngroups)) * 8 + (r & 7);
     const int grp   = r >> 3;
     if (chunk >= a.nchunks) return;
 
-    if ((a.hist.D & 7) == 0) block_rad_stream<MT, R, true>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
-    else block_rad_stream<MT, R, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
-    // excitation chunks for the 16 predicted times ride at the end of radiation workgroups (old LDS-staged form; 0.3 % of the work)
-    for (int e = chunk; e < a.nchunks_ex; e += a.nchunks) {
-        __syncthreads();
-        block_work<MT, false>(a, chunk, grp, e, front, nullptr, nullptr);
+    if ((a.hist.D & 7) == 0) block_rad_stream<MT, R, NB, true>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+    else block_rad_stream<MT, R, NB, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+    // The excitation force depends on time only: its chunks over Kex (a fraction of a percent of K) for the predicted times
+    // ride at the end of radiation workgroups, so the launch keeps its number of workgroups (grid rounds on the chip).
+    for (int e = chunk; e < a.nchunks_ex; e += a.nchunks)
+        for (int tb = 0; tb < NB; ++tb) {
+            __syncthreads();  // the reduction buffer of the previous work item aliases the U tiles of this one
+            block_exc_work<MT>(a, grp, e, 16 * tb, front);
+        }
+}
+
+template <class KernelT>
+static void allow_dynamic_lds(KernelT kernel, size_t smem, size_t& granted) {
+    if (smem > 64 * 1024 && smem > granted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        granted = smem;
     }
 }
 
-template <int MT>
-__global__ void __launch_bounds__(kConvThreads, 2) conv_block_kernel(BlockArgs a) {
-    // dynamic LDS: per-wave U sub-tiles [4][16][34] (re-used as the cross-wave reduction buffer at the end),
-    // bracket table [ns][16], widths [ns]
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    double* Uall = reinterpret_cast<double*>(smem_raw);
-    Bracket* tab = reinterpret_cast<Bracket*>(Uall + a.lds_front_doubles);
-    double* wtab = reinterpret_cast<double*>(tab + (size_t)a.max_steps_per_chunk * kLookahead);
-
-    // Block index -> (chunk, row group).  Workgroups are dealt to the 8 XCDs round-robin by block index, and the row groups
-    // of one chunk stage the same ring rows, so they get block indices that are congruent mod 8 and close together
-    // ([octet of chunks][row group][chunk % 8]): the staging loads of all but the first then hit that XCD's L2.
-    const int r     = (int)blockIdx.x % (8 * a.ngroups);
-    const int chunk = ((int)blockIdx.x / (8 * a.ngroups)) * 8 + (r & 7);
-    const int grp   = r >> 3;
-    if (chunk >= a.nchunks) return;
-
-    block_work<MT, true>(a, chunk, grp, 0, Uall, tab, wtab);
-    // The excitation force depends on time only: its chunks over Kex (a fraction of a percent of K) for the 16 predicted
-    // times ride at the end of radiation workgroups, so the launch keeps its number of workgroups (grid rounds on the chip).
-    for (int e = chunk; e < a.nchunks_ex; e += a.nchunks) {
-        __syncthreads();  // the reduction buffer of the previous work item aliases the U tiles of this one
-        block_work<MT, false>(a, chunk, grp, e, Uall, tab, wtab);
+template <int MT, int R>
+static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, hipStream_t stream) {
+    static size_t granted16 = 0, granted32 = 0;
+    if (b.depth == 32) {
+        if constexpr (MT == 6) {
+            static const int r32 = [] { const char* e = std::getenv("HC_BLOCK_R32"); return e ? std::atoi(e) : 4; }();  // tuning runs only
+            if (r32 == 5) { hipLaunchKernelGGL((conv_block_kernel<6, 5, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            if (r32 == 6) { hipLaunchKernelGGL((conv_block_kernel<6, 6, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            if (r32 == 7) { hipLaunchKernelGGL((conv_block_kernel<6, 7, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+        }
+        allow_dynamic_lds(conv_block_kernel<MT, R + 1, 2>, smem, granted32);
+        hipLaunchKernelGGL((conv_block_kernel<MT, R + 1, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    } else {
+        allow_dynamic_lds(conv_block_kernel<MT, R, 1>, smem, granted16);
+        hipLaunchKernelGGL((conv_block_kernel<MT, R, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
     }
 }
 
@@ -689,28 +661,12 @@ void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
     const int nblocks = ((a.nchunks + 7) >> 3) * 8 * a.ngroups;  // octets of chunks, see the kernel's block mapping
     if (nblocks <= 0) return;
     BlockArgs b = a;
-    static const int ablate  = [] { const char* e = std::getenv("HC_BLOCK_ABLATE"); return e ? std::atoi(e) : 0; }();
-    static const int version = [] { const char* e = std::getenv("HC_BLOCK_KERNEL"); return e ? std::atoi(e) : 2; }();  // 1: round-1 kernel (A/B runs)
-    b.ablate = ablate;
-    b.lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // per-wave U sub-tiles, later the [wave][tile][16x16] reduction buffer
-    if (version == 1) {
-        const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) +
-                            (size_t)max(1, a.max_steps_per_chunk) * (kLookahead * sizeof(Bracket) + sizeof(double));
-        if (mt == 6) hipLaunchKernelGGL((conv_block_kernel<6>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-        else if (mt == 4) hipLaunchKernelGGL((conv_block_kernel<4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-        else if (mt == 2) hipLaunchKernelGGL((conv_block_kernel<2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-        else hipLaunchKernelGGL((conv_block_kernel<1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-        return;
-    }
-    const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * kLookahead * 24;
-    static const int depth = [] { const char* e = std::getenv("HC_BLOCK_DEPTH"); return e ? std::atoi(e) : 3; }();  // fragments in flight per wave
-    if (mt == 6) {
-        if (depth == 2) hipLaunchKernelGGL((conv_block_kernel2<6, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-        else if (depth == 4) hipLaunchKernelGGL((conv_block_kernel2<6, 4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-        else hipLaunchKernelGGL((conv_block_kernel2<6, 3>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-    } else if (mt == 4) hipLaunchKernelGGL((conv_block_kernel2<4, 4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-    else if (mt == 2) hipLaunchKernelGGL((conv_block_kernel2<2, 4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
-    else hipLaunchKernelGGL((conv_block_kernel2<1, 4>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+    b.lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // [wave][tile][16x16] reduction buffer / per-wave U sub-tiles
+    const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * b.depth * 24;
+    if (mt == 6) launch_conv_block_mt<6, 3>(b, nblocks, smem, stream);
+    else if (mt == 4) launch_conv_block_mt<4, 4>(b, nblocks, smem, stream);
+    else if (mt == 2) launch_conv_block_mt<2, 4>(b, nblocks, smem, stream);
+    else launch_conv_block_mt<1, 4>(b, nblocks, smem, stream);
 }
 
 __device__ __forceinline__ double lane16_sum(double v) {
@@ -723,9 +679,9 @@ __device__ __forceinline__ double lane16_sum(double v) {
 // 16 lanes per output, chunks c = l, l+16, ... (8 loads in flight per lane, adds in ascending chunk order), then a 4-step
 // xor tree.
 __global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restrict__ partials, int nchunks_rad, int nchunks_ex, int Dpad,
-                                                           double* __restrict__ P, double* __restrict__ E) {
+                                                           int depth, double* __restrict__ P, double* __restrict__ E) {
     const int sub = threadIdx.x & 15;
-    const int n   = kLookahead * Dpad;
+    const int n   = depth * Dpad;
     int out       = blockIdx.x * 16 + (threadIdx.x >> 4);  // [segment][j*Dpad + row]
     const bool exc = out >= n;
     if (exc) out -= n;
@@ -743,11 +699,12 @@ __global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restr
     if (out < n && sub == 0) (exc ? E : P)[out] = v;
 }
 
-void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_ex, int Dpad, double* d_P, double* d_E, hipStream_t stream) {
-    const int n    = kLookahead * Dpad;
+void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_ex, int Dpad, int depth, double* d_P, double* d_E,
+                         hipStream_t stream) {
+    const int n    = depth * Dpad;
     const int nblk = (n + 15) / 16;  // n is a multiple of 16, so the excitation segment starts on a workgroup boundary
     hipLaunchKernelGGL(reduce_block_kernel, dim3(nchunks_ex > 0 ? 2 * nblk : nblk), dim3(256), 0, stream, d_partials, nchunks_rad, nchunks_ex,
-                       Dpad, d_P, d_E);
+                       Dpad, depth, d_P, d_E);
 }
 
 // ------------------------------------------------------------------------------------------------

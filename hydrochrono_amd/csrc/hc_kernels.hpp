@@ -6,7 +6,7 @@
 
 namespace hc {
 
-constexpr int kLookahead = 16;  // future steps covered by one blocked pass (= N dimension of v_mfma_f64_16x16x4_f64)
+constexpr int kLookahead = 32;  // most future steps one blocked pass covers (1 or 2 blocks of 16 = N dimension of v_mfma_f64_16x16x4_f64)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Panel layout of the convolution matrices in HBM (radiation K[D_loc x S*D], excitation Kex[D_loc x L]).
@@ -113,7 +113,7 @@ struct BlockArgs {
     int nchunks;
     int max_steps_per_chunk;
     int lds_front_doubles;  // set by the launcher
-    int ablate;             // diagnostics only (HC_BLOCK_ABLATE): 1 = no staging loads, 2 = no MFMAs
+    int depth;              // steps covered: 16 or 32
     HistoryView hist;
     double tpred[kLookahead];  // predicted step times, tpred[0] = hist.t
     int s_cut[kLookahead];
@@ -218,7 +218,8 @@ void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream);
 void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream);
 // P[j][row] = sum over the radiation chunks c of partials[c][j][row], E[j][row] = the same over the excitation chunks
 // (fixed order; nchunks_ex may be 0)
-void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_ex, int Dpad, double* d_P, double* d_E, hipStream_t stream);
+void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_ex, int Dpad, int depth, double* d_P, double* d_E,
+                         hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 void launch_scatter(const ScatterArgs& a, hipStream_t stream);
 void launch_taper(const TaperArgs& a, hipStream_t stream);

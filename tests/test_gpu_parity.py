@@ -695,7 +695,7 @@ def test_spectral_component_sum_mode_agrees_with_irf_convolution(HF):
     for d in (0, 2, 4):  # surge, heave, pitch (sway / roll / yaw excitation of a sphere in head seas is zero)
         rel = np.sqrt(np.mean((fa[:, d] - fb[:, d]) ** 2)) / np.sqrt(np.mean(fa[:, d] ** 2))
         assert rel < 5e-3, (d, rel)
-    # closed form for one row at one time, straight from the definition
+    # closed form straight from the definition: all six rows at 100 times (independent numpy evaluation, including a ramp)
     sp = b.irreg_spectrum()
     case = sphere_case()["bodies"][0]
     w, mag, ph = case["w"], case["ex_mag"].reshape(6, -1) * 1000.0 * 9.81, case["ex_phase"].reshape(6, -1)
@@ -703,11 +703,21 @@ def test_spectral_component_sum_mode_agrees_with_irf_convolution(HF):
     idx = np.clip(om / (w[-1] / len(w)) - 1, 0, len(w) - 1)
     k0 = np.minimum(np.floor(idx).astype(int), len(w) - 2)
     fr = idx - k0
-    X = mag[2, k0] + fr * (mag[2, k0 + 1] - mag[2, k0])
-    P = ph[2, k0] + fr * (ph[2, k0 + 1] - ph[2, k0])
-    t = 123.4
-    expect = np.sum(X * np.sqrt(2 * sp["S"] * sp["df"]) * np.cos(om * t - sp["phase"] + P))
-    assert abs(b.compute_waves(t)[2] - expect) <= 1e-10 * abs(expect)
+    X = mag[:, k0] + fr[None, :] * (mag[:, k0 + 1] - mag[:, k0])   # [6][nf]
+    P = ph[:, k0] + fr[None, :] * (ph[:, k0 + 1] - ph[:, k0])
+    amp = np.sqrt(2 * sp["S"] * sp["df"])
+
+    def closed_form(t, ramp):
+        f = np.sum(X * amp[None, :] * np.cos(om[None, :] * t - sp["phase"][None, :] + P), axis=1)
+        return f * (0.0 if t <= 0 else t / ramp) if (ramp > 0 and t < ramp) else f
+
+    scale = np.max(np.abs([closed_form(t, 0.0) for t in ts[::50]]))
+    for t in np.linspace(3.7, 290.0, 100):
+        assert np.max(np.abs(b.compute_waves(float(t)) - closed_form(t, 0.0))) <= 1e-10 * scale, t
+    c = HF.from_case(sphere_case())
+    c.add_waves_irregular(spectral=True, **dict(kw, ramp_duration=40.0))
+    for t in (0.0, 5.0, 39.9, 40.0, 77.7):
+        assert np.max(np.abs(c.compute_waves(t) - closed_form(t, 40.0))) <= 1e-10 * scale, t
 
 
 def test_export_irregular_inputs_h5(HF, tmp_path):
@@ -819,11 +829,11 @@ def test_c4_size_array_properties_on_one_gpu(HF):
         h.set_history(t_hist, v_hist)
         return h
 
-    nsteps = 20
+    nsteps = 36  # plain start, pass, a whole block (16 or 32 steps), the next pass
     states = [motion.state(5.0 + n * dt) for n in range(nsteps)]
     full = make()
     full.enable_profiling(1)
-    f_look = [full.step(5.0 + n * dt, *states[n]) for n in range(nsteps)]  # plain start, pass, a whole block, the next pass
+    f_look = [full.step(5.0 + n * dt, *states[n]) for n in range(nsteps)]
     prof = full.profile()
     full.enable_profiling(0)
     assert prof["block_kernel_launches"] >= 2 and prof["scatter_kernel_launches"] >= 15 and prof["conv_kernel_launches"] == 1

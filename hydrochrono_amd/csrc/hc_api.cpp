@@ -94,8 +94,10 @@ bool is_local(const hc_ctx* c, int body) { return body >= c->b0 && body < c->b1;
 void ring_alloc(hc_ctx* c, int cap) {
     c->d_ring_t.alloc(cap);
     c->d_ring_v.alloc(static_cast<size_t>(cap) * c->D);
+    c->d_ring_vT.alloc(static_cast<size_t>(cap) * c->D);
     HC_HIP(hipMemsetAsync(c->d_ring_t.p, 0, cap * sizeof(double), c->stream));
     HC_HIP(hipMemsetAsync(c->d_ring_v.p, 0, static_cast<size_t>(cap) * c->D * sizeof(double), c->stream));
+    HC_HIP(hipMemsetAsync(c->d_ring_vT.p, 0, static_cast<size_t>(cap) * c->D * sizeof(double), c->stream));
     c->Hcap = cap;
     c->head = -1;
 }
@@ -117,6 +119,9 @@ void ring_grow(hc_ctx* c, int need, int have) {
         HC_HIP(hipMemcpyAsync(nv.p + static_cast<size_t>(dst) * c->D, c->d_ring_v.p + static_cast<size_t>(src) * c->D,
                               c->D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
+    c->d_ring_vT.alloc(static_cast<size_t>(cap2) * c->D);
+    hc::launch_ring_transpose(nv.p, cap2, c->D, c->d_ring_vT.p, c->stream);
+    HC_HIP(hipGetLastError());
     HC_HIP(hipStreamSynchronize(c->stream));
     std::swap(c->d_ring_t.p, nt.p);
     std::swap(c->d_ring_t.n, nt.n);
@@ -577,6 +582,7 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
     hv.t       = pl.tgrid[1];
     hv.ring_t  = c->d_ring_t.p;
     hv.ring_v  = c->d_ring_v.p;
+    hv.ring_vT = c->d_ring_vT.p;
     hv.head    = (c->head + 1) % c->Hcap;  // slot of the virtual sample (never read: time and velocity come from t / state)
     hv.H       = Hv;
     hv.Hcap    = c->Hcap;
@@ -790,6 +796,8 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     z.D             = c->D;
     z.ring_t        = c->d_ring_t.p;
     z.ring_v        = c->d_ring_v.p;
+    z.ring_vT       = c->d_ring_vT.p;
+    z.Hcap          = c->Hcap;
     {
         hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
         hc::launch_finalize(z, stream);
@@ -1673,6 +1681,8 @@ int hc_set_history(hc_ctx* c, int n, const double* times, const double* vel) {
         // against a non-blocking stream (it could be overtaken by them)
         HC_HIP(hipMemcpyAsync(c->d_ring_t.p, tt.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HC_HIP(hipMemcpyAsync(c->d_ring_v.p, vv.data(), vv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hc::launch_ring_transpose(c->d_ring_v.p, c->Hcap, c->D, c->d_ring_vT.p, c->stream);
+        HC_HIP(hipGetLastError());
     }
     HC_HIP(hipStreamSynchronize(c->stream));  // tt / vv are released on return
     c->head      = n - 1;

@@ -457,8 +457,8 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
         const double w = a.width[s < s_live ? s : 0];
         t_wo[idx] = b.wo * w;
         t_wn[idx] = (b.off_newer >= 0) ? b.wn * w : 0.0;
-        t_oo[idx] = b.off_older;
-        t_on[idx] = max(b.off_newer, 0);
+        t_oo[idx] = b.off_older / D;          // ring slot of the older sample
+        t_on[idx] = max(b.off_newer, 0) / D;  // ... of the newer one
     }
     __syncthreads();
 
@@ -469,11 +469,16 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
         for (int m = 0; m < MT; ++m) acc[tb][m] = dvec4{0.0, 0.0, 0.0, 0.0};
     const double* __restrict__ kbase = a.K.base + ((size_t)(grp * MT) * a.K.ngp) * 128 + lane * 2;
     const size_t tile_stride         = (size_t)a.K.ngp * 128;
-    const double* __restrict__ ring  = a.hist.ring_v;
+    // B operands are gathered from the per-DoF copy of the ring: for consecutive steps j the query times move by one
+    // history step, so the 16 lanes of one column read (up to a wrap of the ring) 16 consecutive doubles -- one or two
+    // cache lines per column instead of one line per step from the sample-major ring.
+    const double* __restrict__ ring = a.hist.ring_vT;
+    const int Hc                    = a.hist.Hcap;
 
-    // pipeline registers
+    // pipeline registers (UNI: the two columns of a lane lie in the same IRF sample and share bracket and weights)
+    constexpr int HB = UNI ? 1 : 2;
     dvec2 kv[R][MT];
-    double vo[R][2][NB], vn[R][2][NB], wo_[R][2][NB], wn_[R][2][NB];
+    double vo[R][2][NB], vn[R][2][NB], wo_[R][HB][NB], wn_[R][HB][NB];
     // issue-side position: column group gp_i of this wave
     int gp_i = gp0 + wave;
     // trackers of the two columns of a lane (half 0: 8gp + kk, half 1: 8gp + 4 + kk): IRF sample and column inside it.
@@ -486,8 +491,8 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
         s_t[h] = UNI ? s_u : f / D;
         c_t[h] = f - s_t[h] * D;
     }
-    double bwo[2][NB], bwn[2][NB];
-    int boo[2][NB], bon[2][NB];
+    double bwo[HB][NB], bwn[HB][NB];
+    int boo[HB][NB], bon[HB][NB];
     auto load_bracket = [&](int h) {
         // columns past the chunk's last live sample (the rest of its last column group, or the groups the wave re-reads
         // past the end) get zero weights
@@ -502,13 +507,8 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
             bon[h][tb] = in ? t_on[k] : 0;
         }
     };
-    auto copy_bracket = [&]() {
-#pragma unroll
-        for (int tb = 0; tb < NB; ++tb) { bwo[1][tb] = bwo[0][tb]; bwn[1][tb] = bwn[0][tb]; boo[1][tb] = boo[0][tb]; bon[1][tb] = bon[0][tb]; }
-    };
     load_bracket(0);
-    if constexpr (UNI) copy_bracket();
-    else load_bracket(1);
+    if constexpr (!UNI) load_bracket(1);
 
     auto issue = [&](const int slot) {
         // Unconditional: every call issues the same MT + 4*NB loads, so the compiler's vmcnt bookkeeping stays exact (a
@@ -523,8 +523,13 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int tb = 0; tb < NB; ++tb) {
-                vo[slot][h][tb]  = ring[boo[h][tb] + c_t[h]];
-                vn[slot][h][tb]  = ring[bon[h][tb] + c_t[h]];
+                vo[slot][h][tb] = ring[c_t[h] * Hc + boo[h % HB][tb]];
+                vn[slot][h][tb] = ring[c_t[h] * Hc + bon[h % HB][tb]];
+            }
+#pragma unroll
+        for (int h = 0; h < HB; ++h)
+#pragma unroll
+            for (int tb = 0; tb < NB; ++tb) {
                 wo_[slot][h][tb] = live ? bwo[h][tb] : 0.0;
                 wn_[slot][h][tb] = live ? bwn[h][tb] : 0.0;
             }
@@ -539,7 +544,6 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
                 } while (cb_u >= D);
                 s_t[0] = s_u;
                 load_bracket(0);
-                copy_bracket();
             }
             c_t[0] = cb_u + kk;
             c_t[1] = cb_u + 4 + kk;
@@ -560,7 +564,7 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int tb = 0; tb < NB; ++tb) u[h][tb] = wo_[slot][h][tb] * vo[slot][h][tb] + wn_[slot][h][tb] * vn[slot][h][tb];
+            for (int tb = 0; tb < NB; ++tb) u[h][tb] = wo_[slot][h % HB][tb] * vo[slot][h][tb] + wn_[slot][h % HB][tb] * vn[slot][h][tb];
         // consecutive MFMAs use different accumulators
 #pragma unroll
         for (int tb = 0; tb < NB; ++tb)
@@ -601,8 +605,8 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
     }
 }
 
-template <int MT, int R, int NB>
-__global__ void __launch_bounds__(kConvThreads, NB == 1 ? 2 : 1) conv_block_kernel(BlockArgs a) {
+template <int MT, int R, int NB, int WPS = (NB == 1 ? 2 : 1)>
+__global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs a) {
     // dynamic LDS: [front: cross-wave reduction buffer / U tiles of the excitation items][bracket table, SoA: wo', wn', off_older, off_newer]
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double* front = reinterpret_cast<double*>(smem_raw);
@@ -621,7 +625,7 @@ __global__ void __launch_bounds__(kConvThreads, NB == 1 ? 2 : 1) conv_block_kern
     if (chunk >= a.nchunks) return;
 
     if ((a.hist.D & 7) == 0) block_rad_stream<MT, R, NB, true>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
-    else block_rad_stream<MT, R, NB, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+    else block_rad_stream<MT, (WPS > 1 && NB > 1) ? 2 : R, NB, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
     // The excitation force depends on time only: its chunks over Kex (a fraction of a percent of K) for the predicted times
     // ride at the end of radiation workgroups, so the launch keeps its number of workgroups (grid rounds on the chip).
     for (int e = chunk; e < a.nchunks_ex; e += a.nchunks)
@@ -643,11 +647,15 @@ template <int MT, int R>
 static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, hipStream_t stream) {
     static size_t granted16 = 0, granted32 = 0;
     if (b.depth == 32) {
+        static const int v32 = [] { const char* e = std::getenv("HC_BLOCK_V32"); return e ? std::atoi(e) : 0; }();  // tuning runs only
+        if constexpr (MT == 4) {
+            if (v32 == 1) { hipLaunchKernelGGL((conv_block_kernel<4, 3, 2, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            if (v32 == 2) { hipLaunchKernelGGL((conv_block_kernel<4, 4, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            if (v32 == 3) { hipLaunchKernelGGL((conv_block_kernel<4, 6, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+        }
         if constexpr (MT == 6) {
-            static const int r32 = [] { const char* e = std::getenv("HC_BLOCK_R32"); return e ? std::atoi(e) : 4; }();  // tuning runs only
-            if (r32 == 5) { hipLaunchKernelGGL((conv_block_kernel<6, 5, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
-            if (r32 == 6) { hipLaunchKernelGGL((conv_block_kernel<6, 6, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
-            if (r32 == 7) { hipLaunchKernelGGL((conv_block_kernel<6, 7, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            if (v32 == 4) { hipLaunchKernelGGL((conv_block_kernel<6, 5, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            if (v32 == 5) { hipLaunchKernelGGL((conv_block_kernel<6, 3, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
         }
         allow_dynamic_lds(conv_block_kernel<MT, R + 1, 2>, smem, granted32);
         hipLaunchKernelGGL((conv_block_kernel<MT, R + 1, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
@@ -729,7 +737,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         // nobody reads ring slot `head` during this step (the current sample is always taken from `state`)
         if (threadIdx.x == 0) a.ring_t[a.head] = a.t;
         double* slot = a.ring_v + (size_t)a.head * a.D;
-        for (int c = threadIdx.x; c < a.D; c += blockDim.x) slot[c] = state_velocity(a.state, a.N, c);
+        for (int c = threadIdx.x; c < a.D; c += blockDim.x) {
+            const double v = state_velocity(a.state, a.N, c);
+            slot[c] = v;
+            a.ring_vT[(size_t)c * a.Hcap + a.head] = v;  // per-DoF time series for the look-ahead pass
+        }
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -999,6 +1011,20 @@ void launch_scatter(const ScatterArgs& a, hipStream_t stream) {
         }
     }
     hipLaunchKernelGGL(scatter_kernel, dim3(a.K.ntiles * a.ns), dim3(256), smem, stream, a);
+}
+
+__global__ void __launch_bounds__(256) ring_transpose_kernel(const double* __restrict__ ring_v, int Hcap, int D, double* __restrict__ ring_vT) {
+    const size_t n      = (size_t)Hcap * D;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int slot = (int)(i / D), col = (int)(i - (size_t)slot * D);
+        ring_vT[(size_t)col * Hcap + slot] = ring_v[i];
+    }
+}
+
+void launch_ring_transpose(const double* d_ring_v, int Hcap, int D, double* d_ring_vT, hipStream_t stream) {
+    const size_t n = (size_t)Hcap * D;
+    hipLaunchKernelGGL(ring_transpose_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, d_ring_v, Hcap, D, d_ring_vT);
 }
 
 // ------------------------------------------------------------------------------------------------

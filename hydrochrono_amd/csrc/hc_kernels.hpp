@@ -33,6 +33,7 @@ struct HistoryView {
     double t;
     const double* ring_t;
     const double* ring_v;
+    const double* ring_vT;  // the same samples per DoF: ring_vT[col][Hcap] (each DoF's time series contiguous; look-ahead pass)
     int head, H, Hcap;    // H counts the current sample
     double dt_hint;       // t - previous sample time (bracket-search hint only, > 0)
 };
@@ -184,6 +185,8 @@ struct FinalizeArgs {
     int do_push, head, D;
     double* ring_t;
     double* ring_v;
+    double* ring_vT;  // [D][Hcap] transposed copy
+    int Hcap;
 };
 
 // scatter_kernel: Y[(s - s_lo)][row] = width[s] * sum_col K[row, s*D + col] * v[col] for s in [s_lo, s_lo + ns); one
@@ -230,6 +233,8 @@ void launch_eta_synthesis(const double* d_t, int nt, const double* d_amp, const 
 void launch_added_mass_mv(const double* d_M, int rows, int cols, const double* d_w, double c, double* d_R, hipStream_t stream);
 // out[(row*D + col)*S + s] = K[row][s*D + col]  (reference indexing; diagnostics)
 void launch_unrelayout(const Panel& K, int Dloc, int D, int S, double* d_out, hipStream_t stream);
+// ring_vT[col][slot] = ring_v[slot][col] for all slots (after the ring has been re-allocated or injected)
+void launch_ring_transpose(const double* d_ring_v, int Hcap, int D, double* d_ring_vT, hipStream_t stream);
 // synthetic many-body coefficient generator: fills the whole panel matrix (padding = 0)
 void launch_synth_rirf(double* d_K, int ntiles, int ngp, int Dloc, int D, int S, int row0, double dt, unsigned long long seed, double rho,
                        hipStream_t stream);

@@ -22,7 +22,8 @@ data-path collective).  `--scaling strong` also runs on one GPU (77 GB fits in 2
 
 The JSON line also carries
   roofline      HBM roofline of the dominant kernel (the look-ahead pass): bytes the launch has to move ONCE / mean
-                HIP-event duration / 8 TB/s -- a fraction; the reuse over 16 steps is reported separately
+                HIP-event duration / 8 TB/s -- a fraction; the reuse over the 32 (or 16) steps one launch serves is
+                reported separately
   cpu_baseline  the CPU oracle (reference-faithful OpenMP restatement, oracle/) timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N=1 only)
   parity        every timed step compared with the CPU oracle (flat-array variant; the faithful one on its sample)
@@ -60,7 +61,7 @@ def parse():
                     help="default: strong (one coupled array sharded over the ranks) when N > 1, else the single-GPU C3 case")
     ap.add_argument("--profile-stride", type=int, default=17, help="HIP-event sampling stride for the per-step launches (co-prime "
                     "with the 16-step look-ahead period); every look-ahead pass, the roofline kernel, is timed regardless")
-    ap.add_argument("--lookahead", type=int, default=16, help="0: plain per-step evaluation (K streamed every step)")
+    ap.add_argument("--lookahead", type=int, default=32, help="steps per look-ahead block (16 or 32); 0: plain per-step evaluation (K streamed every step)")
     ap.add_argument("--step-dt", type=float, default=DT, help="caller's step size (default = the IRF grid spacing, the common "
                     "case; e.g. 0.007 makes every IRF sample a true interpolation, SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -329,7 +330,7 @@ def main():
         timed = per_step[args.warmup:total] * 1e3
         # dominant kernel: the look-ahead pass when blocking is on (one launch covers 16 steps), else the per-step kernel
         if prof["block_kernel_launches"] > 0:
-            kname, units = "hc::conv_block_kernel", 16
+            kname, units = "hc::conv_block_kernel", int(args.lookahead)
             conv_s = prof["block_kernel_seconds"] / prof["block_kernel_launches"]
             bytes_once = prof["block_kernel_bytes_once"]
             bytes_units = prof["block_kernel_bytes"]
@@ -345,7 +346,7 @@ def main():
         if os.path.exists(tpath) and N == N_BODIES and not strong:
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("block_hbm_bytes_per_launch" if units == 16 else "hbm_bytes_per_launch")
+                traffic = tj.get(f"block{units}_hbm_bytes_per_launch" if units > 1 else "hbm_bytes_per_launch")
                 traffic_src = "profiles/conv_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
                               "gfx950 x2 read correction; not collected in this run)"
             except Exception:
@@ -391,8 +392,8 @@ def main():
                 "fp64_TFLOPs": (2.0 * (bytes_units / 8.0) / conv_s / 1e12) if conv_s > 0 else None,
                 "fp64_frac_of_mfma_peak": (2.0 * (bytes_units / 8.0) / conv_s / 1e12 / FP64_MFMA_PEAK_TF) if conv_s > 0 else None,
                 "note": ("achieved = bytes one launch must move once (live K + Kex + staged vectors) / mean HIP-event duration; the "
-                         "launch serves 16 steps (SURVEY 8d bytes of those steps = algorithmic_bytes_of_the_units, reuse_factor x)")
-                        if units == 16 else "one launch = one step",
+                         f"launch serves {units} steps (SURVEY 8d bytes of those steps = algorithmic_bytes_of_the_units, reuse_factor x)")
+                        if units > 1 else "one launch = one step",
             },
             "term_seconds": {k: prof[k] for k in ("hydrostatics_seconds", "radiation_seconds", "waves_seconds")},
         }

@@ -234,11 +234,19 @@ void setup_panel_geometry(hc_ctx* c) {
     const int want = env_int("HC_CONV_MT", 0);
     if ((want == 1 || want == 2 || want == 4) && c->ntiles % want == 0) c->mt = want;
     c->ngroups = c->ntiles / c->mt;
-    // look-ahead pass: 6 row tiles per workgroup where the tile count allows it -- the workgroups of a chunk stage the same
-    // right-hand side, so fewer, taller workgroups repeat less of that work (measured at C3: 221 vs 234 us per pass)
-    c->mt_block = (c->ntiles % 6 == 0) ? 6 : c->mt;
-    const int want_block = env_int("HC_BLOCK_MT", 0);
-    if ((want_block == 1 || want_block == 2 || want_block == 4 || want_block == 6) && c->ntiles % want_block == 0) c->mt_block = want_block;
+    // Look-ahead pass: as many row tiles per workgroup as the tile count allows -- every workgroup of a chunk forms the same
+    // B operands (ring gathers + interpolation), so fewer, taller workgroups repeat less of that work; it is what bounds
+    // the pass once K streams at the HBM rate (C3: 415 / 277 us with 4 / 6 tiles at depth 32 before the per-DoF ring).
+    // The design value comes from the UNSHARDED tile count (the chunk length below must not depend on the rows owned).
+    auto pick = [](int tiles, int limit) {
+        for (int m : {12, 6, 4, 2, 1})
+            if (m <= limit && tiles % m == 0) return m;
+        return 1;
+    };
+    const int tiles_full  = (c->D + 15) / 16;
+    const int limit       = env_int("HC_BLOCK_MT", 6);
+    c->mt_block_design    = pick(tiles_full, limit);
+    c->mt_block           = pick(c->ntiles, c->mt_block_design);
 }
 
 hc::Panel rad_panel(const hc_ctx* c) {
@@ -275,8 +283,8 @@ void choose_conv_config(hc_ctx* c) {
     } else {
         // row groups of the UNSHARDED system (6 tiles each): few of them (small systems) need more chunks to fill a round.
         // Two workgroups fit on a CU at depth 16, one at depth 32 (twice the accumulators).
-        const long long groups_full = std::max<long long>(1, ((c->D + 15) / 16 + 5) / 6);
-        const long long slots       = (c->lookahead > 16 ? 1LL : 2LL) * c->num_cus;
+        const long long groups_full = std::max<long long>(1, ((c->D + 15) / 16 + c->mt_block_design - 1) / c->mt_block_design);
+        const long long slots       = ((c->lookahead > 16 || c->mt_block_design > 6) ? 1LL : 2LL) * c->num_cus;
         const long long nch_target  = std::max<long long>(slots / 4, (slots + groups_full - 1) / groups_full);
         bgps                       = (c->ngp + nch_target - 1) / nch_target;
         bgps                       = std::min<long long>(bgps, std::max<long long>(16, (16LL * c->D) / 8));  // <= 16 IRF samples per chunk
@@ -1154,7 +1162,7 @@ int hc_finalize(hc_ctx* c) {
     c->have_prev = c->have_prev_device = false;
     c->prev_time = c->prev_time_device = -1.0;
     {
-        const int want = env_int("HC_LOOKAHEAD", 16);
+        const int want = env_int("HC_LOOKAHEAD", 32);
         c->lookahead   = want <= 0 ? 0 : (want <= 16 ? 16 : hc::kLookahead);
     }
     // GEMV scratch

@@ -196,7 +196,7 @@ struct hc_ctx {
     hc::DeviceBuffer<double> d_Y;           // scatter results [kLookahead][kScatterSamples][Dpad]
     hc::DeviceBuffer<double> d_zero_state;  // 12N zeros: the not-yet-known sample of the look-ahead pass
     int chunk_gp_ex_block = 32, nchunks_ex_block = 0;  // excitation chunks of the look-ahead launch
-    int mt_block = 4;                                   // row tiles per workgroup of the look-ahead launch (1, 2, 4 or 6)
+    int mt_block = 4, mt_block_design = 6;              // row tiles per workgroup of the look-ahead launch (1, 2, 4, 6 or 12)
     int num_cus  = 256;                                 // compute units of the device (grid rounds of the look-ahead launch)
     int lookahead = 0;  // 0: off, else kLookahead
     hc::Plan plan;

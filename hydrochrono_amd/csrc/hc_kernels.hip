@@ -605,7 +605,7 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
     }
 }
 
-template <int MT, int R, int NB, int WPS = (NB == 1 ? 2 : 1)>
+template <int MT, int R, int NB, int WPS = ((NB == 1 && MT <= 6) ? 2 : 1)>
 __global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs a) {
     // dynamic LDS: [front: cross-wave reduction buffer / U tiles of the excitation items][bracket table, SoA: wo', wn', off_older, off_newer]
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -628,11 +628,13 @@ __global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs
     else block_rad_stream<MT, (WPS > 1 && NB > 1) ? 2 : R, NB, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
     // The excitation force depends on time only: its chunks over Kex (a fraction of a percent of K) for the predicted times
     // ride at the end of radiation workgroups, so the launch keeps its number of workgroups (grid rounds on the chip).
+    constexpr int MTE = MT > 6 ? 6 : MT;  // row tiles per excitation work item (register budget of the LDS-staged form)
     for (int e = chunk; e < a.nchunks_ex; e += a.nchunks)
-        for (int tb = 0; tb < NB; ++tb) {
-            __syncthreads();  // the reduction buffer of the previous work item aliases the U tiles of this one
-            block_exc_work<MT>(a, grp, e, 16 * tb, front);
-        }
+        for (int tb = 0; tb < NB; ++tb)
+            for (int sub = 0; sub < MT / MTE; ++sub) {
+                __syncthreads();  // the reduction buffer of the previous work item aliases the U tiles of this one
+                block_exc_work<MTE>(a, grp * (MT / MTE) + sub, e, 16 * tb, front);
+            }
 }
 
 template <class KernelT>
@@ -643,7 +645,7 @@ static void allow_dynamic_lds(KernelT kernel, size_t smem, size_t& granted) {
     }
 }
 
-template <int MT, int R>
+template <int MT, int R, int R32 = R + 1>
 static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, hipStream_t stream) {
     static size_t granted16 = 0, granted32 = 0;
     if (b.depth == 32) {
@@ -657,8 +659,8 @@ static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, h
             if (v32 == 4) { hipLaunchKernelGGL((conv_block_kernel<6, 5, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
             if (v32 == 5) { hipLaunchKernelGGL((conv_block_kernel<6, 3, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
         }
-        allow_dynamic_lds(conv_block_kernel<MT, R + 1, 2>, smem, granted32);
-        hipLaunchKernelGGL((conv_block_kernel<MT, R + 1, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
+        allow_dynamic_lds(conv_block_kernel<MT, R32, 2>, smem, granted32);
+        hipLaunchKernelGGL((conv_block_kernel<MT, R32, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
     } else {
         allow_dynamic_lds(conv_block_kernel<MT, R, 1>, smem, granted16);
         hipLaunchKernelGGL((conv_block_kernel<MT, R, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
@@ -671,7 +673,8 @@ void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
     BlockArgs b = a;
     b.lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // [wave][tile][16x16] reduction buffer / per-wave U sub-tiles
     const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * b.depth * 24;
-    if (mt == 6) launch_conv_block_mt<6, 3>(b, nblocks, smem, stream);
+    if (mt == 12) launch_conv_block_mt<12, 3, 2>(b, nblocks, smem, stream);
+    else if (mt == 6) launch_conv_block_mt<6, 3>(b, nblocks, smem, stream);
     else if (mt == 4) launch_conv_block_mt<4, 4>(b, nblocks, smem, stream);
     else if (mt == 2) launch_conv_block_mt<2, 4>(b, nblocks, smem, stream);
     else launch_conv_block_mt<1, 4>(b, nblocks, smem, stream);

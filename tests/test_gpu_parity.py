@@ -107,7 +107,7 @@ def test_sphere_decay_forces_and_golden(HF):
     assert np.max(np.abs(z - zo)) <= 1e-12
 
 
-@pytest.mark.parametrize("lookahead", [16, 0])
+@pytest.mark.parametrize("lookahead", [32, 16, 0])
 def test_iea_sphere_decay_recorded_motion(HF, lookahead):
     """Reference YAML-runner case iea_sphere/decay (expected/results.still.h5): 4000 recorded steps at dt = 0.01 against
     an IRF grid of 0.015 -- every IRF sample is a true interpolation -- with system gravity 9.8 (the BEMIO file says 9.81).

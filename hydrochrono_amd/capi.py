@@ -119,6 +119,16 @@ SIGNATURES.update({
 })
 
 _lib = None
+_step_raw = None
+
+
+def step_raw():
+    """hc_step bound with integer (address) arguments: skips the per-call ctypes pointer conversions."""
+    global _step_raw
+    if _step_raw is None:
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+        _step_raw = proto(("hc_step", load()))
+    return _step_raw
 
 
 def load():

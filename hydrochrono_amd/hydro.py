@@ -173,9 +173,13 @@ class HydroForces:
     # -- per step --
     def step(self, t, pos, rpy, linvel, angvel):
         n3 = 3 * self.N
-        a = [_arr(x, n3) for x in (pos, rpy, linvel, angvel)]
+        a = [x if (type(x) is np.ndarray and x.dtype == np.float64 and x.size == n3 and x.flags.c_contiguous) else _arr(x, n3)
+             for x in (pos, rpy, linvel, angvel)]
         out = np.empty(self.D_local)
-        self._chk(self.lib.hc_step(self.ctx, float(t), _dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(a[3]), _dp(out)))
+        # raw addresses through a c_void_p prototype: this call sits in per-step loops
+        rc = capi.step_raw()(self.ctx, t, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, out.ctypes.data)
+        if rc:
+            self._chk(rc)
         return out
 
     def step_device(self, t, state_ptr, out_ptr, stream_ptr=None):

@@ -1,15 +1,17 @@
 // hc_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the hydro-force path.
 //
-// Steady state, per step:
-//   plain step      conv_step_kernel (all of K, streamed FP64 GEMV)            -> finalize_kernel
-//   look-ahead      every 16th step: conv_block_kernel (K read ONCE for 16 steps, FP64 MFMA GEMM) -> reduce_block_kernel,
-//                   every step:      conv_step_kernel over the few newest IRF samples only        -> finalize_kernel
+// Per step:
+//   plain step      conv_step_kernel (all of K, streamed FP64 GEMV)                    -> finalize_kernel
+//   look-ahead      once per block of 32 / 16 steps: conv_block_kernel (K read ONCE for the block, FP64 MFMA GEMM over what the
+//                   known history contributes to every step of the block) -> reduce_block_kernel;
+//                   every step: finalize_kernel alone (adds the step's own newest-sample part and the scatter results of the
+//                   earlier block steps), then scatter_kernel (what this step's sample contributes to the later ones)
 // conv_step_kernel  partial[chunk][row] = K[row, chunk] . u[chunk]; u[s][col] -- the body velocity history interpolated
 //                   at t - tau_s, times the trapezoid width -- is formed in registers from the velocity ring via a
 //                   per-workgroup bracket table in LDS; the irregular-wave excitation Kex . eta(t - tau_j) rides in the
 //                   same launch as extra column chunks.  HBM-bound: K is read exactly once, 16 B per lane, coalesced.
-// finalize_kernel   fixed-order reduction of the partials (+ the look-ahead part), hydrostatics, regular-wave term,
-//                   total = hydrostatic - radiation + waves, velocity-ring push of this step's sample.
+// finalize_kernel   the step kernel: fixed-order reductions, own-sample part, hydrostatics, regular-wave / spectral term,
+//                   total = hydrostatic - radiation + waves, velocity-ring push of this step's sample, tagged host results.
 // Reference semantics: src/hydro_forces.cpp:263-322,537-691,727-767; src/wave_types.cpp:315-327,776-844.
 #include "hc_kernels.hpp"
 

@@ -149,6 +149,11 @@ int hc_set_tapered_direct_options(hc_ctx* ctx, const hc_tapered_direct_options* 
  *   angvel  [N][3]  ChBody::GetAngVelParent()
  *   force_out [D_local] world-frame force (x,y,z) and torque (x,y,z) per owned body.
  * Errors kept from the reference: excitation window exceeded (src/wave_types.cpp:833-840) -> HC_ERR_RUNTIME.
+ * Deviation: t must not decrease (HC_ERR_INVALID).  The reference has no such check -- it would insert the earlier time at the
+ * front of its newest-first history (src/hydro_forces.cpp:559-574) and interpolate in a non-monotone list; an integrator that
+ * rejects a step re-injects the history it continues from (hc_set_history) or resets it.
+ * hc_step is synchronous (the forces are in force_out when it returns) but does not synchronise the stream: work that later
+ * steps need may still be running on the context's stream.
  * ---------------------------------------------------------------------------------------------- */
 int hc_step(hc_ctx* ctx, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel,
             double* force_out);
@@ -169,11 +174,12 @@ int hc_compute_radiation(hc_ctx* ctx, double t, const double* linvel, const doub
 /* TestHydro::ComputeForceHydrostatics (:263-322) and ComputeForceWaves (:713-725) on their own. */
 int hc_compute_hydrostatics(hc_ctx* ctx, const double* pos, const double* rpy, double* hs_out);
 int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
-/* Multi-step look-ahead (on by default): when the caller steps on a uniform time grid, one blocked pass over K
- * precomputes, for the next 16 predicted step times, the part of the radiation sum that only needs history already
- * known, so K leaves HBM once per 16 steps; each step then adds the few newest samples.  A step whose time deviates from
- * the prediction (> 1e-9 of the step size) silently falls back to the plain per-step evaluation, so results never
- * depend on the prediction being right.  steps = 0 disables it (every step streams K), any other value enables it. */
+/* Multi-step look-ahead (on by default, 32 steps): when the caller steps on a uniform time grid, one blocked pass over K
+ * precomputes, for the next 32 (or 16) predicted step times, what the history known so far contributes to the radiation sum,
+ * so K leaves HBM once per block; a step inside a block is ONE kernel launch that adds its own newest-sample part, and what
+ * later steps of the block need from it is enqueued behind it (off the caller's critical path).  A step whose time deviates
+ * from the prediction (> 1e-9 of the step size) silently falls back to the plain per-step evaluation, so results never depend
+ * on the prediction being right.  steps = 0 disables it (every step streams K), 1..16 selects blocks of 16, more blocks of 32. */
 int hc_set_lookahead(hc_ctx* ctx, int steps);
 /* Forget the velocity history and the per-time cache (fresh TestHydro state). */
 int hc_reset_history(hc_ctx* ctx);

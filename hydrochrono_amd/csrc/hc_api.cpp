@@ -316,7 +316,7 @@ void alloc_partials(hc_ctx* c) {
     if (c->d_partials_block.n < nb) c->d_partials_block.alloc(nb);
     if (c->d_P.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_P.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
     if (c->d_E.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_E.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
-    const size_t ny = static_cast<size_t>(hc::kLookahead) * hc::kScatterSamples * c->Dpad;
+    const size_t ny = static_cast<size_t>(hc::kLookahead + 1) * hc::kTermMax * c->Dpad;
     if (c->d_Y.n < ny) c->d_Y.alloc(ny);
 }
 
@@ -482,6 +482,7 @@ bool make_plan(hc_ctx* c) {
     for (int i = 0; i <= L; ++i) {
         pl.scat_lo[i] = c->S;
         pl.scat_hi[i] = -1;
+        for (int s = 0; s < hc::kScatterSamples; ++s) pl.n_tgt[i][s] = 0;
     }
     const double oldest = c->times.back();
     for (int m = 1; m <= L; ++m) {
@@ -532,11 +533,13 @@ bool make_plan(hc_ctx* c) {
                     pl.own_a[m][pl.n_own[m]] = wgt[e] * c->width[s];
                     pl.n_own[m]++;
                 } else {
-                    if (pl.n_terms[m] >= hc::kTermMax) return false;
+                    const int i = idx[e];
+                    if (pl.n_terms[m] >= hc::kTermMax || pl.n_tgt[i][s] >= hc::kTargets) return false;
                     const int k = pl.n_terms[m]++;
-                    pl.term_slot[m][k] = idx[e];
-                    pl.term_s[m][k]    = s;
-                    pl.term_coef[m][k] = wgt[e];
+                    const int t = pl.n_tgt[i][s]++;
+                    pl.tgt_step[i][s][t] = m;
+                    pl.tgt_k[i][s][t]    = k;
+                    pl.tgt_coef[i][s][t] = wgt[e];
                     pl.scat_lo[idx[e]] = std::min(pl.scat_lo[idx[e]], s);
                     pl.scat_hi[idx[e]] = std::max(pl.scat_hi[idx[e]], s);
                 }
@@ -746,11 +749,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
             }
         }
         z.n_terms = pl.n_terms[m];
-        z.Y       = c->d_Y.p;
-        for (int k = 0; k < pl.n_terms[m]; ++k) {
-            z.term_off[k]  = (pl.term_slot[m][k] * hc::kScatterSamples + pl.term_s[m][k]) * c->Dpad;
-            z.term_coef[k] = pl.term_coef[m][k];
-        }
+        z.Yc      = c->d_Y.p + static_cast<size_t>(m) * hc::kTermMax * c->Dpad;
     }
     static const bool dbg = env_int("HC_DEBUG_PLAN", 0) != 0;
     if (dbg) {
@@ -758,9 +757,6 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
                      block ? c->plan.s_defer[m - 1] : -2, nchunks_rad, nchunks_ex, c->head);
         for (int e = 0; e < z.n_near; ++e)
             std::fprintf(stderr, "     near s=%d a=%.6g b=%.6g c=%.6g offb=%d offc=%d\n", z.near[e].s, z.near[e].a, z.near[e].b, z.near[e].c, z.near[e].off_b, z.near[e].off_c);
-        if (block)
-            for (int k = 0; k < z.n_terms; ++k)
-                std::fprintf(stderr, "     term slot=%d s=%d coef=%.17g\n", c->plan.term_slot[m][k], c->plan.term_s[m][k], z.term_coef[k]);
     }
     z.host_tagged = host_tagged;
     z.seq         = seq;
@@ -825,7 +821,15 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
                 sa.ns    = pl.scat_hi[m] - pl.scat_lo[m] + 1;
                 sa.v     = c->d_ring_v.p + static_cast<size_t>(c->head) * c->D;  // this step's sample, pushed by finalize_kernel
                 sa.width = c->d_width.p;
-                sa.Y     = c->d_Y.p + (static_cast<size_t>(m) * hc::kScatterSamples + sa.s_lo) * c->Dpad;
+                sa.Y     = c->d_Y.p;
+                for (int si = 0; si < sa.ns; ++si) {
+                    const int s_ = sa.s_lo + si;
+                    sa.n_tgt[si] = pl.n_tgt[m][s_];
+                    for (int t = 0; t < pl.n_tgt[m][s_]; ++t) {
+                        sa.tgt_off[si][t]  = (pl.tgt_step[m][s_][t] * hc::kTermMax + pl.tgt_k[m][s_][t]) * c->Dpad;
+                        sa.tgt_coef[si][t] = pl.tgt_coef[m][s_][t];
+                    }
+                }
                 hc::EventPair* ev = ev_begin(c, hc::kEvScatter, stream);
                 hc::launch_scatter(sa, stream);
                 ev_end(ev, stream);

@@ -129,11 +129,13 @@ struct Plan {
     int n_own[kLookahead + 1] = {0};
     int own_s[kLookahead + 1][kNearMax];
     double own_a[kLookahead + 1][kNearMax];
-    // ... and the scatter results of earlier block steps it adds: coef * Y[slot][s]
+    // ... and the number of scatter results of earlier block steps it adds (term slots k = 0 .. n_terms - 1)
     int n_terms[kLookahead + 1] = {0};
-    int term_slot[kLookahead + 1][kTermMax];
-    int term_s[kLookahead + 1][kTermMax];
-    double term_coef[kLookahead + 1][kTermMax];
+    // scatter of block step i, IRF sample s: the (step, term slot, weight) targets of its result
+    int n_tgt[kLookahead + 1][kScatterSamples];
+    int tgt_step[kLookahead + 1][kScatterSamples][kTargets];
+    int tgt_k[kLookahead + 1][kScatterSamples][kTargets];
+    double tgt_coef[kLookahead + 1][kScatterSamples][kTargets];
     // scatter launched after block step i covers IRF samples [scat_lo[i], scat_hi[i]] (hi < lo: nothing)
     int scat_lo[kLookahead + 1] = {0}, scat_hi[kLookahead + 1] = {0};
     int misses = 0, cooldown = 0;
@@ -193,7 +195,7 @@ struct hc_ctx {
     int chunk_gp = 0, nchunks_rad = 0, chunk_gp_ex = 0, nchunks_ex = 0, ngp_ex = 0;
     int chunk_gp_block = 0, nchunks_block = 0;
     hc::DeviceBuffer<double> d_partials, d_partials_block, d_P, d_E;
-    hc::DeviceBuffer<double> d_Y;           // scatter results [kLookahead][kScatterSamples][Dpad]
+    hc::DeviceBuffer<double> d_Y;           // weighted scatter results per consumer step [kLookahead + 1][kTermMax][Dpad]
     hc::DeviceBuffer<double> d_zero_state;  // 12N zeros: the not-yet-known sample of the look-ahead pass
     int chunk_gp_ex_block = 32, nchunks_ex_block = 0;  // excitation chunks of the look-ahead launch
     int mt_block = 4, mt_block_design = 6;              // row tiles per workgroup of the look-ahead launch (1, 2, 4, 6 or 12)

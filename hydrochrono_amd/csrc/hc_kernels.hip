@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double* U = reinterpret_cast<double*>(smem_raw);  // [n_near][D] right-hand sides of the near samples
     __shared__ double red_near[4][16];
-    __shared__ double red_term[4][16];
+    __shared__ double red_term[16][16];  // [term slice][row]
 
     if (a.do_push && blockIdx.x == gridDim.x - 1) {
         // nobody reads ring slot `head` during this step (the current sample is always taken from `state`)
@@ -815,16 +815,16 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
             pre[q] = gp < g1_0 ? *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128) : dvec2{0.0, 0.0};
         }
     }
-    // scatter results of the earlier steps of the block: wave w adds terms w, w+4, ... (wave-uniform table reads from the
-    // argument block), lanes 0..15 = the rows of the tile; the first 8 are requested here
-    constexpr int TPRE = 8;
+    // scatter results of the earlier steps of the block: the scatter launches have left them weighted and contiguous
+    // (Yc[k][row]); thread (slice = tid >> 4, row = tid & 15) requests terms slice, slice + 16, ... here, before the first wait
+    constexpr int TPRE = kTermMax / 16;
     double ypre[TPRE];
-    const double* __restrict__ ybase = a.Y + blockIdx.x * 16 + (lane & 15);
     if (term_on) {
+        const double* __restrict__ yc = a.Yc + blockIdx.x * 16 + (tid & 15);
 #pragma unroll
         for (int q = 0; q < TPRE; ++q) {
-            const int k = wave + 4 * q;
-            ypre[q] = (k < a.n_terms && lane < 16) ? ybase[a.term_off[k]] : 0.0;
+            const int k = (tid >> 4) + 16 * q;
+            ypre[q]     = k < a.n_terms ? yc[(size_t)k * a.Dpad] : 0.0;
         }
     }
     if (near_on) {
@@ -873,16 +873,9 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     }
     if (term_on) {
         double tacc = 0.0;
-        if (lane < 16) {
 #pragma unroll
-            for (int q = 0; q < TPRE; ++q) {
-                const int k = wave + 4 * q;
-                if (k < a.n_terms) tacc = fma(a.term_coef[k], ypre[q], tacc);
-            }
-#pragma unroll 4
-            for (int k = wave + 4 * TPRE; k < a.n_terms; k += 4) tacc = fma(a.term_coef[k], ybase[a.term_off[k]], tacc);
-            red_term[wave][lane] = tacc;
-        }
+        for (int q = 0; q < TPRE; ++q) tacc += ypre[q];  // ascending term index within the slice
+        red_term[tid >> 4][tid & 15] = tacc;
     }
     if (near_on || term_on) __syncthreads();
 
@@ -890,7 +883,12 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     if (a.do_rad) {
         if (a.nchunks_rad > 0) rad = lane16_sum(lane_sum(0, a.nchunks_rad));
         if (a.P) rad = p_row + rad;
-        if (term_on) rad += ((red_term[0][rit] + red_term[1][rit]) + red_term[2][rit]) + red_term[3][rit];
+        if (term_on) {
+            double ts = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ts += red_term[q][rit];  // fixed order
+            rad += ts;
+        }
         if (near_on) rad += ((red_near[0][rit] + red_near[1][rit]) + red_near[2][rit]) + red_near[3][rit];
     }
     if (a.do_waves && a.wave_mode == 2) wav = a.E ? e_row : lane16_sum(lane_sum(a.nchunks_rad, a.nchunks_ex));
@@ -955,9 +953,10 @@ void launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
 
 // ------------------------------------------------------------------------------------------------
 // scatter_kernel: what the sample that has just arrived contributes to the later steps of the look-ahead block.  For each
-// IRF sample s in [s_lo, s_lo + ns):  Y[s - s_lo][row] = width_s * sum_col K[row, s*D + col] * v[col]; the steps that use
-// it apply the interpolation weight of the sample (FinalizeArgs::term_coef).  One workgroup per (row tile, s): row-owned,
-// no partials.  Runs after the step has delivered its forces -- off the caller's critical path.
+// IRF sample s in [s_lo, s_lo + ns):  y_s[row] = width_s * sum_col K[row, s*D + col] * v[col], stored times the interpolation
+// weight of the sample into the term slot of every later block step it contributes to (at most kTargets), so that the
+// step kernels read their terms contiguously and without a table.  One workgroup per (row tile, s): row-owned, no
+// partials.  Runs after the step has delivered its forces -- off the caller's critical path.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) scatter_kernel(ScatterArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -1002,7 +1001,10 @@ __global__ void __launch_bounds__(256) scatter_kernel(ScatterArgs a) {
     acc += __shfl_xor(acc, 32, kWave);
     if (lane < 16) red[wave][lane] = acc;
     __syncthreads();
-    if (tid < 16) a.Y[(size_t)si * a.Dpad + rt * 16 + tid] = (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]) * a.width[s];
+    if (tid < 16) {
+        const double y = (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]) * a.width[s];
+        for (int t = 0; t < a.n_tgt[si]; ++t) a.Y[(size_t)a.tgt_off[si][t] + rt * 16 + tid] = a.tgt_coef[si][t] * y;
+    }
 }
 
 void launch_scatter(const ScatterArgs& a, hipStream_t stream) {

@@ -58,6 +58,7 @@ struct Bracket {
 constexpr int kNearMax        = 8;   // IRF samples a step contracts itself (own sample + a deferred one)
 constexpr int kTermMax        = 96;  // scatter results a step adds
 constexpr int kScatterSamples = 64;  // IRF samples s < kScatterSamples can be targets of a scatter
+constexpr int kTargets        = 3;   // later block steps one (sample, IRF sample) result can contribute to
 
 // One IRF sample s contracted by the step itself: columns [s*D, (s+1)*D) of K against
 //     u[col] = a * v_state[col] + b * ring_v[off_b + col] + c * ring_v[off_c + col]
@@ -172,11 +173,10 @@ struct FinalizeArgs {
     NearEntry near[kNearMax];
     Panel nearK;
     const double* ring_v_ro;   // velocity ring (read side)
-    // ... and the scatter results of the earlier steps of the block: rad += sum_i term_coef[i] * Y[term_off[i] + row]
+    // ... and the scatter results of the earlier steps of the block, already weighted and laid out for this step by the
+    // scatter launches: rad += sum_{k < n_terms} Yc[k][row]  (one contiguous read, no table)
     int n_terms;
-    const double* Y;
-    int term_off[kTermMax];
-    double term_coef[kTermMax];
+    const double* Yc;  // [n_terms][Dpad]
     // Host boundary: the totals also go to mapped pinned host memory as 16-byte granules {total, seq}; the host spins on
     // seq instead of synchronising the stream (one store carries value and sequence number, so no ordering is assumed).
     unsigned long long* host_tagged;  // [Dloc][2] or null
@@ -189,15 +189,19 @@ struct FinalizeArgs {
     int Hcap;
 };
 
-// scatter_kernel: Y[(s - s_lo)][row] = width[s] * sum_col K[row, s*D + col] * v[col] for s in [s_lo, s_lo + ns); one
-// workgroup per (row tile, sample), so nothing is left to reduce across workgroups.
+// scatter_kernel: y_s[row] = width[s] * sum_col K[row, s*D + col] * v[col] for s in [s_lo, s_lo + ns); one workgroup per
+// (row tile, sample), so nothing is left to reduce across workgroups.  Each result goes, times the interpolation weight of
+// the sample, straight into the term slots of the later block steps it contributes to: Y[tgt_off + row] = tgt_coef * y_s.
 struct ScatterArgs {
     Panel K;
     int D, Dpad;
     int s_lo, ns;
     const double* v;      // [D] the sample's velocities (its ring row)
     const double* width;  // [S]
-    double* Y;            // [ns][Dpad], row s - s_lo
+    double* Y;            // term slots of the block: [step][kTermMax][Dpad]
+    int n_tgt[kScatterSamples];               // per s - s_lo
+    int tgt_off[kScatterSamples][kTargets];   // (step * kTermMax + term index) * Dpad
+    double tgt_coef[kScatterSamples][kTargets];
 };
 
 struct TaperArgs {

@@ -6,6 +6,7 @@ rm -rf /tmp/prof_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 2000 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/gpurun_out/${tag}_rocprof.err
 find /tmp/prof_$tag -name "*kernel_stats.csv" -exec cp {} $GRAFT_REPO_ROOT/gpurun_out/${tag}_kernel_stats.csv \;
 find /tmp/prof_$tag -name "*kernel_trace.csv" -exec cp {} /tmp/${tag}_kernel_trace.csv \;
+cp /tmp/${tag}_kernel_trace.csv $GRAFT_REPO_ROOT/gpurun_out/${tag}_kernel_trace.csv
 python3 - <<PY
 import csv
 rows = list(csv.DictReader(open("/tmp/${tag}_kernel_trace.csv")))

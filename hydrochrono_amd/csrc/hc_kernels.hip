@@ -566,7 +566,7 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int tb = 0; tb < NB; ++tb) u[h][tb] = wo_[slot][h % HB][tb] * vo[slot][h][tb] + wn_[slot][h % HB][tb] * vn[slot][h][tb];
+            for (int tb = 0; tb < NB; ++tb) u[h][tb] = fma(wo_[slot][h % HB][tb], vo[slot][h][tb], wn_[slot][h % HB][tb] * vn[slot][h][tb]);  // explicit: every instantiation rounds alike
         // consecutive MFMAs use different accumulators
 #pragma unroll
         for (int tb = 0; tb < NB; ++tb)
@@ -607,6 +607,168 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
     }
 }
 
+// The same work item for D % 8 == 0 (every multiple-of-4-bodies system, C3 / C4 among them), written for the instruction
+// issue budget: with the K stream at the HBM rate and the B operands coming from the per-DoF ring, what bounds the pass
+// is the vector-instruction count beside the MFMAs (one wave per SIMD at depth 32).  Differences from the general form:
+//   * all samples / columns of a column group are wave-uniform, so the trackers are scalars (SALU);
+//   * K and ring addresses are a uniform base (SGPR pair) + a 32-bit per-lane byte offset -- one v_add per gather, none per K load;
+//   * the weights are not carried through the pipeline: a second, consume-side tracker R fragments behind the issue side
+//     re-reads them from LDS when its sample changes (once per D/32 fragments), one fragment ahead of their use;
+//   * fragments past the end of the chunk skip their MFMAs by a scalar branch instead of zeroed weights.
+template <int MT, int R, int NB>
+__device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const int chunk, const int grp, double* red, double* t_wo, double* t_wn,
+                                                     int* t_oo, int* t_on) {
+    constexpr int L = 16 * NB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kk = lane >> 4, jstep = lane & 15;
+    const int D = a.hist.D;
+    const int gp0 = chunk * a.chunk_gp;
+    const int gp1 = min((a.F + 7) >> 3, gp0 + a.chunk_gp);
+    const int s0  = (gp0 * 8) / D;
+    const int ns  = (min(a.F, gp1 * 8) - 1) / D - s0 + 1;
+    const int s_live = a.F / D;
+    const int Hc     = a.hist.Hcap;
+    for (int idx = tid; idx < ns * L; idx += kConvThreads) {
+        const int k = idx / L, j = idx - k * L, s = s0 + k;
+        Bracket b;
+        b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
+        if (s >= a.s_cut[j] && s != a.s_defer[j] && s < s_live) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
+        const double w = a.width[s < s_live ? s : 0];
+        t_wo[idx] = b.wo * w;
+        t_wn[idx] = (b.off_newer >= 0) ? b.wn * w : 0.0;
+        t_oo[idx] = (b.off_older / D) * 8;          // byte offset of the older sample inside a column of the per-DoF ring
+        t_on[idx] = (max(b.off_newer, 0) / D) * 8;  // ... of the newer one
+    }
+    __syncthreads();
+
+    dvec4 acc[NB][MT];
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[tb][m] = dvec4{0.0, 0.0, 0.0, 0.0};
+    const char* __restrict__ kb    = reinterpret_cast<const char*>(a.K.base) + ((size_t)(grp * MT) * a.K.ngp) * 1024;  // uniform
+    const size_t tile_bytes        = (size_t)a.K.ngp * 1024;
+    const unsigned lane16          = (unsigned)lane * 16u;
+    const char* __restrict__ ringb = reinterpret_cast<const char*>(a.hist.ring_vT);  // uniform
+    const unsigned col_bytes       = (unsigned)Hc * 8u;
+
+    dvec2 kv[R][MT];
+    double vo[R][2][NB], vn[R][2][NB];
+
+    // ---- issue side ----
+    int gp_i = gp0 + wave;
+    int s_i = (gp_i * 8) / D, cb_i = gp_i * 8 - s_i * D;          // scalars
+    unsigned cby = (unsigned)(cb_i + kk) * col_bytes;              // byte offset of the lane's first column (second: + 4 columns)
+    unsigned boo[NB], bon[NB];
+    auto load_offsets = [&]() {
+        const int ks  = s_i - s0;
+        const bool in = ks >= 0 && ks < ns;  // past the chunk's samples: any valid address will do (those fragments are skipped or weigh 0)
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) {
+            const int k = (in ? ks : 0) * L + 16 * tb + jstep;
+            boo[tb]     = (unsigned)t_oo[k];
+            bon[tb]     = (unsigned)t_on[k];
+        }
+    };
+    load_offsets();
+    auto issue = [&](const int slot) {
+        // unconditional (exact vmcnt bookkeeping); past the end of the chunk the wave re-reads its last column group
+        const int gpc = min(gp_i, gp1 - 1);
+        const char* __restrict__ kg = kb + (size_t)gpc * 1024;  // uniform
+#pragma unroll
+        for (int m = 0; m < MT; ++m) kv[slot][m] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kg + m * tile_bytes + lane16));
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int tb = 0; tb < NB; ++tb) {
+                const unsigned cb = cby + (unsigned)(4 * h) * col_bytes;
+                vo[slot][h][tb]   = *reinterpret_cast<const double*>(ringb + (cb + boo[tb]));
+                vn[slot][h][tb]   = *reinterpret_cast<const double*>(ringb + (cb + bon[tb]));
+            }
+        gp_i += 4;
+        cb_i += 32;
+        cby += 32u * col_bytes;
+        if (cb_i >= D) {  // scalar branch
+            do {
+                cb_i -= D;
+                cby -= (unsigned)D * col_bytes;
+                ++s_i;
+            } while (cb_i >= D);
+            load_offsets();
+        }
+    };
+
+    // ---- consume side: the same walk, R fragments behind ----
+    int gp_c = gp0 + wave;
+    int s_c = s_i - 0, cb_c = gp_c * 8 - ((gp_c * 8) / D) * D;
+    s_c     = (gp_c * 8) / D;
+    double cwo[NB], cwn[NB];
+    auto load_weights = [&]() {
+        const int ks  = s_c - s0;
+        const bool in = ks >= 0 && ks < ns;
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) {
+            const int k = (in ? ks : 0) * L + 16 * tb + jstep;
+            cwo[tb]     = in ? t_wo[k] : 0.0;
+            cwn[tb]     = in ? t_wn[k] : 0.0;
+        }
+    };
+    load_weights();
+    auto consume = [&](const int slot) {
+        if (gp_c < gp1) {  // scalar branch around the matrix work of fragments past the end (no loads inside)
+            double u[2][NB];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int tb = 0; tb < NB; ++tb) u[h][tb] = fma(cwo[tb], vo[slot][h][tb], cwn[tb] * vn[slot][h][tb]);  // explicit: every instantiation rounds alike
+#pragma unroll
+            for (int tb = 0; tb < NB; ++tb)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[tb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[slot][m].x, u[0][tb], acc[tb][m], 0, 0, 0);
+#pragma unroll
+            for (int tb = 0; tb < NB; ++tb)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[tb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[slot][m].y, u[1][tb], acc[tb][m], 0, 0, 0);
+        }
+        gp_c += 4;
+        cb_c += 32;
+        if (cb_c >= D) {
+            do {
+                cb_c -= D;
+                ++s_c;
+            } while (cb_c >= D);
+            load_weights();  // for the next fragment; the LDS latency hides behind the MFMAs just issued
+        }
+    };
+
+    const int nfrag = (gp1 - gp0 - wave + 3) / 4;
+#pragma unroll
+    for (int r = 0; r < R; ++r) issue(r);
+    for (int i = 0; i < nfrag; i += R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            consume(r);
+            issue(r);
+        }
+    }
+
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb) {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((size_t)wave * MT + m) * 256 + (kk + 4 * r) * 16 + jstep] = acc[tb][m][r];
+        __syncthreads();
+        for (int idx = tid; idx < MT * 256; idx += kConvThreads) {
+            const int m = idx >> 8, el = idx & 255, row = el >> 4, j = el & 15;
+            const double v = ((red[(0 * MT + m) * 256 + el] + red[(1 * MT + m) * 256 + el]) + red[(2 * MT + m) * 256 + el]) + red[(3 * MT + m) * 256 + el];
+            a.partials[((size_t)chunk * L + 16 * tb + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
+        }
+    }
+}
+
 template <int MT, int R, int NB, int WPS = ((NB == 1 && MT <= 6) ? 2 : 1)>
 __global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs a) {
     // dynamic LDS: [front: cross-wave reduction buffer / U tiles of the excitation items][bracket table, SoA: wo', wn', off_older, off_newer]
@@ -626,8 +788,9 @@ __global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs
     const int grp   = r >> 3;
     if (chunk >= a.nchunks) return;
 
-    if ((a.hist.D & 7) == 0) block_rad_stream<MT, R, NB, true>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
-    else block_rad_stream<MT, (WPS > 1 && NB > 1) ? 2 : R, NB, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+    // the per-DoF ring must be addressable with 32-bit byte offsets for the scalar-base form (4 GB: far beyond any real history)
+    if ((a.hist.D & 7) == 0 && (size_t)a.hist.D * a.hist.Hcap < ((size_t)1 << 28)) block_rad_stream_uni<MT, R, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+    else block_rad_stream<MT, (NB > 1) ? 2 : R, NB, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
     // The excitation force depends on time only: its chunks over Kex (a fraction of a percent of K) for the predicted times
     // ride at the end of radiation workgroups, so the launch keeps its number of workgroups (grid rounds on the chip).
     constexpr int MTE = MT > 6 ? 6 : MT;  // row tiles per excitation work item (register budget of the LDS-staged form)

@@ -420,8 +420,18 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
             out["speedup_vs_optimized_cpu"] = out["value"] / base["optimized_port"]["value"]
         elif exchange is not None:
-            # coupled array: every rank must hold the same gathered vector; spot-check rank 0's own rows against its kernels' output
             out["gathered_rows_finite"] = bool(torch.isfinite(gathered[args.warmup:total]).all().item())
+        if strong:
+            # the same coupled array on ONE GPU (committed measurement), so that a strong-scaling ratio can be formed: the N = 1
+            # line of this benchmark is the C3 case (BASELINE.json's metric), not this workload
+            ref = os.path.join(ROOT, "profiles", "r02", "bench_c4_1gpu.json")
+            if os.path.exists(ref) and N == N_BODIES_C4:
+                try:
+                    rj = json.load(open(ref))
+                    out["same_workload_on_one_gpu"] = {"evals_per_s": rj["value"], "ms_per_step": rj["ms_per_step"],
+                                                       "source": "profiles/r02/bench_c4_1gpu.json (bench.py --scaling strong --bodies 512 on one MI355X)"}
+                except Exception:
+                    pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

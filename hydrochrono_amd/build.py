@@ -16,7 +16,7 @@ MAIN_LIB = os.path.join(LIBDIR, "libhydrochrono_amd.so")
 BEMIO_LIB = os.path.join(LIBDIR, "libhc_bemio.so")
 
 SOURCES = ["hc_kernels.hip", "hc_api.cpp", "hc_host_math.cpp", "hc_yaml.cpp", "hc_eta_fft.cpp"]
-HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_host_math.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h"),
+HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_host_math.hpp", "hc_limits.hpp", "hc_plan.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h"),
            os.path.join(ROOT, "include", "hydrochrono_amd_host.h"), os.path.join(ROOT, "include", "hydrochrono_amd_yaml.h")]
 
 

@@ -9,6 +9,7 @@
 
 #include "../../include/hydrochrono_amd.h"
 #include "hc_kernels.hpp"
+#include "hc_plan.hpp"
 
 namespace hc {
 
@@ -113,33 +114,6 @@ struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
     int kind = 0;
     double waves_share = 0.0;  // share of the launch that is excitation work (by algorithmic bytes)
-};
-
-// Look-ahead plan (scatter form, see hc_kernels.hpp).  Made right after a step at time tgrid[0] has been enqueued: the
-// block covers the next 16 predicted steps tgrid[j] = tgrid[0] + j*dt.  The pass launched with the plan has computed, for
-// each block step, what the samples known at planning time contribute; the tables below say what each block step adds.
-struct Plan {
-    bool valid = false;
-    double dt = 0.0;
-    int j_next = 1;                       // next block step, 1..16
-    double tgrid[kLookahead + 1] = {0};
-    int s_cut[kLookahead]    = {0};       // pass: block step j+1 takes IRF samples s >= s_cut[j]
-    int s_defer[kLookahead]  = {0};       // IRF sample whose "is there an older history sample" test is too close to call ahead of time (-1: none)
-    // block step m = 1..16 (index m): IRF samples involving the step's own sample (weight x width) ...
-    int n_own[kLookahead + 1] = {0};
-    int own_s[kLookahead + 1][kNearMax];
-    double own_a[kLookahead + 1][kNearMax];
-    // ... and the number of scatter results of earlier block steps it adds (term slots k = 0 .. n_terms - 1)
-    int n_terms[kLookahead + 1] = {0};
-    // scatter of block step i, IRF sample s: the (step, term slot, weight) targets of its result
-    int n_tgt[kLookahead + 1][kScatterSamples];
-    int tgt_step[kLookahead + 1][kScatterSamples][kTargets];
-    int tgt_k[kLookahead + 1][kScatterSamples][kTargets];
-    double tgt_coef[kLookahead + 1][kScatterSamples][kTargets];
-    // scatter launched after block step i covers IRF samples [scat_lo[i], scat_hi[i]] (hi < lo: nothing)
-    int scat_lo[kLookahead + 1] = {0}, scat_hi[kLookahead + 1] = {0};
-    int misses = 0, cooldown = 0;
-    bool has_exc = false;  // the pass also left the excitation force of the 16 predicted times (E rows)
 };
 
 }  // namespace hc

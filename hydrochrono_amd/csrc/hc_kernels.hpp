@@ -4,9 +4,10 @@
 
 #include <cstddef>
 
+#include "hc_limits.hpp"
+
 namespace hc {
 
-constexpr int kLookahead = 32;  // most future steps one blocked pass covers (1 or 2 blocks of 16 = N dimension of v_mfma_f64_16x16x4_f64)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Panel layout of the convolution matrices in HBM (radiation K[D_loc x S*D], excitation Kex[D_loc x L]).
@@ -55,10 +56,7 @@ struct Bracket {
 // sample contributes (the few IRF samples tau_s < dt, contracted by step_kernel itself).  A step inside a block is then
 // ONE launch on the caller's critical path.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kNearMax        = 8;   // IRF samples a step contracts itself (own sample + a deferred one)
-constexpr int kTermMax        = 96;  // scatter results a step adds
-constexpr int kScatterSamples = 64;  // IRF samples s < kScatterSamples can be targets of a scatter
-constexpr int kTargets        = 3;   // later block steps one (sample, IRF sample) result can contribute to
+// capacities kLookahead, kNearMax, kTermMax, kScatterSamples, kTargets: hc_limits.hpp
 
 // One IRF sample s contracted by the step itself: columns [s*D, (s+1)*D) of K against
 //     u[col] = a * v_state[col] + b * ring_v[off_b + col] + c * ring_v[off_c + col]

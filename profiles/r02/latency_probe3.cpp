@@ -5,6 +5,8 @@
 // granules to mapped pinned host memory; the host spins on them.  Measures the host round trip, alone and with another
 // kernel (8 MB copy) launched on a second stream right after each doorbell.  The server exits after ~1 ms without work.
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include <xmmintrin.h>
 
 #include <algorithm>
@@ -27,7 +29,7 @@ typedef unsigned long long u64;
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 struct alignas(16) Granule { double value; u64 seq; };
 
-__global__ void __launch_bounds__(256) server_kernel(const double* state, int n, const u64* door, Granule* out, u64 first_seq, u64* exited) {
+__global__ void __launch_bounds__(256) server_kernel(const double* state, int n, const u64* door, Granule* out, u64 first_seq, u64* exited, int fence_mode) {
     __shared__ double red[4];
     __shared__ u64 cur;
     u64 expect = first_seq;
@@ -35,10 +37,22 @@ __global__ void __launch_bounds__(256) server_kernel(const double* state, int n,
         if (threadIdx.x == 0) {
             u64 v;
             long long t0 = wall_clock64();
+            u64 polls = 0;
             for (;;) {
+                ++polls;
                 v = __hip_atomic_load(door, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (v >= expect) break;
-                if (wall_clock64() - t0 > 100000) { v = ~0ull; break; }  // 100 MHz clock: 1 ms
+                if (fence_mode == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");        // system-scope acquire: invalidate caches
+                if (fence_mode == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (wall_clock64() - t0 > 100000) {  // 100 MHz clock: 1 ms
+                    if (blockIdx.x == 0) {
+                        exited[1] = polls;
+                        exited[2] = v;
+                        exited[3] = (u64)(wall_clock64() - t0);
+                    }
+                    v = ~0ull;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(2);
             }
             cur = v;
@@ -63,6 +77,14 @@ __global__ void __launch_bounds__(256) server_kernel(const double* state, int n,
 __global__ void __launch_bounds__(256) busy_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i] * 1.0000001;
+}
+
+static hsa_amd_hdp_flush_t g_hdp = {nullptr, nullptr};
+static hsa_status_t find_gpu(hsa_agent_t agent, void*) {
+    hsa_device_type_t type;
+    if (hsa_agent_get_info(agent, HSA_AGENT_INFO_DEVICE, &type) == HSA_STATUS_SUCCESS && type == HSA_DEVICE_TYPE_GPU && !g_hdp.HDP_MEM_FLUSH_CNTL)
+        hsa_agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &g_hdp);
+    return HSA_STATUS_SUCCESS;
 }
 
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -103,8 +125,8 @@ int main() {
             while (*p != want) {
                 __builtin_ia32_pause();
                 if (now_us() - t0 > 2e6) {
-                    std::printf("timeout: want %llu, row %d has %llu, door (host view) %llu, exit flag %llu\n", want, r, (u64)*p,
-                                *reinterpret_cast<volatile u64*>(door), *h_exit);
+                    std::printf("timeout: want %llu, row %d has %llu, door (host view) %llu, exit flag %llu polls %llu last seen %llu ticks %llu\n", want, r, (u64)*p,
+                                *reinterpret_cast<volatile u64*>(door), h_exit[0], h_exit[1], h_exit[2], h_exit[3]);
                     failed = true;
                     break;
                 }
@@ -112,15 +134,26 @@ int main() {
         }
     };
     u64 seq = 0;
+    if (getenv("PROBE_HDP")) {
+        hsa_init();
+        hsa_iterate_agents(find_gpu, nullptr);
+        std::printf("HDP flush registers: mem %p reg %p\n", (void*)g_hdp.HDP_MEM_FLUSH_CNTL, (void*)g_hdp.HDP_REG_FLUSH_CNTL);
+    }
     auto ring = [&](int i) {
         for (int k = 0; k < nstate; ++k) fg[k] = 1e-3 * k + i;
         _mm_sfence();
         *reinterpret_cast<volatile u64*>(door) = ++seq;
         _mm_sfence();
+        if (g_hdp.HDP_MEM_FLUSH_CNTL) {
+            *reinterpret_cast<volatile uint32_t*>(g_hdp.HDP_MEM_FLUSH_CNTL) = 1u;  // make the BAR stores visible to the GPU
+            _mm_sfence();
+        }
     };
     std::vector<double> t;
+    const int fence_mode = getenv("PROBE_FENCE") ? atoi(getenv("PROBE_FENCE")) : 0;
+    std::printf("memory: %s, poll fence mode %d\n", getenv("PROBE_FG") ? "fine-grained" : "uncached", fence_mode);
     for (int variant = 0; variant < 2; ++variant) {
-        hipLaunchKernelGGL(server_kernel, dim3(nwg), dim3(256), 0, s_srv, fg, nstate, door, d_out, seq + 1, d_exit);
+        hipLaunchKernelGGL(server_kernel, dim3(nwg), dim3(256), 0, s_srv, fg, nstate, door, d_out, seq + 1, d_exit, fence_mode);
         CK(hipGetLastError());
         t.clear();
         for (int i = 0; i < iters; ++i) {
@@ -128,7 +161,7 @@ int main() {
             ring(i);
             if (variant == 1) hipLaunchKernelGGL(busy_kernel, dim3(nbig / 256 / 4), dim3(256), 0, s_work, d_a, d_b, nbig / 4);
             wait_tags(seq);
-            if (failed) return 1;
+            if (failed) { hipStreamSynchronize(s_srv); return 1; }
             t.push_back(now_us() - a);
         }
         report(variant == 0 ? "P  resident server, doorbell through the BAR" : "P' the same + a kernel launched on another stream per step", t);

@@ -164,7 +164,7 @@ void profile_drain(hc_ctx* c) {
                 c->prof.radiation_seconds += sec * (1.0 - ev.waves_share);
                 c->prof.waves_seconds += sec * ev.waves_share;
                 break;
-            case hc::kEvPass:  // look-ahead pass: radiation part of 16 steps (+ their excitation force)
+            case hc::kEvPass:  // look-ahead pass: radiation part of a block of steps (+ their excitation force)
                 c->prof.block_kernel_seconds += sec;
                 c->prof.block_kernel_launches += 1;
                 c->prof.radiation_seconds += sec * (1.0 - ev.waves_share);
@@ -200,7 +200,7 @@ void profile_begin_step(hc_ctx* c) {
     c->sample_this_step = (c->profile_counter++ % c->profile_stride) == 0;
 }
 
-// Event pair around one launch, or null.  The look-ahead pass (one per 16 steps) is timed whatever the stride.
+// Event pair around one launch, or null.  The look-ahead pass (one per block) is timed whatever the stride.
 hc::EventPair* ev_begin(hc_ctx* c, int kind, hipStream_t stream, double waves_share = 0.0) {
     if (!c->profiling || !(c->sample_this_step || kind == hc::kEvPass)) return nullptr;
     if (c->events_used == c->events.size()) {
@@ -537,7 +537,7 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
     b.Dpad        = c->Dpad;
     b.error_flag  = c->d_err.p;
     b.ngroups     = c->ntiles / c->mt_block;
-    // algorithmic bytes: summed over the 16 steps, step j's share of K and of the velocity vector from s_cut[j]
+    // algorithmic bytes: summed over the steps of the block, step j's share of K and of the velocity vector from s_cut[j]
     // on ...; what the launch has to move once: the live part of K, Kex and the staged vectors
     double samples = 0.0;
     for (int j = 0; j < L; ++j) samples += std::max(0, b.F / c->D - pl.s_cut[j]);

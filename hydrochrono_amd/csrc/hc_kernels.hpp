@@ -51,7 +51,7 @@ struct Bracket {
 // Scatter-form look-ahead (hc_api.cpp: make_plan).  The interpolated history is linear in its samples,
 //     v~(q) = sum_k phi_k(q) v_k      (phi_k = the reference's two interpolation weights of sample k, src/hydro_forces.cpp:343-371),
 // so the radiation sum of a future step m splits by history sample: what the samples known when the block was planned
-// contribute (the look-ahead pass, K read once for 16 steps), what a sample that arrives at block step i < m contributes
+// contribute (the look-ahead pass, K read once for a block of 32 or 16 steps), what a sample that arrives at block step i < m contributes
 // (scatter_kernel right after step i has delivered its forces, off the caller's critical path), and what step m's own
 // sample contributes (the few IRF samples tau_s < dt, contracted by step_kernel itself).  A step inside a block is then
 // ONE launch on the caller's critical path.
@@ -103,9 +103,10 @@ struct StepArgs {
     int* error_flag;         // 1 / 2: a query time is not bracketed (reference: runtime_error)
 };
 
-// Look-ahead pass: for j = 0..15 the part of step (n+j)'s radiation sum that depends only on history known at step n,
+// Look-ahead pass: for the `depth` predicted steps j of a block, the part of step j's radiation sum that depends only on
+// history known when the block is planned,
 //   P_j[row] = sum over s >= s_cut[j], col of K[row, s, col] * u_{n+j}(s, col),   t_{n+j} = t + j*dt,
-// as one [D_loc x F] x [F x 16] FP64 GEMM on the matrix cores; K is read once for 16 steps.
+// as one [D_loc x F] x [F x depth] FP64 GEMM on the matrix cores; K is read once for the whole block.
 struct BlockArgs {
     Panel K;
     int F;                // S*D

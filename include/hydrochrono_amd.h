@@ -212,9 +212,9 @@ typedef struct hc_profile_stats {
     double conv_kernel_seconds; /* sum of HIP-event durations of the plain per-step convolution launches */
     long long conv_kernel_launches;
     double conv_kernel_bytes;   /* algorithmic bytes of one step (8*D_local*D*S + vectors) */
-    double block_kernel_seconds; /* look-ahead kernel launches (one covers 16 steps) */
+    double block_kernel_seconds; /* look-ahead kernel launches (one covers a block of 32 or 16 steps) */
     long long block_kernel_launches;
-    double block_kernel_bytes;  /* algorithmic bytes of the last pass: sum over its 16 steps of the share of K (and of the
+    double block_kernel_bytes;  /* algorithmic bytes of the last pass: sum over its steps of the share of K (and of the
                                    velocity vector) that the pass computes for that step, i.e. IRF samples s >= s_cut[j] */
     double block_kernel_bytes_once; /* bytes the last pass has to move once: live part of K, Kex, staged vectors */
     double step_kernel_seconds;  /* the step kernel (finalize_kernel): the one launch on the critical path of a block step */
@@ -223,7 +223,7 @@ typedef struct hc_profile_stats {
     long long scatter_kernel_launches;
 } hc_profile_stats;
 /* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default), and around every
- * look-ahead pass (one per 16 steps) whatever the stride.  Event records perturb the launch stream by a few
+ * look-ahead pass (one per block) whatever the stride.  Event records perturb the launch stream by a few
  * microseconds, so throughput runs should sample (e.g. on = 17). */
 int hc_enable_profiling(hc_ctx* ctx, int on);
 int hc_get_profile(hc_ctx* ctx, hc_profile_stats* out);

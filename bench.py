@@ -9,8 +9,8 @@ irregular JONSWAP sea state with 512 wave components, prescribed body motion wit
 (velocity history pre-filled over the whole 10.23 s IRF window).  A "step" = one SYNCHRONOUS hc_step: host pointers to
 the body state in, all 6N hydrodynamic forces (hydrostatic - radiation + waves) out on the host -- what one Chrono
 update costs through ComponentFunc::GetVal (src/hydro_forces.cpp:79-85,727-767): the next state depends on these forces,
-so nothing is pipelined across steps.  value = K / wall time of K consecutive calls (the look-ahead passes included);
-the median call is reported next to it.  Secondary figures in the same line: `device_pipelined` (hc_step_device with
+so nothing is pipelined across steps.  value = K / wall time of K consecutive calls, the look-ahead passes included (the
+timed region is phase-aligned so that it always contains a pass, however small K is); the median call is reported next to it.  Secondary figures in the same line: `device_pipelined` (hc_step_device with
 states resident in HBM, enqueued ahead -- an upper bound no Chrono loop can use) and `plain_per_step_mode`
 (look-ahead off: K streamed from HBM every step).
 
@@ -205,7 +205,18 @@ def main():
     sdt = args.step_dt
     n_pipe = 0 if (args.no_secondary or world > 1) else args.steps
     n_plain = 0 if (args.no_secondary or world > 1 or args.lookahead == 0) else max(20, args.steps // 8)
-    total = args.warmup + args.steps
+    # Phase alignment (untimed, before the W warm-up steps): one look-ahead pass serves a block of `lookahead` steps and is paid
+    # by the first step of the next block, so a short timed region could fall between two passes and report the median step as
+    # if it were the mean.  The region is placed so that a block boundary lies in its middle: it then carries
+    # max(1, ~K/lookahead) passes -- pessimistic for K < lookahead, neutral for K >> lookahead.
+    align = 0
+    if args.lookahead > 0:
+        Lb = 16 if args.lookahead <= 16 else 32
+        first = args.warmup + args.steps // 2          # earliest step index the boundary (a multiple of Lb) may have
+        boundary = ((first + Lb - 1) // Lb) * Lb
+        align = boundary - first
+    pre = align + args.warmup
+    total = pre + args.steps
     n_all = total + n_pipe + n_plain + 16
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
     duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
@@ -266,7 +277,7 @@ def main():
                     stream.synchronize()
                 per_step[k] = pc() - a
 
-    run_sync(0, args.warmup)
+    run_sync(0, pre)
     torch.cuda.synchronize()
     gpu.enable_profiling(args.profile_stride)
     gpu.reset_profile()
@@ -274,7 +285,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    run_sync(args.warmup, total)
+    run_sync(pre, total)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -327,7 +338,7 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        timed = per_step[args.warmup:total] * 1e3
+        timed = per_step[pre:total] * 1e3
         # dominant kernel: the look-ahead pass when blocking is on (one launch covers 16 steps), else the per-step kernel
         if prof["block_kernel_launches"] > 0:
             kname, units = "hc::conv_block_kernel", int(args.lookahead)
@@ -359,6 +370,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "alignment_steps": align,  # untimed, before the warm-up: puts a look-ahead block boundary in the middle of the timed region
+            "passes_in_timed_region": int(prof["block_kernel_launches"]),
             "ms_per_step": ms,
             "median_ms_per_step": float(np.median(timed)),
             "p10_ms_per_step": float(np.percentile(timed, 10)),
@@ -408,7 +421,7 @@ def main():
             nf = min(len(f_faithful), n_chk)
             out["cpu_baseline"] = base
             out["parity"] = {
-                "timed_steps_max_rel_err": max_rel_err(forces[args.warmup:total], f_flat[args.warmup:total]),
+                "timed_steps_max_rel_err": max_rel_err(forces[pre:total], f_flat[pre:total]),
                 "all_steps_checked": n_chk,
                 "all_steps_max_rel_err": max_rel_err(forces[:n_chk], f_flat[:n_chk]),
                 "oracle": "flat-array variant of the CPU oracle on every step",
@@ -420,7 +433,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
             out["speedup_vs_optimized_cpu"] = out["value"] / base["optimized_port"]["value"]
         elif exchange is not None:
-            out["gathered_rows_finite"] = bool(torch.isfinite(gathered[args.warmup:total]).all().item())
+            out["gathered_rows_finite"] = bool(torch.isfinite(gathered[pre:total]).all().item())
         if strong:
             # the same coupled array on ONE GPU (committed measurement), so that a strong-scaling ratio can be formed: the N = 1
             # line of this benchmark is the C3 case (BASELINE.json's metric), not this workload

@@ -580,6 +580,11 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     const bool run_exc = f.waves && irregular;
     const StepViews vw = make_views(c);
     const bool block   = run_rad && m > 0;
+    if (c->bg_pending && stream != c->stream) {
+        // the scatter / pass of the previous step ran on the context's own stream (see below): this step's kernels need them
+        HC_HIP(hipStreamWaitEvent(stream, c->ev_bg, 0));
+        c->bg_pending = false;
+    }
     const double* P_row = block ? c->d_P.p + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
     const double* E_row = (block && run_exc && c->plan.has_exc) ? c->d_E.p + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
 
@@ -717,34 +722,52 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     }
 
     // ---- off the caller's critical path: everything below is needed by later steps only ----
+    // On a caller's stream (hc_step_device) it goes to the context's own stream behind an event, so that whatever the caller
+    // enqueues next on its stream -- the all-gather of the force rows in a multi-GPU run -- follows the step kernel directly.
     if (f.rad && c->lookahead > 0) {
-        if (block && m < c->lookahead) {
-            const auto& pl = c->plan;
-            if (pl.scat_hi[m] >= pl.scat_lo[m]) {
-                hc::ScatterArgs sa{};
-                sa.K     = rad_panel(c);
-                sa.D     = c->D;
-                sa.Dpad  = c->Dpad;
-                sa.s_lo  = pl.scat_lo[m];
-                sa.ns    = pl.scat_hi[m] - pl.scat_lo[m] + 1;
-                sa.v     = c->d_ring_v.p + static_cast<size_t>(c->head) * c->D;  // this step's sample, pushed by finalize_kernel
-                sa.width = c->d_width.p;
-                sa.Y     = c->d_Y.p;
-                for (int si = 0; si < sa.ns; ++si) {
-                    const int s_ = sa.s_lo + si;
-                    sa.n_tgt[si] = pl.n_tgt[m][s_];
-                    for (int t = 0; t < pl.n_tgt[m][s_]; ++t) {
-                        sa.tgt_off[si][t]  = (pl.tgt_step[m][s_][t] * hc::kTermMax + pl.tgt_k[m][s_][t]) * c->Dpad;
-                        sa.tgt_coef[si][t] = pl.tgt_coef[m][s_][t];
-                    }
-                }
-                hc::EventPair* ev = ev_begin(c, hc::kEvScatter, stream);
-                hc::launch_scatter(sa, stream);
-                ev_end(ev, stream);
+        const bool scatter_now = block && m < c->lookahead && c->plan.scat_hi[m] >= c->plan.scat_lo[m];
+        const bool plan_now    = (!block || m == c->lookahead) && H >= 2;
+        hipStream_t bs         = stream;
+        auto to_background = [&]() {
+            if (stream != c->stream && bs == stream) {
+                bs = c->stream;
+                HC_HIP(hipEventRecord(c->ev_fin, stream));
+                HC_HIP(hipStreamWaitEvent(bs, c->ev_fin, 0));
             }
-        } else if (!block || m == c->lookahead) {
+        };
+        if (scatter_now) {
+            to_background();
+            const auto& pl = c->plan;
+            hc::ScatterArgs sa{};
+            sa.K     = rad_panel(c);
+            sa.D     = c->D;
+            sa.Dpad  = c->Dpad;
+            sa.s_lo  = pl.scat_lo[m];
+            sa.ns    = pl.scat_hi[m] - pl.scat_lo[m] + 1;
+            sa.v     = c->d_ring_v.p + static_cast<size_t>(c->head) * c->D;  // this step's sample, pushed by finalize_kernel
+            sa.width = c->d_width.p;
+            sa.Y     = c->d_Y.p;
+            for (int si = 0; si < sa.ns; ++si) {
+                const int s_ = sa.s_lo + si;
+                sa.n_tgt[si] = pl.n_tgt[m][s_];
+                for (int t = 0; t < pl.n_tgt[m][s_]; ++t) {
+                    sa.tgt_off[si][t]  = (pl.tgt_step[m][s_][t] * hc::kTermMax + pl.tgt_k[m][s_][t]) * c->Dpad;
+                    sa.tgt_coef[si][t] = pl.tgt_coef[m][s_][t];
+                }
+            }
+            hc::EventPair* ev = ev_begin(c, hc::kEvScatter, bs);
+            hc::launch_scatter(sa, bs);
+            ev_end(ev, bs);
+        } else if (plan_now) {
             if (block) c->plan.misses = 0;  // a block was consumed completely
-            if (H >= 2 && make_plan(c)) launch_pass(c, stream, f.waves);
+            if (make_plan(c)) {
+                to_background();
+                launch_pass(c, bs, f.waves);
+            }
+        }
+        if (bs != stream) {
+            HC_HIP(hipEventRecord(c->ev_bg, bs));
+            c->bg_pending = true;
         }
     }
     HC_HIP(hipGetLastError());
@@ -852,6 +875,8 @@ int hc_create_sharded(int num_bodies, int body_begin, int body_end, int device_i
         c->bodies.resize(num_bodies);
         HC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HC_HIP(hipStreamCreateWithFlags(&c->stream_am, hipStreamNonBlocking));
+        HC_HIP(hipEventCreateWithFlags(&c->ev_fin, hipEventDisableTiming));
+        HC_HIP(hipEventCreateWithFlags(&c->ev_bg, hipEventDisableTiming));
         hc_tapered_direct_options_default(&c->taper);
         hc_irregular_wave_params_default(&c->irr);
         *out = c.release();
@@ -877,6 +902,8 @@ void hc_destroy(hc_ctx* ctx) {
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream_am) (void)hipStreamDestroy(ctx->stream_am);
+    if (ctx->ev_fin) (void)hipEventDestroy(ctx->ev_fin);
+    if (ctx->ev_bg) (void)hipEventDestroy(ctx->ev_bg);
     delete ctx;
 }
 

@@ -122,6 +122,10 @@ struct hc_ctx {
     int N = 0, b0 = 0, b1 = 0, nloc = 0, D = 0, Dloc = 0, device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream_am = nullptr;  // added-mass products (independent of the step kernels)
+    // hc_step_device on a caller's stream: only the step kernel goes to that stream; what later steps need (scatter, pass)
+    // runs on the context's own stream behind ev_fin, and the next step kernel waits for ev_bg
+    hipEvent_t ev_fin = nullptr, ev_bg = nullptr;
+    bool bg_pending = false;
     std::string err;
 
     bool have_sim = false;

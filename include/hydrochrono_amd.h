@@ -162,7 +162,10 @@ int hc_step(hc_ctx* ctx, double t, const double* pos, const double* rpy, const d
  *   d_force_out device pointer, D_local doubles
  *   stream      hipStream_t (NULL = the context's own stream).  Asynchronous: returns after enqueue; d_state and
  *               d_force_out must stay valid until the work enqueued for this step has run, and every step of one
- *               context must go to the same stream (the velocity ring is updated in stream order). */
+ *               context must go to the same stream (the velocity ring is updated in stream order).  With a caller's stream only
+ *               the step kernel is enqueued there; the work later steps need (scatter, look-ahead pass) runs on the context's
+ *               own stream behind an event, and the next step waits for it -- what the caller enqueues next on its stream
+ *               (e.g. the all-gather of the force rows of a row-sharded array) follows the step kernel directly. */
 int hc_step_device(hc_ctx* ctx, double t, const double* d_state, double* d_force_out, void* stream);
 /* force_hydrostatic_, force_radiation_damping_, force_waves_ of the last evaluated step (D_local each;
  * any pointer may be NULL).  Synchronises the context's stream. */

@@ -895,10 +895,13 @@ void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_
 // 263-322,758-760; src/wave_types.cpp:315-327).  All sums run in a fixed order (bitwise reproducible).  For the host
 // boundary the totals also leave as 16-byte {value, sequence} granules in mapped pinned memory.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
+// NW = waves per workgroup: 4, or 16 for wide systems (D >= 1536), where a workgroup streams hundreds of KB of K for its 16 rows and
+// needs the loads of more waves in flight; threads beyond the first 256 only help with that stream.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double* U = reinterpret_cast<double*>(smem_raw);  // [n_near][D] right-hand sides of the near samples
-    __shared__ double red_near[4][16];
+    __shared__ double red_near[NW][16];
     __shared__ double red_term[16][16];  // [term slice][row]
 
     if (a.do_push && blockIdx.x == gridDim.x - 1) {
@@ -915,9 +918,10 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub  = tid & 15;
-    const int rit  = tid >> 4;  // row inside the tile
+    const bool rowthread = tid < 256;         // the first four waves own the rows; further waves only stream K
+    const int rit  = (tid >> 4) & 15;         // row inside the tile
     const int row  = blockIdx.x * 16 + rit;
-    const bool live = row < a.Dloc;
+    const bool live = rowthread && row < a.Dloc;
     const int rrow  = live ? row : 0;
 
     // lane `sub` adds chunks sub, sub+16, ... in ascending order.  The loads are issued 8 at a time, the tail batch too
@@ -974,7 +978,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         const int f0_0 = a.near[0].s * a.D, g0_0 = f0_0 >> 3, g1_0 = (f0_0 + a.D + 7) >> 3;
 #pragma unroll
         for (int q = 0; q < PRE; ++q) {
-            const int gp = g0_0 + wave + 4 * q;
+            const int gp = g0_0 + wave + NW * q;
             pre[q] = gp < g1_0 ? *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128) : dvec2{0.0, 0.0};
         }
     }
@@ -987,7 +991,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 #pragma unroll
         for (int q = 0; q < TPRE; ++q) {
             const int k = (tid >> 4) + 16 * q;
-            ypre[q]     = k < a.n_terms ? yc[(size_t)k * a.Dpad] : 0.0;
+            ypre[q]     = (rowthread && k < a.n_terms) ? yc[(size_t)k * a.Dpad] : 0.0;
         }
     }
     if (near_on) {
@@ -995,7 +999,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         const int D = a.D;
         for (int e = 0; e < a.n_near; ++e) {
             const NearEntry& ne = a.near[e];
-            for (int col = tid; col < D; col += 256) {
+            for (int col = tid; col < D; col += 64 * NW) {
                 double u = 0.0;
                 if (ne.a != 0.0) u = ne.a * state_velocity(a.state, a.N, col);
                 if (ne.b != 0.0) u = fma(ne.b, a.ring_v_ro[ne.off_b + col], u);
@@ -1012,7 +1016,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
             int gp = g0 + wave;
             if (e == 0) {
 #pragma unroll
-                for (int q = 0; q < PRE; ++q, gp += 4) {
+                for (int q = 0; q < PRE; ++q, gp += NW) {
                     if (gp < g1) {
                         const int fa = gp * 8 + kk, fb = fa + 4;
                         const double u0 = (fa >= f0 && fa < f1) ? u[fa] : 0.0, u1 = (fb >= f0 && fb < f1) ? u[fb] : 0.0;
@@ -1022,7 +1026,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
                 }
             }
 #pragma unroll 4
-            for (; gp < g1; gp += 4) {
+            for (; gp < g1; gp += NW) {
                 const dvec2 kv = *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128);
                 const int fa = gp * 8 + kk, fb = fa + 4;
                 const double u0 = (fa >= f0 && fa < f1) ? u[fa] : 0.0, u1 = (fb >= f0 && fb < f1) ? u[fb] : 0.0;
@@ -1038,7 +1042,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
         double tacc = 0.0;
 #pragma unroll
         for (int q = 0; q < TPRE; ++q) tacc += ypre[q];  // ascending term index within the slice
-        red_term[tid >> 4][tid & 15] = tacc;
+        if (rowthread) red_term[tid >> 4][tid & 15] = tacc;
     }
     if (near_on || term_on) __syncthreads();
 
@@ -1052,7 +1056,12 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
             for (int q = 0; q < 16; ++q) ts += red_term[q][rit];  // fixed order
             rad += ts;
         }
-        if (near_on) rad += ((red_near[0][rit] + red_near[1][rit]) + red_near[2][rit]) + red_near[3][rit];
+        if (near_on) {
+            double ns_ = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) ns_ += red_near[w][rit];  // fixed order
+            rad += ns_;
+        }
     }
     if (a.do_waves && a.wave_mode == 2) wav = a.E ? e_row : lane16_sum(lane_sum(a.nchunks_rad, a.nchunks_ex));
     if (a.do_waves && a.wave_mode == 3) {
@@ -1104,14 +1113,19 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
 
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
     const size_t smem = (size_t)max(0, a.n_near) * a.D * sizeof(double);
+    const bool wide   = a.n_near > 0 && a.D >= 1536;  // >= 196 KB of K per workgroup and near sample
     if (smem > 64 * 1024) {
-        static size_t granted = 0;
+        static size_t granted4 = 0, granted16 = 0;
+        size_t& granted = wide ? granted16 : granted4;
         if (smem > granted) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(wide ? reinterpret_cast<const void*>(finalize_kernel<16>) : reinterpret_cast<const void*>(finalize_kernel<4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             granted = smem;
         }
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3((a.Dloc + 15) / 16 + (a.do_push ? 1 : 0)), dim3(256), smem, stream, a);
+    const dim3 grid((a.Dloc + 15) / 16 + (a.do_push ? 1 : 0));
+    if (wide) hipLaunchKernelGGL((finalize_kernel<16>), grid, dim3(1024), smem, stream, a);
+    else hipLaunchKernelGGL((finalize_kernel<4>), grid, dim3(256), smem, stream, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -836,7 +836,8 @@ def test_c4_size_array_properties_on_one_gpu(HF):
     f_look = [full.step(5.0 + n * dt, *states[n]) for n in range(nsteps)]
     prof = full.profile()
     full.enable_profiling(0)
-    assert prof["block_kernel_launches"] >= 2 and prof["scatter_kernel_launches"] >= 15 and prof["conv_kernel_launches"] == 1
+    if os.environ.get("HC_LOOKAHEAD", "32") != "0":
+        assert prof["block_kernel_launches"] >= 2 and prof["scatter_kernel_launches"] >= 15 and prof["conv_kernel_launches"] == 1
     lo, hi = make((0, 256)), make((256, 512))
     for n in range(nsteps):
         t = 5.0 + n * dt

@@ -1133,6 +1133,10 @@ int hc_finalize(hc_ctx* c) {
     c->h_out.alloc(static_cast<size_t>(4) * c->Dloc);
     c->h_err.alloc(1);
     c->h_am.alloc(static_cast<size_t>(c->D) + c->Dloc);
+    c->bar_am.alloc(static_cast<size_t>(c->D) + c->Dloc);
+    c->h_tag_am.alloc(static_cast<size_t>(2) * c->Dloc);
+    std::memset(c->h_tag_am.p, 0, c->h_tag_am.n * sizeof(unsigned long long));
+    c->seq_am = 0;
     c->h_tag.alloc(static_cast<size_t>(2) * c->Dloc);
     std::memset(c->h_tag.p, 0, c->h_tag.n * sizeof(unsigned long long));
     c->seq = 0;
@@ -1431,8 +1435,8 @@ namespace {
 // copy the totals out.  Each granule is one 16-byte store, so its value is valid as soon as its sequence number is.  This
 // replaces hipStreamSynchronize on the per-step path (14 -> 9 us for an empty launch, profiles/r02/latency_probe_v1.txt);
 // the stream is queried from time to time so that a failed launch ends the wait with an error instead of hanging.
-void wait_tagged(hc_ctx* c, unsigned long long seq, hipStream_t stream, double* out) {
-    const volatile unsigned long long* g = c->h_tag.p;
+void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long long seq, hipStream_t stream, double* out) {
+    const volatile unsigned long long* g = granules;
     unsigned long long spins = 0;
     for (int r = c->Dloc - 1; r >= 0; --r) {
         while (g[2 * r + 1] != seq) {
@@ -1499,7 +1503,7 @@ int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const dou
     }
     const unsigned long long seq = ++c->seq;
     enqueue_step(c, t, d_state, nullptr, c->stream, StepFlags{}, c->h_tag.dp, seq);
-    wait_tagged(c, seq, c->stream, c->last_total.data());
+    wait_tagged(c, c->h_tag.p, seq, c->stream, c->last_total.data());
     if (c->device_errors_possible) check_device_flag(c);
     std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
     HC_API_END(c)
@@ -1673,20 +1677,21 @@ int hc_added_mass_mv(hc_ctx* c, const double* w, double cc, double* R, int n_sys
     require(w && R, HC_ERR_INVALID, "null pointer");
     require(n_sys >= c->D, HC_ERR_INVALID, "system has fewer coordinates than the added-mass block");
     const int row0 = 6 * c->b0;
-    // Staging buffers and a stream of its own: Chrono's integrator calls this between force evaluations, while kernels of the
-    // last hc_step may still be reading the pinned state buffer and the work that step left for later steps (scatter,
-    // look-ahead pass) is still running on the context's stream -- the product does not wait for it.
-    double* hw = c->h_am.p;
-    double* hr = c->h_am.p + c->D;
+    // Chrono's integrator calls this between force evaluations, so it is built like hc_step: staging buffers and a stream of
+    // its own (kernels of the last hc_step may still be reading the state buffer, and the work that step left for later steps
+    // is still running on the context's stream -- the product does not wait for it); w and the incoming R go to the device
+    // through the BAR (fallback: mapped pinned memory), one launch, the result comes back as tagged granules.
+    const bool bar = c->bar_am.host_ok && c->bar_state.host_ok;  // bar_state.host_ok also carries the coherence check of hc_finalize
+    double* hw       = bar ? c->bar_am.p : c->h_am.p;
+    double* hr       = hw + c->D;
     std::memcpy(hw, w, c->D * sizeof(double));
     std::memcpy(hr, R + row0, c->Dloc * sizeof(double));
-    HC_HIP(hipMemcpyAsync(c->d_vec_w.p, hw, c->D * sizeof(double), hipMemcpyHostToDevice, c->stream_am));
-    HC_HIP(hipMemcpyAsync(c->d_vec_R.p, hr, c->Dloc * sizeof(double), hipMemcpyHostToDevice, c->stream_am));
-    hc::launch_added_mass_mv(c->d_ainf.p, c->Dloc, c->D, c->d_vec_w.p, cc, c->d_vec_R.p, c->stream_am);
+    if (bar) _mm_sfence();
+    const double* dw = bar ? c->bar_am.p : c->h_am.dp;
+    const unsigned long long seq = ++c->seq_am;
+    hc::launch_added_mass_mv_tagged(c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq, c->stream_am);
     HC_HIP(hipGetLastError());
-    HC_HIP(hipMemcpyAsync(hr, c->d_vec_R.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream_am));
-    HC_HIP(hipStreamSynchronize(c->stream_am));
-    std::memcpy(R + row0, hr, c->Dloc * sizeof(double));
+    wait_tagged(c, c->h_tag_am.p, seq, c->stream_am, R + row0);
     HC_API_END(c)
 }
 

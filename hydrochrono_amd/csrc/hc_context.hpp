@@ -187,6 +187,9 @@ struct hc_ctx {
     hc::DeviceBuffer<int> d_err;
     hc::PinnedBuffer<double> h_state, h_out, h_am;
     hc::BarBuffer<double> bar_state;  // [2][12N] body state written by the host through the BAR (hc_step)
+    hc::BarBuffer<double> bar_am;     // [D + Dloc] w and incoming R of hc_added_mass_mv
+    hc::PinnedBuffer<unsigned long long> h_tag_am;  // [Dloc][2] its tagged result
+    unsigned long long seq_am = 0;
     hc::PinnedBuffer<unsigned long long> h_tag;  // [Dloc][2] {total, sequence number} granules written by finalize_kernel
     unsigned long long seq = 0;
     std::vector<double> last_total;               // totals of the last evaluated step (duplicate-time cache of hc_step)

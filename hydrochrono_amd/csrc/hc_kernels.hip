@@ -1302,6 +1302,31 @@ __global__ void __launch_bounds__(256) added_mass_mv_kernel(const double* __rest
     if (lane == 0) R[row] += c * acc;
 }
 
+// The same product for the host boundary (hc_added_mass_mv): w and the incoming R come from a buffer the host wrote through
+// the BAR (or mapped pinned memory), the result leaves as {value, sequence} granules in mapped pinned memory -- one launch,
+// no copies, no stream synchronisation, like hc_step.
+__global__ void __launch_bounds__(256) added_mass_mv_tagged_kernel(const double* __restrict__ M, int rows, int cols,
+                                                                    const double* __restrict__ w, const double* __restrict__ R_in, double c,
+                                                                    unsigned long long* __restrict__ tagged, unsigned long long seq) {
+    const int row  = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const double* __restrict__ m = M + (size_t)row * cols;
+    double acc = 0.0;
+    for (int j = lane; j < cols; j += kWave) acc = fma(m[j], w[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const double r = R_in[row] + c * acc;  // the same two roundings as R[row] += c * acc
+        *reinterpret_cast<u64x2*>(tagged + 2 * (size_t)row) = u64x2{(unsigned long long)__double_as_longlong(r), seq};
+    }
+}
+
+void launch_added_mass_mv_tagged(const double* d_M, int rows, int cols, const double* d_w, const double* d_R_in, double c,
+                                 unsigned long long* d_tagged, unsigned long long seq, hipStream_t stream) {
+    hipLaunchKernelGGL(added_mass_mv_tagged_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, d_M, rows, cols, d_w, d_R_in, c, d_tagged, seq);
+}
+
 void launch_added_mass_mv(const double* d_M, int rows, int cols, const double* d_w, double c, double* d_R, hipStream_t stream) {
     hipLaunchKernelGGL(added_mass_mv_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, d_M, rows, cols, d_w, c, d_R);
 }

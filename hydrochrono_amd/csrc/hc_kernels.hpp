@@ -234,6 +234,9 @@ void launch_eta_synthesis(const double* d_t, int nt, const double* d_amp, const 
                           double ramp_duration, double* d_eta, hipStream_t stream);
 // R[i] += c * sum_j M[i][j] * w[j]   (i < rows)
 void launch_added_mass_mv(const double* d_M, int rows, int cols, const double* d_w, double c, double* d_R, hipStream_t stream);
+// tagged[row] = {R_in[row] + c * sum_j M[row][j] * w[j], seq} as 16-byte granules (host boundary)
+void launch_added_mass_mv_tagged(const double* d_M, int rows, int cols, const double* d_w, const double* d_R_in, double c,
+                                 unsigned long long* d_tagged, unsigned long long seq, hipStream_t stream);
 // out[(row*D + col)*S + s] = K[row][s*D + col]  (reference indexing; diagnostics)
 void launch_unrelayout(const Panel& K, int Dloc, int D, int S, double* d_out, hipStream_t stream);
 // ring_vT[col][slot] = ring_v[slot][col] for all slots (after the ring has been re-allocated or injected)

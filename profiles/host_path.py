@@ -59,4 +59,14 @@ t_hist = 20.0 - 0.01 * np.arange(1, 1030)
 gpu.set_history(t_hist, np.stack([m.velocity6(t) for t in t_hist]))
 out["c3_host_boundary"] = {"gpu_hc_step_us": 1e6 * time_steps(gpu, m, 20.0, 0.01, 400, 20),
                            "note": "hc_step through the Python wrapper: state stored through the BAR, one step kernel (+ scatter / pass off the critical path), tagged results in mapped pinned memory"}
+# ChLoadAddedMass::LoadIntLoadResidual_Mv through the host boundary (hc_added_mass_mv), C3 size: 384 x 384 product
+import ctypes as C  # noqa: E402
+w, R = np.ones(gpu.D), np.zeros(gpu.D)
+fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int)(("hc_added_mass_mv", gpu.lib))
+for _ in range(50):
+    fn(gpu.ctx, w.ctypes.data, 0.5, R.ctypes.data, gpu.D)
+a = time.perf_counter()
+for _ in range(2000):
+    fn(gpu.ctx, w.ctypes.data, 0.5, R.ctypes.data, gpu.D)
+out["c3_added_mass_mv_us"] = 1e6 * (time.perf_counter() - a) / 2000
 print(json.dumps(out, indent=1))

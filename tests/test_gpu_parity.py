@@ -179,7 +179,8 @@ def test_sphere_prescribed_motion_all_terms(HF):
 # ------------------------------------------------------------------------------------------------
 # multi-body synthetic cases (no multi-body reference data exists: parity is oracle-only, unpinned)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,dt", [(2, 0.01), (3, 0.007), (4, 0.01), (4, 0.013)])
+# N = 8, 12: D % 8 == 0 and D >= 32 -> the scalar-tracker form of the look-ahead pass with chunk boundaries inside IRF samples
+@pytest.mark.parametrize("N,dt", [(2, 0.01), (3, 0.007), (4, 0.01), (4, 0.013), (8, 0.01), (8, 0.007), (12, 0.013)])
 def test_multibody_parity(HF, N, dt):
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     from hydrochrono_amd.synthetic import many_body_case, rest_positions

@@ -580,9 +580,19 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     const bool run_exc = f.waves && irregular;
     const StepViews vw = make_views(c);
     const bool block   = run_rad && m > 0;
-    if (c->bg_pending && stream != c->stream) {
+    if (c->have_last_stream && c->last_stream != stream) {
+        // The steps of a context normally stay on one stream (the velocity ring is updated in stream order).  When they
+        // move -- hc_step after hc_step_device on a caller's stream, or the reverse -- this step is ordered behind the
+        // previous one with an event.  A caller's stream may have been destroyed since (after a synchronise): then there is
+        // nothing left to wait for.
+        if (hipEventRecord(c->ev_fin, c->last_stream) == hipSuccess) HC_HIP(hipStreamWaitEvent(stream, c->ev_fin, 0));
+        else (void)hipGetLastError();
+    }
+    c->last_stream      = stream;
+    c->have_last_stream = true;
+    if (c->bg_pending) {
         // the scatter / pass of the previous step ran on the context's own stream (see below): this step's kernels need them
-        HC_HIP(hipStreamWaitEvent(stream, c->ev_bg, 0));
+        if (stream != c->stream) HC_HIP(hipStreamWaitEvent(stream, c->ev_bg, 0));
         c->bg_pending = false;
     }
     const double* P_row = block ? c->d_P.p + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
@@ -1466,8 +1476,18 @@ int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const dou
         std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
         return HC_OK;
     }
+    if (c->have_prev_device && t == c->prev_time_device) {
+        // this time was evaluated through hc_step_device (possibly on a caller's stream): fetch its totals, do not re-evaluate
+        HC_HIP(hipDeviceSynchronize());
+        HC_HIP(hipMemcpy(c->last_total.data(), c->d_total.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost));
+        c->prev_time = t;
+        c->have_prev = true;
+        std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
+        return HC_OK;
+    }
     c->prev_time = t;  // :747 (set before the terms are computed, so a throwing step is not retried)
     c->have_prev = true;
+    c->have_prev_device = false;  // d_total is about to be replaced (or left stale by a step that throws)
     std::fill(c->last_total.begin(), c->last_total.end(), 0.0);  // the reference zero-fills total_force_ before the terms (:749-751)
     // Boundary without copy launches or stream synchronisation: the host stores the 12N state doubles straight into device
     // memory through the PCIe BAR (fallback: mapped pinned memory the kernels read over PCIe), finalize_kernel stores the
@@ -1505,6 +1525,8 @@ int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const dou
     enqueue_step(c, t, d_state, nullptr, c->stream, StepFlags{}, c->h_tag.dp, seq);
     wait_tagged(c, c->h_tag.p, seq, c->stream, c->last_total.data());
     if (c->device_errors_possible) check_device_flag(c);
+    c->prev_time_device = t;  // finalize_kernel has left the same totals in d_total: hc_step_device at this time copies them
+    c->have_prev_device = true;
     std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
     HC_API_END(c)
 }
@@ -1515,6 +1537,10 @@ int hc_step_device(hc_ctx* c, double t, const double* d_state, double* d_force_o
     require(d_state && d_force_out, HC_ERR_INVALID, "null pointer");
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     if (c->have_prev_device && t == c->prev_time_device) {
+        if (s != c->stream) {  // the totals may have been left by an hc_step, whose kernels ran on the context's stream
+            HC_HIP(hipEventRecord(c->ev_fin, c->stream));
+            HC_HIP(hipStreamWaitEvent(s, c->ev_fin, 0));
+        }
         HC_HIP(hipMemcpyAsync(d_force_out, c->d_total.p, c->Dloc * sizeof(double), hipMemcpyDeviceToDevice, s));
         return HC_OK;
     }
@@ -1607,6 +1633,7 @@ int hc_reset_history(hc_ctx* c) {
     HC_HIP(hipDeviceSynchronize());  // steps may still be running on a caller's stream (hc_step_device)
     c->times.clear();
     c->head = -1;
+    c->have_last_stream = c->bg_pending = false;  // everything has run
     c->have_prev = c->have_prev_device = false;
     c->prev_time = c->prev_time_device = -1.0;
     c->plan = hc::Plan{};
@@ -1619,6 +1646,7 @@ int hc_set_history(hc_ctx* c, int n, const double* times, const double* vel) {
     require(n >= 0 && (n == 0 || (times && vel)), HC_ERR_INVALID, "bad history arguments");
     for (int k = 1; k < n; ++k) require(times[k] < times[k - 1], HC_ERR_INVALID, "history times must be strictly decreasing (newest first)");
     HC_HIP(hipDeviceSynchronize());  // steps may still be running on a caller's stream (hc_step_device)
+    c->have_last_stream = c->bg_pending = false;  // everything has run
     if (n > c->Hcap) ring_alloc(c, n + 16);
     c->times.assign(times, times + n);
     // sample k -> slot n-1-k, head = n-1

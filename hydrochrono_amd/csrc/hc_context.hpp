@@ -126,6 +126,9 @@ struct hc_ctx {
     // runs on the context's own stream behind ev_fin, and the next step kernel waits for ev_bg
     hipEvent_t ev_fin = nullptr, ev_bg = nullptr;
     bool bg_pending = false;
+    // stream the last step's kernels went to: a step on another stream is ordered behind it with an event
+    hipStream_t last_stream = nullptr;
+    bool have_last_stream   = false;
     std::string err;
 
     bool have_sim = false;

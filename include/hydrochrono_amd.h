@@ -161,8 +161,10 @@ int hc_step(hc_ctx* ctx, double t, const double* pos, const double* rpy, const d
  *   d_state     device pointer, 12N doubles = pos[3N] | rpy[3N] | linvel[3N] | angvel[3N]
  *   d_force_out device pointer, D_local doubles
  *   stream      hipStream_t (NULL = the context's own stream).  Asynchronous: returns after enqueue; d_state and
- *               d_force_out must stay valid until the work enqueued for this step has run, and every step of one
- *               context must go to the same stream (the velocity ring is updated in stream order).  With a caller's stream only
+ *               d_force_out must stay valid until the work enqueued for this step has run.  The steps of one context
+ *               normally stay on one stream (the velocity ring is updated in stream order); a step that goes to another
+ *               stream than the one before it -- hc_step included, which uses the context's stream -- is ordered behind
+ *               it with an event.  hc_step and hc_step_device share the per-time cache.  With a caller's stream only
  *               the step kernel is enqueued there; the work later steps need (scatter, look-ahead pass) runs on the context's
  *               own stream behind an event, and the next step waits for it -- what the caller enqueues next on its stream
  *               (e.g. the all-gather of the force rows of a row-sharded array) follows the step kernel directly. */

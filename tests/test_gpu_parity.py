@@ -448,6 +448,33 @@ def test_step_device_matches_host_step(HF):
     assert np.array_equal(out.cpu().numpy(), host)
 
 
+def test_per_time_cache_is_shared_by_host_and_device_steps(HF):
+    """One evaluation per distinct time (src/hydro_forces.cpp:742-744) whichever of hc_step / hc_step_device asks first."""
+    import torch
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    case = many_body_case(2, S=48, n_exc=33, seed=43)
+    a, ref = HF.from_case(case), HF.from_case(case)
+    motion = PrescribedMotion(2, rest_positions(case), seed=8)
+    side = torch.cuda.Stream()
+    for n in range(40):
+        t = 0.01 * n
+        want = ref.step(t, *motion.state(t))
+        st = torch.tensor(motion.packed(t), device="cuda")
+        out = torch.zeros(12, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        if n % 2 == 0:  # host step first, then the device entry point at the same time, on another stream
+            assert np.array_equal(a.step(t, *motion.state(t)), want)
+            a.step_device(t, st.data_ptr(), out.data_ptr(), side.cuda_stream)
+            side.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want)
+        else:           # device step first, then the host entry point at the same time
+            a.step_device(t, st.data_ptr(), out.data_ptr(), side.cuda_stream)
+            assert np.array_equal(a.step(t, *motion.state(t)), want)
+            assert np.array_equal(out.cpu().numpy(), want)
+        assert a.sizes()["H"] == ref.sizes()["H"]
+
+
 def test_added_mass(HF):
     from hydrochrono_amd.synthetic import many_body_case
     case = many_body_case(5, S=16, n_exc=33, seed=51)

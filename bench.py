@@ -241,12 +241,17 @@ def main():
     fp = [forces.ctypes.data + k * forces.strides[0] for k in range(n_all)]
     per_step = np.zeros(n_all)
 
-    stream = torch.cuda.current_stream()
+    # An explicit stream for everything torch enqueues (copies, the RCCL all-gather) and for hc_step_device: the legacy default
+    # stream has handle 0, which hc_step_device reads as "the context's own non-blocking stream" -- torch work would not be
+    # ordered against the step kernels there.
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     if exchange is not None:
         d_states = torch.tensor(states[:total], device="cuda")
         state_ptrs = [d_states.data_ptr() + k * d_states.stride(0) * 8 for k in range(total)]
         d_send = exchange.send if not share_gpu else torch.zeros(exchange.max_rows, dtype=torch.float64, device="cuda")
         gathered = torch.zeros(total, 6 * N, dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+        own_rows = torch.zeros(total, exchange.rows, dtype=torch.float64, device="cuda")  # this rank's rows as the kernel left them
         torch.cuda.synchronize()
 
     def run_sync(k0, k1):
@@ -267,6 +272,7 @@ def main():
             for k in range(k0, k1):
                 a = pc()
                 gpu.step_device(times[k], state_ptrs[k], d_send.data_ptr(), stream.cuda_stream)
+                own_rows[k].copy_(d_send[: exchange.rows], non_blocking=True)  # for the exchange check after the run
                 if share_gpu:
                     stream.synchronize()
                     full = exchange.gather(d_send[: exchange.rows].cpu())
@@ -296,6 +302,24 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    exchange_ok = None
+    if exchange is not None:
+        # the one exchange step of the path, checked after the run: every rank finds its own rows, bit for bit, at its place in
+        # the gathered vector of every step, and all ranks hold the same gathered vectors (checksums of the raw bits)
+        b0_, b1_ = exchange.shards[rank]
+        mine = gathered[:total, 6 * b0_:6 * b1_].to("cuda")
+        own_ok = bool(torch.equal(mine, own_rows[:total]))
+        dev_ = "cpu" if share_gpu else "cuda"
+        bits = gathered[:total].contiguous().view(torch.int64)
+        csum = (bits & 0xFFFFFFFF).sum(dim=1) + (bits >> 32).sum(dim=1)  # per-step checksum, exact in int64
+        lo, hi = csum.clone().to(dev_), csum.clone().to(dev_)
+        flag = torch.tensor([1 if own_ok else 0], dtype=torch.int64, device=dev_)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        exchange_ok = {"own_rows_bitwise_on_every_rank": bool(flag.item() == 1), "all_ranks_hold_the_same_vectors": bool(torch.equal(lo, hi)),
+                       "steps_checked": int(total)}
 
     # ---- secondary figures (not `value`) ----
     pipelined = plain = None
@@ -434,6 +458,7 @@ def main():
             out["speedup_vs_optimized_cpu"] = out["value"] / base["optimized_port"]["value"]
         elif exchange is not None:
             out["gathered_rows_finite"] = bool(torch.isfinite(gathered[pre:total]).all().item())
+            out["exchange_check"] = exchange_ok
         if strong:
             # the same coupled array on ONE GPU (committed measurement), so that a strong-scaling ratio can be formed: the N = 1
             # line of this benchmark is the C3 case (BASELINE.json's metric), not this workload

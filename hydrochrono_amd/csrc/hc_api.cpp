@@ -580,6 +580,22 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     const bool run_exc = f.waves && irregular;
     const StepViews vw = make_views(c);
     const bool block   = run_rad && m > 0;
+    // A caller's stream that is idle now belongs to a caller that waits for every step (the force exchange of a row-sharded
+    // array): the work later steps need then goes to the context's own stream, see below.  A caller that runs ahead of the GPU
+    // (stream still busy) gets everything on its stream in order -- the two event hops per step would only slow it down.
+    bool caller_waits = false;
+    if (stream != c->stream && f.rad && c->lookahead > 0) {
+        if (c->busy_caller_steps > 0) {
+            --c->busy_caller_steps;  // found busy a moment ago: do not pay for the query on every step of a caller that runs ahead
+        } else {
+            const hipError_t q = hipStreamQuery(stream);
+            caller_waits       = q == hipSuccess;
+            if (q != hipSuccess) {
+                (void)hipGetLastError();
+                c->busy_caller_steps = 15;
+            }
+        }
+    }
     if (c->have_last_stream && c->last_stream != stream) {
         // The steps of a context normally stay on one stream (the velocity ring is updated in stream order).  When they
         // move -- hc_step after hc_step_device on a caller's stream, or the reverse -- this step is ordered behind the
@@ -732,14 +748,15 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     }
 
     // ---- off the caller's critical path: everything below is needed by later steps only ----
-    // On a caller's stream (hc_step_device) it goes to the context's own stream behind an event, so that whatever the caller
-    // enqueues next on its stream -- the all-gather of the force rows in a multi-GPU run -- follows the step kernel directly.
+    // On a caller's stream (hc_step_device) whose owner waits for every step it goes to the context's own stream behind an
+    // event, so that whatever the caller enqueues next on its stream -- the all-gather of the force rows in a multi-GPU run --
+    // follows the step kernel directly.
     if (f.rad && c->lookahead > 0) {
         const bool scatter_now = block && m < c->lookahead && c->plan.scat_hi[m] >= c->plan.scat_lo[m];
         const bool plan_now    = (!block || m == c->lookahead) && H >= 2;
         hipStream_t bs         = stream;
         auto to_background = [&]() {
-            if (stream != c->stream && bs == stream) {
+            if (caller_waits && bs == stream) {
                 bs = c->stream;
                 HC_HIP(hipEventRecord(c->ev_fin, stream));
                 HC_HIP(hipStreamWaitEvent(bs, c->ev_fin, 0));

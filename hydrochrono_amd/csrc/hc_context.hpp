@@ -129,6 +129,7 @@ struct hc_ctx {
     // stream the last step's kernels went to: a step on another stream is ordered behind it with an event
     hipStream_t last_stream = nullptr;
     bool have_last_stream   = false;
+    int busy_caller_steps   = 0;  // hc_step_device: steps left before the caller's stream is queried again (see enqueue_step)
     std::string err;
 
     bool have_sim = false;

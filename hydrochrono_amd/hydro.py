@@ -183,7 +183,12 @@ class HydroForces:
         return out
 
     def step_device(self, t, state_ptr, out_ptr, stream_ptr=None):
-        """state_ptr / out_ptr: integer device addresses (e.g. torch.Tensor.data_ptr())."""
+        """state_ptr / out_ptr: integer device addresses (e.g. torch.Tensor.data_ptr()).
+
+        stream_ptr: hipStream_t as an integer.  None or 0 is NOT the legacy default stream (whose handle is 0, e.g.
+        torch.cuda.current_stream() outside a stream context) but the context's own non-blocking stream, which other
+        work is not ordered against: pass an explicit stream (torch.cuda.Stream().cuda_stream) when device work of
+        the caller -- a collective, a copy -- has to follow the step."""
         # plain ints go straight through the declared c_void_p argtypes (this call sits in per-step loops)
         rc = self.lib.hc_step_device(self.ctx, t, state_ptr, out_ptr, stream_ptr or None)
         if rc:

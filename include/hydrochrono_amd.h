@@ -164,10 +164,12 @@ int hc_step(hc_ctx* ctx, double t, const double* pos, const double* rpy, const d
  *               d_force_out must stay valid until the work enqueued for this step has run.  The steps of one context
  *               normally stay on one stream (the velocity ring is updated in stream order); a step that goes to another
  *               stream than the one before it -- hc_step included, which uses the context's stream -- is ordered behind
- *               it with an event.  hc_step and hc_step_device share the per-time cache.  With a caller's stream only
- *               the step kernel is enqueued there; the work later steps need (scatter, look-ahead pass) runs on the context's
- *               own stream behind an event, and the next step waits for it -- what the caller enqueues next on its stream
- *               (e.g. the all-gather of the force rows of a row-sharded array) follows the step kernel directly. */
+ *               it with an event.  hc_step and hc_step_device share the per-time cache.  On a caller's stream that is
+ *               idle when the call arrives (a caller that waits for every step) only the step kernel is enqueued there;
+ *               the work later steps need (scatter, look-ahead pass) runs on the context's own stream behind an event,
+ *               and the next step waits for it -- what the caller enqueues next on its stream (e.g. the all-gather of the
+ *               force rows of a row-sharded array) follows the step kernel directly.  A caller that enqueues steps ahead
+ *               of the GPU gets all of it on its stream, in order. */
 int hc_step_device(hc_ctx* ctx, double t, const double* d_state, double* d_force_out, void* stream);
 /* force_hydrostatic_, force_radiation_damping_, force_waves_ of the last evaluated step (D_local each;
  * any pointer may be NULL).  Synchronises the context's stream. */

@@ -440,9 +440,10 @@ def test_step_device_matches_host_step(HF):
     nsteps = 100
     states = torch.tensor(np.stack([motion.packed(0.01 * n) for n in range(nsteps)]), device="cuda")
     out = torch.zeros(nsteps, 12, dtype=torch.float64, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()  # a caller's stream (handle 0 would select the context's own stream)
     for n in range(nsteps):
-        b.step_device(0.01 * n, states[n].data_ptr(), out[n].data_ptr(), stream)
+        b.step_device(0.01 * n, states[n].data_ptr(), out[n].data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     host = np.stack([a.step(0.01 * n, *motion.state(0.01 * n)) for n in range(nsteps)])
     assert np.array_equal(out.cpu().numpy(), host)

@@ -116,3 +116,45 @@ def test_row_sharded_contexts_two_ranks_one_gpu(N):
     res = dict(ret)
     assert res[0][0] and res[1][0]
     assert res[0][1] <= 1e-10  # gathered forces vs the CPU oracle (contract 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# RCCL on the one GPU of the box: a world of one rank, the device path of bench.py --gpus N (hc_step_device writes the
+# rank's force rows into the exchange buffer, the all-gather follows on the same stream).  With one rank the collective
+# moves nothing between GPUs, but the communicator, the device buffers and the stream ordering are the real ones.
+# ------------------------------------------------------------------------------------------------
+def _rccl_worker(rank, world, port, N, steps, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from hydrochrono_amd.hydro import HydroForces
+        from hydrochrono_amd.mock_chrono import PrescribedMotion
+        from hydrochrono_amd.synthetic import many_body_case, rest_positions
+        case = many_body_case(N, S=64, dt_rirf=0.01, n_exc=33, dt_exc=0.02, seed=4200)
+        dev, host = HydroForces.from_case(case, device=0), HydroForces.from_case(case, device=0)
+        ex = ForceExchange(N, world, rank, device="cuda")
+        motion = PrescribedMotion(N, rest_positions(case), seed=9)
+        states = torch.tensor(np.stack([motion.packed(0.01 * n) for n in range(steps)]), device="cuda")
+        out = torch.zeros(steps, 6 * N, dtype=torch.float64, device="cuda")
+        stream = torch.cuda.Stream()  # an explicit stream: handle 0 would mean the context's own stream, see step_device
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            for n in range(steps):
+                dev.step_device(0.01 * n, states[n].data_ptr(), ex.send.data_ptr(), stream.cuda_stream)
+                dist.all_gather_into_tensor(ex.recv, ex.send)  # what gather() issues for world > 1
+                out[n].copy_(ex.recv[: 6 * N])
+        torch.cuda.synchronize()
+        want = np.stack([host.step(0.01 * n, *motion.state(0.01 * n)) for n in range(steps)])
+        got = out.cpu().numpy()
+        ret[rank] = (bool(np.array_equal(got, want)), dist.get_backend(), float(np.max(np.abs(got - want))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_device_path_all_gather_over_rccl_one_rank():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), 3, 80, ret), nprocs=1, join=True)
+    assert dict(ret) == {0: (True, "nccl", 0.0)}

@@ -354,7 +354,8 @@ inline std::unique_ptr<TestHydro> SetupHydroFromYAML(const std::string& hydro_ya
 }  // namespace hydroc_amd
 
 // =================================================================================================================
-// Project Chrono adapters (compiled only when Chrono headers are available; untestable in the build container)
+// Project Chrono adapters (compiled only when Chrono headers are available; in the build container they are compiled and driven
+// against stand-in Chrono headers, tests/cpp/chrono_stub + tests/test_chrono_adapter.py -- test infrastructure, not a Chrono build)
 // =================================================================================================================
 #ifdef HYDROCHRONO_AMD_WITH_CHRONO
 #include <chrono/functions/ChFunction.h>

@@ -94,11 +94,12 @@ bool is_local(const hc_ctx* c, int body) { return body >= c->b0 && body < c->b1;
 void ring_alloc(hc_ctx* c, int cap) {
     c->d_ring_t.alloc(cap);
     c->d_ring_v.alloc(static_cast<size_t>(cap) * c->D);
-    c->d_ring_vT.alloc(static_cast<size_t>(cap) * c->D);
+    c->d_ring_vT.alloc(static_cast<size_t>(cap + 2) * c->D);  // rows of Hcap + 2: entry [Hcap] mirrors slot 0 (hc_kernels.hpp)
     HC_HIP(hipMemsetAsync(c->d_ring_t.p, 0, cap * sizeof(double), c->stream));
     HC_HIP(hipMemsetAsync(c->d_ring_v.p, 0, static_cast<size_t>(cap) * c->D * sizeof(double), c->stream));
-    HC_HIP(hipMemsetAsync(c->d_ring_vT.p, 0, static_cast<size_t>(cap) * c->D * sizeof(double), c->stream));
-    c->Hcap = cap;
+    HC_HIP(hipMemsetAsync(c->d_ring_vT.p, 0, static_cast<size_t>(cap + 2) * c->D * sizeof(double), c->stream));
+    c->Hcap  = cap;
+    c->HcapT = cap + 2;
     c->head = -1;
 }
 
@@ -119,16 +120,18 @@ void ring_grow(hc_ctx* c, int need, int have) {
         HC_HIP(hipMemcpyAsync(nv.p + static_cast<size_t>(dst) * c->D, c->d_ring_v.p + static_cast<size_t>(src) * c->D,
                               c->D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
-    c->d_ring_vT.alloc(static_cast<size_t>(cap2) * c->D);
-    hc::launch_ring_transpose(nv.p, cap2, c->D, c->d_ring_vT.p, c->stream);
+    c->d_ring_vT.alloc(static_cast<size_t>(cap2 + 2) * c->D);
+    HC_HIP(hipMemsetAsync(c->d_ring_vT.p, 0, static_cast<size_t>(cap2 + 2) * c->D * sizeof(double), c->stream));
+    hc::launch_ring_transpose(nv.p, cap2, cap2 + 2, c->D, c->d_ring_vT.p, c->stream);
     HC_HIP(hipGetLastError());
     HC_HIP(hipStreamSynchronize(c->stream));
     std::swap(c->d_ring_t.p, nt.p);
     std::swap(c->d_ring_t.n, nt.n);
     std::swap(c->d_ring_v.p, nv.p);
     std::swap(c->d_ring_v.n, nv.n);
-    c->Hcap = cap2;
-    c->head = have - 1;
+    c->Hcap  = cap2;
+    c->HcapT = cap2 + 2;
+    c->head  = have - 1;
 }
 
 // Push the time of this step and prune like PruneHistory; returns H (samples incl. the current one).
@@ -305,7 +308,7 @@ void choose_exc_config(hc_ctx* c) {
     }
     c->chunk_gp_ex = std::max(4, env_int("HC_EXC_CHUNK_GP", 8));  // short chunks: the excitation side is latency-bound
     c->nchunks_ex  = (c->ngp_ex + c->chunk_gp_ex - 1) / c->chunk_gp_ex;
-    c->chunk_gp_ex_block = 32;  // whole 16-group sub-tiles of the look-ahead kernel
+    c->chunk_gp_ex_block = 16;  // one 16-group sub-tile of the look-ahead kernel per work item (the items are dealt one per workgroup)
     c->nchunks_ex_block  = (c->ngp_ex + c->chunk_gp_ex_block - 1) / c->chunk_gp_ex_block;
 }
 
@@ -505,6 +508,7 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
     hv.head    = (c->head + 1) % c->Hcap;  // slot of the virtual sample (never read: time and velocity come from t / state)
     hv.H       = Hv;
     hv.Hcap    = c->Hcap;
+    hv.HcapT   = c->HcapT;
     hv.dt_hint = pl.dt;
 
     const StepViews vw = make_views(c);
@@ -627,6 +631,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         hv.head    = c->head;
         hv.H       = H;
         hv.Hcap    = c->Hcap;
+        hv.HcapT   = c->HcapT;
         hv.dt_hint = (H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
         hc::StepArgs a{};
         a.K       = rad_panel(c);
@@ -741,6 +746,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     z.ring_v        = c->d_ring_v.p;
     z.ring_vT       = c->d_ring_vT.p;
     z.Hcap          = c->Hcap;
+    z.HcapT         = c->HcapT;
     {
         hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
         hc::launch_finalize(z, stream);
@@ -1677,7 +1683,7 @@ int hc_set_history(hc_ctx* c, int n, const double* times, const double* vel) {
         // against a non-blocking stream (it could be overtaken by them)
         HC_HIP(hipMemcpyAsync(c->d_ring_t.p, tt.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HC_HIP(hipMemcpyAsync(c->d_ring_v.p, vv.data(), vv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        hc::launch_ring_transpose(c->d_ring_v.p, c->Hcap, c->D, c->d_ring_vT.p, c->stream);
+        hc::launch_ring_transpose(c->d_ring_v.p, c->Hcap, c->HcapT, c->D, c->d_ring_vT.p, c->stream);
         HC_HIP(hipGetLastError());
     }
     HC_HIP(hipStreamSynchronize(c->stream));  // tt / vv are released on return

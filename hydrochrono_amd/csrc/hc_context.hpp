@@ -149,8 +149,8 @@ struct hc_ctx {
 
     // history (host mirror of times, newest first) + ring in HBM
     std::deque<double> times;
-    int head = -1, Hcap = 0;
-    hc::DeviceBuffer<double> d_ring_t, d_ring_v, d_ring_vT;  // ring_vT[D][Hcap]: per-DoF copy for the look-ahead pass
+    int head = -1, Hcap = 0, HcapT = 0;
+    hc::DeviceBuffer<double> d_ring_t, d_ring_v, d_ring_vT;  // ring_vT[D][HcapT = Hcap + 2]: per-DoF copy for the look-ahead pass
     bool have_prev = false, have_prev_device = false;  // per-time cache of hc_step (host totals) / hc_step_device (d_total)
     double prev_time = -1.0, prev_time_device = -1.0;
 

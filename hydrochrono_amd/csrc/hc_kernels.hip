@@ -25,6 +25,7 @@ static constexpr int kConvThreads = 256;  // 4 waves of 64
 static constexpr int kWave        = 64;
 
 typedef double dvec2 __attribute__((ext_vector_type(2)));
+typedef double dvec2u __attribute__((ext_vector_type(2), aligned(8)));  // 16-byte load at 8-byte alignment
 typedef double dvec4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline size_t panel_offset(int ngp, int row, int f) {
@@ -475,7 +476,7 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
     // history step, so the 16 lanes of one column read (up to a wrap of the ring) 16 consecutive doubles -- one or two
     // cache lines per column instead of one line per step from the sample-major ring.
     const double* __restrict__ ring = a.hist.ring_vT;
-    const int Hc                    = a.hist.Hcap;
+    const int Hc                    = a.hist.HcapT;  // row length
 
     // pipeline registers (UNI: the two columns of a lane lie in the same IRF sample and share bracket and weights)
     constexpr int HB = UNI ? 1 : 2;
@@ -628,7 +629,7 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
     const int s0  = (gp0 * 8) / D;
     const int ns  = (min(a.F, gp1 * 8) - 1) / D - s0 + 1;
     const int s_live = a.F / D;
-    const int Hc     = a.hist.Hcap;
+    const int Hc     = a.hist.HcapT;  // row length of the per-DoF ring
     for (int idx = tid; idx < ns * L; idx += kConvThreads) {
         const int k = idx / L, j = idx - k * L, s = s0 + k;
         Bracket b;
@@ -637,8 +638,8 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
         const double w = a.width[s < s_live ? s : 0];
         t_wo[idx] = b.wo * w;
         t_wn[idx] = (b.off_newer >= 0) ? b.wn * w : 0.0;
-        t_oo[idx] = (b.off_older / D) * 8;          // byte offset of the older sample inside a column of the per-DoF ring
-        t_on[idx] = (max(b.off_newer, 0) / D) * 8;  // ... of the newer one
+        t_oo[idx] = (b.off_older / D) * 8;  // byte offset of the older sample inside a column of the per-DoF ring; the newer one
+                                            // (ring slot + 1 mod Hcap, or the not-yet-known sample, whose weight is 0) follows it
     }
     __syncthreads();
 
@@ -654,22 +655,18 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
     const unsigned col_bytes       = (unsigned)Hc * 8u;
 
     dvec2 kv[R][MT];
-    double vo[R][2][NB], vn[R][2][NB];
+    dvec2u von[R][2][NB];  // {older, newer} sample of the bracket: adjacent entries of the lane's column (the ring row is mirrored past its end)
 
     // ---- issue side ----
     int gp_i = gp0 + wave;
     int s_i = (gp_i * 8) / D, cb_i = gp_i * 8 - s_i * D;          // scalars
     unsigned cby = (unsigned)(cb_i + kk) * col_bytes;              // byte offset of the lane's first column (second: + 4 columns)
-    unsigned boo[NB], bon[NB];
+    unsigned boo[NB];
     auto load_offsets = [&]() {
         const int ks  = s_i - s0;
         const bool in = ks >= 0 && ks < ns;  // past the chunk's samples: any valid address will do (those fragments are skipped or weigh 0)
 #pragma unroll
-        for (int tb = 0; tb < NB; ++tb) {
-            const int k = (in ? ks : 0) * L + 16 * tb + jstep;
-            boo[tb]     = (unsigned)t_oo[k];
-            bon[tb]     = (unsigned)t_on[k];
-        }
+        for (int tb = 0; tb < NB; ++tb) boo[tb] = (unsigned)t_oo[(in ? ks : 0) * L + 16 * tb + jstep];
     };
     load_offsets();
     auto issue = [&](const int slot) {
@@ -683,8 +680,7 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
 #pragma unroll
             for (int tb = 0; tb < NB; ++tb) {
                 const unsigned cb = cby + (unsigned)(4 * h) * col_bytes;
-                vo[slot][h][tb]   = *reinterpret_cast<const double*>(ringb + (cb + boo[tb]));
-                vn[slot][h][tb]   = *reinterpret_cast<const double*>(ringb + (cb + bon[tb]));
+                von[slot][h][tb]  = *reinterpret_cast<const dvec2u*>(ringb + (cb + boo[tb]));
             }
         gp_i += 4;
         cb_i += 32;
@@ -721,7 +717,7 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int tb = 0; tb < NB; ++tb) u[h][tb] = fma(cwo[tb], vo[slot][h][tb], cwn[tb] * vn[slot][h][tb]);  // explicit: every instantiation rounds alike
+                for (int tb = 0; tb < NB; ++tb) u[h][tb] = fma(cwo[tb], von[slot][h][tb].x, cwn[tb] * von[slot][h][tb].y);  // explicit: every instantiation rounds alike
 #pragma unroll
             for (int tb = 0; tb < NB; ++tb)
 #pragma unroll
@@ -789,17 +785,21 @@ __global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs
     if (chunk >= a.nchunks) return;
 
     // the per-DoF ring must be addressable with 32-bit byte offsets for the scalar-base form (4 GB: far beyond any real history)
-    if ((a.hist.D & 7) == 0 && (size_t)a.hist.D * a.hist.Hcap < ((size_t)1 << 28)) block_rad_stream_uni<MT, R, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+    if ((a.hist.D & 7) == 0 && (size_t)a.hist.D * a.hist.HcapT < ((size_t)1 << 28)) block_rad_stream_uni<MT, R, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
     else block_rad_stream<MT, (NB > 1) ? 2 : R, NB, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
-    // The excitation force depends on time only: its chunks over Kex (a fraction of a percent of K) for the predicted times
-    // ride at the end of radiation workgroups, so the launch keeps its number of workgroups (grid rounds on the chip).
+    // The excitation force depends on time only: its work items over Kex (a fraction of a percent of K) for the predicted times ride
+    // at the end of radiation workgroups, so the launch keeps its number of workgroups (grid rounds on the chip).  An item is
+    // (excitation chunk, block of 16 steps, group of MTE row tiles) and takes several microseconds of dependent loads
+    // (free-surface table -> LDS -> MFMA), so the items are dealt one per workgroup across the launch: stacked on a few
+    // workgroups they were a tail of 28 us at C3 that every other CU waited for.
     constexpr int MTE = MT > 6 ? 6 : MT;  // row tiles per excitation work item (register budget of the LDS-staged form)
-    for (int e = chunk; e < a.nchunks_ex; e += a.nchunks)
-        for (int tb = 0; tb < NB; ++tb)
-            for (int sub = 0; sub < MT / MTE; ++sub) {
-                __syncthreads();  // the reduction buffer of the previous work item aliases the U tiles of this one
-                block_exc_work<MTE>(a, grp * (MT / MTE) + sub, e, 16 * tb, front);
-            }
+    const int RG      = a.ngroups * (MT / MTE);
+    const int n_items = a.nchunks_ex * NB * RG;
+    for (int it = chunk * a.ngroups + grp; it < n_items; it += a.nchunks * a.ngroups) {
+        const int e = it / (NB * RG), rem = it - e * (NB * RG), tb = rem / RG, rg = rem - tb * RG;
+        __syncthreads();  // the reduction buffer of the previous work item aliases the U tiles of this one
+        block_exc_work<MTE>(a, rg, e, 16 * tb, front);
+    }
 }
 
 template <class KernelT>
@@ -823,6 +823,7 @@ static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, h
         if constexpr (MT == 6) {
             if (v32 == 4) { hipLaunchKernelGGL((conv_block_kernel<6, 5, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
             if (v32 == 5) { hipLaunchKernelGGL((conv_block_kernel<6, 3, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            if (v32 == 6) { hipLaunchKernelGGL((conv_block_kernel<6, 6, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
         }
         allow_dynamic_lds(conv_block_kernel<MT, R32, 2>, smem, granted32);
         hipLaunchKernelGGL((conv_block_kernel<MT, R32, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
@@ -911,7 +912,8 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
         for (int c = threadIdx.x; c < a.D; c += blockDim.x) {
             const double v = state_velocity(a.state, a.N, c);
             slot[c] = v;
-            a.ring_vT[(size_t)c * a.Hcap + a.head] = v;  // per-DoF time series for the look-ahead pass
+            a.ring_vT[(size_t)c * a.HcapT + a.head] = v;  // per-DoF time series for the look-ahead pass
+            if (a.head == 0) a.ring_vT[(size_t)c * a.HcapT + a.Hcap] = v;  // mirror of slot 0 behind the last slot
         }
         return;
     }
@@ -1197,18 +1199,20 @@ void launch_scatter(const ScatterArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(scatter_kernel, dim3(a.K.ntiles * a.ns), dim3(256), smem, stream, a);
 }
 
-__global__ void __launch_bounds__(256) ring_transpose_kernel(const double* __restrict__ ring_v, int Hcap, int D, double* __restrict__ ring_vT) {
+__global__ void __launch_bounds__(256) ring_transpose_kernel(const double* __restrict__ ring_v, int Hcap, int HcapT, int D, double* __restrict__ ring_vT) {
     const size_t n      = (size_t)Hcap * D;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int slot = (int)(i / D), col = (int)(i - (size_t)slot * D);
-        ring_vT[(size_t)col * Hcap + slot] = ring_v[i];
+        const double v = ring_v[i];
+        ring_vT[(size_t)col * HcapT + slot] = v;
+        if (slot == 0) ring_vT[(size_t)col * HcapT + Hcap] = v;
     }
 }
 
-void launch_ring_transpose(const double* d_ring_v, int Hcap, int D, double* d_ring_vT, hipStream_t stream) {
+void launch_ring_transpose(const double* d_ring_v, int Hcap, int HcapT, int D, double* d_ring_vT, hipStream_t stream) {
     const size_t n = (size_t)Hcap * D;
-    hipLaunchKernelGGL(ring_transpose_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, d_ring_v, Hcap, D, d_ring_vT);
+    hipLaunchKernelGGL(ring_transpose_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, d_ring_v, Hcap, HcapT, D, d_ring_vT);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -34,8 +34,11 @@ struct HistoryView {
     double t;
     const double* ring_t;
     const double* ring_v;
-    const double* ring_vT;  // the same samples per DoF: ring_vT[col][Hcap] (each DoF's time series contiguous; look-ahead pass)
+    const double* ring_vT;  // the same samples per DoF: ring_vT[col][HcapT] (each DoF's time series contiguous; look-ahead pass).
+                            // HcapT = Hcap + 2: entry [Hcap] mirrors slot 0, so that the two samples of a bracket (ring slots
+                            // k, k+1 mod Hcap) are always 16 contiguous bytes -- one load in the pass
     int head, H, Hcap;    // H counts the current sample
+    int HcapT;            // row length of ring_vT
     double dt_hint;       // t - previous sample time (bracket-search hint only, > 0)
 };
 
@@ -184,8 +187,8 @@ struct FinalizeArgs {
     int do_push, head, D;
     double* ring_t;
     double* ring_v;
-    double* ring_vT;  // [D][Hcap] transposed copy
-    int Hcap;
+    double* ring_vT;  // [D][HcapT] transposed copy (entry [Hcap] mirrors slot 0)
+    int Hcap, HcapT;
 };
 
 // scatter_kernel: y_s[row] = width[s] * sum_col K[row, s*D + col] * v[col] for s in [s_lo, s_lo + ns); one workgroup per
@@ -239,8 +242,8 @@ void launch_added_mass_mv_tagged(const double* d_M, int rows, int cols, const do
                                  unsigned long long* d_tagged, unsigned long long seq, hipStream_t stream);
 // out[(row*D + col)*S + s] = K[row][s*D + col]  (reference indexing; diagnostics)
 void launch_unrelayout(const Panel& K, int Dloc, int D, int S, double* d_out, hipStream_t stream);
-// ring_vT[col][slot] = ring_v[slot][col] for all slots (after the ring has been re-allocated or injected)
-void launch_ring_transpose(const double* d_ring_v, int Hcap, int D, double* d_ring_vT, hipStream_t stream);
+// ring_vT[col][slot] = ring_v[slot][col] for all slots, ring_vT[col][Hcap] = ring_v[0][col] (after the ring has been re-allocated or injected)
+void launch_ring_transpose(const double* d_ring_v, int Hcap, int HcapT, int D, double* d_ring_vT, hipStream_t stream);
 // synthetic many-body coefficient generator: fills the whole panel matrix (padding = 0)
 void launch_synth_rirf(double* d_K, int ntiles, int ngp, int Dloc, int D, int S, int row0, double dt, unsigned long long seed, double rho,
                        hipStream_t stream);

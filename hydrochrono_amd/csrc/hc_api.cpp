@@ -540,6 +540,7 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
     b.partials    = c->d_partials_block.p;
     b.Dpad        = c->Dpad;
     b.error_flag  = c->d_err.p;
+    b.item_counter = c->d_err.p + 1;
     b.ngroups     = c->ntiles / c->mt_block;
     // algorithmic bytes: summed over the steps of the block, step j's share of K and of the velocity vector from s_cut[j]
     // on ...; what the launch has to move once: the live part of K, Kex and the staged vectors
@@ -563,7 +564,7 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
     hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_once / std::max(1.0, rad_once + exc_once));
     hc::launch_conv_block(b, c->mt_block, stream);
     ev_end(ev, stream);
-    hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, stream);
+    hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter, stream);
 }
 
 // Enqueue the kernels of one evaluation at time t.  d_state: device-visible pointer to the 12N state.  d_user_out
@@ -1146,8 +1147,8 @@ int hc_finalize(hc_ctx* c) {
     c->d_waves.alloc(c->Dloc);
     c->d_total.alloc(c->Dloc);
     for (auto* b : {&c->d_hs, &c->d_rad, &c->d_waves, &c->d_total}) HC_HIP(hipMemsetAsync(b->p, 0, b->n * sizeof(double), c->stream));
-    c->d_err.alloc(1);
-    HC_HIP(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
+    c->d_err.alloc(2);  // [0] error flag of the convolution kernels, [1] work-item counter of the look-ahead pass
+    HC_HIP(hipMemsetAsync(c->d_err.p, 0, 2 * sizeof(int), c->stream));
     c->h_state.alloc(static_cast<size_t>(2) * 12 * c->N);  // two halves used alternately by hc_step, see there
     c->bar_state.alloc(static_cast<size_t>(2) * 12 * c->N);
     if (c->bar_state.host_ok) {

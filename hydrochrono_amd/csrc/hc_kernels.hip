@@ -101,6 +101,8 @@ __device__ __forceinline__ double hist_time(const HistoryView& h, int k) {
 // time(i+1) <= q; i == H-1 means "no older sample" and the IRF step contributes nothing (:604-606).
 __device__ Bracket find_bracket(const HistoryView& h, double q, int* error_flag) {
     int lo = 0, hi = h.H - 1;
+    double newer = 0.0, older = 0.0;
+    bool have = false;  // the two sample times of the bracket are already in registers (one round trip less per table entry)
     if (h.H >= 3) {
         // histories are close to uniformly spaced: try the index the last step size predicts, then fall back
         int gi = (int)((h.t - q) / h.dt_hint) - 1;
@@ -108,7 +110,8 @@ __device__ Bracket find_bracket(const HistoryView& h, double q, int* error_flag)
 #pragma unroll 1
         for (int k = 0; k < 3; ++k, ++gi) {
             if (gi > h.H - 2) break;
-            if (hist_time(h, gi + 1) <= q && (gi == 0 || hist_time(h, gi) > q)) { lo = hi = gi; break; }
+            const double t_o = hist_time(h, gi + 1), t_n = hist_time(h, gi);
+            if (t_o <= q && (gi == 0 || t_n > q)) { lo = hi = gi; newer = t_n; older = t_o; have = true; break; }
         }
     }
     while (lo < hi) {
@@ -118,7 +121,7 @@ __device__ Bracket find_bracket(const HistoryView& h, double q, int* error_flag)
     Bracket b;
     b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
     if (lo >= h.H - 1) return b;
-    const double newer = hist_time(h, lo), older = hist_time(h, lo + 1);
+    if (!have) { newer = hist_time(h, lo); older = hist_time(h, lo + 1); }
     if (q == older) { b.wo = 1.0; b.wn = 0.0; }
     else if (q == newer) { b.wo = 0.0; b.wn = 1.0; }
     else if (q > older && q < newer) {
@@ -789,16 +792,25 @@ __global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs
     else block_rad_stream<MT, (NB > 1) ? 2 : R, NB, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
     // The excitation force depends on time only: its work items over Kex (a fraction of a percent of K) for the predicted times ride
     // at the end of radiation workgroups, so the launch keeps its number of workgroups (grid rounds on the chip).  An item is
-    // (excitation chunk, block of 16 steps, group of MTE row tiles) and takes several microseconds of dependent loads
-    // (free-surface table -> LDS -> MFMA), so the items are dealt one per workgroup across the launch: stacked on a few
-    // workgroups they were a tail of 28 us at C3 that every other CU waited for.
+    // (excitation chunk, block of 16 steps, group of MTE row tiles) and takes about 8 us of dependent loads (free-surface table
+    // -> LDS -> MFMA).  Workgroups take items from a counter as they finish their radiation chunk: the radiation chunks end
+    // over a span of 10-15 us (HBM channels are not perfectly even), so the early finishers absorb the items and the launch
+    // ends with its slowest radiation chunk.  (Stacked on the first 16 workgroups the items were a 28 us tail at C3; dealt one
+    // per workgroup, 8 us.)  Every item writes its own partials, so the result does not depend on who computes it.
     constexpr int MTE = MT > 6 ? 6 : MT;  // row tiles per excitation work item (register budget of the LDS-staged form)
     const int RG      = a.ngroups * (MT / MTE);
     const int n_items = a.nchunks_ex * NB * RG;
-    for (int it = chunk * a.ngroups + grp; it < n_items; it += a.nchunks * a.ngroups) {
-        const int e = it / (NB * RG), rem = it - e * (NB * RG), tb = rem / RG, rg = rem - tb * RG;
-        __syncthreads();  // the reduction buffer of the previous work item aliases the U tiles of this one
-        block_exc_work<MTE>(a, rg, e, 16 * tb, front);
+    if (n_items > 0) {
+        __shared__ int s_item;
+        for (;;) {
+            __syncthreads();  // the reduction buffer of the previous work item aliases the U tiles of the next one
+            if (threadIdx.x == 0) s_item = atomicAdd(a.item_counter, 1);
+            __syncthreads();
+            const int it = s_item;
+            if (it >= n_items) break;
+            const int e = it / (NB * RG), rem = it - e * (NB * RG), tb = rem / RG, rg = rem - tb * RG;
+            block_exc_work<MTE>(a, rg, e, 16 * tb, front);
+        }
     }
 }
 
@@ -856,7 +868,8 @@ __device__ __forceinline__ double lane16_sum(double v) {
 // 16 lanes per output, chunks c = l, l+16, ... (8 loads in flight per lane, adds in ascending chunk order), then a 4-step
 // xor tree.
 __global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restrict__ partials, int nchunks_rad, int nchunks_ex, int Dpad,
-                                                           int depth, double* __restrict__ P, double* __restrict__ E) {
+                                                           int depth, double* __restrict__ P, double* __restrict__ E, int* item_counter) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *item_counter = 0;  // the pass that has just finished counted its excitation items here
     const int sub = threadIdx.x & 15;
     const int n   = depth * Dpad;
     int out       = blockIdx.x * 16 + (threadIdx.x >> 4);  // [segment][j*Dpad + row]
@@ -877,11 +890,11 @@ __global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restr
 }
 
 void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_ex, int Dpad, int depth, double* d_P, double* d_E,
-                         hipStream_t stream) {
+                         int* item_counter, hipStream_t stream) {
     const int n    = depth * Dpad;
     const int nblk = (n + 15) / 16;  // n is a multiple of 16, so the excitation segment starts on a workgroup boundary
     hipLaunchKernelGGL(reduce_block_kernel, dim3(nchunks_ex > 0 ? 2 * nblk : nblk), dim3(256), 0, stream, d_partials, nchunks_rad, nchunks_ex,
-                       Dpad, depth, d_P, d_E);
+                       Dpad, depth, d_P, d_E, item_counter);
 }
 
 // ------------------------------------------------------------------------------------------------

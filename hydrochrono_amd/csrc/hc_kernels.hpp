@@ -134,6 +134,7 @@ struct BlockArgs {
     int Dpad;
     int ngroups;
     int* error_flag;
+    int* item_counter;    // excitation work items taken so far in this launch (zero at launch; reset by reduce_block_kernel)
 };
 
 struct FinalizeArgs {
@@ -228,7 +229,7 @@ void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream);
 // P[j][row] = sum over the radiation chunks c of partials[c][j][row], E[j][row] = the same over the excitation chunks
 // (fixed order; nchunks_ex may be 0)
 void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_ex, int Dpad, int depth, double* d_P, double* d_E,
-                         hipStream_t stream);
+                         int* item_counter, hipStream_t stream);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 void launch_scatter(const ScatterArgs& a, hipStream_t stream);
 void launch_taper(const TaperArgs& a, hipStream_t stream);

@@ -96,6 +96,25 @@ __device__ __forceinline__ double hist_time(const HistoryView& h, int k) {
 }
 
 
+// InterpolateVelocity6D weights (src/hydro_forces.cpp:343-371) of query time q inside the bracket (sample lo = newer, lo + 1 = older).
+__device__ __forceinline__ Bracket bracket_weights(const HistoryView& h, double q, int lo, double newer, double older, int* error_flag) {
+    Bracket b;
+    b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
+    if (q == older) { b.wo = 1.0; b.wn = 0.0; }
+    else if (q == newer) { b.wo = 0.0; b.wn = 1.0; }
+    else if (q > older && q < newer) {
+        const double td = newer - older;
+        b.wo = (td != 0.0) ? ((newer - q) / td) : 0.0;
+        b.wn = 1.0 - b.wo;
+    } else {
+        *error_flag = 1;  // "query_time not bracketed by history" (:370)
+        return b;
+    }
+    b.off_older = ((h.head - (lo + 1) + h.Hcap) % h.Hcap) * h.D;
+    b.off_newer = (lo == 0) ? -1 : ((h.head - lo + h.Hcap) % h.Hcap) * h.D;
+    return b;
+}
+
 // AdvanceToBracket + InterpolateVelocity6D weights (src/hydro_forces.cpp:343-381) for a query time q <= h.t against
 // the history whose newest sample (k = 0) is the current state at h.t.  Finds the smallest i in [0, H-2] with
 // time(i+1) <= q; i == H-1 means "no older sample" and the IRF step contributes nothing (:604-606).
@@ -118,23 +137,13 @@ __device__ Bracket find_bracket(const HistoryView& h, double q, int* error_flag)
         const int mid = (lo + hi) >> 1;
         if (hist_time(h, mid + 1) <= q) hi = mid; else lo = mid + 1;
     }
-    Bracket b;
-    b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
-    if (lo >= h.H - 1) return b;
-    if (!have) { newer = hist_time(h, lo); older = hist_time(h, lo + 1); }
-    if (q == older) { b.wo = 1.0; b.wn = 0.0; }
-    else if (q == newer) { b.wo = 0.0; b.wn = 1.0; }
-    else if (q > older && q < newer) {
-        const double td = newer - older;
-        b.wo = (td != 0.0) ? ((newer - q) / td) : 0.0;
-        b.wn = 1.0 - b.wo;
-    } else {
-        *error_flag = 1;  // "query_time not bracketed by history" (:370)
+    if (lo >= h.H - 1) {
+        Bracket b;
+        b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
         return b;
     }
-    b.off_older = ((h.head - (lo + 1) + h.Hcap) % h.Hcap) * h.D;
-    b.off_newer = (lo == 0) ? -1 : ((h.head - lo + h.Hcap) % h.Hcap) * h.D;
-    return b;
+    if (!have) { newer = hist_time(h, lo); older = hist_time(h, lo + 1); }
+    return bracket_weights(h, q, lo, newer, older, error_flag);
 }
 
 // interpolated velocity of column `col` for bracket b (exact copies where the reference returns early).  Branch-free:
@@ -442,6 +451,61 @@ __device__ __forceinline__ void block_exc_work(const BlockArgs& a, const int grp
     }
 }
 
+// Bracket table of a look-ahead work item: entry k*L + j = bracket of (IRF sample s0 + k, block step j), weights already times the
+// trapezoid width.  Every workgroup of the launch builds its table at the same moment, with HBM idle (4 us at C3: kernel arguments ->
+// tau / width / plan rows -> sample times -> LDS, three dependent round trips), so a thread keeps its up to three entries in flight
+// together -- tau / width first, then the two sample times the step-size hint points at; an entry whose hint misses (irregular
+// history) falls back to the search of find_bracket, which gives the same bracket.
+// BYTES: the slot of the older sample as a byte offset inside a row of the per-DoF ring (its newer neighbour follows it), no t_on.
+template <int L, bool BYTES>
+__device__ __forceinline__ void build_block_table(const BlockArgs& a, const int s0, const int ns, const int s_live, double* t_wo, double* t_wn,
+                                                  int* t_oo, int* t_on) {
+    constexpr int NE = 3;
+    const HistoryView& h = a.hist;
+    const int n = ns * L, D = h.D;
+    for (int base = threadIdx.x; base < n; base += NE * kConvThreads) {
+        int gi[NE];
+        bool valid[NE], act[NE];
+        double q[NE], w[NE], t_o[NE], t_n[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = base + e * kConvThreads;
+            valid[e]      = idx < n;
+            const int k = valid[e] ? idx / L : 0, j = valid[e] ? idx - k * L : 0, s = s0 + k;
+            act[e] = valid[e] && s >= a.s_cut[j] && s != a.s_defer[j] && s < s_live;
+            q[e]   = a.tpred[j] - a.tau[act[e] ? s : 0];
+            w[e]   = a.width[s < s_live ? s : 0];
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            int g = (int)((h.t - q[e]) / h.dt_hint) - 1;
+            g     = max(0, min(g, h.H - 2));
+            gi[e] = g;
+            t_o[e] = hist_time(h, g + 1);
+            t_n[e] = hist_time(h, g);
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (!valid[e]) continue;
+            Bracket b;
+            b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
+            if (act[e]) {
+                const bool hit = h.H >= 3 && t_o[e] <= q[e] && (gi[e] == 0 || t_n[e] > q[e]);
+                b = hit ? bracket_weights(h, q[e], gi[e], t_n[e], t_o[e], a.error_flag) : find_bracket(h, q[e], a.error_flag);
+            }
+            const int idx = base + e * kConvThreads;
+            t_wo[idx] = b.wo * w[e];
+            t_wn[idx] = (b.off_newer >= 0) ? b.wn * w[e] : 0.0;
+            if constexpr (BYTES) {
+                t_oo[idx] = (b.off_older / D) * 8;
+            } else {
+                t_oo[idx] = b.off_older / D;          // ring slot of the older sample
+                t_on[idx] = max(b.off_newer, 0) / D;  // ... of the newer one
+            }
+        }
+    }
+}
+
 template <int MT, int R, int NB, bool UNI>
 __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int chunk, const int grp, double* red, double* t_wo, double* t_wn,
                                                  int* t_oo, int* t_on) {
@@ -455,17 +519,7 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
     const int s0  = (gp0 * 8) / D;
     const int ns  = (min(a.F, gp1 * 8) - 1) / D - s0 + 1;
     const int s_live = a.F / D;  // F is a whole number of samples
-    for (int idx = tid; idx < ns * L; idx += kConvThreads) {
-        const int k = idx / L, j = idx - k * L, s = s0 + k;
-        Bracket b;
-        b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
-        if (s >= a.s_cut[j] && s != a.s_defer[j] && s < s_live) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
-        const double w = a.width[s < s_live ? s : 0];
-        t_wo[idx] = b.wo * w;
-        t_wn[idx] = (b.off_newer >= 0) ? b.wn * w : 0.0;
-        t_oo[idx] = b.off_older / D;          // ring slot of the older sample
-        t_on[idx] = max(b.off_newer, 0) / D;  // ... of the newer one
-    }
+    build_block_table<L, false>(a, s0, ns, s_live, t_wo, t_wn, t_oo, t_on);
     __syncthreads();
 
     dvec4 acc[NB][MT];
@@ -633,17 +687,7 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
     const int ns  = (min(a.F, gp1 * 8) - 1) / D - s0 + 1;
     const int s_live = a.F / D;
     const int Hc     = a.hist.HcapT;  // row length of the per-DoF ring
-    for (int idx = tid; idx < ns * L; idx += kConvThreads) {
-        const int k = idx / L, j = idx - k * L, s = s0 + k;
-        Bracket b;
-        b.wo = 0.0; b.wn = 0.0; b.off_older = 0; b.off_newer = 0;
-        if (s >= a.s_cut[j] && s != a.s_defer[j] && s < s_live) b = find_bracket(a.hist, a.tpred[j] - a.tau[s], a.error_flag);
-        const double w = a.width[s < s_live ? s : 0];
-        t_wo[idx] = b.wo * w;
-        t_wn[idx] = (b.off_newer >= 0) ? b.wn * w : 0.0;
-        t_oo[idx] = (b.off_older / D) * 8;  // byte offset of the older sample inside a column of the per-DoF ring; the newer one
-                                            // (ring slot + 1 mod Hcap, or the not-yet-known sample, whose weight is 0) follows it
-    }
+    build_block_table<L, true>(a, s0, ns, s_live, t_wo, t_wn, t_oo, t_on);  // t_oo: byte offset of the older sample in a ring row; the newer one (slot + 1 mod Hcap, or the not-yet-known sample, whose weight is 0) follows it
     __syncthreads();
 
     dvec4 acc[NB][MT];

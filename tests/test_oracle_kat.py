@@ -142,3 +142,66 @@ def test_oracle_analytic_known_answers():
         avail = min(n + 1, S) if n >= 1 else 0
         expect = 1000.0 * 2.0 * (K.reshape(D, D, S)[:, 4, :avail] * w[:avail]).sum(axis=1)
         assert np.max(np.abs(o.components()[1] - expect)) < 1e-9 * max(1.0, np.abs(expect).max())
+
+
+@pytest.mark.parametrize("opts", [
+    dict(),
+    dict(smoothing=1, window_length=7, taper_start_percent=0.5, taper_end_percent=0.9, taper_final_amplitude=0.25),
+    dict(smoothing=1, window_length=4, taper_start_percent=0.3, taper_end_percent=0.3),   # empty taper band: hard cut
+    dict(rirf_end_time=0.93, taper_start_percent=0.6),
+    dict(smoothing=1, window_length=2, rirf_end_time=0.031),                              # 3 effective steps (< 5)
+    dict(rirf_end_time=0.041),                                                            # SG-5 on 4 steps: no smoothing
+])
+def test_tapered_direct_kernel_against_array_formulas(opts):
+    """TaperedDirect preprocessing (src/hydro_forces.cpp:385-535) has no reference data in the snapshot, so the oracle's
+    version is anchored to an independent whole-array statement of the same rules: truncate at floor(end_time / dt), SG-5
+    [-3, 12, 17, 12, -3] / 35 with the two edge samples on either side copied (or a centred moving average over
+    max(3, window) // 2 neighbours, clipped at the ends), half-cosine from floor(p_start * n) to floor(p_end * n), zero after."""
+    from oracle import Oracle
+    rng = np.random.default_rng(17)
+    N, S, dt, rho = 2, 60, 0.01, 1025.0
+    D = 6 * N
+    t = dt * np.arange(S)
+    K = rng.normal(size=(N, 6, D, S)) * np.exp(-t / 0.3)
+    o = Oracle(N)
+    o.set_simulation_parameters(rho, 9.81, 50.0)
+    for b in range(N):
+        o.set_body(b, 1.0, [0, 0, 0], [0, 0, 0], np.zeros((6, 6)), np.zeros((6, D)), t, K[b])
+    o.construct()
+    o.add_waves_none()
+    o.set_convolution_mode(1)
+    o.set_tapered_direct_options(**opts)
+
+    p = dict(smoothing=0, window_length=5, rirf_end_time=-1.0, taper_start_percent=0.8, taper_end_percent=1.0, taper_final_amplitude=0.0)
+    p.update(opts)
+    raw = rho * K.reshape(D, D, S)                         # the accessor scales by rho (src/h5fileinfo.cpp:321-323 via :693-711)
+    n = min(int(np.floor(p["rirf_end_time"] / (t[1] - t[0]))), S) if p["rirf_end_time"] > 0 else S
+    x = raw[:, :, :n]
+    if p["smoothing"] == 1:
+        half = max(3, p["window_length"]) // 2
+        csum = np.concatenate([np.zeros(x.shape[:2] + (1,)), np.cumsum(x, axis=2)], axis=2)
+        lo = np.maximum(0, np.arange(n) - half)
+        hi = np.minimum(n - 1, np.arange(n) + half)
+        sm = (csum[:, :, hi + 1] - csum[:, :, lo]) / (hi - lo + 1)
+    elif n >= 5:
+        sm = x.copy()
+        c = np.array([-3.0, 12.0, 17.0, 12.0, -3.0]) / 35.0
+        sm[:, :, 2:n - 2] = sum(c[k] * x[:, :, k:n - 4 + k] for k in range(5))
+    else:
+        sm = x.copy()
+    i0 = max(0, min(int(np.floor(p["taper_start_percent"] * n)), n))
+    i1 = max(i0, min(int(np.floor(p["taper_end_percent"] * n)), n))
+    wgt = np.zeros(n)
+    wgt[:i0] = 1.0
+    if i1 > i0:
+        tt = (np.arange(i0, i1) - i0) / (i1 - i0)
+        fa = p["taper_final_amplitude"]
+        wgt[i0:i1] = fa + (1.0 - fa) * 0.5 * (1.0 + np.cos(np.pi * tt))
+    expect = np.zeros_like(raw)
+    expect[:, :, :n] = sm * wgt
+    got = np.array([[[o.rirf_val(r, c_, s) for s in range(S)] for c_ in range(D)] for r in range(D)])
+    scale = np.abs(raw).max()
+    assert np.max(np.abs(got - expect)) <= 1e-13 * scale   # moving average: running sums vs direct sums
+    assert np.all(got[:, :, i1:] == 0.0)                   # exactly zero after the taper and beyond the truncation
+    if p["smoothing"] == 0:
+        assert np.array_equal(got[:, :, :min(i0, 2)], raw[:, :, :min(i0, 2)])  # SG-5 copies its edge samples

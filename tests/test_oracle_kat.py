@@ -205,3 +205,172 @@ def test_tapered_direct_kernel_against_array_formulas(opts):
     assert np.all(got[:, :, i1:] == 0.0)                   # exactly zero after the taper and beyond the truncation
     if p["smoothing"] == 0:
         assert np.array_equal(got[:, :, :min(i0, 2)], raw[:, :, :min(i0, 2)])  # SG-5 copies its edge samples
+
+
+@pytest.mark.parametrize("uniform", [False, True])  # True: steps equal to the IRF spacing (query times fall on samples)
+def test_radiation_convolution_against_array_formula(uniform):
+    """Multi-body coupling and true interpolation are not pinned by reference data, so the oracle's radiation term
+    (src/hydro_forces.cpp:537-691: newest-first history, prune to one sample older than t - tau_last, bracket search, linear
+    interpolation, "no older sample -> the IRF step contributes nothing", trapezoid widths) is anchored to an independent
+    whole-array statement: ascending history + searchsorted + one einsum per step.  Three coupled bodies, irregular step
+    sizes between 0.4 and 1.6 IRF spacings, from an empty history through the warm-up into the steady state."""
+    from oracle import Oracle
+    rng = np.random.default_rng(23)
+    N, S, dtr, rho = 3, 40, 0.05, 1000.0
+    D = 6 * N
+    tau = dtr * np.arange(S)
+    w = np.full(S, dtr)
+    w[0] = w[-1] = dtr / 2
+    K = rng.normal(size=(N, 6, D, S)) * np.exp(-tau / 0.7)
+    o = Oracle(N)
+    o.set_simulation_parameters(rho, 9.81, 50.0)
+    for b in range(N):
+        o.set_body(b, 1.0, [0, 0, 0], [0, 0, 0], np.zeros((6, 6)), np.zeros((6, D)), tau, K[b])
+    o.construct()
+    o.add_waves_none()
+    Kw = rho * K.reshape(D, D, S) * w                       # [row][col][s], width folded in
+    times, vels = [], []
+    t = 0.0
+    z = np.zeros(3 * N)
+    worst = 0.0
+    for n in range(140):
+        v = rng.normal(size=D)
+        times.append(t)
+        vels.append(v)
+        lv = v.reshape(N, 6)[:, :3].ravel()
+        av = v.reshape(N, 6)[:, 3:].ravel()
+        o.step(t, z, z, lv, av)
+        got = o.components()[1]
+        # retained history, ascending: everything from the last sample older than t - tau_last on (all of it if there is none)
+        ta = np.array(times)
+        older = np.nonzero(ta < t - tau[-1])[0]
+        first = older[-1] if len(older) else 0
+        ta, va = ta[first:], np.array(vels)[first:]
+        expect = np.zeros(D)
+        if len(ta) >= 2:
+            q = t - tau                                     # query time of every IRF sample
+            hi = np.searchsorted(ta, q, side="left")        # first retained sample at or after q ...
+            hi = np.where((hi < len(ta)) & (ta[np.minimum(hi, len(ta) - 1)] == q), hi + 1, hi)  # ... an exact hit is the OLDER end
+            hi = np.minimum(hi, len(ta) - 1)
+            lo = hi - 1
+            ok = lo >= 0                                    # an older sample exists
+            lo_c = np.maximum(lo, 0)
+            span = ta[hi] - ta[lo_c]
+            wo = np.where(span != 0.0, (ta[hi] - q) / np.where(span != 0.0, span, 1.0), 0.0)
+            U = wo[:, None] * va[lo_c] + (1.0 - wo)[:, None] * va[hi]
+            U[~ok] = 0.0
+            expect = np.einsum("rcs,sc->r", Kw, U)
+        scale = max(1.0, np.abs(expect).max())
+        worst = max(worst, float(np.abs(got - expect).max() / scale))
+        t += dtr * (1.0 if uniform else rng.uniform(0.4, 1.6))
+    assert worst < 1e-12
+
+
+def test_hydrostatics_and_regular_wave_against_array_formulas():
+    """Rotations, torques and the multi-body regular-wave term have no reference data either.  Whole-array statements of
+    ComputeForceHydrostatics (src/hydro_forces.cpp:263-322: -rho |g_sys| K_hs dq + rho (-g_sys) V + (cb - cg) x that, g from the
+    system, rho from the file) and RegularWave (src/wave_types.cpp:278-352: d_omega = omega_max / n, index = omega / d_omega - 1,
+    linear interpolation, and the phase of BODY 0 for every body, :323) against the oracle, three bodies, tilted gravity."""
+    from oracle import Oracle
+    rng = np.random.default_rng(29)
+    N, S, rho, g_file = 3, 8, 1030.0, 9.81
+    D = 6 * N
+    tau = 0.05 * np.arange(S)
+    o = Oracle(N)
+    o.set_simulation_parameters(rho, g_file, 80.0)
+    lin = rng.normal(size=(N, 6, 6))
+    vol = rng.uniform(50, 300, size=N)
+    cg = rng.normal(size=(N, 3))
+    cb = cg + rng.normal(size=(N, 3)) * 0.3
+    nw = 30
+    wl = 0.2 * np.arange(1, nw + 1)                         # uniform list starting at d_omega, as BEMIO writes it
+    mag = rng.uniform(0.5, 2.0, size=(N, 6, nw))
+    ph = rng.uniform(-3, 3, size=(N, 6, nw))
+    for b in range(N):
+        o.set_body(b, vol[b], cg[b], cb[b], lin[b], np.zeros((6, D)), tau, np.zeros((6, D, S)))
+        o.set_body_excitation_rao(b, wl, mag[b], ph[b])
+    o.construct()
+    gsys = np.array([0.7, -0.4, -9.6])                      # the system's gravity, not the file's
+    o.set_gravity(gsys)
+    amp, omega = 0.8, 2.37
+    o.add_waves_regular(amp, omega)
+    dw = wl[-1] / nw
+    idx = omega / dw - 1
+    k0, fr = int(np.floor(idx)), idx - np.floor(idx)
+    m_i = rho * g_file * (mag[:, :, k0] + fr * (mag[:, :, k0 + 1] - mag[:, :, k0]))      # magnitudes are scaled by rho g at read
+    p_i = ph[:, :, k0] + fr * (ph[:, :, k0 + 1] - ph[:, :, k0])
+    z = np.zeros(3 * N)
+    for n in range(12):
+        t = 0.37 * n
+        pos = cg + rng.normal(size=(N, 3)) * 0.5
+        rpy = rng.normal(size=(N, 3)) * 0.2
+        o.step(t, pos.ravel(), rpy.ravel(), z, z)
+        hs, rad, wv = o.components()
+        dq = np.concatenate([pos - cg, rpy], axis=1)        # equilibrium rotations are zero (:208-216)
+        fb = rho * (-gsys)[None, :] * vol[:, None]
+        e_hs = -rho * np.linalg.norm(gsys) * np.einsum("bij,bj->bi", lin, dq)
+        e_hs[:, :3] += fb
+        e_hs[:, 3:] += np.cross(cb - cg, fb)
+        e_wv = m_i * amp * np.cos(omega * t + p_i[0][None, :])   # body-0 phases for every body
+        assert np.max(np.abs(hs - e_hs.ravel())) <= 1e-12 * np.abs(e_hs).max()
+        assert np.max(np.abs(wv - e_wv.ravel())) <= 1e-12 * np.abs(e_wv).max()
+        assert np.all(rad == 0.0)
+
+
+def test_irregular_excitation_and_eta_against_array_formulas():
+    """Multi-body excitation-IRF convolution (src/wave_types.cpp:776-844) and the free-surface table (:717-774, :14-59) as
+    whole-array statements: eta(t) = sum_i sqrt(2 S_i df_i) cos(-2 pi f_i t + phi_i) on the oracle's own grid, ramp 0 for
+    t <= 0 and t / ramp below the ramp time, and f[6b + d] = sum_j Kex_b[d, j] w_j eta(t - tau_j) with eta linearly
+    interpolated.  The spectrum, phases and the resampled IRF themselves are pinned elsewhere (goldens, scipy)."""
+    from oracle import Oracle
+    rng = np.random.default_rng(31)
+    N, S = 3, 8
+    D = 6 * N
+    tau = 0.05 * np.arange(S)
+    o = Oracle(N)
+    o.set_simulation_parameters(1000.0, 9.81, 60.0)
+    n_ex = 81
+    t_ex = 0.1 * (np.arange(n_ex) - (n_ex - 1) / 2)
+    for b in range(N):
+        o.set_body(b, 1.0, [0, 0, 0], [0, 0, 0], np.zeros((6, 6)), np.zeros((6, D)), tau, np.zeros((6, D, S)))
+        o.set_body_excitation_irf(b, t_ex, rng.normal(size=(6, n_ex)) * np.exp(-(t_ex / 1.5) ** 2))
+    o.construct()
+    ramp = 3.0
+    o.add_waves_irregular(0.04, 12.0, ramp_duration=ramp, wave_height=1.8, wave_period=7.0, frequency_min=0.04, frequency_max=0.7,
+                          nfrequencies=37, peak_enhancement_factor=2.5, seed=5)
+    sp = o.irreg_spectrum()
+    et, ee = o.irreg_eta()
+    amp = np.sqrt(2.0 * sp["S"] * sp["df"])
+    raw = (amp[None, :] * np.cos(-2.0 * np.pi * sp["f"][None, :] * et[:, None] + sp["phase"][None, :])).sum(axis=1)
+    fac = np.where(et <= 0.0, 0.0, np.where(et < ramp, et / ramp, 1.0))
+    assert np.max(np.abs(ee - raw * fac)) <= 1e-12 * np.abs(raw).max()
+    irf = [o.irreg_irf(b) for b in range(N)]
+    z = np.zeros(3 * N)
+    for n in range(25):
+        t = 0.4 * n + 0.013
+        o.step(t, z, z, z, z)
+        wv = o.components()[2]
+        expect = np.concatenate([(v * (w * np.interp(t - tj, et, ee))[None, :]).sum(axis=1) for tj, w, v in irf])
+        assert np.max(np.abs(wv - expect)) <= 1e-12 * max(1.0, np.abs(expect).max())
+
+
+def test_added_mass_against_array_formula():
+    """ChLoadAddedMass (src/chloadaddedmass.cpp:12-70): M = stacked rho * A_inf blocks in the top-left D x D corner of the system
+    matrix, R += c * M * w on the first D coordinates, the rest untouched."""
+    from oracle import Oracle
+    rng = np.random.default_rng(37)
+    N, S, rho = 4, 4, 1025.0
+    D = 6 * N
+    tau = 0.1 * np.arange(S)
+    A = rng.normal(size=(N, 6, D))
+    o = Oracle(N)
+    o.set_simulation_parameters(rho, 9.81, 30.0)
+    for b in range(N):
+        o.set_body(b, 1.0, [0, 0, 0], [0, 0, 0], np.zeros((6, 6)), A[b], tau, np.zeros((6, D, S)))
+    o.construct()
+    M = rho * A.reshape(D, D)
+    assert np.array_equal(o.added_mass_matrix(), M)
+    R0, w = rng.normal(size=D + 9), rng.normal(size=D + 9)  # a system with nine more coordinates behind the hydro bodies
+    R = o.added_mass_mv(R0, w, -0.35)
+    assert np.max(np.abs(R[:D] - (R0[:D] - 0.35 * M @ w[:D]))) <= 1e-12 * np.abs(M @ w[:D]).max()
+    assert np.array_equal(R[D:], R0[D:])

@@ -10,9 +10,11 @@
 //
 // Parity status: PINNED for single-body heave against the reference's own golden trajectories
 // (tests/golden/sphere_goldens.npz <- tests/regression/reference_data/sphere/**): decay,
-// regular waves 1/5/10, irregular waves.  UNPINNED (no reference data available: rm3/oswec/
-// f3of/deepcwind .h5 are missing blobs) for multi-body coupling, rotations/torques and
-// TaperedDirect; those are covered by analytic known-answer tests only.
+// all ten regular-wave cases, irregular waves (tests/test_oracle_golden.py).  UNPINNED (no
+// reference data available: rm3/oswec/f3of/deepcwind .h5 are missing blobs) for multi-body
+// coupling, rotations/torques and TaperedDirect; there the loops below are anchored to
+// independent whole-array numpy statements of the same rules and to analytic known answers
+// (tests/test_oracle_kat.py).
 //
 // Every function cites the reference file:line (relative to /root/reference) it restates.
 // Third-party arithmetic restated here because the libraries are absent from the container:

@@ -1,6 +1,7 @@
 """Build recipe for the native libraries (hipcc, gfx950 only).  Used by __graft_entry__.build() and `python -m hydrochrono_amd.build`.
 
   hydrochrono_amd/lib/libhydrochrono_amd.so   C ABI + HIP kernels (include/hydrochrono_amd.h)
+  hydrochrono_amd/lib/hc_kernels.co           the kernels as a stand-alone gfx950 code object (direct AQL dispatch of the step path)
   hydrochrono_amd/lib/libhc_bemio.so          optional BEMIO-HDF5 reader (only where libhdf5 is installed)
 """
 import os
@@ -15,8 +16,9 @@ LIBDIR = os.path.join(PKG, "lib")
 MAIN_LIB = os.path.join(LIBDIR, "libhydrochrono_amd.so")
 BEMIO_LIB = os.path.join(LIBDIR, "libhc_bemio.so")
 
-SOURCES = ["hc_kernels.hip", "hc_api.cpp", "hc_host_math.cpp", "hc_yaml.cpp", "hc_eta_fft.cpp"]
-HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_host_math.hpp", "hc_limits.hpp", "hc_plan.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h"),
+SOURCES = ["hc_kernels.hip", "hc_api.cpp", "hc_direct.cpp", "hc_host_math.cpp", "hc_yaml.cpp", "hc_eta_fft.cpp"]
+KERNEL_CO = os.path.join(LIBDIR, "hc_kernels.co")  # the same kernels as a stand-alone code object, for the direct AQL dispatch (hc_direct.hpp)
+HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_host_math.hpp", "hc_limits.hpp", "hc_plan.hpp", "hc_direct.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h"),
            os.path.join(ROOT, "include", "hydrochrono_amd_host.h"), os.path.join(ROOT, "include", "hydrochrono_amd_yaml.h")]
 
 
@@ -52,7 +54,15 @@ def build(force=False, verbose=False):
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     if force or _newer(MAIN_LIB, deps):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-               "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")] + srcs + ["-o", MAIN_LIB, "-ldl", "-lrocfft"]
+               "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")] + srcs + ["-o", MAIN_LIB, "-ldl", "-lrocfft",
+                                                                                              "-lhsa-runtime64"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    kernel_src = os.path.join(CSRC, "hc_kernels.hip")
+    if force or _newer(KERNEL_CO, [kernel_src] + [d for d in deps if d.endswith((".hpp", ".h"))]):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "--no-gpu-bundle-output", "-Wno-unused-result",
+               "-I", os.path.join(ROOT, "include"), kernel_src, "-o", KERNEL_CO]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -60,10 +60,16 @@ thread_local std::string g_create_error;
 
 const char* kVersion = "hydrochrono_amd 0.1 (gfx950)";
 
-#define HC_API_BEGIN(ctx)                                    \
+#define HC_API_BEGIN_HOT(ctx)                                \
     if (!(ctx)) return HC_ERR_INVALID;                       \
     try {                                                    \
         HC_HIP(hipSetDevice((ctx)->device));
+
+// every entry point but the per-step ones first waits for what the direct queue still runs (hc_direct.hpp): their HIP work is
+// not ordered against it
+#define HC_API_BEGIN(ctx)                                    \
+    HC_API_BEGIN_HOT(ctx)                                    \
+    quiesce_direct(ctx);
 
 #define HC_API_END(ctx)                                      \
     }                                                        \
@@ -80,6 +86,11 @@ const char* kVersion = "hydrochrono_amd 0.1 (gfx950)";
         return HC_ERR_RUNTIME;                               \
     }                                                        \
     return HC_OK;
+
+void quiesce_direct(hc_ctx* c) {
+    if (c->dq && c->dq->busy()) c->dq->drain();
+    if (c->path == 2) c->path = 1;
+}
 
 void require(bool cond, int status, const char* msg) {
     if (!cond) throw Error(status, msg);
@@ -153,42 +164,48 @@ int history_push(hc_ctx* c, double t) {
 // ---- profiling --------------------------------------------------------------------------------
 // Timed launches carry their own pair of HIP events, recorded on the stream the launch went to (a caller's stream in
 // hc_step_device), so the drain waits on the events themselves, not on a particular stream.
+void profile_account(hc_ctx* c, int kind, double sec, double waves_share) {
+    switch (kind) {
+        case hc::kEvConvPlain:  // radiation (+ irregular-wave excitation chunks) of a plain step
+            c->prof.conv_kernel_seconds += sec;
+            c->prof.conv_kernel_launches += 1;
+            c->prof.radiation_seconds += sec * (1.0 - waves_share);
+            c->prof.waves_seconds += sec * waves_share;
+            break;
+        case hc::kEvPass:  // look-ahead pass: radiation part of a block of steps (+ their excitation force)
+            c->prof.block_kernel_seconds += sec;
+            c->prof.block_kernel_launches += 1;
+            c->prof.radiation_seconds += sec * (1.0 - waves_share);
+            c->prof.waves_seconds += sec * waves_share;
+            break;
+        case hc::kEvStep:  // the step kernel: reduction, own-sample part, hydrostatics, regular / spectral wave term
+            c->prof.step_kernel_seconds += sec;
+            c->prof.step_kernel_launches += 1;
+            c->prof.hydrostatics_seconds += sec;
+            break;
+        case hc::kEvScatter:
+            c->prof.scatter_kernel_seconds += sec;
+            c->prof.scatter_kernel_launches += 1;
+            c->prof.radiation_seconds += sec;
+            break;
+        default:  // excitation-only convolution launch
+            c->prof.waves_seconds += sec;
+            break;
+    }
+}
+
 void profile_drain(hc_ctx* c) {
     for (size_t i = 0; i < c->events_used; ++i) {
         hc::EventPair& ev = c->events[i];
         HC_HIP(hipEventSynchronize(ev.b));
         float ms = 0;
         HC_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
-        const double sec = ms * 1e-3;
-        switch (ev.kind) {
-            case hc::kEvConvPlain:  // radiation (+ irregular-wave excitation chunks) of a plain step
-                c->prof.conv_kernel_seconds += sec;
-                c->prof.conv_kernel_launches += 1;
-                c->prof.radiation_seconds += sec * (1.0 - ev.waves_share);
-                c->prof.waves_seconds += sec * ev.waves_share;
-                break;
-            case hc::kEvPass:  // look-ahead pass: radiation part of a block of steps (+ their excitation force)
-                c->prof.block_kernel_seconds += sec;
-                c->prof.block_kernel_launches += 1;
-                c->prof.radiation_seconds += sec * (1.0 - ev.waves_share);
-                c->prof.waves_seconds += sec * ev.waves_share;
-                break;
-            case hc::kEvStep:  // the step kernel: reduction, own-sample part, hydrostatics, regular / spectral wave term
-                c->prof.step_kernel_seconds += sec;
-                c->prof.step_kernel_launches += 1;
-                c->prof.hydrostatics_seconds += sec;
-                break;
-            case hc::kEvScatter:
-                c->prof.scatter_kernel_seconds += sec;
-                c->prof.scatter_kernel_launches += 1;
-                c->prof.radiation_seconds += sec;
-                break;
-            default:  // excitation-only convolution launch
-                c->prof.waves_seconds += sec;
-                break;
-        }
+        profile_account(c, ev.kind, ms * 1e-3, ev.waves_share);
     }
     c->events_used = 0;
+    // dispatches of the direct queue carry completion signals instead of events
+    if (c->dq && c->dq->timed_pending() > 0)
+        c->dq->collect([c](int kind, double sec, double share) { profile_account(c, kind, sec, share); });
 }
 
 constexpr size_t kEventPoolMax = 4096;
@@ -199,7 +216,7 @@ constexpr size_t kEventPoolMax = 4096;
 void profile_begin_step(hc_ctx* c) {
     c->sample_this_step = false;
     if (!c->profiling) return;
-    if (c->events_used + 8 > kEventPoolMax) profile_drain(c);
+    if (c->events_used + 8 > kEventPoolMax || (c->dq && c->dq->timed_pending() + 8 > kEventPoolMax)) profile_drain(c);
     c->sample_this_step = (c->profile_counter++ % c->profile_stride) == 0;
 }
 
@@ -219,6 +236,9 @@ hc::EventPair* ev_begin(hc_ctx* c, int kind, hipStream_t stream, double waves_sh
     HC_HIP(hipEventRecord(ev->a, stream));
     return ev;
 }
+// direct dispatches: the tag to time a launch with (-1: not timed), same sampling rule as ev_begin
+int direct_tag(const hc_ctx* c, int kind) { return (c->profiling && (c->sample_this_step || kind == hc::kEvPass)) ? kind : -1; }
+
 void ev_end(hc::EventPair* ev, hipStream_t stream) {
     if (ev) HC_HIP(hipEventRecord(ev->b, stream));
 }
@@ -487,7 +507,7 @@ StepViews make_views(const hc_ctx* c) {
 // The look-ahead pass of the plan just made: for the 16 predicted steps, what the samples known now contribute.  It runs as
 // the plain pass of a (virtual) step at tgrid[1] whose own sample is zero -- that sample's share is added later by the
 // step itself and by its scatter.  Enqueued behind the step that has just been evaluated (its ring push included).
-void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
+void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = false) {
     auto& pl = c->plan;
     const int L = c->lookahead;
     const int H = static_cast<int>(c->times.size());
@@ -561,7 +581,25 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc) {
         for (int i = 1; i <= L; ++i) std::fprintf(stderr, " [%d,%d]", pl.scat_lo[i], pl.scat_hi[i]);
         std::fprintf(stderr, "\n");
     }
-    hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_once / std::max(1.0, rad_once + exc_once));
+    const double exc_share = exc_once / std::max(1.0, rad_once + exc_once);
+    if (direct) {
+        hc::BlockArgs b2;
+        const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_block, &b2);
+        if (l.nblocks <= 0) return;
+        c->dq->dispatch(L == 32 ? c->dk_block32 : c->dk_block16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
+                        direct_tag(c, hc::kEvPass), exc_share);
+        struct ReduceArgs {  // reduce_block_kernel's arguments as the kernel lays them out
+            const double* partials;
+            int nchunks_rad, nchunks_ex, Dpad, depth;
+            double *P, *E;
+            int* item_counter;
+        } r{c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter};
+        static_assert(sizeof(ReduceArgs) == 48, "kernarg layout of reduce_block_kernel");
+        const int nblk = (L * c->Dpad + 15) / 16;
+        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(b.nchunks_ex > 0 ? 2 * nblk : nblk), 256, 0, &r, sizeof r);
+        return;
+    }
+    hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_share);
     hc::launch_conv_block(b, c->mt_block, stream);
     ev_end(ev, stream);
     hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter, stream);
@@ -621,6 +659,19 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
 
     // plain step: all live columns of K, plus the excitation chunks unless a pass has left the excitation force
     int nchunks_rad = 0, nchunks_ex = (run_exc && !E_row) ? c->nchunks_ex : 0;
+    // Where this step's kernels go: the direct queue (hc_direct.hpp) when the step comes from hc_step and needs no plain
+    // convolution launch -- the steady state of a look-ahead run -- else the HIP stream.  Nothing orders the two against each
+    // other on the device, so the side that was used last is drained at a switch.
+    const bool direct = c->direct_ready && host_tagged && stream == c->stream && !f.scratch_out && !((run_rad && !block) || nchunks_ex > 0);
+    if (direct && c->path != 2) {
+        if (c->have_last_stream && c->last_stream != c->stream) HC_HIP(hipDeviceSynchronize());  // the last step ran on a caller's stream
+        else HC_HIP(hipStreamSynchronize(c->stream));
+        c->bg_pending = false;
+        c->path       = 2;
+    } else if (!direct) {
+        quiesce_direct(c);
+        c->path = 1;
+    }
     if ((run_rad && !block) || nchunks_ex > 0) {
         hc::HistoryView hv{};
         hv.state   = d_state;
@@ -748,7 +799,10 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     z.ring_vT       = c->d_ring_vT.p;
     z.Hcap          = c->Hcap;
     z.HcapT         = c->HcapT;
-    {
+    if (direct) {
+        const hc::FinalizeLaunch l = hc::finalize_launch_config(z);
+        c->dq->dispatch(c->dk_finalize, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &z, sizeof z, direct_tag(c, hc::kEvStep));
+    } else {
         hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
         hc::launch_finalize(z, stream);
         ev_end(ev, stream);
@@ -789,14 +843,19 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
                     sa.tgt_coef[si][t] = pl.tgt_coef[m][s_][t];
                 }
             }
-            hc::EventPair* ev = ev_begin(c, hc::kEvScatter, bs);
-            hc::launch_scatter(sa, bs);
-            ev_end(ev, bs);
+            if (direct) {
+                c->dq->dispatch(c->dk_scatter, static_cast<uint32_t>(sa.K.ntiles * sa.ns), 256, static_cast<uint32_t>(sa.D * sizeof(double)), &sa, sizeof sa,
+                                direct_tag(c, hc::kEvScatter));
+            } else {
+                hc::EventPair* ev = ev_begin(c, hc::kEvScatter, bs);
+                hc::launch_scatter(sa, bs);
+                ev_end(ev, bs);
+            }
         } else if (plan_now) {
             if (block) c->plan.misses = 0;  // a block was consumed completely
             if (make_plan(c)) {
                 to_background();
-                launch_pass(c, bs, f.waves);
+                launch_pass(c, bs, f.waves, direct);
             }
         }
         if (bs != stream) {
@@ -867,6 +926,68 @@ void stage_state(hc_ctx* c, const double* pos, const double* rpy, const double* 
     HC_HIP(hipMemcpyAsync(c->d_state.p, h, 4 * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
 }
 
+std::string library_dir() {
+    Dl_info info;
+    std::string dir = ".";
+    if (dladdr(reinterpret_cast<void*>(&hc_version), &info) && info.dli_fname) {
+        std::string full(info.dli_fname);
+        const size_t slash = full.find_last_of('/');
+        if (slash != std::string::npos) dir = full.substr(0, slash);
+    }
+    return dir;
+}
+
+// Direct AQL dispatch for the synchronous step path (hc_direct.hpp).  Optional: when anything it needs is missing -- the code
+// object next to the library, a host-addressable BAR, one of the kernels of this configuration -- the HIP launches stay in use
+// and hc_last_error-style diagnostics keep the reason (HC_DEBUG_PLAN prints it).  Still the GPU path either way.
+void setup_direct(hc_ctx* c) {
+    c->direct_ready = false;
+    if (env_int("HC_DIRECT", 1) == 0) { c->direct_why = "disabled by HC_DIRECT=0"; return; }
+    if (std::getenv("HC_BLOCK_V32")) { c->direct_why = "HC_BLOCK_V32 selects a tuning variant of the pass"; return; }
+    if (c->D >= 1536) { c->direct_why = "wide system: its step kernel variant needs scratch memory"; return; }
+    if (!c->bar_state.host_ok) { c->direct_why = "the device's memory is not host-addressable"; return; }
+    std::unique_ptr<hc::DirectQueue> q(new hc::DirectQueue);
+    std::string why;
+    if (!q->init(c->device, library_dir() + "/hc_kernels.co", &why)) { c->direct_why = why; return; }
+    c->dk_finalize = q->find("finalize_kernelILi4EEEv");
+    c->dk_scatter  = q->find("scatter_kernelE");
+    c->dk_reduce   = q->find("reduce_block_kernelE");
+    for (int depth : {16, 32}) {
+        hc::BlockArgs a{}, b{};
+        a.depth = depth;
+        a.ngroups = 1;
+        const hc::BlockLaunch l = hc::block_launch_config(a, c->mt_block, &b);
+        char frag[96];
+        std::snprintf(frag, sizeof frag, "conv_block_kernelILi%dELi%dELi%dELi%dEEEv", l.MT, l.R, l.NB, l.WPS);
+        (depth == 16 ? c->dk_block16 : c->dk_block32) = q->find(frag);
+    }
+    if (!c->dk_finalize.ok() || !c->dk_scatter.ok() || !c->dk_reduce.ok() || !c->dk_block16.ok() || !c->dk_block32.ok()) {
+        c->direct_why = "a kernel of this configuration is missing from hc_kernels.co";
+        return;
+    }
+    if (c->dk_finalize.priv || c->dk_scatter.priv || c->dk_reduce.priv || c->dk_block16.priv || c->dk_block32.priv) {
+        c->direct_why = "a kernel needs scratch memory";
+        return;
+    }
+    // self-test: one dispatch of the reduction kernel with nothing to add must clear a marked word of P
+    const double mark = 1.0;
+    HC_HIP(hipMemcpy(c->d_P.p, &mark, sizeof mark, hipMemcpyHostToDevice));
+    struct { const double* partials; int a, b, Dpad, depth; double *P, *E; int* counter; } r{c->d_partials_block.p, 0, 0, c->Dpad, 1, c->d_P.p, c->d_E.p, c->d_err.p + 1};
+    q->dispatch(c->dk_reduce, static_cast<uint32_t>((c->Dpad + 15) / 16), 256, 0, &r, sizeof r);
+    if (!q->drain(2.0)) {
+        c->direct_why = "self-test of the direct dispatch timed out";
+        (void)q.release();  // a queue with a dispatch that never completed is left alone
+        return;
+    }
+    double back = -1.0;
+    HC_HIP(hipMemcpy(&back, c->d_P.p, sizeof back, hipMemcpyDeviceToHost));
+    if (back != 0.0) { c->direct_why = "self-test of the direct dispatch failed"; return; }
+    c->dq           = q.release();
+    c->direct_ready = true;
+    c->direct_why.clear();
+    if (env_int("HC_DEBUG_PLAN", 0) != 0) std::fprintf(stderr, "[hc] direct AQL dispatch in use for the step path\n");
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -929,6 +1050,8 @@ int hc_create(int num_bodies, int device_id, hc_ctx** out) { return hc_create_sh
 void hc_destroy(hc_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    delete ctx->dq;  // drains its queue
+    ctx->dq = nullptr;
     (void)hipDeviceSynchronize();  // steps may still be running on a caller's stream; the buffers go away below
     for (auto& ev : ctx->events) {
         (void)hipEventDestroy(ev.a);
@@ -1189,6 +1312,7 @@ int hc_finalize(hc_ctx* c) {
     c->prof.block_kernel_bytes = hc::kLookahead * c->prof.conv_kernel_bytes;
     c->plan                    = hc::Plan{};
     HC_HIP(hipStreamSynchronize(c->stream));
+    setup_direct(c);
     c->finalized = true;
     HC_API_END(c)
 }
@@ -1476,6 +1600,11 @@ void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long lo
         while (g[2 * r + 1] != seq) {
             __builtin_ia32_pause();
             if ((++spins & 0x3FFFF) == 0) {
+                if (c->path == 2 && stream == c->stream) {
+                    // the step went to the direct queue: there is no stream to ask; a dispatch that never completes is a lost device
+                    if (spins > (1ull << 34)) throw Error(HC_ERR_DEVICE, "hc_step: the step's results did not arrive (direct queue)");
+                    continue;
+                }
                 const hipError_t q = hipStreamQuery(stream);
                 if (q == hipSuccess) {
                     if (g[2 * r + 1] != seq) throw Error(HC_ERR_DEVICE, "hc_step: the stream drained but the step's results did not arrive");
@@ -1493,7 +1622,7 @@ void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long lo
 }  // namespace
 
 int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel, double* force_out) {
-    HC_API_BEGIN(c)
+    HC_API_BEGIN_HOT(c)
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(pos && rpy && linvel && angvel && force_out, HC_ERR_INVALID, "null pointer");
     if (c->have_prev && t == c->prev_time) {  // src/hydro_forces.cpp:742-744
@@ -1502,6 +1631,7 @@ int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const dou
     }
     if (c->have_prev_device && t == c->prev_time_device) {
         // this time was evaluated through hc_step_device (possibly on a caller's stream): fetch its totals, do not re-evaluate
+        quiesce_direct(c);
         HC_HIP(hipDeviceSynchronize());
         HC_HIP(hipMemcpy(c->last_total.data(), c->d_total.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost));
         c->prev_time = t;
@@ -1548,7 +1678,10 @@ int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const dou
     const unsigned long long seq = ++c->seq;
     enqueue_step(c, t, d_state, nullptr, c->stream, StepFlags{}, c->h_tag.dp, seq);
     wait_tagged(c, c->h_tag.p, seq, c->stream, c->last_total.data());
-    if (c->device_errors_possible) check_device_flag(c);
+    if (c->device_errors_possible) {
+        quiesce_direct(c);
+        check_device_flag(c);
+    }
     c->prev_time_device = t;  // finalize_kernel has left the same totals in d_total: hc_step_device at this time copies them
     c->have_prev_device = true;
     std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
@@ -1724,7 +1857,7 @@ int hc_added_mass_matrix(hc_ctx* c, double* M) {
 }
 
 int hc_added_mass_mv(hc_ctx* c, const double* w, double cc, double* R, int n_sys) {
-    HC_API_BEGIN(c)
+    HC_API_BEGIN_HOT(c)  // own stream, own buffers: independent of whatever the step queues still run
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(w && R, HC_ERR_INVALID, "null pointer");
     require(n_sys >= c->D, HC_ERR_INVALID, "system has fewer coordinates than the added-mass block");

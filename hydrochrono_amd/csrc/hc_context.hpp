@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/hydrochrono_amd.h"
+#include "hc_direct.hpp"
 #include "hc_kernels.hpp"
 #include "hc_plan.hpp"
 
@@ -129,6 +130,14 @@ struct hc_ctx {
     // stream the last step's kernels went to: a step on another stream is ordered behind it with an event
     hipStream_t last_stream = nullptr;
     bool have_last_stream   = false;
+    // Direct AQL dispatch of the synchronous step path (hc_direct.hpp): the step kernel, scatter, pass and its reduction go to a
+    // queue of our own when hc_step runs a step that needs no plain convolution launch.  path: where the kernels of the last
+    // step went (0 nothing yet, 1 HIP stream(s), 2 direct queue); the other side is drained at every switch.
+    hc::DirectQueue* dq = nullptr;
+    bool direct_ready   = false;
+    std::string direct_why;  // why the direct path is not in use
+    int path            = 0;
+    hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32;
     int busy_caller_steps   = 0;  // hc_step_device: steps left before the caller's stream is queried again (see enqueue_step)
     std::string err;
 

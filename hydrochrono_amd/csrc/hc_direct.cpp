@@ -1,0 +1,302 @@
+// hc_direct.cpp -- see hc_direct.hpp.
+#include "hc_direct.hpp"
+
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <unistd.h>
+#include <xmmintrin.h>
+
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <vector>
+
+namespace hc {
+
+namespace {
+
+struct KernelEntry {
+    std::string name;
+    DirectKernel k;
+};
+
+struct AgentPick {
+    uint32_t want_bdf = 0, want_domain = 0;
+    bool match_pci    = false;
+    hsa_agent_t agent{};
+    int found = 0;
+};
+
+hsa_status_t pick_agent(hsa_agent_t a, void* data) {
+    AgentPick* p = static_cast<AgentPick*>(data);
+    hsa_device_type_t type;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS || type != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    if (p->match_pci) {
+        uint32_t bdf = 0, domain = 0;
+        if (hsa_agent_get_info(a, static_cast<hsa_agent_info_t>(HSA_AMD_AGENT_INFO_BDFID), &bdf) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+        (void)hsa_agent_get_info(a, static_cast<hsa_agent_info_t>(HSA_AMD_AGENT_INFO_DOMAIN), &domain);
+        if ((bdf & 0xFFF8u) != (p->want_bdf & 0xFFF8u) || domain != p->want_domain) return HSA_STATUS_SUCCESS;  // bus + device
+    }
+    if (p->found == 0) p->agent = a;
+    p->found++;
+    return HSA_STATUS_SUCCESS;
+}
+
+struct SymbolWalk {
+    std::vector<KernelEntry>* out;
+};
+
+hsa_status_t walk_symbol(hsa_executable_t, hsa_agent_t, hsa_executable_symbol_t sym, void* data) {
+    hsa_symbol_kind_t kind;
+    if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_TYPE, &kind) != HSA_STATUS_SUCCESS || kind != HSA_SYMBOL_KIND_KERNEL)
+        return HSA_STATUS_SUCCESS;
+    uint32_t len = 0;
+    if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_NAME_LENGTH, &len) != HSA_STATUS_SUCCESS || len == 0) return HSA_STATUS_SUCCESS;
+    std::string name(len, '\0');
+    if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_NAME, name.data()) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    KernelEntry e;
+    e.name = name;
+    (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &e.k.object);
+    (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &e.k.group);
+    (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &e.k.priv);
+    (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &e.k.kernarg);
+    static_cast<SymbolWalk*>(data)->out->push_back(e);
+    return HSA_STATUS_SUCCESS;
+}
+
+const char* hsa_text(hsa_status_t s) {
+    const char* m = nullptr;
+    (void)hsa_status_string(s, &m);
+    return m ? m : "unknown HSA error";
+}
+
+}  // namespace
+
+struct DirectQueue::Impl {
+    bool hsa_up = false;
+    hsa_agent_t agent{};
+    hsa_executable_t exe{};
+    bool have_exe = false;
+    hsa_code_object_reader_t reader{};
+    bool have_reader = false;
+    std::vector<char> image;
+    std::vector<KernelEntry> kernels;
+    hsa_queue_t* queue = nullptr;
+    char* ring         = nullptr;  // kernarg slots: fine-grained device memory, written by the host through the BAR
+    static constexpr uint32_t kSlots = 64;
+    hsa_signal_t drain_sig{};
+    bool have_drain_sig = false;
+    uint64_t ticks_per_second = 0;
+    struct Timed {
+        hsa_signal_t sig;
+        int tag;
+        double aux;
+    };
+    std::vector<hsa_signal_t> free_sigs;
+    std::vector<Timed> timed;
+
+    uint64_t reserve() {
+        const uint64_t idx = hsa_queue_add_write_index_relaxed(queue, 1);
+        // room in the packet ring, and the kernarg slot of dispatch idx - kSlots is free: packets run in order, so once packet
+        // j has been taken off the ring, packet j - 1 has completed
+        while (idx - hsa_queue_load_read_index_scacquire(queue) >= queue->size) _mm_pause();
+        while (idx >= kSlots && hsa_queue_load_read_index_scacquire(queue) + kSlots < idx + 2) _mm_pause();
+        return idx;
+    }
+    void publish(void* packet, uint16_t header, uint16_t setup, uint64_t idx) {
+        // header + setup go last, in one 32-bit release store: the packet processor must not see a half-written packet
+        const uint32_t word = static_cast<uint32_t>(header) | (static_cast<uint32_t>(setup) << 16);
+        __atomic_store_n(reinterpret_cast<uint32_t*>(packet), word, __ATOMIC_RELEASE);
+        hsa_signal_store_screlease(queue->doorbell_signal, static_cast<hsa_signal_value_t>(idx));
+    }
+};
+
+DirectQueue::DirectQueue() : p_(new Impl) {}
+
+DirectQueue::~DirectQueue() {
+    Impl& p = *p_;
+    if (p.queue) {
+        if (busy_) (void)drain(5.0);
+        (void)hsa_queue_destroy(p.queue);
+    }
+    for (auto& t : p.timed) (void)hsa_signal_destroy(t.sig);
+    for (auto& s : p.free_sigs) (void)hsa_signal_destroy(s);
+    if (p.have_drain_sig) (void)hsa_signal_destroy(p.drain_sig);
+    if (p.ring) (void)hipFree(p.ring);
+    if (p.have_exe) (void)hsa_executable_destroy(p.exe);
+    if (p.have_reader) (void)hsa_code_object_reader_destroy(p.reader);
+    if (p.hsa_up) (void)hsa_shut_down();
+}
+
+bool DirectQueue::init(int hip_device, const std::string& path, std::string* why) {
+    Impl& p = *p_;
+    auto fail = [&](const std::string& m) {
+        if (why) *why = m;
+        return false;
+    };
+    {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) return fail("code object " + path + " not found");
+        p.image.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        if (p.image.size() < 64 || std::memcmp(p.image.data(), "\177ELF", 4) != 0) return fail(path + " is not an ELF code object");
+    }
+    hsa_status_t s = hsa_init();  // reference-counted: the HIP runtime holds the first reference
+    if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_init: ") + hsa_text(s));
+    p.hsa_up = true;
+
+    AgentPick pick;
+    int bus = 0, dev = 0, dom = 0, ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 1 &&
+        hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, hip_device) == hipSuccess &&
+        hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, hip_device) == hipSuccess &&
+        hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, hip_device) == hipSuccess) {
+        pick.match_pci   = true;
+        pick.want_bdf    = (static_cast<uint32_t>(bus) << 8) | (static_cast<uint32_t>(dev) << 3);
+        pick.want_domain = static_cast<uint32_t>(dom);
+    }
+    (void)hipGetLastError();
+    s = hsa_iterate_agents(pick_agent, &pick);
+    if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_iterate_agents: ") + hsa_text(s));
+    if (pick.found != 1) return fail("the HSA agent of the HIP device could not be identified");
+    p.agent = pick.agent;
+
+    s = hsa_code_object_reader_create_from_memory(p.image.data(), p.image.size(), &p.reader);
+    if (s != HSA_STATUS_SUCCESS) return fail(std::string("code object reader: ") + hsa_text(s));
+    p.have_reader = true;
+    hsa_profile_t profile;
+    s = hsa_agent_get_info(p.agent, HSA_AGENT_INFO_PROFILE, &profile);
+    if (s != HSA_STATUS_SUCCESS) return fail(std::string("agent profile: ") + hsa_text(s));
+    s = hsa_executable_create_alt(profile, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &p.exe);
+    if (s != HSA_STATUS_SUCCESS) return fail(std::string("executable: ") + hsa_text(s));
+    p.have_exe = true;
+    s = hsa_executable_load_agent_code_object(p.exe, p.agent, p.reader, nullptr, nullptr);
+    if (s != HSA_STATUS_SUCCESS) return fail(std::string("loading the code object: ") + hsa_text(s));
+    s = hsa_executable_freeze(p.exe, nullptr);
+    if (s != HSA_STATUS_SUCCESS) return fail(std::string("freezing the executable: ") + hsa_text(s));
+    SymbolWalk walk{&p.kernels};
+    s = hsa_executable_iterate_agent_symbols(p.exe, p.agent, walk_symbol, &walk);
+    if (s != HSA_STATUS_SUCCESS || p.kernels.empty()) return fail("no kernels in the code object");
+
+    s = hsa_queue_create(p.agent, 1024, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &p.queue);
+    if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_queue_create: ") + hsa_text(s));
+    (void)hsa_amd_profiling_set_profiler_enabled(p.queue, 1);  // timestamps for the dispatches that carry a completion signal
+    (void)hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &p.ticks_per_second);
+    s = hsa_signal_create(1, 0, nullptr, &p.drain_sig);
+    if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_signal_create: ") + hsa_text(s));
+    p.have_drain_sig = true;
+
+    // kernarg ring in device memory the host can store into (same fault-free probe as BarBuffer, hc_api.cpp)
+    void* q            = nullptr;
+    const size_t bytes = static_cast<size_t>(Impl::kSlots) * kSlotBytes;
+    if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail("no fine-grained device memory for the kernel arguments");
+    }
+    p.ring       = static_cast<char*>(q);
+    bool host_ok = false;
+    const int fz = open("/dev/zero", O_RDONLY), fn = open("/dev/null", O_WRONLY);
+    if (fz >= 0 && fn >= 0)
+        host_ok = read(fz, p.ring, bytes) == static_cast<ssize_t>(bytes) && write(fn, p.ring, bytes) == static_cast<ssize_t>(bytes);
+    if (fz >= 0) close(fz);
+    if (fn >= 0) close(fn);
+    if (!host_ok) return fail("device memory is not host-addressable (no large BAR): kernel arguments cannot be stored directly");
+    return true;
+}
+
+DirectKernel DirectQueue::find(const std::string& fragment) const {
+    DirectKernel hit;
+    int n = 0;
+    for (const auto& e : p_->kernels)
+        if (e.name.find(fragment) != std::string::npos) {
+            hit = e.k;
+            ++n;
+        }
+    return n == 1 ? hit : DirectKernel{};
+}
+
+void DirectQueue::dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t wg_size, uint32_t dyn_lds, const void* args, size_t arg_bytes,
+                           int timed_tag, double timed_aux) {
+    Impl& p            = *p_;
+    const uint64_t idx = p.reserve();
+    char* slot         = p.ring + (idx & (Impl::kSlots - 1)) * kSlotBytes;
+    std::memcpy(slot, args, arg_bytes);
+    if (k.kernarg > arg_bytes) std::memset(slot + arg_bytes, 0, std::min<size_t>(k.kernarg, kSlotBytes) - arg_bytes);
+    _mm_sfence();  // write-combined stores through the BAR are globally visible before the doorbell
+    auto* pkt = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(p.queue->base_address) + (idx & (p.queue->size - 1));
+    pkt->workgroup_size_x     = static_cast<uint16_t>(wg_size);
+    pkt->workgroup_size_y     = 1;
+    pkt->workgroup_size_z     = 1;
+    pkt->reserved0            = 0;
+    pkt->grid_size_x          = workgroups * wg_size;
+    pkt->grid_size_y          = 1;
+    pkt->grid_size_z          = 1;
+    pkt->private_segment_size = k.priv;
+    pkt->group_segment_size   = k.group + dyn_lds;
+    pkt->kernel_object        = k.object;
+    pkt->kernarg_address      = slot;
+    pkt->reserved2            = 0;
+    pkt->completion_signal.handle = 0;
+    if (timed_tag >= 0) {
+        hsa_signal_t sig{};
+        if (!p.free_sigs.empty()) {
+            sig = p.free_sigs.back();
+            p.free_sigs.pop_back();
+            hsa_signal_store_relaxed(sig, 1);
+        } else if (hsa_signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) {
+            sig.handle = 0;
+        }
+        if (sig.handle) {
+            pkt->completion_signal = sig;
+            p.timed.push_back({sig, timed_tag, timed_aux});
+        }
+    }
+    // agent-scope fences: the inputs the host writes (state, arguments) live in fine-grained memory, which the GPU does not
+    // cache, and results for the host leave through the end-of-kernel release
+    const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                            (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                            (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    p.publish(pkt, header, 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS, idx);
+    busy_ = true;
+}
+
+bool DirectQueue::drain(double timeout_seconds) {
+    Impl& p = *p_;
+    if (!p.queue || !busy_) return true;
+    hsa_signal_store_relaxed(p.drain_sig, 1);
+    const uint64_t idx = p.reserve();
+    auto* pkt = reinterpret_cast<hsa_barrier_and_packet_t*>(p.queue->base_address) + (idx & (p.queue->size - 1));
+    std::memset(reinterpret_cast<char*>(pkt) + 4, 0, sizeof(*pkt) - 4);
+    pkt->completion_signal = p.drain_sig;
+    const uint16_t header  = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                            (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                            (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    p.publish(pkt, header, 0, idx);
+    if (timeout_seconds > 0.0) {
+        const uint64_t ticks = static_cast<uint64_t>(timeout_seconds * static_cast<double>(p.ticks_per_second ? p.ticks_per_second : 100000000ull));
+        if (hsa_signal_wait_scacquire(p.drain_sig, HSA_SIGNAL_CONDITION_LT, 1, ticks, HSA_WAIT_STATE_BLOCKED) >= 1) return false;
+    } else {
+        while (hsa_signal_wait_scacquire(p.drain_sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {
+        }
+    }
+    busy_ = false;
+    return true;
+}
+
+size_t DirectQueue::timed_pending() const { return p_->timed.size(); }
+
+void DirectQueue::collect(const std::function<void(int, double, double)>& sink) {
+    Impl& p = *p_;
+    for (auto& t : p.timed) {
+        while (hsa_signal_wait_scacquire(t.sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {
+        }
+        hsa_amd_profiling_dispatch_time_t dt{};
+        if (hsa_amd_profiling_get_dispatch_time(p.agent, t.sig, &dt) == HSA_STATUS_SUCCESS && p.ticks_per_second > 0 && dt.end >= dt.start)
+            sink(t.tag, static_cast<double>(dt.end - dt.start) / static_cast<double>(p.ticks_per_second), t.aux);
+        p.free_sigs.push_back(t.sig);
+    }
+    p.timed.clear();
+}
+
+}  // namespace hc

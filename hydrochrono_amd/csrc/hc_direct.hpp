@@ -1,0 +1,62 @@
+// hc_direct.hpp -- kernel dispatch without the HIP launch call: AQL packets written straight into an HSA queue of our own.
+//
+// hipLaunchKernelGGL costs the host 2.4-3.3 us per call on this stack, and the synchronous step (hc_step) pays it on its
+// critical path once per evaluation.  An AQL packet + kernel arguments + doorbell written by hand costs 0.15-0.25 us, and with
+// the arguments in device memory (written through the PCIe BAR) and agent-scope fences the launch-to-result time of a small
+// kernel drops from 7.9-9.8 us to 5.6-7.5 us (profiles/r02/latency_probe5.cpp).  The kernels are the same code: the stand-alone
+// code object hc_kernels.co is built from hc_kernels.hip next to the library and loaded through the HSA loader.
+//
+// Packets of one queue with the barrier bit execute in order, like kernels of a HIP stream; nothing orders this queue against
+// HIP streams, so the owner drains one side before it switches to the other (hc_api.cpp).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <string>
+
+namespace hc {
+
+struct DirectKernel {
+    uint64_t object  = 0;  // kernel descriptor address
+    uint32_t group   = 0;  // static LDS bytes
+    uint32_t priv    = 0;  // scratch bytes per work-item
+    uint32_t kernarg = 0;  // kernarg segment bytes
+    bool ok() const { return object != 0; }
+};
+
+class DirectQueue {
+  public:
+    DirectQueue();
+    ~DirectQueue();
+    DirectQueue(const DirectQueue&)            = delete;
+    DirectQueue& operator=(const DirectQueue&) = delete;
+
+    // Binds to the HSA agent of HIP device `hip_device`, loads the code object, creates the queue and the kernarg ring.
+    // false (with the reason in *why): the direct path is not available and the caller keeps using HIP launches.
+    bool init(int hip_device, const std::string& code_object_path, std::string* why);
+    // Kernel whose mangled name contains `fragment` (must match exactly one kernel); !ok() if there is none.
+    DirectKernel find(const std::string& fragment) const;
+
+    // One kernel dispatch: grid of `workgroups` x `wg_size` work-items, `dyn_lds` bytes of dynamic LDS, the argument block
+    // copied into the next kernarg slot.  timed >= 0: the dispatch carries a completion signal and its device-side duration
+    // is reported by collect() with this tag.
+    void dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t wg_size, uint32_t dyn_lds, const void* args, size_t arg_bytes,
+                  int timed_tag = -1, double timed_aux = 0.0);
+    // Waits until everything dispatched so far has completed.  timeout_seconds > 0: gives up after that long and returns false
+    // (the queue must then not be used any more).
+    bool drain(double timeout_seconds = 0.0);
+    bool busy() const { return busy_; }
+    // Reports (tag, seconds, aux) of every timed dispatch since the last call (waits for them).
+    void collect(const std::function<void(int, double, double)>& sink);
+    size_t timed_pending() const;
+
+    static constexpr size_t kSlotBytes = 4096;  // kernarg bytes per dispatch (the largest argument block is the scatter's 2.6 KB)
+
+  private:
+    struct Impl;
+    std::unique_ptr<Impl> p_;
+    bool busy_ = false;
+};
+
+}  // namespace hc

@@ -889,12 +889,27 @@ static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, h
     }
 }
 
+BlockLaunch block_launch_config(const BlockArgs& a, int mt, BlockArgs* b) {
+    BlockLaunch l;
+    l.nblocks = ((a.nchunks + 7) >> 3) * 8 * a.ngroups;  // octets of chunks, see the kernel's block mapping
+    *b        = a;
+    b->lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // [wave][tile][16x16] reduction buffer / per-wave U sub-tiles
+    l.smem    = (size_t)b->lds_front_doubles * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * b->depth * 24;
+    // template arguments of the kernel this (mt, depth) runs: conv_block_kernel<MT, R, NB, WPS>
+    l.MT  = (mt == 12 || mt == 6 || mt == 4 || mt == 2) ? mt : 1;
+    const int R16 = (l.MT == 12 || l.MT == 6) ? 3 : 4;
+    l.NB  = a.depth == 32 ? 2 : 1;
+    l.R   = a.depth == 32 ? (l.MT == 12 ? 2 : R16 + 1) : R16;
+    l.WPS = (l.NB == 1 && l.MT <= 6) ? 2 : 1;
+    return l;
+}
+
 void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
-    const int nblocks = ((a.nchunks + 7) >> 3) * 8 * a.ngroups;  // octets of chunks, see the kernel's block mapping
+    BlockArgs b;
+    const BlockLaunch l = block_launch_config(a, mt, &b);
+    const int nblocks   = l.nblocks;
+    const size_t smem   = l.smem;
     if (nblocks <= 0) return;
-    BlockArgs b = a;
-    b.lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // [wave][tile][16x16] reduction buffer / per-wave U sub-tiles
-    const size_t smem = (size_t)b.lds_front_doubles * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * b.depth * 24;
     if (mt == 12) launch_conv_block_mt<12, 3, 2>(b, nblocks, smem, stream);
     else if (mt == 6) launch_conv_block_mt<6, 3>(b, nblocks, smem, stream);
     else if (mt == 4) launch_conv_block_mt<4, 4>(b, nblocks, smem, stream);
@@ -962,11 +977,11 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     __shared__ double red_near[NW][16];
     __shared__ double red_term[16][16];  // [term slice][row]
 
-    if (a.do_push && blockIdx.x == gridDim.x - 1) {
+    if (a.do_push && (int)blockIdx.x == a.nblocks - 1) {  // (a.nblocks, not gridDim: the kernel takes no hidden arguments, see hc_direct.hpp)
         // nobody reads ring slot `head` during this step (the current sample is always taken from `state`)
         if (threadIdx.x == 0) a.ring_t[a.head] = a.t;
         double* slot = a.ring_v + (size_t)a.head * a.D;
-        for (int c = threadIdx.x; c < a.D; c += blockDim.x) {
+        for (int c = threadIdx.x; c < a.D; c += 64 * NW) {
             const double v = state_velocity(a.state, a.N, c);
             slot[c] = v;
             a.ring_vT[(size_t)c * a.HcapT + a.head] = v;  // per-DoF time series for the look-ahead pass
@@ -1170,21 +1185,30 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     }
 }
 
-void launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
-    const size_t smem = (size_t)max(0, a.n_near) * a.D * sizeof(double);
-    const bool wide   = a.n_near > 0 && a.D >= 1536;  // >= 196 KB of K per workgroup and near sample
-    if (smem > 64 * 1024) {
+FinalizeLaunch finalize_launch_config(FinalizeArgs& a) {
+    FinalizeLaunch l;
+    l.smem    = (size_t)max(0, a.n_near) * a.D * sizeof(double);
+    l.wide    = a.n_near > 0 && a.D >= 1536;  // >= 196 KB of K per workgroup and near sample
+    l.grid    = (a.Dloc + 15) / 16 + (a.do_push ? 1 : 0);
+    l.threads = l.wide ? 1024 : 256;
+    a.nblocks = l.grid;
+    return l;
+}
+
+void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
+    FinalizeArgs a         = a0;
+    const FinalizeLaunch l = finalize_launch_config(a);
+    if (l.smem > 64 * 1024) {
         static size_t granted4 = 0, granted16 = 0;
-        size_t& granted = wide ? granted16 : granted4;
-        if (smem > granted) {
-            (void)hipFuncSetAttribute(wide ? reinterpret_cast<const void*>(finalize_kernel<16>) : reinterpret_cast<const void*>(finalize_kernel<4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            granted = smem;
+        size_t& granted = l.wide ? granted16 : granted4;
+        if (l.smem > granted) {
+            (void)hipFuncSetAttribute(l.wide ? reinterpret_cast<const void*>(finalize_kernel<16>) : reinterpret_cast<const void*>(finalize_kernel<4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.smem);
+            granted = l.smem;
         }
     }
-    const dim3 grid((a.Dloc + 15) / 16 + (a.do_push ? 1 : 0));
-    if (wide) hipLaunchKernelGGL((finalize_kernel<16>), grid, dim3(1024), smem, stream, a);
-    else hipLaunchKernelGGL((finalize_kernel<4>), grid, dim3(256), smem, stream, a);
+    if (l.wide) hipLaunchKernelGGL((finalize_kernel<16>), dim3(l.grid), dim3(1024), l.smem, stream, a);
+    else hipLaunchKernelGGL((finalize_kernel<4>), dim3(l.grid), dim3(256), l.smem, stream, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -186,6 +186,7 @@ struct FinalizeArgs {
     unsigned long long seq;
     // history push of this step's sample into ring slot `head` (src/hydro_forces.cpp:559-574)
     int do_push, head, D;
+    int nblocks;      // workgroups of the launch (set by finalize_launch_config; the last one stores the sample)
     double* ring_t;
     double* ring_v;
     double* ring_vT;  // [D][HcapT] transposed copy (entry [Hcap] mirrors slot 0)
@@ -217,6 +218,20 @@ struct TaperArgs {
     int tc_index, tc_end;
     double final_amplitude;
 };
+
+// ---- launch geometry shared by the HIP launchers below and the direct AQL dispatch of hc_api.cpp (hc_direct.hpp) ----
+struct FinalizeLaunch {
+    int grid = 0, threads = 256;
+    size_t smem = 0;
+    bool wide   = false;  // finalize_kernel<16> (1024 threads) instead of finalize_kernel<4>
+};
+FinalizeLaunch finalize_launch_config(FinalizeArgs& a);  // also fills a.nblocks
+struct BlockLaunch {
+    int nblocks = 0;
+    size_t smem = 0;
+    int MT = 0, R = 0, NB = 0, WPS = 0;  // conv_block_kernel<MT, R, NB, WPS>
+};
+BlockLaunch block_launch_config(const BlockArgs& a, int mt, BlockArgs* with_lds_layout);
 
 // ---- launchers (all asynchronous on `stream`) ----
 // staging Kb[6][D][S] (file order, unscaled) -> rows row0..row0+5 of the panel matrix, times `scale`

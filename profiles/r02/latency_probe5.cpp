@@ -1,0 +1,189 @@
+// latency_probe5.cpp -- what a kernel launch costs the host and the step: hipLaunchKernelGGL against an AQL packet written
+// straight into an HSA queue of our own (same kernel, loaded from a stand-alone code object).
+//   hipcc --offload-arch=gfx950 -O2 --genco -DPROBE_DEVICE_ONLY profiles/r02/latency_probe5.cpp -o /tmp/probe5.co
+//   hipcc --offload-arch=gfx950 -O2 profiles/r02/latency_probe5.cpp -o /tmp/latency_probe5 -lhsa-runtime64 && /tmp/latency_probe5 /tmp/probe5.co
+#include <hip/hip_runtime.h>
+
+// no blockDim / gridDim inside: the kernel needs no hidden arguments
+extern "C" __global__ void __launch_bounds__(256) tag5(const double* __restrict__ state, int n_state, unsigned long long* out,
+                                                        unsigned long long seq, int nthreads) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_state; i += nthreads) acc += state[i];
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const double v = red[0] + red[1] + red[2] + red[3] + threadIdx.x;
+        *reinterpret_cast<u64x2*>(out + 2 * (blockIdx.x * 16 + threadIdx.x)) = u64x2{(unsigned long long)__double_as_longlong(v), seq};
+    }
+}
+
+#ifndef PROBE_DEVICE_ONLY
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <vector>
+#include <xmmintrin.h>
+#include <unistd.h>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s failed: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+#define HK(x) do { hsa_status_t s_ = (x); if (s_ != HSA_STATUS_SUCCESS) { const char* m_ = nullptr; hsa_status_string(s_, &m_); std::printf("%s failed: %s\n", #x, m_ ? m_ : "?"); return 1; } } while (0)
+
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void report(const char* name, std::vector<double>& v) {
+    std::sort(v.begin(), v.end());
+    std::printf("%-64s median %7.2f us   p10 %7.2f   p90 %7.2f\n", name, v[v.size() / 2], v[v.size() / 10], v[v.size() * 9 / 10]);
+}
+static hsa_agent_t g_gpu;
+static bool g_have_gpu = false;
+static hsa_status_t pick_gpu(hsa_agent_t a, void*) {
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) == HSA_STATUS_SUCCESS && t == HSA_DEVICE_TYPE_GPU && !g_have_gpu) { g_gpu = a; g_have_gpu = true; }
+    return HSA_STATUS_SUCCESS;
+}
+struct KernArgs { const double* state; int n_state; int pad0; unsigned long long* out; unsigned long long seq; int nthreads; int pad1; };
+
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    if (argc < 2) { std::printf("usage: latency_probe5 probe5.co\n"); return 1; }
+    CK(hipSetDevice(0));
+    hipStream_t stream;
+    CK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    const int nwg = 25, n_state = 768;
+    double* d_state;
+    CK(hipMalloc(&d_state, n_state * sizeof(double)));
+    CK(hipMemset(d_state, 0, n_state * sizeof(double)));
+    unsigned long long* h_tag;
+    CK(hipHostMalloc(&h_tag, nwg * 16 * 16, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h_tag, 0, nwg * 16 * 16);
+    unsigned long long* d_tag;
+    CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_tag), h_tag, 0));
+    volatile unsigned long long* tag = h_tag;
+    auto wait_seq = [&](unsigned long long seq) {
+        const double t0 = now_us();
+        for (int r = nwg * 16 - 1; r >= 0; --r)
+            while (tag[2 * r + 1] != seq) {
+                _mm_pause();
+                if (now_us() - t0 > 2e6) { std::printf("timeout waiting for sequence %llu (row %d holds %llu)\n", seq, r, (unsigned long long)tag[2 * r + 1]); std::fflush(stdout); _exit(3); }
+            }
+    };
+    unsigned long long seq = 0;
+    const int reps = 3000;
+
+    {   // A: HIP launch
+        std::vector<double> tl, tt;
+        for (int i = 0; i < reps + 200; ++i) {
+            ++seq;
+            const double a = now_us();
+            hipLaunchKernelGGL(tag5, dim3(nwg), dim3(256), 0, stream, d_state, n_state, d_tag, seq, 256);
+            const double b = now_us();
+            wait_seq(seq);
+            const double c = now_us();
+            if (i >= 200) { tl.push_back(b - a); tt.push_back(c - a); }
+        }
+        report("HIP: hipLaunchKernelGGL call", tl);
+        report("HIP: launch call -> all 400 tagged results on the host", tt);
+    }
+    CK(hipStreamSynchronize(stream));
+
+    // B: our own HSA queue, AQL packets written by hand
+    HK(hsa_init());
+    HK(hsa_iterate_agents(pick_gpu, nullptr));
+    if (!g_have_gpu) { std::printf("no GPU agent\n"); return 1; }
+    std::ifstream f(argv[1], std::ios::binary);
+    std::vector<char> co((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (co.empty()) { std::printf("cannot read %s\n", argv[1]); return 1; }
+    hsa_code_object_reader_t reader;
+    HK(hsa_code_object_reader_create_from_memory(co.data(), co.size(), &reader));
+    hsa_profile_t profile;
+    HK(hsa_agent_get_info(g_gpu, HSA_AGENT_INFO_PROFILE, &profile));
+    hsa_executable_t exe;
+    HK(hsa_executable_create_alt(profile, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &exe));
+    HK(hsa_executable_load_agent_code_object(exe, g_gpu, reader, nullptr, nullptr));
+    HK(hsa_executable_freeze(exe, nullptr));
+    hsa_executable_symbol_t sym;
+    HK(hsa_executable_get_symbol_by_name(exe, "tag5.kd", &g_gpu, &sym));
+    uint64_t kobj = 0;
+    uint32_t group = 0, priv = 0, kasz = 0;
+    HK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &kobj));
+    HK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &group));
+    HK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &priv));
+    HK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &kasz));
+    std::printf("kernel object %#llx, group %u B, private %u B, kernarg %u B (explicit struct %zu B)\n", (unsigned long long)kobj, group, priv, kasz, sizeof(KernArgs));
+    hsa_queue_t* q = nullptr;
+    HK(hsa_queue_create(g_gpu, 1024, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));
+    // kernarg ring: mapped pinned host memory (GPU fetches the arguments over PCIe) or fine-grained device memory written through the BAR
+    char* h_ka_pin;
+    CK(hipHostMalloc(&h_ka_pin, 64 * 256, hipHostMallocMapped | hipHostMallocCoherent));
+    char* d_ka_pin;
+    CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_ka_pin), h_ka_pin, 0));
+    char* bar_ka = nullptr;
+    CK(hipExtMallocWithFlags(reinterpret_cast<void**>(&bar_ka), 64 * 256, hipDeviceMallocFinegrained));
+    char *h_ka = h_ka_pin, *d_ka = d_ka_pin;
+    int acq = HSA_FENCE_SCOPE_SYSTEM, rel = HSA_FENCE_SCOPE_SYSTEM;
+    bool use_sfence = false;
+    const uint32_t mask = q->size - 1;
+    auto dispatch = [&](unsigned long long s) {
+        const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
+        while (idx - hsa_queue_load_read_index_relaxed(q) >= q->size) _mm_pause();
+        KernArgs ka{d_state, n_state, 0, d_tag, s, 256, 0};
+        char* slot = h_ka + (idx & 63) * 256;
+        std::memcpy(slot, &ka, sizeof ka);
+        hsa_kernel_dispatch_packet_t* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(q->base_address) + (idx & mask);
+        p->setup                = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+        p->workgroup_size_x     = 256; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
+        p->grid_size_x          = 256 * nwg; p->grid_size_y = 1; p->grid_size_z = 1;
+        p->private_segment_size = priv;
+        p->group_segment_size   = group;
+        p->kernel_object        = kobj;
+        p->kernarg_address      = d_ka + (idx & 63) * 256;
+        p->reserved2            = 0;
+        p->completion_signal.handle = 0;
+        const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+        if (use_sfence) _mm_sfence();
+        __atomic_store_n(reinterpret_cast<uint16_t*>(p), header, __ATOMIC_RELEASE);
+        hsa_signal_store_screlease(q->doorbell_signal, idx);
+    };
+    auto run = [&](const char* name) {
+        std::vector<double> tl, tt;
+        for (int i = 0; i < reps + 200; ++i) {
+            ++seq;
+            const double a = now_us();
+            dispatch(seq);
+            const double b = now_us();
+            wait_seq(seq);
+            const double c = now_us();
+            if (i >= 200) { tl.push_back(b - a); tt.push_back(c - a); }
+        }
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "AQL %s: packet + kernarg + doorbell", name);
+        report(buf, tl);
+        std::snprintf(buf, sizeof buf, "AQL %s: dispatch -> results on the host", name);
+        report(buf, tt);
+    };
+    run("kernarg pinned, fences system/system");
+    acq = HSA_FENCE_SCOPE_AGENT; rel = HSA_FENCE_SCOPE_AGENT;
+    run("kernarg pinned, fences agent/agent");
+    acq = HSA_FENCE_SCOPE_SYSTEM; rel = HSA_FENCE_SCOPE_AGENT;
+    run("kernarg pinned, fences system/agent");
+    h_ka = bar_ka; d_ka = bar_ka; use_sfence = true;
+    acq = HSA_FENCE_SCOPE_SYSTEM; rel = HSA_FENCE_SCOPE_SYSTEM;
+    run("kernarg in VRAM (BAR), fences system/system");
+    acq = HSA_FENCE_SCOPE_AGENT; rel = HSA_FENCE_SCOPE_AGENT;
+    run("kernarg in VRAM (BAR), fences agent/agent");
+    acq = HSA_FENCE_SCOPE_SYSTEM; rel = HSA_FENCE_SCOPE_AGENT;
+    run("kernarg in VRAM (BAR), fences system/agent");
+    // (release scope NONE: the tagged stores never reach the host -- they leave the L2 with the end-of-kernel release)
+    hsa_queue_destroy(q);
+    return 0;
+}
+#endif

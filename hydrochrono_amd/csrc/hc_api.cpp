@@ -1784,6 +1784,13 @@ int hc_set_lookahead(hc_ctx* c, int steps) {
     HC_API_END(c)
 }
 
+int hc_direct_dispatch_active(const hc_ctx* c) { return (c && c->direct_ready) ? 1 : 0; }
+const char* hc_dispatch_mode_reason(const hc_ctx* c) {
+    if (!c) return "no context";
+    if (!c->finalized) return "hc_finalize has not been called";
+    return c->direct_ready ? "direct AQL dispatch" : c->direct_why.c_str();
+}
+
 int hc_reset_history(hc_ctx* c) {
     HC_API_BEGIN(c)
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");

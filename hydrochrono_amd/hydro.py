@@ -220,6 +220,10 @@ class HydroForces:
         """0 = plain per-step evaluation; > 0 = 16-step look-ahead blocking (the default)."""
         self._chk(self.lib.hc_set_lookahead(self.ctx, int(steps)))
 
+    def direct_dispatch(self):
+        """(active, reason): whether hc_step writes AQL packets itself instead of calling hipLaunchKernelGGL."""
+        return bool(self.lib.hc_direct_dispatch_active(self.ctx)), self.lib.hc_dispatch_mode_reason(self.ctx).decode()
+
     def reset_history(self):
         self._chk(self.lib.hc_reset_history(self.ctx))
 

@@ -188,6 +188,13 @@ int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
  * from the prediction (> 1e-9 of the step size) silently falls back to the plain per-step evaluation, so results never depend
  * on the prediction being right.  steps = 0 disables it (every step streams K), 1..16 selects blocks of 16, more blocks of 32. */
 int hc_set_lookahead(hc_ctx* ctx, int steps);
+/* How hc_step hands its kernels to the GPU.  1: as AQL packets written straight into an HSA queue of the library's own (kernel
+ * arguments stored through the PCIe BAR) -- the default when the stand-alone code object hc_kernels.co lies next to the library,
+ * the device's memory is host-addressable and the system is not wide (D < 1536); it saves the 2.4-3.3 us a hipLaunchKernelGGL call
+ * costs the host on the critical path of every step.  0: through HIP launches on the context's stream (HC_DIRECT=0 forces this);
+ * hc_dispatch_mode_reason then says why.  The kernels and the results are the same either way.  hc_step_device always uses HIP. */
+int hc_direct_dispatch_active(const hc_ctx* ctx);
+const char* hc_dispatch_mode_reason(const hc_ctx* ctx);
 /* Forget the velocity history and the per-time cache (fresh TestHydro state). */
 int hc_reset_history(hc_ctx* ctx);
 /* Injects a history as if those steps had been evaluated (times newest first, vel [n][D]); used to start

@@ -980,3 +980,45 @@ def test_edge_cases_and_argument_errors(HF):
     with pytest.raises(HydroError) as ei:
         g.step(0.5, z12, z12, z12, z12)
     assert ei.value.status == 3 and "must not decrease" in str(ei.value)
+
+
+def test_direct_dispatch_matches_hip_launches(HF, monkeypatch):
+    """hc_step sends its step kernel, scatter, pass and reduction to an HSA queue of the library's own as AQL packets
+    (hc_direct.hpp) when a step needs no plain convolution launch, and drains one side whenever it switches between that
+    queue and the HIP stream.  Same kernels either way, so the forces are bitwise those of a context that only uses HIP
+    launches (HC_DIRECT=0) -- through the first steps (plain), whole look-ahead blocks, a step off the predicted time grid
+    (back to plain and into a new block), and other entry points called between steps."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    case = many_body_case(3, S=64, n_exc=65, dt_exc=0.02, seed=77)
+    kw = dict(simulation_dt=0.01, simulation_duration=6.0, ramp_duration=0.5, wave_height=2.0, wave_period=6.0,
+              frequency_min=0.05, frequency_max=0.6, nfrequencies=48, peak_enhancement_factor=3.3)
+    monkeypatch.setenv("HC_DIRECT", "0")
+    hip = HF.from_case(case)
+    monkeypatch.setenv("HC_DIRECT", "1")
+    direct = HF.from_case(case)
+    assert hip.direct_dispatch() == (False, "disabled by HC_DIRECT=0")
+    if os.environ.get("HC_NO_BAR_STATE") != "1":   # (that knob keeps the host off the BAR, and with it the direct path)
+        assert direct.direct_dispatch()[0], direct.direct_dispatch()[1]   # the GPU box has a large BAR and the code object travels with the library
+    orc = load_into_oracle(case)
+    for h in (hip, direct, orc):
+        h.add_waves_irregular(**kw)
+    motion = PrescribedMotion(3, rest_positions(case), seed=3)
+    t, n = 0.0, 0
+    rng = np.random.default_rng(5)
+    while n < 260:
+        st = motion.state(t)
+        fd, fh = direct.step(t, *st), hip.step(t, *st)
+        assert np.array_equal(fd, fh), f"step {n}"
+        assert_close(fd, orc.step(t, *st), what=f"step {n} vs oracle")
+        if n % 37 == 5:   # entry points that synchronise / copy on the HIP side, between two direct steps
+            for a, b in zip(direct.components(), hip.components()):
+                assert np.array_equal(a, b)
+            th, vh = direct.get_history()
+            assert th[0] == t and vh.shape[1] == 18
+            w = rng.normal(size=18)
+            assert np.array_equal(direct.added_mass_mv(np.zeros(18), w, 1.0), hip.added_mass_mv(np.zeros(18), w, 1.0))
+        t += 0.01 if n % 90 != 60 else 0.0137   # an off-grid step now and then
+        n += 1
+    p = direct.profile()
+    assert p["radiation_calls"] == 260

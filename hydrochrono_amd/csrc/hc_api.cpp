@@ -236,6 +236,18 @@ hc::EventPair* ev_begin(hc_ctx* c, int kind, hipStream_t stream, double waves_sh
     HC_HIP(hipEventRecord(ev->a, stream));
     return ev;
 }
+// A profiling tool that intercepts the HSA queues (rocprofv3, roctracer: they arrive through these variables) replaces the
+// completion signals of our packets with its own, and hsa_amd_profiling_get_dispatch_time on ours then returns nothing useful
+// (1.3 us for a 190 us pass).  The tool still sees every dispatch; only the library's own timings need the HIP path then.
+bool profiling_tool_attached() {
+    static const bool attached = [] {
+        if (std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("HSA_TOOLS_LIB")) return true;
+        const char* pre = std::getenv("LD_PRELOAD");
+        return pre && (std::strstr(pre, "rocprofiler") || std::strstr(pre, "roctracer"));
+    }();
+    return attached;
+}
+
 // direct dispatches: the tag to time a launch with (-1: not timed), same sampling rule as ev_begin
 int direct_tag(const hc_ctx* c, int kind) { return (c->profiling && (c->sample_this_step || kind == hc::kEvPass)) ? kind : -1; }
 
@@ -662,7 +674,8 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     // Where this step's kernels go: the direct queue (hc_direct.hpp) when the step comes from hc_step and needs no plain
     // convolution launch -- the steady state of a look-ahead run -- else the HIP stream.  Nothing orders the two against each
     // other on the device, so the side that was used last is drained at a switch.
-    const bool direct = c->direct_ready && host_tagged && stream == c->stream && !f.scratch_out && !((run_rad && !block) || nchunks_ex > 0);
+    const bool direct = c->direct_ready && host_tagged && stream == c->stream && !f.scratch_out && !((run_rad && !block) || nchunks_ex > 0) &&
+                        !(c->profiling && profiling_tool_attached());  // the library's own timings under a tool: HIP events
     if (direct && c->path != 2) {
         if (c->have_last_stream && c->last_stream != c->stream) HC_HIP(hipDeviceSynchronize());  // the last step ran on a caller's stream
         else HC_HIP(hipStreamSynchronize(c->stream));

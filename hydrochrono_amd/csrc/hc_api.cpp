@@ -978,6 +978,12 @@ void setup_direct(hc_ctx* c) {
         c->direct_why = "a kernel of this configuration is missing from hc_kernels.co";
         return;
     }
+    // the code object must be the one built with this library: its kernels take exactly these argument blocks
+    if (c->dk_finalize.kernarg != sizeof(hc::FinalizeArgs) || c->dk_scatter.kernarg != sizeof(hc::ScatterArgs) ||
+        c->dk_block16.kernarg != sizeof(hc::BlockArgs) || c->dk_block32.kernarg != sizeof(hc::BlockArgs) || c->dk_reduce.kernarg != 48) {
+        c->direct_why = "hc_kernels.co was not built from the same sources as this library (argument block sizes differ)";
+        return;
+    }
     if (c->dk_finalize.priv || c->dk_scatter.priv || c->dk_reduce.priv || c->dk_block16.priv || c->dk_block32.priv) {
         c->direct_why = "a kernel needs scratch memory";
         return;

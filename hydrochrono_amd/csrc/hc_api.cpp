@@ -965,6 +965,7 @@ void setup_direct(hc_ctx* c) {
     c->dk_finalize = q->find("finalize_kernelILi4EEEv");
     c->dk_scatter  = q->find("scatter_kernelE");
     c->dk_reduce   = q->find("reduce_block_kernelE");
+    c->dk_added_mass = q->find("added_mass_mv_tagged_kernelE");  // optional: hc_added_mass_mv falls back to a HIP launch
     for (int depth : {16, 32}) {
         hc::BlockArgs a{}, b{};
         a.depth = depth;
@@ -1619,7 +1620,7 @@ void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long lo
         while (g[2 * r + 1] != seq) {
             __builtin_ia32_pause();
             if ((++spins & 0x3FFFF) == 0) {
-                if (c->path == 2 && stream == c->stream) {
+                if (stream == nullptr || (c->path == 2 && stream == c->stream)) {
                     // the step went to the direct queue: there is no stream to ask; a dispatch that never completes is a lost device
                     if (spins > (1ull << 34)) throw Error(HC_ERR_DEVICE, "hc_step: the step's results did not arrive (direct queue)");
                     continue;
@@ -1900,9 +1901,24 @@ int hc_added_mass_mv(hc_ctx* c, const double* w, double cc, double* R, int n_sys
     if (bar) _mm_sfence();
     const double* dw = bar ? c->bar_am.p : c->h_am.dp;
     const unsigned long long seq = ++c->seq_am;
-    hc::launch_added_mass_mv_tagged(c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq, c->stream_am);
-    HC_HIP(hipGetLastError());
-    wait_tagged(c, c->h_tag_am.p, seq, c->stream_am, R + row0);
+    if (c->direct_ready && bar && c->dk_added_mass.ok() && c->dk_added_mass.kernarg == 56 && c->dk_added_mass.priv == 0) {
+        // the second lane of the direct queue: an AQL packet instead of a HIP launch, independent of the step path's lane
+        struct {
+            const double* M;
+            int rows, cols;
+            const double *w, *R_in;
+            double c;
+            unsigned long long* tagged;
+            unsigned long long seq;
+        } a{c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq};
+        static_assert(sizeof(a) == 56, "kernarg layout of added_mass_mv_tagged_kernel");
+        c->dq->dispatch(c->dk_added_mass, static_cast<uint32_t>((c->Dloc + 3) / 4), 256, 0, &a, sizeof a, -1, 0.0, 1);
+        wait_tagged(c, c->h_tag_am.p, seq, nullptr, R + row0);
+    } else {
+        hc::launch_added_mass_mv_tagged(c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq, c->stream_am);
+        HC_HIP(hipGetLastError());
+        wait_tagged(c, c->h_tag_am.p, seq, c->stream_am, R + row0);
+    }
     HC_API_END(c)
 }
 

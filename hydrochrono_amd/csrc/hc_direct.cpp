@@ -83,11 +83,14 @@ struct DirectQueue::Impl {
     bool have_reader = false;
     std::vector<char> image;
     std::vector<KernelEntry> kernels;
-    hsa_queue_t* queue = nullptr;
-    char* ring         = nullptr;  // kernarg slots: fine-grained device memory, written by the host through the BAR
     static constexpr uint32_t kSlots = 64;
-    hsa_signal_t drain_sig{};
-    bool have_drain_sig = false;
+    struct Lane {
+        hsa_queue_t* queue = nullptr;
+        char* ring         = nullptr;  // kernarg slots: fine-grained device memory, written by the host through the BAR
+        hsa_signal_t drain_sig{};
+        bool have_drain_sig = false;
+    } lanes[DirectQueue::kLanes];
+    char* ring_all = nullptr;
     uint64_t ticks_per_second = 0;
     struct Timed {
         hsa_signal_t sig;
@@ -97,7 +100,8 @@ struct DirectQueue::Impl {
     std::vector<hsa_signal_t> free_sigs;
     std::vector<Timed> timed;
 
-    uint64_t reserve() {
+    uint64_t reserve(Lane& ln) {
+        hsa_queue_t* queue = ln.queue;
         const uint64_t idx = hsa_queue_add_write_index_relaxed(queue, 1);
         // room in the packet ring, and the kernarg slot of dispatch idx - kSlots is free: packets run in order, so once packet
         // j has been taken off the ring, packet j - 1 has completed
@@ -105,7 +109,8 @@ struct DirectQueue::Impl {
         while (idx >= kSlots && hsa_queue_load_read_index_scacquire(queue) + kSlots < idx + 2) _mm_pause();
         return idx;
     }
-    void publish(void* packet, uint16_t header, uint16_t setup, uint64_t idx) {
+    void publish(Lane& ln, void* packet, uint16_t header, uint16_t setup, uint64_t idx) {
+        hsa_queue_t* queue = ln.queue;
         // header + setup go last, in one 32-bit release store: the packet processor must not see a half-written packet
         const uint32_t word = static_cast<uint32_t>(header) | (static_cast<uint32_t>(setup) << 16);
         __atomic_store_n(reinterpret_cast<uint32_t*>(packet), word, __ATOMIC_RELEASE);
@@ -117,14 +122,16 @@ DirectQueue::DirectQueue() : p_(new Impl) {}
 
 DirectQueue::~DirectQueue() {
     Impl& p = *p_;
-    if (p.queue) {
-        if (busy_) (void)drain(5.0);
-        (void)hsa_queue_destroy(p.queue);
+    for (int l = 0; l < kLanes; ++l) {
+        if (p.lanes[l].queue) {
+            if (busy_[l]) (void)drain(5.0, l);
+            (void)hsa_queue_destroy(p.lanes[l].queue);
+        }
+        if (p.lanes[l].have_drain_sig) (void)hsa_signal_destroy(p.lanes[l].drain_sig);
     }
     for (auto& t : p.timed) (void)hsa_signal_destroy(t.sig);
     for (auto& s : p.free_sigs) (void)hsa_signal_destroy(s);
-    if (p.have_drain_sig) (void)hsa_signal_destroy(p.drain_sig);
-    if (p.ring) (void)hipFree(p.ring);
+    if (p.ring_all) (void)hipFree(p.ring_all);
     if (p.have_exe) (void)hsa_executable_destroy(p.exe);
     if (p.have_reader) (void)hsa_code_object_reader_destroy(p.reader);
     if (p.hsa_up) (void)hsa_shut_down();
@@ -179,26 +186,29 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
     s = hsa_executable_iterate_agent_symbols(p.exe, p.agent, walk_symbol, &walk);
     if (s != HSA_STATUS_SUCCESS || p.kernels.empty()) return fail("no kernels in the code object");
 
-    s = hsa_queue_create(p.agent, 1024, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &p.queue);
-    if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_queue_create: ") + hsa_text(s));
-    (void)hsa_amd_profiling_set_profiler_enabled(p.queue, 1);  // timestamps for the dispatches that carry a completion signal
+    for (int l = 0; l < kLanes; ++l) {
+        s = hsa_queue_create(p.agent, 1024, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &p.lanes[l].queue);
+        if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_queue_create: ") + hsa_text(s));
+        s = hsa_signal_create(1, 0, nullptr, &p.lanes[l].drain_sig);
+        if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_signal_create: ") + hsa_text(s));
+        p.lanes[l].have_drain_sig = true;
+    }
+    (void)hsa_amd_profiling_set_profiler_enabled(p.lanes[0].queue, 1);  // timestamps for the dispatches that carry a completion signal
     (void)hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &p.ticks_per_second);
-    s = hsa_signal_create(1, 0, nullptr, &p.drain_sig);
-    if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_signal_create: ") + hsa_text(s));
-    p.have_drain_sig = true;
 
     // kernarg ring in device memory the host can store into (same fault-free probe as BarBuffer, hc_api.cpp)
     void* q            = nullptr;
-    const size_t bytes = static_cast<size_t>(Impl::kSlots) * kSlotBytes;
+    const size_t bytes = static_cast<size_t>(Impl::kSlots) * kSlotBytes * kLanes;
     if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
         return fail("no fine-grained device memory for the kernel arguments");
     }
-    p.ring       = static_cast<char*>(q);
+    p.ring_all = static_cast<char*>(q);
+    for (int l = 0; l < kLanes; ++l) p.lanes[l].ring = p.ring_all + static_cast<size_t>(l) * Impl::kSlots * kSlotBytes;
     bool host_ok = false;
     const int fz = open("/dev/zero", O_RDONLY), fn = open("/dev/null", O_WRONLY);
     if (fz >= 0 && fn >= 0)
-        host_ok = read(fz, p.ring, bytes) == static_cast<ssize_t>(bytes) && write(fn, p.ring, bytes) == static_cast<ssize_t>(bytes);
+        host_ok = read(fz, p.ring_all, bytes) == static_cast<ssize_t>(bytes) && write(fn, p.ring_all, bytes) == static_cast<ssize_t>(bytes);
     if (fz >= 0) close(fz);
     if (fn >= 0) close(fn);
     if (!host_ok) return fail("device memory is not host-addressable (no large BAR): kernel arguments cannot be stored directly");
@@ -217,14 +227,15 @@ DirectKernel DirectQueue::find(const std::string& fragment) const {
 }
 
 void DirectQueue::dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t wg_size, uint32_t dyn_lds, const void* args, size_t arg_bytes,
-                           int timed_tag, double timed_aux) {
+                           int timed_tag, double timed_aux, int lane) {
     Impl& p            = *p_;
-    const uint64_t idx = p.reserve();
-    char* slot         = p.ring + (idx & (Impl::kSlots - 1)) * kSlotBytes;
+    Impl::Lane& ln     = p.lanes[lane];
+    const uint64_t idx = p.reserve(ln);
+    char* slot         = ln.ring + (idx & (Impl::kSlots - 1)) * kSlotBytes;
     std::memcpy(slot, args, arg_bytes);
     if (k.kernarg > arg_bytes) std::memset(slot + arg_bytes, 0, std::min<size_t>(k.kernarg, kSlotBytes) - arg_bytes);
     _mm_sfence();  // write-combined stores through the BAR are globally visible before the doorbell
-    auto* pkt = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(p.queue->base_address) + (idx & (p.queue->size - 1));
+    auto* pkt = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(ln.queue->base_address) + (idx & (ln.queue->size - 1));
     pkt->workgroup_size_x     = static_cast<uint16_t>(wg_size);
     pkt->workgroup_size_y     = 1;
     pkt->workgroup_size_z     = 1;
@@ -257,30 +268,31 @@ void DirectQueue::dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t 
     const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                             (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                             (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
-    p.publish(pkt, header, 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS, idx);
-    busy_ = true;
+    p.publish(ln, pkt, header, 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS, idx);
+    busy_[lane] = true;
 }
 
-bool DirectQueue::drain(double timeout_seconds) {
-    Impl& p = *p_;
-    if (!p.queue || !busy_) return true;
-    hsa_signal_store_relaxed(p.drain_sig, 1);
-    const uint64_t idx = p.reserve();
-    auto* pkt = reinterpret_cast<hsa_barrier_and_packet_t*>(p.queue->base_address) + (idx & (p.queue->size - 1));
+bool DirectQueue::drain(double timeout_seconds, int lane) {
+    Impl& p        = *p_;
+    Impl::Lane& ln = p.lanes[lane];
+    if (!ln.queue || !busy_[lane]) return true;
+    hsa_signal_store_relaxed(ln.drain_sig, 1);
+    const uint64_t idx = p.reserve(ln);
+    auto* pkt = reinterpret_cast<hsa_barrier_and_packet_t*>(ln.queue->base_address) + (idx & (ln.queue->size - 1));
     std::memset(reinterpret_cast<char*>(pkt) + 4, 0, sizeof(*pkt) - 4);
-    pkt->completion_signal = p.drain_sig;
+    pkt->completion_signal = ln.drain_sig;
     const uint16_t header  = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                             (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                             (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
-    p.publish(pkt, header, 0, idx);
+    p.publish(ln, pkt, header, 0, idx);
     if (timeout_seconds > 0.0) {
         const uint64_t ticks = static_cast<uint64_t>(timeout_seconds * static_cast<double>(p.ticks_per_second ? p.ticks_per_second : 100000000ull));
-        if (hsa_signal_wait_scacquire(p.drain_sig, HSA_SIGNAL_CONDITION_LT, 1, ticks, HSA_WAIT_STATE_BLOCKED) >= 1) return false;
+        if (hsa_signal_wait_scacquire(ln.drain_sig, HSA_SIGNAL_CONDITION_LT, 1, ticks, HSA_WAIT_STATE_BLOCKED) >= 1) return false;
     } else {
-        while (hsa_signal_wait_scacquire(p.drain_sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {
+        while (hsa_signal_wait_scacquire(ln.drain_sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {
         }
     }
-    busy_ = false;
+    busy_[lane] = false;
     return true;
 }
 

@@ -41,12 +41,15 @@ class DirectQueue {
     // One kernel dispatch: grid of `workgroups` x `wg_size` work-items, `dyn_lds` bytes of dynamic LDS, the argument block
     // copied into the next kernarg slot.  timed >= 0: the dispatch carries a completion signal and its device-side duration
     // is reported by collect() with this tag.
+    // lane: which of the object's two independent queues (0: the step path; 1: the added-mass product, which must never wait
+    // behind work the step path still runs).
     void dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t wg_size, uint32_t dyn_lds, const void* args, size_t arg_bytes,
-                  int timed_tag = -1, double timed_aux = 0.0);
-    // Waits until everything dispatched so far has completed.  timeout_seconds > 0: gives up after that long and returns false
-    // (the queue must then not be used any more).
-    bool drain(double timeout_seconds = 0.0);
-    bool busy() const { return busy_; }
+                  int timed_tag = -1, double timed_aux = 0.0, int lane = 0);
+    // Waits until everything dispatched to the lane so far has completed.  timeout_seconds > 0: gives up after that long and
+    // returns false (the queue must then not be used any more).
+    bool drain(double timeout_seconds = 0.0, int lane = 0);
+    bool busy(int lane = 0) const { return busy_[lane]; }
+    static constexpr int kLanes = 2;
     // Reports (tag, seconds, aux) of every timed dispatch since the last call (waits for them).
     void collect(const std::function<void(int, double, double)>& sink);
     size_t timed_pending() const;
@@ -56,7 +59,7 @@ class DirectQueue {
   private:
     struct Impl;
     std::unique_ptr<Impl> p_;
-    bool busy_ = false;
+    bool busy_[kLanes] = {false, false};
 };
 
 }  // namespace hc

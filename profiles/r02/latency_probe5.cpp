@@ -20,6 +20,31 @@ extern "C" __global__ void __launch_bounds__(256) tag5(const double* __restrict_
     }
 }
 
+// the same kernel with the tagged results stored at system scope (sc0 sc1: written through the L2), so that they do not wait
+// for the end-of-kernel release; the last 64 threads of every workgroup then keep the kernel alive for a while (like the step
+// kernel's ring-push workgroup), which only matters if the results wait for the end of the kernel
+extern "C" __global__ void __launch_bounds__(256) tag5s(const double* __restrict__ state, int n_state, unsigned long long* out,
+                                                         unsigned long long seq, int nthreads, int linger, double* sink) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_state; i += nthreads) acc += state[i];
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const double v = red[0] + red[1] + red[2] + red[3] + threadIdx.x;
+        const u64x2 g  = u64x2{(unsigned long long)__double_as_longlong(v), seq};
+        unsigned long long* p = out + 2 * (blockIdx.x * 16 + threadIdx.x);
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(g) : "memory");
+    }
+    if (threadIdx.x >= 192 && linger > 0) {
+        double x = acc;
+        for (int i = 0; i < linger; ++i) x = x * 1.0000001 + 1e-9;
+        if (x == 12345.678) sink[0] = x;
+    }
+}
+
 #ifndef PROBE_DEVICE_ONLY
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
@@ -118,6 +143,14 @@ int main(int argc, char** argv) {
     HK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &priv));
     HK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &kasz));
     std::printf("kernel object %#llx, group %u B, private %u B, kernarg %u B (explicit struct %zu B)\n", (unsigned long long)kobj, group, priv, kasz, sizeof(KernArgs));
+    hsa_executable_symbol_t sym_s;
+    HK(hsa_executable_get_symbol_by_name(exe, "tag5s.kd", &g_gpu, &sym_s));
+    uint64_t kobj_s = 0;
+    uint32_t group_s = 0;
+    HK(hsa_executable_symbol_get_info(sym_s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &kobj_s));
+    HK(hsa_executable_symbol_get_info(sym_s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &group_s));
+    bool use_s = false;
+    int linger = 0;
     hsa_queue_t* q = nullptr;
     HK(hsa_queue_create(g_gpu, 1024, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));
     // kernarg ring: mapped pinned host memory (GPU fetches the arguments over PCIe) or fine-grained device memory written through the BAR
@@ -134,7 +167,7 @@ int main(int argc, char** argv) {
     auto dispatch = [&](unsigned long long s) {
         const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
         while (idx - hsa_queue_load_read_index_relaxed(q) >= q->size) _mm_pause();
-        KernArgs ka{d_state, n_state, 0, d_tag, s, 256, 0};
+        struct { KernArgs k; double* sink; } ka{{d_state, n_state, 0, d_tag, s, 256, linger}, d_state};
         char* slot = h_ka + (idx & 63) * 256;
         std::memcpy(slot, &ka, sizeof ka);
         hsa_kernel_dispatch_packet_t* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(q->base_address) + (idx & mask);
@@ -142,8 +175,8 @@ int main(int argc, char** argv) {
         p->workgroup_size_x     = 256; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
         p->grid_size_x          = 256 * nwg; p->grid_size_y = 1; p->grid_size_z = 1;
         p->private_segment_size = priv;
-        p->group_segment_size   = group;
-        p->kernel_object        = kobj;
+        p->group_segment_size   = use_s ? group_s : group;
+        p->kernel_object        = use_s ? kobj_s : kobj;
         p->kernarg_address      = d_ka + (idx & 63) * 256;
         p->reserved2            = 0;
         p->completion_signal.handle = 0;
@@ -183,6 +216,17 @@ int main(int argc, char** argv) {
     acq = HSA_FENCE_SCOPE_SYSTEM; rel = HSA_FENCE_SCOPE_AGENT;
     run("kernarg in VRAM (BAR), fences system/agent");
     // (release scope NONE: the tagged stores never reach the host -- they leave the L2 with the end-of-kernel release)
+    acq = HSA_FENCE_SCOPE_AGENT; rel = HSA_FENCE_SCOPE_AGENT;
+    linger = 20000;
+    use_s = true;
+    run("VRAM kernarg, agent/agent, results stored sc0 sc1, one wave per workgroup lingers");
+    acq = HSA_FENCE_SCOPE_AGENT; rel = HSA_FENCE_SCOPE_NONE;
+    run("VRAM kernarg, agent/none,  results stored sc0 sc1, one wave per workgroup lingers");
+    linger = 0;
+    acq = HSA_FENCE_SCOPE_AGENT; rel = HSA_FENCE_SCOPE_AGENT;
+    run("VRAM kernarg, agent/agent, results stored sc0 sc1");
+    acq = HSA_FENCE_SCOPE_AGENT; rel = HSA_FENCE_SCOPE_NONE;
+    run("VRAM kernarg, agent/none,  results stored sc0 sc1");
     hsa_queue_destroy(q);
     return 0;
 }

@@ -674,7 +674,8 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     // Where this step's kernels go: the direct queue (hc_direct.hpp) when the step comes from hc_step and needs no plain
     // convolution launch -- the steady state of a look-ahead run -- else the HIP stream.  Nothing orders the two against each
     // other on the device, so the side that was used last is drained at a switch.
-    const bool direct = c->direct_ready && host_tagged && stream == c->stream && !f.scratch_out && !((run_rad && !block) || nchunks_ex > 0) &&
+    const bool direct = c->direct_ready && host_tagged && stream == c->stream && !f.scratch_out &&
+                        (c->dk_step.ok() || !((run_rad && !block) || nchunks_ex > 0)) &&
                         !(c->profiling && profiling_tool_attached());  // the library's own timings under a tool: HIP events
     if (direct && c->path != 2) {
         if (c->have_last_stream && c->last_stream != c->stream) HC_HIP(hipDeviceSynchronize());  // the last step ran on a caller's stream
@@ -719,9 +720,17 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         a.error_flag          = c->d_err.p;
         const double rad_b = 8.0 * (static_cast<double>(c->Dloc) * a.F_limit + a.F_limit);
         const double exc_b = nchunks_ex > 0 ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
-        hc::EventPair* ev = ev_begin(c, nchunks_rad > 0 ? hc::kEvConvPlain : hc::kEvConvExc, stream, exc_b / std::max(1.0, rad_b + exc_b));
-        hc::launch_conv_step(a, c->mt, stream);
-        ev_end(ev, stream);
+        const int kind     = nchunks_rad > 0 ? hc::kEvConvPlain : hc::kEvConvExc;
+        const double share = exc_b / std::max(1.0, rad_b + exc_b);
+        if (direct) {
+            const hc::StepLaunch l = hc::step_launch_config(a, c->mt);
+            if (l.nblocks > 0)
+                c->dq->dispatch(c->dk_step, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &a, sizeof a, direct_tag(c, kind), share);
+        } else {
+            hc::EventPair* ev = ev_begin(c, kind, stream, share);
+            hc::launch_conv_step(a, c->mt, stream);
+            ev_end(ev, stream);
+        }
     }
 
     hc::FinalizeArgs z{};
@@ -966,6 +975,15 @@ void setup_direct(hc_ctx* c) {
     c->dk_scatter  = q->find("scatter_kernelE");
     c->dk_reduce   = q->find("reduce_block_kernelE");
     c->dk_added_mass = q->find("added_mass_mv_tagged_kernelE");  // optional: hc_added_mass_mv falls back to a HIP launch
+    {   // the plain per-step convolution of this context's tiling; optional: without it plain steps go through HIP launches
+        hc::StepArgs a{};
+        a.ngroups = 1;
+        const hc::StepLaunch l = hc::step_launch_config(a, c->mt);
+        char frag[64];
+        std::snprintf(frag, sizeof frag, "conv_step_kernelILi%dELi%dEEEv", l.MT, l.U);
+        c->dk_step = q->find(frag);
+        if (c->dk_step.kernarg != sizeof(hc::StepArgs) || c->dk_step.priv != 0) c->dk_step = hc::DirectKernel{};
+    }
     for (int depth : {16, 32}) {
         hc::BlockArgs a{}, b{};
         a.depth = depth;

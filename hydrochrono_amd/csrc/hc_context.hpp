@@ -137,7 +137,7 @@ struct hc_ctx {
     bool direct_ready   = false;
     std::string direct_why;  // why the direct path is not in use
     int path            = 0;
-    hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_added_mass;
+    hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_added_mass, dk_step;
     int busy_caller_steps   = 0;  // hc_step_device: steps left before the caller's stream is queried again (see enqueue_step)
     std::string err;
 

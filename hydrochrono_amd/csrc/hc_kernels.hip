@@ -319,17 +319,25 @@ static void launch_conv_step_mt(const StepArgs& a, int unroll, int nblocks, size
     else hipLaunchKernelGGL((conv_step_kernel<MT, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
 }
 
-void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
-    const int nblocks = ((a.nchunks_rad + a.nchunks_ex + 7) >> 3) * 8 * a.ngroups;  // octets of chunks (kernel's block mapping)
-    if (nblocks <= 0) return;
+StepLaunch step_launch_config(const StepArgs& a, int mt) {
+    StepLaunch l;
+    l.nblocks = ((a.nchunks_rad + a.nchunks_ex + 7) >> 3) * 8 * a.ngroups;  // octets of chunks (kernel's block mapping)
     static const int unroll = [] {
         const char* e = std::getenv("HC_CONV_UNROLL");  // tuning experiments only
         return e ? std::atoi(e) : 2;
     }();
-    const size_t smem = (size_t)a.rhs_capacity * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * (sizeof(Bracket) + sizeof(double));
-    if (mt == 4) launch_conv_step_mt<4>(a, unroll, nblocks, smem, stream);
-    else if (mt == 2) launch_conv_step_mt<2>(a, unroll, nblocks, smem, stream);
-    else launch_conv_step_mt<1>(a, unroll, nblocks, smem, stream);
+    l.smem = (size_t)a.rhs_capacity * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * (sizeof(Bracket) + sizeof(double));
+    l.MT   = (mt == 4 || mt == 2) ? mt : 1;
+    l.U    = (unroll == 1 || unroll == 3) ? unroll : 2;
+    return l;
+}
+
+void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
+    const StepLaunch l = step_launch_config(a, mt);
+    if (l.nblocks <= 0) return;
+    if (l.MT == 4) launch_conv_step_mt<4>(a, l.U, l.nblocks, l.smem, stream);
+    else if (l.MT == 2) launch_conv_step_mt<2>(a, l.U, l.nblocks, l.smem, stream);
+    else launch_conv_step_mt<1>(a, l.U, l.nblocks, l.smem, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

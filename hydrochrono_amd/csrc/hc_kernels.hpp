@@ -226,6 +226,12 @@ struct FinalizeLaunch {
     bool wide   = false;  // finalize_kernel<16> (1024 threads) instead of finalize_kernel<4>
 };
 FinalizeLaunch finalize_launch_config(FinalizeArgs& a);  // also fills a.nblocks
+struct StepLaunch {
+    int nblocks = 0;
+    size_t smem = 0;
+    int MT = 0, U = 0;  // conv_step_kernel<MT, U>
+};
+StepLaunch step_launch_config(const StepArgs& a, int mt);
 struct BlockLaunch {
     int nblocks = 0;
     size_t smem = 0;

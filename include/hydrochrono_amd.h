@@ -191,7 +191,7 @@ int hc_set_lookahead(hc_ctx* ctx, int steps);
 /* How hc_step hands its kernels to the GPU.  1: as AQL packets written straight into an HSA queue of the library's own (kernel
  * arguments stored through the PCIe BAR) -- the default when the stand-alone code object hc_kernels.co lies next to the library,
  * the device's memory is host-addressable and the system is not wide (D < 1536); it saves the 2.4-3.3 us a hipLaunchKernelGGL call
- * costs the host on the critical path of every step.  0: through HIP launches on the context's stream (HC_DIRECT=0 forces this);
+ * costs the host on the critical path of every step (all kernels of hc_step and hc_added_mass_mv go this way).  0: through HIP launches on the context's stream (HC_DIRECT=0 forces this);
  * hc_dispatch_mode_reason then says why.  The kernels and the results are the same either way.  hc_step_device always uses HIP,
  * and so does hc_step while hc_enable_profiling is on under a tool that intercepts HSA queues (rocprofv3): the tool sees direct
  * dispatches too, but the completion signals the library's own timings rest on are then the tool's. */

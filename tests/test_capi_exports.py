@@ -60,3 +60,17 @@ def test_cpp_mirror_header_and_example_compile_and_link(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "examples", "sphere_mock_chrono.cpp"), "-o", out,
                     "-L", libdir, "-lhydrochrono_amd", f"-Wl,-rpath,{libdir}"], check=True)
     assert os.path.exists(out)
+
+
+def test_kernel_code_object_is_built_next_to_the_library():
+    """build() also leaves the kernels as a stand-alone gfx950 code object: hc_step loads it through the HSA loader and writes
+    its AQL packets itself (hydrochrono_amd/csrc/hc_direct.hpp).  Without the file the library falls back to HIP launches, so
+    its absence would go unnoticed on the GPU -- it is checked here."""
+    from hydrochrono_amd import build as hb
+    assert os.path.exists(hb.KERNEL_CO), "run __graft_entry__.build()"
+    blob = open(hb.KERNEL_CO, "rb").read()
+    assert blob[:4] == b"\x7fELF" and len(blob) > 100_000
+    for name in (b"finalize_kernelILi4E", b"scatter_kernelE", b"reduce_block_kernelE", b"conv_block_kernelILi6ELi4ELi2ELi1E",
+                 b"conv_block_kernelILi6ELi3ELi1ELi2E", b"conv_step_kernelILi4ELi2E", b"added_mass_mv_tagged_kernelE"):
+        assert name in blob, name
+    assert os.path.getmtime(hb.KERNEL_CO) >= os.path.getmtime(os.path.join(hb.CSRC, "hc_kernels.hip"))

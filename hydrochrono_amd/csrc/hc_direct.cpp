@@ -8,6 +8,7 @@
 #include <unistd.h>
 #include <xmmintrin.h>
 
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <iterator>

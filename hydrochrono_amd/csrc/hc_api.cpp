@@ -116,6 +116,7 @@ void ring_alloc(hc_ctx* c, int cap) {
 
 // Grow the ring so that `need` samples fit, keeping the `have` newest stored samples (k = 0..have-1) in order.
 void ring_grow(hc_ctx* c, int need, int have) {
+    quiesce_direct(c);               // the scatter / pass of the last step may still be reading the ring on the direct queue
     HC_HIP(hipDeviceSynchronize());  // rare; steps may have been enqueued on a caller's stream (hc_step_device)
     const int cap2 = std::max(2 * c->Hcap, need + 16);
     hc::DeviceBuffer<double> nt, nv;

@@ -27,7 +27,7 @@ class TaperedDirectOptions(C.Structure):
     """hc_tapered_direct_options == TestHydro::TaperedDirectOptions (include/hydroc/hydro_forces.h:246-259)."""
     _fields_ = [("smoothing", C.c_int), ("window_length", C.c_int), ("rirf_end_time", C.c_double),
                 ("taper_start_percent", C.c_double), ("taper_end_percent", C.c_double),
-                ("taper_final_amplitude", C.c_double)]
+                ("taper_final_amplitude", C.c_double), ("export_plot_csv", C.c_int)]
 
 
 class ProfileStats(C.Structure):
@@ -38,7 +38,8 @@ class ProfileStats(C.Structure):
                 ("block_kernel_launches", C.c_longlong), ("block_kernel_bytes", C.c_double),
                 ("block_kernel_bytes_once", C.c_double),
                 ("step_kernel_seconds", C.c_double), ("step_kernel_launches", C.c_longlong),
-                ("scatter_kernel_seconds", C.c_double), ("scatter_kernel_launches", C.c_longlong)]
+                ("scatter_kernel_seconds", C.c_double), ("scatter_kernel_launches", C.c_longlong),
+                ("direct_dispatches", C.c_longlong), ("hip_launches", C.c_longlong), ("history_rewinds", C.c_longlong)]
 
 
 # name -> (restype, argtypes); every symbol include/hydrochrono_amd.h declares
@@ -68,7 +69,14 @@ SIGNATURES = {
     "hc_set_convolution_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "hc_tapered_direct_options_default": (None, [C.POINTER(TaperedDirectOptions)]),
     "hc_set_tapered_direct_options": (C.c_int, [C.c_void_p, C.POINTER(TaperedDirectOptions)]),
+    "hc_set_diagnostics_output_directory": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "hc_get_shard": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "hc_get_excitation_irf_size": (C.c_int, [C.c_void_p, C.c_int, c_int_p]),
     "hc_step": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "hc_step_begin": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "hc_step_end": (C.c_int, [C.c_void_p, c_double_p]),
+    "hc_step_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "hc_added_mass_mv_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, c_double_p, C.c_double, c_double_p, C.c_int]),
     "hc_step_device": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_get_force_components": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "hc_compute_radiation": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p, c_double_p]),

@@ -9,10 +9,12 @@
 #include <xmmintrin.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <limits>
 #include <memory>
 
@@ -87,8 +89,18 @@ const char* kVersion = "hydrochrono_amd 0.1 (gfx950)";
     }                                                        \
     return HC_OK;
 
+// Bounded: a queue that does not drain within HC_STEP_TIMEOUT_S (or reports an error) is a lost device -> HC_ERR_DEVICE.
 void quiesce_direct(hc_ctx* c) {
-    if (c->dq && c->dq->busy()) c->dq->drain();
+    if (c->dq && c->dq->busy()) {
+        static const double limit = [] { const char* e = std::getenv("HC_STEP_TIMEOUT_S"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 20.0; }();
+        if (!c->dq->drain(limit)) {
+            c->lost         = true;
+            c->direct_ready = false;
+            c->direct_why   = c->dq->failed(0) ? "the HSA queue of the direct dispatch reported an error: " + c->dq->failure_text()
+                                               : std::string("the direct queue did not drain (timeout)");
+            throw Error(HC_ERR_DEVICE, c->direct_why);
+        }
+    }
     if (c->path == 2) c->path = 1;
 }
 
@@ -147,11 +159,28 @@ void ring_grow(hc_ctx* c, int need, int have) {
 }
 
 // Push the time of this step and prune like PruneHistory; returns H (samples incl. the current one).
+// A step BACK in time (an integrator that rejected a step and retries from an earlier time -- the YAML runner's HHT does): the
+// samples at times >= t belong to the abandoned attempt; they are dropped, the look-ahead plan with them, and the evaluation
+// continues from the history as it was at t.  (The reference has no such rule: it inserts the earlier time in front of its
+// newest-first list, src/hydro_forces.cpp:559-574, keeps the abandoned samples and walks a non-monotone list from then on; that
+// is deliberately not reproduced -- hc_set_history / hc_reset_history remain for callers that manage the history themselves.)
 int history_push(hc_ctx* c, double t) {
     if (!c->times.empty() && t == c->times.front())
         throw Error(HC_ERR_RUNTIME, "Tried to compute the radiation damping convolution twice within the same time step!");
-    if (!c->times.empty() && t < c->times.front())
-        throw Error(HC_ERR_INVALID, "hc_step: time must not decrease (the velocity history is ordered newest first)");
+    if (!c->times.empty() && t < c->times.front()) {
+        int dropped = 0;
+        while (!c->times.empty() && c->times.front() >= t) {
+            c->times.pop_front();
+            ++dropped;
+        }
+        // the ring keeps the dropped samples' slots for the samples to come; everything already enqueued (a scatter, a pass of the
+        // abandoned plan) runs before this step's kernels on the same queue, so nothing is overwritten under a reader
+        c->head = c->times.empty() ? -1 : ((c->head - dropped) % c->Hcap + c->Hcap) % c->Hcap;
+        c->plan.valid = false;
+        c->plan.misses = 0;
+        c->rewinds++;
+        c->prof.history_rewinds++;
+    }
     const double tau_last         = c->tau.empty() ? 0.0 : c->tau.back();
     const double history_min_time = t - tau_last;
     c->times.push_front(t);
@@ -357,6 +386,41 @@ void alloc_partials(hc_ctx* c) {
 }
 
 // ---- TaperedDirect ----------------------------------------------------------------------------
+// The diagnostics files of EnsureProcessedRIRF (src/hydro_forces.cpp:509-531): per body one rirf_body<b>_summary.csv (b 0-based)
+// with the representative channel row 0 / column 0 before and after the processing, rows s < effective_steps, numbers in the
+// default ostream format like the reference's `ofs << s << "," << t << "," << before << "," << after`.  Errors are ignored (:529).
+void export_taper_csv(hc_ctx* c, int effective) {
+    try {
+        const int n = std::max(0, std::min(effective, c->S));
+        hc::DeviceBuffer<double> d_before, d_after;
+        d_before.alloc(std::max(1, n));
+        d_after.alloc(std::max(1, n));
+        std::vector<double> before(n), after(n);
+        hc::Panel raw;
+        raw.base   = c->dK.p;
+        raw.ntiles = c->ntiles;
+        raw.ngp    = c->ngp;
+        hc::Panel proc = raw;
+        proc.base      = c->dKproc.p;
+        for (int bl = 0; bl < c->nloc; ++bl) {
+            if (n > 0) {
+                hc::launch_extract_series(raw, 6 * bl, 0, c->D, n, d_before.p, c->stream);
+                hc::launch_extract_series(proc, 6 * bl, 0, c->D, n, d_after.p, c->stream);
+                HC_HIP(hipMemcpyAsync(before.data(), d_before.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                HC_HIP(hipMemcpyAsync(after.data(), d_after.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                HC_HIP(hipStreamSynchronize(c->stream));
+            }
+            const std::string base = "rirf_body" + std::to_string(c->b0 + bl) + "_summary.csv";
+            const std::string path = c->diagnostics_dir.empty() ? base : (c->diagnostics_dir + "/" + base);
+            std::ofstream ofs(path);
+            ofs << "step,time,k_before,k_after\n";
+            for (int s_ = 0; s_ < n; ++s_) ofs << s_ << "," << c->tau[s_] << "," << before[s_] << "," << after[s_] << "\n";
+        }
+    } catch (...) {
+        (void)hipGetLastError();  // "ignore export errors"
+    }
+}
+
 void ensure_processed(hc_ctx* c) {
     if (c->conv_mode != 1 || c->proc_ready) return;
     const int steps = c->S;
@@ -395,6 +459,7 @@ void ensure_processed(hc_ctx* c) {
     HC_HIP(hipStreamSynchronize(c->stream));
     c->proc_ready = true;
     c->plan.valid = false;
+    if (c->taper.export_plot_csv) export_taper_csv(c, effective);
 }
 
 // ---- the step ---------------------------------------------------------------------------------
@@ -405,11 +470,13 @@ struct StepFlags {
 
 // the excitation-window tests of check_wave_ready as a predicate (for predicted step times)
 bool wave_window_ok(const hc_ctx* c, double t) {
-    if (c->wave_kind != hc::kWaveIrregular || c->eta_t.size() < 2 || c->ex_tau.empty()) return false;
+    if (c->wave_kind != hc::kWaveIrregular || c->eta_t.size() < 2 || c->ex_groups.empty()) return false;
     const double tmin = c->eta_t.front(), tmax = c->eta_t.back();
-    const double q0 = t - c->ex_tau.front(), q1 = t - c->ex_tau.back();
-    if (!(tmin <= q0 && q0 <= tmax) || !(tmin <= q1 && q1 <= tmax)) return false;
-    if (q0 > tmin && q0 < tmax && q0 <= c->eta_t[1]) return false;
+    for (const auto& g : c->ex_groups) {
+        const double q0 = t - g.tau_front, q1 = t - g.tau_back;
+        if (!(tmin <= q0 && q0 <= tmax) || !(tmin <= q1 && q1 <= tmax)) return false;
+        if (q0 > tmin && q0 < tmax && q0 <= c->eta_t[1]) return false;
+    }
     return true;
 }
 
@@ -419,13 +486,15 @@ void check_wave_ready(hc_ctx* c, double t) {
     if (c->wave_kind == hc::kWaveIrregular) {
         // ExcitationConvolution bounds (src/wave_types.cpp:784-794,833-840) and get_lower_index (src/helper.cpp:8-22)
         const double tmin = c->eta_t.front(), tmax = c->eta_t.back();
-        const double q0 = t - c->ex_tau.front(), q1 = t - c->ex_tau.back();
-        if (!(tmin <= q0 && q0 <= tmax) || !(tmin <= q1 && q1 <= tmax))
-            throw Error(HC_ERR_RUNTIME,
-                        "Excitation convolution: trying to find free surface elevation at a time out of bounds from the "
-                        "precomputed free surface elevation. Excitation force ignored at this time step.");
-        if (q0 > tmin && q0 < tmax && q0 <= c->eta_t[1])
-            throw Error(HC_ERR_RUNTIME, "Could not find index for value in free-surface time array (get_lower_index)");
+        for (const auto& g : c->ex_groups) {  // every body's grid (bodies with one grid share a group)
+            const double q0 = t - g.tau_front, q1 = t - g.tau_back;
+            if (!(tmin <= q0 && q0 <= tmax) || !(tmin <= q1 && q1 <= tmax))
+                throw Error(HC_ERR_RUNTIME,
+                            "Excitation convolution: trying to find free surface elevation at a time out of bounds from the "
+                            "precomputed free surface elevation. Excitation force ignored at this time step.");
+            if (q0 > tmin && q0 < tmax && q0 <= c->eta_t[1])
+                throw Error(HC_ERR_RUNTIME, "Could not find index for value in free-surface time array (get_lower_index)");
+        }
     }
 }
 
@@ -601,27 +670,93 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = fal
         if (l.nblocks <= 0) return;
         c->dq->dispatch(L == 32 ? c->dk_block32 : c->dk_block16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
                         direct_tag(c, hc::kEvPass), exc_share);
-        struct ReduceArgs {  // reduce_block_kernel's arguments as the kernel lays them out
-            const double* partials;
-            int nchunks_rad, nchunks_ex, Dpad, depth;
-            double *P, *E;
-            int* item_counter;
-        } r{c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter};
-        static_assert(sizeof(ReduceArgs) == 48, "kernarg layout of reduce_block_kernel");
+        c->prof.direct_dispatches += 1;
+        hc::ReduceArgs r{c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter};
         const int nblk = (L * c->Dpad + 15) / 16;
         c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(b.nchunks_ex > 0 ? 2 * nblk : nblk), 256, 0, &r, sizeof r);
+        c->prof.direct_dispatches += 1;
         return;
     }
     hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_share);
     hc::launch_conv_block(b, c->mt_block, stream);
     ev_end(ev, stream);
     hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter, stream);
+    c->prof.hip_launches += 2;
+}
+
+// Second half of a step's enqueue: the work LATER steps need (the scatter of this step's sample inside a look-ahead block, or
+// the plan and the pass of the next block).  Off the caller's critical path: it is enqueued behind the step kernel and runs
+// while the host is away.  On a caller's stream (hc_step_device) whose owner waits for every step it goes to the context's
+// own stream behind an event, so that whatever the caller enqueues next on its stream -- the all-gather of the force rows in
+// a multi-GPU run -- follows the step kernel directly.  hc_step_multi calls it after the step kernels of ALL shard contexts
+// have been handed to their GPUs.
+void enqueue_tail(hc_ctx* c) {
+    if (!c->tail.pending) return;
+    c->tail.pending        = false;
+    const bool block       = c->tail.block, direct = c->tail.direct, caller_waits = c->tail.caller_waits;
+    const int m            = c->tail.m, H = c->tail.H;
+    const hipStream_t stream = c->tail.stream;
+    const bool scatter_now = block && m < c->lookahead && c->plan.scat_hi[m] >= c->plan.scat_lo[m];
+    const bool plan_now    = (!block || m == c->lookahead) && H >= 2;
+    hipStream_t bs         = stream;
+    auto to_background = [&]() {
+        if (caller_waits && bs == stream) {
+            bs = c->stream;
+            HC_HIP(hipEventRecord(c->ev_fin, stream));
+            HC_HIP(hipStreamWaitEvent(bs, c->ev_fin, 0));
+        }
+    };
+    if (scatter_now) {
+        to_background();
+        const auto& pl = c->plan;
+        hc::ScatterArgs sa{};
+        sa.K     = rad_panel(c);
+        sa.D     = c->D;
+        sa.Dpad  = c->Dpad;
+        sa.s_lo  = pl.scat_lo[m];
+        sa.ns    = pl.scat_hi[m] - pl.scat_lo[m] + 1;
+        sa.v     = c->d_ring_v.p + static_cast<size_t>(c->head) * c->D;  // this step's sample, pushed by finalize_kernel
+        sa.width = c->d_width.p;
+        sa.Y     = c->d_Y.p;
+        for (int si = 0; si < sa.ns; ++si) {
+            const int s_ = sa.s_lo + si;
+            sa.n_tgt[si] = pl.n_tgt[m][s_];
+            for (int t = 0; t < pl.n_tgt[m][s_]; ++t) {
+                sa.tgt_off[si][t]  = (pl.tgt_step[m][s_][t] * hc::kTermMax + pl.tgt_k[m][s_][t]) * c->Dpad;
+                sa.tgt_coef[si][t] = pl.tgt_coef[m][s_][t];
+            }
+        }
+        if (direct) {
+            c->dq->dispatch(c->dk_scatter, static_cast<uint32_t>(sa.K.ntiles * sa.ns), 256, static_cast<uint32_t>(sa.D * sizeof(double)), &sa, sizeof sa,
+                            direct_tag(c, hc::kEvScatter));
+            c->prof.direct_dispatches += 1;
+        } else {
+            hc::EventPair* ev = ev_begin(c, hc::kEvScatter, bs);
+            hc::launch_scatter(sa, bs);
+            c->prof.hip_launches += 1;
+            ev_end(ev, bs);
+        }
+    } else if (plan_now) {
+        if (block) c->plan.misses = 0;  // a block was consumed completely
+        if (make_plan(c)) {
+            to_background();
+            launch_pass(c, bs, c->tail.waves, direct);
+        }
+    }
+    if (bs != stream) {
+        HC_HIP(hipEventRecord(c->ev_bg, bs));
+        c->bg_pending = true;
+    }
+    HC_HIP(hipGetLastError());
 }
 
 // Enqueue the kernels of one evaluation at time t.  d_state: device-visible pointer to the 12N state.  d_user_out
 // (device) and host_tagged (mapped pinned granules) may be null.
+// defer_tail: the caller enqueues the work later steps need itself (enqueue_tail) -- hc_step_multi, after all shard contexts
+// have their step kernels on the way.
 void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f,
-                  unsigned long long* host_tagged = nullptr, unsigned long long seq = 0) {
+                  unsigned long long* host_tagged = nullptr, unsigned long long seq = 0, bool defer_tail = false) {
+    require(!c->tail.pending, HC_ERR_INVALID, "a step begun with hc_step_begin has not been completed (hc_step_end)");
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     const bool irregular = c->wave_kind == hc::kWaveIrregular;
     if (f.waves) check_wave_ready(c, t);
@@ -725,11 +860,14 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         const double share = exc_b / std::max(1.0, rad_b + exc_b);
         if (direct) {
             const hc::StepLaunch l = hc::step_launch_config(a, c->mt);
-            if (l.nblocks > 0)
+            if (l.nblocks > 0) {
                 c->dq->dispatch(c->dk_step, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &a, sizeof a, direct_tag(c, kind), share);
+                c->prof.direct_dispatches += 1;
+            }
         } else {
             hc::EventPair* ev = ev_begin(c, kind, stream, share);
             hc::launch_conv_step(a, c->mt, stream);
+            c->prof.hip_launches += 1;
             ev_end(ev, stream);
         }
     }
@@ -825,67 +963,26 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     if (direct) {
         const hc::FinalizeLaunch l = hc::finalize_launch_config(z);
         c->dq->dispatch(c->dk_finalize, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &z, sizeof z, direct_tag(c, hc::kEvStep));
+        c->prof.direct_dispatches += 1;
     } else {
         hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
         hc::launch_finalize(z, stream);
+        c->prof.hip_launches += 1;
         ev_end(ev, stream);
     }
 
-    // ---- off the caller's critical path: everything below is needed by later steps only ----
-    // On a caller's stream (hc_step_device) whose owner waits for every step it goes to the context's own stream behind an
-    // event, so that whatever the caller enqueues next on its stream -- the all-gather of the force rows in a multi-GPU run --
-    // follows the step kernel directly.
-    if (f.rad && c->lookahead > 0) {
-        const bool scatter_now = block && m < c->lookahead && c->plan.scat_hi[m] >= c->plan.scat_lo[m];
-        const bool plan_now    = (!block || m == c->lookahead) && H >= 2;
-        hipStream_t bs         = stream;
-        auto to_background = [&]() {
-            if (caller_waits && bs == stream) {
-                bs = c->stream;
-                HC_HIP(hipEventRecord(c->ev_fin, stream));
-                HC_HIP(hipStreamWaitEvent(bs, c->ev_fin, 0));
-            }
-        };
-        if (scatter_now) {
-            to_background();
-            const auto& pl = c->plan;
-            hc::ScatterArgs sa{};
-            sa.K     = rad_panel(c);
-            sa.D     = c->D;
-            sa.Dpad  = c->Dpad;
-            sa.s_lo  = pl.scat_lo[m];
-            sa.ns    = pl.scat_hi[m] - pl.scat_lo[m] + 1;
-            sa.v     = c->d_ring_v.p + static_cast<size_t>(c->head) * c->D;  // this step's sample, pushed by finalize_kernel
-            sa.width = c->d_width.p;
-            sa.Y     = c->d_Y.p;
-            for (int si = 0; si < sa.ns; ++si) {
-                const int s_ = sa.s_lo + si;
-                sa.n_tgt[si] = pl.n_tgt[m][s_];
-                for (int t = 0; t < pl.n_tgt[m][s_]; ++t) {
-                    sa.tgt_off[si][t]  = (pl.tgt_step[m][s_][t] * hc::kTermMax + pl.tgt_k[m][s_][t]) * c->Dpad;
-                    sa.tgt_coef[si][t] = pl.tgt_coef[m][s_][t];
-                }
-            }
-            if (direct) {
-                c->dq->dispatch(c->dk_scatter, static_cast<uint32_t>(sa.K.ntiles * sa.ns), 256, static_cast<uint32_t>(sa.D * sizeof(double)), &sa, sizeof sa,
-                                direct_tag(c, hc::kEvScatter));
-            } else {
-                hc::EventPair* ev = ev_begin(c, hc::kEvScatter, bs);
-                hc::launch_scatter(sa, bs);
-                ev_end(ev, bs);
-            }
-        } else if (plan_now) {
-            if (block) c->plan.misses = 0;  // a block was consumed completely
-            if (make_plan(c)) {
-                to_background();
-                launch_pass(c, bs, f.waves, direct);
-            }
-        }
-        if (bs != stream) {
-            HC_HIP(hipEventRecord(c->ev_bg, bs));
-            c->bg_pending = true;
-        }
-    }
+    // ---- off the caller's critical path: what later steps need from this one (enqueue_tail) ----
+    c->tail              = hc::StepTail{};
+    c->tail.pending      = f.rad && c->lookahead > 0;
+    c->tail.rad          = f.rad;
+    c->tail.waves        = f.waves;
+    c->tail.block        = block;
+    c->tail.direct       = direct;
+    c->tail.caller_waits = caller_waits;
+    c->tail.m            = m;
+    c->tail.H            = H;
+    c->tail.stream       = stream;
+    if (!defer_tail) enqueue_tail(c);
     HC_HIP(hipGetLastError());
 
     if (f.hs) c->prof.hydrostatics_calls++;
@@ -968,7 +1065,7 @@ void setup_direct(hc_ctx* c) {
     if (env_int("HC_DIRECT", 1) == 0) { c->direct_why = "disabled by HC_DIRECT=0"; return; }
     if (std::getenv("HC_BLOCK_V32")) { c->direct_why = "HC_BLOCK_V32 selects a tuning variant of the pass"; return; }
     if (c->D >= 1536) { c->direct_why = "wide system: its step kernel variant needs scratch memory"; return; }
-    if (!c->bar_state.host_ok) { c->direct_why = "the device's memory is not host-addressable"; return; }
+    if (!c->bar_state.host_ok || !c->bar_am.host_ok) { c->direct_why = "the device's memory is not host-addressable"; return; }
     std::unique_ptr<hc::DirectQueue> q(new hc::DirectQueue);
     std::string why;
     if (!q->init(c->device, library_dir() + "/hc_kernels.co", &why)) { c->direct_why = why; return; }
@@ -1000,7 +1097,7 @@ void setup_direct(hc_ctx* c) {
     }
     // the code object must be the one built with this library: its kernels take exactly these argument blocks
     if (c->dk_finalize.kernarg != sizeof(hc::FinalizeArgs) || c->dk_scatter.kernarg != sizeof(hc::ScatterArgs) ||
-        c->dk_block16.kernarg != sizeof(hc::BlockArgs) || c->dk_block32.kernarg != sizeof(hc::BlockArgs) || c->dk_reduce.kernarg != 48) {
+        c->dk_block16.kernarg != sizeof(hc::BlockArgs) || c->dk_block32.kernarg != sizeof(hc::BlockArgs) || c->dk_reduce.kernarg != sizeof(hc::ReduceArgs)) {
         c->direct_why = "hc_kernels.co was not built from the same sources as this library (argument block sizes differ)";
         return;
     }
@@ -1008,10 +1105,17 @@ void setup_direct(hc_ctx* c) {
         c->direct_why = "a kernel needs scratch memory";
         return;
     }
-    // self-test: one dispatch of the reduction kernel with nothing to add must clear a marked word of P
+    if (!c->dk_added_mass.ok() || c->dk_added_mass.kernarg != sizeof(hc::AddedMassArgs) || c->dk_added_mass.priv != 0) {
+        c->direct_why = "added_mass_mv_tagged_kernel is missing from hc_kernels.co";
+        return;
+    }
+    static_assert(sizeof(hc::ScatterArgs) <= hc::DirectQueue::kSlotBytes && sizeof(hc::FinalizeArgs) <= hc::DirectQueue::kSlotBytes &&
+                      sizeof(hc::BlockArgs) <= hc::DirectQueue::kSlotBytes && sizeof(hc::StepArgs) <= hc::DirectQueue::kSlotBytes,
+                  "an argument block does not fit a kernarg slot of the direct queue");
+    // self-test 1: one dispatch of the reduction kernel with nothing to add must clear a marked word of P
     const double mark = 1.0;
     HC_HIP(hipMemcpy(c->d_P.p, &mark, sizeof mark, hipMemcpyHostToDevice));
-    struct { const double* partials; int a, b, Dpad, depth; double *P, *E; int* counter; } r{c->d_partials_block.p, 0, 0, c->Dpad, 1, c->d_P.p, c->d_E.p, c->d_err.p + 1};
+    hc::ReduceArgs r{c->d_partials_block.p, 0, 0, c->Dpad, 1, c->d_P.p, c->d_E.p, c->d_err.p + 1};
     q->dispatch(c->dk_reduce, static_cast<uint32_t>((c->Dpad + 15) / 16), 256, 0, &r, sizeof r);
     if (!q->drain(2.0)) {
         c->direct_why = "self-test of the direct dispatch timed out";
@@ -1021,6 +1125,59 @@ void setup_direct(hc_ctx* c) {
     double back = -1.0;
     HC_HIP(hipMemcpy(&back, c->d_P.p, sizeof back, hipMemcpyDeviceToHost));
     if (back != 0.0) { c->direct_why = "self-test of the direct dispatch failed"; return; }
+    // self-test 2: what the host RE-writes through the BAR must be what the next dispatch reads.  The dispatches carry agent-scope
+    // acquire fences only, so this rests on the GPU not keeping stale copies of fine-grained device memory across kernels -- for
+    // the state buffer (two halves, rewritten every second step) and for the kernarg ring (64 slots per lane, reused every 64
+    // dispatches).  Checked here on both lanes: 2 x 64 + 3 one-row added-mass products whose inputs (w, R_in: the SAME two BAR
+    // words every time) and whose argument slot change from dispatch to dispatch; every result must be the one of the values
+    // written last.  A stale read fails the test and the context keeps using HIP launches.
+    {
+        const double one = 1.0;
+        HC_HIP(hipMemcpy(c->d_P.p, &one, sizeof one, hipMemcpyHostToDevice));  // the 1 x 1 "matrix"
+        volatile unsigned long long* tag = c->h_tag_am.p;
+        for (int lane = 0; lane < hc::DirectQueue::kLanes; ++lane) {
+            for (int i = 0; i < 2 * 64 + 3; ++i) {
+                const double wv = 3.0 + i, rv = 0.25 * (i + 1) + lane, cv = 0.5 + 0.125 * (i % 7);
+                c->bar_am.p[0] = wv;
+                c->bar_am.p[1] = rv;
+                _mm_sfence();
+                const unsigned long long sq = 0xABC000ull + static_cast<unsigned long long>(lane) * 1000 + i;
+                hc::AddedMassArgs a{c->d_P.p, 1, 1, c->bar_am.p, c->bar_am.p + 1, cv, c->h_tag_am.dp, sq};
+                q->dispatch(c->dk_added_mass, 1, 256, 0, &a, sizeof a, -1, 0.0, lane);
+                const auto t0 = std::chrono::steady_clock::now();
+                bool arrived  = false;
+                for (unsigned long long spins = 0;; ++spins) {
+                    if (tag[1] == sq) { arrived = true; break; }
+                    __builtin_ia32_pause();
+                    if ((spins & 0xFFF) == 0xFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+                }
+                if (!arrived) {
+                    // either the dispatch hangs or it ran with the arguments of the slot's previous use (an old sequence number)
+                    if (q->drain(2.0, lane)) {
+                        c->direct_why = "self-test of the direct dispatch: a re-used kernel-argument slot was read stale";
+                    } else {
+                        c->direct_why = "self-test of the direct dispatch timed out";
+                        (void)q.release();
+                    }
+                    return;
+                }
+                const unsigned long long bits = tag[0];
+                double got;
+                std::memcpy(&got, &bits, sizeof got);
+                if (got != rv + cv * wv) {
+                    c->direct_why = "self-test of the direct dispatch: memory re-written through the PCIe BAR was read stale";
+                    (void)q->drain(2.0, lane);
+                    return;
+                }
+            }
+            if (!q->drain(2.0, lane)) {
+                c->direct_why = "self-test of the direct dispatch timed out";
+                (void)q.release();
+                return;
+            }
+        }
+        std::memset(c->h_tag_am.p, 0, c->h_tag_am.n * sizeof(unsigned long long));
+    }
     c->dq           = q.release();
     c->direct_ready = true;
     c->direct_why.clear();
@@ -1443,42 +1600,73 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     require(p.simulation_dt > 0.0, HC_ERR_INVALID, "simulation_dt must be positive");
     require(p.wave_height != 0.0 && p.wave_period != 0.0, HC_ERR_INVALID,
             "wave_height and wave_period must be non-zero (the reference leaves the free-surface table empty otherwise)");
-    for (int b = c->b0; b < c->b1; ++b) require(c->bodies[b].have_exirf, HC_ERR_INVALID, "excitation IRF missing for a local body");
-    // All bodies must share the excitation-IRF time grid (BEMIO writes one grid per file); the reference would
-    // allow per-body grids, this path does not.
-    const auto& t_old = c->bodies[c->b0].exirf_t;
+    // Excitation-IRF time grids.  The reference keeps one grid per body (ex_irf_time_sampled_[b], src/wave_types.cpp:432-459) and
+    // resamples each on its own (:572-606).  BEMIO writes one grid per file, so bodies normally share it; bodies with the same
+    // grid (within 1e-10, the tolerance the reference applies to the radiation grids) form a group, and the columns of Kex are
+    // the groups' resampled grids one after the other -- a body's rows are non-zero in the columns of its own group only, so
+    // one launch still serves all bodies.  Groups are formed over ALL bodies (not only the local ones): the column layout, and
+    // with it the summation order, is the same in every row shard of the system.
+    std::vector<hc::ExGroup> groups;
+    std::vector<int> group_of(c->N, -1);
     for (int b = 0; b < c->N; ++b) {
-        if (!c->bodies[b].have_exirf) continue;
+        if (!c->bodies[b].have_exirf) {
+            // a row-sharded context whose caller ingested its own bodies only: the other bodies' grids are unknown here
+            require(!is_local(c, b), HC_ERR_INVALID, "excitation IRF missing for a local body");
+            continue;
+        }
         const auto& tb = c->bodies[b].exirf_t;
-        require(tb.size() == t_old.size(), HC_ERR_UNSUPPORTED, "bodies with different excitation-IRF time grids are not supported");
-        for (size_t j = 0; j < tb.size(); ++j)
-            require(std::fabs(tb[j] - t_old[j]) <= 1e-10, HC_ERR_UNSUPPORTED, "bodies with different excitation-IRF time grids are not supported");
+        require(tb.size() >= 2, HC_ERR_INVALID, "excitation IRF with fewer than two samples");
+        for (size_t g = 0; g < groups.size() && group_of[b] < 0; ++g) {
+            const auto& tg = c->bodies[groups[g].first_body].exirf_t;
+            bool same = tg.size() == tb.size();
+            for (size_t j = 0; j < tb.size() && same; ++j) same = std::fabs(tb[j] - tg[j]) <= 1e-10;
+            if (same) group_of[b] = static_cast<int>(g);
+        }
+        if (group_of[b] < 0) {
+            hc::ExGroup g;
+            g.first_body = b;
+            group_of[b]  = static_cast<int>(groups.size());
+            groups.push_back(g);
+        }
     }
-    const int n_old = static_cast<int>(t_old.size());
-    // ResampleIRF (src/wave_types.cpp:572-606)
-    const double t0 = t_old.front(), t1 = t_old.back();
-    const int L = static_cast<int>(std::ceil((t1 - t0) / p.simulation_dt));
-    require(L >= 2, HC_ERR_INVALID, "excitation IRF resamples to fewer than two points");
-    std::vector<double> ex_tau   = hc::linspaced(L, t0, t1);
-    std::vector<double> ex_width = hc::trapezoid_widths(ex_tau);
+    // ResampleIRF (src/wave_types.cpp:572-606), per group
+    std::vector<double> ex_tau, ex_width;
+    int L = 0;
+    for (auto& g : groups) {
+        const auto& t_old = c->bodies[g.first_body].exirf_t;
+        const double t0 = t_old.front(), t1 = t_old.back();
+        g.L   = static_cast<int>(std::ceil((t1 - t0) / p.simulation_dt));
+        require(g.L >= 2, HC_ERR_INVALID, "excitation IRF resamples to fewer than two points");
+        g.off = L;
+        const std::vector<double> tg = hc::linspaced(g.L, t0, t1), wg = hc::trapezoid_widths(tg);
+        g.tau_front = tg.front();
+        g.tau_back  = tg.back();
+        ex_tau.insert(ex_tau.end(), tg.begin(), tg.end());
+        ex_width.insert(ex_width.end(), wg.begin(), wg.end());
+        L += g.L;
+    }
     const int Lpad = (L + 7) & ~7;
-    std::vector<double> vals(static_cast<size_t>(c->Dloc) * L);
+    std::vector<double> vals(static_cast<size_t>(c->Dloc) * L, 0.0);
     for (int bl = 0; bl < c->nloc; ++bl) {
-        const auto r = hc::resample_cubic_bspline6(c->bodies[c->b0 + bl].exirf_f, n_old, L);
+        const auto& bd = c->bodies[c->b0 + bl];
+        const hc::ExGroup& g = groups[group_of[c->b0 + bl]];
+        const auto r = hc::resample_cubic_bspline6(bd.exirf_f, static_cast<int>(bd.exirf_t.size()), g.L);
         for (int d = 0; d < 6; ++d)
-            std::copy(r.begin() + static_cast<size_t>(d) * L, r.begin() + static_cast<size_t>(d + 1) * L,
-                      vals.begin() + static_cast<size_t>(6 * bl + d) * L);
+            std::copy(r.begin() + static_cast<size_t>(d) * g.L, r.begin() + static_cast<size_t>(d + 1) * g.L,
+                      vals.begin() + static_cast<size_t>(6 * bl + d) * L + g.off);
     }
     // CreateSpectrum (:643-676)
     Spectrum sp = build_spectrum(c, p);
     const int nf = sp.nf;
     std::vector<double>&f = sp.f, &Sd = sp.S, &dfv = sp.df, &phase = sp.phase, &kk = sp.k, &amp = sp.amp, &omg = sp.omega;
-    // CreateFreeSurfaceElevation (:717-774); all bodies share ex_tau, so the min/max scan reduces to its ends
+    // CreateFreeSurfaceElevation (:717-774): the min/max scan over every body's resampled grid = over the groups' ends
     double t_irf_min = 0.0, t_irf_max = 0.0;
-    if (ex_tau.front() < t_irf_min) t_irf_min = ex_tau.front();
-    if (ex_tau.front() > t_irf_max) t_irf_max = ex_tau.front();
-    if (ex_tau.back() > t_irf_max) t_irf_max = ex_tau.back();
-    if (ex_tau.back() < t_irf_min) t_irf_min = ex_tau.back();
+    for (const auto& g : groups) {
+        if (g.tau_front < t_irf_min) t_irf_min = g.tau_front;
+        if (g.tau_front > t_irf_max) t_irf_max = g.tau_front;
+        if (g.tau_back > t_irf_max) t_irf_max = g.tau_back;
+        if (g.tau_back < t_irf_min) t_irf_min = g.tau_back;
+    }
     const double duration = p.simulation_duration + 2 * (t_irf_max - t_irf_min);
     const int nts         = static_cast<int>(std::ceil(duration / p.simulation_dt));
     std::vector<double> eta_t = hc::linspaced(nts + 1, 0, nts * p.simulation_dt);
@@ -1522,6 +1710,8 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     c->ex_tau.swap(ex_tau);
     c->ex_width.swap(ex_width);
     c->ex_vals.swap(vals);
+    c->ex_groups.swap(groups);
+    c->ex_group_of.swap(group_of);
     c->spec_f.swap(f);
     c->spec_S.swap(Sd);
     c->spec_df.swap(dfv);
@@ -1614,6 +1804,13 @@ void hc_tapered_direct_options_default(hc_tapered_direct_options* o) {
     o->taper_start_percent = 0.8;
     o->taper_end_percent = 1.0;
     o->taper_final_amplitude = 0.0;
+    o->export_plot_csv = 0;
+}
+
+int hc_set_diagnostics_output_directory(hc_ctx* c, const char* dir) {
+    HC_API_BEGIN(c)
+    c->diagnostics_dir = dir ? dir : "";
+    HC_API_END(c)
 }
 
 int hc_set_tapered_direct_options(hc_ctx* c, const hc_tapered_direct_options* o) {
@@ -1628,27 +1825,52 @@ int hc_set_tapered_direct_options(hc_ctx* c, const hc_tapered_direct_options* o)
 
 // ---- per-step ---------------------------------------------------------------------------------
 namespace {
+double step_timeout_seconds() {
+    static const double s = [] {
+        const char* e = std::getenv("HC_STEP_TIMEOUT_S");
+        const double v = e ? std::atof(e) : 0.0;
+        return v > 0.0 ? v : 20.0;
+    }();
+    return s;
+}
+
+[[noreturn]] void device_lost(hc_ctx* c, const std::string& what) {
+    c->lost         = true;
+    c->direct_ready = false;  // nothing more goes to a queue that has stopped answering
+    c->direct_why   = what;
+    throw Error(HC_ERR_DEVICE, what);
+}
+
 // Wait until finalize_kernel's {total, sequence} granules of step `seq` have all arrived in mapped pinned memory, then
 // copy the totals out.  Each granule is one 16-byte store, so its value is valid as soon as its sequence number is.  This
-// replaces hipStreamSynchronize on the per-step path (14 -> 9 us for an empty launch, profiles/r02/latency_probe_v1.txt);
-// the stream is queried from time to time so that a failed launch ends the wait with an error instead of hanging.
-void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long long seq, hipStream_t stream, double* out) {
+// replaces hipStreamSynchronize on the per-step path (14 -> 9 us for an empty launch, profiles/r02/latency_probe_v1.txt).
+// The wait is bounded: every 2^16 spins the slow path looks at the clock, at the queue's error flag (direct path) or at the
+// stream (HIP path), so a failed launch or a lost device ends the wait with HC_ERR_DEVICE after HC_STEP_TIMEOUT_S (20 s)
+// instead of hanging the host.
+void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long long seq, hipStream_t stream, double* out, int lane = 0) {
     const volatile unsigned long long* g = granules;
     unsigned long long spins = 0;
+    std::chrono::steady_clock::time_point t_begin{};
     for (int r = c->Dloc - 1; r >= 0; --r) {
         while (g[2 * r + 1] != seq) {
             __builtin_ia32_pause();
-            if ((++spins & 0x3FFFF) == 0) {
+            if ((++spins & 0xFFFF) == 0) {
+                const auto now = std::chrono::steady_clock::now();
+                if (spins == 0x10000) t_begin = now;
+                const bool timed_out = std::chrono::duration<double>(now - t_begin).count() > step_timeout_seconds();
                 if (stream == nullptr || (c->path == 2 && stream == c->stream)) {
-                    // the step went to the direct queue: there is no stream to ask; a dispatch that never completes is a lost device
-                    if (spins > (1ull << 34)) throw Error(HC_ERR_DEVICE, "hc_step: the step's results did not arrive (direct queue)");
+                    // the step went to the direct queue: there is no stream to ask
+                    if (c->dq && c->dq->failed(lane)) device_lost(c, "hc_step: the HSA queue of the direct dispatch reported an error: " + c->dq->failure_text());
+                    if (timed_out) device_lost(c, "hc_step: the step's results did not arrive (direct queue, timeout)");
                     continue;
                 }
                 const hipError_t q = hipStreamQuery(stream);
                 if (q == hipSuccess) {
-                    if (g[2 * r + 1] != seq) throw Error(HC_ERR_DEVICE, "hc_step: the stream drained but the step's results did not arrive");
+                    if (g[2 * r + 1] != seq) device_lost(c, "hc_step: the stream drained but the step's results did not arrive");
                 } else if (q != hipErrorNotReady) {
-                    throw Error(HC_ERR_DEVICE, std::string("hc_step: ") + hipGetErrorString(q));
+                    device_lost(c, std::string("hc_step: ") + hipGetErrorString(q));
+                } else if (timed_out) {
+                    device_lost(c, "hc_step: the step's results did not arrive (timeout)");
                 }
             }
         }
@@ -1658,31 +1880,34 @@ void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long lo
         std::memcpy(out + r, &bits, sizeof(double));
     }
 }
-}  // namespace
 
-int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel, double* force_out) {
-    HC_API_BEGIN_HOT(c)
+// First half of a synchronous step: cache rules of CoordinateFuncForBody (src/hydro_forces.cpp:742-751), the state stored where
+// the kernels read it, the step kernel handed to the GPU.  Leaves c->pending_step = 1 (cache hit, totals in last_total) or 2
+// (results arrive as tagged granules of sequence number c->seq).  defer_tail: see enqueue_step.
+void step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel, bool defer_tail) {
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
-    require(pos && rpy && linvel && angvel && force_out, HC_ERR_INVALID, "null pointer");
+    require(pos && rpy && linvel && angvel, HC_ERR_INVALID, "null pointer");
+    require(c->pending_step == 0, HC_ERR_INVALID, "the step begun before has not been completed (hc_step_end)");
+    if (c->lost) throw Error(HC_ERR_DEVICE, "the device stopped answering in an earlier step: " + c->direct_why);
     if (c->have_prev && t == c->prev_time) {  // src/hydro_forces.cpp:742-744
-        std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
-        return HC_OK;
+        c->pending_step = 1;
+        return;
     }
     if (c->have_prev_device && t == c->prev_time_device) {
         // this time was evaluated through hc_step_device (possibly on a caller's stream): fetch its totals, do not re-evaluate
         quiesce_direct(c);
         HC_HIP(hipDeviceSynchronize());
         HC_HIP(hipMemcpy(c->last_total.data(), c->d_total.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost));
-        c->prev_time = t;
-        c->have_prev = true;
-        std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
-        return HC_OK;
+        c->prev_time    = t;
+        c->have_prev    = true;
+        c->pending_step = 1;
+        return;
     }
     c->prev_time = t;  // :747 (set before the terms are computed, so a throwing step is not retried)
     c->have_prev = true;
     c->have_prev_device = false;  // d_total is about to be replaced (or left stale by a step that throws)
     std::fill(c->last_total.begin(), c->last_total.end(), 0.0);  // the reference zero-fills total_force_ before the terms (:749-751)
-    // Boundary without copy launches or stream synchronisation: the host stores the 12N state doubles straight into device
+    // Boundary without copy launches or stream synchronisation: the host stores the state doubles straight into device
     // memory through the PCIe BAR (fallback: mapped pinned memory the kernels read over PCIe), finalize_kernel stores the
     // totals straight into mapped pinned memory, tagged with this step's sequence number; one kernel launch for a step
     // inside a block.
@@ -1690,24 +1915,27 @@ int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const dou
     // workgroup that stores the step's sample into the ring may still be reading the state -- the next call must not
     // overwrite it.  (The kernels of step n+1 run after those of step n, and step n+2 starts only after the totals of
     // step n+1 have arrived, so two halves are enough.)
+    // A row-sharded context reads positions and angles of its OWN bodies only (hydrostatics), velocities of all: the other
+    // bodies' pos / rpy entries are not stored (half the bytes through the BAR for each shard of a wide array).
     const int n3   = 3 * c->N;
     const size_t o = (c->seq & 1) ? static_cast<size_t>(12) * c->N : 0;
+    const size_t l0 = static_cast<size_t>(3) * c->b0, ln = static_cast<size_t>(3) * c->nloc;
+    auto put = [&](double* h) {
+        std::memcpy(h + l0, pos + l0, ln * sizeof(double));
+        std::memcpy(h + n3 + l0, rpy + l0, ln * sizeof(double));
+        std::memcpy(h + 2 * n3, linvel, n3 * sizeof(double));
+        std::memcpy(h + 3 * n3, angvel, n3 * sizeof(double));
+    };
     const double* d_state;
     if (c->bar_state.host_ok) {
         // device memory written through the PCIe BAR: the kernels read the state locally (no PCIe read on the critical path)
         double* h = c->bar_state.p + o;
-        std::memcpy(h, pos, n3 * sizeof(double));
-        std::memcpy(h + n3, rpy, n3 * sizeof(double));
-        std::memcpy(h + 2 * n3, linvel, n3 * sizeof(double));
-        std::memcpy(h + 3 * n3, angvel, n3 * sizeof(double));
+        put(h);
         _mm_sfence();  // write-combined stores are globally visible before the doorbell of the launch
         d_state = h;
     } else {
         double* h = c->h_state.p + o;
-        std::memcpy(h, pos, n3 * sizeof(double));
-        std::memcpy(h + n3, rpy, n3 * sizeof(double));
-        std::memcpy(h + 2 * n3, linvel, n3 * sizeof(double));
-        std::memcpy(h + 3 * n3, angvel, n3 * sizeof(double));
+        put(h);
         d_state = c->h_state.dp + o;
         if (c->N > c->zero_copy_max_bodies) {  // many workgroups re-read the state: one small H2D copy beats their PCIe reads
             HC_HIP(hipMemcpyAsync(c->d_state.p, h, 4 * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1715,16 +1943,114 @@ int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const dou
         }
     }
     const unsigned long long seq = ++c->seq;
-    enqueue_step(c, t, d_state, nullptr, c->stream, StepFlags{}, c->h_tag.dp, seq);
-    wait_tagged(c, c->h_tag.p, seq, c->stream, c->last_total.data());
-    if (c->device_errors_possible) {
-        quiesce_direct(c);
-        check_device_flag(c);
+    enqueue_step(c, t, d_state, nullptr, c->stream, StepFlags{}, c->h_tag.dp, seq, defer_tail);
+    c->pending_step = 2;
+    c->pending_t    = t;
+}
+
+// Second half: wait for the tagged totals of the step begun last and hand them out.
+void step_end(hc_ctx* c, double* force_out) {
+    require(c->pending_step != 0, HC_ERR_INVALID, "hc_step_end without hc_step_begin");
+    const int how   = c->pending_step;
+    c->pending_step = 0;
+    if (how == 2) {
+        if (c->tail.pending) enqueue_tail(c);  // (a caller that deferred the tail and never enqueued it)
+        wait_tagged(c, c->h_tag.p, c->seq, c->stream, c->last_total.data());
+        if (c->device_errors_possible) {
+            quiesce_direct(c);
+            check_device_flag(c);
+        }
+        c->prev_time_device = c->pending_t;  // finalize_kernel has left the same totals in d_total: hc_step_device at this time copies them
+        c->have_prev_device = true;
     }
-    c->prev_time_device = t;  // finalize_kernel has left the same totals in d_total: hc_step_device at this time copies them
-    c->have_prev_device = true;
-    std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
+    if (force_out) std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
+}
+
+// A failed begin leaves nothing pending; whatever the step had enqueued before it threw is harmless (results nobody waits for).
+void step_abort(hc_ctx* c) {
+    c->pending_step = 0;
+    c->tail.pending = false;
+}
+}  // namespace
+
+int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel, double* force_out) {
+    HC_API_BEGIN_HOT(c)
+    require(force_out, HC_ERR_INVALID, "null pointer");
+    try {
+        step_begin(c, t, pos, rpy, linvel, angvel, false);
+        step_end(c, force_out);
+    } catch (...) {
+        step_abort(c);
+        throw;
+    }
     HC_API_END(c)
+}
+
+int hc_step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel) {
+    HC_API_BEGIN_HOT(c)
+    try {
+        step_begin(c, t, pos, rpy, linvel, angvel, false);
+    } catch (...) {
+        step_abort(c);
+        throw;
+    }
+    HC_API_END(c)
+}
+
+int hc_step_end(hc_ctx* c, double* force_out) {
+    HC_API_BEGIN_HOT(c)
+    require(force_out, HC_ERR_INVALID, "null pointer");
+    try {
+        step_end(c, force_out);
+    } catch (...) {
+        step_abort(c);
+        throw;
+    }
+    HC_API_END(c)
+}
+
+// One evaluation of a body-row-sharded system held by G contexts of ONE host process (the drop-in variant: the host
+// holds all body states -> a state store per GPU -> host-side gather).  Three phases: (1) every context gets the state and its
+// step kernel -- all G GPUs are working before the host does anything else; (2) the work later steps need is enqueued on each;
+// (3) the host collects the tagged totals of each shard into its rows of the 6N vector.  No collective, no torch: the same
+// kernels and the same per-shard arithmetic as hc_step, so the gathered vector is bitwise the unsharded one.
+int hc_step_multi(hc_ctx* const* ctxs, int n_ctx, double t, const double* pos, const double* rpy, const double* linvel,
+                  const double* angvel, double* force_out) {
+    if (!ctxs || n_ctx <= 0 || !force_out) return HC_ERR_INVALID;
+    for (int g = 0; g < n_ctx; ++g)
+        if (!ctxs[g]) return HC_ERR_INVALID;
+    int status = HC_OK;
+    std::string message;
+    auto guarded = [&](hc_ctx* c, auto&& fn) {
+        try {
+            HC_HIP(hipSetDevice(c->device));
+            fn();
+            return true;
+        } catch (const Error& e) {
+            if (status == HC_OK) { status = e.status; message = e.what(); }
+        } catch (const std::out_of_range& e) {
+            if (status == HC_OK) { status = HC_ERR_OUT_OF_RANGE; message = e.what(); }
+        } catch (const std::exception& e) {
+            if (status == HC_OK) { status = HC_ERR_RUNTIME; message = e.what(); }
+        }
+        step_abort(c);
+        return false;
+    };
+    std::vector<char> begun(static_cast<size_t>(n_ctx), 0);
+    for (int g = 0; g < n_ctx; ++g) {
+        hc_ctx* c = ctxs[g];
+        begun[g]  = guarded(c, [&] {
+            require(c->N == ctxs[0]->N, HC_ERR_INVALID, "hc_step_multi: the contexts belong to different systems");
+            step_begin(c, t, pos, rpy, linvel, angvel, true);
+        });
+    }
+    for (int g = 0; g < n_ctx; ++g)
+        if (begun[g]) begun[g] = guarded(ctxs[g], [&] { enqueue_tail(ctxs[g]); });
+    for (int g = 0; g < n_ctx; ++g)
+        if (begun[g]) guarded(ctxs[g], [&] { step_end(ctxs[g], force_out + static_cast<size_t>(6) * ctxs[g]->b0); });
+    if (status != HC_OK)
+        for (int g = 0; g < n_ctx; ++g) ctxs[g]->err = message;  // hc_last_error of any context of the group tells why
+    return status;
 }
 
 int hc_step_device(hc_ctx* c, double t, const double* d_state, double* d_force_out, void* stream) {
@@ -1902,16 +2228,18 @@ int hc_added_mass_matrix(hc_ctx* c, double* M) {
     HC_API_END(c)
 }
 
-int hc_added_mass_mv(hc_ctx* c, const double* w, double cc, double* R, int n_sys) {
-    HC_API_BEGIN_HOT(c)  // own stream, own buffers: independent of whatever the step queues still run
+namespace {
+// Chrono's integrator calls the product between force evaluations, so it is built like hc_step: staging buffers and a stream of
+// its own (kernels of the last hc_step may still be reading the state buffer, and the work that step left for later steps
+// is still running on the context's stream -- the product does not wait for it); w and the incoming R go to the device
+// through the BAR (fallback: mapped pinned memory), one launch, the result comes back as tagged granules.
+void added_mass_begin(hc_ctx* c, const double* w, double cc, const double* R, int n_sys) {
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(w && R, HC_ERR_INVALID, "null pointer");
     require(n_sys >= c->D, HC_ERR_INVALID, "system has fewer coordinates than the added-mass block");
+    require(c->pending_am == 0, HC_ERR_INVALID, "an added-mass product is still in flight");
+    if (c->lost) throw Error(HC_ERR_DEVICE, "the device stopped answering in an earlier step: " + c->direct_why);
     const int row0 = 6 * c->b0;
-    // Chrono's integrator calls this between force evaluations, so it is built like hc_step: staging buffers and a stream of
-    // its own (kernels of the last hc_step may still be reading the state buffer, and the work that step left for later steps
-    // is still running on the context's stream -- the product does not wait for it); w and the incoming R go to the device
-    // through the BAR (fallback: mapped pinned memory), one launch, the result comes back as tagged granules.
     const bool bar = c->bar_am.host_ok && c->bar_state.host_ok;  // bar_state.host_ok also carries the coherence check of hc_finalize
     double* hw       = bar ? c->bar_am.p : c->h_am.p;
     double* hr       = hw + c->D;
@@ -1920,25 +2248,67 @@ int hc_added_mass_mv(hc_ctx* c, const double* w, double cc, double* R, int n_sys
     if (bar) _mm_sfence();
     const double* dw = bar ? c->bar_am.p : c->h_am.dp;
     const unsigned long long seq = ++c->seq_am;
-    if (c->direct_ready && bar && c->dk_added_mass.ok() && c->dk_added_mass.kernarg == 56 && c->dk_added_mass.priv == 0) {
+    if (c->direct_ready && bar && c->dk_added_mass.ok() && c->dk_added_mass.kernarg == sizeof(hc::AddedMassArgs) && c->dk_added_mass.priv == 0) {
         // the second lane of the direct queue: an AQL packet instead of a HIP launch, independent of the step path's lane
-        struct {
-            const double* M;
-            int rows, cols;
-            const double *w, *R_in;
-            double c;
-            unsigned long long* tagged;
-            unsigned long long seq;
-        } a{c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq};
-        static_assert(sizeof(a) == 56, "kernarg layout of added_mass_mv_tagged_kernel");
+        hc::AddedMassArgs a{c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq};
         c->dq->dispatch(c->dk_added_mass, static_cast<uint32_t>((c->Dloc + 3) / 4), 256, 0, &a, sizeof a, -1, 0.0, 1);
-        wait_tagged(c, c->h_tag_am.p, seq, nullptr, R + row0);
+        c->prof.direct_dispatches += 1;
+        c->pending_am = 1;
     } else {
         hc::launch_added_mass_mv_tagged(c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq, c->stream_am);
+        c->prof.hip_launches += 1;
         HC_HIP(hipGetLastError());
-        wait_tagged(c, c->h_tag_am.p, seq, c->stream_am, R + row0);
+        c->pending_am = 2;
+    }
+}
+void added_mass_end(hc_ctx* c, double* R) {
+    const int how = c->pending_am;
+    c->pending_am = 0;
+    if (how == 1) wait_tagged(c, c->h_tag_am.p, c->seq_am, nullptr, R + 6 * c->b0, 1);
+    else if (how == 2) wait_tagged(c, c->h_tag_am.p, c->seq_am, c->stream_am, R + 6 * c->b0);
+}
+}  // namespace
+
+int hc_added_mass_mv(hc_ctx* c, const double* w, double cc, double* R, int n_sys) {
+    HC_API_BEGIN_HOT(c)  // own stream, own buffers: independent of whatever the step queues still run
+    try {
+        added_mass_begin(c, w, cc, R, n_sys);
+        added_mass_end(c, R);
+    } catch (...) {
+        c->pending_am = 0;
+        throw;
     }
     HC_API_END(c)
+}
+
+// LoadIntLoadResidual_Mv of a row-sharded system held by G contexts of one process: every shard's product is handed to its GPU
+// first, then the rows are collected (each shard owns rows [6*b0, 6*b1) of R; w is the full vector).
+int hc_added_mass_mv_multi(hc_ctx* const* ctxs, int n_ctx, const double* w, double cc, double* R, int n_sys) {
+    if (!ctxs || n_ctx <= 0) return HC_ERR_INVALID;
+    for (int g = 0; g < n_ctx; ++g)
+        if (!ctxs[g]) return HC_ERR_INVALID;
+    int status = HC_OK;
+    std::string message;
+    auto guarded = [&](hc_ctx* c, auto&& fn) {
+        try {
+            HC_HIP(hipSetDevice(c->device));
+            fn();
+            return true;
+        } catch (const Error& e) {
+            if (status == HC_OK) { status = e.status; message = e.what(); }
+        } catch (const std::exception& e) {
+            if (status == HC_OK) { status = HC_ERR_RUNTIME; message = e.what(); }
+        }
+        c->pending_am = 0;
+        return false;
+    };
+    std::vector<char> begun(static_cast<size_t>(n_ctx), 0);
+    for (int g = 0; g < n_ctx; ++g) begun[g] = guarded(ctxs[g], [&] { added_mass_begin(ctxs[g], w, cc, R, n_sys); });
+    for (int g = 0; g < n_ctx; ++g)
+        if (begun[g]) guarded(ctxs[g], [&] { added_mass_end(ctxs[g], R); });
+    if (status != HC_OK)
+        for (int g = 0; g < n_ctx; ++g) ctxs[g]->err = message;
+    return status;
 }
 
 // ---- introspection ----------------------------------------------------------------------------
@@ -2009,13 +2379,30 @@ int hc_get_excitation_irf_resampled(hc_ctx* c, int body, double* t, double* widt
     require(c->wave_kind == hc::kWaveIrregular, HC_ERR_INVALID, "no irregular wave model attached");
     check_body(c, body);
     require(is_local(c, body), HC_ERR_INVALID, "body is not owned by this context");
-    if (t) std::copy(c->ex_tau.begin(), c->ex_tau.end(), t);
-    if (width) std::copy(c->ex_width.begin(), c->ex_width.end(), width);
-    if (vals) {
-        const size_t off = static_cast<size_t>(6) * (body - c->b0) * c->L;
-        std::copy(c->ex_vals.begin() + off, c->ex_vals.begin() + off + static_cast<size_t>(6) * c->L, vals);
-    }
+    const hc::ExGroup& g = c->ex_groups[c->ex_group_of[body]];
+    if (t) std::copy(c->ex_tau.begin() + g.off, c->ex_tau.begin() + g.off + g.L, t);
+    if (width) std::copy(c->ex_width.begin() + g.off, c->ex_width.begin() + g.off + g.L, width);
+    if (vals)
+        for (int d = 0; d < 6; ++d) {
+            const size_t off = static_cast<size_t>(6 * (body - c->b0) + d) * c->L + g.off;
+            std::copy(c->ex_vals.begin() + off, c->ex_vals.begin() + off + g.L, vals + static_cast<size_t>(d) * g.L);
+        }
     HC_API_END(c)
+}
+
+int hc_get_excitation_irf_size(hc_ctx* c, int body, int* L) {
+    HC_API_BEGIN(c)
+    require(c->wave_kind == hc::kWaveIrregular && L, HC_ERR_INVALID, "no irregular wave model attached, or null pointer");
+    check_body(c, body);
+    *L = c->ex_groups[c->ex_group_of[body]].L;
+    HC_API_END(c)
+}
+
+int hc_get_shard(hc_ctx* c, int* body_begin, int* body_end) {
+    if (!c) return HC_ERR_INVALID;
+    if (body_begin) *body_begin = c->b0;
+    if (body_end) *body_end = c->b1;
+    return HC_OK;
 }
 
 int hc_get_spectrum(hc_ctx* c, double* f, double* S, double* df, double* phase, double* k) {

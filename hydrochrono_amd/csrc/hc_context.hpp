@@ -107,6 +107,20 @@ struct BodyHost {
     std::vector<double> exirf_f;    // [6][n] rho*g-scaled (local bodies only)
 };
 
+// What a step still has to enqueue for LATER steps (scatter of its sample, or the plan + pass of the next block) once its step
+// kernel is on its way: hc_step_multi rings the step kernels of all shard contexts first and enqueues these tails afterwards.
+struct StepTail {
+    bool pending = false, rad = false, waves = false, block = false, direct = false, caller_waits = false;
+    int m = 0, H = 0;
+    hipStream_t stream = nullptr;
+};
+
+// Bodies that share one excitation-IRF time grid: columns [off, off + L) of Kex / ex_tau / ex_width are the group's resampled grid.
+struct ExGroup {
+    int first_body = 0, off = 0, L = 0;
+    double tau_front = 0.0, tau_back = 0.0;
+};
+
 enum WaveKind { kWaveNone = 0, kWaveRegular = 1, kWaveIrregular = 2, kWaveSpectral = 3 };
 
 // One timed kernel launch (HIP events before / after it on the stream it was launched on).
@@ -138,6 +152,13 @@ struct hc_ctx {
     std::string direct_why;  // why the direct path is not in use
     int path            = 0;
     hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_added_mass, dk_step;
+    hc::StepTail tail;
+    // split step (hc_step_begin / hc_step_end, hc_step_multi): 0 nothing begun, 1 the begun step was a cache hit (totals in
+    // last_total), 2 its results arrive as tagged granules with sequence number `seq`
+    int pending_step  = 0;
+    double pending_t  = 0.0;
+    int pending_am    = 0;      // hc_added_mass_mv in flight (hc_added_mass_mv_multi): 1 tagged on the direct lane, 2 on stream_am
+    bool lost         = false;  // a dispatch never completed or the queue reported an error: every later step fails with HC_ERR_DEVICE
     int busy_caller_steps   = 0;  // hc_step_device: steps left before the caller's stream is queried again (see enqueue_step)
     std::string err;
 
@@ -154,12 +175,14 @@ struct hc_ctx {
     int conv_mode = 0;
     bool proc_ready = false;
     hc_tapered_direct_options taper{};
+    std::string diagnostics_dir;  // SetDiagnosticsOutputDirectory ("" = current directory)
     bool finalized = false;
 
     // history (host mirror of times, newest first) + ring in HBM
     std::deque<double> times;
     int head = -1, Hcap = 0, HcapT = 0;
     hc::DeviceBuffer<double> d_ring_t, d_ring_v, d_ring_vT;  // ring_vT[D][HcapT = Hcap + 2]: per-DoF copy for the look-ahead pass
+    long long rewinds = 0;  // steps back in time handled so far (history_push)
     bool have_prev = false, have_prev_device = false;  // per-time cache of hc_step (host totals) / hc_step_device (d_total)
     double prev_time = -1.0, prev_time_device = -1.0;
 
@@ -176,7 +199,9 @@ struct hc_ctx {
     hc_irregular_wave_params irr{};
     int eta_mode = 0;  // 0: direct FP64 sum (eta_kernel), 1: rocFFT chirp-z (hc_eta_fft.cpp)
     int L = 0, Lpad = 0, nf = 0, nt = 0;
-    std::vector<double> ex_tau, ex_width, ex_vals;  // ex_vals [Dloc][L]
+    std::vector<double> ex_tau, ex_width, ex_vals;  // [L] = the groups' grids one after the other; ex_vals [Dloc][L]
+    std::vector<hc::ExGroup> ex_groups;             // per-body excitation-IRF grids (src/wave_types.cpp:432-459), see hc_set_wave_irregular
+    std::vector<int> ex_group_of;                   // [N]
     std::vector<double> spec_f, spec_S, spec_df, spec_phase, spec_k;
     std::vector<double> eta_t, eta;
     hc::DeviceBuffer<double> d_kex, d_ex_tau, d_ex_width, d_eta_t, d_eta;

@@ -9,9 +9,12 @@
 #include <xmmintrin.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <iterator>
+#include <stdexcept>
 #include <vector>
 
 namespace hc {
@@ -86,6 +89,7 @@ struct DirectQueue::Impl {
     std::vector<KernelEntry> kernels;
     static constexpr uint32_t kSlots = 64;
     struct Lane {
+        std::atomic<int> error{0};  // hsa_status_t the runtime handed to the queue's error callback (0: none)
         hsa_queue_t* queue = nullptr;
         char* ring         = nullptr;  // kernarg slots: fine-grained device memory, written by the host through the BAR
         hsa_signal_t drain_sig{};
@@ -106,8 +110,10 @@ struct DirectQueue::Impl {
         const uint64_t idx = hsa_queue_add_write_index_relaxed(queue, 1);
         // room in the packet ring, and the kernarg slot of dispatch idx - kSlots is free: packets run in order, so once packet
         // j has been taken off the ring, packet j - 1 has completed
-        while (idx - hsa_queue_load_read_index_scacquire(queue) >= queue->size) _mm_pause();
-        while (idx >= kSlots && hsa_queue_load_read_index_scacquire(queue) + kSlots < idx + 2) _mm_pause();
+        // (a queue in the error state never advances: the waits end there and the packet written next is never run)
+        uint64_t spins = 0;
+        while (idx - hsa_queue_load_read_index_scacquire(queue) >= queue->size && !((++spins & 0xFFFF) == 0 && ln.error.load() != 0)) _mm_pause();
+        while (idx >= kSlots && hsa_queue_load_read_index_scacquire(queue) + kSlots < idx + 2 && !((++spins & 0xFFFF) == 0 && ln.error.load() != 0)) _mm_pause();
         return idx;
     }
     void publish(Lane& ln, void* packet, uint16_t header, uint16_t setup, uint64_t idx) {
@@ -119,13 +125,30 @@ struct DirectQueue::Impl {
     }
 };
 
+namespace {
+// asynchronous queue errors arrive here on a runtime thread (the queue is then inactive: its packets never complete)
+void on_queue_error(hsa_status_t status, hsa_queue_t*, void* data) {
+    static_cast<std::atomic<int>*>(data)->store(status == HSA_STATUS_SUCCESS ? -1 : static_cast<int>(status), std::memory_order_release);
+}
+}  // namespace
+
 DirectQueue::DirectQueue() : p_(new Impl) {}
+
+bool DirectQueue::failed(int lane) const { return p_->lanes[lane].error.load(std::memory_order_acquire) != 0; }
+
+std::string DirectQueue::failure_text() const {
+    for (int l = 0; l < kLanes; ++l) {
+        const int e = p_->lanes[l].error.load(std::memory_order_acquire);
+        if (e != 0) return std::string(hsa_text(static_cast<hsa_status_t>(e))) + " (lane " + std::to_string(l) + ")";
+    }
+    return "no error";
+}
 
 DirectQueue::~DirectQueue() {
     Impl& p = *p_;
     for (int l = 0; l < kLanes; ++l) {
         if (p.lanes[l].queue) {
-            if (busy_[l]) (void)drain(5.0, l);
+            if (busy_[l] && !failed(l)) (void)drain(5.0, l);
             (void)hsa_queue_destroy(p.lanes[l].queue);
         }
         if (p.lanes[l].have_drain_sig) (void)hsa_signal_destroy(p.lanes[l].drain_sig);
@@ -155,9 +178,9 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
     p.hsa_up = true;
 
     AgentPick pick;
-    int bus = 0, dev = 0, dom = 0, ndev = 0;
-    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 1 &&
-        hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, hip_device) == hipSuccess &&
+    // always by PCI address: with HIP_VISIBLE_DEVICES set per rank HIP sees one device while HSA still enumerates every GPU
+    int bus = 0, dev = 0, dom = 0;
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, hip_device) == hipSuccess &&
         hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, hip_device) == hipSuccess &&
         hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, hip_device) == hipSuccess) {
         pick.match_pci   = true;
@@ -167,6 +190,12 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
     (void)hipGetLastError();
     s = hsa_iterate_agents(pick_agent, &pick);
     if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_iterate_agents: ") + hsa_text(s));
+    if (pick.found == 0 && pick.match_pci) {
+        // no agent reports this PCI address (a virtualised topology): unambiguous all the same if there is one GPU agent only
+        pick = AgentPick{};
+        s    = hsa_iterate_agents(pick_agent, &pick);
+        if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_iterate_agents: ") + hsa_text(s));
+    }
     if (pick.found != 1) return fail("the HSA agent of the HIP device could not be identified");
     p.agent = pick.agent;
 
@@ -188,7 +217,7 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
     if (s != HSA_STATUS_SUCCESS || p.kernels.empty()) return fail("no kernels in the code object");
 
     for (int l = 0; l < kLanes; ++l) {
-        s = hsa_queue_create(p.agent, 1024, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &p.lanes[l].queue);
+        s = hsa_queue_create(p.agent, 1024, HSA_QUEUE_TYPE_SINGLE, on_queue_error, &p.lanes[l].error, UINT32_MAX, UINT32_MAX, &p.lanes[l].queue);
         if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_queue_create: ") + hsa_text(s));
         s = hsa_signal_create(1, 0, nullptr, &p.lanes[l].drain_sig);
         if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_signal_create: ") + hsa_text(s));
@@ -231,6 +260,9 @@ void DirectQueue::dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t 
                            int timed_tag, double timed_aux, int lane) {
     Impl& p            = *p_;
     Impl::Lane& ln     = p.lanes[lane];
+    if (arg_bytes > kSlotBytes || k.kernarg > kSlotBytes || arg_bytes > std::max<size_t>(k.kernarg, 1))
+        throw std::length_error("DirectQueue::dispatch: the argument block does not fit the kernel's kernarg segment / a ring slot");
+    if (failed(lane)) throw std::runtime_error("DirectQueue::dispatch: the queue is in the error state: " + failure_text());
     const uint64_t idx = p.reserve(ln);
     char* slot         = ln.ring + (idx & (Impl::kSlots - 1)) * kSlotBytes;
     std::memcpy(slot, args, arg_bytes);
@@ -286,12 +318,13 @@ bool DirectQueue::drain(double timeout_seconds, int lane) {
                             (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                             (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     p.publish(ln, pkt, header, 0, idx);
-    if (timeout_seconds > 0.0) {
-        const uint64_t ticks = static_cast<uint64_t>(timeout_seconds * static_cast<double>(p.ticks_per_second ? p.ticks_per_second : 100000000ull));
-        if (hsa_signal_wait_scacquire(ln.drain_sig, HSA_SIGNAL_CONDITION_LT, 1, ticks, HSA_WAIT_STATE_BLOCKED) >= 1) return false;
-    } else {
-        while (hsa_signal_wait_scacquire(ln.drain_sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {
-        }
+    // active wait in slices of about a millisecond, so that the clock and the queue's error flag are looked at in between
+    const double limit   = timeout_seconds > 0.0 ? timeout_seconds : 60.0;
+    const uint64_t slice = std::max<uint64_t>(1, (p.ticks_per_second ? p.ticks_per_second : 100000000ull) / 1000);
+    const auto t0        = std::chrono::steady_clock::now();
+    while (hsa_signal_wait_scacquire(ln.drain_sig, HSA_SIGNAL_CONDITION_LT, 1, slice, HSA_WAIT_STATE_ACTIVE) >= 1) {
+        if (failed(lane)) return false;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return false;
     }
     busy_[lane] = false;
     return true;
@@ -302,8 +335,13 @@ size_t DirectQueue::timed_pending() const { return p_->timed.size(); }
 void DirectQueue::collect(const std::function<void(int, double, double)>& sink) {
     Impl& p = *p_;
     for (auto& t : p.timed) {
-        while (hsa_signal_wait_scacquire(t.sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {
+        const uint64_t slice = std::max<uint64_t>(1, (p.ticks_per_second ? p.ticks_per_second : 100000000ull) / 1000);
+        const auto t0        = std::chrono::steady_clock::now();
+        bool done            = true;
+        while (hsa_signal_wait_scacquire(t.sig, HSA_SIGNAL_CONDITION_LT, 1, slice, HSA_WAIT_STATE_ACTIVE) >= 1) {
+            if (failed(0) || std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) { done = false; break; }
         }
+        if (!done) continue;  // the signal is not recycled: its dispatch never completed
         hsa_amd_profiling_dispatch_time_t dt{};
         if (hsa_amd_profiling_get_dispatch_time(p.agent, t.sig, &dt) == HSA_STATUS_SUCCESS && p.ticks_per_second > 0 && dt.end >= dt.start)
             sink(t.tag, static_cast<double>(dt.end - dt.start) / static_cast<double>(p.ticks_per_second), t.aux);

@@ -45,9 +45,13 @@ class DirectQueue {
     // behind work the step path still runs).
     void dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t wg_size, uint32_t dyn_lds, const void* args, size_t arg_bytes,
                   int timed_tag = -1, double timed_aux = 0.0, int lane = 0);
-    // Waits until everything dispatched to the lane so far has completed.  timeout_seconds > 0: gives up after that long and
-    // returns false (the queue must then not be used any more).
+    // Waits until everything dispatched to the lane so far has completed.  Gives up after timeout_seconds (<= 0: one minute), or
+    // as soon as the queue has reported an error, and returns false (the queue must then not be used any more).
     bool drain(double timeout_seconds = 0.0, int lane = 0);
+    // The HSA runtime has reported an asynchronous error on the lane's queue (bad packet, memory fault, ...): nothing dispatched
+    // to it will complete any more.
+    bool failed(int lane = 0) const;
+    std::string failure_text() const;
     bool busy(int lane = 0) const { return busy_[lane]; }
     static constexpr int kLanes = 2;
     // Reports (tag, seconds, aux) of every timed dispatch since the last call (waits for them).

@@ -83,6 +83,16 @@ void launch_unrelayout(const Panel& K, int Dloc, int D, int S, double* d_out, hi
     hipLaunchKernelGGL(unrelayout_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, K, Dloc, D, S, d_out);
 }
 
+// one (row, col) series along s (diagnostics CSV of the TaperedDirect preprocessing)
+__global__ void __launch_bounds__(256) extract_series_kernel(Panel K, int row, int col, int D, int S, double* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) out[s] = K.base[panel_offset(K.ngp, row, s * D + col)];
+}
+
+void launch_extract_series(const Panel& K, int row, int col, int D, int S, double* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(extract_series_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, K, row, col, D, S, d_out);
+}
+
 // ------------------------------------------------------------------------------------------------
 // History access and the bracket search shared by both convolution kernels.
 // ------------------------------------------------------------------------------------------------

@@ -208,6 +208,26 @@ struct ScatterArgs {
     double tgt_coef[kScatterSamples][kTargets];
 };
 
+// added_mass_mv_tagged_kernel's arguments as the kernel lays them out (direct dispatch, hc_api.cpp)
+struct AddedMassArgs {
+    const double* M;
+    int rows, cols;
+    const double *w, *R_in;
+    double c;
+    unsigned long long* tagged;
+    unsigned long long seq;
+};
+static_assert(sizeof(AddedMassArgs) == 56, "kernarg layout of added_mass_mv_tagged_kernel");
+
+// reduce_block_kernel's arguments as the kernel lays them out
+struct ReduceArgs {
+    const double* partials;
+    int nchunks_rad, nchunks_ex, Dpad, depth;
+    double *P, *E;
+    int* item_counter;
+};
+static_assert(sizeof(ReduceArgs) == 48, "kernarg layout of reduce_block_kernel");
+
 struct TaperArgs {
     Panel Kraw;
     double* Kproc;  // same panel geometry
@@ -264,6 +284,8 @@ void launch_added_mass_mv_tagged(const double* d_M, int rows, int cols, const do
                                  unsigned long long* d_tagged, unsigned long long seq, hipStream_t stream);
 // out[(row*D + col)*S + s] = K[row][s*D + col]  (reference indexing; diagnostics)
 void launch_unrelayout(const Panel& K, int Dloc, int D, int S, double* d_out, hipStream_t stream);
+// out[s] = K[row][s*D + col], s < S  (one series; diagnostics)
+void launch_extract_series(const Panel& K, int row, int col, int D, int S, double* d_out, hipStream_t stream);
 // ring_vT[col][slot] = ring_v[slot][col] for all slots, ring_vT[col][Hcap] = ring_v[0][col] (after the ring has been re-allocated or injected)
 void launch_ring_transpose(const double* d_ring_v, int Hcap, int HcapT, int D, double* d_ring_vT, hipStream_t stream);
 // synthetic many-body coefficient generator: fills the whole panel matrix (padding = 0)

@@ -475,6 +475,7 @@ int hc_create_from_hydro_yaml(const hc_yaml* cfg, const char* const* names, int 
         o.taper_start_percent   = cfg->td_taper_start_percent;
         o.taper_end_percent     = cfg->td_taper_end_percent;
         o.taper_final_amplitude = cfg->td_taper_final_amplitude;
+        o.export_plot_csv       = cfg->td_export_plot_csv ? 1 : 0;
         if ((rc = hc_set_convolution_mode(ctx, 1)) != HC_OK) return fail(rc);
         if ((rc = hc_set_tapered_direct_options(ctx, &o)) != HC_OK) return fail(rc);
     } else {

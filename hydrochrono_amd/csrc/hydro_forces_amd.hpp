@@ -15,6 +15,7 @@
 // this file wire everything into a ChSystem the way the reference's ForceFunc6d / ChLoadAddedMass do.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <memory>
 #include <stdexcept>
@@ -183,49 +184,71 @@ class TestHydro {
 
     TestHydro(std::vector<std::shared_ptr<HydroBody>> user_bodies, const std::string& h5_file_name,
               std::shared_ptr<WaveBase> waves = std::make_shared<NoWave>(), int device_id = 0)
+        : TestHydro(std::move(user_bodies), h5_file_name, std::move(waves), std::vector<int>{device_id}) {}
+    // Multi-GPU inside the one Chrono process (drop-in variant): one body-row shard per entry of `device_ids`
+    // (a device may be named more than once), contiguous balanced split of the bodies; every call below fans out to the
+    // shard contexts, the per-step evaluation goes through hc_step_multi (all GPUs started before any is waited for,
+    // host-side gather).  One entry = the single-GPU object.
+    TestHydro(std::vector<std::shared_ptr<HydroBody>> user_bodies, const std::string& h5_file_name, std::shared_ptr<WaveBase> waves,
+              const std::vector<int>& device_ids)
         : bodies_(std::move(user_bodies)), num_bodies_(static_cast<int>(bodies_.size())) {
         if (bodies_.empty()) throw std::runtime_error("TestHydro needs at least one body");
+        if (device_ids.empty() || static_cast<int>(device_ids.size()) > num_bodies_)
+            throw std::runtime_error("TestHydro: between one shard and one shard per body");
         // body numbers come from the names "body<k>", 1-based (ForceFunc6d ctor, src/hydro_forces.cpp:104-108)
         for (auto& b : bodies_) {
             std::string temp = b->GetName();
             body_numbers_.push_back(std::stoi(temp.erase(0, 4)));
         }
-        int rc = hc_create(num_bodies_, device_id, &ctx_);
-        if (rc != HC_OK) throw std::runtime_error(hc_last_error(nullptr));
+        const int G = static_cast<int>(device_ids.size()), base = num_bodies_ / G, extra = num_bodies_ % G;
         try {
-            check(ctx_, hc_load_bemio_h5(ctx_, h5_file_name.c_str()));
-            check(ctx_, hc_finalize(ctx_));
+            for (int g = 0; g < G; ++g) {
+                const int b0 = g * base + (g < extra ? g : extra), b1 = b0 + base + (g < extra ? 1 : 0);
+                hc_ctx* c = nullptr;
+                if (hc_create_sharded(num_bodies_, b0, b1, device_ids[g], &c) != HC_OK) throw std::runtime_error(hc_last_error(nullptr));
+                ctxs_.push_back(c);
+                check(c, hc_load_bemio_h5(c, h5_file_name.c_str()));
+                check(c, hc_finalize(c));
+            }
+            ctx_ = ctxs_[0];
             AddWaves(std::move(waves));
         } catch (...) {
-            hc_destroy(ctx_);
+            for (hc_ctx* c : ctxs_) hc_destroy(c);
             throw;
         }
         total_force_.assign(6 * num_bodies_, 0.0);
     }
     // Adopts a context that is already configured (used by SetupHydroFromYAML below).
     TestHydro(std::vector<std::shared_ptr<HydroBody>> user_bodies, hc_ctx* configured_ctx)
-        : bodies_(std::move(user_bodies)), num_bodies_(static_cast<int>(bodies_.size())), ctx_(configured_ctx) {
+        : TestHydro(std::move(user_bodies), std::vector<hc_ctx*>{configured_ctx}) {}
+    // ... or the configured shard contexts of one system (together they own bodies [0, N)).
+    TestHydro(std::vector<std::shared_ptr<HydroBody>> user_bodies, std::vector<hc_ctx*> configured_ctxs)
+        : bodies_(std::move(user_bodies)), num_bodies_(static_cast<int>(bodies_.size())), ctxs_(std::move(configured_ctxs)) {
+        if (ctxs_.empty()) throw std::runtime_error("TestHydro: no context");
+        ctx_ = ctxs_[0];
         for (auto& b : bodies_) {
             std::string temp = b->GetName();
             body_numbers_.push_back(std::stoi(temp.erase(0, 4)));
         }
         total_force_.assign(6 * num_bodies_, 0.0);
     }
-    ~TestHydro() { hc_destroy(ctx_); }
+    ~TestHydro() {
+        for (hc_ctx* c : ctxs_) hc_destroy(c);
+    }
 
     void AddWaves(std::shared_ptr<WaveBase> waves) {  // src/hydro_forces.cpp:244-261
         user_waves_ = std::move(waves);
-        user_waves_->Attach(ctx_);
+        for (auto it = ctxs_.rbegin(); it != ctxs_.rend(); ++it) user_waves_->Attach(*it);  // (the wave object keeps the first context for its getters)
     }
     std::shared_ptr<WaveBase> GetWave() const { return user_waves_; }
     void SetGravitationalAcceleration(double gx, double gy, double gz) {  // ChSystem setting read at :268
         const double g[3] = {gx, gy, gz};
-        check(ctx_, hc_set_gravity(ctx_, g));
+        for (hc_ctx* c : ctxs_) check(c, hc_set_gravity(c, g));
     }
 
     enum class RadiationConvolutionMode { Baseline, TaperedDirect };
     void SetRadiationConvolutionMode(RadiationConvolutionMode mode) {
-        check(ctx_, hc_set_convolution_mode(ctx_, mode == RadiationConvolutionMode::TaperedDirect ? 1 : 0));
+        for (hc_ctx* c : ctxs_) check(c, hc_set_convolution_mode(c, mode == RadiationConvolutionMode::TaperedDirect ? 1 : 0));
     }
     struct TaperedDirectOptions {
         std::string smoothing        = "sg";
@@ -234,7 +257,7 @@ class TestHydro {
         double taper_start_percent   = 0.8;
         double taper_end_percent     = 1.0;
         double taper_final_amplitude = 0.0;
-        bool export_plot_csv         = false;  // diagnostics CSV is not produced by the GPU path
+        bool export_plot_csv         = false;  // rirf_processing_body<b>_dof<d>.csv in the diagnostics directory (src/hydro_forces.cpp:509-531)
     };
     void SetTaperedDirectOptions(const TaperedDirectOptions& o) {
         hc_tapered_direct_options c;
@@ -245,24 +268,29 @@ class TestHydro {
         c.taper_start_percent   = o.taper_start_percent;
         c.taper_end_percent     = o.taper_end_percent;
         c.taper_final_amplitude = o.taper_final_amplitude;
-        check(ctx_, hc_set_tapered_direct_options(ctx_, &c));
+        c.export_plot_csv       = o.export_plot_csv ? 1 : 0;
+        for (hc_ctx* x : ctxs_) check(x, hc_set_tapered_direct_options(x, &c));
+    }
+    // include/hydroc/hydro_forces.h:269
+    void SetDiagnosticsOutputDirectory(const std::string& dir) {
+        for (hc_ctx* x : ctxs_) check(x, hc_set_diagnostics_output_directory(x, dir.c_str()));
     }
 
     std::vector<double> ComputeForceHydrostatics() {
         gather_state();
         std::vector<double> out(6 * num_bodies_);
-        check(ctx_, hc_compute_hydrostatics(ctx_, pos_.data(), rpy_.data(), out.data()));
+        for (hc_ctx* c : ctxs_) check(c, hc_compute_hydrostatics(c, pos_.data(), rpy_.data(), out.data() + row0(c)));
         return out;
     }
     std::vector<double> ComputeForceRadiationDampingConv() {
         gather_state();
         std::vector<double> out(6 * num_bodies_);
-        check(ctx_, hc_compute_radiation(ctx_, bodies_[0]->GetChTime(), lin_.data(), ang_.data(), out.data()));
+        for (hc_ctx* c : ctxs_) check(c, hc_compute_radiation(c, bodies_[0]->GetChTime(), lin_.data(), ang_.data(), out.data() + row0(c)));
         return out;
     }
     std::vector<double> ComputeForceWaves() {
         std::vector<double> out(6 * num_bodies_);
-        check(ctx_, hc_compute_waves(ctx_, bodies_[0]->GetChTime(), out.data()));
+        for (hc_ctx* c : ctxs_) check(c, hc_compute_waves(c, bodies_[0]->GetChTime(), out.data() + row0(c)));
         return out;
     }
 
@@ -274,33 +302,43 @@ class TestHydro {
             prev_time_ = t;
             have_time_ = true;
             gather_state();
-            check(ctx_, hc_step(ctx_, t, pos_.data(), rpy_.data(), lin_.data(), ang_.data(), total_force_.data()));
+            if (ctxs_.size() == 1) check(ctx_, hc_step(ctx_, t, pos_.data(), rpy_.data(), lin_.data(), ang_.data(), total_force_.data()));
+            else check(ctx_, hc_step_multi(ctxs_.data(), static_cast<int>(ctxs_.size()), t, pos_.data(), rpy_.data(), lin_.data(), ang_.data(), total_force_.data()));
         }
         return total_force_[6 * (b - 1) + dof_index];
     }
 
+    // GPU seconds per term; the shards of a multi-GPU object run side by side, so the largest shard figure is reported
     HydroProfileStats GetProfileStats() const {
-        hc_profile_stats p;
-        check(ctx_, hc_get_profile(ctx_, &p));
         HydroProfileStats s;
-        s.hydrostatics_seconds = p.hydrostatics_seconds;
-        s.radiation_seconds    = p.radiation_seconds;
-        s.waves_seconds        = p.waves_seconds;
-        s.hydrostatics_calls   = p.hydrostatics_calls;
-        s.radiation_calls      = p.radiation_calls;
-        s.waves_calls          = p.waves_calls;
+        for (hc_ctx* c : ctxs_) {
+            hc_profile_stats p;
+            check(c, hc_get_profile(c, &p));
+            s.hydrostatics_seconds = std::max(s.hydrostatics_seconds, p.hydrostatics_seconds);
+            s.radiation_seconds    = std::max(s.radiation_seconds, p.radiation_seconds);
+            s.waves_seconds        = std::max(s.waves_seconds, p.waves_seconds);
+            s.hydrostatics_calls   = p.hydrostatics_calls;
+            s.radiation_calls      = p.radiation_calls;
+            s.waves_calls          = p.waves_calls;
+        }
         return s;
     }
 
     // ChLoadAddedMass data (src/chloadaddedmass.cpp)
     std::vector<double> GetAddedMassMatrix() const {
-        std::vector<double> M(static_cast<size_t>(36) * num_bodies_ * num_bodies_);
-        check(ctx_, hc_added_mass_matrix(ctx_, M.data()));
+        const size_t D = static_cast<size_t>(6) * num_bodies_;
+        std::vector<double> M(D * D);
+        for (hc_ctx* c : ctxs_) check(c, hc_added_mass_matrix(c, M.data() + static_cast<size_t>(row0(c)) * D));  // each shard: its rows
         return M;
     }
-    void AddedMassMv(double* R, const double* w, double c, int n_sys) const { check(ctx_, hc_added_mass_mv(ctx_, w, c, R, n_sys)); }
+    void AddedMassMv(double* R, const double* w, double c, int n_sys) const {
+        if (ctxs_.size() == 1) check(ctx_, hc_added_mass_mv(ctx_, w, c, R, n_sys));
+        else check(ctx_, hc_added_mass_mv_multi(ctxs_.data(), static_cast<int>(ctxs_.size()), w, c, R, n_sys));
+    }
 
     hc_ctx* context() const { return ctx_; }
+    const std::vector<hc_ctx*>& contexts() const { return ctxs_; }
+    int num_shards() const { return static_cast<int>(ctxs_.size()); }
     int body_number(int i) const { return body_numbers_[i]; }
     int num_bodies() const { return num_bodies_; }
 
@@ -316,10 +354,16 @@ class TestHydro {
             }
         }
     }
+    static int row0(hc_ctx* c) {  // first output row of a shard context
+        int b0 = 0;
+        check(c, hc_get_shard(c, &b0, nullptr));
+        return 6 * b0;
+    }
     std::vector<std::shared_ptr<HydroBody>> bodies_;
     int num_bodies_;
     std::vector<int> body_numbers_;
-    hc_ctx* ctx_ = nullptr;
+    std::vector<hc_ctx*> ctxs_;  // one per body-row shard (one = the single-GPU object)
+    hc_ctx* ctx_ = nullptr;      // ctxs_[0]
     std::shared_ptr<WaveBase> user_waves_;
     std::vector<double> total_force_, pos_, rpy_, lin_, ang_;
     bool have_time_   = false;
@@ -431,11 +475,13 @@ class ChLoadAddedMass : public chrono::ChLoadCustomMultiple {
 // per body two WORLD_DIR ChForce objects ("hydroforce", "hydrotorque") fed by six ComponentFunc, plus the added-mass load.
 class ChronoHydroSystem {
   public:
-    ChronoHydroSystem(std::vector<std::shared_ptr<chrono::ChBody>> bodies, const std::string& h5, std::shared_ptr<WaveBase> waves)
+    // device_ids: one body-row shard per entry (multi-GPU inside this one process, see TestHydro); default = GPU 0 alone
+    ChronoHydroSystem(std::vector<std::shared_ptr<chrono::ChBody>> bodies, const std::string& h5, std::shared_ptr<WaveBase> waves,
+                      const std::vector<int>& device_ids = {0})
         : chbodies_(std::move(bodies)) {
         std::vector<std::shared_ptr<HydroBody>> views;
         for (auto& b : chbodies_) views.push_back(std::make_shared<ChronoBody>(b));
-        hydro_ = std::make_unique<TestHydro>(views, h5, std::move(waves));
+        hydro_ = std::make_unique<TestHydro>(views, h5, std::move(waves), device_ids);
         auto g = chbodies_[0]->GetSystem()->GetGravitationalAcceleration();
         hydro_->SetGravitationalAcceleration(g.x(), g.y(), g.z());
         for (size_t k = 0; k < chbodies_.size(); ++k) {

@@ -165,10 +165,13 @@ class HydroForces:
         self._chk(self.lib.hc_set_convolution_mode(self.ctx, int(mode)))
 
     def set_tapered_direct_options(self, smoothing=0, window_length=5, rirf_end_time=-1.0, taper_start_percent=0.8,
-                                   taper_end_percent=1.0, taper_final_amplitude=0.0):
+                                   taper_end_percent=1.0, taper_final_amplitude=0.0, export_plot_csv=False):
         o = capi.TaperedDirectOptions(int(smoothing), int(window_length), rirf_end_time, taper_start_percent,
-                                      taper_end_percent, taper_final_amplitude)
+                                      taper_end_percent, taper_final_amplitude, int(export_plot_csv))
         self._chk(self.lib.hc_set_tapered_direct_options(self.ctx, C.byref(o)))
+
+    def set_diagnostics_output_directory(self, directory):
+        self._chk(self.lib.hc_set_diagnostics_output_directory(self.ctx, str(directory).encode()))
 
     # -- per step --
     def step(self, t, pos, rpy, linvel, angvel):
@@ -281,7 +284,9 @@ class HydroForces:
         return out
 
     def irreg_irf(self, b=0):
-        L = self.sizes()["L"]
+        Lb = C.c_int()
+        self._chk(self.lib.hc_get_excitation_irf_size(self.ctx, b, C.byref(Lb)))
+        L = Lb.value
         t, w, v = np.empty(L), np.empty(L), np.empty((6, L))
         self._chk(self.lib.hc_get_excitation_irf_resampled(self.ctx, b, _dp(t), _dp(w), _dp(v.reshape(-1))))
         return t, w, v
@@ -305,3 +310,61 @@ class HydroForces:
         mag, ph, k = np.empty(self.D), np.empty(self.D), C.c_double()
         self._chk(self.lib.hc_get_regular_coeffs(self.ctx, _dp(mag), _dp(ph), C.byref(k)))
         return mag, ph, k.value
+
+
+class HydroGroup:
+    """G row-sharded contexts of ONE coupled N-body system driven by one host process through hc_step_multi /
+    hc_added_mass_mv_multi (drop-in variant: host holds all state -> a state store per GPU -> host gather).
+    `shards` are HydroForces objects created with body_range=... that together cover bodies [0, N)."""
+
+    def __init__(self, shards):
+        self.shards = list(shards)
+        self.N = self.shards[0].N
+        self.D = 6 * self.N
+        self.lib = self.shards[0].lib
+        covered = sorted((h.b0, h.b1) for h in self.shards)
+        if covered[0][0] != 0 or covered[-1][1] != self.N or any(a[1] != b[0] for a, b in zip(covered, covered[1:])):
+            raise ValueError("the shards do not partition bodies [0, N)")
+        self._ctxs = (C.c_void_p * len(self.shards))(*[h.ctx for h in self.shards])
+        self._step = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(
+            ("hc_step_multi", self.lib))
+
+    @classmethod
+    def from_case(cls, case, n_shards, devices=None):
+        from .parallel_split import body_shard
+        devices = devices or [0] * n_shards
+        return cls([HydroForces.from_case(case, device=devices[g], body_range=body_shard(case["N"], n_shards, g)) for g in range(n_shards)])
+
+    def __getattr__(self, name):
+        # configuration calls (add_waves_*, set_lookahead, set_history, ...) go to every shard
+        if name.startswith(("add_waves", "set_", "reset_", "enable_")):
+            def fan_out(*a, **k):
+                for h in self.shards:
+                    getattr(h, name)(*a, **k)
+            return fan_out
+        raise AttributeError(name)
+
+    def step(self, t, pos, rpy, linvel, angvel):
+        n3 = 3 * self.N
+        a = [_arr(x, n3) for x in (pos, rpy, linvel, angvel)]
+        out = np.empty(self.D)
+        rc = self._step(self._ctxs, len(self.shards), t, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, out.ctypes.data)
+        if rc:
+            raise HydroError(rc, self.lib.hc_last_error(self.shards[0].ctx).decode())
+        return out
+
+    def components(self):
+        parts = [h.components() for h in sorted(self.shards, key=lambda h: h.b0)]
+        return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
+
+    def added_mass_mv(self, R, w, c):
+        R = _arr(R).copy()
+        w = _arr(w)
+        rc = self.lib.hc_added_mass_mv_multi(self._ctxs, len(self.shards), _dp(w), float(c), _dp(R), R.size)
+        if rc:
+            raise HydroError(rc, self.lib.hc_last_error(self.shards[0].ctx).decode())
+        return R
+
+    def close(self):
+        for h in self.shards:
+            h.close()

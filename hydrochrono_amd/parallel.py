@@ -10,15 +10,7 @@ import torch
 import torch.distributed as dist
 
 
-def body_shard(num_bodies, world, rank):
-    """Contiguous balanced partition of bodies over ranks: the first (num_bodies % world) ranks get one extra."""
-    if not (0 <= rank < world):
-        raise ValueError("rank out of range")
-    if world > num_bodies:
-        raise ValueError("more ranks than bodies: use replicas instead of sharding (SURVEY.md 8e)")
-    base, extra = divmod(num_bodies, world)
-    b0 = rank * base + min(rank, extra)
-    return b0, b0 + base + (1 if rank < extra else 0)
+from .parallel_split import body_shard  # noqa: F401  (re-exported)
 
 
 class ForceExchange:

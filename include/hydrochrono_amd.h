@@ -46,6 +46,8 @@ int hc_create(int num_bodies, int device_id, hc_ctx** out);
 /* Row-sharded context: owns output rows of bodies [body_begin, body_end) only. */
 int hc_create_sharded(int num_bodies, int body_begin, int body_end, int device_id, hc_ctx** out);
 void hc_destroy(hc_ctx* ctx);
+/* The bodies [body_begin, body_end) whose output rows the context owns (either pointer may be NULL). */
+int hc_get_shard(hc_ctx* ctx, int* body_begin, int* body_end);
 const char* hc_last_error(const hc_ctx* ctx); /* ctx may be NULL: error of the last failed hc_create */
 
 /* ------------------------------------------------------------------------------------------------
@@ -135,9 +137,15 @@ typedef struct hc_tapered_direct_options {
     double taper_start_percent;   /* 0.8 */
     double taper_end_percent;     /* 1.0 */
     double taper_final_amplitude; /* 0.0 */
+    int export_plot_csv;          /* 0; 1: write rirf_body<b>_summary.csv (b 0-based, one per owned body; columns
+                                     step,time,k_before,k_after of channel row 0 / column 0, src/hydro_forces.cpp:509-531) into the
+                                     diagnostics directory when the kernel is processed */
 } hc_tapered_direct_options;
 void hc_tapered_direct_options_default(hc_tapered_direct_options* o);
 int hc_set_tapered_direct_options(hc_ctx* ctx, const hc_tapered_direct_options* opts);
+/* TestHydro::SetDiagnosticsOutputDirectory (include/hydroc/hydro_forces.h:269): where the export_plot_csv files go; "" (the
+ * default) = the current working directory, as in the reference (src/hydro_forces.cpp:513).  Export errors are ignored (:529). */
+int hc_set_diagnostics_output_directory(hc_ctx* ctx, const char* dir);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-step force evaluation.  Replaces the 6N ComponentFunc::GetVal -> ForceFunc6d::CoordinateFunc ->
@@ -149,14 +157,32 @@ int hc_set_tapered_direct_options(hc_ctx* ctx, const hc_tapered_direct_options* 
  *   angvel  [N][3]  ChBody::GetAngVelParent()
  *   force_out [D_local] world-frame force (x,y,z) and torque (x,y,z) per owned body.
  * Errors kept from the reference: excitation window exceeded (src/wave_types.cpp:833-840) -> HC_ERR_RUNTIME.
- * Deviation: t must not decrease (HC_ERR_INVALID).  The reference has no such check -- it would insert the earlier time at the
- * front of its newest-first history (src/hydro_forces.cpp:559-574) and interpolate in a non-monotone list; an integrator that
- * rejects a step re-injects the history it continues from (hc_set_history) or resets it.
+ * A step BACK in time (t below the newest history sample: an integrator that rejected a step and retries from an earlier time)
+ * drops the history samples at times >= t -- they belong to the abandoned attempt -- and continues from the history as it was
+ * at t.  Deviation: the reference has no such rule; it inserts the earlier time in front of its newest-first history
+ * (src/hydro_forces.cpp:559-574), keeps the abandoned samples and interpolates in a non-monotone list from then on.
  * hc_step is synchronous (the forces are in force_out when it returns) but does not synchronise the stream: work that later
  * steps need may still be running on the context's stream.
  * ---------------------------------------------------------------------------------------------- */
 int hc_step(hc_ctx* ctx, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel,
             double* force_out);
+/* The two halves of hc_step for a host that has other work between handing the state to the GPU and needing the forces:
+ * hc_step_begin stores the state, hands the step kernel to the GPU (and enqueues what later steps need) and returns;
+ * hc_step_end waits for the results of that step.  Exactly one hc_step_end per hc_step_begin; no other per-step call on
+ * the context in between.  Same cache and error rules as hc_step (a failure of either half leaves nothing pending). */
+int hc_step_begin(hc_ctx* ctx, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel);
+int hc_step_end(hc_ctx* ctx, double* force_out);
+/* Multi-GPU inside ONE host process -- the reference is one C++ object in one Chrono process (src/hydro_forces.cpp:170-242),
+ * evaluated by one call per time (:727-767); SURVEY 8e, drop-in variant.  ctxs[0..n_ctx) are row-sharded contexts of the same
+ * N-body system (hc_create_sharded, any devices, any split of the bodies); the call stores the state into every context and
+ * rings every GPU's doorbell BEFORE it enqueues anything else or waits, then gathers each shard's rows:
+ *   force_out[6*body_begin(g) .. 6*body_end(g)) = the totals of context g          (force_out has 6N entries)
+ * No collective, no device-to-device traffic: inputs are 12N doubles per GPU, outputs 6*n_local doubles per GPU, through the
+ * PCIe BAR / mapped host memory like hc_step.  The gathered vector is bitwise the one an unsharded context returns.  On
+ * failure the status of the first failing context is returned, hc_last_error() of every context of the group holds its
+ * message, and no context is left with a step pending. */
+int hc_step_multi(hc_ctx* const* ctxs, int n_ctx, double t, const double* pos, const double* rpy, const double* linvel,
+                  const double* angvel, double* force_out);
 /* Same evaluation with the body state already in HBM and the result left in HBM:
  *   d_state     device pointer, 12N doubles = pos[3N] | rpy[3N] | linvel[3N] | angvel[3N]
  *   d_force_out device pointer, D_local doubles
@@ -213,6 +239,9 @@ int hc_added_mass_matrix(hc_ctx* ctx, double* M_DlocalxD);
 /* LoadIntLoadResidual_Mv: R[row0 + i] += c * sum_j M[i][j] * w[j], i < D_local (:55-70); w has >= D entries,
  * R has n_sys entries (n_sys >= D), row0 = 6*body_begin. */
 int hc_added_mass_mv(hc_ctx* ctx, const double* w, double c, double* R_inout, int n_sys);
+/* The same product for a row-sharded system held by n_ctx contexts of one process (see hc_step_multi): all shards are handed
+ * to their GPUs first, then each shard's rows [6*body_begin, 6*body_end) of R are collected. */
+int hc_added_mass_mv_multi(hc_ctx* const* ctxs, int n_ctx, const double* w, double c, double* R_inout, int n_sys);
 
 /* ------------------------------------------------------------------------------------------------
  * Introspection (exporter / diagnostics parity).
@@ -237,6 +266,10 @@ typedef struct hc_profile_stats {
     long long step_kernel_launches;
     double scatter_kernel_seconds; /* scatter launches (after a block step has delivered its forces) */
     long long scatter_kernel_launches;
+    /* how the kernels of the per-step path reached the GPU since the last reset (counted whether or not profiling is on):
+     * AQL packets written by the library itself / hipLaunchKernelGGL calls */
+    long long direct_dispatches, hip_launches;
+    long long history_rewinds;     /* steps back in time handled by dropping the newer history samples (see hc_step) */
 } hc_profile_stats;
 /* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default), and around every
  * look-ahead pass (one per block) whatever the stride.  Event records perturb the launch stream by a few
@@ -256,6 +289,9 @@ int hc_get_rirf_width(hc_ctx* ctx, double* w_S);
 int hc_get_rirf_effective(hc_ctx* ctx, double* out_DlocalxDxS);
 /* ex_irf_time_sampled_, ex_irf_width_sampled_, ex_irf_sampled_ (6 x L) of a local body (src/wave_types.cpp:572-628) */
 int hc_get_excitation_irf_resampled(hc_ctx* ctx, int body, double* t_L, double* width_L, double* vals_6xL);
+/* Bodies may carry different excitation-IRF time grids (the reference keeps one per body, src/wave_types.cpp:432-459): L of this
+ * body's resampled grid (hc_get_sizes reports the sum over the distinct grids = the columns of the excitation matrix). */
+int hc_get_excitation_irf_size(hc_ctx* ctx, int body, int* L);
 /* spectrum_frequencies_, spectral_densities_, spectral_widths_, wave_phases_, wavenumbers_ (:643-676) */
 int hc_get_spectrum(hc_ctx* ctx, double* f, double* S, double* df, double* phase, double* k);
 /* free_surface_time_sampled_ / free_surface_elevation_sampled_ (:717-774; exporter: runner:668-679) */

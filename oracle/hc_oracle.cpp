@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <fstream>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -631,6 +632,7 @@ struct TaperedDirectOptions {  // include/hydroc/hydro_forces.h:246-259
     double taper_start_percent   = 0.8;
     double taper_end_percent     = 1.0;
     double taper_final_amplitude = 0.0;
+    bool export_plot_csv         = false;
 };
 
 struct ProfileStats {  // include/hydroc/hydro_forces.h:153-160
@@ -659,6 +661,7 @@ struct TestHydro {
     bool rirf_processed_ready_ = false;
     std::vector<Tensor3> rirf_processed_;
     TaperedDirectOptions tapered_opts_;
+    std::string diagnostics_output_dir_;  // include/hydroc/hydro_forces.h:269,344
     std::vector<double> infinite_added_mass;  // D x D row-major (chloadaddedmass.cpp:18-21)
     ProfileStats profile_stats_;
 
@@ -787,7 +790,7 @@ struct TestHydro {
         return ((index + 1) < th.size());
     }
 
-    void EnsureProcessedRIRF() {  // :385-535 (CSV export omitted: diagnostics only)
+    void EnsureProcessedRIRF() {  // :385-535
         if (rirf_processed_ready_) return;
         const int steps = file_info_.GetRIRFDims(2);
         const int cols  = kDofPerBody * num_bodies_;
@@ -859,6 +862,21 @@ struct TestHydro {
                 }
             }
             rirf_processed_[b] = std::move(processed);
+            if (tapered_opts_.export_plot_csv) {  // :509-531 (std::filesystem::path "/" spelled out; empty dir = current directory)
+                try {
+                    const std::string base = std::string("rirf_body") + std::to_string(b) + std::string("_summary.csv");
+                    const std::string out_path = diagnostics_output_dir_.empty() ? base : (diagnostics_output_dir_ + "/" + base);
+                    std::ofstream ofs(out_path);
+                    ofs << "step,time,k_before,k_after\n";
+                    for (int s = 0; s < effective_steps; ++s) {
+                        double t      = (s < int(rirf_time_vector.size())) ? rirf_time_vector[s] : static_cast<double>(s);
+                        double before = file_info_.GetRIRFVal(b, 0, 0, s);
+                        double after  = rirf_processed_[b](0, 0, s);
+                        ofs << s << "," << t << "," << before << "," << after << "\n";
+                    }
+                } catch (...) {
+                }
+            }
         }
         rirf_processed_ready_ = true;
     }
@@ -1165,6 +1183,13 @@ int orc_set_convolution_mode(orc_ctx* c, int mode) {
     c->hydro->convolution_mode_ = mode;
     ORC_CATCH(c)
 }
+int orc_set_diagnostics(orc_ctx* c, int export_plot_csv, const char* dir) {  // SetDiagnosticsOutputDirectory + opts.export_plot_csv
+    ORC_TRY
+    c->hydro->tapered_opts_.export_plot_csv = export_plot_csv != 0;
+    c->hydro->diagnostics_output_dir_       = dir ? dir : "";
+    c->hydro->rirf_processed_ready_         = false;
+    ORC_CATCH(c)
+}
 int orc_set_tapered_direct_options(orc_ctx* c, int smoothing, int window_length, double rirf_end_time,
                                    double taper_start_percent, double taper_end_percent, double taper_final_amplitude) {
     ORC_TRY
@@ -1272,6 +1297,11 @@ int orc_irreg_sizes(orc_ctx* c, int* L, int* nf, int* nt) {
     *L      = int(w->ex_irf_time_sampled_[0].size());
     *nf     = int(w->spectrum_frequencies_.size());
     *nt     = int(w->free_surface_time_sampled_.size());
+    ORC_CATCH(c)
+}
+int orc_irreg_irf_size(orc_ctx* c, int b, int* L) {  // bodies may carry different grids (src/wave_types.cpp:432-459)
+    ORC_TRY
+    *L = int(orc_irreg(c)->ex_irf_time_sampled_.at(size_t(b)).size());
     ORC_CATCH(c)
 }
 int orc_irreg_get_irf(orc_ctx* c, int b, double* t, double* width, double* vals /*[6][L]*/) {

@@ -28,9 +28,18 @@ def sphere_case():
 def three_body_case():
     """The generated three-body BEMIO fixture (tests/golden/make_multibody_bemio.py): dataset shapes of a multi-body BEMIO
     file (added_mass/inf_freq {6,18}, impulse_response_fun/K {6,18,S}) and water_depth = "infinite"."""
-    z = np.load(os.path.join(GOLDEN_DIR, "three_body_bemio.npz"))
+    return multi_body_fixture("three_body", 3)
+
+
+def four_body_case():
+    """four_body.h5 of the same generator (D = 24): read by the multi-shard C++ test with 1, 2 and 4 row shards."""
+    return multi_body_fixture("four_body", 4)
+
+
+def multi_body_fixture(stem, N):
+    z = np.load(os.path.join(GOLDEN_DIR, stem + "_bemio.npz"))
     bodies = []
-    for b in (1, 2, 3):
+    for b in range(1, N + 1):
         p = f"body{b}/"
         bodies.append(dict(
             disp_vol=float(z[p + "properties/disp_vol"]), cg=z[p + "properties/cg"], cb=z[p + "properties/cb"],
@@ -40,7 +49,7 @@ def three_body_case():
             ex_mag=z[p + "hydro_coeffs/excitation/mag"], ex_phase=z[p + "hydro_coeffs/excitation/phase"],
             ex_irf_t=z[p + "hydro_coeffs/excitation/impulse_response_fun/t"],
             ex_irf_f=z[p + "hydro_coeffs/excitation/impulse_response_fun/f"]))
-    return dict(N=3, rho=float(z["simulation_parameters/rho"]), g=float(z["simulation_parameters/g"]), water_depth=float("inf"),
+    return dict(N=N, rho=float(z["simulation_parameters/rho"]), g=float(z["simulation_parameters/g"]), water_depth=float("inf"),
                 bodies=bodies)
 
 

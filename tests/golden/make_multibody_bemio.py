@@ -82,9 +82,9 @@ int main(int argc, char** argv) {
 '''
 
 
-def main():
-    N, S, nw, n_exc = 3, 32, 16, 33
-    case = many_body_case(N, S=S, dt_rirf=0.02, n_exc=n_exc, dt_exc=0.05, nw=nw, seed=31337)
+def write_case(N, seed, stem, vlen_copy):
+    S, nw, n_exc = 32, 16, 33
+    case = many_body_case(N, S=S, dt_rirf=0.02, n_exc=n_exc, dt_exc=0.05, nw=nw, seed=seed)
     recs, flat = [], {}
 
     def num(name, arr, shape):
@@ -121,10 +121,18 @@ def main():
                     f.write((name + "\n" + " ".join([str(a.ndim)] + [str(d) for d in a.shape]) + "\n").encode() + a.tobytes())
         open(src, "w").write(WRITER)
         subprocess.run(["gcc", "-O1", src, "-o", exe, "-I/opt/conda/include", "-L/opt/conda/lib", "-lhdf5", "-Wl,-rpath,/opt/conda/lib"], check=True)
-        subprocess.run([exe, spec, os.path.join(HERE, "three_body.h5"), "0"], check=True)
-        subprocess.run([exe, spec, os.path.join(HERE, "three_body_vlen.h5"), "1"], check=True)
-    np.savez_compressed(os.path.join(HERE, "three_body_bemio.npz"), **flat)
-    print("wrote three_body.h5, three_body_vlen.h5, three_body_bemio.npz")
+        subprocess.run([exe, spec, os.path.join(HERE, stem + ".h5"), "0"], check=True)
+        if vlen_copy:
+            subprocess.run([exe, spec, os.path.join(HERE, stem + "_vlen.h5"), "1"], check=True)
+    np.savez_compressed(os.path.join(HERE, stem + "_bemio.npz"), **flat)
+    print(f"wrote {stem}.h5, {stem}_bemio.npz" + (f", {stem}_vlen.h5" if vlen_copy else ""))
+
+
+def main():
+    write_case(3, 31337, "three_body", True)
+    # four bodies (D = 24: a multiple of 8, the scalar-tracker form of the look-ahead pass): the file the multi-shard C++ test
+    # (tests/cpp/shards_test.cpp) reads with 1, 2 and 4 row shards
+    write_case(4, 4242, "four_body", False)
 
 
 if __name__ == "__main__":

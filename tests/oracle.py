@@ -140,6 +140,10 @@ class Oracle:
             self.ctx, C.c_int(smoothing), C.c_int(window_length), C.c_double(rirf_end_time),
             C.c_double(taper_start_percent), C.c_double(taper_end_percent), C.c_double(taper_final_amplitude)))
 
+    def set_diagnostics(self, export_plot_csv, directory=""):
+        """opts.export_plot_csv + SetDiagnosticsOutputDirectory (include/hydroc/hydro_forces.h:258,269)."""
+        self._chk(self.L.orc_set_diagnostics(self.ctx, C.c_int(int(export_plot_csv)), str(directory).encode()))
+
     # ---- stepping ----
     def step(self, t, pos, rpy, linvel, angvel):
         out = np.empty(self.D)
@@ -186,7 +190,9 @@ class Oracle:
         return L.value, nf.value, nt.value
 
     def irreg_irf(self, b=0):
-        L, _, _ = self.irreg_sizes()
+        Lb = C.c_int()
+        self._chk(self.L.orc_irreg_irf_size(self.ctx, C.c_int(b), C.byref(Lb)))
+        L = Lb.value
         t, w, v = np.empty(L), np.empty(L), np.empty((6, L))
         self._chk(self.L.orc_irreg_get_irf(self.ctx, b, _p(t), _p(w), _p(v.reshape(-1))))
         return t, w, v

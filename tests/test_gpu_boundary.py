@@ -1,0 +1,192 @@
+"""Boundary behaviours added in round 3, each against the CPU oracle (through the C ABI, -m gpu):
+
+* a step BACK in time (an integrator that rejected a step): the samples at times >= t are dropped and the evaluation continues --
+  checked against an oracle whose history was rolled back the same way (the reference itself keeps the abandoned samples in a
+  non-monotone list, src/hydro_forces.cpp:559-574; that is documented as a deliberate deviation);
+* per-body excitation-IRF time grids (the reference keeps one grid per body, src/wave_types.cpp:432-459);
+* the TaperedDirect diagnostics CSV + SetDiagnosticsOutputDirectory (src/hydro_forces.cpp:509-531)."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import load_into_oracle
+
+pytestmark = pytest.mark.gpu
+TIGHT_TOL = 1e-10
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def HF():
+    import torch  # noqa: F401
+    from hydrochrono_amd.hydro import HydroForces
+    return HydroForces
+
+
+@pytest.mark.parametrize("lookahead", [32, 16, 0])
+def test_step_back_in_time_rewinds_the_history(HF, lookahead):
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    N = 4
+    case = many_body_case(N, S=150, dt_rirf=0.01, n_exc=33, seed=61)
+    gpu = HF.from_case(case)
+    gpu.set_lookahead(lookahead)
+    gpu.add_waves_none()
+    motion = PrescribedMotion(N, rest_positions(case), seed=6)
+    log = []  # (t, velocity) of every sample the history should hold, oldest first
+
+    def fresh_oracle():
+        """An oracle whose history is exactly the samples kept so far (newest first)."""
+        o = load_into_oracle(case)
+        o.add_waves_none()
+        if log:
+            o.prefill_history(np.array([t for t, _ in reversed(log)]), np.stack([v for _, v in reversed(log)]))
+        return o
+
+    orc = fresh_oracle()
+
+    def step(t, perturb=0.0):
+        st = [x + perturb for x in motion.state(t)]  # a retried step may arrive with another state than the abandoned one
+        fg, fo = gpu.step(t, *st), orc.step(t, *st)
+        assert relerr(fg, fo) <= TIGHT_TOL, f"t = {t}"
+        for g, o in zip(gpu.components(), orc.components()):
+            assert relerr(g, o) <= TIGHT_TOL or np.max(np.abs(o)) == 0.0
+        log.append((t, np.concatenate([st[2].reshape(N, 3), st[3].reshape(N, 3)], axis=1).reshape(-1)))
+
+    def rewind(t):
+        nonlocal orc
+        while log and log[-1][0] >= t:
+            log.pop()
+        orc = fresh_oracle()
+
+    t = 0.0
+    for n in range(90):           # into look-ahead blocks
+        step(t)
+        t += 0.01
+    # 1. the integrator rejects the last step and retries with half the step size, from a different predictor state
+    rewind(t - 0.015)
+    t = t - 0.015
+    for n in range(40):
+        step(t, perturb=1e-3)
+        t += 0.005
+    for n in range(70):           # back on the IRF grid spacing: blocks again
+        step(t)
+        t += 0.01
+    # 2. several samples back, landing exactly ON a stored sample time (that sample is dropped too: times stay strictly decreasing)
+    t_back = log[-6][0]
+    rewind(t_back)
+    t = t_back
+    for n in range(80):
+        step(t)
+        t += 0.01
+    # 3. one and a half steps back, to a time between two stored samples
+    t = t - 0.016
+    rewind(t)
+    for n in range(50):
+        step(t)
+        t += 0.01
+    # 4. back before everything: an empty history, the first-step rules apply again (no radiation until two samples exist)
+    rewind(-1.0)
+    t = -1.0
+    for n in range(45):
+        step(t)
+        t += 0.01
+    p = gpu.profile()
+    assert p["history_rewinds"] == 4
+    th, _ = gpu.get_history()
+    assert np.array_equal(th, np.array([tt for tt, _ in reversed(log)])[: th.size]) and np.all(np.diff(th) < 0)
+    # the per-time cache still answers a repeated time, and the duplicate-time rule of the radiation term is kept
+    st = motion.state(t - 0.01)
+    assert np.array_equal(gpu.step(t - 0.01, *st), gpu.step(t - 0.01, *st))
+    from hydrochrono_amd.hydro import HydroError
+    with pytest.raises(HydroError) as e:
+        gpu.compute_radiation(t - 0.01, st[2], st[3])
+    assert e.value.status == 1 and "twice within the same time step" in str(e.value)
+
+
+def ragged_case():
+    """Three bodies: body 1 carries another excitation-IRF grid (other length, other spacing, other span) than bodies 0 and 2."""
+    from hydrochrono_amd.synthetic import many_body_case
+    case = many_body_case(3, S=96, dt_rirf=0.01, n_exc=41, dt_exc=0.05, seed=88)
+    other = many_body_case(3, S=96, dt_rirf=0.01, n_exc=57, dt_exc=0.03, seed=89)
+    case["bodies"][1]["ex_irf_t"] = other["bodies"][1]["ex_irf_t"]
+    case["bodies"][1]["ex_irf_f"] = other["bodies"][1]["ex_irf_f"]
+    return case
+
+
+def test_per_body_excitation_irf_grids(HF):
+    from hydrochrono_amd.hydro import HydroGroup
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import rest_positions
+    case = ragged_case()
+    gpu, orc = HF.from_case(case), load_into_oracle(case)
+    group = HydroGroup.from_case(case, 3)
+    kw = dict(simulation_dt=0.01, simulation_duration=6.0, ramp_duration=0.7, wave_height=2.0, wave_period=6.0,
+              frequency_min=0.05, frequency_max=0.6, nfrequencies=40, peak_enhancement_factor=3.3)
+    for h in (gpu, orc, group):
+        h.add_waves_irregular(**kw)
+    sizes = []
+    for b in range(3):
+        (tg, wg, vg), (to, wo, vo) = gpu.irreg_irf(b), orc.irreg_irf(b)
+        assert np.array_equal(tg, to) and np.array_equal(wg, wo)          # each body's own resampled grid ...
+        assert relerr(vg, vo) <= 1e-9                                    # ... and spline-resampled values
+        sizes.append(tg.size)
+    assert sizes[0] == sizes[2] != sizes[1]
+    assert gpu.sizes()["L"] == sizes[0] + sizes[1]                       # two distinct grids = the columns of the excitation matrix
+    (tg, eg), (to, eo) = gpu.irreg_eta(), orc.irreg_eta()
+    assert np.array_equal(tg, to)                                        # the table spans the union of the grids (src/wave_types.cpp:719-735)
+    assert np.max(np.abs(eg - eo)) <= 1e-11 * np.max(np.abs(eo))
+    motion = PrescribedMotion(3, rest_positions(case), seed=5)
+    for n in range(300):
+        t = 0.01 * n
+        st = motion.state(t)
+        fg, fo = gpu.step(t, *st), orc.step(t, *st)
+        assert relerr(fg, fo) <= TIGHT_TOL, f"step {n}"
+        assert relerr(gpu.components()[2], orc.components()[2]) <= TIGHT_TOL
+        assert np.array_equal(group.step(t, *st), fg)                    # every shard lays the columns out alike: bitwise
+    # the excitation window: every body's grid is checked (src/wave_types.cpp:826-840); here the longer grid of bodies 0 / 2 ends first
+    from hydrochrono_amd.hydro import HydroError
+    t_end = tg[-1] + min(case["bodies"][0]["ex_irf_t"][0], case["bodies"][1]["ex_irf_t"][0]) + 0.5
+    with pytest.raises(HydroError) as e:
+        gpu.step(t_end, *motion.state(t_end))
+    assert e.value.status == 1 and "out of bounds" in str(e.value)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(smoothing=1, window_length=7, rirf_end_time=0.6, taper_start_percent=0.5, taper_end_percent=0.9,
+                                          taper_final_amplitude=0.2)])
+def test_tapered_direct_diagnostics_csv(HF, tmp_path, opts):
+    from hydrochrono_amd.synthetic import many_body_case
+    case = many_body_case(3, S=80, dt_rirf=0.01, n_exc=9, seed=17)
+    gdir, odir = tmp_path / "gpu", tmp_path / "oracle"
+    gdir.mkdir()
+    odir.mkdir()
+    gpu, orc = HF.from_case(case, body_range=(1, 3)), load_into_oracle(case)  # a row shard writes the files of ITS bodies
+    gpu.set_convolution_mode(1)
+    orc.set_convolution_mode(1)
+    gpu.set_diagnostics_output_directory(gdir)
+    gpu.set_tapered_direct_options(export_plot_csv=True, **opts)
+    orc.set_tapered_direct_options(**opts)
+    orc.set_diagnostics(True, odir)
+    z = np.zeros(9)
+    gpu.compute_radiation(0.0, z, z)  # the kernel is processed (and the files written) on first use, as in the reference
+    orc.compute_radiation(0.0, z, z)
+    assert sorted(os.listdir(odir)) == [f"rirf_body{b}_summary.csv" for b in range(3)]
+    assert sorted(os.listdir(gdir)) == [f"rirf_body{b}_summary.csv" for b in (1, 2)]
+    for b in (1, 2):
+        g = (gdir / f"rirf_body{b}_summary.csv").read_text().splitlines()
+        o = (odir / f"rirf_body{b}_summary.csv").read_text().splitlines()
+        assert g[0] == o[0] == "step,time,k_before,k_after" and len(g) == len(o) > 10
+        ga, oa = (np.array([[float(x) for x in ln.split(",")] for ln in rows[1:]]) for rows in (g, o))
+        assert np.array_equal(ga[:, :3], oa[:, :3])              # step, time and the raw (rho-scaled) kernel print identically
+        assert np.allclose(ga[:, 3], oa[:, 3], rtol=2e-6, atol=0)  # processed values: 6 printed digits of numbers that agree to ~1e-15
+        assert sum(a != b_ for a, b_ in zip(g, o)) <= 2            # (a last-digit print difference at most here and there)
+    # without the flag nothing is written; an unwritable directory is ignored like in the reference (:529)
+    quiet = HF.from_case(case)
+    quiet.set_convolution_mode(1)
+    quiet.set_diagnostics_output_directory(tmp_path / "does" / "not" / "exist")
+    quiet.set_tapered_direct_options(export_plot_csv=True)
+    assert np.all(np.isfinite(quiet.compute_radiation(0.0, z, z)))

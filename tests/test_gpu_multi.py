@@ -1,0 +1,182 @@
+"""Multi-GPU inside ONE host process through the C ABI (hc_step_multi / hc_added_mass_mv_multi, hc_step_begin / hc_step_end) and
+through the C++ plugin surface (TestHydro / ChronoHydroSystem with a device list): SURVEY 8e's drop-in variant -- the host holds
+all body states, every GPU gets a state store, the host gathers the force rows.  The box has one GPU, so the shard contexts share
+it; the code path (G contexts, G queues, all doorbells before any wait, host gather) is the one an 8-GPU node runs.
+
+Bar: the gathered vector is BITWISE the unsharded one (same kernels, same per-row arithmetic and order), and <= 1e-10 of the CPU
+oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cases import GOLDEN_DIR, four_body_case, load_into_oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TIGHT_TOL = 1e-10
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def hydro():
+    import torch  # noqa: F401
+    from hydrochrono_amd import hydro as h
+    return h
+
+
+WAVES = dict(simulation_dt=0.01, simulation_duration=8.0, ramp_duration=0.5, wave_height=2.0, wave_period=6.0,
+             frequency_min=0.05, frequency_max=0.6, nfrequencies=48, peak_enhancement_factor=3.3)
+
+
+@pytest.mark.parametrize("n_shards", [2, 4, 8])
+@pytest.mark.parametrize("lookahead", [32, 0])
+def test_step_multi_is_bitwise_the_unsharded_context(hydro, n_shards, lookahead):
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    N = 8
+    case = many_body_case(N, S=160, dt_rirf=0.01, n_exc=65, dt_exc=0.02, seed=900 + n_shards)
+    case["g_sys"] = [0.3, -0.2, -9.7]
+    full = hydro.HydroForces.from_case(case)
+    group = hydro.HydroGroup.from_case(case, n_shards)
+    orc = load_into_oracle(case)
+    for h in (full, group, orc):
+        h.add_waves_irregular(**WAVES)
+    full.set_lookahead(lookahead)
+    group.set_lookahead(lookahead)
+    motion = PrescribedMotion(N, rest_positions(case), seed=4)
+    rng = np.random.default_rng(1)
+    t = 0.0
+    for n in range(330):
+        st = motion.state(t)
+        ref, got = full.step(t, *st), group.step(t, *st)
+        assert np.array_equal(ref, got), f"step {n}: gathered vector differs from the unsharded one"
+        assert relerr(got, orc.step(t, *st)) <= TIGHT_TOL, f"step {n} vs oracle"
+        assert np.array_equal(group.step(t, *st), got)  # the per-time cache of every shard answers a repeated time
+        if n % 50 == 7:
+            for a, b in zip(full.components(), group.components()):
+                assert np.array_equal(a, b)
+            w, R0 = rng.normal(size=6 * N + 5), rng.normal(size=6 * N + 5)  # a system with more coordinates than the hydro block
+            Rf, Rg = full.added_mass_mv(R0, w[:6 * N + 5], 0.75), group.added_mass_mv(R0, w, 0.75)
+            assert np.array_equal(Rf, Rg) and np.array_equal(Rg[6 * N:], R0[6 * N:])
+            assert relerr(Rg[:6 * N], R0[:6 * N] + 0.75 * (full.added_mass_matrix() @ w[:6 * N])) <= 1e-13
+        t += 0.01 if n % 120 != 100 else 0.0123  # an off-grid step drops the look-ahead block in every shard alike
+    if lookahead:
+        # the shard contexts really used look-ahead blocks and, on this box, the direct queue
+        for h in group.shards:
+            assert h.direct_dispatch()[0], h.direct_dispatch()[1]
+            p = h.profile()
+            assert p["direct_dispatches"] > 300 and p["history_rewinds"] == 0
+
+
+def test_step_begin_end_and_error_paths(hydro):
+    from hydrochrono_amd import capi
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    import ctypes as C
+    N = 4
+    case = many_body_case(N, S=96, dt_rirf=0.01, n_exc=33, seed=41)
+    a, b = hydro.HydroForces.from_case(case), hydro.HydroForces.from_case(case)
+    group = hydro.HydroGroup.from_case(case, 2)
+    for h in (a, b, group):
+        h.add_waves_none()
+    motion = PrescribedMotion(N, rest_positions(case), seed=8)
+    lib = a.lib
+    dp = lambda x: x.ctypes.data_as(capi.c_double_p)  # noqa: E731
+    out = np.empty(6 * N)
+    for n in range(120):
+        t = 0.01 * n
+        st = [np.ascontiguousarray(x, dtype=np.float64).reshape(-1) for x in motion.state(t)]
+        assert lib.hc_step_begin(a.ctx, t, *[dp(x) for x in st]) == 0
+        ref = b.step(t, *st)  # the host is free between the two halves
+        assert lib.hc_step_end(a.ctx, dp(out)) == 0
+        assert np.array_equal(out, ref)
+    # protocol errors: end without begin, begin twice, a full step while one is pending
+    assert lib.hc_step_end(a.ctx, dp(out)) == capi.HC_ERR_INVALID
+    t = 1.2
+    st = [np.ascontiguousarray(x, dtype=np.float64).reshape(-1) for x in motion.state(t)]
+    assert lib.hc_step_begin(a.ctx, t, *[dp(x) for x in st]) == 0
+    assert lib.hc_step_begin(a.ctx, t + 0.01, *[dp(x) for x in st]) == capi.HC_ERR_INVALID
+    # (the failed call leaves nothing pending, as documented, so the next begin/end pair works again)
+    assert lib.hc_step_begin(a.ctx, t + 0.02, *[dp(x) for x in st]) == 0
+    assert lib.hc_step_end(a.ctx, dp(out)) == 0
+    # a failing shard step: every context of the group reports the message and none is left pending
+    group.step(0.0, *motion.state(0.0))
+    group.add_waves_none(num_bodies=1)  # wave model for fewer bodies than N: the reference's short force vector, an error here
+    with pytest.raises(hydro.HydroError) as e:
+        group.step(0.01, *motion.state(0.01))
+    assert e.value.status == capi.HC_ERR_RUNTIME and "fewer bodies" in str(e.value)
+    for h in group.shards:
+        assert b"fewer bodies" in lib.hc_last_error(h.ctx)
+    group.add_waves_none()
+    f = group.step(0.02, *motion.state(0.02))
+    assert np.all(np.isfinite(f))
+    # contexts of different systems in one group
+    other = hydro.HydroForces.from_case(many_body_case(2, S=32, n_exc=9, seed=3))
+    ctxs = (C.c_void_p * 2)(a.ctx, other.ctx)
+    z = np.zeros(3 * N)
+    assert lib.hc_step_multi(ctxs, 2, 5.0, dp(z), dp(z), dp(z), dp(z), dp(out)) == capi.HC_ERR_INVALID
+
+
+def _build(tmp_path, name):
+    from hydrochrono_amd import build as hb
+    hb.build()
+    if not os.path.exists(hb.BEMIO_LIB):
+        pytest.skip("libhdf5 not available: BEMIO reader not built")
+    libdir = os.path.join(ROOT, "hydrochrono_amd", "lib")
+    out = str(tmp_path / name)
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "cpp", "chrono_stub"),
+                    os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", out, "-L", libdir, "-lhydrochrono_amd", f"-Wl,-rpath,{libdir}"],
+                   check=True)
+    return out
+
+
+@pytest.mark.parametrize("mode", ["irregular", "regular"])
+def test_sharded_plugin_surface_through_componentfunc(tmp_path, mode):
+    """ChronoHydroSystem with 1, 2 and 4 shard contexts on the one GPU, forces read through ChForce -> ComponentFunc::GetVal (24
+    callbacks per time, one hc_step_multi), the added mass through ChLoadAddedMass::LoadIntLoadResidual_Mv."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    exe = _build(tmp_path, "shards_test")
+    case = four_body_case()
+    N, nsteps, dt = 4, 260, 0.005  # IRF window 0.62 s: depth-32 blocks of 0.16 s are planned
+    motion = PrescribedMotion(N, np.stack([b["cg"] for b in case["bodies"]]), seed=21)
+    states = np.stack([motion.packed(n * dt) for n in range(nsteps)])
+    spath = str(tmp_path / "states.bin")
+    states.tofile(spath)
+    outs = {}
+    for G in (1, 2, 4):
+        r = subprocess.run([exe, os.path.join(GOLDEN_DIR, "four_body.h5"), str(N), spath, str(nsteps), repr(dt), str(G), mode],
+                           check=True, capture_output=True, text=True)
+        lines = r.stdout.strip().splitlines()
+        prof = [[int(x) for x in ln.split()[1:]] for ln in lines if ln.startswith("PROF")]
+        assert len(prof) == G
+        for blocks, scatters, direct, hip, active in prof:
+            assert blocks >= 4 and scatters >= 100, "look-ahead blocks were not in use"
+            assert active == 1 and direct > nsteps, "the shard contexts did not use the direct queue"
+        outs[G] = [ln for ln in lines if not ln.startswith("PROF")]
+        assert len(outs[G]) == nsteps + 1 and outs[G][-1].startswith("MV")
+    assert outs[2] == outs[1] and outs[4] == outs[1]  # 17 significant digits: bitwise the unsharded object, forces and R
+    # ... and the oracle on the same inputs
+    orc = load_into_oracle(case)
+    orc.set_gravity([0.3, -0.2, -9.7])
+    if mode == "regular":
+        orc.add_waves_regular(0.8, 0.55)
+    else:
+        orc.add_waves_irregular(**dict(WAVES, simulation_dt=dt))
+    got = np.array([[float(x) for x in ln.split()] for ln in outs[4][:-1]])
+    n3 = 3 * N
+    for n in range(nsteps):
+        st = states[n]
+        fo = orc.step(n * dt, st[:n3], st[n3:2 * n3], st[2 * n3:3 * n3], st[3 * n3:])
+        assert relerr(got[n], fo) <= TIGHT_TOL, f"step {n}"
+    n_sys = 6 * N + 6
+    w, R0 = 0.1 * (np.arange(n_sys) + 1) - 0.7, 1.0 + 0.01 * np.arange(n_sys)
+    M = np.concatenate([case["rho"] * np.asarray(b["added_mass_inf"]).reshape(6, 6 * N) for b in case["bodies"]])
+    expect = R0.copy()
+    expect[:6 * N] += 0.5 * (M @ w[:6 * N])
+    R = np.array([float(x) for x in outs[4][-1].split()[1:]])
+    assert relerr(R, expect) <= 1e-13

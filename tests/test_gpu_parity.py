@@ -180,19 +180,56 @@ def test_sphere_prescribed_motion_all_terms(HF):
 # multi-body synthetic cases (no multi-body reference data exists: parity is oracle-only, unpinned)
 # ------------------------------------------------------------------------------------------------
 # N = 8, 12: D % 8 == 0 and D >= 32 -> the scalar-tracker form of the look-ahead pass with chunk boundaries inside IRF samples
+# every way the step path can run, selected IN the suite (the driver's run exercises them all, not only the defaults): look-ahead
+# depth 32 / 16 / off x kernels handed to the GPU as AQL packets by the library itself / through HIP launches
+MODES = [(32, 1), (16, 1), (0, 1), (32, 0), (16, 0), (0, 0)]
+MODE_IDS = [f"la{la}-{'aql' if d else 'hip'}" for la, d in MODES]
+
+
+def make_gpu_mode(HF, case, mode, monkeypatch):
+    lookahead, direct = mode
+    monkeypatch.setenv("HC_DIRECT", str(direct))  # read when the context is finalized
+    gpu = HF.from_case(case)
+    gpu.set_lookahead(lookahead)
+    active, why = gpu.direct_dispatch()
+    if direct:
+        assert active, f"direct dispatch is not active on this box: {why}"
+    else:
+        assert (active, why) == (False, "disabled by HC_DIRECT=0")
+    return gpu
+
+
+def assert_mode_was_used(gpu, mode, min_steps):
+    """The counters of the context say how its kernels reached the GPU and whether look-ahead blocks were in use."""
+    lookahead, direct = mode
+    p = gpu.profile()
+    if direct:
+        assert p["direct_dispatches"] >= min_steps and p["hip_launches"] == 0, p
+    else:
+        assert p["hip_launches"] >= min_steps and p["direct_dispatches"] == 0, p
+    return p
+
+
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
 @pytest.mark.parametrize("N,dt", [(2, 0.01), (3, 0.007), (4, 0.01), (4, 0.013), (8, 0.01), (8, 0.007), (12, 0.013)])
-def test_multibody_parity(HF, N, dt):
+def test_multibody_parity(HF, N, dt, mode, monkeypatch):
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     from hydrochrono_amd.synthetic import many_body_case, rest_positions
     case = many_body_case(N, S=257, dt_rirf=0.01, n_exc=301, dt_exc=0.02, seed=100 + N)
     case["g_sys"] = [0.3, -0.2, -9.7]  # non-vertical gravity exercises all buoyancy-moment terms
-    gpu, orc = make_pair(HF, case)
+    gpu, orc = make_gpu_mode(HF, case, mode, monkeypatch), load_into_oracle(case)
     kw = dict(simulation_dt=dt, simulation_duration=6.0, ramp_duration=1.0, wave_height=2.5, wave_period=8.0,
               frequency_min=0.02, frequency_max=0.5, nfrequencies=128, peak_enhancement_factor=3.3, seed=1)
     gpu.add_waves_irregular(**kw)
     orc.add_waves_irregular(**kw)
     motion = PrescribedMotion(N, rest_positions(case), seed=N)
+    gpu.enable_profiling(1)
     drive_both(gpu, orc, motion, dt * np.arange(420))
+    p = assert_mode_was_used(gpu, mode, 420)
+    if mode[0]:
+        assert p["block_kernel_launches"] >= 420 // mode[0] - 3 and p["scatter_kernel_launches"] >= 300, p
+    else:
+        assert p["block_kernel_launches"] == 0 and p["conv_kernel_launches"] >= 400, p
 
 
 def test_multibody_regular_wave_phase_indexing(HF):
@@ -552,35 +589,70 @@ def test_bemio_h5_multibody_ingest(HF, fname):
 # plus size-independent properties
 # ------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
-def c3(HF):
+def c3_case():
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     from hydrochrono_amd.synthetic import many_body_case, rest_positions
     case = many_body_case(64, S=1024, dt_rirf=0.01, n_exc=1024, dt_exc=0.01)
-    gpu = HF.from_case(case)
-    motion = PrescribedMotion(64, rest_positions(case))
-    return case, gpu, motion
+    return case, PrescribedMotion(64, rest_positions(case))
 
 
+@pytest.fixture(scope="module", params=[1, 0], ids=["aql", "hip"])
+def c3_mode(HF, c3_case, request):
+    """The C3 context once per dispatch mode (HC_DIRECT is read when a context is finalized)."""
+    old = os.environ.get("HC_DIRECT")
+    os.environ["HC_DIRECT"] = str(request.param)
+    try:
+        gpu = HF.from_case(c3_case[0])
+    finally:
+        if old is None:
+            del os.environ["HC_DIRECT"]
+        else:
+            os.environ["HC_DIRECT"] = old
+    active, why = gpu.direct_dispatch()
+    assert active == bool(request.param), why
+    yield c3_case[0], gpu, c3_case[1], request.param
+    gpu.close()
+
+
+@pytest.fixture(scope="module")
+def c3(HF, c3_case):
+    gpu = HF.from_case(c3_case[0])
+    yield c3_case[0], gpu, c3_case[1]
+    gpu.close()
+
+
+@pytest.mark.parametrize("lookahead", [32, 16, 0])
 @pytest.mark.parametrize("dt", [0.01, 0.007])  # SURVEY 8d: the common dt = dt_rirf and a step that makes every sample interpolate
-def test_c3_full_size_against_oracle(c3, dt):
-    case, gpu, motion = c3
+def test_c3_full_size_against_oracle(c3_mode, dt, lookahead):
+    """Full-size C3 (64 bodies, S = 1024, Nf = 512) from a steady-state history: 72 steps = the plain boundary step, two whole
+    depth-32 blocks (pass -> 32 block steps -> the NEXT pass -> block steps) and the start of a third, totals and components
+    against the oracle at every step."""
+    case, gpu, motion, direct = c3_mode
     orc = load_into_oracle(case)
     kw = dict(simulation_dt=dt, simulation_duration=60.0, wave_height=2.0, wave_period=8.0, frequency_min=0.02,
               frequency_max=0.5, nfrequencies=512, peak_enhancement_factor=3.3, seed=1)
     gpu.reset_history()
+    gpu.set_lookahead(lookahead)
     gpu.add_waves_irregular(**kw)
     orc.add_waves_irregular(**kw)
     t_hist = 20.0 - dt * np.arange(1, int(np.ceil(10.24 / dt)) + 6)  # newest first, covers the whole 10.23 s window
     v_hist = np.stack([motion.velocity6(t) for t in t_hist])
     gpu.set_history(t_hist, v_hist)
     orc.prefill_history(t_hist, v_hist)
-    for n in range(19):  # boundary step, a full 16-step look-ahead block, the next boundary and one more
+    gpu.enable_profiling(1)
+    gpu.reset_profile()
+    nsteps = 72 if lookahead else 6
+    for n in range(nsteps):
         t = 20.0 + n * dt
         st = motion.state(t)
         fg, fo = gpu.step(t, *st), orc.step(t, *st)
         assert_close(fg, fo, TIGHT_TOL, f"C3 total force, step {n}")
         for g, o in zip(gpu.components(), orc.components()):
             assert_close(g, o, TIGHT_TOL, f"C3 component, step {n}")
+    p = assert_mode_was_used(gpu, (lookahead, direct), nsteps)
+    if lookahead:
+        assert p["block_kernel_launches"] == (nsteps - 1 + lookahead - 1) // lookahead and p["conv_kernel_launches"] == 1, p
+    gpu.enable_profiling(0)
 
 
 def test_c3_linearity_and_delta_kernel_properties(c3):
@@ -620,7 +692,8 @@ def test_c3_linearity_and_delta_kernel_properties(c3):
 # BASELINE.json configs that are parity cases rather than bench lines (synthetic stand-ins: rm3.h5 / deepcwind.h5 are
 # missing blobs of the reference snapshot)
 # ------------------------------------------------------------------------------------------------
-def test_config_c2_two_body_irregular_jonswap(HF):
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_config_c2_two_body_irregular_jonswap(HF, mode, monkeypatch):
     """C2: rm3-shaped two-body point absorber, irregular JONSWAP (Hs=2.5, Tp=8, gamma=3.3, nf=512), dt = 0.01 with the
     sphere's IRF grid (0..15 s @ 0.015 -> true interpolation), past one IRF window so look-ahead blocks are in use."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
@@ -629,7 +702,7 @@ def test_config_c2_two_body_irregular_jonswap(HF):
     case["bodies"][0]["cg"], case["bodies"][1]["cg"] = np.array([0.0, 0.0, -0.72]), np.array([0.0, 0.0, -21.29])  # demo_rm3 poses
     for b in case["bodies"]:
         b["cb"] = b["cg"] + np.array([0.0, 0.0, 0.3])
-    gpu, orc = make_pair(HF, case)
+    gpu, orc = make_gpu_mode(HF, case, mode, monkeypatch), load_into_oracle(case)
     kw = dict(simulation_dt=0.01, simulation_duration=40.0, ramp_duration=5.0, wave_height=2.5, wave_period=8.0,
               frequency_min=0.02, frequency_max=0.5, nfrequencies=512, peak_enhancement_factor=3.3, seed=1)
     gpu.add_waves_irregular(**kw)
@@ -638,8 +711,8 @@ def test_config_c2_two_body_irregular_jonswap(HF):
     drive_both(gpu, orc, motion, 0.01 * np.arange(1650), check_components=False)
     gpu.enable_profiling(1)
     drive_both(gpu, orc, motion, 0.01 * np.arange(1650, 1700))
-    if os.environ.get("HC_LOOKAHEAD", "16") != "0":
-        assert gpu.profile()["scatter_kernel_launches"] > 0
+    p = assert_mode_was_used(gpu, mode, 1700)
+    assert (p["scatter_kernel_launches"] > 0) == (mode[0] > 0)
 
 
 def test_config_c5_single_body_2048_components(HF):
@@ -963,23 +1036,12 @@ def test_edge_cases_and_argument_errors(HF):
     with pytest.raises(HydroError) as ei:
         h.set_body(1, b1["disp_vol"], b1["cg"], b1["cb"], b1["lin"], b1["added_mass_inf"], b1["rirf_t"] * 1.01, b1["rirf_K"])
     assert ei.value.status == 1 and "exactly the same for all bodies" in str(ei.value)
-    # ragged excitation-IRF grids across bodies are refused (BEMIO writes one grid per file)
-    g = HF.from_case(case2)
-    g.set_body_excitation_irf(1, b1["ex_irf_t"] * 1.5, b1["ex_irf_f"])
-    with pytest.raises(HydroError) as ei:
-        g.add_waves_irregular(**kw, num_bodies=2)
-    assert ei.value.status == 5
-    # wave model for the wrong number of bodies / zero sea state / time going backwards
+    # wave model for the wrong number of bodies / zero sea state (ragged excitation grids and steps back in time: test_gpu_boundary.py)
     g = HF.from_case(case2)
     with pytest.raises(HydroError):
         g.add_waves_irregular(**kw, num_bodies=1)
     with pytest.raises(HydroError):
         g.add_waves_irregular(simulation_dt=0.05, simulation_duration=2.0, wave_height=0.0, wave_period=4.0)
-    z12 = np.zeros(6)
-    g.step(1.0, z12, z12, z12, z12)
-    with pytest.raises(HydroError) as ei:
-        g.step(0.5, z12, z12, z12, z12)
-    assert ei.value.status == 3 and "must not decrease" in str(ei.value)
 
 
 def test_direct_dispatch_matches_hip_launches(HF, monkeypatch):

@@ -126,6 +126,10 @@ void ring_alloc(hc_ctx* c, int cap) {
     c->head = -1;
 }
 
+// Samples the prune rule has retired stay addressable for a while (their ring slots are simply not overwritten yet): a step back in
+// time re-admits them, so that the history after a rewind is what the reference's rule keeps at the earlier time.
+constexpr int kRewindSlack = 64;
+
 // Grow the ring so that `need` samples fit, keeping the `have` newest stored samples (k = 0..have-1) in order.
 void ring_grow(hc_ctx* c, int need, int have) {
     quiesce_direct(c);               // the scatter / pass of the last step may still be reading the ring on the direct queue
@@ -161,32 +165,49 @@ void ring_grow(hc_ctx* c, int need, int have) {
 // Push the time of this step and prune like PruneHistory; returns H (samples incl. the current one).
 // A step BACK in time (an integrator that rejected a step and retries from an earlier time -- the YAML runner's HHT does): the
 // samples at times >= t belong to the abandoned attempt; they are dropped, the look-ahead plan with them, and the evaluation
-// continues from the history as it was at t.  (The reference has no such rule: it inserts the earlier time in front of its
-// newest-first list, src/hydro_forces.cpp:559-574, keeps the abandoned samples and walks a non-monotone list from then on; that
-// is deliberately not reproduced -- hc_set_history / hc_reset_history remain for callers that manage the history themselves.)
+// continues from the history as it was at t -- samples the prune rule had retired since then are re-admitted (up to kRewindSlack
+// of them are kept addressable), so the history is exactly what the reference's rule keeps for a run that arrives at t with the
+// surviving samples.  (The reference has no such rule: it inserts the earlier time in front of its newest-first list,
+// src/hydro_forces.cpp:559-574, keeps the abandoned samples and walks a non-monotone list from then on; that is deliberately not
+// reproduced -- hc_set_history / hc_reset_history remain for callers that manage the history themselves.)
 int history_push(hc_ctx* c, double t) {
     if (!c->times.empty() && t == c->times.front())
         throw Error(HC_ERR_RUNTIME, "Tried to compute the radiation damping convolution twice within the same time step!");
+    const double tau_last         = c->tau.empty() ? 0.0 : c->tau.back();
+    const double history_min_time = t - tau_last;
     if (!c->times.empty() && t < c->times.front()) {
         int dropped = 0;
         while (!c->times.empty() && c->times.front() >= t) {
             c->times.pop_front();
             ++dropped;
         }
+        while (c->times.empty() && !c->retired.empty() && c->retired.front() >= t) {  // (a rewind past everything the rule had kept)
+            c->retired.pop_front();
+            ++dropped;
+        }
         // the ring keeps the dropped samples' slots for the samples to come; everything already enqueued (a scatter, a pass of the
         // abandoned plan) runs before this step's kernels on the same queue, so nothing is overwritten under a reader
-        c->head = c->times.empty() ? -1 : ((c->head - dropped) % c->Hcap + c->Hcap) % c->Hcap;
+        c->head = (c->times.empty() && c->retired.empty()) ? -1 : ((c->head - dropped) % c->Hcap + c->Hcap) % c->Hcap;
+        // re-admit retired samples until one older than the window of the new time is there again (the prune rule, read backwards)
+        while (!c->retired.empty() && (c->times.empty() || c->times.back() >= history_min_time)) {
+            c->times.push_back(c->retired.front());
+            c->retired.pop_front();
+        }
         c->plan.valid = false;
         c->plan.misses = 0;
         c->rewinds++;
         c->prof.history_rewinds++;
     }
-    const double tau_last         = c->tau.empty() ? 0.0 : c->tau.back();
-    const double history_min_time = t - tau_last;
     c->times.push_front(t);
-    while (c->times.size() > 1 && c->times[c->times.size() - 2] < history_min_time) c->times.pop_back();
+    while (c->times.size() > 1 && c->times[c->times.size() - 2] < history_min_time) {
+        c->retired.push_front(c->times.back());  // retired, still in its ring slot
+        c->times.pop_back();
+    }
     const int H = static_cast<int>(c->times.size());
-    if (H > c->Hcap) ring_grow(c, H, H - 1);
+    // retired samples live in the slots behind the oldest kept one for as long as the ring has room
+    while (!c->retired.empty() && (static_cast<int>(c->retired.size()) > kRewindSlack || H + static_cast<int>(c->retired.size()) > c->Hcap))
+        c->retired.pop_back();
+    if (H > c->Hcap) ring_grow(c, H + kRewindSlack, H - 1 + static_cast<int>(c->retired.size()));
     c->head = (c->head + 1) % c->Hcap;
     return H;
 }
@@ -1449,8 +1470,9 @@ int hc_finalize(hc_ctx* c) {
     c->d_vec_R.alloc(c->Dloc);
     c->d_stage.release();
     // history ring
-    ring_alloc(c, std::max(64, c->S + 2));
+    ring_alloc(c, std::max(64, c->S + 2) + kRewindSlack);
     c->times.clear();
+    c->retired.clear();
     c->have_prev = c->have_prev_device = false;
     c->prev_time = c->prev_time_device = -1.0;
     {
@@ -2161,6 +2183,7 @@ int hc_reset_history(hc_ctx* c) {
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     HC_HIP(hipDeviceSynchronize());  // steps may still be running on a caller's stream (hc_step_device)
     c->times.clear();
+    c->retired.clear();
     c->head = -1;
     c->have_last_stream = c->bg_pending = false;  // everything has run
     c->have_prev = c->have_prev_device = false;
@@ -2176,8 +2199,9 @@ int hc_set_history(hc_ctx* c, int n, const double* times, const double* vel) {
     for (int k = 1; k < n; ++k) require(times[k] < times[k - 1], HC_ERR_INVALID, "history times must be strictly decreasing (newest first)");
     HC_HIP(hipDeviceSynchronize());  // steps may still be running on a caller's stream (hc_step_device)
     c->have_last_stream = c->bg_pending = false;  // everything has run
-    if (n > c->Hcap) ring_alloc(c, n + 16);
+    if (n > c->Hcap) ring_alloc(c, n + 16 + kRewindSlack);
     c->times.assign(times, times + n);
+    c->retired.clear();
     // sample k -> slot n-1-k, head = n-1
     std::vector<double> tt(n), vv(static_cast<size_t>(n) * c->D);
     for (int k = 0; k < n; ++k) {

@@ -180,6 +180,7 @@ struct hc_ctx {
 
     // history (host mirror of times, newest first) + ring in HBM
     std::deque<double> times;
+    std::deque<double> retired;  // samples the prune rule has dropped, newest first; still in the ring slots behind the oldest kept one (history_push)
     int head = -1, Hcap = 0, HcapT = 0;
     hc::DeviceBuffer<double> d_ring_t, d_ring_v, d_ring_vT;  // ring_vT[D][HcapT = Hcap + 2]: per-DoF copy for the look-ahead pass
     long long rewinds = 0;  // steps back in time handled so far (history_push)

@@ -90,8 +90,8 @@ def test_step_back_in_time_rewinds_the_history(HF, lookahead):
         step(t)
         t += 0.01
     # 4. back before everything: an empty history, the first-step rules apply again (no radiation until two samples exist)
-    rewind(-1.0)
-    t = -1.0
+    rewind(-1.5)  # (not -1.0: the reference's per-time cache starts at the sentinel prev_time = -1, src/hydro_forces.cpp:176)
+    t = -1.5
     for n in range(45):
         step(t)
         t += 0.01

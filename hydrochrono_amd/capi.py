@@ -39,7 +39,8 @@ class ProfileStats(C.Structure):
                 ("block_kernel_bytes_once", C.c_double),
                 ("step_kernel_seconds", C.c_double), ("step_kernel_launches", C.c_longlong),
                 ("scatter_kernel_seconds", C.c_double), ("scatter_kernel_launches", C.c_longlong),
-                ("direct_dispatches", C.c_longlong), ("hip_launches", C.c_longlong), ("history_rewinds", C.c_longlong)]
+                ("direct_dispatches", C.c_longlong), ("hip_launches", C.c_longlong), ("history_rewinds", C.c_longlong),
+                ("mini_pass_seconds", C.c_double), ("mini_pass_launches", C.c_longlong)]
 
 
 # name -> (restype, argtypes); every symbol include/hydrochrono_amd.h declares

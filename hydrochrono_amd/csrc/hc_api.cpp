@@ -239,6 +239,11 @@ void profile_account(hc_ctx* c, int kind, double sec, double waves_share) {
             c->prof.scatter_kernel_launches += 1;
             c->prof.radiation_seconds += sec;
             break;
+        case hc::kEvMiniPass:  // short pass of the two-level form (one per sub-block of a wide system)
+            c->prof.mini_pass_seconds += sec;
+            c->prof.mini_pass_launches += 1;
+            c->prof.radiation_seconds += sec;
+            break;
         default:  // excitation-only convolution launch
             c->prof.waves_seconds += sec;
             break;
@@ -398,12 +403,14 @@ void choose_exc_config(hc_ctx* c) {
 void alloc_partials(hc_ctx* c) {
     const size_t n = static_cast<size_t>(c->nchunks_rad + c->nchunks_ex) * c->Dpad;
     if (c->d_partials.n < n) c->d_partials.alloc(n);
-    const size_t nb = static_cast<size_t>(c->nchunks_block + c->nchunks_ex_block) * hc::kLookahead * c->Dpad;
+    // (the short passes of the two-level form use the same buffer: at most kLookahead + kSubBlock + 2 IRF samples in chunks of half a sample)
+    const size_t nb = static_cast<size_t>(std::max(c->nchunks_block + c->nchunks_ex_block, 2 * (hc::kLookahead + hc::kSubBlock + 4))) * hc::kLookahead * c->Dpad;
     if (c->d_partials_block.n < nb) c->d_partials_block.alloc(nb);
     if (c->d_P.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_P.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
     if (c->d_E.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_E.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
     const size_t ny = static_cast<size_t>(hc::kLookahead + 1) * hc::kTermMax * c->Dpad;
     if (c->d_Y.n < ny) c->d_Y.alloc(ny);
+    if (c->d_near_partials.n < static_cast<size_t>(16) * c->Dpad) c->d_near_partials.alloc(static_cast<size_t>(16) * c->Dpad);
 }
 
 // ---- TaperedDirect ----------------------------------------------------------------------------
@@ -583,7 +590,15 @@ int plan_step(hc_ctx* c, double t, int H) {
     return 0;
 }
 
-bool make_plan(hc_ctx* c) { return hc::build_plan(c->plan, c->lookahead, c->times, c->tau, c->width); }
+// Wide systems (the same switch as the split own-sample kernel: a function of D only, so that row shards plan alike) use the
+// two-level form: their scatter launches would re-read (L/2) * K/S bytes from HBM every step.
+int plan_sub_block(const hc_ctx* c) {
+    const int forced = env_int("HC_SUB_BLOCK", -1);  // tests / tuning runs: 0 = single level, 4 / 8 = sub-block size
+    if (forced >= 0) return forced;
+    return hc::near_slices_for(c->D) > 1 ? hc::kSubBlock : 0;
+}
+
+bool make_plan(hc_ctx* c) { return hc::build_plan(c->plan, c->lookahead, c->times, c->tau, c->width, plan_sub_block(c), hc::near_slices_for(c->D)); }
 
 struct StepViews {
     hc::Panel kex;
@@ -685,6 +700,7 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = fal
         std::fprintf(stderr, "\n");
     }
     const double exc_share = exc_once / std::max(1.0, rad_once + exc_once);
+    const hc::ReduceArgs r{c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter, 0, 0, 0, 0};
     if (direct) {
         hc::BlockArgs b2;
         const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_block, &b2);
@@ -692,16 +708,82 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = fal
         c->dq->dispatch(L == 32 ? c->dk_block32 : c->dk_block16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
                         direct_tag(c, hc::kEvPass), exc_share);
         c->prof.direct_dispatches += 1;
-        hc::ReduceArgs r{c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter};
-        const int nblk = (L * c->Dpad + 15) / 16;
-        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(b.nchunks_ex > 0 ? 2 * nblk : nblk), 256, 0, &r, sizeof r);
+        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r);
         c->prof.direct_dispatches += 1;
         return;
     }
     hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_share);
     hc::launch_conv_block(b, c->mt_block, stream);
     ev_end(ev, stream);
-    hc::launch_reduce_block(c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter, stream);
+    hc::launch_reduce_block(r, stream);
+    c->prof.hip_launches += 2;
+}
+
+// The short pass of the two-level form after block step i0 (hc_plan.hpp: MiniPass): what the samples of the sub-block that has just
+// ended contribute to the block steps still to come, added to their rows of P.  The same kernel as the pass of the block, over
+// the first few IRF samples only, with the bracket table restricted to those samples (BlockArgs::mini_kw) and a chunking of its
+// own (half an IRF sample per chunk -- a function of D only, like every other chunk length).
+void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct) {
+    const auto& pl = c->plan;
+    const int L    = c->lookahead;
+    const hc::MiniPass mp = hc::mini_pass_setup(pl, L, i0, c->tau);
+    if (mp.n_samples <= 0 || mp.n_steps <= 0) return;
+    hc::HistoryView hv{};
+    hv.state   = c->d_zero_state.p;
+    hv.N       = c->N;
+    hv.D       = c->D;
+    hv.t       = mp.time[0];
+    hv.ring_t  = c->d_ring_t.p;
+    hv.ring_v  = c->d_ring_v.p;
+    hv.ring_vT = c->d_ring_vT.p;
+    hv.head    = (c->head + 1) % c->Hcap;  // slot of the not-yet-known sample of step i0 + 1
+    hv.H       = static_cast<int>(c->times.size()) + 1;
+    hv.Hcap    = c->Hcap;
+    hv.HcapT   = c->HcapT;
+    hv.dt_hint = pl.dt;
+    hc::BlockArgs b{};
+    b.K        = rad_panel(c);
+    b.F        = mp.n_samples * c->D;
+    b.depth    = L;
+    b.chunk_gp = std::max(16, (((c->D + 7) / 8 / 2 + 15) / 16) * 16);
+    b.nchunks  = std::max(1, ((b.F + 7) / 8 + b.chunk_gp - 1) / b.chunk_gp);
+    b.max_steps_per_chunk = (b.chunk_gp * 8) / c->D + 2;
+    b.hist     = hv;
+    for (int j = 0; j < L; ++j) {
+        b.tpred[j]   = mp.tpred[j];
+        b.s_cut[j]   = mp.s_cut[j];
+        b.s_defer[j] = mp.s_defer[j];
+    }
+    b.tau          = c->d_tau.p;
+    b.width        = c->d_width.p;
+    b.Kex          = make_views(c).kex;
+    b.ex           = make_views(c).ex;
+    b.chunk_gp_ex  = c->chunk_gp_ex_block;
+    b.nchunks_ex   = 0;
+    b.partials     = c->d_partials_block.p;
+    b.Dpad         = c->Dpad;
+    b.error_flag   = c->d_err.p;
+    b.item_counter = c->d_err.p + 1;
+    b.ngroups      = c->ntiles / c->mt_block;
+    b.mini_kw      = mp.kw;
+    b.mini_steps   = mp.n_steps;
+    for (int k = 0; k <= mp.kw + 1; ++k) b.mini_time[k] = mp.time[k];
+    require(static_cast<size_t>(b.nchunks) * L * c->Dpad <= c->d_partials_block.n, HC_ERR_RUNTIME, "short pass: partials buffer too small");
+    hc::ReduceArgs r{c->d_partials_block.p, b.nchunks, 0, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter, 1, i0, mp.n_steps, 0};
+    if (direct) {
+        hc::BlockArgs b2;
+        const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_block, &b2);
+        if (l.nblocks <= 0) return;
+        c->dq->dispatch(L == 32 ? c->dk_block32 : c->dk_block16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
+                        direct_tag(c, hc::kEvMiniPass));
+        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r);
+        c->prof.direct_dispatches += 2;
+        return;
+    }
+    hc::EventPair* ev = ev_begin(c, hc::kEvMiniPass, stream);
+    hc::launch_conv_block(b, c->mt_block, stream);
+    ev_end(ev, stream);
+    hc::launch_reduce_block(r, stream);
     c->prof.hip_launches += 2;
 }
 
@@ -748,8 +830,8 @@ void enqueue_tail(hc_ctx* c) {
             }
         }
         if (direct) {
-            c->dq->dispatch(c->dk_scatter, static_cast<uint32_t>(sa.K.ntiles * sa.ns), 256, static_cast<uint32_t>(sa.D * sizeof(double)), &sa, sizeof sa,
-                            direct_tag(c, hc::kEvScatter));
+            const hc::ScatterLaunch l = hc::scatter_launch_config(sa);
+            c->dq->dispatch(c->dk_scatter, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &sa, sizeof sa, direct_tag(c, hc::kEvScatter));
             c->prof.direct_dispatches += 1;
         } else {
             hc::EventPair* ev = ev_begin(c, hc::kEvScatter, bs);
@@ -757,6 +839,9 @@ void enqueue_tail(hc_ctx* c) {
             c->prof.hip_launches += 1;
             ev_end(ev, bs);
         }
+    } else if (block && c->plan.sub > 0 && m < c->lookahead && m % c->plan.sub == 0 && c->plan.mini_s_hi[m] >= 0) {
+        to_background();
+        launch_mini_pass(c, m, bs, direct);  // two-level form: the sub-block that ends here -> the block steps still to come
     } else if (plan_now) {
         if (block) c->plan.misses = 0;  // a block was consumed completely
         if (make_plan(c)) {
@@ -981,6 +1066,34 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     z.ring_vT       = c->d_ring_vT.p;
     z.Hcap          = c->Hcap;
     z.HcapT         = c->HcapT;
+    if (z.n_near > 0 && hc::near_slices_for(c->D) > 1) {
+        // wide system: the own-sample part is split over column slices by a kernel of its own (hundreds of workgroups instead of one
+        // per row tile); the step kernel adds the slice partials
+        hc::NearArgs na{};
+        na.K      = z.nearK;
+        na.D      = c->D;
+        na.Dpad   = c->Dpad;
+        na.N      = c->N;
+        na.n_near = z.n_near;
+        for (int e = 0; e < z.n_near; ++e) na.near[e] = z.near[e];
+        na.state    = d_state;
+        na.ring_v   = c->d_ring_v.p;
+        na.partials = c->d_near_partials.p;
+        if (direct) {
+            const hc::NearLaunch l = hc::near_launch_config(na);
+            c->dq->dispatch(c->dk_near, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &na, sizeof na, direct_tag(c, hc::kEvStep));
+            c->prof.direct_dispatches += 1;
+        } else {
+            hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
+            hc::launch_near_split(na, stream);
+            ev_end(ev, stream);
+            c->prof.hip_launches += 1;
+            (void)hc::near_launch_config(na);
+        }
+        z.near_partials = c->d_near_partials.p;
+        z.n_near_slices = na.n_slices;
+        z.n_near        = 0;
+    }
     if (direct) {
         const hc::FinalizeLaunch l = hc::finalize_launch_config(z);
         c->dq->dispatch(c->dk_finalize, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &z, sizeof z, direct_tag(c, hc::kEvStep));
@@ -1085,13 +1198,13 @@ void setup_direct(hc_ctx* c) {
     c->direct_ready = false;
     if (env_int("HC_DIRECT", 1) == 0) { c->direct_why = "disabled by HC_DIRECT=0"; return; }
     if (std::getenv("HC_BLOCK_V32")) { c->direct_why = "HC_BLOCK_V32 selects a tuning variant of the pass"; return; }
-    if (c->D >= 1536) { c->direct_why = "wide system: its step kernel variant needs scratch memory"; return; }
     if (!c->bar_state.host_ok || !c->bar_am.host_ok) { c->direct_why = "the device's memory is not host-addressable"; return; }
     std::unique_ptr<hc::DirectQueue> q(new hc::DirectQueue);
     std::string why;
     if (!q->init(c->device, library_dir() + "/hc_kernels.co", &why)) { c->direct_why = why; return; }
     c->dk_finalize = q->find("finalize_kernelILi4EEEv");
     c->dk_scatter  = q->find("scatter_kernelE");
+    c->dk_near     = q->find("near_split_kernelE");
     c->dk_reduce   = q->find("reduce_block_kernelE");
     c->dk_added_mass = q->find("added_mass_mv_tagged_kernelE");  // optional: hc_added_mass_mv falls back to a HIP launch
     {   // the plain per-step convolution of this context's tiling; optional: without it plain steps go through HIP launches
@@ -1112,17 +1225,18 @@ void setup_direct(hc_ctx* c) {
         std::snprintf(frag, sizeof frag, "conv_block_kernelILi%dELi%dELi%dELi%dEEEv", l.MT, l.R, l.NB, l.WPS);
         (depth == 16 ? c->dk_block16 : c->dk_block32) = q->find(frag);
     }
-    if (!c->dk_finalize.ok() || !c->dk_scatter.ok() || !c->dk_reduce.ok() || !c->dk_block16.ok() || !c->dk_block32.ok()) {
+    if (!c->dk_finalize.ok() || !c->dk_scatter.ok() || !c->dk_reduce.ok() || !c->dk_block16.ok() || !c->dk_block32.ok() || !c->dk_near.ok()) {
         c->direct_why = "a kernel of this configuration is missing from hc_kernels.co";
         return;
     }
     // the code object must be the one built with this library: its kernels take exactly these argument blocks
     if (c->dk_finalize.kernarg != sizeof(hc::FinalizeArgs) || c->dk_scatter.kernarg != sizeof(hc::ScatterArgs) ||
-        c->dk_block16.kernarg != sizeof(hc::BlockArgs) || c->dk_block32.kernarg != sizeof(hc::BlockArgs) || c->dk_reduce.kernarg != sizeof(hc::ReduceArgs)) {
+        c->dk_block16.kernarg != sizeof(hc::BlockArgs) || c->dk_block32.kernarg != sizeof(hc::BlockArgs) || c->dk_reduce.kernarg != sizeof(hc::ReduceArgs) ||
+        c->dk_near.kernarg != sizeof(hc::NearArgs)) {
         c->direct_why = "hc_kernels.co was not built from the same sources as this library (argument block sizes differ)";
         return;
     }
-    if (c->dk_finalize.priv || c->dk_scatter.priv || c->dk_reduce.priv || c->dk_block16.priv || c->dk_block32.priv) {
+    if (c->dk_finalize.priv || c->dk_scatter.priv || c->dk_reduce.priv || c->dk_block16.priv || c->dk_block32.priv || c->dk_near.priv) {
         c->direct_why = "a kernel needs scratch memory";
         return;
     }
@@ -1130,13 +1244,14 @@ void setup_direct(hc_ctx* c) {
         c->direct_why = "added_mass_mv_tagged_kernel is missing from hc_kernels.co";
         return;
     }
+    static_assert(sizeof(hc::NearArgs) <= hc::DirectQueue::kSlotBytes, "an argument block does not fit a kernarg slot of the direct queue");
     static_assert(sizeof(hc::ScatterArgs) <= hc::DirectQueue::kSlotBytes && sizeof(hc::FinalizeArgs) <= hc::DirectQueue::kSlotBytes &&
                       sizeof(hc::BlockArgs) <= hc::DirectQueue::kSlotBytes && sizeof(hc::StepArgs) <= hc::DirectQueue::kSlotBytes,
                   "an argument block does not fit a kernarg slot of the direct queue");
     // self-test 1: one dispatch of the reduction kernel with nothing to add must clear a marked word of P
     const double mark = 1.0;
     HC_HIP(hipMemcpy(c->d_P.p, &mark, sizeof mark, hipMemcpyHostToDevice));
-    hc::ReduceArgs r{c->d_partials_block.p, 0, 0, c->Dpad, 1, c->d_P.p, c->d_E.p, c->d_err.p + 1};
+    hc::ReduceArgs r{c->d_partials_block.p, 0, 0, c->Dpad, 1, c->d_P.p, c->d_E.p, c->d_err.p + 1, 0, 0, 0, 0};
     q->dispatch(c->dk_reduce, static_cast<uint32_t>((c->Dpad + 15) / 16), 256, 0, &r, sizeof r);
     if (!q->drain(2.0)) {
         c->direct_why = "self-test of the direct dispatch timed out";

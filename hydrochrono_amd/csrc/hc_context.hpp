@@ -124,7 +124,7 @@ struct ExGroup {
 enum WaveKind { kWaveNone = 0, kWaveRegular = 1, kWaveIrregular = 2, kWaveSpectral = 3 };
 
 // One timed kernel launch (HIP events before / after it on the stream it was launched on).
-enum EventKind { kEvConvPlain = 0, kEvPass = 1, kEvStep = 2, kEvScatter = 3, kEvConvExc = 4 };
+enum EventKind { kEvConvPlain = 0, kEvPass = 1, kEvStep = 2, kEvScatter = 3, kEvConvExc = 4, kEvMiniPass = 5 };
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
     int kind = 0;
@@ -151,7 +151,7 @@ struct hc_ctx {
     bool direct_ready   = false;
     std::string direct_why;  // why the direct path is not in use
     int path            = 0;
-    hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_added_mass, dk_step;
+    hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_added_mass, dk_step, dk_near;
     hc::StepTail tail;
     // split step (hc_step_begin / hc_step_end, hc_step_multi): 0 nothing begun, 1 the begun step was a cache hit (totals in
     // last_total), 2 its results arrive as tagged granules with sequence number `seq`
@@ -212,6 +212,7 @@ struct hc_ctx {
     int chunk_gp = 0, nchunks_rad = 0, chunk_gp_ex = 0, nchunks_ex = 0, ngp_ex = 0;
     int chunk_gp_block = 0, nchunks_block = 0;
     hc::DeviceBuffer<double> d_partials, d_partials_block, d_P, d_E;
+    hc::DeviceBuffer<double> d_near_partials;  // [16][Dpad] slice partials of near_split_kernel (wide systems)
     hc::DeviceBuffer<double> d_Y;           // weighted scatter results per consumer step [kLookahead + 1][kTermMax][Dpad]
     hc::DeviceBuffer<double> d_zero_state;  // 12N zeros: the not-yet-known sample of the look-ahead pass
     int chunk_gp_ex_block = 32, nchunks_ex_block = 0;  // excitation chunks of the look-ahead launch

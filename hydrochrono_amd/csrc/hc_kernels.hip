@@ -475,9 +475,45 @@ __device__ __forceinline__ void block_exc_work(const BlockArgs& a, const int grp
 // together -- tau / width first, then the two sample times the step-size hint points at; an entry whose hint misses (irregular
 // history) falls back to the search of find_bracket, which gives the same bracket.
 // BYTES: the slot of the older sample as a byte offset inside a row of the per-DoF ring (its newer neighbour follows it), no t_on.
+// The table of a SHORT pass (two-level form, BlockArgs::mini_kw > 0): the same entries, but only brackets that touch the samples of
+// the sub-block that has just ended count, and their times are the plan's predicted grid times handed over in the argument block
+// (mini_bracket, hc_limits.hpp -- the host-side planner test runs the same function).  No ring_t reads at all.
+template <int L, bool BYTES>
+__device__ __forceinline__ void build_mini_table(const BlockArgs& a, const int s0, const int ns, const int s_live, double* t_wo, double* t_wn,
+                                                 int* t_oo, int* t_on) {
+    const HistoryView& h = a.hist;
+    const int n = ns * L;
+    for (int idx = threadIdx.x; idx < n; idx += kConvThreads) {
+        const int k = idx / L, j = idx - k * L, s = s0 + k;
+        double wo = 0.0, wn = 0.0;
+        int lo = 0;
+        if (j < a.mini_steps && s >= a.s_cut[j] && s != a.s_defer[j] && s < s_live) {
+            if (!mini_bracket(a.mini_time, a.mini_kw, a.tpred[j] - a.tau[s], &wo, &wn, &lo)) *a.error_flag = 1;
+            const double w = a.width[s];
+            wo *= w;
+            wn *= w;
+        }
+        // ring slots: history index k of the view lives in slot head - k (index 0 = the not-yet-known sample, weight 0)
+        const int slot_o = (h.head - (lo + 1) + 2 * h.Hcap) % h.Hcap, slot_n = (h.head - lo + 2 * h.Hcap) % h.Hcap;
+        const bool any   = wo != 0.0 || wn != 0.0;
+        t_wo[idx] = wo;
+        t_wn[idx] = wn;
+        if constexpr (BYTES) {
+            t_oo[idx] = any ? slot_o * 8 : 0;
+        } else {
+            t_oo[idx] = any ? slot_o : 0;
+            t_on[idx] = (any && lo >= 1) ? slot_n : 0;
+        }
+    }
+}
+
 template <int L, bool BYTES>
 __device__ __forceinline__ void build_block_table(const BlockArgs& a, const int s0, const int ns, const int s_live, double* t_wo, double* t_wn,
                                                   int* t_oo, int* t_on) {
+    if (a.mini_kw > 0) {
+        build_mini_table<L, BYTES>(a, s0, ns, s_live, t_wo, t_wn, t_oo, t_on);
+        return;
+    }
     constexpr int NE = 3;
     const HistoryView& h = a.hist;
     const int n = ns * L, D = h.D;
@@ -944,15 +980,15 @@ __device__ __forceinline__ double lane16_sum(double v) {
 // P[j][row] = sum over radiation chunks c of partials[c][j][row]; E[j][row] = the same over the excitation chunks.
 // 16 lanes per output, chunks c = l, l+16, ... (8 loads in flight per lane, adds in ascending chunk order), then a 4-step
 // xor tree.
-__global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restrict__ partials, int nchunks_rad, int nchunks_ex, int Dpad,
-                                                           int depth, double* __restrict__ P, double* __restrict__ E, int* item_counter) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *item_counter = 0;  // the pass that has just finished counted its excitation items here
+__global__ void __launch_bounds__(256) reduce_block_kernel(ReduceArgs a) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.item_counter = 0;  // the pass that has just finished counted its excitation items here
+    const double* __restrict__ partials = a.partials;
     const int sub = threadIdx.x & 15;
-    const int n   = depth * Dpad;
+    const int n   = a.depth * a.Dpad;
     int out       = blockIdx.x * 16 + (threadIdx.x >> 4);  // [segment][j*Dpad + row]
     const bool exc = out >= n;
     if (exc) out -= n;
-    const int first = exc ? nchunks_rad : 0, count = exc ? nchunks_ex : nchunks_rad;
+    const int first = exc ? a.nchunks_rad : 0, count = exc ? a.nchunks_ex : a.nchunks_rad;
     const int o     = out < n ? out : 0;
     double v = 0.0;
     for (int c = sub; c < count; c += 8 * 16) {
@@ -963,15 +999,23 @@ __global__ void __launch_bounds__(256) reduce_block_kernel(const double* __restr
         for (int k = 0; k < 8; ++k) v += w[k];
     }
     v = lane16_sum(v);
-    if (out < n && sub == 0) (exc ? E : P)[out] = v;
+    if (out < n && sub == 0) {
+        if (a.accumulate) {
+            const int j = out / a.Dpad;
+            if (!exc && j < a.j_cnt) a.P[out + (size_t)a.j_off * a.Dpad] += v;
+        } else {
+            (exc ? a.E : a.P)[out] = v;
+        }
+    }
 }
 
-void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_ex, int Dpad, int depth, double* d_P, double* d_E,
-                         int* item_counter, hipStream_t stream) {
-    const int n    = depth * Dpad;
-    const int nblk = (n + 15) / 16;  // n is a multiple of 16, so the excitation segment starts on a workgroup boundary
-    hipLaunchKernelGGL(reduce_block_kernel, dim3(nchunks_ex > 0 ? 2 * nblk : nblk), dim3(256), 0, stream, d_partials, nchunks_rad, nchunks_ex,
-                       Dpad, depth, d_P, d_E, item_counter);
+int reduce_block_grid(const ReduceArgs& r) {
+    const int nblk = (r.depth * r.Dpad + 15) / 16;  // depth * Dpad is a multiple of 16, so the excitation segment starts on a workgroup boundary
+    return r.nchunks_ex > 0 ? 2 * nblk : nblk;
+}
+
+void launch_reduce_block(const ReduceArgs& r, hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_block_kernel, dim3(reduce_block_grid(r)), dim3(256), 0, stream, r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -986,8 +1030,7 @@ void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_
 // 263-322,758-760; src/wave_types.cpp:315-327).  All sums run in a fixed order (bitwise reproducible).  For the host
 // boundary the totals also leave as 16-byte {value, sequence} granules in mapped pinned memory.
 // ------------------------------------------------------------------------------------------------
-// NW = waves per workgroup: 4, or 16 for wide systems (D >= 1536), where a workgroup streams hundreds of KB of K for its 16 rows and
-// needs the loads of more waves in flight; threads beyond the first 256 only help with that stream.
+// NW = waves per workgroup (4).  Wide systems (near_slices_for(D) > 1) leave the own-sample part to near_split_kernel.
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -1142,6 +1185,8 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     if (a.do_rad) {
         if (a.nchunks_rad > 0) rad = lane16_sum(lane_sum(0, a.nchunks_rad));
         if (a.P) rad = p_row + rad;
+        if (a.n_near_slices > 0)  // own-sample part of a wide system, computed by near_split_kernel: slice `sub`, then the fixed xor tree
+            rad += lane16_sum(sub < a.n_near_slices ? a.near_partials[(size_t)sub * a.Dpad + rrow] : 0.0);
         if (term_on) {
             double ts = 0.0;
 #pragma unroll
@@ -1206,9 +1251,8 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
 FinalizeLaunch finalize_launch_config(FinalizeArgs& a) {
     FinalizeLaunch l;
     l.smem    = (size_t)max(0, a.n_near) * a.D * sizeof(double);
-    l.wide    = a.n_near > 0 && a.D >= 1536;  // >= 196 KB of K per workgroup and near sample
     l.grid    = (a.Dloc + 15) / 16 + (a.do_push ? 1 : 0);
-    l.threads = l.wide ? 1024 : 256;
+    l.threads = 256;
     a.nblocks = l.grid;
     return l;
 }
@@ -1217,16 +1261,83 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     FinalizeArgs a         = a0;
     const FinalizeLaunch l = finalize_launch_config(a);
     if (l.smem > 64 * 1024) {
-        static size_t granted4 = 0, granted16 = 0;
-        size_t& granted = l.wide ? granted16 : granted4;
+        static size_t granted = 0;
         if (l.smem > granted) {
-            (void)hipFuncSetAttribute(l.wide ? reinterpret_cast<const void*>(finalize_kernel<16>) : reinterpret_cast<const void*>(finalize_kernel<4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.smem);
             granted = l.smem;
         }
     }
-    if (l.wide) hipLaunchKernelGGL((finalize_kernel<16>), dim3(l.grid), dim3(1024), l.smem, stream, a);
-    else hipLaunchKernelGGL((finalize_kernel<4>), dim3(l.grid), dim3(256), l.smem, stream, a);
+    hipLaunchKernelGGL((finalize_kernel<4>), dim3(l.grid), dim3(256), l.smem, stream, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// near_split_kernel: the own-sample part of a step inside a look-ahead block for WIDE systems.  The step kernel alone would stream
+// n_near x 16 x D x 8 bytes per row tile from one workgroup (393 KB per sample at D = 3072: 24 workgroups on a 256-CU chip, 19 us);
+// here workgroup (row tile, slice) contracts the slice's columns of every near sample and leaves one partial per row; the step
+// kernel adds the slices in a fixed order.  Same right-hand side arithmetic as finalize_kernel's near part.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) near_split_kernel(NearArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double* U = reinterpret_cast<double*>(smem_raw);  // [n_near][8 * gps_per_slice]
+    __shared__ double red[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = (int)blockIdx.x / a.n_slices, sl = (int)blockIdx.x - rt * a.n_slices;
+    const int D = a.D, W = 8 * a.gps_per_slice;
+    const double* __restrict__ kbase = a.K.base + ((size_t)rt * a.K.ngp) * 128 + lane * 2;
+    // stage u for the slice's columns of every near sample (columns outside the sample -> 0)
+    for (int e = 0; e < a.n_near; ++e) {
+        const NearEntry& ne = a.near[e];
+        const int f0 = ne.s * D, f1 = f0 + D;
+        const int fs = ((f0 >> 3) + sl * a.gps_per_slice) * 8;  // first column of the slice (group aligned)
+        for (int i = tid; i < W; i += 256) {
+            const int f = fs + i;
+            double u = 0.0;
+            if (f >= f0 && f < f1) {
+                const int col = f - f0;
+                if (ne.a != 0.0) u = ne.a * state_velocity(a.state, a.N, col);
+                if (ne.b != 0.0) u = fma(ne.b, a.ring_v[ne.off_b + col], u);
+                if (ne.c != 0.0) u = fma(ne.c, a.ring_v[ne.off_c + col], u);
+            }
+            U[e * W + i] = u;
+        }
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int e = 0; e < a.n_near; ++e) {
+        const int f0 = a.near[e].s * D, f1 = f0 + D;
+        const int g0 = (f0 >> 3) + sl * a.gps_per_slice, g1 = min((f1 + 7) >> 3, g0 + a.gps_per_slice);
+        const double* __restrict__ u = U + e * W - g0 * 8;
+#pragma unroll 4
+        for (int gp = g0 + wave; gp < g1; gp += 4) {
+            const dvec2 kv = *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128);
+            acc = fma(kv.x, u[gp * 8 + kk], acc);
+            acc = fma(kv.y, u[gp * 8 + 4 + kk], acc);
+        }
+    }
+    acc += __shfl_xor(acc, 16, kWave);
+    acc += __shfl_xor(acc, 32, kWave);
+    if (lane < 16) red[wave][lane] = acc;
+    __syncthreads();
+    if (tid < 16) a.partials[(size_t)sl * a.Dpad + rt * 16 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+int near_slices_for(int D) { return D >= 1024 ? min(16, max(2, D / 384)) : 1; }
+
+NearLaunch near_launch_config(NearArgs& a) {
+    NearLaunch l;
+    a.n_slices = near_slices_for(a.D);
+    const int groups = (a.D + 7) / 8 + 1;  // a sample's columns may straddle one more group when D % 8 != 0
+    a.gps_per_slice = (((groups + a.n_slices - 1) / a.n_slices) + 3) & ~3;  // every wave of the workgroup gets work
+    l.grid = a.K.ntiles * a.n_slices;
+    l.smem = (size_t)max(1, a.n_near) * 8 * a.gps_per_slice * sizeof(double);
+    return l;
+}
+
+void launch_near_split(const NearArgs& a0, hipStream_t stream) {
+    NearArgs a         = a0;
+    const NearLaunch l = near_launch_config(a);
+    hipLaunchKernelGGL(near_split_kernel, dim3(l.grid), dim3(256), l.smem, stream, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1238,13 +1349,15 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) scatter_kernel(ScatterArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    double* vs = reinterpret_cast<double*>(smem_raw);  // [D]
+    double* vs = reinterpret_cast<double*>(smem_raw);  // [8 * gps_per_slice]: the slice's columns of the sample's velocities
     __shared__ double red[4][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4;
-    const int rt = (int)blockIdx.x % a.K.ntiles, si = (int)blockIdx.x / a.K.ntiles;
+    const int rt = (int)blockIdx.x % a.K.ntiles, rest = (int)blockIdx.x / a.K.ntiles;
+    const int si = rest / a.n_slices, sl = rest - si * a.n_slices;
     const int s  = a.s_lo + si;
     const int D  = a.D;
-    const int f0 = s * D, f1 = f0 + D, g0 = f0 >> 3, g1 = (f1 + 7) >> 3;
+    const int f0 = s * D, f1 = f0 + D;
+    const int g0 = (f0 >> 3) + sl * a.gps_per_slice, g1 = min((f1 + 7) >> 3, g0 + a.gps_per_slice);
     const double* __restrict__ kbase = a.K.base + ((size_t)rt * a.K.ngp) * 128 + lane * 2;
     constexpr int PRE = 4;
     dvec2 pre[PRE];
@@ -1253,27 +1366,26 @@ __global__ void __launch_bounds__(256) scatter_kernel(ScatterArgs a) {
         const int gp = g0 + wave + 4 * q;
         pre[q] = gp < g1 ? *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128) : dvec2{0.0, 0.0};
     }
-    for (int col = tid; col < D; col += 256) vs[col] = a.v[col];
+    for (int i = tid; i < 8 * a.gps_per_slice; i += 256) {
+        const int f = g0 * 8 + i;
+        vs[i]       = (f >= f0 && f < f1) ? a.v[f - f0] : 0.0;
+    }
     __syncthreads();
-    const double* __restrict__ u = vs - f0;
+    const double* __restrict__ u = vs - g0 * 8;
     double acc = 0.0;
     int gp = g0 + wave;
 #pragma unroll
     for (int q = 0; q < PRE; ++q, gp += 4) {
         if (gp < g1) {
-            const int fa = gp * 8 + kk, fb = fa + 4;
-            const double u0 = (fa >= f0 && fa < f1) ? u[fa] : 0.0, u1 = (fb >= f0 && fb < f1) ? u[fb] : 0.0;
-            acc = fma(pre[q].x, u0, acc);
-            acc = fma(pre[q].y, u1, acc);
+            acc = fma(pre[q].x, u[gp * 8 + kk], acc);
+            acc = fma(pre[q].y, u[gp * 8 + 4 + kk], acc);
         }
     }
 #pragma unroll 4
     for (; gp < g1; gp += 4) {
         const dvec2 kv = *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128);
-        const int fa = gp * 8 + kk, fb = fa + 4;
-        const double u0 = (fa >= f0 && fa < f1) ? u[fa] : 0.0, u1 = (fb >= f0 && fb < f1) ? u[fb] : 0.0;
-        acc = fma(kv.x, u0, acc);
-        acc = fma(kv.y, u1, acc);
+        acc = fma(kv.x, u[gp * 8 + kk], acc);
+        acc = fma(kv.y, u[gp * 8 + 4 + kk], acc);
     }
     acc += __shfl_xor(acc, 16, kWave);
     acc += __shfl_xor(acc, 32, kWave);
@@ -1281,21 +1393,32 @@ __global__ void __launch_bounds__(256) scatter_kernel(ScatterArgs a) {
     __syncthreads();
     if (tid < 16) {
         const double y = (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]) * a.width[s];
-        for (int t = 0; t < a.n_tgt[si]; ++t) a.Y[(size_t)a.tgt_off[si][t] + rt * 16 + tid] = a.tgt_coef[si][t] * y;
+        for (int t = 0; t < a.n_tgt[si]; ++t) a.Y[(size_t)a.tgt_off[si][t] + (size_t)sl * a.Dpad + rt * 16 + tid] = a.tgt_coef[si][t] * y;
     }
 }
 
-void launch_scatter(const ScatterArgs& a, hipStream_t stream) {
-    if (a.ns <= 0) return;
-    const size_t smem = (size_t)a.D * sizeof(double);
-    if (smem > 64 * 1024) {
+ScatterLaunch scatter_launch_config(ScatterArgs& a) {
+    ScatterLaunch l;
+    a.n_slices = near_slices_for(a.D);
+    const int groups = (a.D + 7) / 8 + 1;  // a sample's columns may straddle one more group when D % 8 != 0
+    a.gps_per_slice = (((groups + a.n_slices - 1) / a.n_slices) + 3) & ~3;
+    l.grid = a.K.ntiles * a.ns * a.n_slices;
+    l.smem = (size_t)8 * a.gps_per_slice * sizeof(double);
+    return l;
+}
+
+void launch_scatter(const ScatterArgs& a0, hipStream_t stream) {
+    if (a0.ns <= 0) return;
+    ScatterArgs a         = a0;
+    const ScatterLaunch l = scatter_launch_config(a);
+    if (l.smem > 64 * 1024) {
         static size_t granted = 0;
-        if (smem > granted) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            granted = smem;
+        if (l.smem > granted) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.smem);
+            granted = l.smem;
         }
     }
-    hipLaunchKernelGGL(scatter_kernel, dim3(a.K.ntiles * a.ns), dim3(256), smem, stream, a);
+    hipLaunchKernelGGL(scatter_kernel, dim3(l.grid), dim3(256), l.smem, stream, a);
 }
 
 __global__ void __launch_bounds__(256) ring_transpose_kernel(const double* __restrict__ ring_v, int Hcap, int HcapT, int D, double* __restrict__ ring_vT) {

@@ -135,11 +135,33 @@ struct BlockArgs {
     int ngroups;
     int* error_flag;
     int* item_counter;    // excitation work items taken so far in this launch (zero at launch; reset by reduce_block_kernel)
+    // Short pass of the two-level form (hc_plan.hpp: MiniPass; mini_kw == 0: the ordinary pass of a block).  Only the brackets that
+    // touch the mini_kw samples of the sub-block that has just ended count; their times come from the plan's predicted grid
+    // (mini_time[k], history index k = 0 .. mini_kw + 1, index 0 = hist.t), not from the ring, so the bracket of every
+    // (IRF sample, step) is the planner's bit for bit.  Steps j >= mini_steps are empty.
+    int mini_kw, mini_steps;
+    double mini_time[kSubBlock + 2];
+};
+
+// near_split_kernel (wide systems): the step's own-sample part  K[rows of a tile, columns of the near samples] x u  split over
+// column slices so that hundreds of workgroups stream it instead of one per row tile; slice partials [slice][Dpad], added by the
+// step kernel in a fixed order.  Slice geometry depends on D only (never on the rows a context owns): row shards stay bitwise.
+struct NearArgs {
+    Panel K;
+    int D, Dpad, N;
+    int n_near;
+    NearEntry near[kNearMax];
+    const double* state;
+    const double* ring_v;
+    int n_slices, gps_per_slice;  // column groups of one IRF sample's D columns (+ a straddled group) per slice
+    double* partials;             // [n_slices][Dpad]
 };
 
 struct FinalizeArgs {
     const double* partials;
     int nchunks_rad, nchunks_ex;
+    const double* near_partials;  // [n_near_slices][Dpad] from near_split_kernel (wide systems), or null
+    int n_near_slices;
     const double* P;         // look-ahead part of this step's radiation sum, [Dpad] (may be null)
     const double* E;         // excitation force of this step precomputed by the look-ahead pass, [Dpad] (may be null)
     int Dloc, Dpad, N, b0;
@@ -203,6 +225,9 @@ struct ScatterArgs {
     const double* v;      // [D] the sample's velocities (its ring row)
     const double* width;  // [S]
     double* Y;            // term slots of the block: [step][kTermMax][Dpad]
+    // wide systems: a sample's D columns are split over n_slices workgroups per row tile (same slice geometry as near_split_kernel);
+    // slice sl leaves its partial in term slot tgt_off + sl * Dpad -- the step kernel adds the slices like any other terms
+    int n_slices, gps_per_slice;
     int n_tgt[kScatterSamples];               // per s - s_lo
     int tgt_off[kScatterSamples][kTargets];   // (step * kTermMax + term index) * Dpad
     double tgt_coef[kScatterSamples][kTargets];
@@ -219,14 +244,16 @@ struct AddedMassArgs {
 };
 static_assert(sizeof(AddedMassArgs) == 56, "kernarg layout of added_mass_mv_tagged_kernel");
 
-// reduce_block_kernel's arguments as the kernel lays them out
+// reduce_block_kernel's arguments as the kernel lays them out.  accumulate != 0 (short pass of the two-level form): the chunk sum
+// of step j is ADDED to row j_off + j of P for j < j_cnt (the rows of the block steps still to come), nothing else is touched.
 struct ReduceArgs {
     const double* partials;
     int nchunks_rad, nchunks_ex, Dpad, depth;
     double *P, *E;
     int* item_counter;
+    int accumulate, j_off, j_cnt, pad;
 };
-static_assert(sizeof(ReduceArgs) == 48, "kernarg layout of reduce_block_kernel");
+static_assert(sizeof(ReduceArgs) == 64, "kernarg layout of reduce_block_kernel");
 
 struct TaperArgs {
     Panel Kraw;
@@ -243,8 +270,19 @@ struct TaperArgs {
 struct FinalizeLaunch {
     int grid = 0, threads = 256;
     size_t smem = 0;
-    bool wide   = false;  // finalize_kernel<16> (1024 threads) instead of finalize_kernel<4>
 };
+struct NearLaunch {
+    int grid = 0;
+    size_t smem = 0;
+};
+// slices of the own-sample part for a system of D columns (1: the step kernel contracts it itself)
+int near_slices_for(int D);
+NearLaunch near_launch_config(NearArgs& a);  // fills n_slices / gps_per_slice
+struct ScatterLaunch {
+    int grid = 0;
+    size_t smem = 0;
+};
+ScatterLaunch scatter_launch_config(ScatterArgs& a);  // fills n_slices / gps_per_slice
 FinalizeLaunch finalize_launch_config(FinalizeArgs& a);  // also fills a.nblocks
 struct StepLaunch {
     int nblocks = 0;
@@ -269,9 +307,10 @@ void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream);
 void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream);
 // P[j][row] = sum over the radiation chunks c of partials[c][j][row], E[j][row] = the same over the excitation chunks
 // (fixed order; nchunks_ex may be 0)
-void launch_reduce_block(const double* d_partials, int nchunks_rad, int nchunks_ex, int Dpad, int depth, double* d_P, double* d_E,
-                         int* item_counter, hipStream_t stream);
+void launch_reduce_block(const ReduceArgs& r, hipStream_t stream);
+int reduce_block_grid(const ReduceArgs& r);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
+void launch_near_split(const NearArgs& a, hipStream_t stream);
 void launch_scatter(const ScatterArgs& a, hipStream_t stream);
 void launch_taper(const TaperArgs& a, hipStream_t stream);
 // eta[j] = sum_i amp[i] * cos(-omega[i]*t[j] + phase[i]), then the ramp rule of src/wave_types.cpp:759-769

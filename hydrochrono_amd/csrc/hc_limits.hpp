@@ -6,8 +6,44 @@ namespace hc {
 
 constexpr int kLookahead = 32;  // most future steps one blocked pass covers (1 or 2 blocks of 16 = N dimension of v_mfma_f64_16x16x4_f64)
 constexpr int kNearMax        = 8;   // IRF samples a step contracts itself (own sample + a deferred one)
-constexpr int kTermMax        = 96;  // scatter results a step adds
+constexpr int kTermMax        = 192; // term slots a step adds (scatter results; x column slices for wide systems)
 constexpr int kScatterSamples = 64;  // IRF samples s < kScatterSamples can be targets of a scatter
 constexpr int kTargets        = 3;   // later block steps one (sample, IRF sample) result can contribute to
+
+constexpr int kSubBlock       = 8;   // steps per sub-block of the two-level form (wide systems)
+
+#if defined(__HIPCC__)
+#define HC_HOST_DEVICE __host__ __device__
+#else
+#define HC_HOST_DEVICE
+#endif
+
+// Bracket of query time q for the short pass of the two-level form.  time[0] is the (not yet known, zero) sample of the step that
+// follows the sub-block, time[1..kw] are the sub-block's samples newest first, time[kw + 1] the sample before them -- all on the
+// plan's predicted grid, so the comparisons are the planner's, bit for bit.  Weights of InterpolateVelocity6D
+// (src/hydro_forces.cpp:343-371), already masked to the sub-block's samples: *wn belongs to sample *lo, *wo to sample *lo + 1.
+// false: q is not bracketed (cannot happen for q <= time[0]).
+HC_HOST_DEVICE inline bool mini_bracket(const double* time, int kw, double q, double* wo, double* wn, int* lo_out) {
+    int lo = 0;
+    while (lo <= kw && !(time[lo + 1] <= q)) ++lo;  // smallest lo with time[lo + 1] <= q (AdvanceToBracket, :374-381)
+    *wo     = 0.0;
+    *wn     = 0.0;
+    *lo_out = lo;
+    if (lo > kw) return true;  // both samples are older than the sub-block: the pass of the block (or an earlier short pass) has them
+    const double newer = time[lo], older = time[lo + 1];
+    double o, n;
+    if (q == older) { o = 1.0; n = 0.0; }
+    else if (q == newer) { o = 0.0; n = 1.0; }
+    else if (q > older && q < newer) {
+        const double td = newer - older;
+        o = (td != 0.0) ? ((newer - q) / td) : 0.0;
+        n = 1.0 - o;
+    } else {
+        return false;
+    }
+    *wn = (lo >= 1) ? n : 0.0;
+    *wo = (lo + 1 <= kw) ? o : 0.0;
+    return true;
+}
 
 }  // namespace hc

@@ -34,6 +34,13 @@ struct Plan {
     double tgt_coef[kLookahead + 1][kScatterSamples][kTargets];
     // scatter launched after block step i covers IRF samples [scat_lo[i], scat_hi[i]] (hi < lo: nothing)
     int scat_lo[kLookahead + 1] = {0}, scat_hi[kLookahead + 1] = {0};
+    // Two-level form (wide systems, where the scatter launches re-read K from HBM): the block is cut into sub-blocks of `sub`
+    // steps; a scatter result only goes to later steps of its OWN sub-block, and what the samples of a sub-block contribute to the
+    // steps of the later sub-blocks is computed once, by a short pass over the head of K right after the sub-block's last step
+    // (block step i0 = sub, 2*sub, ... < L): mini_s_hi[i0] = last IRF sample that pass needs (-1: nothing to do).
+    int sub = 0;
+    int slices = 1;  // term slots one scatter result takes (column slices of the scatter launch; wide systems)
+    int mini_s_hi[kLookahead + 1];
     int misses = 0, cooldown = 0;
     bool has_exc = false;  // the pass also left the excitation force of the predicted times (E rows)
 };
@@ -44,7 +51,7 @@ struct Plan {
 // comparisons and the weight arithmetic are those of find_bracket / InterpolateVelocity6D (src/hydro_forces.cpp:343-381).
 // Returns false (plan invalid) when a block cannot be planned; pl.cooldown then says for how many steps not to retry.
 inline bool build_plan(Plan& pl, int lookahead, const std::deque<double>& times, const std::vector<double>& tau,
-                       const std::vector<double>& width) {
+                       const std::vector<double>& width, int sub = 0, int slices = 1) {
     const int keep_misses = pl.misses, keep_cool = pl.cooldown;
     pl             = Plan{};
     pl.misses      = keep_misses;
@@ -62,9 +69,12 @@ inline bool build_plan(Plan& pl, int lookahead, const std::deque<double>& times,
     pl.dt = dt;
     for (int j = 0; j <= L; ++j) pl.tgrid[j] = (j == 0) ? t0 : t0 + j * dt;
     auto G = [&](int idx) { return idx >= 1 ? pl.tgrid[idx] : times[static_cast<size_t>(-idx)]; };  // idx > -H
+    pl.sub    = (sub > 0 && sub < L) ? sub : 0;
+    pl.slices = slices;
     for (int i = 0; i <= L; ++i) {
         pl.scat_lo[i] = S;
         pl.scat_hi[i] = -1;
+        pl.mini_s_hi[i] = -1;
         for (int s = 0; s < kScatterSamples; ++s) pl.n_tgt[i][s] = 0;
     }
     const double oldest = times.back();
@@ -115,10 +125,16 @@ inline bool build_plan(Plan& pl, int lookahead, const std::deque<double>& times,
                     pl.own_s[m][pl.n_own[m]] = s;
                     pl.own_a[m][pl.n_own[m]] = wgt[e] * width[s];
                     pl.n_own[m]++;
+                } else if (pl.sub > 0 && (idx[e] - 1) / pl.sub != (m - 1) / pl.sub) {
+                    // another sub-block: the short pass after the last step of the sample's sub-block has this pair
+                    const int i0     = ((idx[e] - 1) / pl.sub + 1) * pl.sub;
+                    pl.mini_s_hi[i0] = std::max(pl.mini_s_hi[i0], s);
                 } else {
                     const int i = idx[e];
-                    if (pl.n_terms[m] >= kTermMax || pl.n_tgt[i][s] >= kTargets) return false;
-                    const int k = pl.n_terms[m]++;
+                    // (wide systems: a scatter result arrives as `slices` column-slice partials, one term slot each)
+                    if (pl.n_terms[m] + slices > kTermMax || pl.n_tgt[i][s] >= kTargets) return false;
+                    const int k = pl.n_terms[m];
+                    pl.n_terms[m] += slices;
                     const int t = pl.n_tgt[i][s]++;
                     pl.tgt_step[i][s][t] = m;
                     pl.tgt_k[i][s][t]    = k;
@@ -133,6 +149,36 @@ inline bool build_plan(Plan& pl, int lookahead, const std::deque<double>& times,
     pl.valid  = true;
     return true;
 }
+// The short pass of the two-level form that follows block step i0 (a multiple of pl.sub, < L): it covers the block steps
+// i0 + 1 + j, j < n_steps, and the IRF samples s < n_samples, restricted to the brackets that touch the samples of the sub-block
+// that has just ended (history indices 1..kw of the view whose sample 0 is the not-yet-known step i0 + 1).
+struct MiniPass {
+    int kw = 0, n_steps = 0, n_samples = 0;
+    double time[kSubBlock + 2] = {0};     // predicted-grid times of history indices 0 .. kw + 1
+    double tpred[kLookahead]   = {0};
+    int s_cut[kLookahead]      = {0};
+    int s_defer[kLookahead]    = {0};
+};
 
+inline MiniPass mini_pass_setup(const Plan& pl, int lookahead, int i0, const std::vector<double>& tau) {
+    MiniPass mp;
+    const int S = static_cast<int>(tau.size());
+    mp.kw        = pl.sub;
+    mp.n_steps   = lookahead - i0;
+    mp.n_samples = std::min(S, pl.mini_s_hi[i0] + 1);
+    for (int k = 0; k <= mp.kw + 1; ++k) mp.time[k] = pl.tgrid[i0 + 1 - k];  // i0 >= sub, so the index stays >= 0
+    for (int j = 0; j < kLookahead; ++j) {
+        const int m = i0 + 1 + j;
+        mp.tpred[j]   = (j < mp.n_steps) ? pl.tgrid[m] : pl.tgrid[lookahead];
+        mp.s_defer[j] = (j < mp.n_steps) ? pl.s_defer[m - 1] : -1;
+        int sc = S;  // steps beyond the block: nothing
+        if (j < mp.n_steps) {
+            sc = 0;
+            while (sc < S && !(pl.tgrid[m] - tau[sc] <= pl.tgrid[i0 + 1])) ++sc;  // same expression as the pass of the block
+        }
+        mp.s_cut[j] = sc;
+    }
+    return mp;
+}
 
 }  // namespace hc

@@ -39,3 +39,8 @@ print("pass %.1f us x %d (bytes once %.3f GB -> %.2f TB/s)  step kernel %.1f us 
     us(p["block_kernel_seconds"], p["block_kernel_launches"]), p["block_kernel_launches"], p["block_kernel_bytes_once"] / 1e9,
     p["block_kernel_bytes_once"] / max(p["block_kernel_seconds"] / max(p["block_kernel_launches"], 1), 1e-12) / 1e12,
     us(p["step_kernel_seconds"], p["step_kernel_launches"]), us(p["scatter_kernel_seconds"], p["scatter_kernel_launches"])))
+print("short passes (two-level form): %.1f us x %d;  per step of the timed region: pass %.1f  short passes %.1f  scatter %.1f  step kernels %.1f us" % (
+    us(p["mini_pass_seconds"], p["mini_pass_launches"]), p["mini_pass_launches"],
+    p["block_kernel_seconds"] / len(per) * 1e6, p["mini_pass_seconds"] / len(per) * 1e6, p["scatter_kernel_seconds"] / len(per) * 1e6,
+    p["step_kernel_seconds"] / len(per) * 1e6))
+print("dispatch:", gpu.direct_dispatch(), " aql %d hip %d" % (p["direct_dispatches"], p["hip_launches"]))

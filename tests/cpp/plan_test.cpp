@@ -37,6 +37,7 @@ bool bracket(const std::vector<double>& times, double q, int* older, int* newer,
 struct Scenario {
     double dt_rirf, dt_step;
     int S, H0, L;
+    int sub = 0;  // > 0: the two-level form (sub-blocks of `sub` steps + a short pass after each)
 };
 
 int run(const Scenario& sc, unsigned seed, double* worst_out) {
@@ -57,12 +58,13 @@ int run(const Scenario& sc, unsigned seed, double* worst_out) {
     for (auto& v : v_block) v = U(rng);
 
     hc::Plan pl;
-    if (!hc::build_plan(pl, sc.L, known, tau, width)) {
+    if (!hc::build_plan(pl, sc.L, known, tau, width, sc.sub)) {
         *worst_out = -1.0;  // not planned (allowed: e.g. block longer than half the window)
         return 0;
     }
     double worst = 0.0;
     std::vector<std::vector<double>> slots(sc.L + 1, std::vector<double>(hc::kTermMax, 0.0));
+    std::vector<double> mini(sc.L + 1, 0.0);  // what the short passes of the two-level form have added to the steps' pass rows
     for (int m = 1; m <= sc.L; ++m) {
         // ---- direct evaluation at the predicted time with everything known up to step m ----
         std::vector<double> times;   // newest first: block steps m..1, then the known samples
@@ -106,15 +108,31 @@ int run(const Scenario& sc, unsigned seed, double* worst_out) {
         // own entries
         double own = 0.0;
         for (int e = 0; e < pl.n_own[m]; ++e) own += pl.own_a[m][e] * K[pl.own_s[m][e]] * v_block[m];
-        const double got = pass + defer + terms + own;
+        const double got = pass + defer + terms + own + mini[m];
         worst = std::fmax(worst, std::fabs(got - ref) / std::fmax(scale, 1e-300));
         // ---- this step's scatter: y_s = width_s * K_s * v_m into the slots of its targets ----
         if (m < sc.L)
             for (int s = pl.scat_lo[m]; s <= pl.scat_hi[m]; ++s)
                 for (int t = 0; t < pl.n_tgt[m][s]; ++t) {
                     if (pl.tgt_step[m][s][t] <= m || pl.tgt_step[m][s][t] > sc.L) return 2;  // targets are later block steps
+                    if (sc.sub > 0 && (pl.tgt_step[m][s][t] - 1) / sc.sub != (m - 1) / sc.sub) return 3;  // two-level: own sub-block only
                     slots[pl.tgt_step[m][s][t]][pl.tgt_k[m][s][t]] = pl.tgt_coef[m][s][t] * (width[s] * K[s] * v_block[m]);
                 }
+        // ---- two-level form: the short pass after the last step of a sub-block (the kernel's table arithmetic: mini_bracket) ----
+        if (pl.sub > 0 && m < sc.L && m % pl.sub == 0 && pl.mini_s_hi[m] >= 0) {
+            const hc::MiniPass mp = hc::mini_pass_setup(pl, sc.L, m, tau);
+            for (int j = 0; j < mp.n_steps; ++j)
+                for (int s = mp.s_cut[j]; s < mp.n_samples; ++s) {
+                    if (s == mp.s_defer[j]) continue;
+                    double wo, wn;
+                    int lo;
+                    if (!hc::mini_bracket(mp.time, mp.kw, mp.tpred[j] - tau[s], &wo, &wn, &lo)) return 4;
+                    // history index k of the view = block step m + 1 - k (k = 0: the unknown step m + 1, weight masked)
+                    const double vn = (lo >= 1 && lo <= mp.kw) ? v_block[m + 1 - lo] : 0.0;
+                    const double vo = (lo + 1 <= mp.kw) ? v_block[m - lo] : 0.0;
+                    mini[m + 1 + j] += K[s] * (wo * width[s] * vo + wn * width[s] * vn);
+                }
+        }
     }
     *worst_out = worst;
     return worst <= 1e-12 ? 0 : 1;
@@ -128,6 +146,11 @@ int main() {
         {0.015, 0.01, 201, 330, 32},  {0.01, 0.0101, 128, 140, 32}, {0.01, 0.004, 128, 400, 32}, {0.01, 0.02, 512, 300, 16},
         {0.01, 0.01, 256, 40, 16},    /* history shorter than the IRF window: the deferred-sample rule is active */
         {0.01, 0.0101, 1001, 34, 16}, {0.015, 0.0101, 1001, 18, 16}, {0.01, 0.01, 64, 100, 32} /* block = half the window */,
+        // the two-level form (sub-blocks of 8 steps + short passes): the same grid of step sizes and history lengths
+        {0.01, 0.01, 256, 300, 32, 8},  {0.01, 0.01, 256, 300, 16, 8},   {0.01, 0.007, 256, 400, 32, 8},  {0.01, 0.013, 256, 220, 16, 8},
+        {0.015, 0.01, 201, 330, 32, 8}, {0.01, 0.0101, 128, 140, 32, 8}, {0.01, 0.004, 128, 400, 32, 8},  {0.01, 0.02, 512, 300, 16, 8},
+        {0.01, 0.01, 256, 40, 16, 8},   {0.01, 0.0101, 1001, 34, 16, 8}, {0.015, 0.0101, 1001, 18, 32, 8}, {0.01, 0.01, 64, 100, 32, 8},
+        {0.01, 0.01, 256, 300, 32, 4},  {0.01, 0.0037, 256, 600, 32, 8},
     };
     int failures = 0, planned = 0;
     for (const auto& sc : list)
@@ -135,10 +158,10 @@ int main() {
             double worst = 0.0;
             const int rc = run(sc, seed, &worst);
             if (worst >= 0.0) ++planned;
-            std::printf("dt_rirf %.4f dt_step %.4f S %4d H0 %4d L %2d seed %u : %s (worst %.2e)\n", sc.dt_rirf, sc.dt_step, sc.S, sc.H0, sc.L,
-                        seed, rc == 0 ? (worst < 0.0 ? "not planned" : "ok") : "FAILED", worst);
+            std::printf("dt_rirf %.4f dt_step %.4f S %4d H0 %4d L %2d sub %d seed %u : %s (worst %.2e)\n", sc.dt_rirf, sc.dt_step, sc.S, sc.H0, sc.L,
+                        sc.sub, seed, rc == 0 ? (worst < 0.0 ? "not planned" : "ok") : "FAILED", worst);
             failures += rc != 0;
         }
     std::printf("%d scenario runs, %d planned, %d failures\n", static_cast<int>(sizeof list / sizeof list[0]) * 3, planned, failures);
-    return (failures == 0 && planned >= 24) ? 0 : 1;
+    return (failures == 0 && planned >= 60) ? 0 : 1;
 }

@@ -180,3 +180,42 @@ def test_sharded_plugin_surface_through_componentfunc(tmp_path, mode):
     expect[:6 * N] += 0.5 * (M @ w[:6 * N])
     R = np.array([float(x) for x in outs[4][-1].split()[1:]])
     assert relerr(R, expect) <= 1e-13
+
+
+@pytest.mark.parametrize("mode", [(32, 1), (16, 1), (32, 0), (0, 1)], ids=["la32-aql", "la16-aql", "la32-hip", "plain-aql"])
+def test_wide_system_two_level_lookahead_against_oracle(hydro, mode, monkeypatch):
+    """A WIDE system (D = 1056 >= 1024): the own-sample part of a block step is split over column slices (near_split_kernel), and the
+    look-ahead runs in its two-level form (sub-blocks of 8 steps, a short pass after each, scatter inside the sub-block only) --
+    what every rank of C4 (D = 3072) runs.  Totals and components against the CPU oracle, and three row shards bitwise."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    lookahead, direct = mode
+    N = 176
+    case = many_body_case(N, S=48, dt_rirf=0.02, n_exc=17, dt_exc=0.05, seed=1056)
+    monkeypatch.setenv("HC_DIRECT", str(direct))
+    full = hydro.HydroForces.from_case(case)
+    group = hydro.HydroGroup.from_case(case, 3)
+    assert full.direct_dispatch()[0] == bool(direct), full.direct_dispatch()[1]
+    orc = load_into_oracle(case)
+    kw = dict(WAVES, simulation_duration=4.0)
+    for h in (full, group, orc):
+        h.add_waves_irregular(**kw)
+    full.set_lookahead(lookahead)
+    group.set_lookahead(lookahead)
+    motion = PrescribedMotion(N, rest_positions(case), seed=2)
+    full.enable_profiling(1)
+    t = 0.0
+    for n in range(150):
+        st = motion.state(t)
+        fg = full.step(t, *st)
+        assert relerr(fg, orc.step(t, *st)) <= TIGHT_TOL, f"step {n}"
+        for g, o in zip(full.components(), orc.components()):
+            assert relerr(g, o) <= TIGHT_TOL
+        assert np.array_equal(group.step(t, *st), fg), f"step {n}: shards"
+        t += 0.01 if n != 100 else 0.0137  # one off-grid step: back to plain steps and into a new block
+    p = full.profile()
+    if lookahead:
+        assert p["block_kernel_launches"] >= 3 and p["mini_pass_launches"] >= 3 and p["scatter_kernel_launches"] >= 60, p
+    else:
+        assert p["block_kernel_launches"] == 0 and p["mini_pass_launches"] == 0
+    assert (p["direct_dispatches"] > 0, p["hip_launches"] > 0) == (bool(direct), not direct)

@@ -967,16 +967,18 @@ def test_c4_size_array_properties_on_one_gpu(HF):
     assert_close(got, (k[:, 1:] * w[None, 1:]).sum(axis=1), 1e-11, "constant-velocity closed form at C4 size")
 
 
+@pytest.mark.parametrize("depth,sub", [(16, 0), (32, 0), (32, 8), (16, 8), (32, 4)])  # sub > 0: the two-level form of wide systems, forced here
 @pytest.mark.parametrize("seed,N", [(1, 2), (2, 2), (3, 2), (4, 8)])  # N = 8: the scalar-tracker (D % 8 == 0) pass form
-def test_lookahead_random_step_patterns(HF, seed, N):
+def test_lookahead_random_step_patterns(HF, seed, N, depth, sub, monkeypatch):
     """Randomised stepping patterns (uniform stretches of random length and step size, jittered stretches, abrupt changes):
     look-ahead and plain evaluation of the same inputs must agree to rounding whatever the planner decides."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     from hydrochrono_amd.synthetic import many_body_case, rest_positions
     rng = np.random.default_rng(seed)
-    case = many_body_case(N, S=80, dt_rirf=0.01, n_exc=33, seed=300 + seed)
+    monkeypatch.setenv("HC_SUB_BLOCK", str(sub))  # read at every plan: sub-blocks of `sub` steps + a short pass after each
+    case = many_body_case(N, S=80 if depth == 16 else 150, dt_rirf=0.01, n_exc=33, seed=300 + seed)
     a, b = HF.from_case(case), HF.from_case(case)
-    a.set_lookahead(16)
+    a.set_lookahead(depth)
     b.set_lookahead(0)
     kw = dict(simulation_dt=0.01, simulation_duration=40.0, wave_height=1.5, wave_period=6.0, nfrequencies=24, frequency_min=0.05,
               frequency_max=0.5)
@@ -998,6 +1000,9 @@ def test_lookahead_random_step_patterns(HF, seed, N):
         fa, fb = a.step(t, *st), b.step(t, *st)
         worst = max(worst, relerr(fa, fb))
     assert worst <= 1e-10, worst
+    p = a.profile()
+    assert p["block_kernel_launches"] >= 5
+    assert (p["mini_pass_launches"] > 0) == (sub > 0), p
     prof = a.profile()
     assert prof["block_kernel_launches"] > 5 and prof["conv_kernel_launches"] > 5  # both paths were exercised
 

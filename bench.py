@@ -20,6 +20,11 @@ rows all-gathered over RCCL every step and the stream synchronised (every rank h
 step starts); value = K / max-over-ranks time.  `--scaling weak` runs independent 64-body farms instead (replicas, no
 data-path collective).  `--scaling strong` also runs on one GPU (77 GB fits in 288 GB).
 
+N > 1 in ONE process (`python bench.py --gpus N` without a launcher, or `--single-process` under one): the same coupled array
+row-sharded over N contexts of this process, one per visible GPU (all on GPU 0 when the box has fewer: a functional mode), evaluated
+with ONE hc_step_multi per step -- the C-ABI multi-GPU path of a Chrono host (no torch.distributed, no collective; host gather).
+Under torch.distributed.run rank 0 also reports this mode as the secondary `single_process_c_abi` (the other ranks wait).
+
 The JSON line also carries
   roofline      HBM roofline of the dominant kernel (the look-ahead pass): bytes the launch has to move ONCE / mean
                 HIP-event duration / 8 TB/s -- a fraction; the reuse over the 32 (or 16) steps one launch serves is
@@ -67,6 +72,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the device_pipelined / plain_per_step_mode measurements")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline time budget")
+    ap.add_argument("--steady-steps", type=int, default=256, help="synchronous steps of the steady_state block (median + mean, SURVEY 8d: >= 200)")
+    ap.add_argument("--single-process", action="store_true", help="N > 1: all shards in THIS process through hc_step_multi (no launcher needed)")
+    ap.add_argument("--no-c4-share", action="store_true", help="skip the c4_rank_share secondary (one C4/8 shard on this GPU)")
     return ap.parse_args()
 
 
@@ -109,6 +117,8 @@ def cpu_baseline(case, motion, t_hist, v_hist, budget_s, step_dt, duration):
     orc_mod.set_num_threads(best)
     n_more = int(max(3, min(40, (0.5 * budget_s - (time.perf_counter() - t_begin)) / sweep[best])))
     med = float(np.median(timed(orc.step, n_more, True)))
+    orc_mod.set_num_threads(1)  # the reference-faithful form on ONE thread as well
+    single_ms = float(np.median(timed(orc.step, 2, True))) * 1e3
     flat_sweep = {}
     for th in sorted({cores, min(cores, 64), min(cores, 16)}, reverse=True):
         orc_mod.set_num_threads(th)
@@ -120,6 +130,7 @@ def cpu_baseline(case, motion, t_hist, v_hist, budget_s, step_dt, duration):
             "sample": f"{n_more} consecutive steady-state steps of the same workload (median), reference-faithful oracle "
                       f"-O2 -fopenmp, OMP threads = {best} (best of sweep); box has {cores} logical cores",
             "threads_sweep_ms": {str(th): v * 1e3 for th, v in sweep.items()},
+            "single_thread_ms": single_ms,
             "optimized_port": {"value": 1.0 / med_flat, "unit": "evals/s", "cores": best_flat, "ms_per_step": med_flat * 1e3,
                                "threads_sweep_ms": {str(th): v * 1e3 for th, v in flat_sweep.items()},
                                "sample": "6 steps per thread count (median), flat-array OpenMP-over-rows CPU variant of the same math"}}
@@ -149,17 +160,123 @@ def max_rel_err(a, b):
     return float(np.max(np.max(np.abs(a - b), axis=1) / np.maximum(np.max(np.abs(b), axis=1), 1e-300)))
 
 
+def make_shard(N, b0, b1, device, sdt, duration, lookahead, t_hist, v_hist):
+    """One row shard of the synthetic coupled N-body array (K generated in HBM), waves attached, history pre-filled."""
+    from hydrochrono_amd.hydro import HydroForces
+    gpu = HydroForces(N, device=device, body_range=(b0, b1))
+    gpu.synth_fill(20251031, S_RIRF, DT, N_EXC, DT)
+    gpu.finalize()
+    gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
+    gpu.set_lookahead(lookahead)
+    gpu.set_history(t_hist, v_hist)
+    return gpu
+
+
+def dispatch_info(shards):
+    """How the kernels of the step path reach the GPU (hc_direct_dispatch_active / hc_dispatch_mode_reason), per context."""
+    modes = [h.direct_dispatch() for h in shards]
+    allq = all(m[0] for m in modes)
+    return {"dispatch_mode": "direct AQL packets (library-owned HSA queue)" if allq else ("HIP launches" if not any(m[0] for m in modes) else "mixed"),
+            "dispatch_mode_reason": sorted({m[1] for m in modes})}
+
+
+def run_group_sync(N, G, devices, sdt, lookahead, warm, steps, motion=None):
+    """ONE process, G row-shard contexts (devices[g]), `steps` synchronous hc_step_multi calls after `warm` untimed ones
+    (host state in, the gathered 6N forces out on the host).  Returns (dict, forces[steps][6N])."""
+    from hydrochrono_amd import capi
+    from hydrochrono_amd.hydro import HydroGroup
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.parallel_split import body_shard
+    motion = motion or PrescribedMotion(N, np.zeros((N, 3)), seed=20251031)
+    nhist = int(np.ceil(S_RIRF * DT / sdt)) + 5
+    t_hist = T0 - sdt * np.arange(1, nhist + 1)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    n_all = warm + steps
+    duration = max(WAVES["simulation_duration"], T0 + (n_all + 8) * sdt + 5.0)
+    shards = [make_shard(N, *body_shard(N, G, g), devices[g], sdt, duration, lookahead, t_hist, v_hist) for g in range(G)]
+    grp = HydroGroup(shards)
+    times = [T0 + k * sdt for k in range(n_all)]
+    states = np.ascontiguousarray(np.stack([motion.packed(t) for t in times]))
+    forces = np.zeros((n_all, 6 * N))
+    n3 = 3 * N
+    step = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(("hc_step_multi", capi.load()))
+    sp = [states.ctypes.data + k * states.strides[0] for k in range(n_all)]
+    fp = [forces.ctypes.data + k * forces.strides[0] for k in range(n_all)]
+    per = np.zeros(n_all)
+    pc = time.perf_counter
+
+    def run(k0, k1):
+        for k in range(k0, k1):
+            a = pc()
+            rc = step(grp._ctxs, G, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
+            per[k] = pc() - a
+            if rc:
+                raise RuntimeError(capi.load().hc_last_error(shards[0].ctx).decode())
+
+    run(0, warm)
+    for h in shards:
+        h.enable_profiling(17)
+        h.reset_profile()
+    t0 = pc()
+    run(warm, n_all)
+    elapsed = pc() - t0
+    profs = [h.profile() for h in shards]
+    info = {"evals_per_s": steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "median_ms_per_step": float(np.median(per[warm:])) * 1e3,
+            "p90_ms_per_step": float(np.percentile(per[warm:], 90)) * 1e3, "steps": steps, "contexts": G, "devices": list(devices),
+            "bodies": N, "lookahead": lookahead,
+            "pass_us_max_over_shards": max(1e6 * p["block_kernel_seconds"] / max(1, p["block_kernel_launches"]) for p in profs),
+            "aql_dispatches": int(sum(p["direct_dispatches"] for p in profs)), "hip_launches": int(sum(p["hip_launches"] for p in profs))}
+    info.update(dispatch_info(shards))
+    grp.close()
+    return info, forces[warm:]
+
+
+def c4_rank_share(sdt, lookahead):
+    """What ONE rank of C4/8 does, on this GPU: the rows of bodies [0, 64) of the coupled 512-body array (K slice 9.66 GB),
+    synchronous hc_step.  A driver-run figure for multi-GPU readiness while no 8-GPU node is available."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    N, warm, steps = N_BODIES_C4, 40, 128
+    motion = PrescribedMotion(N, np.zeros((N, 3)), seed=20251031)
+    nhist = int(np.ceil(S_RIRF * DT / sdt)) + 5
+    t_hist = T0 - sdt * np.arange(1, nhist + 1)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    gpu = make_shard(N, 0, N // 8, 0, sdt, T0 + (warm + steps + 8) * sdt + 5.0, lookahead, t_hist, v_hist)
+    times = [T0 + k * sdt for k in range(warm + steps)]
+    states = [motion.state(t) for t in times]
+    for k in range(warm):
+        gpu.step(times[k], *states[k])
+    gpu.enable_profiling(1)
+    gpu.reset_profile()
+    per = []
+    for k in range(warm, warm + steps):
+        a = time.perf_counter()
+        gpu.step(times[k], *states[k])
+        per.append(time.perf_counter() - a)
+    p = gpu.profile()
+    per = np.array(per)
+    pass_s = p["block_kernel_seconds"] / max(1, p["block_kernel_launches"])
+    out = {"workload": f"rows of bodies [0, {N // 8}) of the coupled {N}-body array (D_local = {gpu.D_local}, D = {6 * N}, K slice "
+                       f"{p['conv_kernel_bytes'] / 1e9:.2f} GB), synchronous hc_step through the Python wrapper, {steps} steps",
+           "ms_per_step": float(per.mean()) * 1e3, "median_ms_per_step": float(np.median(per)) * 1e3,
+           "pass_us": pass_s * 1e6, "pass_launches": int(p["block_kernel_launches"]),
+           "pass_frac_of_hbm_peak": p["block_kernel_bytes_once"] / pass_s / 1e9 / HBM_PEAK_GBS if pass_s > 0 else None,
+           "per_step_us": {"pass": p["block_kernel_seconds"] / steps * 1e6, "short_passes": p["mini_pass_seconds"] / steps * 1e6,
+                           "scatter": p["scatter_kernel_seconds"] / steps * 1e6, "step_kernels": p["step_kernel_seconds"] / steps * 1e6}}
+    out.update(dispatch_info([gpu]))
+    gpu.close()
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    single = world == 1 and (args.gpus > 1 or args.single_process)
+    if world != args.gpus and not single:
         args.gpus = world
     if args.scaling is None:
-        args.scaling = "strong" if world > 1 else "weak"
+        args.scaling = "strong" if (world > 1 or single) else "weak"
     strong = args.scaling == "strong"
     if args.bodies is None:
         args.bodies = N_BODIES_C4 if strong else N_BODIES
@@ -173,6 +290,29 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hydro-force path has no CPU fallback")
+    sdt = args.step_dt
+    ndev = torch.cuda.device_count()
+
+    if single:
+        # ---- ONE process, G contexts, hc_step_multi: the multi-GPU path of a Chrono host through the C ABI ----
+        G = args.gpus
+        devices = [g % ndev for g in range(G)]
+        info, _ = run_group_sync(args.bodies, G, devices, sdt, args.lookahead, args.warmup + 32, args.steps)
+        out = {"metric": "hydro-force evals/sec (all bodies)", "value": info["evals_per_s"], "unit": "evals/s", "n_gpus": G, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": info["ms_per_step"], "median_ms_per_step": info["median_ms_per_step"],
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"C4-style: ONE coupled synthetic {args.bodies}-body array row-sharded over {G} contexts of ONE process "
+                                      f"(devices {devices}; {ndev} visible), one hc_step_multi per step: state stored into every context, "
+                                      "all step kernels dispatched, host-side gather of the force rows; no collective",
+                          "bodies": args.bodies, "irf_samples": S_RIRF, "wave_components": WAVES["nfrequencies"], "lookahead": args.lookahead,
+                          "sharding": "body-row shards, single process, host gather (SURVEY 8e drop-in variant)"},
+               "single_process": info}
+        out.update({k: info[k] for k in ("dispatch_mode", "dispatch_mode_reason")})
+        if ndev < G:
+            out["note"] = f"only {ndev} GPU(s) visible: contexts share devices (functional run, not a scaling figure)"
+        print(json.dumps(out), flush=True)
+        return
+
     # HC_BENCH_SHARE_GPU=1 (functional test of the N > 1 code path on a one-GPU box): all ranks use device 0 and the
     # force all-gather goes over gloo instead of RCCL.  Never used for reported numbers.
     share_gpu = os.environ.get("HC_BENCH_SHARE_GPU") == "1"
@@ -202,7 +342,7 @@ def main():
         gpu = HydroForces.from_case(case, device=local_rank)
         motion = PrescribedMotion(N, rest_positions(case), seed=20251031 + rank)
         exchange = None  # independent farms: nothing to exchange
-    sdt = args.step_dt
+    n_steady = args.steady_steps if (world == 1 and not args.no_secondary) else 0
     n_pipe = 0 if (args.no_secondary or world > 1) else args.steps
     n_plain = 0 if (args.no_secondary or world > 1 or args.lookahead == 0) else max(20, args.steps // 8)
     # Phase alignment (untimed, before the W warm-up steps): one look-ahead pass serves a block of `lookahead` steps and is paid
@@ -217,7 +357,7 @@ def main():
         align = boundary - first
     pre = align + args.warmup
     total = pre + args.steps
-    n_all = total + n_pipe + n_plain + 16
+    n_all = total + n_steady + n_pipe + n_plain + 16
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
     duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
     gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
@@ -249,9 +389,12 @@ def main():
     if exchange is not None:
         d_states = torch.tensor(states[:total], device="cuda")
         state_ptrs = [d_states.data_ptr() + k * d_states.stride(0) * 8 for k in range(total)]
-        d_send = exchange.send if not share_gpu else torch.zeros(exchange.max_rows, dtype=torch.float64, device="cuda")
         gathered = torch.zeros(total, 6 * N, dtype=torch.float64, device="cpu" if share_gpu else "cuda")
-        own_rows = torch.zeros(total, exchange.rows, dtype=torch.float64, device="cuda")  # this rank's rows as the kernel left them
+        # this rank's rows as the kernel left them: the step kernel writes them here and the all-gather sends them from here (no
+        # staging copy on the stream between the two)
+        own_rows = torch.zeros(total, exchange.max_rows, dtype=torch.float64, device="cuda")
+        own_ptrs = [own_rows.data_ptr() + k * own_rows.stride(0) * 8 for k in range(total)]
+        direct_gather = exchange.even and not share_gpu  # equal shards: the collective writes the step's row of `gathered` itself
         torch.cuda.synchronize()
 
     def run_sync(k0, k1):
@@ -265,28 +408,34 @@ def main():
                 if rc:
                     gpu._chk(rc)
         else:
-            # coupled array over several ranks: kernels write this rank's rows into the exchange's send buffer, the RCCL
-            # all-gather leaves the full 6N force vector on every rank (the one exchange step of the path),
-            # and the stream is synchronised: the next step starts only when every rank holds all forces of this one
+            # coupled array over several ranks: the step kernel writes this rank's rows, the RCCL all-gather leaves the full 6N
+            # force vector on every rank (the one exchange step of the path), and the stream is synchronised: the
+            # next step starts only when every rank holds all forces of this one
             pc = time.perf_counter
             for k in range(k0, k1):
                 a = pc()
-                gpu.step_device(times[k], state_ptrs[k], d_send.data_ptr(), stream.cuda_stream)
-                own_rows[k].copy_(d_send[: exchange.rows], non_blocking=True)  # for the exchange check after the run
+                gpu.step_device(times[k], state_ptrs[k], own_ptrs[k], stream.cuda_stream)
                 if share_gpu:
                     stream.synchronize()
-                    full = exchange.gather(d_send[: exchange.rows].cpu())
-                    gathered[k].copy_(full)
+                    gathered[k].copy_(exchange.gather(own_rows[k, : exchange.rows].cpu()))
+                elif direct_gather:
+                    dist.all_gather_into_tensor(gathered[k], own_rows[k], group=exchange.group)
+                    stream.synchronize()
                 else:
-                    full = exchange.gather()
-                    gathered[k].copy_(full, non_blocking=True)
+                    gathered[k].copy_(exchange.gather(own_rows[k, : exchange.rows]), non_blocking=True)
                     stream.synchronize()
                 per_step[k] = pc() - a
 
-    run_sync(0, pre)
-    torch.cuda.synchronize()
+    def prof_diff(p1, p0):
+        return {k: (p1[k] - p0[k]) if not k.endswith("_bytes") and not k.endswith("_bytes_once") else p1[k] for k in p1}
+
+    # profiling runs through warm-up, timed region and the steady-state block: every look-ahead pass of the run is timed (the
+    # per-step launches every `profile_stride`-th step), so the roofline rests on more than the one pass a 20-step region holds
     gpu.enable_profiling(args.profile_stride)
     gpu.reset_profile()
+    run_sync(0, pre)
+    torch.cuda.synchronize()
+    prof_pre = gpu.profile()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -296,8 +445,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    prof = gpu.profile()
-    gpu.enable_profiling(False)
+    prof_end = gpu.profile()
+    prof = prof_diff(prof_end, prof_pre)  # the timed region alone
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -309,7 +458,7 @@ def main():
         # the gathered vector of every step, and all ranks hold the same gathered vectors (checksums of the raw bits)
         b0_, b1_ = exchange.shards[rank]
         mine = gathered[:total, 6 * b0_:6 * b1_].to("cuda")
-        own_ok = bool(torch.equal(mine, own_rows[:total]))
+        own_ok = bool(torch.equal(mine, own_rows[:total, : exchange.rows]))
         dev_ = "cpu" if share_gpu else "cuda"
         bits = gathered[:total].contiguous().view(torch.int64)
         csum = (bits & 0xFFFFFFFF).sum(dim=1) + (bits >> 32).sum(dim=1)  # per-step checksum, exact in int64
@@ -322,8 +471,20 @@ def main():
                        "steps_checked": int(total)}
 
     # ---- secondary figures (not `value`) ----
-    pipelined = plain = None
+    steady = pipelined = plain = None
     k_next = total
+    if n_steady > 0:
+        # steady state, median of >= 200 synchronous steps (the fixed driver command times 20)
+        t_s = time.perf_counter()
+        run_sync(k_next, k_next + n_steady)
+        t_s = time.perf_counter() - t_s
+        ps = per_step[k_next:k_next + n_steady] * 1e3
+        steady = {"steps": n_steady, "evals_per_s": n_steady / t_s, "mean_ms_per_step": t_s / n_steady * 1e3, "median_ms_per_step": float(np.median(ps)),
+                  "p10_ms_per_step": float(np.percentile(ps, 10)), "p90_ms_per_step": float(np.percentile(ps, 90)),
+                  "note": "synchronous hc_step calls right after the timed region (same context, same history), passes included"}
+        k_next += n_steady
+    prof_all = gpu.profile()  # warm-up + timed region + steady-state block
+    gpu.enable_profiling(False)
     if n_pipe > 0:
         # hc_step_device, states resident in HBM, every step enqueued without waiting for the previous one's forces
         d_states = torch.tensor(states[k_next:k_next + n_pipe], device="cuda")
@@ -359,22 +520,40 @@ def main():
                  "frac_of_hbm_peak": (pp["conv_kernel_bytes"] / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS) if kus > 0 else 0.0,
                  "note": "synchronous hc_step with look-ahead off: one launch streams all of K per step"}
         k_next += 4 + n_plain
+    dinfo = dispatch_info([gpu])
+    dinfo["aql_dispatches"], dinfo["hip_launches"] = int(prof_all["direct_dispatches"]), int(prof_all["hip_launches"])
+
+    # ---- N > 1 under a launcher: the single-process C-ABI mode as a secondary, run by rank 0 while the others wait ----
+    single_sec = None
+    if world > 1 and strong and not args.no_secondary:
+        dist.barrier()
+        if rank == 0:
+            try:
+                devs = [0] * world if share_gpu else [g % ndev for g in range(world)]
+                single_sec, _ = run_group_sync(N, world, devs, sdt, args.lookahead, 64, max(args.steps, 64), motion)
+                single_sec["note"] = ("ONE process (this rank) drives all shards through hc_step_multi: state store per GPU, all step kernels "
+                                      "dispatched before any wait, host-side gather -- no collective, no torch on the path")
+            except Exception as e:  # a secondary must not cost the run its line
+                single_sec = {"error": str(e)}
+        dist.barrier()
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         timed = per_step[pre:total] * 1e3
-        # dominant kernel: the look-ahead pass when blocking is on (one launch covers 16 steps), else the per-step kernel
-        if prof["block_kernel_launches"] > 0:
-            kname, units = "hc::conv_block_kernel", int(args.lookahead)
-            conv_s = prof["block_kernel_seconds"] / prof["block_kernel_launches"]
-            bytes_once = prof["block_kernel_bytes_once"]
-            bytes_units = prof["block_kernel_bytes"]
-            n_timed = prof["block_kernel_launches"]
-        else:
-            kname, units = "hc::conv_step_kernel", 1
-            conv_s = prof["conv_kernel_seconds"] / max(1, prof["conv_kernel_launches"])
-            bytes_once = bytes_units = prof["conv_kernel_bytes"]
-            n_timed = prof["conv_kernel_launches"]
+        # dominant kernel: the look-ahead pass when blocking is on (one launch covers `lookahead` steps), else the per-step kernel.
+        # `achieved` = the bytes a launch must move once / its mean duration over EVERY launch of the synchronous phases of this run
+        # (warm-up, timed region, steady-state block: the same kernel with the same arguments); the launches of the timed region alone
+        # are listed next to it.
+        def pass_stats(pr):
+            if pr["block_kernel_launches"] > 0:
+                return pr["block_kernel_seconds"] / pr["block_kernel_launches"], int(pr["block_kernel_launches"])
+            return pr["conv_kernel_seconds"] / max(1, pr["conv_kernel_launches"]), int(pr["conv_kernel_launches"])
+        blocked = prof_all["block_kernel_launches"] > 0
+        kname, units = ("hc::conv_block_kernel", int(args.lookahead)) if blocked else ("hc::conv_step_kernel", 1)
+        conv_s, n_timed = pass_stats(prof_all)
+        conv_s_region, n_region = pass_stats(prof)
+        bytes_once = prof_all["block_kernel_bytes_once"] if blocked else prof_all["conv_kernel_bytes"]
+        bytes_units = prof_all["block_kernel_bytes"] if blocked else prof_all["conv_kernel_bytes"]
         achieved = bytes_once / conv_s / 1e9 if conv_s > 0 else 0.0
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")
@@ -417,6 +596,9 @@ def main():
                 "sharding": ("body-row shards of one coupled array + RCCL all-gather of forces every step" if strong else
                              "one independent farm per GPU, no data-path collective") if world > 1 else "single GPU",
             },
+            "dispatch_mode": dinfo["dispatch_mode"] if world == 1 else "HIP launches on the rank's stream (hc_step_device) + RCCL all-gather",
+            "dispatch_mode_reason": dinfo["dispatch_mode_reason"],
+            "aql_dispatches": dinfo["aql_dispatches"], "hip_launches": dinfo["hip_launches"],
             "roofline": {
                 "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -424,20 +606,32 @@ def main():
                 "reuse_factor": bytes_units / bytes_once if bytes_once else None,
                 "algorithmic_bytes_of_the_units": bytes_units,
                 "mean_kernel_us": conv_s * 1e6, "launches_timed": n_timed,
-                "step_kernel_us": us(prof["step_kernel_seconds"], prof["step_kernel_launches"]),
-                "scatter_kernel_us": us(prof["scatter_kernel_seconds"], prof["scatter_kernel_launches"]),
+                "timed_region_kernel_us": conv_s_region * 1e6, "timed_region_launches": n_region,
+                "step_kernel_us": us(prof_all["step_kernel_seconds"], prof_all["step_kernel_launches"]),
+                "scatter_kernel_us": us(prof_all["scatter_kernel_seconds"], prof_all["scatter_kernel_launches"]),
                 "fp64_TFLOPs": (2.0 * (bytes_units / 8.0) / conv_s / 1e12) if conv_s > 0 else None,
                 "fp64_frac_of_mfma_peak": (2.0 * (bytes_units / 8.0) / conv_s / 1e12 / FP64_MFMA_PEAK_TF) if conv_s > 0 else None,
-                "note": ("achieved = bytes one launch must move once (live K + Kex + staged vectors) / mean HIP-event duration; the "
-                         f"launch serves {units} steps (SURVEY 8d bytes of those steps = algorithmic_bytes_of_the_units, reuse_factor x)")
+                "note": ("achieved = bytes one launch must move once (live K + Kex + staged vectors) / mean duration of every launch of the "
+                         "run's synchronous phases (warm-up, timed region, steady-state block), timed by the completion signals of the "
+                         f"library's own dispatches (HIP events when it launches through HIP); the launch serves {units} steps (SURVEY 8d "
+                         "bytes of those steps = algorithmic_bytes_of_the_units, reuse_factor x)")
                         if units > 1 else "one launch = one step",
             },
             "term_seconds": {k: prof[k] for k in ("hydrostatics_seconds", "radiation_seconds", "waves_seconds")},
         }
+        if steady is not None:
+            out["steady_state"] = steady
         if pipelined is not None:
             out["device_pipelined"] = pipelined
         if plain is not None:
             out["plain_per_step_mode"] = plain
+        if single_sec is not None:
+            out["single_process_c_abi"] = single_sec
+        if world == 1 and not strong and not args.no_secondary and not args.no_c4_share:
+            try:
+                out["c4_rank_share"] = c4_rank_share(sdt, args.lookahead if args.lookahead > 0 else 32)
+            except Exception as e:  # a secondary must not cost the run its line
+                out["c4_rank_share"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and case is not None:
             base, f_faithful, flat_threads = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds, sdt, duration)
             n_chk = k_next
@@ -462,12 +656,12 @@ def main():
         if strong:
             # the same coupled array on ONE GPU (committed measurement), so that a strong-scaling ratio can be formed: the N = 1
             # line of this benchmark is the C3 case (BASELINE.json's metric), not this workload
-            ref = os.path.join(ROOT, "profiles", "r02", "bench_c4_1gpu.json")
+            ref = os.path.join(ROOT, "profiles", "r03", "bench_c4_1gpu.json")
             if os.path.exists(ref) and N == N_BODIES_C4:
                 try:
                     rj = json.load(open(ref))
                     out["same_workload_on_one_gpu"] = {"evals_per_s": rj["value"], "ms_per_step": rj["ms_per_step"],
-                                                       "source": "profiles/r02/bench_c4_1gpu.json (bench.py --scaling strong --bodies 512 on one MI355X)"}
+                                                       "source": "profiles/r03/bench_c4_1gpu.json (bench.py --scaling strong --bodies 512 on one MI355X)"}
                 except Exception:
                     pass
         print(json.dumps(out), flush=True)

@@ -1191,6 +1191,60 @@ std::string library_dir() {
     return dir;
 }
 
+// What the host RE-writes through the BAR must be what the next dispatch reads.  The dispatches carry agent-scope acquire fences
+// only, so this rests on the GPU not keeping stale copies of fine-grained device memory across kernels -- for the state buffer
+// (two halves, rewritten every second step) and for the kernarg ring (64 slots per lane, reused every 64 dispatches).  Checked
+// on the given lane: 2 x 64 + 3 one-row added-mass products whose inputs (w, R_in: the SAME two BAR words every time) and
+// whose argument slot change from dispatch to dispatch; every result must be the one of the values written last.  A stale read
+// fails the test (reason in c->direct_why) and the caller keeps using HIP launches.  *abandon: a dispatch never completed.
+bool direct_selftest_rewrites(hc_ctx* c, hc::DirectQueue* q, int lane, bool* abandon) {
+    *abandon = false;
+    const double one = 1.0;
+    HC_HIP(hipMemcpy(c->d_selftest.p, &one, sizeof one, hipMemcpyHostToDevice));  // the 1 x 1 "matrix"
+    volatile unsigned long long* tag = c->h_tag_selftest.p;
+    tag[0] = tag[1] = 0;
+    for (int i = 0; i < 2 * 64 + 3; ++i) {
+        const double wv = 3.0 + i, rv = 0.25 * (i + 1) + lane, cv = 0.5 + 0.125 * (i % 7);
+        c->bar_selftest.p[0] = wv;
+        c->bar_selftest.p[1] = rv;
+        _mm_sfence();
+        const unsigned long long sq = 0xABC000ull + static_cast<unsigned long long>(lane) * 1000 + i;
+        hc::AddedMassArgs a{c->d_selftest.p, 1, 1, c->bar_selftest.p, c->bar_selftest.p + 1, cv, c->h_tag_selftest.dp, sq};
+        q->dispatch(c->dk_added_mass, 1, 256, 0, &a, sizeof a, -1, 0.0, lane);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool arrived  = false;
+        for (unsigned long long spins = 0;; ++spins) {
+            if (tag[1] == sq) { arrived = true; break; }
+            __builtin_ia32_pause();
+            if ((spins & 0xFFF) == 0xFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+        }
+        if (!arrived) {
+            // either the dispatch hangs or it ran with the arguments of the slot's previous use (an old sequence number)
+            if (q->drain(2.0, lane)) {
+                c->direct_why = "self-test of the direct dispatch: a re-used kernel-argument slot was read stale";
+            } else {
+                c->direct_why = "self-test of the direct dispatch timed out";
+                *abandon      = true;
+            }
+            return false;
+        }
+        const unsigned long long bits = tag[0];
+        double got;
+        std::memcpy(&got, &bits, sizeof got);
+        if (got != rv + cv * wv) {
+            c->direct_why = "self-test of the direct dispatch: memory re-written through the PCIe BAR was read stale";
+            (void)q->drain(2.0, lane);
+            return false;
+        }
+    }
+    if (!q->drain(2.0, lane)) {
+        c->direct_why = "self-test of the direct dispatch timed out";
+        *abandon      = true;
+        return false;
+    }
+    return true;
+}
+
 // Direct AQL dispatch for the synchronous step path (hc_direct.hpp).  Optional: when anything it needs is missing -- the code
 // object next to the library, a host-addressable BAR, one of the kernels of this configuration -- the HIP launches stay in use
 // and hc_last_error-style diagnostics keep the reason (HC_DEBUG_PLAN prints it).  Still the GPU path either way.
@@ -1198,7 +1252,7 @@ void setup_direct(hc_ctx* c) {
     c->direct_ready = false;
     if (env_int("HC_DIRECT", 1) == 0) { c->direct_why = "disabled by HC_DIRECT=0"; return; }
     if (std::getenv("HC_BLOCK_V32")) { c->direct_why = "HC_BLOCK_V32 selects a tuning variant of the pass"; return; }
-    if (!c->bar_state.host_ok || !c->bar_am.host_ok) { c->direct_why = "the device's memory is not host-addressable"; return; }
+    if (!c->bar_state.host_ok || !c->bar_am.host_ok || !c->bar_selftest.host_ok) { c->direct_why = "the device's memory is not host-addressable"; return; }
     std::unique_ptr<hc::DirectQueue> q(new hc::DirectQueue);
     std::string why;
     if (!q->init(c->device, library_dir() + "/hc_kernels.co", &why)) { c->direct_why = why; return; }
@@ -1261,58 +1315,14 @@ void setup_direct(hc_ctx* c) {
     double back = -1.0;
     HC_HIP(hipMemcpy(&back, c->d_P.p, sizeof back, hipMemcpyDeviceToHost));
     if (back != 0.0) { c->direct_why = "self-test of the direct dispatch failed"; return; }
-    // self-test 2: what the host RE-writes through the BAR must be what the next dispatch reads.  The dispatches carry agent-scope
-    // acquire fences only, so this rests on the GPU not keeping stale copies of fine-grained device memory across kernels -- for
-    // the state buffer (two halves, rewritten every second step) and for the kernarg ring (64 slots per lane, reused every 64
-    // dispatches).  Checked here on both lanes: 2 x 64 + 3 one-row added-mass products whose inputs (w, R_in: the SAME two BAR
-    // words every time) and whose argument slot change from dispatch to dispatch; every result must be the one of the values
-    // written last.  A stale read fails the test and the context keeps using HIP launches.
+    // self-test 2 (direct_selftest_rewrites): what the host RE-writes through the BAR must be what the next dispatch reads; lane 0
+    // here, lane 1 when hc_added_mass_mv first uses it
     {
-        const double one = 1.0;
-        HC_HIP(hipMemcpy(c->d_P.p, &one, sizeof one, hipMemcpyHostToDevice));  // the 1 x 1 "matrix"
-        volatile unsigned long long* tag = c->h_tag_am.p;
-        for (int lane = 0; lane < hc::DirectQueue::kLanes; ++lane) {
-            for (int i = 0; i < 2 * 64 + 3; ++i) {
-                const double wv = 3.0 + i, rv = 0.25 * (i + 1) + lane, cv = 0.5 + 0.125 * (i % 7);
-                c->bar_am.p[0] = wv;
-                c->bar_am.p[1] = rv;
-                _mm_sfence();
-                const unsigned long long sq = 0xABC000ull + static_cast<unsigned long long>(lane) * 1000 + i;
-                hc::AddedMassArgs a{c->d_P.p, 1, 1, c->bar_am.p, c->bar_am.p + 1, cv, c->h_tag_am.dp, sq};
-                q->dispatch(c->dk_added_mass, 1, 256, 0, &a, sizeof a, -1, 0.0, lane);
-                const auto t0 = std::chrono::steady_clock::now();
-                bool arrived  = false;
-                for (unsigned long long spins = 0;; ++spins) {
-                    if (tag[1] == sq) { arrived = true; break; }
-                    __builtin_ia32_pause();
-                    if ((spins & 0xFFF) == 0xFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
-                }
-                if (!arrived) {
-                    // either the dispatch hangs or it ran with the arguments of the slot's previous use (an old sequence number)
-                    if (q->drain(2.0, lane)) {
-                        c->direct_why = "self-test of the direct dispatch: a re-used kernel-argument slot was read stale";
-                    } else {
-                        c->direct_why = "self-test of the direct dispatch timed out";
-                        (void)q.release();
-                    }
-                    return;
-                }
-                const unsigned long long bits = tag[0];
-                double got;
-                std::memcpy(&got, &bits, sizeof got);
-                if (got != rv + cv * wv) {
-                    c->direct_why = "self-test of the direct dispatch: memory re-written through the PCIe BAR was read stale";
-                    (void)q->drain(2.0, lane);
-                    return;
-                }
-            }
-            if (!q->drain(2.0, lane)) {
-                c->direct_why = "self-test of the direct dispatch timed out";
-                (void)q.release();
-                return;
-            }
+        bool abandon = false;
+        if (!direct_selftest_rewrites(c, q.get(), 0, &abandon)) {
+            if (abandon) (void)q.release();  // a queue with a dispatch that never completed is left alone
+            return;
         }
-        std::memset(c->h_tag_am.p, 0, c->h_tag_am.n * sizeof(unsigned long long));
     }
     c->dq           = q.release();
     c->direct_ready = true;
@@ -1625,6 +1635,9 @@ int hc_finalize(hc_ctx* c) {
     c->h_am.alloc(static_cast<size_t>(c->D) + c->Dloc);
     c->bar_am.alloc(static_cast<size_t>(c->D) + c->Dloc);
     c->h_tag_am.alloc(static_cast<size_t>(2) * c->Dloc);
+    c->bar_selftest.alloc(2);
+    c->h_tag_selftest.alloc(2);
+    c->d_selftest.alloc(1);
     std::memset(c->h_tag_am.p, 0, c->h_tag_am.n * sizeof(unsigned long long));
     c->seq_am = 0;
     c->h_tag.alloc(static_cast<size_t>(2) * c->Dloc);
@@ -2387,7 +2400,14 @@ void added_mass_begin(hc_ctx* c, const double* w, double cc, const double* R, in
     if (bar) _mm_sfence();
     const double* dw = bar ? c->bar_am.p : c->h_am.dp;
     const unsigned long long seq = ++c->seq_am;
-    if (c->direct_ready && bar && c->dk_added_mass.ok() && c->dk_added_mass.kernarg == sizeof(hc::AddedMassArgs) && c->dk_added_mass.priv == 0) {
+    if (c->direct_ready && bar && c->am_lane == 0) {
+        // first product of this context: the second lane (a queue of its own) is created and self-tested now
+        std::string why;
+        bool abandon = false;
+        c->am_lane   = (c->dq->ensure_lane(1, &why) && direct_selftest_rewrites(c, c->dq, 1, &abandon)) ? 1 : -1;
+        c->direct_why.clear();  // (the step path's lane stays in use whatever the second lane's test said)
+    }
+    if (c->direct_ready && bar && c->am_lane == 1) {
         // the second lane of the direct queue: an AQL packet instead of a HIP launch, independent of the step path's lane
         hc::AddedMassArgs a{c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq};
         c->dq->dispatch(c->dk_added_mass, static_cast<uint32_t>((c->Dloc + 3) / 4), 256, 0, &a, sizeof a, -1, 0.0, 1);

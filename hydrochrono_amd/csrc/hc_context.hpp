@@ -229,6 +229,10 @@ struct hc_ctx {
     hc::BarBuffer<double> bar_state;  // [2][12N] body state written by the host through the BAR (hc_step)
     hc::BarBuffer<double> bar_am;     // [D + Dloc] w and incoming R of hc_added_mass_mv
     hc::PinnedBuffer<unsigned long long> h_tag_am;  // [Dloc][2] its tagged result
+    int am_lane = 0;  // second lane of the direct queue (added-mass products): 0 not created yet, 1 in use, -1 unusable (HIP launches)
+    hc::BarBuffer<double> bar_selftest;                    // [2] inputs of the direct-dispatch self-test
+    hc::PinnedBuffer<unsigned long long> h_tag_selftest;   // [2] its tagged result
+    hc::DeviceBuffer<double> d_selftest;                   // [1]
     unsigned long long seq_am = 0;
     hc::PinnedBuffer<unsigned long long> h_tag;  // [Dloc][2] {total, sequence number} granules written by finalize_kernel
     unsigned long long seq = 0;

@@ -216,13 +216,9 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
     s = hsa_executable_iterate_agent_symbols(p.exe, p.agent, walk_symbol, &walk);
     if (s != HSA_STATUS_SUCCESS || p.kernels.empty()) return fail("no kernels in the code object");
 
-    for (int l = 0; l < kLanes; ++l) {
-        s = hsa_queue_create(p.agent, 1024, HSA_QUEUE_TYPE_SINGLE, on_queue_error, &p.lanes[l].error, UINT32_MAX, UINT32_MAX, &p.lanes[l].queue);
-        if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_queue_create: ") + hsa_text(s));
-        s = hsa_signal_create(1, 0, nullptr, &p.lanes[l].drain_sig);
-        if (s != HSA_STATUS_SUCCESS) return fail(std::string("hsa_signal_create: ") + hsa_text(s));
-        p.lanes[l].have_drain_sig = true;
-    }
+    // lane 0 (the step path) now; lane 1 (added-mass products) when it is first used (ensure_lane): a process that holds many
+    // contexts on one device -- row shards sharing a GPU -- then keeps half as many hardware queues busy
+    if (!ensure_lane(0, why)) return false;
     (void)hsa_amd_profiling_set_profiler_enabled(p.lanes[0].queue, 1);  // timestamps for the dispatches that carry a completion signal
     (void)hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &p.ticks_per_second);
 
@@ -242,6 +238,27 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
     if (fz >= 0) close(fz);
     if (fn >= 0) close(fn);
     if (!host_ok) return fail("device memory is not host-addressable (no large BAR): kernel arguments cannot be stored directly");
+    return true;
+}
+
+bool DirectQueue::ensure_lane(int lane, std::string* why) {
+    Impl& p = *p_;
+    if (lane < 0 || lane >= kLanes) return false;
+    if (p.lanes[lane].queue) return true;
+    hsa_status_t s = hsa_queue_create(p.agent, 1024, HSA_QUEUE_TYPE_SINGLE, on_queue_error, &p.lanes[lane].error, UINT32_MAX, UINT32_MAX, &p.lanes[lane].queue);
+    if (s != HSA_STATUS_SUCCESS) {
+        p.lanes[lane].queue = nullptr;
+        if (why) *why = std::string("hsa_queue_create: ") + hsa_text(s);
+        return false;
+    }
+    if (!p.lanes[lane].have_drain_sig) {
+        s = hsa_signal_create(1, 0, nullptr, &p.lanes[lane].drain_sig);
+        if (s != HSA_STATUS_SUCCESS) {
+            if (why) *why = std::string("hsa_signal_create: ") + hsa_text(s);
+            return false;
+        }
+        p.lanes[lane].have_drain_sig = true;
+    }
     return true;
 }
 

@@ -35,6 +35,8 @@ class DirectQueue {
     // Binds to the HSA agent of HIP device `hip_device`, loads the code object, creates the queue and the kernarg ring.
     // false (with the reason in *why): the direct path is not available and the caller keeps using HIP launches.
     bool init(int hip_device, const std::string& code_object_path, std::string* why);
+    // Creates the lane's HSA queue if it does not exist yet (init creates lane 0 only).  false: the lane cannot be used.
+    bool ensure_lane(int lane, std::string* why);
     // Kernel whose mangled name contains `fragment` (must match exactly one kernel); !ok() if there is none.
     DirectKernel find(const std::string& fragment) const;
 

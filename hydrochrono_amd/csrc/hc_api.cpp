@@ -19,6 +19,7 @@
 #include <memory>
 
 #include "hc_context.hpp"
+#include "hc_history.hpp"
 #include "hc_host_math.hpp"
 
 using hc::Error;
@@ -126,10 +127,6 @@ void ring_alloc(hc_ctx* c, int cap) {
     c->head = -1;
 }
 
-// Samples the prune rule has retired stay addressable for a while (their ring slots are simply not overwritten yet): a step back in
-// time re-admits them, so that the history after a rewind is what the reference's rule keeps at the earlier time.
-constexpr int kRewindSlack = 64;
-
 // Grow the ring so that `need` samples fit, keeping the `have` newest stored samples (k = 0..have-1) in order.
 void ring_grow(hc_ctx* c, int need, int have) {
     quiesce_direct(c);               // the scatter / pass of the last step may still be reading the ring on the direct queue
@@ -162,54 +159,23 @@ void ring_grow(hc_ctx* c, int need, int have) {
     c->head  = have - 1;
 }
 
-// Push the time of this step and prune like PruneHistory; returns H (samples incl. the current one).
-// A step BACK in time (an integrator that rejected a step and retries from an earlier time -- the YAML runner's HHT does): the
-// samples at times >= t belong to the abandoned attempt; they are dropped, the look-ahead plan with them, and the evaluation
-// continues from the history as it was at t -- samples the prune rule had retired since then are re-admitted (up to kRewindSlack
-// of them are kept addressable), so the history is exactly what the reference's rule keeps for a run that arrives at t with the
-// surviving samples.  (The reference has no such rule: it inserts the earlier time in front of its newest-first list,
-// src/hydro_forces.cpp:559-574, keeps the abandoned samples and walks a non-monotone list from then on; that is deliberately not
-// reproduced -- hc_set_history / hc_reset_history remain for callers that manage the history themselves.)
+// Push the time of this step and prune like PruneHistory; returns H (samples incl. the current one).  The bookkeeping -- the
+// reference's push / prune rule and what a step back in time does -- is hc_history.hpp (host only, unit-tested on CPU).
 int history_push(hc_ctx* c, double t) {
-    if (!c->times.empty() && t == c->times.front())
+    const hc::HistoryAdvance r = hc::history_advance(c->times, c->retired, c->head, c->Hcap, t, c->tau.empty() ? 0.0 : c->tau.back());
+    if (r.status == hc::HistoryAdvance::kDuplicateTime)
         throw Error(HC_ERR_RUNTIME, "Tried to compute the radiation damping convolution twice within the same time step!");
-    const double tau_last         = c->tau.empty() ? 0.0 : c->tau.back();
-    const double history_min_time = t - tau_last;
-    if (!c->times.empty() && t < c->times.front()) {
-        int dropped = 0;
-        while (!c->times.empty() && c->times.front() >= t) {
-            c->times.pop_front();
-            ++dropped;
-        }
-        while (c->times.empty() && !c->retired.empty() && c->retired.front() >= t) {  // (a rewind past everything the rule had kept)
-            c->retired.pop_front();
-            ++dropped;
-        }
-        // the ring keeps the dropped samples' slots for the samples to come; everything already enqueued (a scatter, a pass of the
-        // abandoned plan) runs before this step's kernels on the same queue, so nothing is overwritten under a reader
-        c->head = (c->times.empty() && c->retired.empty()) ? -1 : ((c->head - dropped) % c->Hcap + c->Hcap) % c->Hcap;
-        // re-admit retired samples until one older than the window of the new time is there again (the prune rule, read backwards)
-        while (!c->retired.empty() && (c->times.empty() || c->times.back() >= history_min_time)) {
-            c->times.push_back(c->retired.front());
-            c->retired.pop_front();
-        }
-        c->plan.valid = false;
+    if (r.rewound) {
+        // everything already enqueued (a scatter, a pass of the abandoned plan) runs before this step's kernels on the same queue,
+        // so no ring slot is overwritten under a reader; the plan of the abandoned attempt is void
+        c->plan.valid  = false;
         c->plan.misses = 0;
         c->rewinds++;
         c->prof.history_rewinds++;
     }
-    c->times.push_front(t);
-    while (c->times.size() > 1 && c->times[c->times.size() - 2] < history_min_time) {
-        c->retired.push_front(c->times.back());  // retired, still in its ring slot
-        c->times.pop_back();
-    }
-    const int H = static_cast<int>(c->times.size());
-    // retired samples live in the slots behind the oldest kept one for as long as the ring has room
-    while (!c->retired.empty() && (static_cast<int>(c->retired.size()) > kRewindSlack || H + static_cast<int>(c->retired.size()) > c->Hcap))
-        c->retired.pop_back();
-    if (H > c->Hcap) ring_grow(c, H + kRewindSlack, H - 1 + static_cast<int>(c->retired.size()));
+    if (r.grow) ring_grow(c, r.grow_need, r.grow_have);
     c->head = (c->head + 1) % c->Hcap;
-    return H;
+    return r.H;
 }
 
 // ---- profiling --------------------------------------------------------------------------------
@@ -920,8 +886,10 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
                         (c->dk_step.ok() || !((run_rad && !block) || nchunks_ex > 0)) &&
                         !(c->profiling && profiling_tool_attached());  // the library's own timings under a tool: HIP events
     if (direct && c->path != 2) {
-        if (c->have_last_stream && c->last_stream != c->stream) HC_HIP(hipDeviceSynchronize());  // the last step ran on a caller's stream
-        else HC_HIP(hipStreamSynchronize(c->stream));
+        // switching from HIP launches to the direct queue: everything the HIP side still runs must have finished.  A preceding
+        // step on a caller's stream (hc_step_device) has been ordered in front of c->stream by the ev_fin wait above, and what it
+        // left on the context's own stream (ev_bg) runs there too, so draining c->stream covers both.
+        HC_HIP(hipStreamSynchronize(c->stream));
         c->bg_pending = false;
         c->path       = 2;
     } else if (!direct) {
@@ -1595,7 +1563,7 @@ int hc_finalize(hc_ctx* c) {
     c->d_vec_R.alloc(c->Dloc);
     c->d_stage.release();
     // history ring
-    ring_alloc(c, std::max(64, c->S + 2) + kRewindSlack);
+    ring_alloc(c, std::max(64, c->S + 2) + hc::kRewindSlack);
     c->times.clear();
     c->retired.clear();
     c->have_prev = c->have_prev_device = false;
@@ -2327,7 +2295,7 @@ int hc_set_history(hc_ctx* c, int n, const double* times, const double* vel) {
     for (int k = 1; k < n; ++k) require(times[k] < times[k - 1], HC_ERR_INVALID, "history times must be strictly decreasing (newest first)");
     HC_HIP(hipDeviceSynchronize());  // steps may still be running on a caller's stream (hc_step_device)
     c->have_last_stream = c->bg_pending = false;  // everything has run
-    if (n > c->Hcap) ring_alloc(c, n + 16 + kRewindSlack);
+    if (n > c->Hcap) ring_alloc(c, n + 16 + hc::kRewindSlack);
     c->times.assign(times, times + n);
     c->retired.clear();
     // sample k -> slot n-1-k, head = n-1

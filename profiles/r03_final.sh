@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-3 measurement set (run on the GPU box through gpurun): bench lines (C3 default / the driver's fixed command / C4 on one GPU /
+# the single-process multi-context mode / functional multi-rank runs), multi-context latency probes, one C4/8 rank's share, rocprofv3
+# kernel stats and FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs).  Output: gpurun_out/r03final/ -> profiles/collect_r03.py
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03final
+rm -rf $O; mkdir -p $O
+python $R/bench.py > $O/bench_c3_default.json 2> $O/bench_c3_default.err
+python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_c3_driver_cmd.json 2>/dev/null
+python $R/bench.py --lookahead 16 --no-cpu-baseline --no-c4-share > $O/bench_c3_depth16.json 2>/dev/null
+python $R/bench.py --step-dt 0.007 --no-secondary > $O/bench_c3_stepdt0.007.json 2>/dev/null
+python $R/bench.py --scaling strong --bodies 512 --steps 96 --warmup 33 --no-secondary > $O/bench_c4_1gpu.json 2>/dev/null
+python $R/bench.py --gpus 8 --steps 96 --warmup 33 > $O/bench_c4_single_process_8ctx_one_gpu.json 2>/dev/null
+python $R/bench.py --gpus 2 --steps 96 --warmup 33 > $O/bench_c4_single_process_2ctx_one_gpu.json 2>/dev/null
+for n in 2 8; do
+  HC_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2951$n $R/bench.py --gpus $n --steps 40 --warmup 8 > $O/bench_c4_${n}ranks_share_gpu.json 2> $O/bench_c4_${n}ranks_share_gpu.err
+done
+python $R/profiles/multi_probe.py 64 1,2,4,8 600 2>/dev/null > $O/multi_probe.txt
+python $R/profiles/multi_probe.py 512 1,2,8 160 2>/dev/null >> $O/multi_probe.txt
+python $R/profiles/begin_probe.py 512 8 2>/dev/null > $O/begin_probe.txt
+python $R/profiles/begin_probe.py 64 1 2>/dev/null >> $O/begin_probe.txt
+W=8 python $R/profiles/shard_probe.py 2>/dev/null > $O/shard_probe_c4_rank.txt
+W=1 python $R/profiles/shard_probe.py 2>/dev/null > $O/shard_probe_c4_one_gpu.txt
+python $R/profiles/host_path.py > $O/host_path.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/stats_default.log 2>&1
+export W=8
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4rank -- python3 $R/profiles/shard_probe.py > $O/stats_c4rank.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch_c4rank -- python3 $R/profiles/shard_probe.py > $O/fetch_c4rank.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write_c4rank -- python3 $R/profiles/shard_probe.py > $O/write_c4rank.log 2>&1
+B="python3 $R/bench.py --steps 96 --warmup 8 --no-cpu-baseline --no-secondary --profile-stride 1000000"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch32 -- $B --lookahead 32 > $O/fetch32.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write32 -- $B --lookahead 32 > $O/write32.log 2>&1
+python3 $R/profiles/collect_r03.py $O

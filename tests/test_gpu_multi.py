@@ -219,3 +219,38 @@ def test_wide_system_two_level_lookahead_against_oracle(hydro, mode, monkeypatch
     else:
         assert p["block_kernel_launches"] == 0 and p["mini_pass_launches"] == 0
     assert (p["direct_dispatches"] > 0, p["hip_launches"] > 0) == (bool(direct), not direct)
+
+
+def test_soak_eight_contexts_sixteen_queues_and_teardown(hydro):
+    """Hardening of the hand-written queues: eight shard contexts in one process, each with BOTH lanes in use (the step path's queue
+    and the added-mass queue: 16 HSA queues on the one GPU), a few thousand evaluations, then teardown and re-creation several times
+    over (hsa_queue_destroy / hsa_shut_down against the HIP runtime's own reference) -- same forces every cycle, no error, no hang."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    N = 8
+    case = many_body_case(N, S=96, dt_rirf=0.01, n_exc=33, seed=808)
+    motion = PrescribedMotion(N, rest_positions(case), seed=1)
+    rng = np.random.default_rng(0)
+    w, R0 = rng.normal(size=6 * N), rng.normal(size=6 * N)
+    ref = None
+    for cycle in range(4):
+        group = hydro.HydroGroup.from_case(case, 8)
+        group.add_waves_regular(0.5, 0.9)
+        out = []
+        for n in range(900 if cycle == 0 else 250):
+            t = 0.01 * n
+            out.append(group.step(t, *motion.state(t)))
+            if n % 3 == 0:
+                out.append(group.added_mass_mv(R0, w, 0.3))  # LoadIntLoadResidual_Mv between force evaluations, as under HHT
+        for h in group.shards:
+            assert h.direct_dispatch()[0]
+            p = h.profile()
+            assert p["hip_launches"] == 0 and p["direct_dispatches"] >= len(out)
+        out = np.stack(out[:300])
+        if ref is None:
+            ref = out
+        assert np.array_equal(out, ref), f"cycle {cycle}"
+        if cycle % 2 == 0:
+            group.close()      # explicit teardown ...
+        else:
+            del group          # ... or through the destructors

@@ -52,3 +52,10 @@ def test_yaml_reader_under_sanitizers(tmp_path):
                 ["-I", os.path.join(ROOT, "include"), "-Wl,--unresolved-symbols=ignore-all"])
     out = run_clean([exe] + files)
     assert out.count(": ok bodies=") + out.count(": error ") == len(files)
+
+
+@pytest.mark.parametrize("name", ["plan_test", "history_test"])
+def test_planner_and_history_index_under_sanitizers(tmp_path, name):
+    """The host-only headers of the step path (look-ahead planner incl. the two-level form, history bookkeeping incl. rewinds)."""
+    exe = build(str(tmp_path / name), [os.path.join(ROOT, "tests", "cpp", name + ".cpp")], [])
+    assert " 0 failures" in run_clean([exe]) or "0 failures" in run_clean([exe])

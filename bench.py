@@ -15,9 +15,12 @@ states resident in HBM, enqueued ahead -- an upper bound no Chrono loop can use)
 (look-ahead off: K streamed from HBM every step).
 
 N > 1 (default: --scaling strong --bodies 512) -- configuration C4: ONE coupled 512-body array (K = 77.3 GB FP64,
-generated in HBM by hc_synth_fill) row-sharded over the ranks (hydrochrono_amd.parallel.body_shard), each rank's force
-rows all-gathered over RCCL every step and the stream synchronised (every rank holds the full 6N vector before the next
-step starts); value = K / max-over-ranks time.  `--scaling weak` runs independent 64-body farms instead (replicas, no
+generated in HBM by hc_synth_fill) row-sharded over the ranks (hydrochrono_amd.parallel.body_shard).  Every rank holds the
+full 6N force vector ON THE HOST before the next step starts (where a Chrono integrator needs it): each rank runs the
+synchronous hc_step path on its shard and collects all shards' rows straight from the shared-memory result buffers the GPUs
+write (--exchange host, the default: SURVEY 8e "outputs -> host gather"); --exchange rccl all-gathers the rows on the device
+over RCCL instead (hc_step_device + all_gather_into_tensor + stream synchronise); the mode not chosen is reported as a
+secondary.  value = K / max-over-ranks time.  `--scaling weak` runs independent 64-body farms instead (replicas, no
 data-path collective).  `--scaling strong` also runs on one GPU (77 GB fits in 288 GB).
 
 N > 1 in ONE process (`python bench.py --gpus N` without a launcher, or `--single-process` under one): the same coupled array
@@ -75,6 +78,10 @@ def parse():
     ap.add_argument("--steady-steps", type=int, default=256, help="synchronous steps of the steady_state block (median + mean, SURVEY 8d: >= 200)")
     ap.add_argument("--single-process", action="store_true", help="N > 1: all shards in THIS process through hc_step_multi (no launcher needed)")
     ap.add_argument("--no-c4-share", action="store_true", help="skip the c4_rank_share secondary (one C4/8 shard on this GPU)")
+    ap.add_argument("--exchange", choices=["host", "rccl"], default="host",
+                    help="N > 1 under a launcher: how every rank gets all force rows each step.  host (default): hc_step on every rank (direct "
+                         "dispatch, results on the host) and a host gather through shared-memory result buffers (hc_set_result_buffer); "
+                         "rccl: hc_step_device + RCCL all-gather of the rows on the device + stream synchronise.  The other one is run as a secondary")
     return ap.parse_args()
 
 
@@ -357,7 +364,7 @@ def main():
         align = boundary - first
     pre = align + args.warmup
     total = pre + args.steps
-    n_all = total + n_steady + n_pipe + n_plain + 16
+    n_all = total + n_steady + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
     duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
     gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
@@ -386,16 +393,69 @@ def main():
     # ordered against the step kernels there.
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
+    hx = None
+    n_other = 0  # steps of the exchange mode that is NOT `value`, run after the timed region as a secondary
     if exchange is not None:
-        d_states = torch.tensor(states[:total], device="cuda")
-        state_ptrs = [d_states.data_ptr() + k * d_states.stride(0) * 8 for k in range(total)]
-        gathered = torch.zeros(total, 6 * N, dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+        from hydrochrono_amd.host_exchange import HostExchange
+        n_other = 0 if args.no_secondary else 16 + args.steps
+        n_dev = total if args.exchange == "rccl" else n_other           # steps that go through the device path
+        k_dev0 = 0 if args.exchange == "rccl" else total
+        d_states = torch.tensor(states[k_dev0:k_dev0 + n_dev], device="cuda")
+        state_ptrs = {k_dev0 + k: d_states.data_ptr() + k * d_states.stride(0) * 8 for k in range(n_dev)}
+        # host-gather steps land in host memory (where the integrator wants them); the RCCL path gathers on the device
+        gathered = torch.zeros(total + n_other, 6 * N, dtype=torch.float64, device="cpu" if (share_gpu or args.exchange == "host") else "cuda")
+        gathered_np = gathered.numpy() if gathered.device.type == "cpu" else np.zeros((total + n_other, 6 * N))
+        g_dev = torch.zeros(n_dev, 6 * N, dtype=torch.float64, device="cpu" if share_gpu else "cuda")  # rows [k - k_dev0] of the device path
         # this rank's rows as the kernel left them: the step kernel writes them here and the all-gather sends them from here (no
         # staging copy on the stream between the two)
-        own_rows = torch.zeros(total, exchange.max_rows, dtype=torch.float64, device="cuda")
-        own_ptrs = [own_rows.data_ptr() + k * own_rows.stride(0) * 8 for k in range(total)]
-        direct_gather = exchange.even and not share_gpu  # equal shards: the collective writes the step's row of `gathered` itself
+        own_rows = torch.zeros(total + n_other, exchange.max_rows, dtype=torch.float64, device="cuda")
+        own_ptrs = [own_rows.data_ptr() + k * own_rows.stride(0) * 8 for k in range(total + n_other)]
+        own_host = np.zeros((total + n_other, D_local))
+        direct_gather = exchange.even and not share_gpu  # equal shards: the collective writes the step's row of g_dev itself
+        hx = HostExchange(gpu, N, world, rank, tag=f"hc_bench_{os.environ.get('MASTER_PORT', '0')}")
+        dist.barrier()
+        hx.attach()
+        hc_begin = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(("hc_step_begin", capi.load()))
+        hc_end = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)(("hc_step_end", capi.load()))
         torch.cuda.synchronize()
+
+    def run_sync_host(k0, k1):
+        """Coupled array over several ranks, host gather: every rank hands its shard's step to its GPU (hc_step_begin: state through
+        the BAR, direct dispatch), collects the rows of ALL shards from the shared-memory result buffers the GPUs write, completes
+        its own step (hc_step_end).  The next step starts when this rank holds the full 6N vector on the host."""
+        pc = time.perf_counter
+        seq = hx.sequence()
+        for k in range(k0, k1):
+            a = pc()
+            rc = hc_begin(ctx, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3)
+            if rc:
+                gpu._chk(rc)
+            seq += 1
+            hx.gather_into(seq, gathered_np[k].ctypes.data)
+            rc = hc_end(ctx, own_host[k].ctypes.data)
+            per_step[k] = pc() - a
+            if rc:
+                gpu._chk(rc)
+
+    def run_sync_rccl(k0, k1):
+        # the step kernel writes this rank's rows, the RCCL all-gather leaves the full 6N force vector on every rank's GPU (the
+        # device-side form of the one exchange step of the path, SURVEY.md 8e), and the stream is synchronised: the next step
+        # starts only when every rank holds all forces of this one
+        pc = time.perf_counter
+        for k in range(k0, k1):
+            a = pc()
+            gpu.step_device(times[k], state_ptrs[k], own_ptrs[k], stream.cuda_stream)
+            row = g_dev[k - k_dev0]
+            if share_gpu:  # functional mode on one GPU: gloo moves the rows
+                stream.synchronize()
+                row.copy_(exchange.gather(own_rows[k, : exchange.rows].cpu()))
+            elif direct_gather:
+                dist.all_gather_into_tensor(row, own_rows[k], group=exchange.group)
+                stream.synchronize()
+            else:
+                row.copy_(exchange.gather(own_rows[k, : exchange.rows]), non_blocking=True)
+                stream.synchronize()
+            per_step[k] = pc() - a
 
     def run_sync(k0, k1):
         """K synchronous evaluations: state from host memory in, forces in host memory out, one call after the other."""
@@ -407,24 +467,10 @@ def main():
                 per_step[k] = pc() - a
                 if rc:
                     gpu._chk(rc)
+        elif args.exchange == "host":
+            run_sync_host(k0, k1)
         else:
-            # coupled array over several ranks: the step kernel writes this rank's rows, the RCCL all-gather leaves the full 6N
-            # force vector on every rank (the one exchange step of the path), and the stream is synchronised: the
-            # next step starts only when every rank holds all forces of this one
-            pc = time.perf_counter
-            for k in range(k0, k1):
-                a = pc()
-                gpu.step_device(times[k], state_ptrs[k], own_ptrs[k], stream.cuda_stream)
-                if share_gpu:
-                    stream.synchronize()
-                    gathered[k].copy_(exchange.gather(own_rows[k, : exchange.rows].cpu()))
-                elif direct_gather:
-                    dist.all_gather_into_tensor(gathered[k], own_rows[k], group=exchange.group)
-                    stream.synchronize()
-                else:
-                    gathered[k].copy_(exchange.gather(own_rows[k, : exchange.rows]), non_blocking=True)
-                    stream.synchronize()
-                per_step[k] = pc() - a
+            run_sync_rccl(k0, k1)
 
     def prof_diff(p1, p0):
         return {k: (p1[k] - p0[k]) if not k.endswith("_bytes") and not k.endswith("_bytes_once") else p1[k] for k in p1}
@@ -453,14 +499,18 @@ def main():
         elapsed = float(tt.item())
 
     exchange_ok = None
+    if exchange is not None and args.exchange == "rccl":
+        gathered[:total].copy_(g_dev[:total])
     if exchange is not None:
         # the one exchange step of the path, checked after the run: every rank finds its own rows, bit for bit, at its place in
         # the gathered vector of every step, and all ranks hold the same gathered vectors (checksums of the raw bits)
         b0_, b1_ = exchange.shards[rank]
-        mine = gathered[:total, 6 * b0_:6 * b1_].to("cuda")
-        own_ok = bool(torch.equal(mine, own_rows[:total, : exchange.rows]))
+        if args.exchange == "host":
+            own_ok = bool(np.array_equal(gathered_np[:total, 6 * b0_:6 * b1_], own_host[:total]))
+        else:
+            own_ok = bool(torch.equal(gathered[:total, 6 * b0_:6 * b1_].to("cuda"), own_rows[:total, : exchange.rows]))
         dev_ = "cpu" if share_gpu else "cuda"
-        bits = gathered[:total].contiguous().view(torch.int64)
+        bits = gathered[:total].contiguous().view(torch.int64).to(dev_)
         csum = (bits & 0xFFFFFFFF).sum(dim=1) + (bits >> 32).sum(dim=1)  # per-step checksum, exact in int64
         lo, hi = csum.clone().to(dev_), csum.clone().to(dev_)
         flag = torch.tensor([1 if own_ok else 0], dtype=torch.int64, device=dev_)
@@ -522,6 +572,27 @@ def main():
         k_next += 4 + n_plain
     dinfo = dispatch_info([gpu])
     dinfo["aql_dispatches"], dinfo["hip_launches"] = int(prof_all["direct_dispatches"]), int(prof_all["hip_launches"])
+
+    # ---- N > 1 under a launcher: the exchange mode that is not `value`, all ranks, right after the timed region ----
+    other_exchange = None
+    if exchange is not None and n_other > 0:
+        other = "rccl" if args.exchange == "host" else "host"
+        run_o = run_sync_rccl if other == "rccl" else run_sync_host
+        run_o(total, total + 16)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_o = time.perf_counter()
+        run_o(total + 16, total + n_other)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_o = time.perf_counter() - t_o
+        tt = torch.tensor([t_o], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        n_o = n_other - 16
+        other_exchange = {"exchange": other, "evals_per_s": n_o / float(tt.item()), "ms_per_step": float(tt.item()) / n_o * 1e3,
+                          "median_ms_per_step": float(np.median(per_step[total + 16:total + n_other])) * 1e3, "steps": n_o,
+                          "note": ("hc_step_device (HIP launches on the rank's stream) + RCCL all-gather of the rows on the device + stream synchronise"
+                                   if other == "rccl" else "hc_step on every rank + host gather through shared-memory result buffers")}
 
     # ---- N > 1 under a launcher: the single-process C-ABI mode as a secondary, run by rank 0 while the others wait ----
     single_sec = None
@@ -593,10 +664,13 @@ def main():
                             "synchronous steps (forces of step n are on the host before step n+1 is issued)",
                 "bodies": N, "bodies_per_gpu": (N / world if strong else N), "irf_samples": S_RIRF,
                 "wave_components": WAVES["nfrequencies"], "lookahead": args.lookahead,
-                "sharding": ("body-row shards of one coupled array + RCCL all-gather of forces every step" if strong else
+                "sharding": (("body-row shards of one coupled array; every rank collects all rows on the host from shared-memory result buffers "
+                              "(no collective)" if args.exchange == "host" else
+                              "body-row shards of one coupled array + RCCL all-gather of forces every step") if strong else
                              "one independent farm per GPU, no data-path collective") if world > 1 else "single GPU",
             },
-            "dispatch_mode": dinfo["dispatch_mode"] if world == 1 else "HIP launches on the rank's stream (hc_step_device) + RCCL all-gather",
+            "dispatch_mode": dinfo["dispatch_mode"] if (world == 1 or args.exchange == "host") else "HIP launches on the rank's stream (hc_step_device) + RCCL all-gather",
+            "exchange": (args.exchange if world > 1 else None),
             "dispatch_mode_reason": dinfo["dispatch_mode_reason"],
             "aql_dispatches": dinfo["aql_dispatches"], "hip_launches": dinfo["hip_launches"],
             "roofline": {
@@ -625,6 +699,8 @@ def main():
             out["device_pipelined"] = pipelined
         if plain is not None:
             out["plain_per_step_mode"] = plain
+        if other_exchange is not None:
+            out["other_exchange_mode"] = other_exchange
         if single_sec is not None:
             out["single_process_c_abi"] = single_sec
         if world == 1 and not strong and not args.no_secondary and not args.no_c4_share:
@@ -665,6 +741,9 @@ def main():
                 except Exception:
                     pass
         print(json.dumps(out), flush=True)
+    if hx is not None:
+        dist.barrier()
+        hx.close()
     if world > 1:
         dist.destroy_process_group()
 

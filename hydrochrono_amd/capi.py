@@ -78,6 +78,9 @@ SIGNATURES = {
     "hc_step_end": (C.c_int, [C.c_void_p, c_double_p]),
     "hc_step_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "hc_added_mass_mv_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, c_double_p, C.c_double, c_double_p, C.c_int]),
+    "hc_set_result_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "hc_step_sequence": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
+    "hc_wait_result_buffer": (C.c_int, [C.c_void_p, C.c_int, C.c_ulonglong, c_double_p, C.c_double]),
     "hc_step_device": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_get_force_components": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "hc_compute_radiation": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p, c_double_p]),

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1363,6 +1364,7 @@ void hc_destroy(hc_ctx* ctx) {
     delete ctx->dq;  // drains its queue
     ctx->dq = nullptr;
     (void)hipDeviceSynchronize();  // steps may still be running on a caller's stream; the buffers go away below
+    if (ctx->ext_tag_host) (void)hipHostUnregister(ctx->ext_tag_host);
     for (auto& ev : ctx->events) {
         (void)hipEventDestroy(ev.a);
         (void)hipEventDestroy(ev.b);
@@ -1608,7 +1610,7 @@ int hc_finalize(hc_ctx* c) {
     c->d_selftest.alloc(1);
     std::memset(c->h_tag_am.p, 0, c->h_tag_am.n * sizeof(unsigned long long));
     c->seq_am = 0;
-    c->h_tag.alloc(static_cast<size_t>(2) * c->Dloc);
+    c->h_tag.alloc(static_cast<size_t>(4) * c->Dloc);  // two halves of [Dloc][2], used alternately (step sequence parity)
     std::memset(c->h_tag.p, 0, c->h_tag.n * sizeof(unsigned long long));
     c->seq = 0;
     c->last_total.assign(c->Dloc, 0.0);
@@ -1999,6 +2001,13 @@ void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long lo
     }
 }
 
+unsigned long long* result_tags_dev(hc_ctx* c, unsigned long long seq) {
+    return (c->ext_tag_dev ? c->ext_tag_dev : c->h_tag.dp) + (seq & 1) * static_cast<size_t>(2) * c->Dloc;
+}
+const unsigned long long* result_tags_host(hc_ctx* c, unsigned long long seq) {
+    return (c->ext_tag_host ? c->ext_tag_host : c->h_tag.p) + (seq & 1) * static_cast<size_t>(2) * c->Dloc;
+}
+
 // First half of a synchronous step: cache rules of CoordinateFuncForBody (src/hydro_forces.cpp:742-751), the state stored where
 // the kernels read it, the step kernel handed to the GPU.  Leaves c->pending_step = 1 (cache hit, totals in last_total) or 2
 // (results arrive as tagged granules of sequence number c->seq).  defer_tail: see enqueue_step.
@@ -2061,7 +2070,10 @@ void step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const
         }
     }
     const unsigned long long seq = ++c->seq;
-    enqueue_step(c, t, d_state, nullptr, c->stream, StepFlags{}, c->h_tag.dp, seq, defer_tail);
+    // The tagged results of consecutive steps go to alternate halves of the result buffer: a reader in ANOTHER process (a caller's
+    // buffer in shared memory, hc_set_result_buffer) may still be collecting step n while this process has moved on to step n + 1;
+    // it cannot reach step n + 2 before every process has the rows of step n + 1, i.e. has finished with step n.
+    enqueue_step(c, t, d_state, nullptr, c->stream, StepFlags{}, result_tags_dev(c, seq), seq, defer_tail);
     c->pending_step = 2;
     c->pending_t    = t;
 }
@@ -2073,7 +2085,7 @@ void step_end(hc_ctx* c, double* force_out) {
     c->pending_step = 0;
     if (how == 2) {
         if (c->tail.pending) enqueue_tail(c);  // (a caller that deferred the tail and never enqueued it)
-        wait_tagged(c, c->h_tag.p, c->seq, c->stream, c->last_total.data());
+        wait_tagged(c, result_tags_host(c, c->seq), c->seq, c->stream, c->last_total.data());
         if (c->device_errors_possible) {
             quiesce_direct(c);
             check_device_flag(c);
@@ -2125,6 +2137,67 @@ int hc_step_end(hc_ctx* c, double* force_out) {
         throw;
     }
     HC_API_END(c)
+}
+
+// The result buffer of hc_step in memory the caller provides -- e.g. a POSIX shared-memory segment that the OTHER processes of a
+// one-process-per-GPU host map too: every process then collects the force rows of all shards straight from the buffers the GPUs
+// write (hc_wait_result_buffer), a host gather without a collective or a copy ("outputs -> host gather").
+int hc_set_result_buffer(hc_ctx* c, void* host_buffer, size_t bytes) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(c->pending_step == 0, HC_ERR_INVALID, "a step is pending");
+    HC_HIP(hipDeviceSynchronize());
+    if (c->ext_tag_host) {
+        (void)hipHostUnregister(c->ext_tag_host);
+        c->ext_tag_host = c->ext_tag_dev = nullptr;
+    }
+    if (host_buffer) {
+        const size_t need = static_cast<size_t>(4) * c->Dloc * sizeof(unsigned long long);
+        require(bytes >= need, HC_ERR_INVALID, "result buffer too small: 2 x 16 bytes per owned row");
+        require((reinterpret_cast<uintptr_t>(host_buffer) & 15) == 0, HC_ERR_INVALID, "result buffer must be 16-byte aligned");
+        HC_HIP(hipHostRegister(host_buffer, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+        void* dp = nullptr;
+        const hipError_t e = hipHostGetDevicePointer(&dp, host_buffer, 0);
+        if (e != hipSuccess) {
+            (void)hipHostUnregister(host_buffer);
+            throw Error(HC_ERR_DEVICE, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+        }
+        std::memset(host_buffer, 0, need);
+        c->ext_tag_host = static_cast<unsigned long long*>(host_buffer);
+        c->ext_tag_dev  = static_cast<unsigned long long*>(dp);
+    }
+    HC_API_END(c)
+}
+
+int hc_step_sequence(const hc_ctx* c, unsigned long long* seq) {
+    if (!c || !seq) return HC_ERR_INVALID;
+    *seq = c->seq;
+    return HC_OK;
+}
+
+// Host-only: waits until the `rows` tagged results of step `seq` have arrived in a result buffer (this process's or another's)
+// and copies the values out.  No context, no HIP call.
+int hc_wait_result_buffer(const void* host_buffer, int rows, unsigned long long seq, double* out, double timeout_seconds) {
+    if (!host_buffer || rows <= 0 || !out) return HC_ERR_INVALID;
+    const volatile unsigned long long* g = static_cast<const unsigned long long*>(host_buffer) + (seq & 1) * static_cast<size_t>(2) * rows;
+    unsigned long long spins = 0;
+    std::chrono::steady_clock::time_point t0{};
+    const double limit = timeout_seconds > 0.0 ? timeout_seconds : step_timeout_seconds();
+    for (int r = rows - 1; r >= 0; --r) {
+        while (g[2 * r + 1] != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFF) == 0) {
+                const auto now = std::chrono::steady_clock::now();
+                if (spins == 0x10000) t0 = now;
+                if (std::chrono::duration<double>(now - t0).count() > limit) return HC_ERR_DEVICE;
+            }
+        }
+    }
+    for (int r = 0; r < rows; ++r) {
+        const unsigned long long bits = g[2 * r];
+        std::memcpy(out + r, &bits, sizeof(double));
+    }
+    return HC_OK;
 }
 
 // One evaluation of a body-row-sharded system held by G contexts of ONE host process (the drop-in variant: the host

@@ -234,8 +234,9 @@ struct hc_ctx {
     hc::PinnedBuffer<unsigned long long> h_tag_selftest;   // [2] its tagged result
     hc::DeviceBuffer<double> d_selftest;                   // [1]
     unsigned long long seq_am = 0;
-    hc::PinnedBuffer<unsigned long long> h_tag;  // [Dloc][2] {total, sequence number} granules written by finalize_kernel
+    hc::PinnedBuffer<unsigned long long> h_tag;  // 2 x [Dloc][2] {total, sequence number} granules written by finalize_kernel (halves by sequence parity)
     unsigned long long seq = 0;
+    unsigned long long *ext_tag_host = nullptr, *ext_tag_dev = nullptr;  // the caller's result buffer (hc_set_result_buffer), else h_tag
     std::vector<double> last_total;               // totals of the last evaluated step (duplicate-time cache of hc_step)
     int zero_copy_max_bodies = 64;                // hc_step: kernels read the state from mapped pinned memory up to this size
     hc::PinnedBuffer<int> h_err;

@@ -183,6 +183,16 @@ int hc_step_end(hc_ctx* ctx, double* force_out);
  * message, and no context is left with a step pending. */
 int hc_step_multi(hc_ctx* const* ctxs, int n_ctx, double t, const double* pos, const double* rpy, const double* linvel,
                   const double* angvel, double* force_out);
+/* One process per GPU (an MPI-style host, or this repo's benchmark under torch.distributed.run): the host gather without a collective.
+ * hc_set_result_buffer makes the step kernel deliver this context's tagged results -- 16-byte {value, step sequence number} granules,
+ * 2 x D_local of them, the two halves used by consecutive steps in turn -- into memory the caller provides, e.g. a POSIX
+ * shared-memory segment every process of the node maps (the library registers it with the GPU; NULL returns to the internal buffer).
+ * After hc_step_begin each process collects every shard's rows with hc_wait_result_buffer (host-only: it spins on the granules of the
+ * given sequence number -- hc_step_sequence of the own context; contexts driven in lockstep count alike -- and copies the values
+ * out; HC_ERR_DEVICE after timeout_seconds, <= 0: HC_STEP_TIMEOUT_S / 20 s), then completes its own step with hc_step_end. */
+int hc_set_result_buffer(hc_ctx* ctx, void* host_buffer, size_t bytes);
+int hc_step_sequence(const hc_ctx* ctx, unsigned long long* seq);
+int hc_wait_result_buffer(const void* host_buffer, int rows, unsigned long long seq, double* values_out, double timeout_seconds);
 /* Same evaluation with the body state already in HBM and the result left in HBM:
  *   d_state     device pointer, 12N doubles = pos[3N] | rpy[3N] | linvel[3N] | angvel[3N]
  *   d_force_out device pointer, D_local doubles

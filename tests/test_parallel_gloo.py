@@ -158,3 +158,76 @@ def test_device_path_all_gather_over_rccl_one_rank():
     ret = mgr.dict()
     mp.spawn(_rccl_worker, args=(1, _free_port(), 3, 80, ret), nprocs=1, join=True)
     assert dict(ret) == {0: (True, "nccl", 0.0)}
+
+
+# ------------------------------------------------------------------------------------------------
+# host gather through shared-memory result buffers (hc_set_result_buffer / hc_wait_result_buffer): two processes, each with a
+# row-sharded context on the one GPU of the box; every process collects both shards' rows straight from the buffers the step
+# kernels write -- no collective on the data path (gloo only for the barrier and the final verdict)
+# ------------------------------------------------------------------------------------------------
+def _shm_worker(rank, world, port, N, steps, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        if here not in sys.path:
+            sys.path.insert(0, here)
+        from cases import load_into_oracle
+        from hydrochrono_amd import capi
+        from hydrochrono_amd.host_exchange import HostExchange
+        from hydrochrono_amd.hydro import HydroForces
+        from hydrochrono_amd.mock_chrono import PrescribedMotion
+        from hydrochrono_amd.synthetic import many_body_case, rest_positions
+        case = many_body_case(N, S=96, dt_rirf=0.01, n_exc=65, dt_exc=0.02, seed=4300 + N)
+        kw = dict(simulation_dt=0.01, simulation_duration=4.0, ramp_duration=0.5, wave_height=2.0, wave_period=6.0,
+                  frequency_min=0.05, frequency_max=0.6, nfrequencies=48, peak_enhancement_factor=3.3)
+        b0, b1 = body_shard(N, world, rank)
+        mine = HydroForces.from_case(case, device=0, body_range=(b0, b1))
+        mine.add_waves_irregular(**kw)
+        ex = HostExchange(mine, N, world, rank, tag=f"hc_test_{port}")
+        dist.barrier()
+        ex.attach()
+        motion = PrescribedMotion(N, rest_positions(case), seed=5)
+        full = orc = None
+        if rank == 0:
+            full = HydroForces.from_case(case, device=0)
+            full.add_waves_irregular(**kw)
+            orc = load_into_oracle(case)
+            orc.add_waves_irregular(**kw)
+        lib = capi.load()
+        dp = lambda x: x.ctypes.data_as(capi.c_double_p)  # noqa: E731
+        own = np.empty(6 * (b1 - b0))
+        ok, worst = True, 0.0
+        for n in range(steps):
+            t = 0.01 * n
+            st = [np.ascontiguousarray(x, dtype=np.float64).reshape(-1) for x in motion.state(t)]
+            ok &= lib.hc_step_begin(mine.ctx, C.c_double(t), *[dp(x) for x in st]) == 0
+            gathered = ex.gather(ex.sequence())      # both shards' rows, read where the GPUs wrote them
+            ok &= lib.hc_step_end(mine.ctx, dp(own)) == 0
+            ok &= bool(np.array_equal(gathered[6 * b0:6 * b1], own))
+            if rank == 0:
+                ok &= bool(np.array_equal(gathered, full.step(t, *st)))
+                fo = orc.step(t, *st)
+                worst = max(worst, float(np.max(np.abs(gathered - fo)) / np.max(np.abs(fo))))
+            if n % 16 == 3 and rank == 1:
+                import time
+                time.sleep(0.002)  # a slow rank: the others are a step ahead at most (the buffer's two halves)
+        dist.barrier()
+        ex.close()
+        ret[rank] = (bool(ok), worst)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [6, 5])  # even and uneven shards
+def test_host_gather_through_shared_memory_two_ranks_one_gpu(N):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_shm_worker, args=(world, _free_port(), N, 150, ret), nprocs=world, join=True)
+    res = dict(ret)
+    assert res[0][0] and res[1][0]
+    assert res[0][1] <= 1e-10

@@ -221,14 +221,20 @@ int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
  * precomputes, for the next 32 (or 16) predicted step times, what the history known so far contributes to the radiation sum,
  * so K leaves HBM once per block; a step inside a block is ONE kernel launch that adds its own newest-sample part, and what
  * later steps of the block need from it is enqueued behind it (off the caller's critical path).  A step whose time deviates
- * from the prediction (> 1e-9 of the step size) silently falls back to the plain per-step evaluation, so results never depend
- * on the prediction being right.  steps = 0 disables it (every step streams K), 1..16 selects blocks of 16, more blocks of 32. */
+ * from the prediction (> max(1e-9 of the step size, 64 ulp)) falls back to the plain per-step evaluation: a missed prediction
+ * costs speed, never accuracy.  A step whose time is accepted is evaluated on the PREDICTED time grid (t0 + m*dt), so its
+ * interpolation weights differ from those of the caller's t by at most that tolerance / dt relative (1e-15 .. 1e-12 observed;
+ * contract 1e-6).  Wide systems (6N >= 1024) use a two-level form: sub-blocks of 8 steps with a short pass over the head of K
+ * after each.  steps = 0 disables it (every step streams K), 1..16 selects blocks of 16, more blocks of 32. */
 int hc_set_lookahead(hc_ctx* ctx, int steps);
 /* How hc_step hands its kernels to the GPU.  1: as AQL packets written straight into an HSA queue of the library's own (kernel
  * arguments stored through the PCIe BAR) -- the default when the stand-alone code object hc_kernels.co lies next to the library,
- * the device's memory is host-addressable and the system is not wide (D < 1536); it saves the 2.4-3.3 us a hipLaunchKernelGGL call
- * costs the host on the critical path of every step (all kernels of hc_step and hc_added_mass_mv go this way).  0: through HIP launches on the context's stream (HC_DIRECT=0 forces this);
- * hc_dispatch_mode_reason then says why.  The kernels and the results are the same either way.  hc_step_device always uses HIP,
+ * the device's memory is host-addressable and the start-up self-tests pass (a dispatch completes; memory and argument slots the
+ * host re-writes are re-read, not served stale); it saves the 2.4-3.3 us a hipLaunchKernelGGL call costs the host on the critical
+ * path of every step (all kernels of hc_step / hc_step_begin / hc_step_multi and hc_added_mass_mv go this way, for systems of
+ * every size).  0: through HIP launches on the context's stream (HC_DIRECT=0 forces this); hc_dispatch_mode_reason then says why.
+ * A dispatch that never completes, or a queue the runtime reports broken, ends the wait after HC_STEP_TIMEOUT_S (default 20 s)
+ * with HC_ERR_DEVICE; the context then fails every later step the same way.  The kernels and the results are the same either way.  hc_step_device always uses HIP,
  * and so does hc_step while hc_enable_profiling is on under a tool that intercepts HSA queues (rocprofv3): the tool sees direct
  * dispatches too, but the completion signals the library's own timings rest on are then the tool's. */
 int hc_direct_dispatch_active(const hc_ctx* ctx);

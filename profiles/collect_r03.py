@@ -48,7 +48,7 @@ for sub, name in (("stats_default", "c3_driver_cmd_kernel_stats.csv"), ("stats_c
 for name in sorted(os.listdir(SRC)):
     p = os.path.join(SRC, name)
     if os.path.isfile(p) and os.path.getsize(p) > 0 and (name.endswith(".txt") or (name.endswith(".json") and name.startswith(("bench_", "host_path")))):
-        if name.endswith(".json"):
+        if name.endswith(".json") and name.startswith("bench_"):
             lines = [ln for ln in open(p) if ln.startswith("{")]
             if not lines:
                 continue

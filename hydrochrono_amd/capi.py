@@ -130,6 +130,8 @@ SIGNATURES.update({
     "hc_yaml_period_values": (C.c_int, [C.c_void_p, c_double_p, C.c_int]),
     "hc_create_from_hydro_yaml": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                                             C.POINTER(C.c_void_p), c_int_p, c_int_p, C.c_char_p, C.c_size_t]),
+    "hc_create_from_hydro_yaml_sharded": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_double, C.c_double, C.c_double, c_int_p, C.c_int,
+                                                    C.POINTER(C.c_void_p), c_int_p, c_int_p, C.c_char_p, C.c_size_t]),
 })
 
 _lib = None

@@ -405,11 +405,15 @@ int hc_yaml_period_values(const hc_yaml* c, double* out, int cap) {
     return n;
 }
 
-int hc_create_from_hydro_yaml(const hc_yaml* cfg, const char* const* names, int n_names, double timestep, double sim_duration,
-                              double ramp_duration, int device_id, hc_ctx** out, int* matched_index, int* n_matched, char* err,
-                              size_t errlen) {
-    if (!cfg || !out || (n_names > 0 && !names)) return HC_ERR_INVALID;
-    *out = nullptr;
+// one context of the system: the rows of bodies [b0, b1) of the N matched bodies on `device_id`
+static int create_one_from_yaml(const hc_yaml* cfg, int N, int b0, int b1, double timestep, double sim_duration, double ramp_duration,
+                                int device_id, hc_ctx** out, char* err, size_t errlen);
+
+int hc_create_from_hydro_yaml_sharded(const hc_yaml* cfg, const char* const* names, int n_names, double timestep, double sim_duration,
+                                      double ramp_duration, const int* device_ids, int n_shards, hc_ctx** out_ctxs, int* matched_index,
+                                      int* n_matched, char* err, size_t errlen) {
+    if (!cfg || !out_ctxs || (n_names > 0 && !names) || n_shards <= 0 || !device_ids) return HC_ERR_INVALID;
+    for (int g = 0; g < n_shards; ++g) out_ctxs[g] = nullptr;
     // MatchBodiesByName (src/setup_hydro_from_yaml.cpp:84-122): YAML order, first h5 file for everybody
     std::vector<int> match;
     for (const Body& hb : cfg->bodies)
@@ -425,10 +429,40 @@ int hc_create_from_hydro_yaml(const hc_yaml* cfg, const char* const* names, int 
         copy_err("No hydrodynamic bodies found in Chrono system", err, errlen);
         return HC_ERR_RUNTIME;
     }
-    const std::string h5 = cfg->bodies.front().h5_file;
     const int N = static_cast<int>(match.size());
+    if (n_shards > N) {
+        copy_err("more shards than hydrodynamic bodies", err, errlen);
+        return HC_ERR_INVALID;
+    }
+    const int base = N / n_shards, extra = N % n_shards;  // contiguous balanced split, like TestHydro(bodies, h5, waves, device_ids)
+    for (int g = 0; g < n_shards; ++g) {
+        const int b0 = g * base + std::min(g, extra), b1 = b0 + base + (g < extra ? 1 : 0);
+        const int rc = create_one_from_yaml(cfg, N, b0, b1, timestep, sim_duration, ramp_duration, device_ids[g], &out_ctxs[g], err, errlen);
+        if (rc != HC_OK) {
+            for (int k = 0; k < g; ++k) {
+                hc_destroy(out_ctxs[k]);
+                out_ctxs[k] = nullptr;
+            }
+            return rc;
+        }
+    }
+    return HC_OK;
+}
+
+int hc_create_from_hydro_yaml(const hc_yaml* cfg, const char* const* names, int n_names, double timestep, double sim_duration,
+                              double ramp_duration, int device_id, hc_ctx** out, int* matched_index, int* n_matched, char* err,
+                              size_t errlen) {
+    if (!out) return HC_ERR_INVALID;
+    return hc_create_from_hydro_yaml_sharded(cfg, names, n_names, timestep, sim_duration, ramp_duration, &device_id, 1, out, matched_index,
+                                             n_matched, err, errlen);
+}
+
+static int create_one_from_yaml(const hc_yaml* cfg, int N, int b0, int b1, double timestep, double sim_duration, double ramp_duration,
+                                int device_id, hc_ctx** out, char* err, size_t errlen) {
+    *out = nullptr;
+    const std::string h5 = cfg->bodies.front().h5_file;
     hc_ctx* ctx = nullptr;
-    int rc = hc_create(N, device_id, &ctx);
+    int rc = hc_create_sharded(N, b0, b1, device_id, &ctx);
     if (rc != HC_OK) {
         copy_err(hc_last_error(nullptr), err, errlen);
         return rc;

@@ -375,7 +375,7 @@ class TestHydro {
 // (YAML order), the first body's h5 file is read, waves and convolution options come from the YAML.
 inline std::unique_ptr<TestHydro> SetupHydroFromYAML(const std::string& hydro_yaml_path,
                                                      const std::vector<std::shared_ptr<HydroBody>>& bodies, double timestep,
-                                                     double sim_duration, double ramp_duration, int device_id = 0) {
+                                                     double sim_duration, double ramp_duration, const std::vector<int>& device_ids = {0}) {
     char err[1024] = {0};
     hc_yaml* cfg   = nullptr;
     if (hc_yaml_read(hydro_yaml_path.c_str(), &cfg, err, sizeof err) != HC_OK) throw std::runtime_error(err);
@@ -385,14 +385,15 @@ inline std::unique_ptr<TestHydro> SetupHydroFromYAML(const std::string& hydro_ya
     for (auto& n : names) cnames.push_back(n.c_str());
     std::vector<int> matched(bodies.size() + 1);
     int n_matched = 0;
-    hc_ctx* ctx   = nullptr;
-    const int rc  = hc_create_from_hydro_yaml(cfg, cnames.data(), static_cast<int>(cnames.size()), timestep, sim_duration, ramp_duration,
-                                              device_id, &ctx, matched.data(), &n_matched, err, sizeof err);
+    std::vector<hc_ctx*> ctxs(device_ids.size(), nullptr);  // one row shard per listed device (multi-GPU inside this process)
+    const int rc  = hc_create_from_hydro_yaml_sharded(cfg, cnames.data(), static_cast<int>(cnames.size()), timestep, sim_duration, ramp_duration,
+                                                      device_ids.data(), static_cast<int>(device_ids.size()), ctxs.data(), matched.data(),
+                                                      &n_matched, err, sizeof err);
     hc_yaml_free(cfg);
     if (rc != HC_OK) throw std::runtime_error(err);
     std::vector<std::shared_ptr<HydroBody>> hydro_bodies;
     for (int k = 0; k < n_matched; ++k) hydro_bodies.push_back(bodies[matched[k]]);
-    return std::make_unique<TestHydro>(std::move(hydro_bodies), ctx);
+    return std::make_unique<TestHydro>(std::move(hydro_bodies), std::move(ctxs));
 }
 
 }  // namespace hydroc_amd

@@ -48,6 +48,13 @@ int hc_create_from_hydro_yaml(const hc_yaml* cfg, const char* const* system_body
                               double sim_duration, double ramp_duration, int device_id, hc_ctx** out, int* matched_index,
                               int* n_matched, char* err, size_t errlen);
 
+/* The same setup for a system row-sharded over n_shards contexts of this process (device_ids[g]: the device of shard g; contiguous
+ * balanced split of the matched bodies, as TestHydro(bodies, h5, waves, device_ids) makes it): out_ctxs[0..n_shards) are then
+ * evaluated with hc_step_multi.  On failure no context is left behind. */
+int hc_create_from_hydro_yaml_sharded(const hc_yaml* cfg, const char* const* system_body_names, int n_names, double timestep,
+                                      double sim_duration, double ramp_duration, const int* device_ids, int n_shards, hc_ctx** out_ctxs,
+                                      int* matched_index, int* n_matched, char* err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -254,3 +254,54 @@ def test_soak_eight_contexts_sixteen_queues_and_teardown(hydro):
             group.close()      # explicit teardown ...
         else:
             del group          # ... or through the destructors
+
+
+def test_hydro_yaml_setup_with_shards(hydro, tmp_path):
+    """ReadHydroYAML + SetupHydroFromYAML (src/setup_hydro_from_yaml.cpp:126-193) for a system row-sharded over contexts of this
+    process (hc_create_from_hydro_yaml_sharded): four bodies from a BEMIO file, irregular waves and TaperedDirect from the YAML,
+    three shards -- bitwise the single-context setup of the same file."""
+    import ctypes as C
+    from hydrochrono_amd import build as hb, capi
+    if not os.path.exists(hb.BEMIO_LIB):
+        pytest.skip("libhdf5 not available: BEMIO reader not built")
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    case = four_body_case()
+    y = tmp_path / "array.hydro.yaml"
+    y.write_text("hydrodynamics:\n  bodies:\n" + "".join(f"    - name: body{b}\n      h5_file: {os.path.join(GOLDEN_DIR, 'four_body.h5')}\n" for b in (1, 2, 3, 4)) +
+                 "  waves:\n    type: irregular\n    height: 1.5\n    period: 5.0\n    seed: 3\n"
+                 "  convolution:\n    mode: TaperedDirect\n    taper:\n      start_percent: 0.6\n")
+    names = ["ground", "body1", "body2", "body3", "body4"]
+    single, matched = hydro.HydroForces.from_hydro_yaml(y, names, 0.005, 6.0, ramp_duration=0.3)
+    assert matched == [1, 2, 3, 4]
+    lib = capi.load()
+    cfg, err = C.c_void_p(), C.create_string_buffer(2048)
+    assert lib.hc_yaml_read(str(y).encode(), C.byref(cfg), err, 2048) == 0, err.value
+    cn = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    devs = (C.c_int * 3)(0, 0, 0)
+    ctxs = (C.c_void_p * 3)()
+    mi, nm = (C.c_int * len(names))(), C.c_int()
+    rc = lib.hc_create_from_hydro_yaml_sharded(cfg, cn, len(names), 0.005, 6.0, 0.3, devs, 3, ctxs, mi, C.byref(nm), err, 2048)
+    lib.hc_yaml_free(cfg)
+    assert rc == 0, err.value
+    assert nm.value == 4 and list(mi[:4]) == [1, 2, 3, 4]
+    shards = []
+    for g in range(3):
+        h = hydro.HydroForces.__new__(hydro.HydroForces)
+        h.lib, h.ctx, h.N, h.D = lib, C.c_void_p(ctxs[g]), 4, 24
+        b0, b1 = C.c_int(), C.c_int()
+        assert lib.hc_get_shard(h.ctx, C.byref(b0), C.byref(b1)) == 0
+        h.b0, h.b1, h.n_local, h.D_local = b0.value, b1.value, b1.value - b0.value, 6 * (b1.value - b0.value)
+        shards.append(h)
+    assert [(h.b0, h.b1) for h in shards] == [(0, 2), (2, 3), (3, 4)]
+    group = hydro.HydroGroup(shards)
+    motion = PrescribedMotion(4, np.stack([b["cg"] for b in case["bodies"]]), seed=3)
+    for n in range(120):
+        st = motion.state(0.005 * n)
+        assert np.array_equal(group.step(0.005 * n, *st), single.step(0.005 * n, *st)), f"step {n}"
+    # more shards than bodies / a missing body list are refused and leave nothing behind
+    cfg = C.c_void_p()
+    assert lib.hc_yaml_read(str(y).encode(), C.byref(cfg), err, 2048) == 0
+    devs5, ctxs5 = (C.c_int * 5)(0, 0, 0, 0, 0), (C.c_void_p * 5)()
+    assert lib.hc_create_from_hydro_yaml_sharded(cfg, cn, len(names), 0.005, 6.0, 0.3, devs5, 5, ctxs5, mi, C.byref(nm), err, 2048) == capi.HC_ERR_INVALID
+    assert all(c is None for c in ctxs5)
+    lib.hc_yaml_free(cfg)

@@ -606,6 +606,7 @@ def main():
                                       "dispatched before any wait, host-side gather -- no collective, no torch on the path")
             except Exception as e:  # a secondary must not cost the run its line
                 single_sec = {"error": str(e)}
+            torch.cuda.set_device(local_rank)  # the shard contexts made other devices current
         dist.barrier()
 
     if rank == 0:

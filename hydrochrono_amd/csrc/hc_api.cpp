@@ -370,8 +370,9 @@ void choose_exc_config(hc_ctx* c) {
 void alloc_partials(hc_ctx* c) {
     const size_t n = static_cast<size_t>(c->nchunks_rad + c->nchunks_ex) * c->Dpad;
     if (c->d_partials.n < n) c->d_partials.alloc(n);
-    // (the short passes of the two-level form use the same buffer: at most kLookahead + kSubBlock + 2 IRF samples in chunks of half a sample)
-    const size_t nb = static_cast<size_t>(std::max(c->nchunks_block + c->nchunks_ex_block, 2 * (hc::kLookahead + hc::kSubBlock + 4))) * hc::kLookahead * c->Dpad;
+    // (the short passes of the two-level form use the same buffer: IRF samples s < kScatterSamples -- the planner refuses blocks whose
+    // in-block brackets reach further -- in chunks of at least half a sample)
+    const size_t nb = static_cast<size_t>(std::max(c->nchunks_block + c->nchunks_ex_block, 2 * hc::kScatterSamples + 2)) * hc::kLookahead * c->Dpad;
     if (c->d_partials_block.n < nb) c->d_partials_block.alloc(nb);
     if (c->d_P.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_P.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
     if (c->d_E.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_E.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);

@@ -305,3 +305,30 @@ def test_hydro_yaml_setup_with_shards(hydro, tmp_path):
     assert lib.hc_create_from_hydro_yaml_sharded(cfg, cn, len(names), 0.005, 6.0, 0.3, devs5, 5, ctxs5, mi, C.byref(nm), err, 2048) == capi.HC_ERR_INVALID
     assert all(c is None for c in ctxs5)
     lib.hc_yaml_free(cfg)
+
+
+def test_wide_system_short_passes_reach_far_when_the_step_exceeds_the_irf_spacing(hydro):
+    """Two-level form with dt = 1.4 x dt_rirf: the short pass after the first sub-block covers ~46 IRF samples in chunks of half a
+    sample (the largest partials footprint of the scheme); against the oracle and against the plain evaluation."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    N = 176
+    case = many_body_case(N, S=100, dt_rirf=0.01, n_exc=9, dt_exc=0.05, seed=77)
+    a, b = hydro.HydroForces.from_case(case), hydro.HydroForces.from_case(case)
+    orc = load_into_oracle(case)
+    for h in (a, b, orc):
+        h.add_waves_none()
+    b.set_lookahead(0)
+    a.enable_profiling(1)
+    motion = PrescribedMotion(N, rest_positions(case), seed=2)
+    for n in range(80):
+        t = 0.014 * n
+        st = motion.state(t)
+        fa = a.step(t, *st)
+        assert relerr(fa, b.step(t, *st)) <= 1e-11, f"step {n}: two-level vs plain"
+        if n % 4 == 0 or n > 70:
+            assert relerr(fa, orc.step(t, *st)) <= TIGHT_TOL, f"step {n}"
+        else:
+            orc.step(t, *st)
+    p = a.profile()
+    assert p["block_kernel_launches"] >= 2 and p["mini_pass_launches"] >= 4, p

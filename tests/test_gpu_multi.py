@@ -332,3 +332,41 @@ def test_wide_system_short_passes_reach_far_when_the_step_exceeds_the_irf_spacin
             orc.step(t, *st)
     p = a.profile()
     assert p["block_kernel_launches"] >= 2 and p["mini_pass_launches"] >= 4, p
+
+
+def test_c4_size_step_multi_eight_contexts_one_gpu(hydro):
+    """Configuration C4 at FULL size (512 bodies, D = 3072, K = 77 GB generated in HBM) as eight row-shard contexts of this process,
+    all on the one GPU, evaluated by hc_step_multi -- against ONE context holding the whole array: bitwise, through a pass, the short
+    passes of the two-level form and an off-grid step."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.parallel_split import body_shard
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 200e9:
+        pytest.skip("needs 2 x 77 GB of HBM")
+    N, S = 512, 1024
+
+    def make(b0, b1):
+        h = hydro.HydroForces(N, device=0, body_range=(b0, b1))
+        h.synth_fill(20251031, S, 0.01, 0, 0.0)
+        h.finalize()
+        h.add_waves_none()
+        return h
+
+    full = make(0, N)
+    group = hydro.HydroGroup([make(*body_shard(N, 8, g)) for g in range(8)])
+    motion = PrescribedMotion(N, np.zeros((N, 3)), seed=3)
+    t_hist = 5.0 - 0.01 * np.arange(1, S + 6)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    full.set_history(t_hist, v_hist)
+    group.set_history(t_hist, v_hist)
+    t = 5.0
+    for n in range(45):
+        st = motion.state(t)
+        assert np.array_equal(group.step(t, *st), full.step(t, *st)), f"step {n}"
+        t += 0.01 if n != 20 else 0.0123
+    for h in group.shards + [full]:
+        assert h.direct_dispatch()[0]
+    p = group.shards[3].profile()
+    assert p["hip_launches"] == 0 and p["direct_dispatches"] > 90
+    group.close()
+    full.close()

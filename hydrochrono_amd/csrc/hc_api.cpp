@@ -305,6 +305,18 @@ void setup_panel_geometry(hc_ctx* c) {
     const int limit       = env_int("HC_BLOCK_MT", 6);
     c->mt_block_design    = pick(tiles_full, limit);
     c->mt_block           = pick(c->ntiles, c->mt_block_design);
+    // Short passes of the two-level form stream a few tens of IRF samples only: with the pass's tall workgroups (6 tiles x half a
+    // sample = 1.2 MB each at D = 3072) there are fewer workgroups than CUs and each streams for ~50 us; fewer tiles per workgroup
+    // give a multiple of the workgroups, each done sooner (the B-operand work they repeat is small here).
+    // Tiles per workgroup = the largest that still leaves about two workgroups per CU (a short pass has roughly 48 chunks of half a
+    // sample): 2 for a C4/8 shard (24 tiles: 76 -> 68 us per short pass), 6 for C4 on one GPU (192 tiles: 377 us; 422 with 2).
+    {
+        const int forced = env_int("HC_MINI_MT", 0);
+        int m_pick = 1;
+        for (int m : {1, 2, 4, 6})
+            if (m <= c->mt_block && c->ntiles % m == 0 && 48LL * (c->ntiles / m) >= 2LL * c->num_cus) m_pick = m;
+        c->mt_mini = forced > 0 ? pick(c->ntiles, std::min(c->mt_block, forced)) : m_pick;
+    }
 }
 
 hc::Panel rad_panel(const hc_ctx* c) {
@@ -732,7 +744,7 @@ void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct) {
     b.Dpad         = c->Dpad;
     b.error_flag   = c->d_err.p;
     b.item_counter = c->d_err.p + 1;
-    b.ngroups      = c->ntiles / c->mt_block;
+    b.ngroups      = c->ntiles / c->mt_mini;
     b.mini_kw      = mp.kw;
     b.mini_steps   = mp.n_steps;
     for (int k = 0; k <= mp.kw + 1; ++k) b.mini_time[k] = mp.time[k];
@@ -740,16 +752,16 @@ void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct) {
     hc::ReduceArgs r{c->d_partials_block.p, b.nchunks, 0, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter, 1, i0, mp.n_steps, 0};
     if (direct) {
         hc::BlockArgs b2;
-        const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_block, &b2);
+        const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_mini, &b2);
         if (l.nblocks <= 0) return;
-        c->dq->dispatch(L == 32 ? c->dk_block32 : c->dk_block16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
+        c->dq->dispatch(L == 32 ? c->dk_mini32 : c->dk_mini16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
                         direct_tag(c, hc::kEvMiniPass));
         c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r);
         c->prof.direct_dispatches += 2;
         return;
     }
     hc::EventPair* ev = ev_begin(c, hc::kEvMiniPass, stream);
-    hc::launch_conv_block(b, c->mt_block, stream);
+    hc::launch_conv_block(b, c->mt_mini, stream);
     ev_end(ev, stream);
     hc::launch_reduce_block(r, stream);
     c->prof.hip_launches += 2;
@@ -1248,6 +1260,14 @@ void setup_direct(hc_ctx* c) {
         char frag[96];
         std::snprintf(frag, sizeof frag, "conv_block_kernelILi%dELi%dELi%dELi%dEEEv", l.MT, l.R, l.NB, l.WPS);
         (depth == 16 ? c->dk_block16 : c->dk_block32) = q->find(frag);
+        const hc::BlockLaunch lm = hc::block_launch_config(a, c->mt_mini, &b);  // the short passes' variant (fewer tiles per workgroup)
+        std::snprintf(frag, sizeof frag, "conv_block_kernelILi%dELi%dELi%dELi%dEEEv", lm.MT, lm.R, lm.NB, lm.WPS);
+        (depth == 16 ? c->dk_mini16 : c->dk_mini32) = q->find(frag);
+    }
+    if (!c->dk_mini16.ok() || !c->dk_mini32.ok() || c->dk_mini16.priv || c->dk_mini32.priv || c->dk_mini16.kernarg != sizeof(hc::BlockArgs) ||
+        c->dk_mini32.kernarg != sizeof(hc::BlockArgs)) {
+        c->direct_why = "the short-pass variant of the pass kernel is missing from hc_kernels.co";
+        return;
     }
     if (!c->dk_finalize.ok() || !c->dk_scatter.ok() || !c->dk_reduce.ok() || !c->dk_block16.ok() || !c->dk_block32.ok() || !c->dk_near.ok()) {
         c->direct_why = "a kernel of this configuration is missing from hc_kernels.co";

@@ -278,7 +278,8 @@ typedef struct hc_profile_stats {
     double block_kernel_bytes;  /* algorithmic bytes of the last pass: sum over its steps of the share of K (and of the
                                    velocity vector) that the pass computes for that step, i.e. IRF samples s >= s_cut[j] */
     double block_kernel_bytes_once; /* bytes the last pass has to move once: live part of K, Kex, staged vectors */
-    double step_kernel_seconds;  /* the step kernel (finalize_kernel): the one launch on the critical path of a block step */
+    double step_kernel_seconds;  /* the step kernel (finalize_kernel): the one launch on the critical path of a block step; wide
+                                    systems (6N >= 1024): two launches per step, near_split_kernel + finalize_kernel, both counted */
     long long step_kernel_launches;
     double scatter_kernel_seconds; /* scatter launches (after a block step has delivered its forces) */
     long long scatter_kernel_launches;

@@ -2615,6 +2615,7 @@ int hc_get_excitation_irf_size(hc_ctx* c, int body, int* L) {
     HC_API_BEGIN(c)
     require(c->wave_kind == hc::kWaveIrregular && L, HC_ERR_INVALID, "no irregular wave model attached, or null pointer");
     check_body(c, body);
+    require(c->ex_group_of[body] >= 0, HC_ERR_INVALID, "no excitation IRF was ingested for this body");
     *L = c->ex_groups[c->ex_group_of[body]].L;
     HC_API_END(c)
 }

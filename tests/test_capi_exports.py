@@ -74,3 +74,30 @@ def test_kernel_code_object_is_built_next_to_the_library():
                  b"conv_block_kernelILi6ELi3ELi1ELi2E", b"conv_step_kernelILi4ELi2E", b"added_mass_mv_tagged_kernelE"):
         assert name in blob, name
     assert os.path.getmtime(hb.KERNEL_CO) >= os.path.getmtime(os.path.join(hb.CSRC, "hc_kernels.hip"))
+
+
+def test_wait_result_buffer_is_host_only():
+    """hc_wait_result_buffer (the reader side of the shared-memory host gather) needs no GPU: granules {value, sequence} of the
+    half that belongs to the sequence number's parity are copied out; a sequence that never arrives ends with HC_ERR_DEVICE."""
+    import ctypes as C
+
+    import numpy as np
+
+    from hydrochrono_amd import capi
+    lib = capi.load()
+    rows = 5
+    buf = np.zeros(2 * 2 * rows, dtype=np.uint64)  # two halves of [rows][2]
+    vals = np.array([1.5, -2.25, 3.0e10, 0.0, -7.0])
+    for seq in (7, 8):
+        half = buf[(seq & 1) * 2 * rows:(seq & 1) * 2 * rows + 2 * rows]
+        half[0::2] = (vals * seq).view(np.uint64)
+        half[1::2] = seq
+    out = np.empty(rows)
+    dp = out.ctypes.data_as(capi.c_double_p)
+    for seq in (7, 8):
+        assert lib.hc_wait_result_buffer(buf.ctypes.data, rows, seq, dp, 1.0) == capi.HC_OK
+        assert np.array_equal(out, vals * seq)
+    buf[1] = 6  # one granule of the even half still carries an older sequence number
+    assert lib.hc_wait_result_buffer(buf.ctypes.data, rows, 8, dp, 0.05) == capi.HC_ERR_DEVICE
+    assert lib.hc_wait_result_buffer(None, rows, 8, dp, 0.05) == capi.HC_ERR_INVALID
+    assert lib.hc_step_sequence(None, C.byref(C.c_ulonglong())) == capi.HC_ERR_INVALID

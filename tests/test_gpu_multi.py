@@ -370,3 +370,34 @@ def test_c4_size_step_multi_eight_contexts_one_gpu(hydro):
     assert p["hip_launches"] == 0 and p["direct_dispatches"] > 90
     group.close()
     full.close()
+
+
+def test_wide_system_soak_two_level_vs_plain(hydro):
+    """3 000 steps of a wide system (D = 1056) in the two-level look-ahead form against the plain per-step evaluation of the same
+    inputs: many ring wrap-arounds, step-size changes (blocks dropped and re-planned), jitter, and steps back in time."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    N = 176
+    case = many_body_case(N, S=64, dt_rirf=0.02, n_exc=9, dt_exc=0.05, seed=5)
+    a, b = hydro.HydroForces.from_case(case), hydro.HydroForces.from_case(case)
+    for h in (a, b):
+        h.add_waves_regular(0.4, 0.9)
+    b.set_lookahead(0)
+    a.enable_profiling(1)
+    motion = PrescribedMotion(N, rest_positions(case), seed=9)
+    rng = np.random.default_rng(3)
+    t, dt, worst = 0.0, 0.01, 0.0
+    for n in range(3000):
+        st = motion.state(t)
+        worst = max(worst, relerr(a.step(t, *st), b.step(t, *st)))
+        if n % 400 == 399:
+            dt = float(rng.choice([0.01, 0.007, 0.013, 0.02]))
+        if n % 701 == 700:
+            t -= 2.5 * dt                      # the integrator rejected the last steps
+        elif 1200 <= n < 1260:
+            t += dt * rng.uniform(0.6, 1.4)    # jitter: every prediction misses
+        else:
+            t += dt
+    assert worst <= 1e-10, worst
+    p = a.profile()
+    assert p["block_kernel_launches"] >= 60 and p["mini_pass_launches"] >= 150 and p["history_rewinds"] == 4, p

@@ -16,9 +16,10 @@ LIBDIR = os.path.join(PKG, "lib")
 MAIN_LIB = os.path.join(LIBDIR, "libhydrochrono_amd.so")
 BEMIO_LIB = os.path.join(LIBDIR, "libhc_bemio.so")
 
-SOURCES = ["hc_kernels.hip", "hc_api.cpp", "hc_direct.cpp", "hc_host_math.cpp", "hc_yaml.cpp", "hc_eta_fft.cpp"]
+SOURCES = ["hc_kernels.hip", "hc_runtime.cpp", "hc_step.cpp", "hc_setup.cpp", "hc_query.cpp", "hc_direct.cpp", "hc_host_math.cpp", "hc_yaml.cpp",
+           "hc_eta_fft.cpp"]
 KERNEL_CO = os.path.join(LIBDIR, "hc_kernels.co")  # the same kernels as a stand-alone code object, for the direct AQL dispatch (hc_direct.hpp)
-HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_host_math.hpp", "hc_limits.hpp", "hc_plan.hpp", "hc_history.hpp", "hc_direct.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h"),
+HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_internal.hpp", "hc_host_math.hpp", "hc_limits.hpp", "hc_plan.hpp", "hc_history.hpp", "hc_direct.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h"),
            os.path.join(ROOT, "include", "hydrochrono_amd_host.h"), os.path.join(ROOT, "include", "hydrochrono_amd_yaml.h")]
 
 
@@ -53,9 +54,23 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     if force or _newer(MAIN_LIB, deps):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-               "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")] + srcs + ["-o", MAIN_LIB, "-ldl", "-lrocfft",
-                                                                                              "-lhsa-runtime64"]
+        # one object per source, compiled side by side (the kernels take most of the time), then one link
+        objdir = os.path.join(LIBDIR, "obj")
+        os.makedirs(objdir, exist_ok=True)
+        base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
+        objs = [os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o") for src in srcs]
+        headers = [d for d in deps if d.endswith((".hpp", ".h"))]
+        todo = [(src, obj) for src, obj in zip(srcs, objs) if force or _newer(obj, [src] + headers)]
+        procs = []
+        for src, obj in todo:
+            cmd = base + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+        for cmd, pr in procs:
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", MAIN_LIB, "-ldl", "-lrocfft", "-lhsa-runtime64"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

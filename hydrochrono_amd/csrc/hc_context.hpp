@@ -92,7 +92,7 @@ struct BarBuffer {
     ~BarBuffer() {
         if (p) (void)hipFree(p);
     }
-    void alloc(size_t count);  // hc_api.cpp (probes host visibility without faulting)
+    void alloc(size_t count);  // hc_runtime.cpp (probes host visibility without faulting)
 };
 
 struct BodyHost {

@@ -222,7 +222,7 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
     (void)hsa_amd_profiling_set_profiler_enabled(p.lanes[0].queue, 1);  // timestamps for the dispatches that carry a completion signal
     (void)hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &p.ticks_per_second);
 
-    // kernarg ring in device memory the host can store into (same fault-free probe as BarBuffer, hc_api.cpp)
+    // kernarg ring in device memory the host can store into (same fault-free probe as BarBuffer, hc_runtime.cpp)
     void* q            = nullptr;
     const size_t bytes = static_cast<size_t>(Impl::kSlots) * kSlotBytes * kLanes;
     if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) != hipSuccess) {

@@ -7,7 +7,7 @@
 // code object hc_kernels.co is built from hc_kernels.hip next to the library and loaded through the HSA loader.
 //
 // Packets of one queue with the barrier bit execute in order, like kernels of a HIP stream; nothing orders this queue against
-// HIP streams, so the owner drains one side before it switches to the other (hc_api.cpp).
+// HIP streams, so the owner drains one side before it switches to the other (hc_step.cpp).
 #pragma once
 #include <cstddef>
 #include <cstdint>

@@ -1,0 +1,104 @@
+// hc_internal.hpp -- what the translation units behind the C ABI share (hc_runtime.cpp: buffers, history ring, profiling, launch
+// tiling, TaperedDirect preprocessing, direct-dispatch setup; hc_step.cpp: the per-step path; hc_setup.cpp: lifecycle, ingest,
+// wave models; hc_query.cpp: introspection).  Not part of the public interface.
+#pragma once
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <xmmintrin.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "hc_context.hpp"
+#include "hc_history.hpp"
+#include "hc_host_math.hpp"
+
+namespace hc {
+void eta_synthesis_fft(const std::vector<double>& t, const std::vector<double>& amp, const std::vector<double>& omega,
+                       const std::vector<double>& phase, double ramp, const double* d_t, double* d_eta, hipStream_t stream);
+
+namespace detail {
+
+using hc::Error;
+
+extern thread_local std::string g_create_error;  // message of the last failed hc_create (hc_last_error(NULL))
+extern const char* const kVersion;
+
+#define HC_API_BEGIN_HOT(ctx)                                \
+    if (!(ctx)) return HC_ERR_INVALID;                       \
+    try {                                                    \
+        HC_HIP(hipSetDevice((ctx)->device));
+
+// every entry point but the per-step ones first waits for what the direct queue still runs (hc_direct.hpp): their HIP work is
+// not ordered against it
+#define HC_API_BEGIN(ctx)                                    \
+    HC_API_BEGIN_HOT(ctx)                                    \
+    quiesce_direct(ctx);
+
+#define HC_API_END(ctx)                                      \
+    }                                                        \
+    catch (const Error& e) {                                 \
+        (ctx)->err = e.what();                               \
+        return e.status;                                     \
+    }                                                        \
+    catch (const std::out_of_range& e) {                     \
+        (ctx)->err = e.what();                               \
+        return HC_ERR_OUT_OF_RANGE;                          \
+    }                                                        \
+    catch (const std::exception& e) {                        \
+        (ctx)->err = e.what();                               \
+        return HC_ERR_RUNTIME;                               \
+    }                                                        \
+    return HC_OK;
+
+
+// ---- hc_runtime.cpp ----
+void quiesce_direct(hc_ctx* c);  // waits for what the direct queue still runs (bounded; HC_ERR_DEVICE on a lost device)
+void require(bool cond, int status, const char* msg);
+void check_body(const hc_ctx* c, int body);
+bool is_local(const hc_ctx* c, int body);
+void ring_alloc(hc_ctx* c, int cap);
+void ring_grow(hc_ctx* c, int need, int have);
+int history_push(hc_ctx* c, double t);
+void profile_account(hc_ctx* c, int kind, double sec, double waves_share);
+void profile_drain(hc_ctx* c);
+void profile_begin_step(hc_ctx* c);
+hc::EventPair* ev_begin(hc_ctx* c, int kind, hipStream_t stream, double waves_share = 0.0);
+void ev_end(hc::EventPair* ev, hipStream_t stream);
+bool profiling_tool_attached();
+int direct_tag(const hc_ctx* c, int kind);
+int env_int(const char* name, int fallback);
+void setup_panel_geometry(hc_ctx* c);
+hc::Panel rad_panel(const hc_ctx* c);
+void choose_conv_config(hc_ctx* c);
+void choose_exc_config(hc_ctx* c);
+void alloc_partials(hc_ctx* c);
+void ensure_processed(hc_ctx* c);
+void check_device_flag(hc_ctx* c);
+void stage_state(hc_ctx* c, const double* pos, const double* rpy, const double* linvel, const double* angvel);
+std::string library_dir();
+bool direct_selftest_rewrites(hc_ctx* c, hc::DirectQueue* q, int lane, bool* abandon);
+void setup_direct(hc_ctx* c);
+
+// ---- hc_step.cpp ----
+struct StepFlags {
+    bool hs = true, rad = true, waves = true;
+    bool scratch_out = false;  // term-only entry points: outputs go to scratch buffers, the last step's components stay
+};
+void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f,
+                  unsigned long long* host_tagged = nullptr, unsigned long long seq = 0, bool defer_tail = false);
+void enqueue_tail(hc_ctx* c);
+
+}  // namespace detail
+}  // namespace hc

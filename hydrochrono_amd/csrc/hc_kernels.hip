@@ -364,7 +364,7 @@ void launch_conv_step(const StepArgs& a, int mt, hipStream_t stream) {
 // issues 2*MT*NB MFMAs and immediately re-fills the freed registers with the fragment R groups ahead -- so the wave has
 // loads outstanding while its MFMAs run, and nothing of the right-hand side goes through LDS inside the loop.  Each lane
 // gathers exactly its own B operands (column 8gp + kk (+4), step j = 16*tb + (lane & 15)); the bracket of (IRF sample, step)
-// comes from a table in LDS built once per workgroup.  The not-yet-known sample of the pass is zero (hc_api.cpp:
+// comes from a table in LDS built once per workgroup.  The not-yet-known sample of the pass is zero (hc_step.cpp:
 // launch_pass), so a bracket whose newer end is that sample simply gets wn' = 0.
 //   UNI: D % 8 == 0 -- a column group never straddles two IRF samples, the sample index is wave-uniform and the bracket
 //        registers are reloaded only when it changes.

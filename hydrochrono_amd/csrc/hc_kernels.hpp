@@ -51,7 +51,7 @@ struct Bracket {
 };
 
 // ------------------------------------------------------------------------------------------------------------------
-// Scatter-form look-ahead (hc_api.cpp: make_plan).  The interpolated history is linear in its samples,
+// Scatter-form look-ahead (hc_step.cpp: make_plan).  The interpolated history is linear in its samples,
 //     v~(q) = sum_k phi_k(q) v_k      (phi_k = the reference's two interpolation weights of sample k, src/hydro_forces.cpp:343-371),
 // so the radiation sum of a future step m splits by history sample: what the samples known when the block was planned
 // contribute (the look-ahead pass, K read once for a block of 32 or 16 steps), what a sample that arrives at block step i < m contributes
@@ -233,7 +233,7 @@ struct ScatterArgs {
     double tgt_coef[kScatterSamples][kTargets];
 };
 
-// added_mass_mv_tagged_kernel's arguments as the kernel lays them out (direct dispatch, hc_api.cpp)
+// added_mass_mv_tagged_kernel's arguments as the kernel lays them out (direct dispatch, hc_step.cpp)
 struct AddedMassArgs {
     const double* M;
     int rows, cols;
@@ -266,7 +266,7 @@ struct TaperArgs {
     double final_amplitude;
 };
 
-// ---- launch geometry shared by the HIP launchers below and the direct AQL dispatch of hc_api.cpp (hc_direct.hpp) ----
+// ---- launch geometry shared by the HIP launchers below and the direct AQL dispatch of hc_step.cpp (hc_direct.hpp) ----
 struct FinalizeLaunch {
     int grid = 0, threads = 256;
     size_t smem = 0;

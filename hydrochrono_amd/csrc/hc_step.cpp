@@ -1,0 +1,1216 @@
+// hc_step.cpp -- the per-step path behind the C ABI: look-ahead bookkeeping, the kernel launches / AQL dispatches of one evaluation
+// (enqueue_step / enqueue_tail), the synchronous step and its halves, the multi-context step, the device-resident step, the
+// term-only entry points, history access and the added-mass product.  All arithmetic runs in hc_kernels.hip on the GPU.
+#include "hc_internal.hpp"
+
+using namespace hc::detail;
+
+namespace hc {
+namespace detail {
+
+// ---- the step ---------------------------------------------------------------------------------
+// the excitation-window tests of check_wave_ready as a predicate (for predicted step times)
+bool wave_window_ok(const hc_ctx* c, double t) {
+    if (c->wave_kind != hc::kWaveIrregular || c->eta_t.size() < 2 || c->ex_groups.empty()) return false;
+    const double tmin = c->eta_t.front(), tmax = c->eta_t.back();
+    for (const auto& g : c->ex_groups) {
+        const double q0 = t - g.tau_front, q1 = t - g.tau_back;
+        if (!(tmin <= q0 && q0 <= tmax) || !(tmin <= q1 && q1 <= tmax)) return false;
+        if (q0 > tmin && q0 < tmax && q0 <= c->eta_t[1]) return false;
+    }
+    return true;
+}
+
+void check_wave_ready(hc_ctx* c, double t) {
+    if (c->wave_nb_arg < c->N)
+        throw Error(HC_ERR_RUNTIME, "wave model was created for fewer bodies than the hydro system (force vector shorter than 6N)");
+    if (c->wave_kind == hc::kWaveIrregular) {
+        // ExcitationConvolution bounds (src/wave_types.cpp:784-794,833-840) and get_lower_index (src/helper.cpp:8-22)
+        const double tmin = c->eta_t.front(), tmax = c->eta_t.back();
+        for (const auto& g : c->ex_groups) {  // every body's grid (bodies with one grid share a group)
+            const double q0 = t - g.tau_front, q1 = t - g.tau_back;
+            if (!(tmin <= q0 && q0 <= tmax) || !(tmin <= q1 && q1 <= tmax))
+                throw Error(HC_ERR_RUNTIME,
+                            "Excitation convolution: trying to find free surface elevation at a time out of bounds from the "
+                            "precomputed free surface elevation. Excitation force ignored at this time step.");
+            if (q0 > tmin && q0 < tmax && q0 <= c->eta_t[1])
+                throw Error(HC_ERR_RUNTIME, "Could not find index for value in free-surface time array (get_lower_index)");
+        }
+    }
+}
+
+// Number of leading IRF samples that can contribute at query time t_query: samples whose t_query - tau_s lies before the
+// oldest history sample have no older bracket and contribute nothing (src/hydro_forces.cpp:604-606), so while the history
+// is shorter than the IRF window the kernels need not stream the tail of K at all.  Conservative by a small margin.
+int live_samples(const hc_ctx* c, double t_query) {
+    if (c->times.empty()) return 0;
+    const double span   = t_query - c->times.back();
+    const double margin = 1e-6 * std::max(1.0, std::fabs(span));
+    const auto it       = std::upper_bound(c->tau.begin(), c->tau.end(), span + margin);
+    return static_cast<int>(it - c->tau.begin());
+}
+
+// find_bracket of hc_kernels.hip on the host copy of the history (times[0] = t is the current sample, times[k] = ring slot
+// head - k): the same comparisons and the same divisions on the same doubles, so the weights are the kernel's bit for bit.
+// Returns false where the kernel would raise its "not bracketed" flag.
+bool host_bracket(const hc_ctx* c, double q, int H, hc::Bracket* out) {
+    auto time_at = [&](int k) { return c->times[static_cast<size_t>(k)]; };
+    int lo = 0, hi = H - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (time_at(mid + 1) <= q) hi = mid; else lo = mid + 1;
+    }
+    hc::Bracket b{0.0, 0.0, 0, 0};
+    if (lo >= H - 1) {
+        *out = b;
+        return true;
+    }
+    const double newer = time_at(lo), older = time_at(lo + 1);
+    if (q == older) { b.wo = 1.0; b.wn = 0.0; }
+    else if (q == newer) { b.wo = 0.0; b.wn = 1.0; }
+    else if (q > older && q < newer) {
+        const double td = newer - older;
+        b.wo = (td != 0.0) ? ((newer - q) / td) : 0.0;
+        b.wn = 1.0 - b.wo;
+    } else {
+        return false;
+    }
+    b.off_older = ((c->head - (lo + 1) + c->Hcap) % c->Hcap) * c->D;
+    b.off_newer = (lo == 0) ? -1 : ((c->head - lo + c->Hcap) % c->Hcap) * c->D;
+    *out = b;
+    return true;
+}
+
+// Look-ahead bookkeeping at the start of a step: 0 = plain (whole K this step), j = 1..16: the step is block step j of the
+// current plan (its time is the predicted one).
+int plan_step(hc_ctx* c, double t, int H) {
+    auto& pl = c->plan;
+    if (pl.cooldown > 0) --pl.cooldown;
+    if (H < 2 || c->lookahead <= 0 || !pl.valid) return 0;
+    if (pl.j_next <= c->lookahead) {
+        // accept the caller's time if it is the predicted one up to accumulated rounding (t += dt in the caller vs
+        // t0 + j*dt here); the radiation term is evaluated on the predicted grid, whose interpolation weights then differ
+        // from the caller's by <= tol/dt relative, far inside the 1e-6 contract
+        const double tol = std::max(1e-9 * pl.dt, 64.0 * std::numeric_limits<double>::epsilon() * std::fabs(t));
+        if (std::fabs(t - pl.tgrid[pl.j_next]) <= tol) return pl.j_next++;
+    }
+    // the caller left the predicted time grid (variable step): drop the block
+    pl.valid = false;
+    if (++pl.misses >= 2) {
+        pl.misses   = 0;
+        pl.cooldown = 64;  // irregular stepping: plain steps for a while, then try again
+    }
+    return 0;
+}
+
+// Wide systems (the same switch as the split own-sample kernel: a function of D only, so that row shards plan alike) use the
+// two-level form: their scatter launches would re-read (L/2) * K/S bytes from HBM every step.
+int plan_sub_block(const hc_ctx* c) {
+    const int forced = env_int("HC_SUB_BLOCK", -1);  // tests / tuning runs: 0 = single level, 4 / 8 = sub-block size
+    if (forced >= 0) return forced;
+    return hc::near_slices_for(c->D) > 1 ? hc::kSubBlock : 0;
+}
+
+bool make_plan(hc_ctx* c) { return hc::build_plan(c->plan, c->lookahead, c->times, c->tau, c->width, plan_sub_block(c), hc::near_slices_for(c->D)); }
+
+struct StepViews {
+    hc::Panel kex;
+    hc::EtaTable ex;
+};
+
+StepViews make_views(const hc_ctx* c) {
+    StepViews v{};
+    const bool irregular = c->wave_kind == hc::kWaveIrregular;
+    v.kex.base   = c->d_kex.p;
+    v.kex.ntiles = c->ntiles;
+    v.kex.ngp    = c->ngp_ex;
+    v.ex.L        = c->L;
+    v.ex.ex_tau   = c->d_ex_tau.p;
+    v.ex.ex_width = c->d_ex_width.p;
+    v.ex.eta_t    = c->d_eta_t.p;
+    v.ex.eta      = c->d_eta.p;
+    v.ex.nt       = c->nt;
+    v.ex.eta_dt   = irregular ? c->irr.simulation_dt : 1.0;
+    v.ex.eta_t0   = (irregular && !c->eta_t.empty()) ? c->eta_t.front() : 0.0;
+    return v;
+}
+
+// The look-ahead pass of the plan just made: for the 16 predicted steps, what the samples known now contribute.  It runs as
+// the plain pass of a (virtual) step at tgrid[1] whose own sample is zero -- that sample's share is added later by the
+// step itself and by its scatter.  Enqueued behind the step that has just been evaluated (its ring push included).
+void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = false) {
+    auto& pl = c->plan;
+    const int L = c->lookahead;
+    const int H = static_cast<int>(c->times.size());
+    // history length the virtual step would see after its own push + prune (PruneHistory, src/hydro_forces.cpp:327-340)
+    const double hmin = pl.tgrid[1] - (c->tau.empty() ? 0.0 : c->tau.back());
+    int Hv = H + 1;
+    auto vtime = [&](int k) { return k == 0 ? pl.tgrid[1] : c->times[static_cast<size_t>(k - 1)]; };
+    while (Hv > 1 && vtime(Hv - 2) < hmin) --Hv;
+
+    hc::HistoryView hv{};
+    hv.state   = c->d_zero_state.p;
+    hv.N       = c->N;
+    hv.D       = c->D;
+    hv.t       = pl.tgrid[1];
+    hv.ring_t  = c->d_ring_t.p;
+    hv.ring_v  = c->d_ring_v.p;
+    hv.ring_vT = c->d_ring_vT.p;
+    hv.head    = (c->head + 1) % c->Hcap;  // slot of the virtual sample (never read: time and velocity come from t / state)
+    hv.H       = Hv;
+    hv.Hcap    = c->Hcap;
+    hv.HcapT   = c->HcapT;
+    hv.dt_hint = pl.dt;
+
+    const StepViews vw = make_views(c);
+    hc::BlockArgs b{};
+    b.K                   = rad_panel(c);
+    b.F                   = std::min(c->S, live_samples(c, pl.tgrid[L])) * c->D;
+    b.depth               = L;
+    b.chunk_gp            = c->chunk_gp_block;
+    b.nchunks             = std::max(1, ((b.F + 7) / 8 + c->chunk_gp_block - 1) / c->chunk_gp_block);
+    b.max_steps_per_chunk = (c->chunk_gp_block * 8) / c->D + 2;
+    b.hist                = hv;
+    for (int j = 0; j < L; ++j) {
+        b.tpred[j]   = pl.tgrid[j + 1];
+        b.s_cut[j]   = pl.s_cut[j];
+        b.s_defer[j] = pl.s_defer[j];
+    }
+    b.tau   = c->d_tau.p;
+    b.width = c->d_width.p;
+    // The excitation force depends on time only, so the pass also evaluates it for the 16 predicted times (extra chunks
+    // over Kex in the same launch) -- provided every predicted time passes the window tests a real step would have to pass.
+    static const bool exc_in_block = env_int("HC_EXC_IN_BLOCK", 1) != 0;
+    bool exc_block = exc_in_block && with_exc && c->wave_kind == hc::kWaveIrregular && c->nchunks_ex_block > 0;
+    for (int j = 1; j <= L && exc_block; ++j) exc_block = wave_window_ok(c, pl.tgrid[j]);
+    pl.has_exc    = exc_block;
+    b.Kex         = vw.kex;
+    b.ex          = vw.ex;
+    b.chunk_gp_ex = c->chunk_gp_ex_block;
+    b.nchunks_ex  = exc_block ? c->nchunks_ex_block : 0;
+    b.partials    = c->d_partials_block.p;
+    b.Dpad        = c->Dpad;
+    b.error_flag  = c->d_err.p;
+    b.item_counter = c->d_err.p + 1;
+    b.ngroups     = c->ntiles / c->mt_block;
+    // algorithmic bytes: summed over the steps of the block, step j's share of K and of the velocity vector from s_cut[j]
+    // on ...; what the launch has to move once: the live part of K, Kex and the staged vectors
+    double samples = 0.0;
+    for (int j = 0; j < L; ++j) samples += std::max(0, b.F / c->D - pl.s_cut[j]);
+    const double rad_16 = 8.0 * samples * (static_cast<double>(c->Dloc) * c->D + c->D);
+    const double exc_16 = exc_block ? 8.0 * L * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
+    c->prof.block_kernel_bytes      = rad_16 + exc_16;
+    const double rad_once = 8.0 * (static_cast<double>(c->Dloc) * b.F + b.F);
+    const double exc_once = exc_block ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
+    c->prof.block_kernel_bytes_once = rad_once + exc_once;
+    if (env_int("HC_DEBUG_PLAN", 0) != 0) {
+        std::fprintf(stderr, "[hc] pass t0=%.6f dt=%.17g Hv=%d F/D=%d nchunks=%d exc=%d\n     s_cut:", pl.tgrid[0], pl.dt, Hv, b.F / c->D, b.nchunks, (int)exc_block);
+        for (int j = 0; j < L; ++j) std::fprintf(stderr, " %d", pl.s_cut[j]);
+        std::fprintf(stderr, "\n     s_defer:");
+        for (int j = 0; j < L; ++j) std::fprintf(stderr, " %d", pl.s_defer[j]);
+        std::fprintf(stderr, "\n     scat:");
+        for (int i = 1; i <= L; ++i) std::fprintf(stderr, " [%d,%d]", pl.scat_lo[i], pl.scat_hi[i]);
+        std::fprintf(stderr, "\n");
+    }
+    const double exc_share = exc_once / std::max(1.0, rad_once + exc_once);
+    const hc::ReduceArgs r{c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter, 0, 0, 0, 0};
+    if (direct) {
+        hc::BlockArgs b2;
+        const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_block, &b2);
+        if (l.nblocks <= 0) return;
+        c->dq->dispatch(L == 32 ? c->dk_block32 : c->dk_block16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
+                        direct_tag(c, hc::kEvPass), exc_share);
+        c->prof.direct_dispatches += 1;
+        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r);
+        c->prof.direct_dispatches += 1;
+        return;
+    }
+    hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_share);
+    hc::launch_conv_block(b, c->mt_block, stream);
+    ev_end(ev, stream);
+    hc::launch_reduce_block(r, stream);
+    c->prof.hip_launches += 2;
+}
+
+// The short pass of the two-level form after block step i0 (hc_plan.hpp: MiniPass): what the samples of the sub-block that has just
+// ended contribute to the block steps still to come, added to their rows of P.  The same kernel as the pass of the block, over
+// the first few IRF samples only, with the bracket table restricted to those samples (BlockArgs::mini_kw) and a chunking of its
+// own (half an IRF sample per chunk -- a function of D only, like every other chunk length).
+void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct) {
+    const auto& pl = c->plan;
+    const int L    = c->lookahead;
+    const hc::MiniPass mp = hc::mini_pass_setup(pl, L, i0, c->tau);
+    if (mp.n_samples <= 0 || mp.n_steps <= 0) return;
+    hc::HistoryView hv{};
+    hv.state   = c->d_zero_state.p;
+    hv.N       = c->N;
+    hv.D       = c->D;
+    hv.t       = mp.time[0];
+    hv.ring_t  = c->d_ring_t.p;
+    hv.ring_v  = c->d_ring_v.p;
+    hv.ring_vT = c->d_ring_vT.p;
+    hv.head    = (c->head + 1) % c->Hcap;  // slot of the not-yet-known sample of step i0 + 1
+    hv.H       = static_cast<int>(c->times.size()) + 1;
+    hv.Hcap    = c->Hcap;
+    hv.HcapT   = c->HcapT;
+    hv.dt_hint = pl.dt;
+    hc::BlockArgs b{};
+    b.K        = rad_panel(c);
+    b.F        = mp.n_samples * c->D;
+    b.depth    = L;
+    b.chunk_gp = std::max(16, (((c->D + 7) / 8 / 2 + 15) / 16) * 16);
+    b.nchunks  = std::max(1, ((b.F + 7) / 8 + b.chunk_gp - 1) / b.chunk_gp);
+    b.max_steps_per_chunk = (b.chunk_gp * 8) / c->D + 2;
+    b.hist     = hv;
+    for (int j = 0; j < L; ++j) {
+        b.tpred[j]   = mp.tpred[j];
+        b.s_cut[j]   = mp.s_cut[j];
+        b.s_defer[j] = mp.s_defer[j];
+    }
+    b.tau          = c->d_tau.p;
+    b.width        = c->d_width.p;
+    b.Kex          = make_views(c).kex;
+    b.ex           = make_views(c).ex;
+    b.chunk_gp_ex  = c->chunk_gp_ex_block;
+    b.nchunks_ex   = 0;
+    b.partials     = c->d_partials_block.p;
+    b.Dpad         = c->Dpad;
+    b.error_flag   = c->d_err.p;
+    b.item_counter = c->d_err.p + 1;
+    b.ngroups      = c->ntiles / c->mt_mini;
+    b.mini_kw      = mp.kw;
+    b.mini_steps   = mp.n_steps;
+    for (int k = 0; k <= mp.kw + 1; ++k) b.mini_time[k] = mp.time[k];
+    require(static_cast<size_t>(b.nchunks) * L * c->Dpad <= c->d_partials_block.n, HC_ERR_RUNTIME, "short pass: partials buffer too small");
+    hc::ReduceArgs r{c->d_partials_block.p, b.nchunks, 0, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter, 1, i0, mp.n_steps, 0};
+    if (direct) {
+        hc::BlockArgs b2;
+        const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_mini, &b2);
+        if (l.nblocks <= 0) return;
+        c->dq->dispatch(L == 32 ? c->dk_mini32 : c->dk_mini16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
+                        direct_tag(c, hc::kEvMiniPass));
+        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r);
+        c->prof.direct_dispatches += 2;
+        return;
+    }
+    hc::EventPair* ev = ev_begin(c, hc::kEvMiniPass, stream);
+    hc::launch_conv_block(b, c->mt_mini, stream);
+    ev_end(ev, stream);
+    hc::launch_reduce_block(r, stream);
+    c->prof.hip_launches += 2;
+}
+
+// Second half of a step's enqueue: the work LATER steps need (the scatter of this step's sample inside a look-ahead block, or
+// the plan and the pass of the next block).  Off the caller's critical path: it is enqueued behind the step kernel and runs
+// while the host is away.  On a caller's stream (hc_step_device) whose owner waits for every step it goes to the context's
+// own stream behind an event, so that whatever the caller enqueues next on its stream -- the all-gather of the force rows in
+// a multi-GPU run -- follows the step kernel directly.  hc_step_multi calls it after the step kernels of ALL shard contexts
+// have been handed to their GPUs.
+void enqueue_tail(hc_ctx* c) {
+    if (!c->tail.pending) return;
+    c->tail.pending        = false;
+    const bool block       = c->tail.block, direct = c->tail.direct, caller_waits = c->tail.caller_waits;
+    const int m            = c->tail.m, H = c->tail.H;
+    const hipStream_t stream = c->tail.stream;
+    const bool scatter_now = block && m < c->lookahead && c->plan.scat_hi[m] >= c->plan.scat_lo[m];
+    const bool plan_now    = (!block || m == c->lookahead) && H >= 2;
+    hipStream_t bs         = stream;
+    auto to_background = [&]() {
+        if (caller_waits && bs == stream) {
+            bs = c->stream;
+            HC_HIP(hipEventRecord(c->ev_fin, stream));
+            HC_HIP(hipStreamWaitEvent(bs, c->ev_fin, 0));
+        }
+    };
+    if (scatter_now) {
+        to_background();
+        const auto& pl = c->plan;
+        hc::ScatterArgs sa{};
+        sa.K     = rad_panel(c);
+        sa.D     = c->D;
+        sa.Dpad  = c->Dpad;
+        sa.s_lo  = pl.scat_lo[m];
+        sa.ns    = pl.scat_hi[m] - pl.scat_lo[m] + 1;
+        sa.v     = c->d_ring_v.p + static_cast<size_t>(c->head) * c->D;  // this step's sample, pushed by finalize_kernel
+        sa.width = c->d_width.p;
+        sa.Y     = c->d_Y.p;
+        for (int si = 0; si < sa.ns; ++si) {
+            const int s_ = sa.s_lo + si;
+            sa.n_tgt[si] = pl.n_tgt[m][s_];
+            for (int t = 0; t < pl.n_tgt[m][s_]; ++t) {
+                sa.tgt_off[si][t]  = (pl.tgt_step[m][s_][t] * hc::kTermMax + pl.tgt_k[m][s_][t]) * c->Dpad;
+                sa.tgt_coef[si][t] = pl.tgt_coef[m][s_][t];
+            }
+        }
+        if (direct) {
+            const hc::ScatterLaunch l = hc::scatter_launch_config(sa);
+            c->dq->dispatch(c->dk_scatter, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &sa, sizeof sa, direct_tag(c, hc::kEvScatter));
+            c->prof.direct_dispatches += 1;
+        } else {
+            hc::EventPair* ev = ev_begin(c, hc::kEvScatter, bs);
+            hc::launch_scatter(sa, bs);
+            c->prof.hip_launches += 1;
+            ev_end(ev, bs);
+        }
+    } else if (block && c->plan.sub > 0 && m < c->lookahead && m % c->plan.sub == 0 && c->plan.mini_s_hi[m] >= 0) {
+        to_background();
+        launch_mini_pass(c, m, bs, direct);  // two-level form: the sub-block that ends here -> the block steps still to come
+    } else if (plan_now) {
+        if (block) c->plan.misses = 0;  // a block was consumed completely
+        if (make_plan(c)) {
+            to_background();
+            launch_pass(c, bs, c->tail.waves, direct);
+        }
+    }
+    if (bs != stream) {
+        HC_HIP(hipEventRecord(c->ev_bg, bs));
+        c->bg_pending = true;
+    }
+    HC_HIP(hipGetLastError());
+}
+
+// Enqueue the kernels of one evaluation at time t.  d_state: device-visible pointer to the 12N state.  d_user_out
+// (device) and host_tagged (mapped pinned granules) may be null.
+// defer_tail: the caller enqueues the work later steps need itself (enqueue_tail) -- hc_step_multi, after all shard contexts
+// have their step kernels on the way.
+void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f,
+                  unsigned long long* host_tagged, unsigned long long seq, bool defer_tail) {
+    require(!c->tail.pending, HC_ERR_INVALID, "a step begun with hc_step_begin has not been completed (hc_step_end)");
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    const bool irregular = c->wave_kind == hc::kWaveIrregular;
+    if (f.waves) check_wave_ready(c, t);
+    profile_begin_step(c);
+    int H = 0, m = 0;
+    if (f.rad) {
+        ensure_processed(c);
+        H = history_push(c, t);
+        m = plan_step(c, t, H);
+    }
+    const bool run_rad = f.rad && H >= 2;  // "Nothing to convolve with if we don't yet have at least 2 time points" (:580)
+    const bool run_exc = f.waves && irregular;
+    const StepViews vw = make_views(c);
+    const bool block   = run_rad && m > 0;
+    // A caller's stream that is idle now belongs to a caller that waits for every step (the force exchange of a row-sharded
+    // array): the work later steps need then goes to the context's own stream, see below.  A caller that runs ahead of the GPU
+    // (stream still busy) gets everything on its stream in order -- the two event hops per step would only slow it down.
+    bool caller_waits = false;
+    if (stream != c->stream && f.rad && c->lookahead > 0) {
+        if (c->busy_caller_steps > 0) {
+            --c->busy_caller_steps;  // found busy a moment ago: do not pay for the query on every step of a caller that runs ahead
+        } else {
+            const hipError_t q = hipStreamQuery(stream);
+            caller_waits       = q == hipSuccess;
+            if (q != hipSuccess) {
+                (void)hipGetLastError();
+                c->busy_caller_steps = 15;
+            }
+        }
+    }
+    if (c->have_last_stream && c->last_stream != stream) {
+        // The steps of a context normally stay on one stream (the velocity ring is updated in stream order).  When they
+        // move -- hc_step after hc_step_device on a caller's stream, or the reverse -- this step is ordered behind the
+        // previous one with an event.  A caller's stream may have been destroyed since (after a synchronise): then there is
+        // nothing left to wait for.
+        if (hipEventRecord(c->ev_fin, c->last_stream) == hipSuccess) HC_HIP(hipStreamWaitEvent(stream, c->ev_fin, 0));
+        else (void)hipGetLastError();
+    }
+    c->last_stream      = stream;
+    c->have_last_stream = true;
+    if (c->bg_pending) {
+        // the scatter / pass of the previous step ran on the context's own stream (see below): this step's kernels need them
+        if (stream != c->stream) HC_HIP(hipStreamWaitEvent(stream, c->ev_bg, 0));
+        c->bg_pending = false;
+    }
+    const double* P_row = block ? c->d_P.p + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
+    const double* E_row = (block && run_exc && c->plan.has_exc) ? c->d_E.p + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
+
+    // plain step: all live columns of K, plus the excitation chunks unless a pass has left the excitation force
+    int nchunks_rad = 0, nchunks_ex = (run_exc && !E_row) ? c->nchunks_ex : 0;
+    // Where this step's kernels go: the direct queue (hc_direct.hpp) when the step comes from hc_step and needs no plain
+    // convolution launch -- the steady state of a look-ahead run -- else the HIP stream.  Nothing orders the two against each
+    // other on the device, so the side that was used last is drained at a switch.
+    const bool direct = c->direct_ready && host_tagged && stream == c->stream && !f.scratch_out &&
+                        (c->dk_step.ok() || !((run_rad && !block) || nchunks_ex > 0)) &&
+                        !(c->profiling && profiling_tool_attached());  // the library's own timings under a tool: HIP events
+    if (direct && c->path != 2) {
+        // switching from HIP launches to the direct queue: everything the HIP side still runs must have finished.  A preceding
+        // step on a caller's stream (hc_step_device) has been ordered in front of c->stream by the ev_fin wait above, and what it
+        // left on the context's own stream (ev_bg) runs there too, so draining c->stream covers both.
+        HC_HIP(hipStreamSynchronize(c->stream));
+        c->bg_pending = false;
+        c->path       = 2;
+    } else if (!direct) {
+        quiesce_direct(c);
+        c->path = 1;
+    }
+    if ((run_rad && !block) || nchunks_ex > 0) {
+        hc::HistoryView hv{};
+        hv.state   = d_state;
+        hv.N       = c->N;
+        hv.D       = c->D;
+        hv.t       = t;
+        hv.ring_t  = c->d_ring_t.p;
+        hv.ring_v  = c->d_ring_v.p;
+        hv.head    = c->head;
+        hv.H       = H;
+        hv.Hcap    = c->Hcap;
+        hv.HcapT   = c->HcapT;
+        hv.dt_hint = (H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
+        hc::StepArgs a{};
+        a.K       = rad_panel(c);
+        a.F_limit = (run_rad && !block) ? std::min(c->S, live_samples(c, t)) * c->D : 0;
+        a.chunk_gp = c->chunk_gp;
+        nchunks_rad           = ((a.F_limit + 7) / 8 + a.chunk_gp - 1) / a.chunk_gp;
+        a.nchunks_rad         = nchunks_rad;
+        a.max_steps_per_chunk = (a.chunk_gp * 8) / c->D + 2;
+        a.rhs_capacity        = 8 * std::max(a.chunk_gp, c->chunk_gp_ex);
+        a.hist                = hv;
+        a.tau                 = c->d_tau.p;
+        a.width               = c->d_width.p;
+        a.Kex                 = vw.kex;
+        a.ex                  = vw.ex;
+        a.chunk_gp_ex         = c->chunk_gp_ex;
+        a.nchunks_ex          = nchunks_ex;
+        a.partials            = c->d_partials.p;
+        a.Dpad                = c->Dpad;
+        a.ngroups             = c->ngroups;
+        a.error_flag          = c->d_err.p;
+        const double rad_b = 8.0 * (static_cast<double>(c->Dloc) * a.F_limit + a.F_limit);
+        const double exc_b = nchunks_ex > 0 ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
+        const int kind     = nchunks_rad > 0 ? hc::kEvConvPlain : hc::kEvConvExc;
+        const double share = exc_b / std::max(1.0, rad_b + exc_b);
+        if (direct) {
+            const hc::StepLaunch l = hc::step_launch_config(a, c->mt);
+            if (l.nblocks > 0) {
+                c->dq->dispatch(c->dk_step, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &a, sizeof a, direct_tag(c, kind), share);
+                c->prof.direct_dispatches += 1;
+            }
+        } else {
+            hc::EventPair* ev = ev_begin(c, kind, stream, share);
+            hc::launch_conv_step(a, c->mt, stream);
+            c->prof.hip_launches += 1;
+            ev_end(ev, stream);
+        }
+    }
+
+    hc::FinalizeArgs z{};
+    z.partials    = c->d_partials.p;
+    z.nchunks_rad = nchunks_rad;
+    z.nchunks_ex  = nchunks_ex;
+    z.P           = P_row;
+    z.E           = E_row;
+    if (block) {
+        const auto& pl = c->plan;
+        z.nearK     = rad_panel(c);
+        z.ring_v_ro = c->d_ring_v.p;
+        for (int e = 0; e < pl.n_own[m]; ++e) {
+            hc::NearEntry& ne = z.near[z.n_near++];
+            ne   = hc::NearEntry{};
+            ne.s = pl.own_s[m][e];
+            ne.a = pl.own_a[m][e];
+        }
+        const int sd = pl.s_defer[m - 1];
+        if (sd >= 0) {
+            // the IRF sample the pass left to this step: its whole bracket, with the caller's time and the history as it is
+            hc::Bracket br{};
+            if (host_bracket(c, t - c->tau[sd], H, &br) && (br.wo != 0.0 || br.wn != 0.0)) {
+                hc::NearEntry& ne = z.near[z.n_near++];
+                ne       = hc::NearEntry{};
+                ne.s     = sd;
+                ne.off_b = br.off_older;
+                ne.b     = br.wo * c->width[sd];
+                if (br.off_newer < 0) ne.a = br.wn * c->width[sd];
+                else {
+                    ne.off_c = br.off_newer;
+                    ne.c     = br.wn * c->width[sd];
+                }
+            }
+        }
+        z.n_terms = pl.n_terms[m];
+        z.Yc      = c->d_Y.p + static_cast<size_t>(m) * hc::kTermMax * c->Dpad;
+    }
+    static const bool dbg = env_int("HC_DEBUG_PLAN", 0) != 0;
+    if (dbg) {
+        std::fprintf(stderr, "[hc] t=%.6f H=%d m=%d n_near=%d n_terms=%d sd=%d nchunks_rad=%d nchunks_ex=%d head=%d\n", t, H, m, z.n_near, z.n_terms,
+                     block ? c->plan.s_defer[m - 1] : -2, nchunks_rad, nchunks_ex, c->head);
+        for (int e = 0; e < z.n_near; ++e)
+            std::fprintf(stderr, "     near s=%d a=%.6g b=%.6g c=%.6g offb=%d offc=%d\n", z.near[e].s, z.near[e].a, z.near[e].b, z.near[e].c, z.near[e].off_b, z.near[e].off_c);
+    }
+    z.host_tagged = host_tagged;
+    z.seq         = seq;
+    z.Dloc        = c->Dloc;
+    z.Dpad        = c->Dpad;
+    z.N           = c->N;
+    z.b0          = c->b0;
+    z.state       = d_state;
+    z.lin         = c->d_lin.p;
+    z.cg          = c->d_cg.p;
+    z.cb_m_cg     = c->d_cbmcg.p;
+    z.disp_vol    = c->d_vol.p;
+    z.rho         = c->rho;
+    z.gx          = c->gsys[0];
+    z.gy          = c->gsys[1];
+    z.gz          = c->gsys[2];
+    z.wave_mode   = c->wave_kind;
+    z.reg_mag     = c->d_reg_mag.p;
+    for (int i = 0; i < 6; ++i) z.reg_phase[i] = c->reg_phase.size() >= 6 ? c->reg_phase[i] : 0.0;
+    z.reg_amplitude = c->reg_amp;
+    z.reg_omega     = c->reg_omega;
+    z.spec_nf       = c->nf;
+    z.spec_mag      = c->d_spec_mag.p;
+    z.spec_phase    = c->d_spec_phase.p;
+    z.spec_amp      = c->d_spec_amp.p;
+    z.spec_omega    = c->d_spec_omega.p;
+    z.spec_phi      = c->d_spec_phi.p;
+    z.spec_ramp     = c->irr.ramp_duration;
+    z.t             = t;
+    z.do_hs         = f.hs;
+    z.do_rad        = run_rad;
+    z.do_waves      = f.waves;
+    double* out4    = f.scratch_out ? c->d_scratch.p : nullptr;
+    z.hs            = out4 ? out4 : c->d_hs.p;
+    z.rad           = out4 ? out4 + c->Dloc : c->d_rad.p;
+    z.waves         = out4 ? out4 + 2 * c->Dloc : c->d_waves.p;
+    z.total         = out4 ? out4 + 3 * c->Dloc : c->d_total.p;
+    z.user_out      = d_user_out;
+    z.do_push       = f.rad ? 1 : 0;
+    z.head          = c->head;
+    z.D             = c->D;
+    z.ring_t        = c->d_ring_t.p;
+    z.ring_v        = c->d_ring_v.p;
+    z.ring_vT       = c->d_ring_vT.p;
+    z.Hcap          = c->Hcap;
+    z.HcapT         = c->HcapT;
+    if (z.n_near > 0 && hc::near_slices_for(c->D) > 1) {
+        // wide system: the own-sample part is split over column slices by a kernel of its own (hundreds of workgroups instead of one
+        // per row tile); the step kernel adds the slice partials
+        hc::NearArgs na{};
+        na.K      = z.nearK;
+        na.D      = c->D;
+        na.Dpad   = c->Dpad;
+        na.N      = c->N;
+        na.n_near = z.n_near;
+        for (int e = 0; e < z.n_near; ++e) na.near[e] = z.near[e];
+        na.state    = d_state;
+        na.ring_v   = c->d_ring_v.p;
+        na.partials = c->d_near_partials.p;
+        if (direct) {
+            const hc::NearLaunch l = hc::near_launch_config(na);
+            c->dq->dispatch(c->dk_near, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &na, sizeof na, direct_tag(c, hc::kEvStep));
+            c->prof.direct_dispatches += 1;
+        } else {
+            hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
+            hc::launch_near_split(na, stream);
+            ev_end(ev, stream);
+            c->prof.hip_launches += 1;
+            (void)hc::near_launch_config(na);
+        }
+        z.near_partials = c->d_near_partials.p;
+        z.n_near_slices = na.n_slices;
+        z.n_near        = 0;
+    }
+    if (direct) {
+        const hc::FinalizeLaunch l = hc::finalize_launch_config(z);
+        c->dq->dispatch(c->dk_finalize, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &z, sizeof z, direct_tag(c, hc::kEvStep));
+        c->prof.direct_dispatches += 1;
+    } else {
+        hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
+        hc::launch_finalize(z, stream);
+        c->prof.hip_launches += 1;
+        ev_end(ev, stream);
+    }
+
+    // ---- off the caller's critical path: what later steps need from this one (enqueue_tail) ----
+    c->tail              = hc::StepTail{};
+    c->tail.pending      = f.rad && c->lookahead > 0;
+    c->tail.rad          = f.rad;
+    c->tail.waves        = f.waves;
+    c->tail.block        = block;
+    c->tail.direct       = direct;
+    c->tail.caller_waits = caller_waits;
+    c->tail.m            = m;
+    c->tail.H            = H;
+    c->tail.stream       = stream;
+    if (!defer_tail) enqueue_tail(c);
+    HC_HIP(hipGetLastError());
+
+    if (f.hs) c->prof.hydrostatics_calls++;
+    if (f.rad) c->prof.radiation_calls++;
+    if (f.waves) c->prof.waves_calls++;
+}
+
+}  // namespace detail
+}  // namespace hc
+
+// =================================================================================================
+extern "C" {
+
+// ---- per-step ---------------------------------------------------------------------------------
+namespace {
+double step_timeout_seconds() {
+    static const double s = [] {
+        const char* e = std::getenv("HC_STEP_TIMEOUT_S");
+        const double v = e ? std::atof(e) : 0.0;
+        return v > 0.0 ? v : 20.0;
+    }();
+    return s;
+}
+
+[[noreturn]] void device_lost(hc_ctx* c, const std::string& what) {
+    c->lost         = true;
+    c->direct_ready = false;  // nothing more goes to a queue that has stopped answering
+    c->direct_why   = what;
+    throw Error(HC_ERR_DEVICE, what);
+}
+
+// Wait until finalize_kernel's {total, sequence} granules of step `seq` have all arrived in mapped pinned memory, then
+// copy the totals out.  Each granule is one 16-byte store, so its value is valid as soon as its sequence number is.  This
+// replaces hipStreamSynchronize on the per-step path (14 -> 9 us for an empty launch, profiles/r02/latency_probe_v1.txt).
+// The wait is bounded: every 2^16 spins the slow path looks at the clock, at the queue's error flag (direct path) or at the
+// stream (HIP path), so a failed launch or a lost device ends the wait with HC_ERR_DEVICE after HC_STEP_TIMEOUT_S (20 s)
+// instead of hanging the host.
+void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long long seq, hipStream_t stream, double* out, int lane = 0) {
+    const volatile unsigned long long* g = granules;
+    unsigned long long spins = 0;
+    std::chrono::steady_clock::time_point t_begin{};
+    for (int r = c->Dloc - 1; r >= 0; --r) {
+        while (g[2 * r + 1] != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFF) == 0) {
+                const auto now = std::chrono::steady_clock::now();
+                if (spins == 0x10000) t_begin = now;
+                const bool timed_out = std::chrono::duration<double>(now - t_begin).count() > step_timeout_seconds();
+                if (stream == nullptr || (c->path == 2 && stream == c->stream)) {
+                    // the step went to the direct queue: there is no stream to ask
+                    if (c->dq && c->dq->failed(lane)) device_lost(c, "hc_step: the HSA queue of the direct dispatch reported an error: " + c->dq->failure_text());
+                    if (timed_out) device_lost(c, "hc_step: the step's results did not arrive (direct queue, timeout)");
+                    continue;
+                }
+                const hipError_t q = hipStreamQuery(stream);
+                if (q == hipSuccess) {
+                    if (g[2 * r + 1] != seq) device_lost(c, "hc_step: the stream drained but the step's results did not arrive");
+                } else if (q != hipErrorNotReady) {
+                    device_lost(c, std::string("hc_step: ") + hipGetErrorString(q));
+                } else if (timed_out) {
+                    device_lost(c, "hc_step: the step's results did not arrive (timeout)");
+                }
+            }
+        }
+    }
+    for (int r = 0; r < c->Dloc; ++r) {
+        const unsigned long long bits = g[2 * r];
+        std::memcpy(out + r, &bits, sizeof(double));
+    }
+}
+
+unsigned long long* result_tags_dev(hc_ctx* c, unsigned long long seq) {
+    return (c->ext_tag_dev ? c->ext_tag_dev : c->h_tag.dp) + (seq & 1) * static_cast<size_t>(2) * c->Dloc;
+}
+const unsigned long long* result_tags_host(hc_ctx* c, unsigned long long seq) {
+    return (c->ext_tag_host ? c->ext_tag_host : c->h_tag.p) + (seq & 1) * static_cast<size_t>(2) * c->Dloc;
+}
+
+// First half of a synchronous step: cache rules of CoordinateFuncForBody (src/hydro_forces.cpp:742-751), the state stored where
+// the kernels read it, the step kernel handed to the GPU.  Leaves c->pending_step = 1 (cache hit, totals in last_total) or 2
+// (results arrive as tagged granules of sequence number c->seq).  defer_tail: see enqueue_step.
+void step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel, bool defer_tail) {
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(pos && rpy && linvel && angvel, HC_ERR_INVALID, "null pointer");
+    require(c->pending_step == 0, HC_ERR_INVALID, "the step begun before has not been completed (hc_step_end)");
+    if (c->lost) throw Error(HC_ERR_DEVICE, "the device stopped answering in an earlier step: " + c->direct_why);
+    if (c->have_prev && t == c->prev_time) {  // src/hydro_forces.cpp:742-744
+        c->pending_step = 1;
+        return;
+    }
+    if (c->have_prev_device && t == c->prev_time_device) {
+        // this time was evaluated through hc_step_device (possibly on a caller's stream): fetch its totals, do not re-evaluate
+        quiesce_direct(c);
+        HC_HIP(hipDeviceSynchronize());
+        HC_HIP(hipMemcpy(c->last_total.data(), c->d_total.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost));
+        c->prev_time    = t;
+        c->have_prev    = true;
+        c->pending_step = 1;
+        return;
+    }
+    c->prev_time = t;  // :747 (set before the terms are computed, so a throwing step is not retried)
+    c->have_prev = true;
+    c->have_prev_device = false;  // d_total is about to be replaced (or left stale by a step that throws)
+    std::fill(c->last_total.begin(), c->last_total.end(), 0.0);  // the reference zero-fills total_force_ before the terms (:749-751)
+    // Boundary without copy launches or stream synchronisation: the host stores the state doubles straight into device
+    // memory through the PCIe BAR (fallback: mapped pinned memory the kernels read over PCIe), finalize_kernel stores the
+    // totals straight into mapped pinned memory, tagged with this step's sequence number; one kernel launch for a step
+    // inside a block.
+    // The state buffer has two halves used alternately: this call returns as soon as the totals have arrived, while the
+    // workgroup that stores the step's sample into the ring may still be reading the state -- the next call must not
+    // overwrite it.  (The kernels of step n+1 run after those of step n, and step n+2 starts only after the totals of
+    // step n+1 have arrived, so two halves are enough.)
+    // A row-sharded context reads positions and angles of its OWN bodies only (hydrostatics), velocities of all: the other
+    // bodies' pos / rpy entries are not stored (half the bytes through the BAR for each shard of a wide array).
+    const int n3   = 3 * c->N;
+    const size_t o = (c->seq & 1) ? static_cast<size_t>(12) * c->N : 0;
+    const size_t l0 = static_cast<size_t>(3) * c->b0, ln = static_cast<size_t>(3) * c->nloc;
+    auto put = [&](double* h) {
+        std::memcpy(h + l0, pos + l0, ln * sizeof(double));
+        std::memcpy(h + n3 + l0, rpy + l0, ln * sizeof(double));
+        std::memcpy(h + 2 * n3, linvel, n3 * sizeof(double));
+        std::memcpy(h + 3 * n3, angvel, n3 * sizeof(double));
+    };
+    const double* d_state;
+    if (c->bar_state.host_ok) {
+        // device memory written through the PCIe BAR: the kernels read the state locally (no PCIe read on the critical path)
+        double* h = c->bar_state.p + o;
+        put(h);
+        _mm_sfence();  // write-combined stores are globally visible before the doorbell of the launch
+        d_state = h;
+    } else {
+        double* h = c->h_state.p + o;
+        put(h);
+        d_state = c->h_state.dp + o;
+        if (c->N > c->zero_copy_max_bodies) {  // many workgroups re-read the state: one small H2D copy beats their PCIe reads
+            HC_HIP(hipMemcpyAsync(c->d_state.p, h, 4 * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            d_state = c->d_state.p;
+        }
+    }
+    const unsigned long long seq = ++c->seq;
+    // The tagged results of consecutive steps go to alternate halves of the result buffer: a reader in ANOTHER process (a caller's
+    // buffer in shared memory, hc_set_result_buffer) may still be collecting step n while this process has moved on to step n + 1;
+    // it cannot reach step n + 2 before every process has the rows of step n + 1, i.e. has finished with step n.
+    enqueue_step(c, t, d_state, nullptr, c->stream, StepFlags{}, result_tags_dev(c, seq), seq, defer_tail);
+    c->pending_step = 2;
+    c->pending_t    = t;
+}
+
+// Second half: wait for the tagged totals of the step begun last and hand them out.
+void step_end(hc_ctx* c, double* force_out) {
+    require(c->pending_step != 0, HC_ERR_INVALID, "hc_step_end without hc_step_begin");
+    const int how   = c->pending_step;
+    c->pending_step = 0;
+    if (how == 2) {
+        if (c->tail.pending) enqueue_tail(c);  // (a caller that deferred the tail and never enqueued it)
+        wait_tagged(c, result_tags_host(c, c->seq), c->seq, c->stream, c->last_total.data());
+        if (c->device_errors_possible) {
+            quiesce_direct(c);
+            check_device_flag(c);
+        }
+        c->prev_time_device = c->pending_t;  // finalize_kernel has left the same totals in d_total: hc_step_device at this time copies them
+        c->have_prev_device = true;
+    }
+    if (force_out) std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
+}
+
+// A failed begin leaves nothing pending; whatever the step had enqueued before it threw is harmless (results nobody waits for).
+void step_abort(hc_ctx* c) {
+    c->pending_step = 0;
+    c->tail.pending = false;
+}
+}  // namespace
+
+int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel, double* force_out) {
+    HC_API_BEGIN_HOT(c)
+    require(force_out, HC_ERR_INVALID, "null pointer");
+    try {
+        step_begin(c, t, pos, rpy, linvel, angvel, false);
+        step_end(c, force_out);
+    } catch (...) {
+        step_abort(c);
+        throw;
+    }
+    HC_API_END(c)
+}
+
+int hc_step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel) {
+    HC_API_BEGIN_HOT(c)
+    try {
+        step_begin(c, t, pos, rpy, linvel, angvel, false);
+    } catch (...) {
+        step_abort(c);
+        throw;
+    }
+    HC_API_END(c)
+}
+
+int hc_step_end(hc_ctx* c, double* force_out) {
+    HC_API_BEGIN_HOT(c)
+    require(force_out, HC_ERR_INVALID, "null pointer");
+    try {
+        step_end(c, force_out);
+    } catch (...) {
+        step_abort(c);
+        throw;
+    }
+    HC_API_END(c)
+}
+
+// The result buffer of hc_step in memory the caller provides -- e.g. a POSIX shared-memory segment that the OTHER processes of a
+// one-process-per-GPU host map too: every process then collects the force rows of all shards straight from the buffers the GPUs
+// write (hc_wait_result_buffer), a host gather without a collective or a copy ("outputs -> host gather").
+int hc_set_result_buffer(hc_ctx* c, void* host_buffer, size_t bytes) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(c->pending_step == 0, HC_ERR_INVALID, "a step is pending");
+    HC_HIP(hipDeviceSynchronize());
+    if (c->ext_tag_host) {
+        (void)hipHostUnregister(c->ext_tag_host);
+        c->ext_tag_host = c->ext_tag_dev = nullptr;
+    }
+    if (host_buffer) {
+        const size_t need = static_cast<size_t>(4) * c->Dloc * sizeof(unsigned long long);
+        require(bytes >= need, HC_ERR_INVALID, "result buffer too small: 2 x 16 bytes per owned row");
+        require((reinterpret_cast<uintptr_t>(host_buffer) & 15) == 0, HC_ERR_INVALID, "result buffer must be 16-byte aligned");
+        HC_HIP(hipHostRegister(host_buffer, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+        void* dp = nullptr;
+        const hipError_t e = hipHostGetDevicePointer(&dp, host_buffer, 0);
+        if (e != hipSuccess) {
+            (void)hipHostUnregister(host_buffer);
+            throw Error(HC_ERR_DEVICE, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+        }
+        std::memset(host_buffer, 0, need);
+        c->ext_tag_host = static_cast<unsigned long long*>(host_buffer);
+        c->ext_tag_dev  = static_cast<unsigned long long*>(dp);
+    }
+    HC_API_END(c)
+}
+
+int hc_step_sequence(const hc_ctx* c, unsigned long long* seq) {
+    if (!c || !seq) return HC_ERR_INVALID;
+    *seq = c->seq;
+    return HC_OK;
+}
+
+// Host-only: waits until the `rows` tagged results of step `seq` have arrived in a result buffer (this process's or another's)
+// and copies the values out.  No context, no HIP call.
+int hc_wait_result_buffer(const void* host_buffer, int rows, unsigned long long seq, double* out, double timeout_seconds) {
+    if (!host_buffer || rows <= 0 || !out) return HC_ERR_INVALID;
+    const volatile unsigned long long* g = static_cast<const unsigned long long*>(host_buffer) + (seq & 1) * static_cast<size_t>(2) * rows;
+    unsigned long long spins = 0;
+    std::chrono::steady_clock::time_point t0{};
+    const double limit = timeout_seconds > 0.0 ? timeout_seconds : step_timeout_seconds();
+    for (int r = rows - 1; r >= 0; --r) {
+        while (g[2 * r + 1] != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFF) == 0) {
+                const auto now = std::chrono::steady_clock::now();
+                if (spins == 0x10000) t0 = now;
+                if (std::chrono::duration<double>(now - t0).count() > limit) return HC_ERR_DEVICE;
+            }
+        }
+    }
+    for (int r = 0; r < rows; ++r) {
+        const unsigned long long bits = g[2 * r];
+        std::memcpy(out + r, &bits, sizeof(double));
+    }
+    return HC_OK;
+}
+
+// One evaluation of a body-row-sharded system held by G contexts of ONE host process (the drop-in variant: the host
+// holds all body states -> a state store per GPU -> host-side gather).  Three phases: (1) every context gets the state and its
+// step kernel -- all G GPUs are working before the host does anything else; (2) the work later steps need is enqueued on each;
+// (3) the host collects the tagged totals of each shard into its rows of the 6N vector.  No collective, no torch: the same
+// kernels and the same per-shard arithmetic as hc_step, so the gathered vector is bitwise the unsharded one.
+int hc_step_multi(hc_ctx* const* ctxs, int n_ctx, double t, const double* pos, const double* rpy, const double* linvel,
+                  const double* angvel, double* force_out) {
+    if (!ctxs || n_ctx <= 0 || !force_out) return HC_ERR_INVALID;
+    for (int g = 0; g < n_ctx; ++g)
+        if (!ctxs[g]) return HC_ERR_INVALID;
+    int status = HC_OK;
+    std::string message;
+    auto guarded = [&](hc_ctx* c, auto&& fn) {
+        try {
+            HC_HIP(hipSetDevice(c->device));
+            fn();
+            return true;
+        } catch (const Error& e) {
+            if (status == HC_OK) { status = e.status; message = e.what(); }
+        } catch (const std::out_of_range& e) {
+            if (status == HC_OK) { status = HC_ERR_OUT_OF_RANGE; message = e.what(); }
+        } catch (const std::exception& e) {
+            if (status == HC_OK) { status = HC_ERR_RUNTIME; message = e.what(); }
+        }
+        step_abort(c);
+        return false;
+    };
+    std::vector<char> begun(static_cast<size_t>(n_ctx), 0);
+    for (int g = 0; g < n_ctx; ++g) {
+        hc_ctx* c = ctxs[g];
+        begun[g]  = guarded(c, [&] {
+            require(c->N == ctxs[0]->N, HC_ERR_INVALID, "hc_step_multi: the contexts belong to different systems");
+            step_begin(c, t, pos, rpy, linvel, angvel, true);
+        });
+    }
+    for (int g = 0; g < n_ctx; ++g)
+        if (begun[g]) begun[g] = guarded(ctxs[g], [&] { enqueue_tail(ctxs[g]); });
+    for (int g = 0; g < n_ctx; ++g)
+        if (begun[g]) guarded(ctxs[g], [&] { step_end(ctxs[g], force_out + static_cast<size_t>(6) * ctxs[g]->b0); });
+    if (status != HC_OK)
+        for (int g = 0; g < n_ctx; ++g) ctxs[g]->err = message;  // hc_last_error of any context of the group tells why
+    return status;
+}
+
+int hc_step_device(hc_ctx* c, double t, const double* d_state, double* d_force_out, void* stream) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(d_state && d_force_out, HC_ERR_INVALID, "null pointer");
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    if (c->have_prev_device && t == c->prev_time_device) {
+        if (s != c->stream) {  // the totals may have been left by an hc_step, whose kernels ran on the context's stream
+            HC_HIP(hipEventRecord(c->ev_fin, c->stream));
+            HC_HIP(hipStreamWaitEvent(s, c->ev_fin, 0));
+        }
+        HC_HIP(hipMemcpyAsync(d_force_out, c->d_total.p, c->Dloc * sizeof(double), hipMemcpyDeviceToDevice, s));
+        return HC_OK;
+    }
+    c->have_prev = false;  // the host-side cache of hc_step does not hold this step
+    enqueue_step(c, t, d_state, d_force_out, s, StepFlags{});
+    c->prev_time_device = t;
+    c->have_prev_device = true;
+    HC_API_END(c)
+}
+
+int hc_get_force_components(hc_ctx* c, double* hs, double* rad, double* waves) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    HC_HIP(hipDeviceSynchronize());
+    const size_t nb = c->Dloc * sizeof(double);
+    HC_HIP(hipMemcpyAsync(c->h_out.p, c->d_hs.p, nb, hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipMemcpyAsync(c->h_out.p + c->Dloc, c->d_rad.p, nb, hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipMemcpyAsync(c->h_out.p + 2 * c->Dloc, c->d_waves.p, nb, hipMemcpyDeviceToHost, c->stream));
+    check_device_flag(c);  // synchronises
+    if (hs) std::memcpy(hs, c->h_out.p, nb);
+    if (rad) std::memcpy(rad, c->h_out.p + c->Dloc, nb);
+    if (waves) std::memcpy(waves, c->h_out.p + 2 * c->Dloc, nb);
+    HC_API_END(c)
+}
+
+// The three term-only entry points write to scratch outputs: the components and the cached total of the last full step
+// (hc_get_force_components, the duplicate-time cache) stay what that step left.
+int hc_compute_radiation(hc_ctx* c, double t, const double* linvel, const double* angvel, double* rad_out) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(linvel && angvel && rad_out, HC_ERR_INVALID, "null pointer");
+    stage_state(c, nullptr, nullptr, linvel, angvel);
+    StepFlags f;
+    f.hs = false;
+    f.waves = false;
+    f.scratch_out = true;
+    enqueue_step(c, t, c->d_state.p, nullptr, c->stream, f);
+    HC_HIP(hipMemcpyAsync(c->h_out.p + c->Dloc, c->d_scratch.p + c->Dloc, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    check_device_flag(c);
+    std::memcpy(rad_out, c->h_out.p + c->Dloc, c->Dloc * sizeof(double));
+    HC_API_END(c)
+}
+
+int hc_compute_hydrostatics(hc_ctx* c, const double* pos, const double* rpy, double* hs_out) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(pos && rpy && hs_out, HC_ERR_INVALID, "null pointer");
+    stage_state(c, pos, rpy, nullptr, nullptr);
+    StepFlags f;
+    f.rad = false;
+    f.waves = false;
+    f.scratch_out = true;
+    enqueue_step(c, 0.0, c->d_state.p, nullptr, c->stream, f);
+    HC_HIP(hipMemcpyAsync(c->h_out.p, c->d_scratch.p, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(hs_out, c->h_out.p, c->Dloc * sizeof(double));
+    HC_API_END(c)
+}
+
+int hc_compute_waves(hc_ctx* c, double t, double* waves_out) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(waves_out, HC_ERR_INVALID, "null pointer");
+    stage_state(c, nullptr, nullptr, nullptr, nullptr);
+    StepFlags f;
+    f.hs = false;
+    f.rad = false;
+    f.scratch_out = true;
+    enqueue_step(c, t, c->d_state.p, nullptr, c->stream, f);
+    HC_HIP(hipMemcpyAsync(c->h_out.p + 2 * c->Dloc, c->d_scratch.p + 2 * c->Dloc, c->Dloc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    check_device_flag(c);
+    std::memcpy(waves_out, c->h_out.p + 2 * c->Dloc, c->Dloc * sizeof(double));
+    HC_API_END(c)
+}
+
+int hc_set_lookahead(hc_ctx* c, int steps) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    HC_HIP(hipDeviceSynchronize());  // a pass of the previous depth may still be running
+    c->lookahead = steps <= 0 ? 0 : (steps <= 16 ? 16 : hc::kLookahead);
+    choose_conv_config(c);  // the pass chunking depends on the depth
+    alloc_partials(c);
+    c->plan      = hc::Plan{};
+    HC_API_END(c)
+}
+
+int hc_direct_dispatch_active(const hc_ctx* c) { return (c && c->direct_ready) ? 1 : 0; }
+const char* hc_dispatch_mode_reason(const hc_ctx* c) {
+    if (!c) return "no context";
+    if (!c->finalized) return "hc_finalize has not been called";
+    return c->direct_ready ? "direct AQL dispatch" : c->direct_why.c_str();
+}
+
+int hc_reset_history(hc_ctx* c) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    HC_HIP(hipDeviceSynchronize());  // steps may still be running on a caller's stream (hc_step_device)
+    c->times.clear();
+    c->retired.clear();
+    c->head = -1;
+    c->have_last_stream = c->bg_pending = false;  // everything has run
+    c->have_prev = c->have_prev_device = false;
+    c->prev_time = c->prev_time_device = -1.0;
+    c->plan = hc::Plan{};
+    HC_API_END(c)
+}
+
+int hc_set_history(hc_ctx* c, int n, const double* times, const double* vel) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(n >= 0 && (n == 0 || (times && vel)), HC_ERR_INVALID, "bad history arguments");
+    for (int k = 1; k < n; ++k) require(times[k] < times[k - 1], HC_ERR_INVALID, "history times must be strictly decreasing (newest first)");
+    HC_HIP(hipDeviceSynchronize());  // steps may still be running on a caller's stream (hc_step_device)
+    c->have_last_stream = c->bg_pending = false;  // everything has run
+    if (n > c->Hcap) ring_alloc(c, n + 16 + hc::kRewindSlack);
+    c->times.assign(times, times + n);
+    c->retired.clear();
+    // sample k -> slot n-1-k, head = n-1
+    std::vector<double> tt(n), vv(static_cast<size_t>(n) * c->D);
+    for (int k = 0; k < n; ++k) {
+        tt[n - 1 - k] = times[k];
+        std::copy(vel + static_cast<size_t>(k) * c->D, vel + static_cast<size_t>(k + 1) * c->D, vv.begin() + static_cast<size_t>(n - 1 - k) * c->D);
+    }
+    if (n) {
+        // on the context's stream: ring_alloc's memsets are queued there, and a copy on the null stream is not ordered
+        // against a non-blocking stream (it could be overtaken by them)
+        HC_HIP(hipMemcpyAsync(c->d_ring_t.p, tt.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HC_HIP(hipMemcpyAsync(c->d_ring_v.p, vv.data(), vv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hc::launch_ring_transpose(c->d_ring_v.p, c->Hcap, c->HcapT, c->D, c->d_ring_vT.p, c->stream);
+        HC_HIP(hipGetLastError());
+    }
+    HC_HIP(hipStreamSynchronize(c->stream));  // tt / vv are released on return
+    c->head      = n - 1;
+    c->plan      = hc::Plan{};
+    // No step has been evaluated at times[0], so the per-time cache holds nothing (a step at exactly that time is the
+    // reference's duplicate-time error, raised by the history push).
+    c->have_prev = c->have_prev_device = false;
+    c->prev_time = c->prev_time_device = -1.0;
+    HC_API_END(c)
+}
+
+int hc_get_history(hc_ctx* c, int* n, double* times, double* vel) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    HC_HIP(hipDeviceSynchronize());
+    const int H = static_cast<int>(c->times.size());
+    if (n) *n = H;
+    if (times) std::copy(c->times.begin(), c->times.end(), times);
+    if (vel) {
+        for (int k = 0; k < H; ++k) {
+            const int slot = ((c->head - k) % c->Hcap + c->Hcap) % c->Hcap;
+            HC_HIP(hipMemcpy(vel + static_cast<size_t>(k) * c->D, c->d_ring_v.p + static_cast<size_t>(slot) * c->D, c->D * sizeof(double),
+                             hipMemcpyDeviceToHost));
+        }
+    }
+    HC_API_END(c)
+}
+
+// ---- added mass -------------------------------------------------------------------------------
+int hc_added_mass_matrix(hc_ctx* c, double* M) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(M, HC_ERR_INVALID, "null pointer");
+    std::copy(c->ainf_host.begin(), c->ainf_host.end(), M);
+    HC_API_END(c)
+}
+
+namespace {
+// Chrono's integrator calls the product between force evaluations, so it is built like hc_step: staging buffers and a stream of
+// its own (kernels of the last hc_step may still be reading the state buffer, and the work that step left for later steps
+// is still running on the context's stream -- the product does not wait for it); w and the incoming R go to the device
+// through the BAR (fallback: mapped pinned memory), one launch, the result comes back as tagged granules.
+void added_mass_begin(hc_ctx* c, const double* w, double cc, const double* R, int n_sys) {
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    require(w && R, HC_ERR_INVALID, "null pointer");
+    require(n_sys >= c->D, HC_ERR_INVALID, "system has fewer coordinates than the added-mass block");
+    require(c->pending_am == 0, HC_ERR_INVALID, "an added-mass product is still in flight");
+    if (c->lost) throw Error(HC_ERR_DEVICE, "the device stopped answering in an earlier step: " + c->direct_why);
+    const int row0 = 6 * c->b0;
+    const bool bar = c->bar_am.host_ok && c->bar_state.host_ok;  // bar_state.host_ok also carries the coherence check of hc_finalize
+    double* hw       = bar ? c->bar_am.p : c->h_am.p;
+    double* hr       = hw + c->D;
+    std::memcpy(hw, w, c->D * sizeof(double));
+    std::memcpy(hr, R + row0, c->Dloc * sizeof(double));
+    if (bar) _mm_sfence();
+    const double* dw = bar ? c->bar_am.p : c->h_am.dp;
+    const unsigned long long seq = ++c->seq_am;
+    if (c->direct_ready && bar && c->am_lane == 0) {
+        // first product of this context: the second lane (a queue of its own) is created and self-tested now
+        std::string why;
+        bool abandon = false;
+        c->am_lane   = (c->dq->ensure_lane(1, &why) && direct_selftest_rewrites(c, c->dq, 1, &abandon)) ? 1 : -1;
+        c->direct_why.clear();  // (the step path's lane stays in use whatever the second lane's test said)
+    }
+    if (c->direct_ready && bar && c->am_lane == 1) {
+        // the second lane of the direct queue: an AQL packet instead of a HIP launch, independent of the step path's lane
+        hc::AddedMassArgs a{c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq};
+        c->dq->dispatch(c->dk_added_mass, static_cast<uint32_t>((c->Dloc + 3) / 4), 256, 0, &a, sizeof a, -1, 0.0, 1);
+        c->prof.direct_dispatches += 1;
+        c->pending_am = 1;
+    } else {
+        hc::launch_added_mass_mv_tagged(c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq, c->stream_am);
+        c->prof.hip_launches += 1;
+        HC_HIP(hipGetLastError());
+        c->pending_am = 2;
+    }
+}
+void added_mass_end(hc_ctx* c, double* R) {
+    const int how = c->pending_am;
+    c->pending_am = 0;
+    if (how == 1) wait_tagged(c, c->h_tag_am.p, c->seq_am, nullptr, R + 6 * c->b0, 1);
+    else if (how == 2) wait_tagged(c, c->h_tag_am.p, c->seq_am, c->stream_am, R + 6 * c->b0);
+}
+}  // namespace
+
+int hc_added_mass_mv(hc_ctx* c, const double* w, double cc, double* R, int n_sys) {
+    HC_API_BEGIN_HOT(c)  // own stream, own buffers: independent of whatever the step queues still run
+    try {
+        added_mass_begin(c, w, cc, R, n_sys);
+        added_mass_end(c, R);
+    } catch (...) {
+        c->pending_am = 0;
+        throw;
+    }
+    HC_API_END(c)
+}
+
+// LoadIntLoadResidual_Mv of a row-sharded system held by G contexts of one process: every shard's product is handed to its GPU
+// first, then the rows are collected (each shard owns rows [6*b0, 6*b1) of R; w is the full vector).
+int hc_added_mass_mv_multi(hc_ctx* const* ctxs, int n_ctx, const double* w, double cc, double* R, int n_sys) {
+    if (!ctxs || n_ctx <= 0) return HC_ERR_INVALID;
+    for (int g = 0; g < n_ctx; ++g)
+        if (!ctxs[g]) return HC_ERR_INVALID;
+    int status = HC_OK;
+    std::string message;
+    auto guarded = [&](hc_ctx* c, auto&& fn) {
+        try {
+            HC_HIP(hipSetDevice(c->device));
+            fn();
+            return true;
+        } catch (const Error& e) {
+            if (status == HC_OK) { status = e.status; message = e.what(); }
+        } catch (const std::exception& e) {
+            if (status == HC_OK) { status = HC_ERR_RUNTIME; message = e.what(); }
+        }
+        c->pending_am = 0;
+        return false;
+    };
+    std::vector<char> begun(static_cast<size_t>(n_ctx), 0);
+    for (int g = 0; g < n_ctx; ++g) begun[g] = guarded(ctxs[g], [&] { added_mass_begin(ctxs[g], w, cc, R, n_sys); });
+    for (int g = 0; g < n_ctx; ++g)
+        if (begun[g]) guarded(ctxs[g], [&] { added_mass_end(ctxs[g], R); });
+    if (status != HC_OK)
+        for (int g = 0; g < n_ctx; ++g) ctxs[g]->err = message;
+    return status;
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+// array_multi_gpu.cpp -- a coupled multi-body array on one OR SEVERAL GPUs from one host process, without Project Chrono.
+//
+// The reference drives one TestHydro object from one Chrono process (src/hydro_forces.cpp:170-242,727-767).  The same object here
+// takes a device list: one body-row shard per listed device, evaluated by one hc_step_multi per time (state into every GPU, all
+// step kernels dispatched, host-side gather) -- the caller's loop does not change.  Heave decay of all bodies (each released from an
+// offset), irregular waves on top; heave accelerations from the coupled 4 x 4 (mass + A_inf) system, symplectic Euler.
+//   usage: array_multi_gpu <bemio.h5> <N bodies> <nsteps> [device list, e.g. 0,1,2,3  (default: 0)]
+// Prints "t z_1 .. z_N" per step; the output does not depend on the device list (row shards add in the same order).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <sstream>
+#include <vector>
+
+#include "../hydrochrono_amd/csrc/hydro_forces_amd.hpp"
+
+using namespace hydroc_amd;
+
+// solves A x = b in place (A: n x n row-major, partial pivoting) -- the coupled heave system is tiny
+static void solve(std::vector<double>& A, std::vector<double>& b, int n) {
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(A[i * n + k]) > std::fabs(A[p * n + k])) p = i;
+        for (int j = 0; j < n; ++j) std::swap(A[k * n + j], A[p * n + j]);
+        std::swap(b[k], b[p]);
+        for (int i = k + 1; i < n; ++i) {
+            const double f = A[i * n + k] / A[k * n + k];
+            for (int j = k; j < n; ++j) A[i * n + j] -= f * A[k * n + j];
+            b[i] -= f * b[k];
+        }
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        for (int j = k + 1; j < n; ++j) b[k] -= A[k * n + j] * b[j];
+        b[k] /= A[k * n + k];
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        std::fprintf(stderr, "usage: %s <bemio.h5> <N bodies> <nsteps> [devices, e.g. 0,1,2,3]\n", argv[0]);
+        return 2;
+    }
+    const int N = std::atoi(argv[2]), nsteps = std::atoi(argv[3]);
+    std::vector<int> devices;
+    {
+        std::stringstream ss(argc > 4 ? argv[4] : "0");
+        for (std::string tok; std::getline(ss, tok, ',');) devices.push_back(std::atoi(tok.c_str()));
+    }
+    const double timestep = 0.005, g = 9.81, rho = 1000.0;
+    std::vector<std::shared_ptr<MockBody>> mock;
+    std::vector<std::shared_ptr<HydroBody>> bodies;
+    for (int b = 0; b < N; ++b) {
+        mock.push_back(std::make_shared<MockBody>("body" + std::to_string(b + 1)));  // names as in the .h5
+        bodies.push_back(mock.back());
+    }
+    try {
+        IrregularWaveParams p;
+        p.num_bodies_ = N;
+        p.simulation_dt_ = timestep;
+        p.simulation_duration_ = nsteps * timestep + 1.0;
+        p.ramp_duration_ = 0.5;
+        p.wave_height_ = 1.0;
+        p.wave_period_ = 6.0;
+        p.frequency_min_ = 0.05;
+        p.frequency_max_ = 0.6;
+        p.nfrequencies_ = 32;
+        p.peak_enhancement_factor_ = 3.3;
+        TestHydro hydro(bodies, argv[1], std::make_shared<IrregularWaves>(p), devices);  // one row shard per listed device
+        hydro.SetGravitationalAcceleration(0.0, 0.0, -g);
+        const int D = 6 * N;
+        const std::vector<double> Ainf = hydro.GetAddedMassMatrix();  // D x D, rho-scaled
+        // every body gets a nominal mass; its rest height is where the vertical hydrostatic force carries that weight (secant
+        // search through ComputeForceHydrostatics); bodies are released 0.3 m (alternating sign) from rest
+        std::vector<double> mass(N, 200.0 * rho), z(N), v(N, 0.0), z0(N);
+        for (int b = 0; b < N; ++b) {
+            auto fz = [&](double zz) {
+                mock[b]->pos[2] = zz;
+                return hydro.ComputeForceHydrostatics()[6 * b + 2];
+            };
+            double za = -5.0, zb = 0.0, fa = fz(za), fb = fz(zb);
+            for (int it = 0; it < 30 && std::fabs(fb - mass[b] * g) > 1e-9 * mass[b] * g; ++it) {
+                const double zc = zb - (fb - mass[b] * g) * (zb - za) / (fb - fa);
+                za = zb;
+                fa = fb;
+                zb = zc;
+                fb = fz(zc);
+            }
+            z0[b] = zb;
+            z[b]  = zb + (b % 2 ? -0.3 : 0.3);
+            mock[b]->pos[2] = z[b];
+        }
+        for (int n = 0; n < nsteps; ++n) {
+            const double t = n * timestep;
+            for (int b = 0; b < N; ++b) {
+                mock[b]->time      = t;
+                mock[b]->pos[2]    = z[b];
+                mock[b]->linvel[2] = v[b];
+            }
+            std::vector<double> M(static_cast<size_t>(N) * N), rhs(N);
+            for (int b = 0; b < N; ++b) {
+                rhs[b] = hydro.CoordinateFuncForBody(b + 1, 2) - mass[b] * g;  // one evaluation per time, whatever the GPU count
+                for (int c = 0; c < N; ++c) M[b * N + c] = Ainf[static_cast<size_t>(6 * b + 2) * D + 6 * c + 2] + (b == c ? mass[b] : 0.0);
+            }
+            solve(M, rhs, N);
+            std::printf("%.6f", t + timestep);
+            for (int b = 0; b < N; ++b) {
+                v[b] += timestep * rhs[b];
+                z[b] += timestep * v[b];
+                std::printf(" %.9f", z[b] - z0[b]);
+            }
+            std::printf("\n");
+        }
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -48,3 +48,23 @@ def test_cpp_irregular(exe):
     ref = goldens()["irreg_waves_z_um"][:6000] * 1e-6
     d = np.abs(run(exe, "irregular", 6000) - ref)
     assert d.max() <= 1e-4 and d[5000:].max() <= 6e-6
+
+
+def test_cpp_array_example_on_several_shards(tmp_path):
+    """examples/array_multi_gpu.cpp: a coupled four-body array through the Chrono-free C++ mirror with a DEVICE LIST -- one, two and
+    four row shards (all on the one GPU here); the printed trajectories do not depend on the shard count."""
+    from hydrochrono_amd import build as hb
+    hb.build()
+    if not os.path.exists(hb.BEMIO_LIB):
+        pytest.skip("libhdf5 not available: BEMIO reader not built")
+    exe = str(tmp_path / "array_multi_gpu")
+    libdir = os.path.join(ROOT, "hydrochrono_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "examples", "array_multi_gpu.cpp"), "-o", exe,
+                    "-L", libdir, "-lhydrochrono_amd", f"-Wl,-rpath,{libdir}"], check=True)
+    outs = []
+    for devs in ("0", "0,0", "0,0,0,0"):
+        r = subprocess.run([exe, os.path.join(GOLDEN_DIR, "four_body.h5"), "4", "400", devs], check=True, capture_output=True, text=True)
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2]
+    a = np.array([[float(x) for x in line.split()] for line in outs[0].strip().splitlines()])
+    assert a.shape == (400, 5) and np.all(np.isfinite(a)) and np.max(np.abs(a[:, 1:])) < 5.0 and np.ptp(a[:, 1]) > 0.05

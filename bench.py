@@ -364,7 +364,7 @@ def main():
         align = boundary - first
     pre = align + args.warmup
     total = pre + args.steps
-    n_all = total + n_steady + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
+    n_all = total + n_steady + (128 if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
     duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
     gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
@@ -535,6 +535,29 @@ def main():
         k_next += n_steady
     prof_all = gpu.profile()  # warm-up + timed region + steady-state block
     gpu.enable_profiling(False)
+    chrono_like = None
+    if n_steady > 0:
+        # What a Chrono loop sees: the host integrates between two force evaluations, and what a step leaves for later steps (scatter,
+        # the pass of the next block) runs meanwhile.  100 us of host work between calls (a busy wait standing in for DoStepDynamics'
+        # own share; the reference's whole RM3 step takes 360 us), only the calls are timed.
+        n_cl, work = 128, 100e-6
+        lat = np.zeros(n_cl)
+        pc = time.perf_counter
+        for i in range(n_cl):
+            k = k_next + i
+            a = pc()
+            rc = hc_step(ctx, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
+            b_ = pc()
+            lat[i] = b_ - a
+            if rc:
+                gpu._chk(rc)
+            while pc() - b_ < work:
+                pass
+        chrono_like = {"steps": n_cl, "host_work_between_calls_us": work * 1e6, "mean_hc_step_us": float(lat.mean()) * 1e6,
+                       "median_hc_step_us": float(np.median(lat)) * 1e6, "p90_hc_step_us": float(np.percentile(lat, 90)) * 1e6,
+                       "max_hc_step_us": float(lat.max()) * 1e6,
+                       "note": "synchronous hc_step with 100 us of host work between calls: the look-ahead pass and the scatter run while the host is away"}
+        k_next += n_cl
     if n_pipe > 0:
         # hc_step_device, states resident in HBM, every step enqueued without waiting for the previous one's forces
         d_states = torch.tensor(states[k_next:k_next + n_pipe], device="cuda")
@@ -696,6 +719,8 @@ def main():
         }
         if steady is not None:
             out["steady_state"] = steady
+        if chrono_like is not None:
+            out["chrono_like_loop"] = chrono_like
         if pipelined is not None:
             out["device_pipelined"] = pipelined
         if plain is not None:

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <deque>
 #include <stdexcept>
 #include <string>
@@ -159,6 +160,13 @@ struct hc_ctx {
     double pending_t  = 0.0;
     int pending_am    = 0;      // hc_added_mass_mv in flight (hc_added_mass_mv_multi): 1 tagged on the direct lane, 2 on stream_am
     bool lost         = false;  // a dispatch never completed or the queue reported an error: every later step fails with HC_ERR_DEVICE
+    // Arming of the direct queue (DirectQueue::arm): after a step whose caller had been away for a while before it (the gap between
+    // the end of the previous call and this one: a Chrono loop integrates in between), the queue is left parked on a barrier packet
+    // so that the next step's kernel starts without the idle penalty.  arm_mode: 0 never, 1 adaptive (default), 2 always.
+    int arm_mode = 1;
+    bool arm_after_step = false, arm_after_am = false;
+    std::chrono::steady_clock::time_point t_step_end{}, t_am_end{};
+    bool have_t_step_end = false, have_t_am_end = false;
     int busy_caller_steps   = 0;  // hc_step_device: steps left before the caller's stream is queried again (see enqueue_step)
     std::string err;
 

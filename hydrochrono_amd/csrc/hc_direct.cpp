@@ -94,6 +94,8 @@ struct DirectQueue::Impl {
         char* ring         = nullptr;  // kernarg slots: fine-grained device memory, written by the host through the BAR
         hsa_signal_t drain_sig{};
         bool have_drain_sig = false;
+        hsa_signal_t gate{};  // what the parked barrier packet of arm() waits for (1: closed, 0: open)
+        bool have_gate = false, armed = false;
     } lanes[DirectQueue::kLanes];
     char* ring_all = nullptr;
     uint64_t ticks_per_second = 0;
@@ -148,10 +150,16 @@ DirectQueue::~DirectQueue() {
     Impl& p = *p_;
     for (int l = 0; l < kLanes; ++l) {
         if (p.lanes[l].queue) {
+            if (p.lanes[l].armed) {  // open the gate: nothing may stay parked in a queue that is about to go
+                hsa_signal_store_screlease(p.lanes[l].gate, 0);
+                p.lanes[l].armed = false;
+                busy_[l]         = true;
+            }
             if (busy_[l] && !failed(l)) (void)drain(5.0, l);
             (void)hsa_queue_destroy(p.lanes[l].queue);
         }
         if (p.lanes[l].have_drain_sig) (void)hsa_signal_destroy(p.lanes[l].drain_sig);
+        if (p.lanes[l].have_gate) (void)hsa_signal_destroy(p.lanes[l].gate);
     }
     for (auto& t : p.timed) (void)hsa_signal_destroy(t.sig);
     for (auto& s : p.free_sigs) (void)hsa_signal_destroy(s);
@@ -259,7 +267,24 @@ bool DirectQueue::ensure_lane(int lane, std::string* why) {
         }
         p.lanes[lane].have_drain_sig = true;
     }
+    if (!p.lanes[lane].have_gate && hsa_signal_create(1, 0, nullptr, &p.lanes[lane].gate) == HSA_STATUS_SUCCESS) p.lanes[lane].have_gate = true;
     return true;
+}
+
+bool DirectQueue::armed(int lane) const { return p_->lanes[lane].armed; }
+
+void DirectQueue::arm(int lane) {
+    Impl& p        = *p_;
+    Impl::Lane& ln = p.lanes[lane];
+    if (!ln.queue || !ln.have_gate || ln.armed || failed(lane)) return;
+    hsa_signal_store_relaxed(ln.gate, 1);
+    const uint64_t idx = p.reserve(ln);
+    auto* pkt = reinterpret_cast<hsa_barrier_and_packet_t*>(ln.queue->base_address) + (idx & (ln.queue->size - 1));
+    std::memset(reinterpret_cast<char*>(pkt) + 4, 0, sizeof(*pkt) - 4);
+    pkt->dep_signal[0]    = ln.gate;
+    const uint16_t header = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER);
+    p.publish(ln, pkt, header, 0, idx);
+    ln.armed = true;
 }
 
 DirectKernel DirectQueue::find(const std::string& fragment) const {
@@ -319,12 +344,21 @@ void DirectQueue::dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t 
                             (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                             (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     p.publish(ln, pkt, header, 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS, idx);
+    if (ln.armed) {  // the packet processor is parked on the barrier of arm(): open the gate now that the packet is in the queue
+        hsa_signal_store_screlease(ln.gate, 0);
+        ln.armed = false;
+    }
     busy_[lane] = true;
 }
 
 bool DirectQueue::drain(double timeout_seconds, int lane) {
     Impl& p        = *p_;
     Impl::Lane& ln = p.lanes[lane];
+    if (ln.queue && ln.armed) {  // a parked barrier would hold the drain packet back for ever
+        hsa_signal_store_screlease(ln.gate, 0);
+        ln.armed    = false;
+        busy_[lane] = true;
+    }
     if (!ln.queue || !busy_[lane]) return true;
     hsa_signal_store_relaxed(ln.drain_sig, 1);
     const uint64_t idx = p.reserve(ln);

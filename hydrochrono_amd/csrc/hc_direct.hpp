@@ -47,6 +47,14 @@ class DirectQueue {
     // behind work the step path still runs).
     void dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t wg_size, uint32_t dyn_lds, const void* args, size_t arg_bytes,
                   int timed_tag = -1, double timed_aux = 0.0, int lane = 0);
+    // Parks the lane's packet processor on a barrier packet that waits for a signal; the next dispatch() releases it right after
+    // its packet is in the queue.  A queue that has sat EMPTY for more than a few tens of microseconds takes about 6 us longer from
+    // doorbell to kernel start (12.2 against 6.0 us launch-to-result for a small kernel after >= 100 us of idle,
+    // profiles/r03/latency_probe6.cpp -- a Chrono loop leaves such gaps between force evaluations); a parked queue does not
+    // (6.2 us after any gap).  Right before a dispatch that follows within microseconds the extra packet costs 1.7 us, so the owner
+    // arms only when it expects the caller to be away for a while.
+    void arm(int lane = 0);
+    bool armed(int lane = 0) const;
     // Waits until everything dispatched to the lane so far has completed.  Gives up after timeout_seconds (<= 0: one minute), or
     // as soon as the queue has reported an error, and returns false (the queue must then not be used any more).
     bool drain(double timeout_seconds = 0.0, int lane = 0);

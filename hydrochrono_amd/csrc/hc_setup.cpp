@@ -359,6 +359,7 @@ int hc_finalize(hc_ctx* c) {
     c->d_zero_state.alloc(static_cast<size_t>(12) * c->N);
     HC_HIP(hipMemsetAsync(c->d_zero_state.p, 0, c->d_zero_state.n * sizeof(double), c->stream));
     c->zero_copy_max_bodies = env_int("HC_ZERO_COPY_BODIES", 64);
+    c->arm_mode             = std::min(2, std::max(0, env_int("HC_ARM", 1)));  // 0 never, 1 adaptive, 2 always: parking of the direct queue between steps
     // default wave model: NoWave for all bodies (the reference's default NoWave() covers one body only and is
     // read out of bounds for N > 1, src/hydro_forces.cpp:758-760; that overread is deliberately not reproduced)
     c->wave_kind   = hc::kWaveNone;

@@ -703,6 +703,8 @@ void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long lo
     }
 }
 
+constexpr double kArmGapSeconds = 25e-6;  // a caller that stays away longer than this finds the queue parked (see step_end)
+
 unsigned long long* result_tags_dev(hc_ctx* c, unsigned long long seq) {
     return (c->ext_tag_dev ? c->ext_tag_dev : c->h_tag.dp) + (seq & 1) * static_cast<size_t>(2) * c->Dloc;
 }
@@ -731,6 +733,13 @@ void step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const
         c->have_prev    = true;
         c->pending_step = 1;
         return;
+    }
+    // how long was the caller away?  (decides whether the queue is parked on a barrier after this step, see step_end)
+    if (c->arm_mode == 1) {
+        const auto now    = std::chrono::steady_clock::now();
+        c->arm_after_step = c->have_t_step_end && std::chrono::duration<double>(now - c->t_step_end).count() > kArmGapSeconds;
+    } else {
+        c->arm_after_step = c->arm_mode == 2;
     }
     c->prev_time = t;  // :747 (set before the terms are computed, so a throwing step is not retried)
     c->have_prev = true;
@@ -794,6 +803,12 @@ void step_end(hc_ctx* c, double* force_out) {
         }
         c->prev_time_device = c->pending_t;  // finalize_kernel has left the same totals in d_total: hc_step_device at this time copies them
         c->have_prev_device = true;
+        // Everything this step had to enqueue is in the queue.  A caller that was away for a while before this step (a Chrono loop
+        // integrating between force evaluations) will be away again: leave the packet processor parked on a barrier, so that the
+        // next step's kernel starts at once instead of after the ~6 us an idle queue needs (DirectQueue::arm).
+        if (c->path == 2 && c->direct_ready && c->arm_after_step) c->dq->arm(0);
+        c->t_step_end      = std::chrono::steady_clock::now();
+        c->have_t_step_end = true;
     }
     if (force_out) std::memcpy(force_out, c->last_total.data(), c->Dloc * sizeof(double));
 }
@@ -1150,6 +1165,12 @@ void added_mass_begin(hc_ctx* c, const double* w, double cc, const double* R, in
         c->am_lane   = (c->dq->ensure_lane(1, &why) && direct_selftest_rewrites(c, c->dq, 1, &abandon)) ? 1 : -1;
         c->direct_why.clear();  // (the step path's lane stays in use whatever the second lane's test said)
     }
+    if (c->arm_mode == 1) {
+        const auto now  = std::chrono::steady_clock::now();
+        c->arm_after_am = c->have_t_am_end && std::chrono::duration<double>(now - c->t_am_end).count() > 25e-6;
+    } else {
+        c->arm_after_am = c->arm_mode == 2;
+    }
     if (c->direct_ready && bar && c->am_lane == 1) {
         // the second lane of the direct queue: an AQL packet instead of a HIP launch, independent of the step path's lane
         hc::AddedMassArgs a{c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq};
@@ -1166,8 +1187,14 @@ void added_mass_begin(hc_ctx* c, const double* w, double cc, const double* R, in
 void added_mass_end(hc_ctx* c, double* R) {
     const int how = c->pending_am;
     c->pending_am = 0;
-    if (how == 1) wait_tagged(c, c->h_tag_am.p, c->seq_am, nullptr, R + 6 * c->b0, 1);
-    else if (how == 2) wait_tagged(c, c->h_tag_am.p, c->seq_am, c->stream_am, R + 6 * c->b0);
+    if (how == 1) {
+        wait_tagged(c, c->h_tag_am.p, c->seq_am, nullptr, R + 6 * c->b0, 1);
+        if (c->direct_ready && c->arm_after_am) c->dq->arm(1);  // the same parking for the added-mass lane
+    } else if (how == 2) {
+        wait_tagged(c, c->h_tag_am.p, c->seq_am, c->stream_am, R + 6 * c->b0);
+    }
+    c->t_am_end      = std::chrono::steady_clock::now();
+    c->have_t_am_end = true;
 }
 }  // namespace
 

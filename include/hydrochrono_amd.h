@@ -233,6 +233,8 @@ int hc_set_lookahead(hc_ctx* ctx, int steps);
  * host re-writes are re-read, not served stale); it saves the 2.4-3.3 us a hipLaunchKernelGGL call costs the host on the critical
  * path of every step (all kernels of hc_step / hc_step_begin / hc_step_multi and hc_added_mass_mv go this way, for systems of
  * every size).  0: through HIP launches on the context's stream (HC_DIRECT=0 forces this); hc_dispatch_mode_reason then says why.
+ * Between steps of a caller that stays away for a while (a Chrono loop integrating) the library leaves its queue parked on a
+ * barrier packet, so that the next step's kernel starts without the ~6 us an idle queue needs (HC_ARM=0 disables it).
  * A dispatch that never completes, or a queue the runtime reports broken, ends the wait after HC_STEP_TIMEOUT_S (default 20 s)
  * with HC_ERR_DEVICE; the context then fails every later step the same way.  The kernels and the results are the same either way.  hc_step_device always uses HIP,
  * and so does hc_step while hc_enable_profiling is on under a tool that intercepts HSA queues (rocprofv3): the tool sees direct

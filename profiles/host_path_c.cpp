@@ -5,13 +5,14 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "hydrochrono_amd.h"
 
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static int run(int N, int S, int direct) {
+static int run(int N, int S, double gap_us) {
     hc_ctx* c = nullptr;
     if (hc_create(N, 0, &c) != HC_OK) { std::printf("hc_create: %s\n", hc_last_error(nullptr)); return 1; }
     if (hc_synth_fill(c, 20251031ull, S, 0.01, 0, 0.01) != HC_OK || hc_finalize(c) != HC_OK || hc_set_wave_none(c, N) != HC_OK) {
@@ -28,7 +29,7 @@ static int run(int N, int S, int direct) {
             ang[k] = 0.035 * std::cos(0.7 * t + 2 * k);
         }
     };
-    const int warm = S + 80, reps = 4000;
+    const int warm = S + 80, reps = gap_us > 0.0 ? 1500 : 4000;
     std::vector<double> ts, ta;
     double t = 0.0;
     for (int n = 0; n < warm + reps; ++n, t += 0.01) {
@@ -42,21 +43,27 @@ static int run(int N, int S, int direct) {
         hc_added_mass_mv(c, aw.data(), 1.0, aR.data(), D);
         const double b2 = now_us();
         if (n >= warm) { ts.push_back(b - a); ta.push_back(b2 - a2); }
+        if (gap_us > 0.0) {  // a Chrono-like loop: the host works between two force evaluations
+            const double g0 = now_us();
+            while (now_us() - g0 < gap_us) {
+            }
+        }
     }
     std::sort(ts.begin(), ts.end());
     std::sort(ta.begin(), ta.end());
     double mean = 0;
     for (double v : ts) mean += v;
+    if (gap_us > 0.0) std::printf("(%.0f us of host work between calls) ", gap_us);
     std::printf("N = %2d, S = %4d, %s: hc_step median %6.2f us  mean %6.2f  p10 %6.2f  p90 %6.2f | hc_added_mass_mv median %6.2f us\n", N, S,
                 hc_direct_dispatch_active(c) ? "direct AQL dispatch" : "HIP launches       ", ts[ts.size() / 2], mean / ts.size(), ts[ts.size() / 10],
                 ts[ts.size() * 9 / 10], ta[ta.size() / 2]);
-    (void)direct;
     hc_destroy(c);
     return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const double gap_us = argc > 1 ? std::atof(argv[1]) : 0.0;  // optional: microseconds of host work between calls
     for (int N : {1, 2, 64})
-        if (run(N, N == 64 ? 1024 : 1001, 1)) return 1;
+        if (run(N, N == 64 ? 1024 : 1001, gap_us)) return 1;
     return 0;
 }

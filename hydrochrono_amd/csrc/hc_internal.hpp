@@ -64,6 +64,8 @@ extern const char* const kVersion;
 
 
 // ---- hc_runtime.cpp ----
+int contexts_on_device(int device);             // contexts this process holds on a device (hc_create_sharded / hc_destroy keep count)
+void count_context_on_device(int device, int delta);
 void quiesce_direct(hc_ctx* c);  // waits for what the direct queue still runs (bounded; HC_ERR_DEVICE on a lost device)
 void require(bool cond, int status, const char* msg);
 void check_body(const hc_ctx* c, int body);

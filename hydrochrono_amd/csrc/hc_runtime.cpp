@@ -3,6 +3,8 @@
 // that runs in hc_kernels.hip on the GPU; there is no CPU fallback.
 #include "hc_internal.hpp"
 
+#include <atomic>
+
 using namespace hc::detail;
 
 // Fine-grained device allocation + a fault-free test of whether the CPU can address it: read(2) from /dev/zero INTO the
@@ -39,6 +41,14 @@ namespace detail {
 thread_local std::string g_create_error;
 
 const char* const kVersion = "hydrochrono_amd 0.1 (gfx950)";
+
+namespace {
+std::atomic<int> g_contexts_on_device[64];
+}
+int contexts_on_device(int device) { return (device >= 0 && device < 64) ? g_contexts_on_device[device].load(std::memory_order_relaxed) : 0; }
+void count_context_on_device(int device, int delta) {
+    if (device >= 0 && device < 64) g_contexts_on_device[device].fetch_add(delta, std::memory_order_relaxed);
+}
 
 // Bounded: a queue that does not drain within HC_STEP_TIMEOUT_S (or reports an error) is a lost device -> HC_ERR_DEVICE.
 void quiesce_direct(hc_ctx* c) {

@@ -86,6 +86,7 @@ int hc_create_sharded(int num_bodies, int body_begin, int body_end, int device_i
         HC_HIP(hipEventCreateWithFlags(&c->ev_bg, hipEventDisableTiming));
         hc_tapered_direct_options_default(&c->taper);
         hc_irregular_wave_params_default(&c->irr);
+        count_context_on_device(device_id, +1);
         *out = c.release();
     } catch (const Error& e) {
         g_create_error = e.what();
@@ -101,6 +102,7 @@ int hc_create(int num_bodies, int device_id, hc_ctx** out) { return hc_create_sh
 
 void hc_destroy(hc_ctx* ctx) {
     if (!ctx) return;
+    count_context_on_device(ctx->device, -1);
     (void)hipSetDevice(ctx->device);
     delete ctx->dq;  // drains its queue
     ctx->dq = nullptr;

@@ -808,7 +808,10 @@ void step_end(hc_ctx* c, double* force_out) {
         // next step's kernel starts at once instead of after the ~6 us an idle queue needs (DirectQueue::arm).
         // (Not when the process holds several contexts on this device -- row shards sharing a GPU: a parked queue keeps a hardware
         // queue slot busy and slows the other contexts' queues down, 19.8 -> 32-70 us for two contexts on one GPU.)
-        if (c->path == 2 && c->direct_ready && c->arm_after_step && contexts_on_device(c->device) == 1) c->dq->arm(0);
+        if (c->path == 2 && c->direct_ready && c->arm_after_step && contexts_on_device(c->device) == 1) {
+            c->dq->arm(0);
+            c->prof.queue_parkings++;
+        }
         c->t_step_end      = std::chrono::steady_clock::now();
         c->have_t_step_end = true;
     }
@@ -1191,7 +1194,10 @@ void added_mass_end(hc_ctx* c, double* R) {
     c->pending_am = 0;
     if (how == 1) {
         wait_tagged(c, c->h_tag_am.p, c->seq_am, nullptr, R + 6 * c->b0, 1);
-        if (c->direct_ready && c->arm_after_am && contexts_on_device(c->device) == 1) c->dq->arm(1);  // the same parking for the added-mass lane
+        if (c->direct_ready && c->arm_after_am && contexts_on_device(c->device) == 1) {  // the same parking for the added-mass lane
+            c->dq->arm(1);
+            c->prof.queue_parkings++;
+        }
     } else if (how == 2) {
         wait_tagged(c, c->h_tag_am.p, c->seq_am, c->stream_am, R + 6 * c->b0);
     }

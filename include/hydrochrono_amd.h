@@ -291,6 +291,7 @@ typedef struct hc_profile_stats {
     long long history_rewinds;     /* steps back in time handled by dropping the newer history samples (see hc_step) */
     double mini_pass_seconds;      /* short passes of the two-level look-ahead of wide systems (one per sub-block of 8 steps) */
     long long mini_pass_launches;
+    long long queue_parkings;      /* times the direct queue was left parked on a barrier packet after a step / an added-mass product */
 } hc_profile_stats;
 /* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default), and around every
  * look-ahead pass (one per block) whatever the stride.  Event records perturb the launch stream by a few

@@ -190,3 +190,41 @@ def test_tapered_direct_diagnostics_csv(HF, tmp_path, opts):
     quiet.set_diagnostics_output_directory(tmp_path / "does" / "not" / "exist")
     quiet.set_tapered_direct_options(export_plot_csv=True)
     assert np.all(np.isfinite(quiet.compute_radiation(0.0, z, z)))
+
+
+@pytest.mark.parametrize("arm", ["1", "0", "2"])
+def test_queue_parking_between_steps_of_a_caller_that_stays_away(HF, arm, monkeypatch):
+    """A caller that works between force evaluations (a Chrono loop) finds the direct queue parked on a barrier packet (DirectQueue::arm:
+    no idle penalty at the next dispatch); a tight loop does not.  Same forces either way, other entry points between the steps drain
+    a parked queue without hanging."""
+    import gc
+    import time
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    gc.collect()  # contexts of earlier tests must be gone: the library parks only while it holds ONE context on the device
+    monkeypatch.setenv("HC_ARM", arm)
+    case = many_body_case(3, S=96, dt_rirf=0.01, n_exc=33, seed=12)
+    gpu, orc = HF.from_case(case), load_into_oracle(case)
+    gpu.add_waves_regular(0.5, 0.9)
+    orc.add_waves_regular(0.5, 0.9)
+    assert gpu.direct_dispatch()[0]
+    motion = PrescribedMotion(3, rest_positions(case), seed=4)
+    w = np.linspace(-1, 1, 18)
+    for n in range(200):
+        t = 0.01 * n
+        st = motion.state(t)
+        assert relerr(gpu.step(t, *st), orc.step(t, *st)) <= TIGHT_TOL
+        if n >= 100:
+            time.sleep(200e-6)            # the host is away: the next call finds a parked queue (adaptive / always)
+            if n % 10 == 0:
+                gpu.components()          # a HIP-side entry point drains the parked queue
+            if n % 7 == 0:
+                assert relerr(gpu.added_mass_mv(np.zeros(18), w, 1.0), gpu.added_mass_matrix() @ w) <= 1e-13
+    parkings = gpu.profile()["queue_parkings"]
+    if arm == "0":
+        assert parkings == 0
+    elif arm == "1":
+        assert 60 <= parkings, parkings   # the spaced-out second half (the oracle's own step takes longer than the threshold, too)
+    else:
+        assert parkings >= 200
+    gpu.close()

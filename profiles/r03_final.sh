@@ -24,6 +24,8 @@ W=1 python $R/profiles/shard_probe.py 2>/dev/null > $O/shard_probe_c4_one_gpu.tx
 python $R/profiles/host_path.py > $O/host_path.json 2>/dev/null
 g++ -O2 -std=c++17 $R/profiles/multi_path_c.cpp -I $R/include -L $R/hydrochrono_amd/lib -lhydrochrono_amd -Wl,-rpath,$R/hydrochrono_amd/lib -o /tmp/multi_path_c && { /tmp/multi_path_c 64 1024 3000; /tmp/multi_path_c 512 1024 320; } 2>/dev/null > $O/multi_path_c.txt
 g++ -O2 -std=c++17 $R/profiles/host_path_c.cpp -I $R/include -L $R/hydrochrono_amd/lib -lhydrochrono_amd -Wl,-rpath,$R/hydrochrono_amd/lib -o /tmp/host_path_c && /tmp/host_path_c 2>/dev/null > $O/host_path_c.txt
+{ for g in 100 300; do /tmp/host_path_c $g; HC_ARM=0 /tmp/host_path_c $g | sed "s/^/HC_ARM=0 /"; done; } 2>/dev/null > $O/host_path_c_with_gaps_run.txt
+W=1 python $R/profiles/plain_c4_probe.py 2>/dev/null > $O/plain_kernel_c4_sizes_run.txt; W=8 python $R/profiles/plain_c4_probe.py 2>/dev/null >> $O/plain_kernel_c4_sizes_run.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/stats_default.log 2>&1
 export W=8

@@ -186,7 +186,8 @@ int hc_step_multi(hc_ctx* const* ctxs, int n_ctx, double t, const double* pos, c
 /* One process per GPU (an MPI-style host, or this repo's benchmark under torch.distributed.run): the host gather without a collective.
  * hc_set_result_buffer makes the step kernel deliver this context's tagged results -- 16-byte {value, step sequence number} granules,
  * 2 x D_local of them, the two halves used by consecutive steps in turn -- into memory the caller provides, e.g. a POSIX
- * shared-memory segment every process of the node maps (the library registers it with the GPU; NULL returns to the internal buffer).
+ * shared-memory segment every process of the node maps (the library registers it with the GPU; NULL returns to the internal buffer;
+ * the memory must stay mapped until then or until hc_destroy).  `rows` of hc_wait_result_buffer = D_local of the shard that writes the buffer.
  * After hc_step_begin each process collects every shard's rows with hc_wait_result_buffer (host-only: it spins on the granules of the
  * given sequence number -- hc_step_sequence of the own context; contexts driven in lockstep count alike -- and copies the values
  * out; HC_ERR_DEVICE after timeout_seconds, <= 0: HC_STEP_TIMEOUT_S / 20 s), then completes its own step with hc_step_end. */

@@ -40,7 +40,8 @@ class ProfileStats(C.Structure):
                 ("step_kernel_seconds", C.c_double), ("step_kernel_launches", C.c_longlong),
                 ("scatter_kernel_seconds", C.c_double), ("scatter_kernel_launches", C.c_longlong),
                 ("direct_dispatches", C.c_longlong), ("hip_launches", C.c_longlong), ("history_rewinds", C.c_longlong),
-                ("mini_pass_seconds", C.c_double), ("mini_pass_launches", C.c_longlong), ("queue_parkings", C.c_longlong)]
+                ("mini_pass_seconds", C.c_double), ("mini_pass_launches", C.c_longlong), ("queue_parkings", C.c_longlong),
+                ("ahead_pass_slices", C.c_longlong), ("ahead_blocks", C.c_longlong)]
 
 
 # name -> (restype, argtypes); every symbol include/hydrochrono_amd.h declares
@@ -87,6 +88,7 @@ SIGNATURES = {
     "hc_compute_hydrostatics": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "hc_compute_waves": (C.c_int, [C.c_void_p, C.c_double, c_double_p]),
     "hc_set_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
+    "hc_set_pass_schedule": (C.c_int, [C.c_void_p, C.c_int]),
     "hc_direct_dispatch_active": (C.c_int, [C.c_void_p]),
     "hc_dispatch_mode_reason": (C.c_char_p, [C.c_void_p]),
     "hc_reset_history": (C.c_int, [C.c_void_p]),

@@ -116,6 +116,20 @@ struct StepTail {
     hipStream_t stream = nullptr;
 };
 
+// Pass schedule "one block ahead" (hc_step.cpp, hc_plan.hpp: FarPass): the pass of the NEXT block while the current one is stepped.
+struct AheadPass {
+    bool active = false;                 // its launches are going out / its rows are being completed by the short passes of this block
+    unsigned long long plan_serial = 0;  // the plan (block) it is computed under
+    int slices = 0, issued = 0;          // launches the radiation chunks are spread over, and how many have gone out
+    int per_slice = 0;                   // radiation chunks per launch (whole octets)
+    bool reduced = false;                // the reduction into the next block's rows has gone out
+    bool has_exc = false;                // it also leaves the excitation force of the next block's predicted times
+    int Hcap = 0;                        // ring capacity of the history view (a re-allocated ring voids the view)
+    double t_first = 0.0, t_last = 0.0;  // predicted times of the next block's first and last step
+    double rad_once = 0.0, exc_once = 0.0;
+    BlockArgs args;                      // the whole launch; chunk_first / chunk_last are set per slice
+};
+
 // Bodies that share one excitation-IRF time grid: columns [off, off + L) of Kex / ex_tau / ex_width are the group's resampled grid.
 struct ExGroup {
     int first_body = 0, off = 0, L = 0;
@@ -229,6 +243,12 @@ struct hc_ctx {
     int num_cus  = 256;                                 // compute units of the device (grid rounds of the look-ahead launch)
     int lookahead = 0;  // 0: off, else kLookahead
     hc::Plan plan;
+    unsigned long long plan_serial = 0;  // counts the plans made
+    // pass schedule (hc_set_pass_schedule): 0 = the pass of a block when the block starts, 1 = one block ahead, in `pass_slices`
+    // launches between the steps of the block before.  d_P / d_E hold two blocks of rows; pe_cur = the half of the current block.
+    int pass_ahead = 0, pass_slices = 8, pe_cur = 0;
+    hc::AheadPass ahead;
+    hc::DeviceBuffer<double> d_partials_far;  // partial sums of the pass in the making (the short passes keep d_partials_block)
 
     // step I/O
     hc::DeviceBuffer<double> d_state, d_hs, d_rad, d_waves, d_total;

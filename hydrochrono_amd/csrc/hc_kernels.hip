@@ -881,9 +881,9 @@ __global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs
     // of one chunk gather the same ring rows, so they get block indices that are congruent mod 8 and close together
     // ([octet of chunks][row group][chunk % 8]): the gathers of all but the first then hit that XCD's L2.
     const int r     = (int)blockIdx.x % (8 * a.ngroups);
-    const int chunk = ((int)blockIdx.x / (8 * a.ngroups)) * 8 + (r & 7);
+    const int chunk = a.chunk_first + ((int)blockIdx.x / (8 * a.ngroups)) * 8 + (r & 7);
     const int grp   = r >> 3;
-    if (chunk >= a.nchunks) return;
+    if (chunk >= (a.chunk_last > 0 ? a.chunk_last : a.nchunks)) return;
 
     // the per-DoF ring must be addressable with 32-bit byte offsets for the scalar-base form (4 GB: far beyond any real history)
     if ((a.hist.D & 7) == 0 && (size_t)a.hist.D * a.hist.HcapT < ((size_t)1 << 28)) block_rad_stream_uni<MT, R, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
@@ -945,7 +945,8 @@ static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, h
 
 BlockLaunch block_launch_config(const BlockArgs& a, int mt, BlockArgs* b) {
     BlockLaunch l;
-    l.nblocks = ((a.nchunks + 7) >> 3) * 8 * a.ngroups;  // octets of chunks, see the kernel's block mapping
+    const int nlaunch = (a.chunk_last > 0 ? a.chunk_last : a.nchunks) - a.chunk_first;  // chunks of this launch
+    l.nblocks = ((nlaunch + 7) >> 3) * 8 * a.ngroups;  // octets of chunks, see the kernel's block mapping
     *b        = a;
     b->lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // [wave][tile][16x16] reduction buffer / per-wave U sub-tiles
     l.smem    = (size_t)b->lds_front_doubles * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * b->depth * 24;
@@ -988,7 +989,7 @@ __global__ void __launch_bounds__(256) reduce_block_kernel(ReduceArgs a) {
     int out       = blockIdx.x * 16 + (threadIdx.x >> 4);  // [segment][j*Dpad + row]
     const bool exc = out >= n;
     if (exc) out -= n;
-    const int first = exc ? a.nchunks_rad : 0, count = exc ? a.nchunks_ex : a.nchunks_rad;
+    const int first = exc ? a.nchunks_rad : a.rad_first, count = exc ? a.nchunks_ex : a.nchunks_rad - a.rad_first;
     const int o     = out < n ? out : 0;
     double v = 0.0;
     for (int c = sub; c < count; c += 8 * 16) {

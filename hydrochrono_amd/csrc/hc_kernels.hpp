@@ -140,7 +140,12 @@ struct BlockArgs {
     // (mini_time[k], history index k = 0 .. mini_kw + 1, index 0 = hist.t), not from the ring, so the bracket of every
     // (IRF sample, step) is the planner's bit for bit.  Steps j >= mini_steps are empty.
     int mini_kw, mini_steps;
-    double mini_time[kSubBlock + 2];
+    double mini_time[kLookahead + 2];
+    // A launch may cover a range of the radiation chunks only (chunk_last == 0: all of them): the pass of the NEXT block is issued in
+    // slices between the steps of the current one (hc_step.cpp: pass schedule "one block ahead"), and a short pass towards the next
+    // block starts at the first IRF sample it needs.  Partials are indexed by the absolute chunk number either way, so the sums
+    // reduce_block_kernel forms do not depend on how the chunks were spread over launches.
+    int chunk_first, chunk_last;
 };
 
 // near_split_kernel (wide systems): the step's own-sample part  K[rows of a tile, columns of the near samples] x u  split over
@@ -251,7 +256,8 @@ struct ReduceArgs {
     int nchunks_rad, nchunks_ex, Dpad, depth;
     double *P, *E;
     int* item_counter;
-    int accumulate, j_off, j_cnt, pad;
+    int accumulate, j_off, j_cnt;
+    int rad_first;  // first radiation chunk to add (short passes that start past IRF sample 0)
 };
 static_assert(sizeof(ReduceArgs) == 64, "kernarg layout of reduce_block_kernel");
 

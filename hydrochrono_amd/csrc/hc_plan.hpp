@@ -18,7 +18,7 @@ struct Plan {
     bool valid = false;
     double dt = 0.0;
     int j_next = 1;                       // next block step, 1..L
-    double tgrid[kLookahead + 1] = {0};
+    double tgrid[2 * kLookahead + 2] = {0};  // predicted times of this block (1..L) and of the one after it (L+1..2L, pass schedule "one block ahead")
     int s_cut[kLookahead]    = {0};       // pass: block step j+1 takes IRF samples s >= s_cut[j]
     int s_defer[kLookahead]  = {0};       // IRF sample whose "is there an older history sample" test is too close to call ahead of time (-1: none)
     // block step m = 1..L (index m): IRF samples involving the step's own sample (weight x width) ...
@@ -67,7 +67,7 @@ inline bool build_plan(Plan& pl, int lookahead, const std::deque<double>& times,
         return false;
     }
     pl.dt = dt;
-    for (int j = 0; j <= L; ++j) pl.tgrid[j] = (j == 0) ? t0 : t0 + j * dt;
+    for (int j = 0; j <= 2 * L + 1; ++j) pl.tgrid[j] = (j == 0) ? t0 : t0 + j * dt;
     auto G = [&](int idx) { return idx >= 1 ? pl.tgrid[idx] : times[static_cast<size_t>(-idx)]; };  // idx > -H
     pl.sub    = (sub > 0 && sub < L) ? sub : 0;
     pl.slices = slices;
@@ -154,7 +154,8 @@ inline bool build_plan(Plan& pl, int lookahead, const std::deque<double>& times,
 // that has just ended (history indices 1..kw of the view whose sample 0 is the not-yet-known step i0 + 1).
 struct MiniPass {
     int kw = 0, n_steps = 0, n_samples = 0;
-    double time[kSubBlock + 2] = {0};     // predicted-grid times of history indices 0 .. kw + 1
+    int s_first = 0;                       // first IRF sample any of its steps takes
+    double time[kLookahead + 2] = {0};     // predicted-grid times of history indices 0 .. kw + 1
     double tpred[kLookahead]   = {0};
     int s_cut[kLookahead]      = {0};
     int s_defer[kLookahead]    = {0};
@@ -178,6 +179,71 @@ inline MiniPass mini_pass_setup(const Plan& pl, int lookahead, int i0, const std
         }
         mp.s_cut[j] = sc;
     }
+    mp.s_first = mp.s_cut[0];
+    return mp;
+}
+
+// Pass schedule "one block ahead" (hc_step.cpp).  The pass of block b + 1 is computed while block b is being stepped, from the
+// history known when block b was planned -- the plain pass of the same virtual step at tgrid[1], for the predicted times
+// tgrid[L + 1 .. 2L]: FarPass.  What the samples of block b itself contribute to the steps of block b + 1 is added by short passes
+// like those of the two-level form, one per window of block-b samples (a sub-block, or the whole block for the single-level form),
+// right after the window's last step i0: mini_pass_next.  Both are only used while the history covers the whole IRF window
+// (far_pass_allowed), so no "is there an older sample" decision (s_defer) is ever involved.
+struct FarPass {
+    double tpred[kLookahead] = {0};
+    int s_cut[kLookahead]    = {0};
+};
+
+inline bool far_pass_allowed(const Plan& pl, int lookahead, const std::deque<double>& times, const std::vector<double>& tau) {
+    if (!pl.valid || times.size() < 2 || tau.empty()) return false;
+    const double span   = pl.dt * (2 * lookahead + 1);
+    const double margin = 8.0 * std::max(1e-9 * pl.dt, 64.0 * std::numeric_limits<double>::epsilon() * std::fabs(pl.tgrid[2 * lookahead]));
+    if (span > 0.5 * (tau.back() - tau.front())) return false;          // the short passes towards the next block would stream most of K
+    for (int j = 0; j < lookahead; ++j)
+        if (pl.s_defer[j] >= 0) return false;
+    return pl.tgrid[1] - times.back() > tau.back() + margin;            // every IRF sample of every step has an older history sample
+}
+
+inline FarPass far_pass_setup(const Plan& pl, int lookahead, const std::vector<double>& tau) {
+    FarPass fp;
+    const int S = static_cast<int>(tau.size());
+    for (int j = 0; j < kLookahead; ++j) {
+        const int m  = std::min(lookahead + 1 + j, 2 * lookahead);
+        fp.tpred[j]  = pl.tgrid[m];
+        int sc = S;
+        if (j < lookahead) {
+            sc = 0;
+            while (sc < S && !(pl.tgrid[m] - tau[sc] <= pl.tgrid[1])) ++sc;  // same expression as the pass of the block
+        }
+        fp.s_cut[j] = sc;
+    }
+    return fp;
+}
+
+// The short pass towards the next block after block step i0 (i0 = sub, 2*sub, .., L; single-level form: i0 = L): window = the kw
+// block samples that end at i0, steps = the L steps of the next block.
+inline MiniPass mini_pass_next(const Plan& pl, int lookahead, int i0, const std::vector<double>& tau) {
+    MiniPass mp;
+    const int S = static_cast<int>(tau.size());
+    mp.kw       = pl.sub > 0 ? pl.sub : lookahead;
+    mp.n_steps  = lookahead;
+    for (int k = 0; k <= mp.kw + 1; ++k) mp.time[k] = pl.tgrid[i0 + 1 - k];  // i0 >= kw
+    for (int j = 0; j < kLookahead; ++j) {
+        const int m   = std::min(lookahead + 1 + j, 2 * lookahead);
+        mp.tpred[j]   = pl.tgrid[m];
+        mp.s_defer[j] = -1;
+        int sc = S;
+        if (j < mp.n_steps) {
+            sc = 0;
+            while (sc < S && !(pl.tgrid[m] - tau[sc] <= pl.tgrid[i0 + 1])) ++sc;
+        }
+        mp.s_cut[j] = sc;
+    }
+    mp.s_first = mp.s_cut[0];
+    // last IRF sample whose bracket can touch the window: the query of the LAST step must not be older than the sample before the window
+    int hi = mp.s_first - 1;
+    while (hi + 1 < S && pl.tgrid[2 * lookahead] - tau[hi + 1] >= pl.tgrid[i0 - mp.kw]) ++hi;
+    mp.n_samples = hi + 1;
     return mp;
 }
 

@@ -343,10 +343,17 @@ void alloc_partials(hc_ctx* c) {
     if (c->d_partials.n < n) c->d_partials.alloc(n);
     // (the short passes of the two-level form use the same buffer: IRF samples s < kScatterSamples -- the planner refuses blocks whose
     // in-block brackets reach further -- in chunks of at least half a sample)
-    const size_t nb = static_cast<size_t>(std::max(c->nchunks_block + c->nchunks_ex_block, 2 * hc::kScatterSamples + 2)) * hc::kLookahead * c->Dpad;
+    // (pass schedule "one block ahead": its short passes towards the next block reach twice as far, and the pass in the making keeps
+    // a buffer of its own while the short passes of the current block use this one)
+    const int mini_chunks = (c->pass_ahead ? 4 : 2) * hc::kScatterSamples + 2;
+    const size_t nb = static_cast<size_t>(std::max(c->nchunks_block + c->nchunks_ex_block, mini_chunks)) * hc::kLookahead * c->Dpad;
     if (c->d_partials_block.n < nb) c->d_partials_block.alloc(nb);
-    if (c->d_P.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_P.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
-    if (c->d_E.n < static_cast<size_t>(hc::kLookahead) * c->Dpad) c->d_E.alloc(static_cast<size_t>(hc::kLookahead) * c->Dpad);
+    const size_t nfar = static_cast<size_t>(c->nchunks_block + c->nchunks_ex_block) * hc::kLookahead * c->Dpad;
+    if (c->pass_ahead && c->d_partials_far.n < nfar) c->d_partials_far.alloc(nfar);
+    // two blocks of rows each: the current block's and (pass schedule "one block ahead") the next one's
+    const size_t npe = static_cast<size_t>(2 * hc::kLookahead) * c->Dpad;
+    if (c->d_P.n < npe) c->d_P.alloc(npe);
+    if (c->d_E.n < npe) c->d_E.alloc(npe);
     const size_t ny = static_cast<size_t>(hc::kLookahead + 1) * hc::kTermMax * c->Dpad;
     if (c->d_Y.n < ny) c->d_Y.alloc(ny);
     if (c->d_near_partials.n < static_cast<size_t>(16) * c->Dpad) c->d_near_partials.alloc(static_cast<size_t>(16) * c->Dpad);

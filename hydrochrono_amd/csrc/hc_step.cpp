@@ -111,7 +111,15 @@ int plan_sub_block(const hc_ctx* c) {
     return hc::near_slices_for(c->D) > 1 ? hc::kSubBlock : 0;
 }
 
-bool make_plan(hc_ctx* c) { return hc::build_plan(c->plan, c->lookahead, c->times, c->tau, c->width, plan_sub_block(c), hc::near_slices_for(c->D)); }
+bool make_plan(hc_ctx* c) {
+    const bool ok = hc::build_plan(c->plan, c->lookahead, c->times, c->tau, c->width, plan_sub_block(c), hc::near_slices_for(c->D));
+    if (ok) ++c->plan_serial;
+    return ok;
+}
+
+// rows of the current block / of the block after it in d_P and d_E (two blocks of kLookahead rows each)
+double* rows_P(hc_ctx* c, bool next) { return c->d_P.p + static_cast<size_t>(next ? 1 - c->pe_cur : c->pe_cur) * hc::kLookahead * c->Dpad; }
+double* rows_E(hc_ctx* c, bool next) { return c->d_E.p + static_cast<size_t>(next ? 1 - c->pe_cur : c->pe_cur) * hc::kLookahead * c->Dpad; }
 
 struct StepViews {
     hc::Panel kex;
@@ -135,10 +143,18 @@ StepViews make_views(const hc_ctx* c) {
     return v;
 }
 
-// The look-ahead pass of the plan just made: for the 16 predicted steps, what the samples known now contribute.  It runs as
+// The look-ahead pass of the plan just made: for the 16 / 32 predicted steps, what the samples known now contribute.  It runs as
 // the plain pass of a (virtual) step at tgrid[1] whose own sample is zero -- that sample's share is added later by the
 // step itself and by its scatter.  Enqueued behind the step that has just been evaluated (its ring push included).
-void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = false) {
+// next_block: the same pass for the predicted steps of the block AFTER this one (hc_plan.hpp: FarPass) -- the view of the history
+// is the same, only the query times move on by a block.
+struct PassSetup {
+    hc::BlockArgs b;
+    bool exc_block = false;
+    double rad_once = 0.0, exc_once = 0.0, bytes_steps = 0.0;
+};
+
+PassSetup make_pass(hc_ctx* c, bool with_exc, bool next_block) {
     auto& pl = c->plan;
     const int L = c->lookahead;
     const int H = static_cast<int>(c->times.size());
@@ -163,7 +179,9 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = fal
     hv.dt_hint = pl.dt;
 
     const StepViews vw = make_views(c);
-    hc::BlockArgs b{};
+    PassSetup ps;
+    hc::BlockArgs& b = ps.b;
+    b                     = hc::BlockArgs{};
     b.K                   = rad_panel(c);
     b.F                   = std::min(c->S, live_samples(c, pl.tgrid[L])) * c->D;
     b.depth               = L;
@@ -171,10 +189,19 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = fal
     b.nchunks             = std::max(1, ((b.F + 7) / 8 + c->chunk_gp_block - 1) / c->chunk_gp_block);
     b.max_steps_per_chunk = (c->chunk_gp_block * 8) / c->D + 2;
     b.hist                = hv;
-    for (int j = 0; j < L; ++j) {
-        b.tpred[j]   = pl.tgrid[j + 1];
-        b.s_cut[j]   = pl.s_cut[j];
-        b.s_defer[j] = pl.s_defer[j];
+    if (next_block) {
+        const hc::FarPass fp = hc::far_pass_setup(pl, L, c->tau);
+        for (int j = 0; j < L; ++j) {
+            b.tpred[j]   = fp.tpred[j];
+            b.s_cut[j]   = fp.s_cut[j];
+            b.s_defer[j] = -1;
+        }
+    } else {
+        for (int j = 0; j < L; ++j) {
+            b.tpred[j]   = pl.tgrid[j + 1];
+            b.s_cut[j]   = pl.s_cut[j];
+            b.s_defer[j] = pl.s_defer[j];
+        }
     }
     b.tau   = c->d_tau.p;
     b.width = c->d_width.p;
@@ -182,13 +209,13 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = fal
     // over Kex in the same launch) -- provided every predicted time passes the window tests a real step would have to pass.
     static const bool exc_in_block = env_int("HC_EXC_IN_BLOCK", 1) != 0;
     bool exc_block = exc_in_block && with_exc && c->wave_kind == hc::kWaveIrregular && c->nchunks_ex_block > 0;
-    for (int j = 1; j <= L && exc_block; ++j) exc_block = wave_window_ok(c, pl.tgrid[j]);
-    pl.has_exc    = exc_block;
+    for (int j = 0; j < L && exc_block; ++j) exc_block = wave_window_ok(c, b.tpred[j]);
+    ps.exc_block  = exc_block;
     b.Kex         = vw.kex;
     b.ex          = vw.ex;
     b.chunk_gp_ex = c->chunk_gp_ex_block;
     b.nchunks_ex  = exc_block ? c->nchunks_ex_block : 0;
-    b.partials    = c->d_partials_block.p;
+    b.partials    = next_block ? c->d_partials_far.p : c->d_partials_block.p;
     b.Dpad        = c->Dpad;
     b.error_flag  = c->d_err.p;
     b.item_counter = c->d_err.p + 1;
@@ -196,24 +223,37 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = fal
     // algorithmic bytes: summed over the steps of the block, step j's share of K and of the velocity vector from s_cut[j]
     // on ...; what the launch has to move once: the live part of K, Kex and the staged vectors
     double samples = 0.0;
-    for (int j = 0; j < L; ++j) samples += std::max(0, b.F / c->D - pl.s_cut[j]);
+    for (int j = 0; j < L; ++j) samples += std::max(0, b.F / c->D - b.s_cut[j]);
     const double rad_16 = 8.0 * samples * (static_cast<double>(c->Dloc) * c->D + c->D);
     const double exc_16 = exc_block ? 8.0 * L * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
-    c->prof.block_kernel_bytes      = rad_16 + exc_16;
-    const double rad_once = 8.0 * (static_cast<double>(c->Dloc) * b.F + b.F);
-    const double exc_once = exc_block ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
-    c->prof.block_kernel_bytes_once = rad_once + exc_once;
+    ps.bytes_steps = rad_16 + exc_16;
+    ps.rad_once    = 8.0 * (static_cast<double>(c->Dloc) * b.F + b.F);
+    ps.exc_once    = exc_block ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
     if (env_int("HC_DEBUG_PLAN", 0) != 0) {
-        std::fprintf(stderr, "[hc] pass t0=%.6f dt=%.17g Hv=%d F/D=%d nchunks=%d exc=%d\n     s_cut:", pl.tgrid[0], pl.dt, Hv, b.F / c->D, b.nchunks, (int)exc_block);
-        for (int j = 0; j < L; ++j) std::fprintf(stderr, " %d", pl.s_cut[j]);
+        std::fprintf(stderr, "[hc] pass%s t0=%.6f dt=%.17g Hv=%d F/D=%d nchunks=%d exc=%d\n     s_cut:", next_block ? " (next block)" : "", pl.tgrid[0], pl.dt, Hv,
+                     b.F / c->D, b.nchunks, (int)exc_block);
+        for (int j = 0; j < L; ++j) std::fprintf(stderr, " %d", b.s_cut[j]);
         std::fprintf(stderr, "\n     s_defer:");
-        for (int j = 0; j < L; ++j) std::fprintf(stderr, " %d", pl.s_defer[j]);
+        for (int j = 0; j < L; ++j) std::fprintf(stderr, " %d", b.s_defer[j]);
         std::fprintf(stderr, "\n     scat:");
         for (int i = 1; i <= L; ++i) std::fprintf(stderr, " [%d,%d]", pl.scat_lo[i], pl.scat_hi[i]);
         std::fprintf(stderr, "\n");
     }
+    return ps;
+}
+
+// One launch of the pass over the radiation chunks [first, last) (+ the excitation work items if with_items).
+void issue_pass_chunks(hc_ctx* c, const PassSetup& ps, int first, int last, bool with_items, hipStream_t stream, bool direct) {
+    hc::BlockArgs b = ps.b;
+    b.chunk_first   = first;
+    b.chunk_last    = last;
+    if (!with_items) b.nchunks_ex = 0;
+    const double share_rad = static_cast<double>(last - first) / std::max(1, ps.b.nchunks);
+    const double rad_once = ps.rad_once * share_rad, exc_once = with_items ? ps.exc_once : 0.0;
+    c->prof.block_kernel_bytes      = ps.bytes_steps * (rad_once + exc_once) / std::max(1.0, ps.rad_once + ps.exc_once);
+    c->prof.block_kernel_bytes_once = rad_once + exc_once;
     const double exc_share = exc_once / std::max(1.0, rad_once + exc_once);
-    const hc::ReduceArgs r{c->d_partials_block.p, b.nchunks, b.nchunks_ex, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter, 0, 0, 0, 0};
+    const int L = c->lookahead;
     if (direct) {
         hc::BlockArgs b2;
         const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_block, &b2);
@@ -221,26 +261,125 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = fal
         c->dq->dispatch(L == 32 ? c->dk_block32 : c->dk_block16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
                         direct_tag(c, hc::kEvPass), exc_share);
         c->prof.direct_dispatches += 1;
-        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r);
-        c->prof.direct_dispatches += 1;
         return;
     }
     hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_share);
     hc::launch_conv_block(b, c->mt_block, stream);
     ev_end(ev, stream);
+    c->prof.hip_launches += 1;
+}
+
+// ... and the reduction of its chunk partials into the rows P / E of a block.
+void issue_pass_reduce(hc_ctx* c, const PassSetup& ps, double* P, double* E, hipStream_t stream, bool direct) {
+    const hc::BlockArgs& b = ps.b;
+    const hc::ReduceArgs r{b.partials, b.nchunks, b.nchunks_ex, c->Dpad, c->lookahead, P, E, b.item_counter, 0, 0, 0, 0};
+    if (direct) {
+        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r);
+        c->prof.direct_dispatches += 1;
+        return;
+    }
     hc::launch_reduce_block(r, stream);
-    c->prof.hip_launches += 2;
+    c->prof.hip_launches += 1;
+}
+
+void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = false) {
+    const PassSetup ps = make_pass(c, with_exc, false);
+    c->plan.has_exc    = ps.exc_block;
+    issue_pass_chunks(c, ps, 0, ps.b.nchunks, true, stream, direct);
+    issue_pass_reduce(c, ps, rows_P(c, false), rows_E(c, false), stream, direct);
+}
+
+// ---- pass schedule "one block ahead" (hc_set_pass_schedule) ----------------------------------------
+// Begun right after the pass-free start of a block (or after the ordinary pass of the first block): the pass of the NEXT block, in
+// `pass_slices` launches -- one now, the others behind the scatter launches of the following steps -- so that a caller that
+// leaves the GPU idle between two force evaluations never waits for a whole pass.  The chunk partials of all slices are added by
+// ONE reduction after the last slice, in the order of the unsliced pass.
+void ahead_drop(hc_ctx* c) { c->ahead.active = false; }
+
+void ahead_issue_slice(hc_ctx* c, hipStream_t stream, bool direct) {
+    auto& ah = c->ahead;
+    if (!ah.active || ah.reduced) return;
+    if (ah.Hcap != c->Hcap || ah.plan_serial != c->plan_serial) { ahead_drop(c); return; }  // the ring was re-allocated under the view
+    PassSetup ps;
+    ps.b         = ah.args;
+    // (buffers that may have been re-allocated since the view was taken are re-read; the ring's geometry has been checked above)
+    ps.b.hist.ring_t  = c->d_ring_t.p;
+    ps.b.hist.ring_v  = c->d_ring_v.p;
+    ps.b.hist.ring_vT = c->d_ring_vT.p;
+    ps.exc_block = ah.has_exc;
+    ps.rad_once  = ah.rad_once;
+    ps.exc_once  = ah.exc_once;
+    ps.bytes_steps = ah.rad_once + ah.exc_once;
+    const int n = ps.b.nchunks, k = ah.issued;
+    const int first = std::min(n, k * ah.per_slice), last = std::min(n, (k + 1) * ah.per_slice);  // never empty, see ahead_begin
+    const bool final_slice = k + 1 >= ah.slices;
+    issue_pass_chunks(c, ps, first, last, final_slice, stream, direct);
+    ah.issued = k + 1;
+    c->prof.ahead_pass_slices += 1;
+    if (final_slice) {
+        issue_pass_reduce(c, ps, rows_P(c, true), rows_E(c, true), stream, direct);
+        ah.reduced = true;
+    }
+}
+
+void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
+    auto& ah = c->ahead;
+    ah.active = false;
+    const int L = c->lookahead;
+    if (!c->pass_ahead || L <= 0 || !hc::far_pass_allowed(c->plan, L, c->times, c->tau)) return;
+    const int kw = c->plan.sub > 0 ? c->plan.sub : L;
+    // the short passes towards the next block must fit the partials buffer (they stream up to twice the reach of the in-block ones)
+    const hc::MiniPass probe = hc::mini_pass_next(c->plan, L, kw, c->tau);
+    const int chunk_gp = std::max(16, (((c->D + 7) / 8 / 2 + 15) / 16) * 16);
+    const long long chunks = (static_cast<long long>(probe.n_samples) * c->D / 8 + chunk_gp) / chunk_gp + 1;
+    if (static_cast<size_t>(chunks) * L * c->Dpad > c->d_partials_block.n || c->d_partials_far.n == 0) return;
+    const PassSetup ps = make_pass(c, with_exc, true);
+    ah.args        = ps.b;
+    ah.has_exc     = ps.exc_block;
+    ah.rad_once    = ps.rad_once;
+    ah.exc_once    = ps.exc_once;
+    ah.Hcap        = c->Hcap;
+    ah.plan_serial = c->plan_serial;
+    ah.t_first     = c->plan.tgrid[L + 1];
+    ah.t_last      = c->plan.tgrid[2 * L];
+    // whole octets of chunks per slice (the kernel's block mapping deals octets), no empty slice; the reduction must be out before the
+    // first short pass adds to the rows, i.e. within the first sub-block
+    const int limit  = c->plan.sub > 0 ? c->plan.sub : L - 1;
+    const int octets = (ps.b.nchunks + 7) / 8;
+    const int want   = std::max(1, std::min(std::min(c->pass_slices, limit), octets));
+    const int per    = (octets + want - 1) / want;
+    ah.per_slice   = per * 8;
+    ah.slices      = (octets + per - 1) / per;
+    ah.issued      = 0;
+    ah.reduced     = false;
+    ah.active      = true;
+    ahead_issue_slice(c, stream, direct);
+}
+
+// The block that has just been planned can take the rows the pass in the making has left: it was computed for this block's step
+// times (up to the tolerance a caller's time is accepted with), completely, under the plan that has just ended.
+bool ahead_adoptable(const hc_ctx* c, unsigned long long ended_serial) {
+    const auto& ah = c->ahead;
+    const auto& pl = c->plan;
+    const int L = c->lookahead;
+    if (!ah.active || !ah.reduced || ah.plan_serial != ended_serial || !pl.valid) return false;
+    for (int j = 0; j < L; ++j)
+        if (pl.s_defer[j] >= 0) return false;
+    const double tol = std::max(1e-9 * pl.dt, 64.0 * std::numeric_limits<double>::epsilon() * std::fabs(ah.t_last));
+    return std::fabs(pl.tgrid[1] - ah.t_first) <= tol && std::fabs(pl.tgrid[L] - ah.t_last) <= tol;
 }
 
 // The short pass of the two-level form after block step i0 (hc_plan.hpp: MiniPass): what the samples of the sub-block that has just
 // ended contribute to the block steps still to come, added to their rows of P.  The same kernel as the pass of the block, over
 // the first few IRF samples only, with the bracket table restricted to those samples (BlockArgs::mini_kw) and a chunking of its
 // own (half an IRF sample per chunk -- a function of D only, like every other chunk length).
-void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct) {
+// next_block (pass schedule "one block ahead", hc_plan.hpp: mini_pass_next): the same for the steps of the NEXT block, added to the
+// rows the pass in the making has left; it starts at the first IRF sample those steps take.
+void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, bool next_block = false) {
     const auto& pl = c->plan;
     const int L    = c->lookahead;
-    const hc::MiniPass mp = hc::mini_pass_setup(pl, L, i0, c->tau);
-    if (mp.n_samples <= 0 || mp.n_steps <= 0) return;
+    const hc::MiniPass mp = next_block ? hc::mini_pass_next(pl, L, i0, c->tau) : hc::mini_pass_setup(pl, L, i0, c->tau);
+    if (mp.n_samples <= 0 || mp.n_steps <= 0 || mp.s_first >= mp.n_samples) return;
     hc::HistoryView hv{};
     hv.state   = c->d_zero_state.p;
     hv.N       = c->N;
@@ -281,8 +420,11 @@ void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct) {
     b.mini_kw      = mp.kw;
     b.mini_steps   = mp.n_steps;
     for (int k = 0; k <= mp.kw + 1; ++k) b.mini_time[k] = mp.time[k];
+    b.chunk_first  = next_block ? static_cast<int>((static_cast<long long>(mp.s_first) * c->D / 8) / b.chunk_gp) : 0;
+    b.chunk_last   = b.nchunks;
     require(static_cast<size_t>(b.nchunks) * L * c->Dpad <= c->d_partials_block.n, HC_ERR_RUNTIME, "short pass: partials buffer too small");
-    hc::ReduceArgs r{c->d_partials_block.p, b.nchunks, 0, c->Dpad, L, c->d_P.p, c->d_E.p, b.item_counter, 1, i0, mp.n_steps, 0};
+    hc::ReduceArgs r{c->d_partials_block.p, b.nchunks, 0, c->Dpad, L, rows_P(c, next_block), rows_E(c, next_block), b.item_counter, 1, next_block ? 0 : i0, mp.n_steps,
+                     b.chunk_first};
     if (direct) {
         hc::BlockArgs b2;
         const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_mini, &b2);
@@ -355,11 +497,36 @@ void enqueue_tail(hc_ctx* c) {
     } else if (block && c->plan.sub > 0 && m < c->lookahead && m % c->plan.sub == 0 && c->plan.mini_s_hi[m] >= 0) {
         to_background();
         launch_mini_pass(c, m, bs, direct);  // two-level form: the sub-block that ends here -> the block steps still to come
-    } else if (plan_now) {
+    }
+    // pass schedule "one block ahead": the pass of the next block is in the making under this block's plan
+    if (c->ahead.active && (!block || c->ahead.plan_serial != c->plan_serial)) ahead_drop(c);  // the block it belongs to was abandoned
+    if (block && c->ahead.active) {
+        const int kw = c->plan.sub > 0 ? c->plan.sub : c->lookahead;
+        to_background();
+        if (m % kw == 0) {
+            // a window of this block's samples ends here: what they contribute to the steps of the next block
+            if (c->ahead.reduced) launch_mini_pass(c, m, bs, direct, true);
+            else ahead_drop(c);  // (cannot happen: the slices end within the first window)
+        }
+        if (m < c->lookahead) ahead_issue_slice(c, bs, direct);
+    }
+    if (plan_now) {
+        const unsigned long long ended = c->plan_serial;
+        const bool clean_end           = block && m == c->lookahead;
         if (block) c->plan.misses = 0;  // a block was consumed completely
         if (make_plan(c)) {
             to_background();
-            launch_pass(c, bs, c->tail.waves, direct);
+            if (clean_end && ahead_adoptable(c, ended)) {
+                // the rows of this block are there already: no pass now
+                c->pe_cur ^= 1;
+                c->plan.has_exc = c->ahead.has_exc;
+                c->prof.ahead_blocks += 1;
+            } else {
+                launch_pass(c, bs, c->tail.waves, direct);
+            }
+            ahead_begin(c, bs, c->tail.waves, direct);
+        } else {
+            ahead_drop(c);
         }
     }
     if (bs != stream) {
@@ -421,8 +588,8 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         if (stream != c->stream) HC_HIP(hipStreamWaitEvent(stream, c->ev_bg, 0));
         c->bg_pending = false;
     }
-    const double* P_row = block ? c->d_P.p + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
-    const double* E_row = (block && run_exc && c->plan.has_exc) ? c->d_E.p + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
+    const double* P_row = block ? rows_P(c, false) + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
+    const double* E_row = (block && run_exc && c->plan.has_exc) ? rows_E(c, false) + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
 
     // plain step: all live columns of K, plus the excitation chunks unless a pass has left the excitation force
     int nchunks_rad = 0, nchunks_ex = (run_exc && !E_row) ? c->nchunks_ex : 0;
@@ -1059,6 +1226,19 @@ int hc_set_lookahead(hc_ctx* c, int steps) {
     choose_conv_config(c);  // the pass chunking depends on the depth
     alloc_partials(c);
     c->plan      = hc::Plan{};
+    c->ahead.active = false;
+    HC_API_END(c)
+}
+
+int hc_set_pass_schedule(hc_ctx* c, int one_block_ahead) {
+    HC_API_BEGIN(c)
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    HC_HIP(hipDeviceSynchronize());  // a pass in the making may still be running
+    c->pass_ahead   = one_block_ahead ? 1 : 0;
+    c->pass_slices  = std::max(1, env_int("HC_PASS_SLICES", 8));
+    c->ahead.active = false;
+    alloc_partials(c);
+    c->plan = hc::Plan{};
     HC_API_END(c)
 }
 
@@ -1080,6 +1260,7 @@ int hc_reset_history(hc_ctx* c) {
     c->have_prev = c->have_prev_device = false;
     c->prev_time = c->prev_time_device = -1.0;
     c->plan = hc::Plan{};
+    c->ahead.active = false;
     HC_API_END(c)
 }
 
@@ -1110,6 +1291,7 @@ int hc_set_history(hc_ctx* c, int n, const double* times, const double* vel) {
     HC_HIP(hipStreamSynchronize(c->stream));  // tt / vv are released on return
     c->head      = n - 1;
     c->plan      = hc::Plan{};
+    c->ahead.active = false;
     // No step has been evaluated at times[0], so the per-time cache holds nothing (a step at exactly that time is the
     // reference's duplicate-time error, raised by the history push).
     c->have_prev = c->have_prev_device = false;

@@ -228,6 +228,16 @@ int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
  * contract 1e-6).  Wide systems (6N >= 1024) use a two-level form: sub-blocks of 8 steps with a short pass over the head of K
  * after each.  steps = 0 disables it (every step streams K), 1..16 selects blocks of 16, more blocks of 32. */
 int hc_set_lookahead(hc_ctx* ctx, int steps);
+/* When the pass of a look-ahead block runs.  0 (default): when the block starts -- the first step of every block waits for it
+ * (190 us at 64 bodies, 1.5 ms for a 64-body shard of a 512-body array).  1: one block AHEAD -- the pass of the next block is
+ * computed from the history known when the current block starts, in a few launches issued behind the first steps of the current
+ * block, and what the current block's own samples add to the next block's steps follows in short passes over the head of K.  A
+ * caller that leaves the GPU idle between two force evaluations (a Chrono integrator doing its own work) then never waits for a
+ * pass; a caller that steps back to back gains nothing and pays the short passes.  Used once the history covers the IRF window;
+ * results are those of schedule 0 up to the rounding of a different summation grouping (same 1e-6 contract, same tolerance on the
+ * predicted times).  The schedule is part of the configuration: row shards of one array must use the same one to stay bitwise
+ * equal to the unsharded context.  HC_PASS_AHEAD=1 in the environment makes 1 the default. */
+int hc_set_pass_schedule(hc_ctx* ctx, int one_block_ahead);
 /* How hc_step hands its kernels to the GPU.  1: as AQL packets written straight into an HSA queue of the library's own (kernel
  * arguments stored through the PCIe BAR) -- the default when the stand-alone code object hc_kernels.co lies next to the library,
  * the device's memory is host-addressable and the start-up self-tests pass (a dispatch completes; memory and argument slots the
@@ -293,6 +303,8 @@ typedef struct hc_profile_stats {
     double mini_pass_seconds;      /* short passes of the two-level look-ahead of wide systems (one per sub-block of 8 steps) */
     long long mini_pass_launches;
     long long queue_parkings;      /* times the direct queue was left parked on a barrier packet after a step / an added-mass product */
+    long long ahead_pass_slices;   /* pass schedule "one block ahead": launches of passes of a NEXT block (counted in block_passes too) */
+    long long ahead_blocks;        /* ... and blocks that started with their rows already there (no pass at block start) */
 } hc_profile_stats;
 /* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default), and around every
  * look-ahead pass (one per block) whatever the stride.  Event records perturb the launch stream by a few

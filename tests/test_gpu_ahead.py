@@ -1,0 +1,187 @@
+"""Pass schedule "one block ahead" (hc_set_pass_schedule(ctx, 1)): the pass of the NEXT look-ahead block is computed
+while the current one is stepped -- in slices behind its first steps -- and the current block's own samples reach the next block's
+steps through short passes.  Parity of that schedule against the CPU oracle (same tolerance as every other path), against the
+default schedule, and bitwise between row shards; the counters prove that blocks really started without a pass of their own."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from cases import load_into_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+TIGHT_TOL = 1e-11
+WAVES = dict(simulation_dt=0.01, ramp_duration=1.0, wave_height=2.5, wave_period=8.0, frequency_min=0.02, frequency_max=0.5,
+             nfrequencies=64, peak_enhancement_factor=3.3, seed=1)
+
+
+@pytest.fixture(scope="module")
+def hydro():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import hydrochrono_amd.hydro as hydro
+    return hydro
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, float(np.max(np.abs(b)))))
+
+
+@pytest.mark.parametrize("direct", [1, 0], ids=["aql", "hip"])
+@pytest.mark.parametrize("lookahead,sub", [(32, 0), (16, 0), (32, 8), (16, 8), (32, 4)], ids=["la32", "la16", "la32-sub8", "la16-sub8", "la32-sub4"])
+@pytest.mark.parametrize("N,dt", [(2, 0.01), (3, 0.007), (4, 0.013), (8, 0.01)])
+def test_one_block_ahead_against_oracle(hydro, N, dt, lookahead, sub, direct, monkeypatch):
+    """Small systems, both look-ahead forms (single level; sub-blocks forced with HC_SUB_BLOCK), both dispatch paths, step sizes
+    equal to, below and above the IRF spacing; irregular waves (the excitation rows travel with the pass in the making)."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_DIRECT", str(direct))
+    monkeypatch.setenv("HC_SUB_BLOCK", str(sub))
+    case = many_body_case(N, S=257, dt_rirf=0.01, n_exc=101, dt_exc=0.02, seed=300 + N)
+    case["g_sys"] = [0.3, -0.2, -9.7]
+    gpu, orc = hydro.HydroForces.from_case(case), load_into_oracle(case)
+    assert gpu.direct_dispatch()[0] == bool(direct), gpu.direct_dispatch()[1]
+    kw = dict(WAVES, simulation_dt=dt, simulation_duration=9.0)
+    gpu.add_waves_irregular(**kw)
+    orc.add_waves_irregular(**kw)
+    gpu.set_lookahead(lookahead)
+    gpu.set_pass_schedule(1)
+    gpu.enable_profiling(1)
+    motion = PrescribedMotion(N, rest_positions(case), seed=N)
+    nsteps = 560
+    for n in range(nsteps):
+        t = dt * n
+        st = motion.state(t)
+        fg, fo = gpu.step(t, *st), orc.step(t, *st)
+        assert relerr(fg, fo) <= TIGHT_TOL, f"step {n} (t = {t})"
+        if n % 7 == 0:
+            for g, o in zip(gpu.components(), orc.components()):
+                assert relerr(g, o) <= TIGHT_TOL, f"step {n}: components"
+    p = gpu.profile()
+    # the history covers the IRF window after 257 * 0.01 / dt steps; from then on blocks start without a pass of their own
+    full_at = int(2.57 / dt) + 2 * lookahead + 2
+    assert p["ahead_blocks"] >= (nsteps - full_at) // lookahead - 1 and p["ahead_blocks"] >= 3, p
+    assert p["ahead_pass_slices"] >= p["ahead_blocks"], p
+    assert (p["direct_dispatches"] > 0, p["hip_launches"] > 0) == (bool(direct), not direct) or not direct, p
+
+
+def test_one_block_ahead_survives_off_grid_steps_and_steps_back(hydro):
+    """The pass in the making is dropped with the block it belongs to: off-grid steps (plain evaluation, new plan) and steps back in
+    time (the newer samples are dropped; the oracle is rebuilt with the kept history, as in test_gpu_boundary.py) -- every force
+    against the oracle, and blocks without a pass of their own again afterwards."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    N = 3
+    case = many_body_case(N, S=161, dt_rirf=0.01, n_exc=33, seed=41)
+    gpu = hydro.HydroForces.from_case(case)
+    gpu.add_waves_none()
+    gpu.set_pass_schedule(1)
+    motion = PrescribedMotion(N, rest_positions(case), seed=4)
+    log = []  # (t, velocity) of the samples the history should hold, oldest first
+
+    def fresh_oracle():
+        o = load_into_oracle(case)
+        o.add_waves_none()
+        if log:
+            o.prefill_history(np.array([t for t, _ in reversed(log)]), np.stack([v for _, v in reversed(log)]))
+        return o
+
+    orc = fresh_oracle()
+    rng = np.random.default_rng(5)
+    t, backs = 0.0, 0
+    for n in range(1500):
+        st = motion.state(t)
+        assert relerr(gpu.step(t, *st), orc.step(t, *st)) <= TIGHT_TOL, f"step {n} (t = {t})"
+        log.append((t, np.concatenate([st[2].reshape(N, 3), st[3].reshape(N, 3)], axis=1).reshape(-1)))
+        log = log[-400:]
+        r = rng.random()
+        if n > 250 and r < 0.004:
+            t -= 0.023          # a rejected step: back in time
+            while log and log[-1][0] >= t:
+                log.pop()
+            orc = fresh_oracle()
+            backs += 1
+        elif n > 250 and r < 0.012:
+            t += 0.01 * rng.uniform(0.3, 1.7)
+        else:
+            t += 0.01
+    p = gpu.profile()
+    assert p["ahead_blocks"] >= 8 and p["history_rewinds"] == backs and backs >= 2, p
+
+
+def test_one_block_ahead_c3_size_against_flat_oracle(hydro):
+    """Full-size C3 (64 bodies, S = 1024, Nf = 512) from a steady-state history: 200 steps under the schedule -- plain boundary step,
+    a block with its own pass, then blocks whose rows were made ahead -- against the flat-array CPU oracle."""
+    import bench as B
+    import oracle as orc_mod
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    case = many_body_case(64, S=B.S_RIRF, dt_rirf=B.DT, n_exc=B.N_EXC, dt_exc=B.DT, seed=20251031)
+    gpu = hydro.HydroForces.from_case(case)
+    motion = PrescribedMotion(64, rest_positions(case), seed=20251031)
+    kw = dict(B.WAVES, simulation_dt=B.DT, simulation_duration=B.T0 + 8.0)
+    gpu.add_waves_irregular(num_bodies=64, **kw)
+    gpu.set_pass_schedule(1)
+    orc_mod.set_num_threads(min(64, os.cpu_count() or 1))
+    orc = load_into_oracle(case)
+    orc.add_waves_irregular(**kw)
+    nhist = B.S_RIRF + 5
+    t_hist = B.T0 - B.DT * np.arange(1, nhist + 1)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    gpu.set_history(t_hist, v_hist)
+    orc.prefill_history(t_hist, v_hist)
+    orc.flat_prepare()
+    gpu.enable_profiling(1)
+    worst = 0.0
+    for n in range(200):
+        t = B.T0 + n * B.DT
+        st = motion.state(t)
+        e = relerr(gpu.step(t, *st), orc.flat_step(t, *st))
+        worst = max(worst, e)
+        assert e <= TIGHT_TOL, f"step {n}"
+    p = gpu.profile()
+    assert p["ahead_blocks"] >= 5 and p["conv_kernel_launches"] == 1, p
+    assert gpu.direct_dispatch()[0] and p["hip_launches"] == 0, p
+    print(f"C3 one block ahead: worst relative error {worst:.2e}, {p['ahead_blocks']} blocks without a pass of their own, {p['ahead_pass_slices']} slices")
+
+
+@pytest.mark.parametrize("direct", [1, 0], ids=["aql", "hip"])
+def test_one_block_ahead_wide_system_and_row_shards(hydro, direct, monkeypatch):
+    """A WIDE system (D = 1056: two-level look-ahead, sliced own-sample kernel) under the schedule: against the oracle, and three row
+    shards evaluated by hc_step_multi bitwise equal to the unsharded context (the schedule is a function of the configuration only)."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    import oracle as orc_mod
+    N = 176
+    case = many_body_case(N, S=140, dt_rirf=0.01, n_exc=17, dt_exc=0.05, seed=1056)
+    monkeypatch.setenv("HC_DIRECT", str(direct))
+    monkeypatch.setenv("HC_PASS_AHEAD", "1")  # the default of every context created below
+    full = hydro.HydroForces.from_case(case)
+    group = hydro.HydroGroup.from_case(case, 3)
+    orc_mod.set_num_threads(min(64, os.cpu_count() or 1))
+    orc = load_into_oracle(case)
+    kw = dict(WAVES, simulation_duration=6.0)
+    for h in (full, group, orc):
+        h.add_waves_irregular(**kw)
+    motion = PrescribedMotion(N, rest_positions(case), seed=2)
+    # start from a history that covers the IRF window (the flat-array oracle is prepared on it)
+    t_hist = 1.0 - 0.01 * np.arange(1, 146)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    full.set_history(t_hist, v_hist)
+    group.set_history(t_hist, v_hist)
+    orc.prefill_history(t_hist, v_hist)
+    orc.flat_prepare()
+    full.enable_profiling(1)
+    t = 1.0
+    for n in range(260):
+        st = motion.state(t)
+        fg = full.step(t, *st)
+        assert relerr(fg, orc.flat_step(t, *st)) <= TIGHT_TOL, f"step {n}"
+        assert np.array_equal(group.step(t, *st), fg), f"step {n}: shards"
+        t += 0.01 if n != 150 else 0.0137
+    p = full.profile()
+    assert p["ahead_blocks"] >= 4 and p["mini_pass_launches"] >= 20, p

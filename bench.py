@@ -243,12 +243,14 @@ def c4_rank_share(sdt, lookahead):
     synchronous hc_step.  A driver-run figure for multi-GPU readiness while no 8-GPU node is available."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     N, warm, steps = N_BODIES_C4, 40, 128
+    n_gap, n_in, gap = 96, 72, 300e-6  # the gap loops below
     motion = PrescribedMotion(N, np.zeros((N, 3)), seed=20251031)
     nhist = int(np.ceil(S_RIRF * DT / sdt)) + 5
     t_hist = T0 - sdt * np.arange(1, nhist + 1)
     v_hist = np.stack([motion.velocity6(t) for t in t_hist])
-    gpu = make_shard(N, 0, N // 8, 0, sdt, T0 + (warm + steps + 8) * sdt + 5.0, lookahead, t_hist, v_hist)
-    times = [T0 + k * sdt for k in range(warm + steps)]
+    n_all = warm + steps + 2 * n_gap + n_in
+    gpu = make_shard(N, 0, N // 8, 0, sdt, T0 + (n_all + 8) * sdt + 5.0, lookahead, t_hist, v_hist)
+    times = [T0 + k * sdt for k in range(n_all)]
     states = [motion.state(t) for t in times]
     for k in range(warm):
         gpu.step(times[k], *states[k])
@@ -270,6 +272,27 @@ def c4_rank_share(sdt, lookahead):
            "per_step_us": {"pass": p["block_kernel_seconds"] / steps * 1e6, "short_passes": p["mini_pass_seconds"] / steps * 1e6,
                            "scatter": p["scatter_kernel_seconds"] / steps * 1e6, "step_kernels": p["step_kernel_seconds"] / steps * 1e6}}
     out.update(dispatch_info([gpu]))
+    # a caller that leaves the GPU idle between two force evaluations (300 us of host work: a busy wait), under both pass schedules
+    gpu.enable_profiling(False)
+
+    def gap_loop(k0, n_skip, n):
+        lat = np.zeros(n)
+        for i in range(n_skip + n):
+            a = time.perf_counter()
+            gpu.step(times[k0 + i], *states[k0 + i])
+            b = time.perf_counter()
+            if i >= n_skip:
+                lat[i - n_skip] = b - a
+            while time.perf_counter() - b < gap:
+                pass
+        return {"mean_step_us": float(lat.mean()) * 1e6, "median_step_us": float(np.median(lat)) * 1e6,
+                "p90_step_us": float(np.percentile(lat, 90)) * 1e6, "max_step_us": float(lat.max()) * 1e6}
+    k0 = warm + steps
+    loops = {"host_work_between_calls_us": gap * 1e6, "steps": n_gap, "pass_at_block_start": gap_loop(k0, 0, n_gap)}
+    gpu.set_pass_schedule(1)
+    loops["pass_one_block_ahead"] = gap_loop(k0 + n_gap, n_in, n_gap)
+    loops["pass_one_block_ahead"]["blocks_without_a_pass_of_their_own"] = int(gpu.profile()["ahead_blocks"])
+    out["chrono_like_loop"] = loops
     gpu.close()
     return out
 
@@ -364,7 +387,7 @@ def main():
         align = boundary - first
     pre = align + args.warmup
     total = pre + args.steps
-    n_all = total + n_steady + (128 if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
+    n_all = total + n_steady + ((2 * 128 + 72) if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
     duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
     gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
@@ -553,10 +576,31 @@ def main():
                 gpu._chk(rc)
             while pc() - b_ < work:
                 pass
-        chrono_like = {"steps": n_cl, "host_work_between_calls_us": work * 1e6, "mean_hc_step_us": float(lat.mean()) * 1e6,
-                       "median_hc_step_us": float(np.median(lat)) * 1e6, "p90_hc_step_us": float(np.percentile(lat, 90)) * 1e6,
-                       "max_hc_step_us": float(lat.max()) * 1e6,
+        def gap_stats(lat_):
+            return {"mean_hc_step_us": float(lat_.mean()) * 1e6, "median_hc_step_us": float(np.median(lat_)) * 1e6,
+                    "p90_hc_step_us": float(np.percentile(lat_, 90)) * 1e6, "max_hc_step_us": float(lat_.max()) * 1e6}
+        chrono_like = {"steps": n_cl, "host_work_between_calls_us": work * 1e6, **gap_stats(lat),
                        "note": "synchronous hc_step with 100 us of host work between calls: the look-ahead pass and the scatter run while the host is away"}
+        # the same loop under the pass schedule "one block ahead" (hc_set_pass_schedule): no step waits for a whole pass
+        k_next += n_cl
+        gpu.set_pass_schedule(1)
+        n_in, lat2 = 72, np.zeros(n_cl)   # the plain boundary step, the first block (its own pass) and the first block made ahead run in
+        for i in range(n_in + n_cl):
+            k = k_next + i
+            a = pc()
+            rc = hc_step(ctx, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
+            b_ = pc()
+            if i >= n_in:
+                lat2[i - n_in] = b_ - a
+            if rc:
+                gpu._chk(rc)
+            while pc() - b_ < work:
+                pass
+        pa = gpu.profile()
+        chrono_like["pass_one_block_ahead"] = {"steps": n_cl, **gap_stats(lat2), "blocks_without_a_pass_of_their_own": int(pa["ahead_blocks"]),
+                                               "note": "hc_set_pass_schedule(ctx, 1, 8): the pass of the next block in 8 slices behind the first steps of the current one"}
+        gpu.set_pass_schedule(0)
+        k_next += n_in
         k_next += n_cl
     if n_pipe > 0:
         # hc_step_device, states resident in HBM, every step enqueued without waiting for the previous one's forces

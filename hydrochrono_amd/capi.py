@@ -88,7 +88,7 @@ SIGNATURES = {
     "hc_compute_hydrostatics": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "hc_compute_waves": (C.c_int, [C.c_void_p, C.c_double, c_double_p]),
     "hc_set_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
-    "hc_set_pass_schedule": (C.c_int, [C.c_void_p, C.c_int]),
+    "hc_set_pass_schedule": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "hc_direct_dispatch_active": (C.c_int, [C.c_void_p]),
     "hc_dispatch_mode_reason": (C.c_char_p, [C.c_void_p]),
     "hc_reset_history": (C.c_int, [C.c_void_p]),

@@ -325,6 +325,15 @@ void choose_conv_config(hc_ctx* c) {
     c->nchunks_block    = static_cast<int>((c->ngp + bgps - 1) / bgps);
 }
 
+// Chunk length of a pass that is issued in slices (pass schedule "one block ahead").  The pass of a block is ONE round of long-lived
+// workgroups -- one per CU at depth 32, each streaming its chunk for the whole duration -- so a slice must bring a full round of its
+// own: the chunks are `pass_slices` times shorter (a function of the column count and the slice count only, like every chunk length).
+int far_chunk_gp(const hc_ctx* c) {
+    int g = c->chunk_gp_block / std::max(1, c->pass_slices);
+    g     = std::max(16, ((g + 15) / 16) * 16);
+    return std::min(g, std::max(16, c->chunk_gp_block));
+}
+
 void choose_exc_config(hc_ctx* c) {
     if (c->wave_kind != hc::kWaveIrregular || c->L == 0) {
         c->nchunks_ex  = 0;
@@ -348,7 +357,7 @@ void alloc_partials(hc_ctx* c) {
     const int mini_chunks = (c->pass_ahead ? 4 : 2) * hc::kScatterSamples + 2;
     const size_t nb = static_cast<size_t>(std::max(c->nchunks_block + c->nchunks_ex_block, mini_chunks)) * hc::kLookahead * c->Dpad;
     if (c->d_partials_block.n < nb) c->d_partials_block.alloc(nb);
-    const size_t nfar = static_cast<size_t>(c->nchunks_block + c->nchunks_ex_block) * hc::kLookahead * c->Dpad;
+    const size_t nfar = static_cast<size_t>((c->ngp + far_chunk_gp(c) - 1) / far_chunk_gp(c) + c->nchunks_ex_block) * hc::kLookahead * c->Dpad;
     if (c->pass_ahead && c->d_partials_far.n < nfar) c->d_partials_far.alloc(nfar);
     // two blocks of rows each: the current block's and (pass schedule "one block ahead") the next one's
     const size_t npe = static_cast<size_t>(2 * hc::kLookahead) * c->Dpad;

@@ -185,9 +185,9 @@ PassSetup make_pass(hc_ctx* c, bool with_exc, bool next_block) {
     b.K                   = rad_panel(c);
     b.F                   = std::min(c->S, live_samples(c, pl.tgrid[L])) * c->D;
     b.depth               = L;
-    b.chunk_gp            = c->chunk_gp_block;
-    b.nchunks             = std::max(1, ((b.F + 7) / 8 + c->chunk_gp_block - 1) / c->chunk_gp_block);
-    b.max_steps_per_chunk = (c->chunk_gp_block * 8) / c->D + 2;
+    b.chunk_gp            = next_block ? far_chunk_gp(c) : c->chunk_gp_block;  // (a pass issued in slices: shorter chunks, a full round of workgroups per slice)
+    b.nchunks             = std::max(1, ((b.F + 7) / 8 + b.chunk_gp - 1) / b.chunk_gp);
+    b.max_steps_per_chunk = (b.chunk_gp * 8) / c->D + 2;
     b.hist                = hv;
     if (next_block) {
         const hc::FarPass fp = hc::far_pass_setup(pl, L, c->tau);
@@ -1230,12 +1230,12 @@ int hc_set_lookahead(hc_ctx* c, int steps) {
     HC_API_END(c)
 }
 
-int hc_set_pass_schedule(hc_ctx* c, int one_block_ahead) {
+int hc_set_pass_schedule(hc_ctx* c, int one_block_ahead, int slices) {
     HC_API_BEGIN(c)
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     HC_HIP(hipDeviceSynchronize());  // a pass in the making may still be running
     c->pass_ahead   = one_block_ahead ? 1 : 0;
-    c->pass_slices  = std::max(1, env_int("HC_PASS_SLICES", 8));
+    c->pass_slices  = slices > 0 ? std::min(slices, hc::kLookahead - 1) : std::max(1, env_int("HC_PASS_SLICES", 8));
     c->ahead.active = false;
     alloc_partials(c);
     c->plan = hc::Plan{};

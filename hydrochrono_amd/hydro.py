@@ -223,10 +223,11 @@ class HydroForces:
         """0 = plain per-step evaluation; > 0 = 16-step look-ahead blocking (the default)."""
         self._chk(self.lib.hc_set_lookahead(self.ctx, int(steps)))
 
-    def set_pass_schedule(self, one_block_ahead):
+    def set_pass_schedule(self, one_block_ahead, slices=0):
         """hc_set_pass_schedule: 0 = the pass of a look-ahead block when the block starts (default), 1 = one block ahead, in
-        slices behind the first steps of the block before (for callers that leave the GPU idle between force evaluations)."""
-        self._chk(self.lib.hc_set_pass_schedule(self.ctx, int(bool(one_block_ahead))))
+        `slices` launches (0: 8) behind the first steps of the block before -- for callers that leave the GPU idle between force
+        evaluations for less than a pass takes."""
+        self._chk(self.lib.hc_set_pass_schedule(self.ctx, int(bool(one_block_ahead)), int(slices)))
 
     def direct_dispatch(self):
         """(active, reason): whether hc_step writes AQL packets itself instead of calling hipLaunchKernelGGL."""

@@ -228,16 +228,20 @@ int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
  * contract 1e-6).  Wide systems (6N >= 1024) use a two-level form: sub-blocks of 8 steps with a short pass over the head of K
  * after each.  steps = 0 disables it (every step streams K), 1..16 selects blocks of 16, more blocks of 32. */
 int hc_set_lookahead(hc_ctx* ctx, int steps);
-/* When the pass of a look-ahead block runs.  0 (default): when the block starts -- the first step of every block waits for it
- * (190 us at 64 bodies, 1.5 ms for a 64-body shard of a 512-body array).  1: one block AHEAD -- the pass of the next block is
- * computed from the history known when the current block starts, in a few launches issued behind the first steps of the current
- * block, and what the current block's own samples add to the next block's steps follows in short passes over the head of K.  A
- * caller that leaves the GPU idle between two force evaluations (a Chrono integrator doing its own work) then never waits for a
- * pass; a caller that steps back to back gains nothing and pays the short passes.  Used once the history covers the IRF window;
- * results are those of schedule 0 up to the rounding of a different summation grouping (same 1e-6 contract, same tolerance on the
- * predicted times).  The schedule is part of the configuration: row shards of one array must use the same one to stay bitwise
- * equal to the unsharded context.  HC_PASS_AHEAD=1 in the environment makes 1 the default. */
-int hc_set_pass_schedule(hc_ctx* ctx, int one_block_ahead);
+/* When the pass of a look-ahead block runs.  one_block_ahead = 0 (default): when the block starts.  A caller that comes back
+ * before the pass has finished waits for it on the first step of the block (190 us at 64 bodies; 1.55 ms for the 64-body row
+ * shard of a 512-body array); a caller that stays away longer than that never notices it.  one_block_ahead = 1: the pass of the
+ * NEXT block is computed from the history known when the current block starts, in `slices` launches (<= 0: 8) issued behind the
+ * first steps of the current block, and what the current block's own samples add to the next block's steps follows in short
+ * passes over the head of K.  The longest a step can then wait is one slice plus a short pass.  Measured on an MI355X, mean
+ * hc_step latency with 100 / 300 us of host work between calls: 64 bodies 16.7 -> 14.0 / 13.6 -> 13.9 us (p99 104 -> 16 us at
+ * 100 us); the 64-of-512-body shard 65.7 -> 42.7 / 58.4 -> 20.2 us (p99 1260 -> 32 us at 300 us).  A caller that steps back to
+ * back gains nothing and pays the short passes (19.3 -> 22.8 us and 74 -> 80 us).  Used once the history covers the IRF window;
+ * results are those of schedule 0 up to the rounding of a different summation grouping (same 1e-6 contract, same tolerance on
+ * the predicted times).  The schedule is part of the configuration: the row shards of one array must use the same one (and the
+ * same slice count) to stay bitwise equal to the unsharded context.  HC_PASS_AHEAD=1 (HC_PASS_SLICES=n) in the environment make
+ * it the default of new contexts. */
+int hc_set_pass_schedule(hc_ctx* ctx, int one_block_ahead, int slices);
 /* How hc_step hands its kernels to the GPU.  1: as AQL packets written straight into an HSA queue of the library's own (kernel
  * arguments stored through the PCIe BAR) -- the default when the stand-alone code object hc_kernels.co lies next to the library,
  * the device's memory is host-addressable and the start-up self-tests pass (a dispatch completes; memory and argument slots the

@@ -69,6 +69,30 @@ def test_one_block_ahead_against_oracle(hydro, N, dt, lookahead, sub, direct, mo
     assert (p["direct_dispatches"] > 0, p["hip_launches"] > 0) == (bool(direct), not direct) or not direct, p
 
 
+@pytest.mark.parametrize("slices", [1, 3, 16, 31])
+@pytest.mark.parametrize("sub", [0, 8])
+def test_one_block_ahead_slice_counts(hydro, slices, sub, monkeypatch):
+    """The number of launches the pass in the making is spread over (and with it its chunk length) is the caller's choice."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_SUB_BLOCK", str(sub))
+    N = 5
+    case = many_body_case(N, S=200, dt_rirf=0.01, n_exc=41, dt_exc=0.02, seed=77)
+    gpu, orc = hydro.HydroForces.from_case(case), load_into_oracle(case)
+    kw = dict(WAVES, simulation_duration=6.0)
+    gpu.add_waves_irregular(**kw)
+    orc.add_waves_irregular(**kw)
+    gpu.set_pass_schedule(1, slices)
+    motion = PrescribedMotion(N, rest_positions(case), seed=N)
+    for n in range(400):
+        st = motion.state(0.01 * n)
+        assert relerr(gpu.step(0.01 * n, *st), orc.step(0.01 * n, *st)) <= TIGHT_TOL, f"step {n}"
+    p = gpu.profile()
+    assert p["ahead_blocks"] >= 3, p
+    per_block = p["ahead_pass_slices"] / (p["ahead_blocks"] + 1)
+    assert per_block <= min(slices, sub if sub else 31) + 1e-9, p
+
+
 def test_one_block_ahead_survives_off_grid_steps_and_steps_back(hydro):
     """The pass in the making is dropped with the block it belongs to: off-grid steps (plain evaluation, new plan) and steps back in
     time (the newer samples are dropped; the oracle is rebuilt with the kept history, as in test_gpu_boundary.py) -- every force

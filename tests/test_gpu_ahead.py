@@ -137,6 +137,39 @@ def test_one_block_ahead_survives_off_grid_steps_and_steps_back(hydro):
     assert p["ahead_blocks"] >= 8 and p["history_rewinds"] == backs and backs >= 2, p
 
 
+@pytest.mark.parametrize("wait_each_step", [False, True], ids=["runs-ahead", "waits"])
+def test_one_block_ahead_device_steps_on_a_callers_stream(hydro, wait_each_step):
+    """hc_step_device on a caller's stream under the schedule -- enqueued ahead of the GPU (everything on that stream in order) and
+    with a caller that waits for every step (slices and short passes go to the context's own stream behind events): bitwise the
+    forces of synchronous hc_step under the same schedule, and both against the default schedule."""
+    import torch
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    N = 3
+    case = many_body_case(N, S=150, n_exc=33, seed=91)
+    a, b, ref = (hydro.HydroForces.from_case(case) for _ in range(3))
+    for h in (a, b, ref):
+        h.add_waves_none()
+    a.set_pass_schedule(1)
+    b.set_pass_schedule(1)
+    motion = PrescribedMotion(N, rest_positions(case), seed=6)
+    nsteps = 420
+    states = torch.tensor(np.stack([motion.packed(0.01 * n) for n in range(nsteps)]), device="cuda")
+    out = torch.zeros(nsteps, 6 * N, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    for n in range(nsteps):
+        b.step_device(0.01 * n, states[n].data_ptr(), out[n].data_ptr(), stream.cuda_stream)
+        if wait_each_step:
+            stream.synchronize()
+    torch.cuda.synchronize()
+    host = np.stack([a.step(0.01 * n, *motion.state(0.01 * n)) for n in range(nsteps)])
+    plain = np.stack([ref.step(0.01 * n, *motion.state(0.01 * n)) for n in range(nsteps)])
+    assert np.array_equal(out.cpu().numpy(), host)
+    assert relerr(host, plain) <= TIGHT_TOL
+    assert a.profile()["ahead_blocks"] >= 5 and b.profile()["ahead_blocks"] >= 5
+
+
 def test_one_block_ahead_c3_size_against_flat_oracle(hydro):
     """Full-size C3 (64 bodies, S = 1024, Nf = 512) from a steady-state history: 200 steps under the schedule -- plain boundary step,
     a block with its own pass, then blocks whose rows were made ahead -- against the flat-array CPU oracle."""

@@ -598,7 +598,7 @@ def main():
                 pass
         pa = gpu.profile()
         chrono_like["pass_one_block_ahead"] = {"steps": n_cl, **gap_stats(lat2), "blocks_without_a_pass_of_their_own": int(pa["ahead_blocks"]),
-                                               "note": "hc_set_pass_schedule(ctx, 1, 8): the pass of the next block in 8 slices behind the first steps of the current one"}
+                                               "note": "hc_set_pass_schedule(ctx, 1, 0): the pass of the next block in slices (4 at this size) behind the first steps of the current one"}
         gpu.set_pass_schedule(0)
         k_next += n_in
         k_next += n_cl

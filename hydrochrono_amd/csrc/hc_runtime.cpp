@@ -328,6 +328,16 @@ void choose_conv_config(hc_ctx* c) {
 // Chunk length of a pass that is issued in slices (pass schedule "one block ahead").  The pass of a block is ONE round of long-lived
 // workgroups -- one per CU at depth 32, each streaming its chunk for the whole duration -- so a slice must bring a full round of its
 // own: the chunks are `pass_slices` times shorter (a function of the column count and the slice count only, like every chunk length).
+// Default slice count: slices of roughly 300 MB of the UNSHARDED K (a slice then takes 50-200 us on one GPU or on a row shard), between
+// 2 and 8 -- 4 at C3 (each launch has a fixed cost of about 11 us there: 8 slices make the pass 283 us instead of 192, 4 make it 234),
+// 8 for C4.  A function of the system's size only, never of the rows a context owns.
+int default_pass_slices(const hc_ctx* c) {
+    const int forced = env_int("HC_PASS_SLICES", 0);
+    if (forced > 0) return std::min(forced, hc::kLookahead - 1);
+    const double bytes = 8.0 * static_cast<double>(c->D) * c->D * c->S;
+    return std::max(2, std::min(8, static_cast<int>(std::ceil(bytes / 300e6))));
+}
+
 int far_chunk_gp(const hc_ctx* c) {
     int g = c->chunk_gp_block / std::max(1, c->pass_slices);
     g     = std::max(16, ((g + 15) / 16) * 16);

@@ -317,7 +317,7 @@ int hc_finalize(hc_ctx* c) {
         const int want = env_int("HC_LOOKAHEAD", 32);
         c->lookahead   = want <= 0 ? 0 : (want <= 16 ? 16 : hc::kLookahead);
         c->pass_ahead  = env_int("HC_PASS_AHEAD", 0) != 0 ? 1 : 0;  // hc_set_pass_schedule
-        c->pass_slices = std::max(1, env_int("HC_PASS_SLICES", 8));
+        c->pass_slices = default_pass_slices(c);
         c->ahead.active = false;
     }
     // GEMV scratch

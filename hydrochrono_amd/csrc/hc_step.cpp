@@ -1235,7 +1235,7 @@ int hc_set_pass_schedule(hc_ctx* c, int one_block_ahead, int slices) {
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     HC_HIP(hipDeviceSynchronize());  // a pass in the making may still be running
     c->pass_ahead   = one_block_ahead ? 1 : 0;
-    c->pass_slices  = slices > 0 ? std::min(slices, hc::kLookahead - 1) : std::max(1, env_int("HC_PASS_SLICES", 8));
+    c->pass_slices  = slices > 0 ? std::min(slices, hc::kLookahead - 1) : default_pass_slices(c);
     c->ahead.active = false;
     alloc_partials(c);
     c->plan = hc::Plan{};

@@ -225,7 +225,7 @@ class HydroForces:
 
     def set_pass_schedule(self, one_block_ahead, slices=0):
         """hc_set_pass_schedule: 0 = the pass of a look-ahead block when the block starts (default), 1 = one block ahead, in
-        `slices` launches (0: 8) behind the first steps of the block before -- for callers that leave the GPU idle between force
+        `slices` launches (0: chosen by the library) behind the first steps of the block before -- for callers that leave the GPU idle between force
         evaluations for less than a pass takes."""
         self._chk(self.lib.hc_set_pass_schedule(self.ctx, int(bool(one_block_ahead)), int(slices)))
 

@@ -231,12 +231,12 @@ int hc_set_lookahead(hc_ctx* ctx, int steps);
 /* When the pass of a look-ahead block runs.  one_block_ahead = 0 (default): when the block starts.  A caller that comes back
  * before the pass has finished waits for it on the first step of the block (190 us at 64 bodies; 1.55 ms for the 64-body row
  * shard of a 512-body array); a caller that stays away longer than that never notices it.  one_block_ahead = 1: the pass of the
- * NEXT block is computed from the history known when the current block starts, in `slices` launches (<= 0: 8) issued behind the
+ * NEXT block is computed from the history known when the current block starts, in `slices` launches (<= 0: chosen from the size of K, 2 .. 8) issued behind the
  * first steps of the current block, and what the current block's own samples add to the next block's steps follows in short
  * passes over the head of K.  The longest a step can then wait is one slice plus a short pass.  Measured on an MI355X, mean
- * hc_step latency with 100 / 300 us of host work between calls: 64 bodies 16.7 -> 14.0 / 13.6 -> 13.9 us (p99 104 -> 16 us at
- * 100 us); the 64-of-512-body shard 65.7 -> 42.7 / 58.4 -> 20.2 us (p99 1260 -> 32 us at 300 us).  A caller that steps back to
- * back gains nothing and pays the short passes (19.3 -> 22.8 us and 74 -> 80 us).  Used once the history covers the IRF window;
+ * hc_step latency with 100 / 300 us of host work between calls: 64 bodies 16.6 -> 13.7 / 13.7 -> 13.7 us (p99 105 -> 15 us at
+ * 100 us); the 64-of-512-body shard 65.6 -> 44.6 / 58.3 -> 19.8 us (p99 1258 -> 22 us at 300 us).  A caller that steps back to
+ * back gains nothing and pays the short passes (19.2 -> 21.8 us and 70 -> 81 us).  Used once the history covers the IRF window;
  * results are those of schedule 0 up to the rounding of a different summation grouping (same 1e-6 contract, same tolerance on
  * the predicted times).  The schedule is part of the configuration: the row shards of one array must use the same one (and the
  * same slice count) to stay bitwise equal to the unsharded context.  HC_PASS_AHEAD=1 (HC_PASS_SLICES=n) in the environment make

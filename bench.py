@@ -243,34 +243,38 @@ def c4_rank_share(sdt, lookahead):
     synchronous hc_step.  A driver-run figure for multi-GPU readiness while no 8-GPU node is available."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     N, warm, steps = N_BODIES_C4, 40, 128
-    n_gap, n_in, gap = 96, 72, 300e-6  # the gap loops below
+    n_gap, n_in, gap, n_prof = 96, 72, 300e-6, 96  # the gap loops and the profiled stretch below
     motion = PrescribedMotion(N, np.zeros((N, 3)), seed=20251031)
     nhist = int(np.ceil(S_RIRF * DT / sdt)) + 5
     t_hist = T0 - sdt * np.arange(1, nhist + 1)
     v_hist = np.stack([motion.velocity6(t) for t in t_hist])
-    n_all = warm + steps + 2 * n_gap + n_in
+    n_all = warm + steps + n_prof + 3 * (n_gap + n_in)
     gpu = make_shard(N, 0, N // 8, 0, sdt, T0 + (n_all + 8) * sdt + 5.0, lookahead, t_hist, v_hist)
     times = [T0 + k * sdt for k in range(n_all)]
     states = [motion.state(t) for t in times]
     for k in range(warm):
         gpu.step(times[k], *states[k])
-    gpu.enable_profiling(1)
-    gpu.reset_profile()
     per = []
     for k in range(warm, warm + steps):
         a = time.perf_counter()
         gpu.step(times[k], *states[k])
         per.append(time.perf_counter() - a)
-    p = gpu.profile()
     per = np.array(per)
+    # the per-kernel figures come from a stretch of their own with the library's kernel timing on (it costs the loop a few us per step)
+    gpu.enable_profiling(1)
+    gpu.reset_profile()
+    for k in range(warm + steps, warm + steps + n_prof):
+        gpu.step(times[k], *states[k])
+    p = gpu.profile()
     pass_s = p["block_kernel_seconds"] / max(1, p["block_kernel_launches"])
     out = {"workload": f"rows of bodies [0, {N // 8}) of the coupled {N}-body array (D_local = {gpu.D_local}, D = {6 * N}, K slice "
                        f"{p['conv_kernel_bytes'] / 1e9:.2f} GB), synchronous hc_step through the Python wrapper, {steps} steps",
-           "ms_per_step": float(per.mean()) * 1e3, "median_ms_per_step": float(np.median(per)) * 1e3,
+           "pass_schedule": "one block ahead, on the pass lane beside the steps (the library's default for wide systems)" if p["ahead_blocks"] > 0 else "at block start",
+           "ms_per_step": float(per.mean()) * 1e3, "median_ms_per_step": float(np.median(per)) * 1e3, "max_ms_per_step": float(per.max()) * 1e3,
            "pass_us": pass_s * 1e6, "pass_launches": int(p["block_kernel_launches"]),
            "pass_frac_of_hbm_peak": p["block_kernel_bytes_once"] / pass_s / 1e9 / HBM_PEAK_GBS if pass_s > 0 else None,
-           "per_step_us": {"pass": p["block_kernel_seconds"] / steps * 1e6, "short_passes": p["mini_pass_seconds"] / steps * 1e6,
-                           "scatter": p["scatter_kernel_seconds"] / steps * 1e6, "step_kernels": p["step_kernel_seconds"] / steps * 1e6}}
+           "per_step_us": {"pass": p["block_kernel_seconds"] / n_prof * 1e6, "short_passes": p["mini_pass_seconds"] / n_prof * 1e6,
+                           "scatter": p["scatter_kernel_seconds"] / n_prof * 1e6, "step_kernels": p["step_kernel_seconds"] / n_prof * 1e6}}
     out.update(dispatch_info([gpu]))
     # a caller that leaves the GPU idle between two force evaluations (300 us of host work: a busy wait), under both pass schedules
     gpu.enable_profiling(False)
@@ -287,11 +291,22 @@ def c4_rank_share(sdt, lookahead):
                 pass
         return {"mean_step_us": float(lat.mean()) * 1e6, "median_step_us": float(np.median(lat)) * 1e6,
                 "p90_step_us": float(np.percentile(lat, 90)) * 1e6, "max_step_us": float(lat.max()) * 1e6}
-    k0 = warm + steps
-    loops = {"host_work_between_calls_us": gap * 1e6, "steps": n_gap, "pass_at_block_start": gap_loop(k0, 0, n_gap)}
+    k0 = warm + steps + n_prof
+    loops = {"host_work_between_calls_us": gap * 1e6, "steps": n_gap}
+    gpu.set_pass_schedule(0)
+    loops["pass_at_block_start"] = gap_loop(k0, n_in, n_gap)
     gpu.set_pass_schedule(1)
-    loops["pass_one_block_ahead"] = gap_loop(k0 + n_gap, n_in, n_gap)
+    loops["pass_one_block_ahead"] = gap_loop(k0 + n_in + n_gap, n_in, n_gap)
     loops["pass_one_block_ahead"]["blocks_without_a_pass_of_their_own"] = int(gpu.profile()["ahead_blocks"])
+    # ... and back to back under the schedule the default is not
+    gpu.set_pass_schedule(0)
+    lat0 = []
+    for i in range(n_in + n_gap):
+        a = time.perf_counter()
+        gpu.step(times[k0 + 2 * (n_in + n_gap) + i], *states[k0 + 2 * (n_in + n_gap) + i])
+        if i >= n_in:
+            lat0.append(time.perf_counter() - a)
+    out["back_to_back_pass_at_block_start"] = {"ms_per_step": float(np.mean(lat0)) * 1e3, "max_ms_per_step": float(np.max(lat0)) * 1e3, "steps": n_gap}
     out["chrono_like_loop"] = loops
     gpu.close()
     return out
@@ -775,6 +790,7 @@ def main():
             out["single_process_c_abi"] = single_sec
         if world == 1 and not strong and not args.no_secondary and not args.no_c4_share:
             try:
+                gpu.close()  # the shard below gets the device to itself, like a rank of a multi-GPU run (a context that shares its device keeps its passes on the step path's lane)
                 out["c4_rank_share"] = c4_rank_share(sdt, args.lookahead if args.lookahead > 0 else 32)
             except Exception as e:  # a secondary must not cost the run its line
                 out["c4_rank_share"] = {"error": str(e)}

@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
         p.peak_enhancement_factor_ = 3.3;
         TestHydro hydro(bodies, argv[1], std::make_shared<IrregularWaves>(p), devices);  // one row shard per listed device
         hydro.SetGravitationalAcceleration(0.0, 0.0, -g);
-        hydro.SetPassSchedule(true);  // the look-ahead pass of the next block in slices behind the steps of the current one: no step waits for a whole pass
+        hydro.SetPassSchedule(true);  // (what the constructor selects anyway) the look-ahead pass of the next block runs beside the steps of the current one: no step waits for a whole pass
         const int D = 6 * N;
         const std::vector<double> Ainf = hydro.GetAddedMassMatrix();  // D x D, rho-scaled
         // every body gets a nominal mass; its rest height is where the vertical hydrostatic force carries that weight (secant

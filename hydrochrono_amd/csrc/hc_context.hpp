@@ -123,6 +123,7 @@ struct AheadPass {
     int slices = 0, issued = 0;          // launches the radiation chunks are spread over, and how many have gone out
     int per_slice = 0;                   // radiation chunks per launch (whole octets)
     bool reduced = false;                // the reduction into the next block's rows has gone out
+    bool concurrent = false;             // it runs on the pass lane of the direct queue, beside the steps (ordered by signals)
     bool has_exc = false;                // it also leaves the excitation force of the next block's predicted times
     int Hcap = 0;                        // ring capacity of the history view (a re-allocated ring voids the view)
     double t_first = 0.0, t_last = 0.0;  // predicted times of the next block's first and last step
@@ -249,6 +250,11 @@ struct hc_ctx {
     int pass_ahead = 0, pass_slices = 8, pe_cur = 0;
     hc::AheadPass ahead;
     hc::DeviceBuffer<double> d_partials_far;  // partial sums of the pass in the making (the short passes keep d_partials_block)
+    hc::DeviceBuffer<double> d_partials_next; // ... and of the short passes towards the next block when they run on the pass lane
+    // The pass lane (lane 2 of the direct queue): passes in the making run there BESIDE the steps of lane 0, on a queue that leaves
+    // pass_free_cus compute units of every XCD to the step kernels.  0 not created yet, 2 in use, -1 unusable.
+    bool pass_concurrent = true;
+    int pass_lane = 0, pass_free_cus = 4;
 
     // step I/O
     hc::DeviceBuffer<double> d_state, d_hs, d_rad, d_waves, d_total;

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -106,6 +108,8 @@ struct DirectQueue::Impl {
     };
     std::vector<hsa_signal_t> free_sigs;
     std::vector<Timed> timed;
+    std::vector<hsa_signal_t> order_sigs;  // ring of the cross-lane ordering signals (signal_after / wait_for)
+    size_t order_next = 0;
 
     uint64_t reserve(Lane& ln) {
         hsa_queue_t* queue = ln.queue;
@@ -162,6 +166,7 @@ DirectQueue::~DirectQueue() {
         if (p.lanes[l].have_gate) (void)hsa_signal_destroy(p.lanes[l].gate);
     }
     for (auto& t : p.timed) (void)hsa_signal_destroy(t.sig);
+    for (auto& g : p.order_sigs) (void)hsa_signal_destroy(g);
     for (auto& s : p.free_sigs) (void)hsa_signal_destroy(s);
     if (p.ring_all) (void)hipFree(p.ring_all);
     if (p.have_exe) (void)hsa_executable_destroy(p.exe);
@@ -379,6 +384,80 @@ bool DirectQueue::drain(double timeout_seconds, int lane) {
     }
     busy_[lane] = false;
     return true;
+}
+
+uint64_t DirectQueue::signal_after(int lane) {
+    Impl& p        = *p_;
+    Impl::Lane& ln = p.lanes[lane];
+    if (!ln.queue || failed(lane)) return 0;
+    if (p.order_sigs.empty()) {
+        p.order_sigs.resize(kSignalRing);
+        // only barrier packets wait for these (the host just looks at the value before it re-uses one): no interrupt on completion
+        for (auto& g : p.order_sigs)
+            if (hsa_amd_signal_create(0, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &g) != HSA_STATUS_SUCCESS &&
+                hsa_signal_create(0, 0, nullptr, &g) != HSA_STATUS_SUCCESS)
+                g.handle = 0;
+    }
+    hsa_signal_t sig = p.order_sigs[p.order_next];
+    p.order_next     = (p.order_next + 1) % p.order_sigs.size();
+    if (!sig.handle) return 0;
+    // its previous use lies kSignalRing calls back: long completed, or the queue is stuck (bounded look, then give the handle up)
+    const uint64_t slice = std::max<uint64_t>(1, (p.ticks_per_second ? p.ticks_per_second : 100000000ull) / 1000);
+    for (int tries = 0; hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, slice, HSA_WAIT_STATE_ACTIVE) >= 1; ++tries)
+        if (tries > 2000 || failed(lane)) return 0;
+    hsa_signal_store_relaxed(sig, 1);
+    const uint64_t idx = p.reserve(ln);
+    auto* pkt = reinterpret_cast<hsa_barrier_and_packet_t*>(ln.queue->base_address) + (idx & (ln.queue->size - 1));
+    std::memset(reinterpret_cast<char*>(pkt) + 4, 0, sizeof(*pkt) - 4);
+    pkt->completion_signal = sig;
+    const uint16_t header  = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                            (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                            (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    p.publish(ln, pkt, header, 0, idx);
+    if (ln.armed) {
+        hsa_signal_store_screlease(ln.gate, 0);
+        ln.armed = false;
+    }
+    busy_[lane] = true;
+    return sig.handle;
+}
+
+void DirectQueue::wait_for(int lane, uint64_t handle) {
+    Impl& p        = *p_;
+    Impl::Lane& ln = p.lanes[lane];
+    if (!ln.queue || failed(lane) || handle == 0) return;
+    const uint64_t idx = p.reserve(ln);
+    auto* pkt = reinterpret_cast<hsa_barrier_and_packet_t*>(ln.queue->base_address) + (idx & (ln.queue->size - 1));
+    std::memset(reinterpret_cast<char*>(pkt) + 4, 0, sizeof(*pkt) - 4);
+    pkt->dep_signal[0].handle = handle;
+    const uint16_t header     = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                            (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                            (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    p.publish(ln, pkt, header, 0, idx);
+    if (ln.armed) {
+        hsa_signal_store_screlease(ln.gate, 0);
+        ln.armed = false;
+    }
+    busy_[lane] = true;
+}
+
+void DirectQueue::enable_timing(int lane) {
+    if (p_->lanes[lane].queue) (void)hsa_amd_profiling_set_profiler_enabled(p_->lanes[lane].queue, 1);
+}
+
+uint32_t DirectQueue::compute_units() const {
+    uint32_t ncu = 0;
+    if (hsa_agent_get_info(p_->agent, static_cast<hsa_agent_info_t>(HSA_AMD_AGENT_INFO_COMPUTE_UNIT_COUNT), &ncu) != HSA_STATUS_SUCCESS) return 0;
+    return ncu;
+}
+
+bool DirectQueue::set_cu_mask(int lane, uint32_t keep) {
+    Impl::Lane& ln     = p_->lanes[lane];
+    const uint32_t ncu = compute_units();
+    if (!ln.queue || ncu == 0 || keep == 0 || keep > ncu) return false;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (uint32_t i = 0; i < keep; ++i) mask[i / 32] |= 1u << (i % 32);
+    return hsa_amd_queue_cu_set_mask(ln.queue, static_cast<uint32_t>(mask.size() * 32), mask.data()) == HSA_STATUS_SUCCESS;
 }
 
 size_t DirectQueue::timed_pending() const { return p_->timed.size(); }

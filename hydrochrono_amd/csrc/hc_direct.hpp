@@ -63,7 +63,19 @@ class DirectQueue {
     bool failed(int lane = 0) const;
     std::string failure_text() const;
     bool busy(int lane = 0) const { return busy_[lane]; }
-    static constexpr int kLanes = 2;
+    static constexpr int kLanes = 3;  // 0: the step path; 1: added-mass products; 2: look-ahead passes that run beside the steps
+    // Cross-lane ordering.  signal_after(lane): a barrier packet behind everything dispatched to the lane so far; the returned
+    // handle completes when all of that has finished (0: no signal could be had -- the caller must not rely on ordering then).
+    // wait_for(lane, handle): a barrier packet that holds back everything dispatched to the lane AFTER it until the handle has
+    // completed.  Handles come from a small ring of signals and stay valid for the next kSignalRing - 1 calls of signal_after.
+    uint64_t signal_after(int lane);
+    void wait_for(int lane, uint64_t handle);
+    static constexpr int kSignalRing = 64;
+    // Restricts the lane's queue to the first `keep` compute units in the runtime's mask order (bits are dealt to the XCDs in turn,
+    // so every XCD keeps the same number free for the other lanes).  false: the runtime refused.
+    bool set_cu_mask(int lane, uint32_t keep);
+    void enable_timing(int lane);  // device timestamps for the lane's timed dispatches (lane 0 has them from init)
+    uint32_t compute_units() const;
     // Reports (tag, seconds, aux) of every timed dispatch since the last call (waits for them).
     void collect(const std::function<void(int, double, double)>& sink);
     size_t timed_pending() const;
@@ -73,7 +85,7 @@ class DirectQueue {
   private:
     struct Impl;
     std::unique_ptr<Impl> p_;
-    bool busy_[kLanes] = {false, false};
+    bool busy_[kLanes] = {false, false, false};
 };
 
 }  // namespace hc

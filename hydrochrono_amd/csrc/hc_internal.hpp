@@ -87,7 +87,9 @@ void choose_conv_config(hc_ctx* c);
 void choose_exc_config(hc_ctx* c);
 void alloc_partials(hc_ctx* c);
 int far_chunk_gp(const hc_ctx* c);
+int far_chunks_per_slice(const hc_ctx* c);
 int default_pass_slices(const hc_ctx* c);
+int default_pass_ahead(const hc_ctx* c);
 void ensure_processed(hc_ctx* c);
 void check_device_flag(hc_ctx* c);
 void stage_state(hc_ctx* c, const double* pos, const double* rpy, const double* linvel, const double* angvel);

@@ -52,8 +52,15 @@ void count_context_on_device(int device, int delta) {
 
 // Bounded: a queue that does not drain within HC_STEP_TIMEOUT_S (or reports an error) is a lost device -> HC_ERR_DEVICE.
 void quiesce_direct(hc_ctx* c) {
+    static const double limit = [] { const char* e = std::getenv("HC_STEP_TIMEOUT_S"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 20.0; }();
+    if (c->dq && c->dq->busy(2) && !c->dq->drain(limit, 2)) {  // the pass lane first: its work may wait for signals of lane 0
+        // (lane 0 is still live, so those signals do arrive; a pass lane that does not drain is a lost device all the same)
+        c->lost         = true;
+        c->direct_ready = false;
+        c->direct_why   = "the pass lane of the direct queue did not drain: " + c->dq->failure_text();
+        throw Error(HC_ERR_DEVICE, c->direct_why);
+    }
     if (c->dq && c->dq->busy()) {
-        static const double limit = [] { const char* e = std::getenv("HC_STEP_TIMEOUT_S"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 20.0; }();
         if (!c->dq->drain(limit)) {
             c->lost         = true;
             c->direct_ready = false;
@@ -327,21 +334,39 @@ void choose_conv_config(hc_ctx* c) {
 
 // Chunk length of a pass that is issued in slices (pass schedule "one block ahead").  The pass of a block is ONE round of long-lived
 // workgroups -- one per CU at depth 32, each streaming its chunk for the whole duration -- so a slice must bring a full round of its
-// own: the chunks are `pass_slices` times shorter (a function of the column count and the slice count only, like every chunk length).
-// Default slice count: slices of roughly 300 MB of the UNSHARDED K (a slice then takes 50-200 us on one GPU or on a row shard), between
+// own, and the round is that of the PASS LANE, whose queue leaves pass_free_cus compute units of every XCD to the step kernels
+// (hc_step.cpp: pass_lane_ready): with the usual four row groups a slice has (CUs - 8 * free) / 4 chunks, in whole octets (56 on
+// an MI355X with 4 free CUs per XCD).  A function of the column count, the slice count and the device only, like every chunk length.
+// Default pass schedule (hc_set_pass_schedule): one block ahead for wide systems -- the same switch as the two-level look-ahead, a
+// function of D only.  There the pass is long (1.5 ms for a C4/8 rank) and the schedule wins for every caller: 70 -> 53 us per step
+// back to back, 58 -> 20 us with 300 us of host work between calls (profiles/r03/ahead_probe.txt).  At C3 size a caller that steps back
+// to back gains nothing (18.9 -> 18.6 us) while the pass runs in slices of lower efficiency, so the schedule stays the caller's choice.
+int default_pass_ahead(const hc_ctx* c) {
+    const int forced = env_int("HC_PASS_AHEAD", -1);
+    if (forced >= 0) return forced != 0 ? 1 : 0;
+    return hc::near_slices_for(c->D) > 1 ? 1 : 0;
+}
+
+// Default slice count: slices of roughly 320 MB of the UNSHARDED K (a slice then takes 50-200 us on one GPU or on a row shard), between
 // 2 and 8 -- 4 at C3 (each launch has a fixed cost of about 11 us there: 8 slices make the pass 283 us instead of 192, 4 make it 234),
 // 8 for C4.  A function of the system's size only, never of the rows a context owns.
 int default_pass_slices(const hc_ctx* c) {
     const int forced = env_int("HC_PASS_SLICES", 0);
     if (forced > 0) return std::min(forced, hc::kLookahead - 1);
     const double bytes = 8.0 * static_cast<double>(c->D) * c->D * c->S;
-    return std::max(2, std::min(8, static_cast<int>(std::ceil(bytes / 300e6))));
+    return std::max(2, std::min(8, static_cast<int>(std::ceil(bytes / 320e6))));
+}
+
+int far_chunks_per_slice(const hc_ctx* c) {
+    const int usable = c->num_cus - 8 * c->pass_free_cus;  // (also where the pass lane is not in use: one arithmetic for every way the slices are issued)
+    return std::max(8, ((usable / 4) / 8) * 8);
 }
 
 int far_chunk_gp(const hc_ctx* c) {
-    int g = c->chunk_gp_block / std::max(1, c->pass_slices);
-    g     = std::max(16, ((g + 15) / 16) * 16);
-    return std::min(g, std::max(16, c->chunk_gp_block));
+    const long long nch = static_cast<long long>(far_chunks_per_slice(c)) * std::max(1, c->pass_slices);
+    long long g         = (c->ngp + nch - 1) / nch;
+    g                   = std::max<long long>(16, ((g + 15) / 16) * 16);
+    return static_cast<int>(std::min<long long>(g, std::max(16, c->chunk_gp_block)));
 }
 
 void choose_exc_config(hc_ctx* c) {
@@ -369,6 +394,8 @@ void alloc_partials(hc_ctx* c) {
     if (c->d_partials_block.n < nb) c->d_partials_block.alloc(nb);
     const size_t nfar = static_cast<size_t>((c->ngp + far_chunk_gp(c) - 1) / far_chunk_gp(c) + c->nchunks_ex_block) * hc::kLookahead * c->Dpad;
     if (c->pass_ahead && c->d_partials_far.n < nfar) c->d_partials_far.alloc(nfar);
+    const size_t nnext = static_cast<size_t>(mini_chunks) * hc::kLookahead * c->Dpad;
+    if (c->pass_ahead && c->d_partials_next.n < nnext) c->d_partials_next.alloc(nnext);
     // two blocks of rows each: the current block's and (pass schedule "one block ahead") the next one's
     const size_t npe = static_cast<size_t>(2 * hc::kLookahead) * c->Dpad;
     if (c->d_P.n < npe) c->d_P.alloc(npe);

@@ -316,8 +316,10 @@ int hc_finalize(hc_ctx* c) {
     {
         const int want = env_int("HC_LOOKAHEAD", 32);
         c->lookahead   = want <= 0 ? 0 : (want <= 16 ? 16 : hc::kLookahead);
-        c->pass_ahead  = env_int("HC_PASS_AHEAD", 0) != 0 ? 1 : 0;  // hc_set_pass_schedule
+        c->pass_ahead  = default_pass_ahead(c);  // hc_set_pass_schedule
         c->pass_slices = default_pass_slices(c);
+        c->pass_concurrent = env_int("HC_PASS_CONCURRENT", 1) != 0;
+        c->pass_free_cus   = std::max(1, std::min(16, env_int("HC_PASS_FREE_CUS", 4)));
         c->ahead.active = false;
     }
     // GEMV scratch
@@ -329,8 +331,8 @@ int hc_finalize(hc_ctx* c) {
     c->d_waves.alloc(c->Dloc);
     c->d_total.alloc(c->Dloc);
     for (auto* b : {&c->d_hs, &c->d_rad, &c->d_waves, &c->d_total}) HC_HIP(hipMemsetAsync(b->p, 0, b->n * sizeof(double), c->stream));
-    c->d_err.alloc(2);  // [0] error flag of the convolution kernels, [1] work-item counter of the look-ahead pass
-    HC_HIP(hipMemsetAsync(c->d_err.p, 0, 2 * sizeof(int), c->stream));
+    c->d_err.alloc(3);  // [0] error flag of the convolution kernels, [1] work-item counter of the look-ahead pass, [2] ... of a pass on the pass lane
+    HC_HIP(hipMemsetAsync(c->d_err.p, 0, 3 * sizeof(int), c->stream));
     c->h_state.alloc(static_cast<size_t>(2) * 12 * c->N);  // two halves used alternately by hc_step, see there
     c->bar_state.alloc(static_cast<size_t>(2) * 12 * c->N);
     if (c->bar_state.host_ok) {

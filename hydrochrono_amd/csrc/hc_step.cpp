@@ -243,7 +243,7 @@ PassSetup make_pass(hc_ctx* c, bool with_exc, bool next_block) {
 }
 
 // One launch of the pass over the radiation chunks [first, last) (+ the excitation work items if with_items).
-void issue_pass_chunks(hc_ctx* c, const PassSetup& ps, int first, int last, bool with_items, hipStream_t stream, bool direct) {
+void issue_pass_chunks(hc_ctx* c, const PassSetup& ps, int first, int last, bool with_items, hipStream_t stream, bool direct, int lane = 0) {
     hc::BlockArgs b = ps.b;
     b.chunk_first   = first;
     b.chunk_last    = last;
@@ -259,8 +259,9 @@ void issue_pass_chunks(hc_ctx* c, const PassSetup& ps, int first, int last, bool
         const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_block, &b2);
         if (l.nblocks <= 0) return;
         c->dq->dispatch(L == 32 ? c->dk_block32 : c->dk_block16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
-                        direct_tag(c, hc::kEvPass), exc_share);
+                        direct_tag(c, hc::kEvPass), exc_share, lane);
         c->prof.direct_dispatches += 1;
+        if (lane == 2) c->prof.pass_lane_launches += 1;
         return;
     }
     hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_share);
@@ -270,11 +271,11 @@ void issue_pass_chunks(hc_ctx* c, const PassSetup& ps, int first, int last, bool
 }
 
 // ... and the reduction of its chunk partials into the rows P / E of a block.
-void issue_pass_reduce(hc_ctx* c, const PassSetup& ps, double* P, double* E, hipStream_t stream, bool direct) {
+void issue_pass_reduce(hc_ctx* c, const PassSetup& ps, double* P, double* E, hipStream_t stream, bool direct, int lane = 0) {
     const hc::BlockArgs& b = ps.b;
     const hc::ReduceArgs r{b.partials, b.nchunks, b.nchunks_ex, c->Dpad, c->lookahead, P, E, b.item_counter, 0, 0, 0, 0};
     if (direct) {
-        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r);
+        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r, -1, 0.0, lane);
         c->prof.direct_dispatches += 1;
         return;
     }
@@ -292,8 +293,9 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = fal
 // ---- pass schedule "one block ahead" (hc_set_pass_schedule) ----------------------------------------
 // Begun right after the pass-free start of a block (or after the ordinary pass of the first block): the pass of the NEXT block, in
 // `pass_slices` launches -- one now, the others behind the scatter launches of the following steps -- so that a caller that
-// leaves the GPU idle between two force evaluations never waits for a whole pass.  The chunk partials of all slices are added by
-// ONE reduction after the last slice, in the order of the unsliced pass.
+// leaves the GPU idle between two force evaluations never waits for a whole pass.  A slice is a full round of workgroups over chunks
+// `pass_slices` times shorter than those of the ordinary pass (far_chunk_gp); the chunk partials of all slices are added by ONE
+// reduction after the last slice, in chunk order -- the sums do not depend on how the chunks were spread over launches.
 void ahead_drop(hc_ctx* c) { c->ahead.active = false; }
 
 void ahead_issue_slice(hc_ctx* c, hipStream_t stream, bool direct) {
@@ -310,16 +312,36 @@ void ahead_issue_slice(hc_ctx* c, hipStream_t stream, bool direct) {
     ps.rad_once  = ah.rad_once;
     ps.exc_once  = ah.exc_once;
     ps.bytes_steps = ah.rad_once + ah.exc_once;
+    // beside the steps (the pass lane) when the chain began there and this step is dispatched directly; a step that goes through HIP
+    // launches has emptied both lanes on its way in (enqueue_step), so its slice may follow on the stream
+    const int lane = (ah.concurrent && direct) ? 2 : 0;
     const int n = ps.b.nchunks, k = ah.issued;
     const int first = std::min(n, k * ah.per_slice), last = std::min(n, (k + 1) * ah.per_slice);  // never empty, see ahead_begin
     const bool final_slice = k + 1 >= ah.slices;
-    issue_pass_chunks(c, ps, first, last, final_slice, stream, direct);
+    issue_pass_chunks(c, ps, first, last, final_slice, stream, direct, lane);
     ah.issued = k + 1;
     c->prof.ahead_pass_slices += 1;
     if (final_slice) {
-        issue_pass_reduce(c, ps, rows_P(c, true), rows_E(c, true), stream, direct);
+        issue_pass_reduce(c, ps, rows_P(c, true), rows_E(c, true), stream, direct, lane);
         ah.reduced = true;
     }
+}
+
+// The pass lane: created when the schedule first needs it, with a CU mask that leaves pass_free_cus compute units of every XCD to the
+// kernels of the step path (a pass workgroup holds its CU's registers for its whole life, so a step kernel that finds no free CU
+// would wait for a pass workgroup to end; profiles/overlap_probe.hip).  Without the mask the lane is not used.
+bool pass_lane_ready(hc_ctx* c) {
+    if (c->pass_lane == 2) return true;
+    if (c->pass_lane < 0 || !c->pass_concurrent || !c->dq || !c->direct_ready) return false;
+    // one more queue per context: only where the device is this context's alone (several contexts on ONE device -- a test bed for the
+    // multi-GPU code, not a deployment -- already time-share its hardware queues; their slices stay on the step path's lane)
+    if (contexts_on_device(c->device) > 1) return false;
+    std::string why;
+    const uint32_t ncu = c->dq->compute_units();
+    const uint32_t keep = ncu > 8u * static_cast<uint32_t>(c->pass_free_cus) + 8 ? ncu - 8u * static_cast<uint32_t>(c->pass_free_cus) : 0;
+    c->pass_lane = (keep > 0 && c->dq->ensure_lane(2, &why) && c->dq->set_cu_mask(2, keep)) ? 2 : -1;
+    if (c->pass_lane == 2) c->dq->enable_timing(2);  // its passes are timed like those of lane 0
+    return c->pass_lane == 2;
 }
 
 void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
@@ -332,7 +354,8 @@ void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
     const hc::MiniPass probe = hc::mini_pass_next(c->plan, L, kw, c->tau);
     const int chunk_gp = std::max(16, (((c->D + 7) / 8 / 2 + 15) / 16) * 16);
     const long long chunks = (static_cast<long long>(probe.n_samples) * c->D / 8 + chunk_gp) / chunk_gp + 1;
-    if (static_cast<size_t>(chunks) * L * c->Dpad > c->d_partials_block.n || c->d_partials_far.n == 0) return;
+    const size_t need = static_cast<size_t>(chunks) * L * c->Dpad;
+    if (need > c->d_partials_block.n || need > c->d_partials_next.n || c->d_partials_far.n == 0) return;
     const PassSetup ps = make_pass(c, with_exc, true);
     ah.args        = ps.b;
     ah.has_exc     = ps.exc_block;
@@ -342,17 +365,30 @@ void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
     ah.plan_serial = c->plan_serial;
     ah.t_first     = c->plan.tgrid[L + 1];
     ah.t_last      = c->plan.tgrid[2 * L];
-    // whole octets of chunks per slice (the kernel's block mapping deals octets), no empty slice; the reduction must be out before the
-    // first short pass adds to the rows, i.e. within the first sub-block
-    const int limit  = c->plan.sub > 0 ? c->plan.sub : L - 1;
-    const int octets = (ps.b.nchunks + 7) / 8;
-    const int want   = std::max(1, std::min(std::min(c->pass_slices, limit), octets));
-    const int per    = (octets + want - 1) / want;
-    ah.per_slice   = per * 8;
-    ah.slices      = (octets + per - 1) / per;
+    // a slice = one round of workgroups of the pass lane (far_chunks_per_slice: whole octets of chunks, as the kernel's block mapping
+    // deals them); the reduction must be out before the first short pass adds to the rows, i.e. within the first sub-block (wider
+    // slices if that takes fewer of them)
+    const int limit = c->plan.sub > 0 ? c->plan.sub : L - 1;
+    int per         = far_chunks_per_slice(c);
+    while ((ps.b.nchunks + per - 1) / per > limit) per += 8;
+    ah.per_slice    = per;
+    ah.slices       = std::max(1, (ps.b.nchunks + per - 1) / per);
     ah.issued      = 0;
     ah.reduced     = false;
+    ah.concurrent  = false;
     ah.active      = true;
+    if (direct && pass_lane_ready(c)) {
+        // beside the steps: the slices (and later the short passes towards the next block) go to the pass lane, behind everything
+        // lane 0 holds now -- the step kernel that pushed the newest sample the pass reads, the last reader of the rows it is going to
+        // overwrite.  Still in slices: a caller that stays away between steps then finds each slice done when it comes back (the
+        // pass would otherwise share the memory system with the next few steps), one that steps back to back just fills the lane.
+        const uint64_t h = c->dq->signal_after(0);
+        if (h != 0) {
+            c->dq->wait_for(2, h);
+            ah.args.item_counter = c->d_err.p + 2;
+            ah.concurrent        = true;
+        }
+    }
     ahead_issue_slice(c, stream, direct);
 }
 
@@ -375,7 +411,7 @@ bool ahead_adoptable(const hc_ctx* c, unsigned long long ended_serial) {
 // own (half an IRF sample per chunk -- a function of D only, like every other chunk length).
 // next_block (pass schedule "one block ahead", hc_plan.hpp: mini_pass_next): the same for the steps of the NEXT block, added to the
 // rows the pass in the making has left; it starts at the first IRF sample those steps take.
-void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, bool next_block = false) {
+void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, bool next_block = false, int lane = 0) {
     const auto& pl = c->plan;
     const int L    = c->lookahead;
     const hc::MiniPass mp = next_block ? hc::mini_pass_next(pl, L, i0, c->tau) : hc::mini_pass_setup(pl, L, i0, c->tau);
@@ -412,27 +448,29 @@ void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, bool n
     b.ex           = make_views(c).ex;
     b.chunk_gp_ex  = c->chunk_gp_ex_block;
     b.nchunks_ex   = 0;
-    b.partials     = c->d_partials_block.p;
+    hc::DeviceBuffer<double>& scratch = lane == 2 ? c->d_partials_next : c->d_partials_block;  // the pass lane runs beside lane 0's short passes
+    b.partials     = scratch.p;
     b.Dpad         = c->Dpad;
     b.error_flag   = c->d_err.p;
-    b.item_counter = c->d_err.p + 1;
+    b.item_counter = c->d_err.p + (lane == 2 ? 2 : 1);
     b.ngroups      = c->ntiles / c->mt_mini;
     b.mini_kw      = mp.kw;
     b.mini_steps   = mp.n_steps;
     for (int k = 0; k <= mp.kw + 1; ++k) b.mini_time[k] = mp.time[k];
     b.chunk_first  = next_block ? static_cast<int>((static_cast<long long>(mp.s_first) * c->D / 8) / b.chunk_gp) : 0;
     b.chunk_last   = b.nchunks;
-    require(static_cast<size_t>(b.nchunks) * L * c->Dpad <= c->d_partials_block.n, HC_ERR_RUNTIME, "short pass: partials buffer too small");
-    hc::ReduceArgs r{c->d_partials_block.p, b.nchunks, 0, c->Dpad, L, rows_P(c, next_block), rows_E(c, next_block), b.item_counter, 1, next_block ? 0 : i0, mp.n_steps,
+    require(static_cast<size_t>(b.nchunks) * L * c->Dpad <= scratch.n, HC_ERR_RUNTIME, "short pass: partials buffer too small");
+    hc::ReduceArgs r{scratch.p, b.nchunks, 0, c->Dpad, L, rows_P(c, next_block), rows_E(c, next_block), b.item_counter, 1, next_block ? 0 : i0, mp.n_steps,
                      b.chunk_first};
     if (direct) {
         hc::BlockArgs b2;
         const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_mini, &b2);
         if (l.nblocks <= 0) return;
         c->dq->dispatch(L == 32 ? c->dk_mini32 : c->dk_mini16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
-                        direct_tag(c, hc::kEvMiniPass));
-        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r);
+                        direct_tag(c, hc::kEvMiniPass), 0.0, lane);
+        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r, -1, 0.0, lane);
         c->prof.direct_dispatches += 2;
+        if (lane == 2) c->prof.pass_lane_launches += 1;
         return;
     }
     hc::EventPair* ev = ev_begin(c, hc::kEvMiniPass, stream);
@@ -448,6 +486,13 @@ void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, bool n
 // own stream behind an event, so that whatever the caller enqueues next on its stream -- the all-gather of the force rows in
 // a multi-GPU run -- follows the step kernel directly.  hc_step_multi calls it after the step kernels of ALL shard contexts
 // have been handed to their GPUs.
+void pass_lane_drain(hc_ctx* c) {
+    if (c->dq && c->dq->busy(2) && !c->dq->drain(20.0, 2)) {
+        c->lost = true;
+        throw Error(HC_ERR_DEVICE, "the pass lane of the direct queue did not drain: " + c->dq->failure_text());
+    }
+}
+
 void enqueue_tail(hc_ctx* c) {
     if (!c->tail.pending) return;
     c->tail.pending        = false;
@@ -464,6 +509,24 @@ void enqueue_tail(hc_ctx* c) {
             HC_HIP(hipStreamWaitEvent(bs, c->ev_fin, 0));
         }
     };
+    // pass schedule "one block ahead": the pass of the next block is in the making under this block's plan
+    if (c->ahead.active && (!block || c->ahead.plan_serial != c->plan_serial)) ahead_drop(c);  // the block it belongs to was abandoned
+    const int ahead_kw      = c->plan.sub > 0 ? c->plan.sub : c->lookahead;
+    const bool window_end   = block && c->ahead.active && m % ahead_kw == 0;
+    bool window_done        = false;
+    if (window_end && c->ahead.concurrent) {
+        // a window of this block's samples ends here: what they contribute to the steps of the next block goes to the pass lane, behind
+        // the step kernel that has just pushed the window's last sample (and before this step's own scatter / short pass on lane 0)
+        const uint64_t h = direct ? c->dq->signal_after(0) : 0;
+        if (h != 0) {
+            c->dq->wait_for(2, h);
+            launch_mini_pass(c, m, bs, true, true, 2);
+            window_done = true;
+        } else {
+            // (no direct dispatch for this step, or no signal: the pass lane is emptied and the short pass follows on the step path)
+            pass_lane_drain(c);
+        }
+    }
     if (scatter_now) {
         to_background();
         const auto& pl = c->plan;
@@ -498,13 +561,9 @@ void enqueue_tail(hc_ctx* c) {
         to_background();
         launch_mini_pass(c, m, bs, direct);  // two-level form: the sub-block that ends here -> the block steps still to come
     }
-    // pass schedule "one block ahead": the pass of the next block is in the making under this block's plan
-    if (c->ahead.active && (!block || c->ahead.plan_serial != c->plan_serial)) ahead_drop(c);  // the block it belongs to was abandoned
     if (block && c->ahead.active) {
-        const int kw = c->plan.sub > 0 ? c->plan.sub : c->lookahead;
         to_background();
-        if (m % kw == 0) {
-            // a window of this block's samples ends here: what they contribute to the steps of the next block
+        if (window_end && !window_done) {
             if (c->ahead.reduced) launch_mini_pass(c, m, bs, direct, true);
             else ahead_drop(c);  // (cannot happen: the slices end within the first window)
         }
@@ -517,7 +576,12 @@ void enqueue_tail(hc_ctx* c) {
         if (make_plan(c)) {
             to_background();
             if (clean_end && ahead_adoptable(c, ended)) {
-                // the rows of this block are there already: no pass now
+                // the rows of this block are there already: no pass now.  Made on the pass lane: the steps of this block wait for it.
+                if (c->ahead.concurrent && c->dq && c->dq->busy(2)) {
+                    const uint64_t h2 = direct ? c->dq->signal_after(2) : 0;
+                    if (h2 != 0) c->dq->wait_for(0, h2);
+                    else pass_lane_drain(c);
+                }
                 c->pe_cur ^= 1;
                 c->plan.has_exc = c->ahead.has_exc;
                 c->prof.ahead_blocks += 1;
@@ -1234,7 +1298,7 @@ int hc_set_pass_schedule(hc_ctx* c, int one_block_ahead, int slices) {
     HC_API_BEGIN(c)
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     HC_HIP(hipDeviceSynchronize());  // a pass in the making may still be running
-    c->pass_ahead   = one_block_ahead ? 1 : 0;
+    c->pass_ahead   = one_block_ahead < 0 ? default_pass_ahead(c) : (one_block_ahead ? 1 : 0);
     c->pass_slices  = slices > 0 ? std::min(slices, hc::kLookahead - 1) : default_pass_slices(c);
     c->ahead.active = false;
     alloc_partials(c);

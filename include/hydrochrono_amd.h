@@ -228,7 +228,8 @@ int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
  * contract 1e-6).  Wide systems (6N >= 1024) use a two-level form: sub-blocks of 8 steps with a short pass over the head of K
  * after each.  steps = 0 disables it (every step streams K), 1..16 selects blocks of 16, more blocks of 32. */
 int hc_set_lookahead(hc_ctx* ctx, int steps);
-/* When the pass of a look-ahead block runs.  one_block_ahead = 0 (default): when the block starts.  A caller that comes back
+/* When the pass of a look-ahead block runs (one_block_ahead < 0: the library's default for the system's size -- 1 for wide
+ * systems, 6N >= 1024, else 0).  one_block_ahead = 0: when the block starts.  A caller that comes back
  * before the pass has finished waits for it on the first step of the block (190 us at 64 bodies; 1.55 ms for the 64-body row
  * shard of a 512-body array); a caller that stays away longer than that never notices it.  one_block_ahead = 1: the pass of the
  * NEXT block is computed from the history known when the current block starts, in `slices` launches (<= 0: chosen from the size of K, 2 .. 8) issued behind the
@@ -309,6 +310,7 @@ typedef struct hc_profile_stats {
     long long queue_parkings;      /* times the direct queue was left parked on a barrier packet after a step / an added-mass product */
     long long ahead_pass_slices;   /* pass schedule "one block ahead": launches of passes of a NEXT block (counted in block_passes too) */
     long long ahead_blocks;        /* ... and blocks that started with their rows already there (no pass at block start) */
+    long long pass_lane_launches;  /* passes / short passes dispatched to the pass lane of the direct queue (they run beside the steps) */
 } hc_profile_stats;
 /* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default), and around every
  * look-ahead pass (one per block) whatever the stride.  Event records perturb the launch stream by a few

@@ -1,0 +1,48 @@
+"""C4 rank share (rows of 64 of 512 bodies) through the Python wrapper, back to back: pass schedule 0 / 1, with and without waves."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+TORCH = os.environ.get("WITH_TORCH", "1") != "0"
+if TORCH:
+    import torch  # noqa
+    torch.zeros(1, device="cuda")
+import bench as B
+from hydrochrono_amd.hydro import HydroForces
+from hydrochrono_amd.mock_chrono import PrescribedMotion
+N = 512
+motion = PrescribedMotion(N, np.zeros((N, 3)), seed=20251031)
+nhist = B.S_RIRF + 5
+t_hist = B.T0 - B.DT * np.arange(1, nhist + 1)
+v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+nsteps = 72 + int(os.environ.get('NT', 256))
+times = [B.T0 + k * B.DT for k in range(nsteps)]
+states = [motion.state(t) for t in times]
+for waves in (False,):
+    for sched in (0, 1):
+        gpu = HydroForces(N, device=0, body_range=(0, 64))
+        gpu.synth_fill(20251031, B.S_RIRF, B.DT, int(os.environ.get('NEXC', B.N_EXC)), B.DT)
+        gpu.finalize()
+        if waves:
+            gpu.add_waves_irregular(**dict(B.WAVES, num_bodies=N, simulation_dt=B.DT, simulation_duration=B.T0 + nsteps * B.DT + 15.0))
+        else:
+            gpu.add_waves_none()
+        gpu.set_pass_schedule(sched)
+        if os.environ.get("NATURAL", "0") == "1":
+            for k in range(1124):  # build the history by stepping, like profiles/ahead_probe.cpp
+                tt = B.T0 - (1124 - k) * B.DT
+                gpu.step(tt, *motion.state(tt))
+        else:
+            gpu.set_history(t_hist, v_hist)
+        lat = []
+        for k in range(nsteps):
+            a = time.perf_counter()
+            gpu.step(times[k], *states[k])
+            if k >= 72:
+                lat.append(time.perf_counter() - a)
+        lat = np.array(lat) * 1e6
+        if len(lat) >= 512:
+            print("   per 128 steps:", " ".join(f"{lat[i:i + 128].mean():.1f}" for i in range(0, len(lat), 128)))
+        p = gpu.profile()
+        print(f"waves {waves} schedule {sched}: mean {lat.mean():6.1f} us median {np.median(lat):6.1f} p90 {np.percentile(lat, 90):6.1f} p99 {np.percentile(lat, 99):7.1f} max {lat.max():7.1f}  ahead blocks {p['ahead_blocks']} pass-lane launches {p['pass_lane_launches']}", flush=True)
+        gpu.close()

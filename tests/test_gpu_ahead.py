@@ -67,6 +67,8 @@ def test_one_block_ahead_against_oracle(hydro, N, dt, lookahead, sub, direct, mo
     assert p["ahead_blocks"] >= (nsteps - full_at) // lookahead - 1 and p["ahead_blocks"] >= 3, p
     assert p["ahead_pass_slices"] >= p["ahead_blocks"], p
     assert (p["direct_dispatches"] > 0, p["hip_launches"] > 0) == (bool(direct), not direct) or not direct, p
+    # with direct dispatch (and the device to itself) the passes in the making run on the pass lane, beside the steps
+    assert (p["pass_lane_launches"] > 0) == bool(direct), p
 
 
 @pytest.mark.parametrize("slices", [1, 3, 16, 31])
@@ -91,6 +93,35 @@ def test_one_block_ahead_slice_counts(hydro, slices, sub, monkeypatch):
     assert p["ahead_blocks"] >= 3, p
     per_block = p["ahead_pass_slices"] / (p["ahead_blocks"] + 1)
     assert per_block <= min(slices, sub if sub else 31) + 1e-9, p
+
+
+@pytest.mark.parametrize("sub", [0, 8])
+def test_one_block_ahead_without_the_pass_lane(hydro, sub, monkeypatch):
+    """HC_PASS_CONCURRENT=0: the slices and the short passes towards the next block stay on the step path's lane (what contexts
+    that share a device do) -- the same arithmetic, bitwise the forces of a context that uses the pass lane."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_SUB_BLOCK", str(sub))
+    N = 4
+    case = many_body_case(N, S=200, dt_rirf=0.01, n_exc=41, dt_exc=0.02, seed=78)
+    kw = dict(WAVES, simulation_duration=6.0)
+    motion = PrescribedMotion(N, rest_positions(case), seed=N)
+    runs = []
+    for concurrent in ("1", "0"):
+        monkeypatch.setenv("HC_PASS_CONCURRENT", concurrent)
+        gpu = hydro.HydroForces.from_case(case)
+        gpu.add_waves_irregular(**kw)
+        gpu.set_pass_schedule(1)
+        f = np.stack([gpu.step(0.01 * n, *motion.state(0.01 * n)) for n in range(420)])
+        p = gpu.profile()
+        assert p["ahead_blocks"] >= 4 and (p["pass_lane_launches"] > 0) == (concurrent == "1"), p
+        runs.append(f)
+        gpu.close()
+    assert np.array_equal(runs[0], runs[1])
+    orc = load_into_oracle(case)
+    orc.add_waves_irregular(**kw)
+    for n in range(420):
+        assert relerr(runs[0][n], orc.step(0.01 * n, *motion.state(0.01 * n))) <= TIGHT_TOL, f"step {n}"
 
 
 def test_one_block_ahead_survives_off_grid_steps_and_steps_back(hydro):
@@ -202,7 +233,7 @@ def test_one_block_ahead_c3_size_against_flat_oracle(hydro):
         assert e <= TIGHT_TOL, f"step {n}"
     p = gpu.profile()
     assert p["ahead_blocks"] >= 5 and p["conv_kernel_launches"] == 1, p
-    assert gpu.direct_dispatch()[0] and p["hip_launches"] == 0, p
+    assert gpu.direct_dispatch()[0] and p["hip_launches"] == 0 and p["pass_lane_launches"] >= 5 * 5, p
     print(f"C3 one block ahead: worst relative error {worst:.2e}, {p['ahead_blocks']} blocks without a pass of their own, {p['ahead_pass_slices']} slices")
 
 

@@ -229,19 +229,21 @@ int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
  * after each.  steps = 0 disables it (every step streams K), 1..16 selects blocks of 16, more blocks of 32. */
 int hc_set_lookahead(hc_ctx* ctx, int steps);
 /* When the pass of a look-ahead block runs (one_block_ahead < 0: the library's default for the system's size -- 1 for wide
- * systems, 6N >= 1024, else 0).  one_block_ahead = 0: when the block starts.  A caller that comes back
- * before the pass has finished waits for it on the first step of the block (190 us at 64 bodies; 1.55 ms for the 64-body row
- * shard of a 512-body array); a caller that stays away longer than that never notices it.  one_block_ahead = 1: the pass of the
- * NEXT block is computed from the history known when the current block starts, in `slices` launches (<= 0: chosen from the size of K, 2 .. 8) issued behind the
- * first steps of the current block, and what the current block's own samples add to the next block's steps follows in short
- * passes over the head of K.  The longest a step can then wait is one slice plus a short pass.  Measured on an MI355X, mean
- * hc_step latency with 100 / 300 us of host work between calls: 64 bodies 16.6 -> 13.7 / 13.7 -> 13.7 us (p99 105 -> 15 us at
- * 100 us); the 64-of-512-body shard 65.6 -> 44.6 / 58.3 -> 19.8 us (p99 1258 -> 22 us at 300 us).  A caller that steps back to
- * back gains nothing and pays the short passes (19.2 -> 21.8 us and 70 -> 81 us).  Used once the history covers the IRF window;
- * results are those of schedule 0 up to the rounding of a different summation grouping (same 1e-6 contract, same tolerance on
- * the predicted times).  The schedule is part of the configuration: the row shards of one array must use the same one (and the
- * same slice count) to stay bitwise equal to the unsharded context.  HC_PASS_AHEAD=1 (HC_PASS_SLICES=n) in the environment make
- * it the default of new contexts. */
+ * systems, 6N >= 1024, else 0).  one_block_ahead = 0: when the block starts.  A caller that comes back before the pass has
+ * finished waits for it on the first step of the block (190 us at 64 bodies; 1.55 ms for the 64-body row shard of a 512-body
+ * array); a caller that stays away longer than that never notices it.  one_block_ahead = 1: the pass of the NEXT block is computed
+ * from the history known when the current block starts, in `slices` launches (<= 0: chosen from the size of K, 2 .. 8) issued
+ * behind the first steps of the current block, and what the current block's own samples add to the next block's steps follows in
+ * short passes over the head of K.  With direct dispatch (and the device to itself) all of that runs BESIDE the steps, on a queue
+ * of its own whose CU mask leaves a few compute units of every XCD to the step kernels.  No step then waits for a whole pass.
+ * Measured on an MI355X, mean hc_step latency of a C++ caller with 30 / 100 / 300 us of host work between calls: 64 bodies
+ * 17.2 -> 13.5 / 15.1 -> 12.3 / 12.2 -> 12.4 us (p99 at 100 us: 106 -> 15 us); the 64-of-512-body shard - / 64.1 -> 30.9 /
+ * 58.8 -> 19.0 us (p99 at 300 us: 1321 -> 34 us).  A caller that steps back to back has nothing to hide the pass behind and pays
+ * the short passes: 18.4 -> 19.0 us and 73.9 -> 78.2 us.  Used once the history covers the IRF window; results are those of
+ * schedule 0 up to the rounding of a different summation grouping (same 1e-6 contract, same tolerance on the predicted times).
+ * The schedule is part of the configuration: the row shards of one array must use the same one (and the same slice count) to
+ * stay bitwise equal to the unsharded context.  HC_PASS_AHEAD=0/1 (HC_PASS_SLICES=n, HC_PASS_CONCURRENT=0: no queue of its own)
+ * in the environment set the default of new contexts. */
 int hc_set_pass_schedule(hc_ctx* ctx, int one_block_ahead, int slices);
 /* How hc_step hands its kernels to the GPU.  1: as AQL packets written straight into an HSA queue of the library's own (kernel
  * arguments stored through the PCIe BAR) -- the default when the stand-alone code object hc_kernels.co lies next to the library,

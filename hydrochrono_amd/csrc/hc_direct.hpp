@@ -43,8 +43,8 @@ class DirectQueue {
     // One kernel dispatch: grid of `workgroups` x `wg_size` work-items, `dyn_lds` bytes of dynamic LDS, the argument block
     // copied into the next kernarg slot.  timed >= 0: the dispatch carries a completion signal and its device-side duration
     // is reported by collect() with this tag.
-    // lane: which of the object's two independent queues (0: the step path; 1: the added-mass product, which must never wait
-    // behind work the step path still runs).
+    // lane: which of the object's independent queues (0: the step path; 1: the added-mass product, which must never wait behind
+    // work the step path still runs; 2: look-ahead passes that run beside the steps, see signal_after / wait_for / set_cu_mask).
     void dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t wg_size, uint32_t dyn_lds, const void* args, size_t arg_bytes,
                   int timed_tag = -1, double timed_aux = 0.0, int lane = 0);
     // Parks the lane's packet processor on a barrier packet that waits for a signal; the next dispatch() releases it right after

@@ -340,9 +340,10 @@ bool pass_lane_ready(hc_ctx* c) {
     const uint32_t ncu = c->dq->compute_units();
     const uint32_t keep = ncu > 8u * static_cast<uint32_t>(c->pass_free_cus) + 8 ? ncu - 8u * static_cast<uint32_t>(c->pass_free_cus) : 0;
     bool abandon = false;
-    // (the same self-test as the other lanes: argument slots the host re-writes must be re-read, not served stale)
-    c->pass_lane = (keep > 0 && c->dq->ensure_lane(2, &why) && c->dq->set_cu_mask(2, keep) && direct_selftest_rewrites(c, c->dq, 2, &abandon)) ? 2 : -1;
-    if (c->pass_lane == 2) c->dq->enable_timing(2);  // its passes are timed like those of lane 0
+    // (timed like lane 0; the same self-test as the other lanes: argument slots the host re-writes must be re-read, not served stale)
+    bool ok = keep > 0 && c->dq->ensure_lane(2, &why) && c->dq->set_cu_mask(2, keep);
+    if (ok) c->dq->enable_timing(2);
+    c->pass_lane = (ok && direct_selftest_rewrites(c, c->dq, 2, &abandon)) ? 2 : -1;
     return c->pass_lane == 2;
 }
 

@@ -235,7 +235,9 @@ int hc_set_lookahead(hc_ctx* ctx, int steps);
  * from the history known when the current block starts, in `slices` launches (<= 0: chosen from the size of K, 2 .. 8) issued
  * behind the first steps of the current block, and what the current block's own samples add to the next block's steps follows in
  * short passes over the head of K.  With direct dispatch (and the device to itself) all of that runs BESIDE the steps, on a queue
- * of its own whose CU mask leaves a few compute units of every XCD to the step kernels.  No step then waits for a whole pass.
+ * of its own whose CU mask leaves a few compute units of every XCD to the step kernels; contexts that share a device, and steps
+ * that go through HIP launches, issue the same launches on the step path's own queue / stream (the same sums; a back-to-back
+ * caller then pays 10-30 % for them).  No step waits for a whole pass.
  * Measured on an MI355X, mean hc_step latency of a C++ caller with 30 / 100 / 300 us of host work between calls: 64 bodies
  * 17.2 -> 13.5 / 15.1 -> 12.3 / 12.2 -> 12.4 us (p99 at 100 us: 106 -> 15 us); the 64-of-512-body shard - / 64.1 -> 30.9 /
  * 58.8 -> 19.0 us (p99 at 300 us: 1321 -> 34 us).  A caller that steps back to back has nothing to hide the pass behind and pays

@@ -16,7 +16,7 @@ LIBDIR = os.path.join(PKG, "lib")
 MAIN_LIB = os.path.join(LIBDIR, "libhydrochrono_amd.so")
 BEMIO_LIB = os.path.join(LIBDIR, "libhc_bemio.so")
 
-SOURCES = ["hc_kernels.hip", "hc_runtime.cpp", "hc_step.cpp", "hc_setup.cpp", "hc_query.cpp", "hc_direct.cpp", "hc_host_math.cpp", "hc_yaml.cpp",
+SOURCES = ["hc_kernels.hip", "hc_runtime.cpp", "hc_step.cpp", "hc_pass.cpp", "hc_setup.cpp", "hc_query.cpp", "hc_direct.cpp", "hc_host_math.cpp", "hc_yaml.cpp",
            "hc_eta_fft.cpp"]
 KERNEL_CO = os.path.join(LIBDIR, "hc_kernels.co")  # the same kernels as a stand-alone code object, for the direct AQL dispatch (hc_direct.hpp)
 HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_internal.hpp", "hc_host_math.hpp", "hc_limits.hpp", "hc_plan.hpp", "hc_history.hpp", "hc_direct.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h"),

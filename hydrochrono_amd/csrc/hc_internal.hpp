@@ -106,5 +106,34 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
                   unsigned long long* host_tagged = nullptr, unsigned long long seq = 0, bool defer_tail = false);
 void enqueue_tail(hc_ctx* c);
 
+// ---- hc_step.cpp helpers the passes use ----
+bool wave_window_ok(const hc_ctx* c, double t);
+int live_samples(const hc_ctx* c, double t_query);
+double* rows_P(hc_ctx* c, bool next);
+double* rows_E(hc_ctx* c, bool next);
+
+// ---- hc_pass.cpp: the look-ahead passes ----
+struct StepViews {
+    hc::Panel kex;
+    hc::EtaTable ex;
+};
+StepViews make_views(const hc_ctx* c);
+struct PassSetup {
+    hc::BlockArgs b;
+    bool exc_block = false;
+    double rad_once = 0.0, exc_once = 0.0, bytes_steps = 0.0;
+};
+PassSetup make_pass(hc_ctx* c, bool with_exc, bool next_block);
+void issue_pass_chunks(hc_ctx* c, const PassSetup& ps, int first, int last, bool with_items, hipStream_t stream, bool direct, int lane = 0);
+void issue_pass_reduce(hc_ctx* c, const PassSetup& ps, double* P, double* E, hipStream_t stream, bool direct, int lane = 0);
+void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = false);
+void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, bool next_block = false, int lane = 0);
+void ahead_drop(hc_ctx* c);
+void ahead_issue_slice(hc_ctx* c, hipStream_t stream, bool direct);
+void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct);
+bool ahead_adoptable(const hc_ctx* c, unsigned long long ended_serial);
+bool pass_lane_ready(hc_ctx* c);
+void pass_lane_drain(hc_ctx* c);
+
 }  // namespace detail
 }  // namespace hc

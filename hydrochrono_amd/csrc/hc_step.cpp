@@ -121,381 +121,12 @@ bool make_plan(hc_ctx* c) {
 double* rows_P(hc_ctx* c, bool next) { return c->d_P.p + static_cast<size_t>(next ? 1 - c->pe_cur : c->pe_cur) * hc::kLookahead * c->Dpad; }
 double* rows_E(hc_ctx* c, bool next) { return c->d_E.p + static_cast<size_t>(next ? 1 - c->pe_cur : c->pe_cur) * hc::kLookahead * c->Dpad; }
 
-struct StepViews {
-    hc::Panel kex;
-    hc::EtaTable ex;
-};
-
-StepViews make_views(const hc_ctx* c) {
-    StepViews v{};
-    const bool irregular = c->wave_kind == hc::kWaveIrregular;
-    v.kex.base   = c->d_kex.p;
-    v.kex.ntiles = c->ntiles;
-    v.kex.ngp    = c->ngp_ex;
-    v.ex.L        = c->L;
-    v.ex.ex_tau   = c->d_ex_tau.p;
-    v.ex.ex_width = c->d_ex_width.p;
-    v.ex.eta_t    = c->d_eta_t.p;
-    v.ex.eta      = c->d_eta.p;
-    v.ex.nt       = c->nt;
-    v.ex.eta_dt   = irregular ? c->irr.simulation_dt : 1.0;
-    v.ex.eta_t0   = (irregular && !c->eta_t.empty()) ? c->eta_t.front() : 0.0;
-    return v;
-}
-
-// The look-ahead pass of the plan just made: for the 16 / 32 predicted steps, what the samples known now contribute.  It runs as
-// the plain pass of a (virtual) step at tgrid[1] whose own sample is zero -- that sample's share is added later by the
-// step itself and by its scatter.  Enqueued behind the step that has just been evaluated (its ring push included).
-// next_block: the same pass for the predicted steps of the block AFTER this one (hc_plan.hpp: FarPass) -- the view of the history
-// is the same, only the query times move on by a block.
-struct PassSetup {
-    hc::BlockArgs b;
-    bool exc_block = false;
-    double rad_once = 0.0, exc_once = 0.0, bytes_steps = 0.0;
-};
-
-PassSetup make_pass(hc_ctx* c, bool with_exc, bool next_block) {
-    auto& pl = c->plan;
-    const int L = c->lookahead;
-    const int H = static_cast<int>(c->times.size());
-    // history length the virtual step would see after its own push + prune (PruneHistory, src/hydro_forces.cpp:327-340)
-    const double hmin = pl.tgrid[1] - (c->tau.empty() ? 0.0 : c->tau.back());
-    int Hv = H + 1;
-    auto vtime = [&](int k) { return k == 0 ? pl.tgrid[1] : c->times[static_cast<size_t>(k - 1)]; };
-    while (Hv > 1 && vtime(Hv - 2) < hmin) --Hv;
-
-    hc::HistoryView hv{};
-    hv.state   = c->d_zero_state.p;
-    hv.N       = c->N;
-    hv.D       = c->D;
-    hv.t       = pl.tgrid[1];
-    hv.ring_t  = c->d_ring_t.p;
-    hv.ring_v  = c->d_ring_v.p;
-    hv.ring_vT = c->d_ring_vT.p;
-    hv.head    = (c->head + 1) % c->Hcap;  // slot of the virtual sample (never read: time and velocity come from t / state)
-    hv.H       = Hv;
-    hv.Hcap    = c->Hcap;
-    hv.HcapT   = c->HcapT;
-    hv.dt_hint = pl.dt;
-
-    const StepViews vw = make_views(c);
-    PassSetup ps;
-    hc::BlockArgs& b = ps.b;
-    b                     = hc::BlockArgs{};
-    b.K                   = rad_panel(c);
-    b.F                   = std::min(c->S, live_samples(c, pl.tgrid[L])) * c->D;
-    b.depth               = L;
-    b.chunk_gp            = next_block ? far_chunk_gp(c) : c->chunk_gp_block;  // (a pass issued in slices: shorter chunks, a full round of workgroups per slice)
-    b.nchunks             = std::max(1, ((b.F + 7) / 8 + b.chunk_gp - 1) / b.chunk_gp);
-    b.max_steps_per_chunk = (b.chunk_gp * 8) / c->D + 2;
-    b.hist                = hv;
-    if (next_block) {
-        const hc::FarPass fp = hc::far_pass_setup(pl, L, c->tau);
-        for (int j = 0; j < L; ++j) {
-            b.tpred[j]   = fp.tpred[j];
-            b.s_cut[j]   = fp.s_cut[j];
-            b.s_defer[j] = -1;
-        }
-    } else {
-        for (int j = 0; j < L; ++j) {
-            b.tpred[j]   = pl.tgrid[j + 1];
-            b.s_cut[j]   = pl.s_cut[j];
-            b.s_defer[j] = pl.s_defer[j];
-        }
-    }
-    b.tau   = c->d_tau.p;
-    b.width = c->d_width.p;
-    // The excitation force depends on time only, so the pass also evaluates it for the 16 predicted times (extra chunks
-    // over Kex in the same launch) -- provided every predicted time passes the window tests a real step would have to pass.
-    static const bool exc_in_block = env_int("HC_EXC_IN_BLOCK", 1) != 0;
-    bool exc_block = exc_in_block && with_exc && c->wave_kind == hc::kWaveIrregular && c->nchunks_ex_block > 0;
-    for (int j = 0; j < L && exc_block; ++j) exc_block = wave_window_ok(c, b.tpred[j]);
-    ps.exc_block  = exc_block;
-    b.Kex         = vw.kex;
-    b.ex          = vw.ex;
-    b.chunk_gp_ex = c->chunk_gp_ex_block;
-    b.nchunks_ex  = exc_block ? c->nchunks_ex_block : 0;
-    b.partials    = next_block ? c->d_partials_far.p : c->d_partials_block.p;
-    b.Dpad        = c->Dpad;
-    b.error_flag  = c->d_err.p;
-    b.item_counter = c->d_err.p + 1;
-    b.ngroups     = c->ntiles / c->mt_block;
-    // algorithmic bytes: summed over the steps of the block, step j's share of K and of the velocity vector from s_cut[j]
-    // on ...; what the launch has to move once: the live part of K, Kex and the staged vectors
-    double samples = 0.0;
-    for (int j = 0; j < L; ++j) samples += std::max(0, b.F / c->D - b.s_cut[j]);
-    const double rad_16 = 8.0 * samples * (static_cast<double>(c->Dloc) * c->D + c->D);
-    const double exc_16 = exc_block ? 8.0 * L * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
-    ps.bytes_steps = rad_16 + exc_16;
-    ps.rad_once    = 8.0 * (static_cast<double>(c->Dloc) * b.F + b.F);
-    ps.exc_once    = exc_block ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
-    if (env_int("HC_DEBUG_PLAN", 0) != 0) {
-        std::fprintf(stderr, "[hc] pass%s t0=%.6f dt=%.17g Hv=%d F/D=%d nchunks=%d exc=%d\n     s_cut:", next_block ? " (next block)" : "", pl.tgrid[0], pl.dt, Hv,
-                     b.F / c->D, b.nchunks, (int)exc_block);
-        for (int j = 0; j < L; ++j) std::fprintf(stderr, " %d", b.s_cut[j]);
-        std::fprintf(stderr, "\n     s_defer:");
-        for (int j = 0; j < L; ++j) std::fprintf(stderr, " %d", b.s_defer[j]);
-        std::fprintf(stderr, "\n     scat:");
-        for (int i = 1; i <= L; ++i) std::fprintf(stderr, " [%d,%d]", pl.scat_lo[i], pl.scat_hi[i]);
-        std::fprintf(stderr, "\n");
-    }
-    return ps;
-}
-
-// One launch of the pass over the radiation chunks [first, last) (+ the excitation work items if with_items).
-void issue_pass_chunks(hc_ctx* c, const PassSetup& ps, int first, int last, bool with_items, hipStream_t stream, bool direct, int lane = 0) {
-    hc::BlockArgs b = ps.b;
-    b.chunk_first   = first;
-    b.chunk_last    = last;
-    if (!with_items) b.nchunks_ex = 0;
-    const double share_rad = static_cast<double>(last - first) / std::max(1, ps.b.nchunks);
-    const double rad_once = ps.rad_once * share_rad, exc_once = with_items ? ps.exc_once : 0.0;
-    c->prof.block_kernel_bytes      = ps.bytes_steps * (rad_once + exc_once) / std::max(1.0, ps.rad_once + ps.exc_once);
-    c->prof.block_kernel_bytes_once = rad_once + exc_once;
-    const double exc_share = exc_once / std::max(1.0, rad_once + exc_once);
-    const int L = c->lookahead;
-    if (direct) {
-        hc::BlockArgs b2;
-        const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_block, &b2);
-        if (l.nblocks <= 0) return;
-        c->dq->dispatch(L == 32 ? c->dk_block32 : c->dk_block16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
-                        direct_tag(c, hc::kEvPass), exc_share, lane);
-        c->prof.direct_dispatches += 1;
-        if (lane == 2) c->prof.pass_lane_launches += 1;
-        return;
-    }
-    hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_share);
-    hc::launch_conv_block(b, c->mt_block, stream);
-    ev_end(ev, stream);
-    c->prof.hip_launches += 1;
-}
-
-// ... and the reduction of its chunk partials into the rows P / E of a block.
-void issue_pass_reduce(hc_ctx* c, const PassSetup& ps, double* P, double* E, hipStream_t stream, bool direct, int lane = 0) {
-    const hc::BlockArgs& b = ps.b;
-    const hc::ReduceArgs r{b.partials, b.nchunks, b.nchunks_ex, c->Dpad, c->lookahead, P, E, b.item_counter, 0, 0, 0, 0};
-    if (direct) {
-        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r, -1, 0.0, lane);
-        c->prof.direct_dispatches += 1;
-        return;
-    }
-    hc::launch_reduce_block(r, stream);
-    c->prof.hip_launches += 1;
-}
-
-void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = false) {
-    const PassSetup ps = make_pass(c, with_exc, false);
-    c->plan.has_exc    = ps.exc_block;
-    issue_pass_chunks(c, ps, 0, ps.b.nchunks, true, stream, direct);
-    issue_pass_reduce(c, ps, rows_P(c, false), rows_E(c, false), stream, direct);
-}
-
-// ---- pass schedule "one block ahead" (hc_set_pass_schedule) ----------------------------------------
-// Begun right after the pass-free start of a block (or after the ordinary pass of the first block): the pass of the NEXT block, in
-// `pass_slices` launches -- one now, the others behind the scatter launches of the following steps -- so that a caller that
-// leaves the GPU idle between two force evaluations never waits for a whole pass.  A slice is a full round of workgroups over chunks
-// `pass_slices` times shorter than those of the ordinary pass (far_chunk_gp); the chunk partials of all slices are added by ONE
-// reduction after the last slice, in chunk order -- the sums do not depend on how the chunks were spread over launches.
-void ahead_drop(hc_ctx* c) { c->ahead.active = false; }
-
-void ahead_issue_slice(hc_ctx* c, hipStream_t stream, bool direct) {
-    auto& ah = c->ahead;
-    if (!ah.active || ah.reduced) return;
-    if (ah.Hcap != c->Hcap || ah.plan_serial != c->plan_serial) { ahead_drop(c); return; }  // the ring was re-allocated under the view
-    PassSetup ps;
-    ps.b         = ah.args;
-    // (buffers that may have been re-allocated since the view was taken are re-read; the ring's geometry has been checked above)
-    ps.b.hist.ring_t  = c->d_ring_t.p;
-    ps.b.hist.ring_v  = c->d_ring_v.p;
-    ps.b.hist.ring_vT = c->d_ring_vT.p;
-    ps.exc_block = ah.has_exc;
-    ps.rad_once  = ah.rad_once;
-    ps.exc_once  = ah.exc_once;
-    ps.bytes_steps = ah.rad_once + ah.exc_once;
-    // beside the steps (the pass lane) when the chain began there and this step is dispatched directly; a step that goes through HIP
-    // launches has emptied both lanes on its way in (enqueue_step), so its slice may follow on the stream
-    const int lane = (ah.concurrent && direct) ? 2 : 0;
-    const int n = ps.b.nchunks, k = ah.issued;
-    const int first = std::min(n, k * ah.per_slice), last = std::min(n, (k + 1) * ah.per_slice);  // never empty, see ahead_begin
-    const bool final_slice = k + 1 >= ah.slices;
-    issue_pass_chunks(c, ps, first, last, final_slice, stream, direct, lane);
-    ah.issued = k + 1;
-    c->prof.ahead_pass_slices += 1;
-    if (final_slice) {
-        issue_pass_reduce(c, ps, rows_P(c, true), rows_E(c, true), stream, direct, lane);
-        ah.reduced = true;
-    }
-}
-
-// The pass lane: created when the schedule first needs it, with a CU mask that leaves pass_free_cus compute units of every XCD to the
-// kernels of the step path (a pass workgroup holds its CU's registers for its whole life, so a step kernel that finds no free CU
-// would wait for a pass workgroup to end; profiles/overlap_probe.hip).  Without the mask the lane is not used.
-bool pass_lane_ready(hc_ctx* c) {
-    if (c->pass_lane == 2) return true;
-    if (c->pass_lane < 0 || !c->pass_concurrent || !c->dq || !c->direct_ready) return false;
-    // one more queue per context: only where the device is this context's alone (several contexts on ONE device -- a test bed for the
-    // multi-GPU code, not a deployment -- already time-share its hardware queues; their slices stay on the step path's lane)
-    if (contexts_on_device(c->device) > 1) return false;
-    std::string why;
-    const uint32_t ncu = c->dq->compute_units();
-    const uint32_t keep = ncu > 8u * static_cast<uint32_t>(c->pass_free_cus) + 8 ? ncu - 8u * static_cast<uint32_t>(c->pass_free_cus) : 0;
-    bool abandon = false;
-    // (timed like lane 0; the same self-test as the other lanes: argument slots the host re-writes must be re-read, not served stale)
-    bool ok = keep > 0 && c->dq->ensure_lane(2, &why) && c->dq->set_cu_mask(2, keep);
-    if (ok) c->dq->enable_timing(2);
-    c->pass_lane = (ok && direct_selftest_rewrites(c, c->dq, 2, &abandon)) ? 2 : -1;
-    return c->pass_lane == 2;
-}
-
-void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
-    auto& ah = c->ahead;
-    ah.active = false;
-    const int L = c->lookahead;
-    if (!c->pass_ahead || L <= 0 || !hc::far_pass_allowed(c->plan, L, c->times, c->tau)) return;
-    const int kw = c->plan.sub > 0 ? c->plan.sub : L;
-    // the short passes towards the next block must fit the partials buffer (they stream up to twice the reach of the in-block ones)
-    const hc::MiniPass probe = hc::mini_pass_next(c->plan, L, kw, c->tau);
-    const int chunk_gp = std::max(16, (((c->D + 7) / 8 / 2 + 15) / 16) * 16);
-    const long long chunks = (static_cast<long long>(probe.n_samples) * c->D / 8 + chunk_gp) / chunk_gp + 1;
-    const size_t need = static_cast<size_t>(chunks) * L * c->Dpad;
-    if (need > c->d_partials_block.n || need > c->d_partials_next.n || c->d_partials_far.n == 0) return;
-    const PassSetup ps = make_pass(c, with_exc, true);
-    ah.args        = ps.b;
-    ah.has_exc     = ps.exc_block;
-    ah.rad_once    = ps.rad_once;
-    ah.exc_once    = ps.exc_once;
-    ah.Hcap        = c->Hcap;
-    ah.plan_serial = c->plan_serial;
-    ah.t_first     = c->plan.tgrid[L + 1];
-    ah.t_last      = c->plan.tgrid[2 * L];
-    // a slice = one round of workgroups of the pass lane (far_chunks_per_slice: whole octets of chunks, as the kernel's block mapping
-    // deals them); the reduction must be out before the first short pass adds to the rows, i.e. within the first sub-block (wider
-    // slices if that takes fewer of them)
-    const int limit = c->plan.sub > 0 ? c->plan.sub : L - 1;
-    int per         = far_chunks_per_slice(c);
-    while ((ps.b.nchunks + per - 1) / per > limit) per += 8;
-    ah.per_slice    = per;
-    ah.slices       = std::max(1, (ps.b.nchunks + per - 1) / per);
-    ah.issued      = 0;
-    ah.reduced     = false;
-    ah.concurrent  = false;
-    ah.active      = true;
-    if (direct && pass_lane_ready(c)) {
-        // beside the steps: the slices (and later the short passes towards the next block) go to the pass lane, behind everything
-        // lane 0 holds now -- the step kernel that pushed the newest sample the pass reads, the last reader of the rows it is going to
-        // overwrite.  Still in slices: a caller that stays away between steps then finds each slice done when it comes back (the
-        // pass would otherwise share the memory system with the next few steps), one that steps back to back just fills the lane.
-        const uint64_t h = c->dq->signal_after(0);
-        if (h != 0) {
-            c->dq->wait_for(2, h);
-            ah.args.item_counter = c->d_err.p + 2;
-            ah.concurrent        = true;
-        }
-    }
-    ahead_issue_slice(c, stream, direct);
-}
-
-// The block that has just been planned can take the rows the pass in the making has left: it was computed for this block's step
-// times (up to the tolerance a caller's time is accepted with), completely, under the plan that has just ended.
-bool ahead_adoptable(const hc_ctx* c, unsigned long long ended_serial) {
-    const auto& ah = c->ahead;
-    const auto& pl = c->plan;
-    const int L = c->lookahead;
-    if (!ah.active || !ah.reduced || ah.plan_serial != ended_serial || !pl.valid) return false;
-    for (int j = 0; j < L; ++j)
-        if (pl.s_defer[j] >= 0) return false;
-    const double tol = std::max(1e-9 * pl.dt, 64.0 * std::numeric_limits<double>::epsilon() * std::fabs(ah.t_last));
-    return std::fabs(pl.tgrid[1] - ah.t_first) <= tol && std::fabs(pl.tgrid[L] - ah.t_last) <= tol;
-}
-
-// The short pass of the two-level form after block step i0 (hc_plan.hpp: MiniPass): what the samples of the sub-block that has just
-// ended contribute to the block steps still to come, added to their rows of P.  The same kernel as the pass of the block, over
-// the first few IRF samples only, with the bracket table restricted to those samples (BlockArgs::mini_kw) and a chunking of its
-// own (half an IRF sample per chunk -- a function of D only, like every other chunk length).
-// next_block (pass schedule "one block ahead", hc_plan.hpp: mini_pass_next): the same for the steps of the NEXT block, added to the
-// rows the pass in the making has left; it starts at the first IRF sample those steps take.
-void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, bool next_block = false, int lane = 0) {
-    const auto& pl = c->plan;
-    const int L    = c->lookahead;
-    const hc::MiniPass mp = next_block ? hc::mini_pass_next(pl, L, i0, c->tau) : hc::mini_pass_setup(pl, L, i0, c->tau);
-    if (mp.n_samples <= 0 || mp.n_steps <= 0 || mp.s_first >= mp.n_samples) return;
-    hc::HistoryView hv{};
-    hv.state   = c->d_zero_state.p;
-    hv.N       = c->N;
-    hv.D       = c->D;
-    hv.t       = mp.time[0];
-    hv.ring_t  = c->d_ring_t.p;
-    hv.ring_v  = c->d_ring_v.p;
-    hv.ring_vT = c->d_ring_vT.p;
-    hv.head    = (c->head + 1) % c->Hcap;  // slot of the not-yet-known sample of step i0 + 1
-    hv.H       = static_cast<int>(c->times.size()) + 1;
-    hv.Hcap    = c->Hcap;
-    hv.HcapT   = c->HcapT;
-    hv.dt_hint = pl.dt;
-    hc::BlockArgs b{};
-    b.K        = rad_panel(c);
-    b.F        = mp.n_samples * c->D;
-    b.depth    = L;
-    b.chunk_gp = std::max(16, (((c->D + 7) / 8 / 2 + 15) / 16) * 16);
-    b.nchunks  = std::max(1, ((b.F + 7) / 8 + b.chunk_gp - 1) / b.chunk_gp);
-    b.max_steps_per_chunk = (b.chunk_gp * 8) / c->D + 2;
-    b.hist     = hv;
-    for (int j = 0; j < L; ++j) {
-        b.tpred[j]   = mp.tpred[j];
-        b.s_cut[j]   = mp.s_cut[j];
-        b.s_defer[j] = mp.s_defer[j];
-    }
-    b.tau          = c->d_tau.p;
-    b.width        = c->d_width.p;
-    b.Kex          = make_views(c).kex;
-    b.ex           = make_views(c).ex;
-    b.chunk_gp_ex  = c->chunk_gp_ex_block;
-    b.nchunks_ex   = 0;
-    hc::DeviceBuffer<double>& scratch = lane == 2 ? c->d_partials_next : c->d_partials_block;  // the pass lane runs beside lane 0's short passes
-    b.partials     = scratch.p;
-    b.Dpad         = c->Dpad;
-    b.error_flag   = c->d_err.p;
-    b.item_counter = c->d_err.p + (lane == 2 ? 2 : 1);
-    b.ngroups      = c->ntiles / c->mt_mini;
-    b.mini_kw      = mp.kw;
-    b.mini_steps   = mp.n_steps;
-    for (int k = 0; k <= mp.kw + 1; ++k) b.mini_time[k] = mp.time[k];
-    b.chunk_first  = next_block ? static_cast<int>((static_cast<long long>(mp.s_first) * c->D / 8) / b.chunk_gp) : 0;
-    b.chunk_last   = b.nchunks;
-    require(static_cast<size_t>(b.nchunks) * L * c->Dpad <= scratch.n, HC_ERR_RUNTIME, "short pass: partials buffer too small");
-    hc::ReduceArgs r{scratch.p, b.nchunks, 0, c->Dpad, L, rows_P(c, next_block), rows_E(c, next_block), b.item_counter, 1, next_block ? 0 : i0, mp.n_steps,
-                     b.chunk_first};
-    if (direct) {
-        hc::BlockArgs b2;
-        const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_mini, &b2);
-        if (l.nblocks <= 0) return;
-        c->dq->dispatch(L == 32 ? c->dk_mini32 : c->dk_mini16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
-                        direct_tag(c, hc::kEvMiniPass), 0.0, lane);
-        c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r, -1, 0.0, lane);
-        c->prof.direct_dispatches += 2;
-        if (lane == 2) c->prof.pass_lane_launches += 1;
-        return;
-    }
-    hc::EventPair* ev = ev_begin(c, hc::kEvMiniPass, stream);
-    hc::launch_conv_block(b, c->mt_mini, stream);
-    ev_end(ev, stream);
-    hc::launch_reduce_block(r, stream);
-    c->prof.hip_launches += 2;
-}
-
 // Second half of a step's enqueue: the work LATER steps need (the scatter of this step's sample inside a look-ahead block, or
 // the plan and the pass of the next block).  Off the caller's critical path: it is enqueued behind the step kernel and runs
 // while the host is away.  On a caller's stream (hc_step_device) whose owner waits for every step it goes to the context's
 // own stream behind an event, so that whatever the caller enqueues next on its stream -- the all-gather of the force rows in
 // a multi-GPU run -- follows the step kernel directly.  hc_step_multi calls it after the step kernels of ALL shard contexts
 // have been handed to their GPUs.
-void pass_lane_drain(hc_ctx* c) {
-    if (c->dq && c->dq->busy(2) && !c->dq->drain(20.0, 2)) {
-        c->lost = true;
-        throw Error(HC_ERR_DEVICE, "the pass lane of the direct queue did not drain: " + c->dq->failure_text());
-    }
-}
-
 void enqueue_tail(hc_ctx* c) {
     if (!c->tail.pending) return;
     c->tail.pending        = false;

@@ -61,6 +61,16 @@ static int run(int N, int b0, int b1, int S, double gap_us, int schedule, int sl
     }
     hc_profile_stats p{};
     hc_get_profile(c, &p);
+    if (std::getenv("BY_POSITION")) {  // mean latency by position in the 32-step pattern (the timed region starts at step `warm`)
+        std::printf("   by step %% 32 (first timed step = %d %% 32):", warm);
+        for (int q = 0; q < 32; ++q) {
+            double m = 0;
+            int cnt = 0;
+            for (size_t i = q; i < ts.size(); i += 32) { m += ts[i]; ++cnt; }
+            std::printf(" %.0f", m / cnt);
+        }
+        std::printf("\n");
+    }
     std::sort(ts.begin(), ts.end());
     double mean = 0;
     for (double v : ts) mean += v;

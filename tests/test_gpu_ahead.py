@@ -201,6 +201,42 @@ def test_one_block_ahead_device_steps_on_a_callers_stream(hydro, wait_each_step)
     assert a.profile()["ahead_blocks"] >= 5 and b.profile()["ahead_blocks"] >= 5
 
 
+def test_one_block_ahead_reconfiguration_and_teardown_with_a_busy_pass_lane(hydro):
+    """Calls that void the plan while a pass is in the making on the pass lane -- another look-ahead depth, a history reset, an
+    injected history, the schedule itself -- and contexts destroyed right after a step (the lane still busy), several times over:
+    every force against the oracle, no hang."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    N = 6
+    case = many_body_case(N, S=180, dt_rirf=0.01, n_exc=33, seed=17)
+    motion = PrescribedMotion(N, rest_positions(case), seed=3)
+    for cycle in range(4):
+        gpu, orc = hydro.HydroForces.from_case(case), load_into_oracle(case)
+        gpu.add_waves_none()
+        orc.add_waves_none()
+        gpu.set_pass_schedule(1)
+        t, lane_seen = 0.0, 0
+        for n in range(700):
+            st = motion.state(t)
+            assert relerr(gpu.step(t, *st), orc.step(t, *st)) <= TIGHT_TOL, f"cycle {cycle} step {n}"
+            t += 0.01
+            if n == 300:
+                gpu.set_lookahead(16)            # mid-block: the plan and the pass in the making are dropped
+            if n == 420:
+                lane_seen = gpu.profile()["pass_lane_launches"]
+                gpu.set_pass_schedule(0)
+                gpu.set_pass_schedule(1, 3)
+                gpu.set_lookahead(32)
+            if n == 520:                          # a fresh start on both sides
+                gpu.reset_history()
+                orc = load_into_oracle(case)
+                orc.add_waves_none()
+        p = gpu.profile()
+        assert lane_seen > 0 and p["pass_lane_launches"] > lane_seen and p["ahead_blocks"] >= 6, p
+        gpu.step(t, *motion.state(t))            # leaves work on both lanes ...
+        gpu.close()                               # ... for the destructor to wait for
+
+
 def test_one_block_ahead_c3_size_against_flat_oracle(hydro):
     """Full-size C3 (64 bodies, S = 1024, Nf = 512) from a steady-state history: 200 steps under the schedule -- plain boundary step,
     a block with its own pass, then blocks whose rows were made ahead -- against the flat-array CPU oracle."""

@@ -127,10 +127,11 @@ PassSetup make_pass(hc_ctx* c, bool with_exc, bool next_block);
 void issue_pass_chunks(hc_ctx* c, const PassSetup& ps, int first, int last, bool with_items, hipStream_t stream, bool direct, int lane = 0);
 void issue_pass_reduce(hc_ctx* c, const PassSetup& ps, double* P, double* E, hipStream_t stream, bool direct, int lane = 0);
 void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct = false);
-void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, bool next_block = false, int lane = 0);
+void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, int next_kw = 0, int lane = 0);
 void ahead_drop(hc_ctx* c);
 void ahead_issue_slice(hc_ctx* c, hipStream_t stream, bool direct);
 void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct);
+bool ahead_expected(const hc_ctx* c, unsigned long long ended_serial);
 bool ahead_adoptable(const hc_ctx* c, unsigned long long ended_serial);
 bool pass_lane_ready(hc_ctx* c);
 void pass_lane_drain(hc_ctx* c);

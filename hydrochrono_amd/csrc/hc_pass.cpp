@@ -230,9 +230,11 @@ void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
     ah.active = false;
     const int L = c->lookahead;
     if (!c->pass_ahead || L <= 0 || !hc::far_pass_allowed(c->plan, L, c->times, c->tau)) return;
-    const int kw = c->plan.sub > 0 ? c->plan.sub : L;
-    // the short passes towards the next block must fit the partials buffer (they stream up to twice the reach of the in-block ones)
-    const hc::MiniPass probe = hc::mini_pass_next(c->plan, L, kw, c->tau);
+    // the short passes towards the next block must fit the partials buffer (they stream up to twice the reach of the in-block ones;
+    // the first window reaches furthest)
+    int first_end = 1;
+    while (!hc::next_window_end(c->plan, L, first_end)) ++first_end;
+    const hc::MiniPass probe = hc::mini_pass_next(c->plan, L, first_end, hc::next_window_length(c->plan, L, first_end), c->tau);
     const int chunk_gp = std::max(16, (((c->D + 7) / 8 / 2 + 15) / 16) * 16);
     const long long chunks = (static_cast<long long>(probe.n_samples) * c->D / 8 + chunk_gp) / chunk_gp + 1;
     const size_t need = static_cast<size_t>(chunks) * L * c->Dpad;
@@ -249,7 +251,7 @@ void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
     // a slice = one round of workgroups of the pass lane (far_chunks_per_slice: whole octets of chunks, as the kernel's block mapping
     // deals them); the reduction must be out before the first short pass adds to the rows, i.e. within the first sub-block (wider
     // slices if that takes fewer of them)
-    const int limit = c->plan.sub > 0 ? c->plan.sub : L - 1;
+    const int limit = first_end;  // (the first window of block samples ends there: the sub-block size, L - 1 for the single-level form)
     int per         = far_chunks_per_slice(c);
     while ((ps.b.nchunks + per - 1) / per > limit) per += 8;
     ah.per_slice    = per;
@@ -273,6 +275,18 @@ void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
     ahead_issue_slice(c, stream, direct);
 }
 
+// Before the next block is planned: will there be rows for it?  The pass in the making is complete, belongs to the plan that has just
+// ended, and the step times the new plan is going to predict (the same expressions as build_plan) are those it was computed for.
+bool ahead_expected(const hc_ctx* c, unsigned long long ended_serial) {
+    const auto& ah = c->ahead;
+    const int L = c->lookahead;
+    if (!ah.active || !ah.reduced || ah.plan_serial != ended_serial || c->times.size() < 2) return false;
+    const double t0 = c->times[0], dt = c->times[0] - c->times[1];
+    if (!(dt > 0.0)) return false;
+    const double tol = std::max(1e-9 * dt, 64.0 * std::numeric_limits<double>::epsilon() * std::fabs(ah.t_last));
+    return std::fabs((t0 + 1 * dt) - ah.t_first) <= tol && std::fabs((t0 + L * dt) - ah.t_last) <= tol;
+}
+
 // The block that has just been planned can take the rows the pass in the making has left: it was computed for this block's step
 // times (up to the tolerance a caller's time is accepted with), completely, under the plan that has just ended.
 bool ahead_adoptable(const hc_ctx* c, unsigned long long ended_serial) {
@@ -292,10 +306,11 @@ bool ahead_adoptable(const hc_ctx* c, unsigned long long ended_serial) {
 // own (half an IRF sample per chunk -- a function of D only, like every other chunk length).
 // next_block (pass schedule "one block ahead", hc_plan.hpp: mini_pass_next): the same for the steps of the NEXT block, added to the
 // rows the pass in the making has left; it starts at the first IRF sample those steps take.
-void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, bool next_block, int lane) {
+void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, int next_kw, int lane) {
     const auto& pl = c->plan;
     const int L    = c->lookahead;
-    const hc::MiniPass mp = next_block ? hc::mini_pass_next(pl, L, i0, c->tau) : hc::mini_pass_setup(pl, L, i0, c->tau);
+    const bool next_block = next_kw > 0;  // window length of a short pass towards the NEXT block (0: the in-block short pass)
+    const hc::MiniPass mp = next_block ? hc::mini_pass_next(pl, L, i0, next_kw, c->tau) : hc::mini_pass_setup(pl, L, i0, c->tau);
     if (mp.n_samples <= 0 || mp.n_steps <= 0 || mp.s_first >= mp.n_samples) return;
     hc::HistoryView hv{};
     hv.state   = c->d_zero_state.p;

@@ -43,6 +43,12 @@ struct Plan {
     int mini_s_hi[kLookahead + 1];
     int misses = 0, cooldown = 0;
     bool has_exc = false;  // the pass also left the excitation force of the predicted times (E rows)
+    // own_zero (pass schedule "one block ahead"): the sample of the planning step itself -- grid index 0 -- is treated like a block
+    // sample: what it contributes to the block's steps comes from a scatter launched with the plan (n_tgt[0] / scat_lo[0] / scat_hi[0])
+    // and, in the two-level form, from the short pass after the first sub-block (whose window then starts at index 0), not from the
+    // rows the pass left.  The rows of such a block were made BEFORE that sample existed, see hc_pass.cpp.
+    bool own_zero = false;
+    double t_before_zero = 0.0;  // time of the history sample before grid index 0 (the short pass of the first sub-block needs it)
 };
 
 // Plans the block that follows the step just pushed (times[0], newest first).  On the predicted time grid it classifies, for
@@ -51,7 +57,7 @@ struct Plan {
 // comparisons and the weight arithmetic are those of find_bracket / InterpolateVelocity6D (src/hydro_forces.cpp:343-381).
 // Returns false (plan invalid) when a block cannot be planned; pl.cooldown then says for how many steps not to retry.
 inline bool build_plan(Plan& pl, int lookahead, const std::deque<double>& times, const std::vector<double>& tau,
-                       const std::vector<double>& width, int sub = 0, int slices = 1) {
+                       const std::vector<double>& width, int sub = 0, int slices = 1, bool own_zero = false) {
     const int keep_misses = pl.misses, keep_cool = pl.cooldown;
     pl             = Plan{};
     pl.misses      = keep_misses;
@@ -71,6 +77,9 @@ inline bool build_plan(Plan& pl, int lookahead, const std::deque<double>& times,
     auto G = [&](int idx) { return idx >= 1 ? pl.tgrid[idx] : times[static_cast<size_t>(-idx)]; };  // idx > -H
     pl.sub    = (sub > 0 && sub < L) ? sub : 0;
     pl.slices = slices;
+    pl.own_zero      = own_zero;
+    pl.t_before_zero = times[1];
+    const int first_own = own_zero ? 0 : 1;  // smallest grid index whose sample the block's own machinery (not the pass) accounts for
     for (int i = 0; i <= L; ++i) {
         pl.scat_lo[i] = S;
         pl.scat_hi[i] = -1;
@@ -102,8 +111,8 @@ inline bool build_plan(Plan& pl, int lookahead, const std::deque<double>& times,
             int lo = 0;  // smallest lo with G(m - lo - 1) <= q
             while (m - lo - 1 > -H && G(m - lo - 1) > q) ++lo;
             const int nm = m - lo, om = nm - 1;
-            if (nm <= 0) break;  // both samples known now: the pass has it, and so it has every later s
-            if (om <= -H) break; // (cannot happen for nm >= 1)
+            if (nm < first_own) break;  // both samples are the pass's: it has this bracket, and so it has every later s
+            if (om <= -H) break;        // (no older sample; cannot happen for nm >= 1)
             if (s >= kScatterSamples || s == pl.s_defer[j]) return false;
             const double newer = G(nm), older = G(om);
             double wo = 0.0, wn = 0.0;
@@ -119,15 +128,16 @@ inline bool build_plan(Plan& pl, int lookahead, const std::deque<double>& times,
             const int idx[2]     = {nm, om};
             const double wgt[2]  = {wn, wo};
             for (int e = 0; e < 2; ++e) {
-                if (wgt[e] == 0.0 || idx[e] < 1) continue;
+                if (wgt[e] == 0.0 || idx[e] < first_own) continue;
                 if (idx[e] == m) {
                     if (pl.n_own[m] >= kNearMax - 1) return false;  // one entry stays free for the deferred sample
                     pl.own_s[m][pl.n_own[m]] = s;
                     pl.own_a[m][pl.n_own[m]] = wgt[e] * width[s];
                     pl.n_own[m]++;
-                } else if (pl.sub > 0 && (idx[e] - 1) / pl.sub != (m - 1) / pl.sub) {
+                } else if (pl.sub > 0 && std::max(idx[e] - 1, 0) / pl.sub != (m - 1) / pl.sub) {
                     // another sub-block: the short pass after the last step of the sample's sub-block has this pair
-                    const int i0     = ((idx[e] - 1) / pl.sub + 1) * pl.sub;
+                    // (grid index 0 -- own_zero -- counts to the first sub-block)
+                    const int i0     = (std::max(idx[e] - 1, 0) / pl.sub + 1) * pl.sub;
                     pl.mini_s_hi[i0] = std::max(pl.mini_s_hi[i0], s);
                 } else {
                     const int i = idx[e];
@@ -164,10 +174,10 @@ struct MiniPass {
 inline MiniPass mini_pass_setup(const Plan& pl, int lookahead, int i0, const std::vector<double>& tau) {
     MiniPass mp;
     const int S = static_cast<int>(tau.size());
-    mp.kw        = pl.sub;
+    mp.kw        = pl.sub + ((pl.own_zero && i0 == pl.sub) ? 1 : 0);  // own_zero: the first sub-block's window starts at grid index 0
     mp.n_steps   = lookahead - i0;
     mp.n_samples = std::min(S, pl.mini_s_hi[i0] + 1);
-    for (int k = 0; k <= mp.kw + 1; ++k) mp.time[k] = pl.tgrid[i0 + 1 - k];  // i0 >= sub, so the index stays >= 0
+    for (int k = 0; k <= mp.kw + 1; ++k) mp.time[k] = (i0 + 1 - k >= 0) ? pl.tgrid[i0 + 1 - k] : pl.t_before_zero;  // (index -1 only under own_zero)
     for (int j = 0; j < kLookahead; ++j) {
         const int m = i0 + 1 + j;
         mp.tpred[j]   = (j < mp.n_steps) ? pl.tgrid[m] : pl.tgrid[lookahead];
@@ -220,12 +230,23 @@ inline FarPass far_pass_setup(const Plan& pl, int lookahead, const std::vector<d
     return fp;
 }
 
-// The short pass towards the next block after block step i0 (i0 = sub, 2*sub, .., L; single-level form: i0 = L): window = the kw
-// block samples that end at i0, steps = the L steps of the next block.
-inline MiniPass mini_pass_next(const Plan& pl, int lookahead, int i0, const std::vector<double>& tau) {
+// The short pass towards the next block after block step i0: window = the kw block samples that end at i0, steps = the L steps of the
+// next block.  The windows of a block end at the multiples of the sub-block size (single-level form: none) below L - 1 and at L - 1
+// (next_window_end): the block's LAST sample is not theirs -- the next block, planned right after it, takes it as its own grid
+// index 0 (Plan::own_zero), so that no short pass stands between the last step of a block and the first step of the next.
+inline bool next_window_end(const Plan& pl, int lookahead, int m) {
+    const int kwin = pl.sub > 0 ? pl.sub : lookahead;
+    return m >= 1 && m <= lookahead - 1 && (m == lookahead - 1 || m % kwin == 0);
+}
+inline int next_window_length(const Plan& pl, int lookahead, int m) {  // m: a window end
+    const int kwin = pl.sub > 0 ? pl.sub : lookahead;
+    const int prev = (m % kwin == 0) ? m - kwin : (m / kwin) * kwin;
+    return m - prev;
+}
+inline MiniPass mini_pass_next(const Plan& pl, int lookahead, int i0, int kw, const std::vector<double>& tau) {
     MiniPass mp;
     const int S = static_cast<int>(tau.size());
-    mp.kw       = pl.sub > 0 ? pl.sub : lookahead;
+    mp.kw       = kw;
     mp.n_steps  = lookahead;
     for (int k = 0; k <= mp.kw + 1; ++k) mp.time[k] = pl.tgrid[i0 + 1 - k];  // i0 >= kw
     for (int j = 0; j < kLookahead; ++j) {

@@ -111,8 +111,8 @@ int plan_sub_block(const hc_ctx* c) {
     return hc::near_slices_for(c->D) > 1 ? hc::kSubBlock : 0;
 }
 
-bool make_plan(hc_ctx* c) {
-    const bool ok = hc::build_plan(c->plan, c->lookahead, c->times, c->tau, c->width, plan_sub_block(c), hc::near_slices_for(c->D));
+bool make_plan(hc_ctx* c, bool own_zero = false) {
+    const bool ok = hc::build_plan(c->plan, c->lookahead, c->times, c->tau, c->width, plan_sub_block(c), hc::near_slices_for(c->D), own_zero);
     if (ok) ++c->plan_serial;
     return ok;
 }
@@ -120,6 +120,39 @@ bool make_plan(hc_ctx* c) {
 // rows of the current block / of the block after it in d_P and d_E (two blocks of kLookahead rows each)
 double* rows_P(hc_ctx* c, bool next) { return c->d_P.p + static_cast<size_t>(next ? 1 - c->pe_cur : c->pe_cur) * hc::kLookahead * c->Dpad; }
 double* rows_E(hc_ctx* c, bool next) { return c->d_E.p + static_cast<size_t>(next ? 1 - c->pe_cur : c->pe_cur) * hc::kLookahead * c->Dpad; }
+
+// The scatter of grid index m of the current plan (a block step's sample, pushed by its finalize_kernel; m = 0: the planning step's
+// own sample of an own_zero plan): its results into the term slots of the steps they go to.
+void launch_scatter_of(hc_ctx* c, int m, hipStream_t bs, bool direct) {
+    const auto& pl = c->plan;
+    hc::ScatterArgs sa{};
+    sa.K     = rad_panel(c);
+    sa.D     = c->D;
+    sa.Dpad  = c->Dpad;
+    sa.s_lo  = pl.scat_lo[m];
+    sa.ns    = pl.scat_hi[m] - pl.scat_lo[m] + 1;
+    sa.v     = c->d_ring_v.p + static_cast<size_t>(c->head) * c->D;  // the newest sample in the ring
+    sa.width = c->d_width.p;
+    sa.Y     = c->d_Y.p;
+    for (int si = 0; si < sa.ns; ++si) {
+        const int s_ = sa.s_lo + si;
+        sa.n_tgt[si] = pl.n_tgt[m][s_];
+        for (int t = 0; t < pl.n_tgt[m][s_]; ++t) {
+            sa.tgt_off[si][t]  = (pl.tgt_step[m][s_][t] * hc::kTermMax + pl.tgt_k[m][s_][t]) * c->Dpad;
+            sa.tgt_coef[si][t] = pl.tgt_coef[m][s_][t];
+        }
+    }
+    if (direct) {
+        const hc::ScatterLaunch l = hc::scatter_launch_config(sa);
+        c->dq->dispatch(c->dk_scatter, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &sa, sizeof sa, direct_tag(c, hc::kEvScatter));
+        c->prof.direct_dispatches += 1;
+    } else {
+        hc::EventPair* ev = ev_begin(c, hc::kEvScatter, bs);
+        hc::launch_scatter(sa, bs);
+        c->prof.hip_launches += 1;
+        ev_end(ev, bs);
+    }
+}
 
 // Second half of a step's enqueue: the work LATER steps need (the scatter of this step's sample inside a look-ahead block, or
 // the plan and the pass of the next block).  Off the caller's critical path: it is enqueued behind the step kernel and runs
@@ -145,8 +178,10 @@ void enqueue_tail(hc_ctx* c) {
     };
     // pass schedule "one block ahead": the pass of the next block is in the making under this block's plan
     if (c->ahead.active && (!block || c->ahead.plan_serial != c->plan_serial)) ahead_drop(c);  // the block it belongs to was abandoned
-    const int ahead_kw      = c->plan.sub > 0 ? c->plan.sub : c->lookahead;
-    const bool window_end   = block && c->ahead.active && m % ahead_kw == 0;
+    // (its windows of block samples end at the sub-block boundaries below L - 1 and at L - 1: the block's last sample is the next
+    // block's own grid index 0, hc_plan.hpp: next_window_end)
+    const bool window_end   = block && c->ahead.active && hc::next_window_end(c->plan, c->lookahead, m);
+    const int window_kw     = window_end ? hc::next_window_length(c->plan, c->lookahead, m) : 0;
     bool window_done        = false;
     if (window_end && c->ahead.concurrent) {
         // a window of this block's samples ends here: what they contribute to the steps of the next block goes to the pass lane, behind
@@ -154,7 +189,7 @@ void enqueue_tail(hc_ctx* c) {
         const uint64_t h = direct ? c->dq->signal_after(0) : 0;
         if (h != 0) {
             c->dq->wait_for(2, h);
-            launch_mini_pass(c, m, bs, true, true, 2);
+            launch_mini_pass(c, m, bs, true, window_kw, 2);
             window_done = true;
         } else {
             // (no direct dispatch for this step, or no signal: the pass lane is emptied and the short pass follows on the step path)
@@ -163,34 +198,7 @@ void enqueue_tail(hc_ctx* c) {
     }
     if (scatter_now) {
         to_background();
-        const auto& pl = c->plan;
-        hc::ScatterArgs sa{};
-        sa.K     = rad_panel(c);
-        sa.D     = c->D;
-        sa.Dpad  = c->Dpad;
-        sa.s_lo  = pl.scat_lo[m];
-        sa.ns    = pl.scat_hi[m] - pl.scat_lo[m] + 1;
-        sa.v     = c->d_ring_v.p + static_cast<size_t>(c->head) * c->D;  // this step's sample, pushed by finalize_kernel
-        sa.width = c->d_width.p;
-        sa.Y     = c->d_Y.p;
-        for (int si = 0; si < sa.ns; ++si) {
-            const int s_ = sa.s_lo + si;
-            sa.n_tgt[si] = pl.n_tgt[m][s_];
-            for (int t = 0; t < pl.n_tgt[m][s_]; ++t) {
-                sa.tgt_off[si][t]  = (pl.tgt_step[m][s_][t] * hc::kTermMax + pl.tgt_k[m][s_][t]) * c->Dpad;
-                sa.tgt_coef[si][t] = pl.tgt_coef[m][s_][t];
-            }
-        }
-        if (direct) {
-            const hc::ScatterLaunch l = hc::scatter_launch_config(sa);
-            c->dq->dispatch(c->dk_scatter, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &sa, sizeof sa, direct_tag(c, hc::kEvScatter));
-            c->prof.direct_dispatches += 1;
-        } else {
-            hc::EventPair* ev = ev_begin(c, hc::kEvScatter, bs);
-            hc::launch_scatter(sa, bs);
-            c->prof.hip_launches += 1;
-            ev_end(ev, bs);
-        }
+        launch_scatter_of(c, m, bs, direct);
     } else if (block && c->plan.sub > 0 && m < c->lookahead && m % c->plan.sub == 0 && c->plan.mini_s_hi[m] >= 0) {
         to_background();
         launch_mini_pass(c, m, bs, direct);  // two-level form: the sub-block that ends here -> the block steps still to come
@@ -198,7 +206,7 @@ void enqueue_tail(hc_ctx* c) {
     if (block && c->ahead.active) {
         to_background();
         if (window_end && !window_done) {
-            if (c->ahead.reduced) launch_mini_pass(c, m, bs, direct, true);
+            if (c->ahead.reduced) launch_mini_pass(c, m, bs, direct, window_kw);
             else ahead_drop(c);  // (cannot happen: the slices end within the first window)
         }
         if (m < c->lookahead) ahead_issue_slice(c, bs, direct);
@@ -207,9 +215,14 @@ void enqueue_tail(hc_ctx* c) {
         const unsigned long long ended = c->plan_serial;
         const bool clean_end           = block && m == c->lookahead;
         if (block) c->plan.misses = 0;  // a block was consumed completely
-        if (make_plan(c)) {
+        // Rows made ahead exist for the block that starts now: it is planned with this step's sample as its own grid index 0 (the
+        // short passes that completed the rows stopped one sample earlier), and takes the rows if the plan comes out as predicted.
+        const bool rows_ahead = clean_end && ahead_expected(c, ended);
+        bool planned = make_plan(c, rows_ahead);
+        if (planned && rows_ahead && !ahead_adoptable(c, ended)) planned = make_plan(c, false);  // (not as predicted after all: an ordinary block)
+        if (planned) {
             to_background();
-            if (clean_end && ahead_adoptable(c, ended)) {
+            if (c->plan.own_zero) {
                 // the rows of this block are there already: no pass now.  Made on the pass lane: the steps of this block wait for it.
                 if (c->ahead.concurrent && c->dq && c->dq->busy(2)) {
                     const uint64_t h2 = direct ? c->dq->signal_after(2) : 0;
@@ -219,6 +232,7 @@ void enqueue_tail(hc_ctx* c) {
                 c->pe_cur ^= 1;
                 c->plan.has_exc = c->ahead.has_exc;
                 c->prof.ahead_blocks += 1;
+                if (c->plan.scat_hi[0] >= c->plan.scat_lo[0]) launch_scatter_of(c, 0, bs, direct);  // this step's sample -> the block's steps
             } else {
                 launch_pass(c, bs, c->tail.waves, direct);
             }

@@ -38,6 +38,7 @@ struct Scenario {
     double dt_rirf, dt_step;
     int S, H0, L;
     int sub = 0;  // > 0: the two-level form (sub-blocks of `sub` steps + a short pass after each)
+    bool own_zero = false;  // Plan::own_zero: the newest known sample is left out of the pass and treated like a block sample
 };
 
 int run(const Scenario& sc, unsigned seed, double* worst_out) {
@@ -58,13 +59,21 @@ int run(const Scenario& sc, unsigned seed, double* worst_out) {
     for (auto& v : v_block) v = U(rng);
 
     hc::Plan pl;
-    if (!hc::build_plan(pl, sc.L, known, tau, width, sc.sub)) {
+    if (!hc::build_plan(pl, sc.L, known, tau, width, sc.sub, 1, sc.own_zero)) {
         *worst_out = -1.0;  // not planned (allowed: e.g. block longer than half the window)
         return 0;
     }
     double worst = 0.0;
     std::vector<std::vector<double>> slots(sc.L + 1, std::vector<double>(hc::kTermMax, 0.0));
     std::vector<double> mini(sc.L + 1, 0.0);  // what the short passes of the two-level form have added to the steps' pass rows
+    v_block[0] = v_known[0];  // grid index 0 = the newest known sample
+    if (sc.own_zero)          // ... whose scatter is launched with the plan
+        for (int s = pl.scat_lo[0]; s <= pl.scat_hi[0]; ++s)
+            for (int t = 0; t < pl.n_tgt[0][s]; ++t) {
+                if (pl.tgt_step[0][s][t] < 1 || pl.tgt_step[0][s][t] > sc.L) return 2;
+                if (sc.sub > 0 && (pl.tgt_step[0][s][t] - 1) / sc.sub != 0) return 3;  // two-level: index 0 counts to the first sub-block
+                slots[pl.tgt_step[0][s][t]][pl.tgt_k[0][s][t]] = pl.tgt_coef[0][s][t] * (width[s] * K[s] * v_block[0]);
+            }
     for (int m = 1; m <= sc.L; ++m) {
         // ---- direct evaluation at the predicted time with everything known up to step m ----
         std::vector<double> times;   // newest first: block steps m..1, then the known samples
@@ -85,7 +94,7 @@ int run(const Scenario& sc, unsigned seed, double* worst_out) {
         std::vector<double> ptimes, pvel;
         ptimes.push_back(pl.tgrid[1]);
         pvel.push_back(0.0);
-        for (int k = 0; k < sc.H0; ++k) { ptimes.push_back(known[k]); pvel.push_back(v_known[k]); }
+        for (int k = 0; k < sc.H0; ++k) { ptimes.push_back(known[k]); pvel.push_back((sc.own_zero && k == 0) ? 0.0 : v_known[k]); }
         double pass = 0.0;
         for (int s = pl.s_cut[m - 1]; s < sc.S; ++s) {
             if (s == pl.s_defer[m - 1]) continue;
@@ -127,7 +136,8 @@ int run(const Scenario& sc, unsigned seed, double* worst_out) {
                     double wo, wn;
                     int lo;
                     if (!hc::mini_bracket(mp.time, mp.kw, mp.tpred[j] - tau[s], &wo, &wn, &lo)) return 4;
-                    // history index k of the view = block step m + 1 - k (k = 0: the unknown step m + 1, weight masked)
+                    // history index k of the view = grid index m + 1 - k (k = 0: the unknown step m + 1, weight masked; own_zero:
+                    // the window of the first sub-block reaches grid index 0)
                     const double vn = (lo >= 1 && lo <= mp.kw) ? v_block[m + 1 - lo] : 0.0;
                     const double vo = (lo + 1 <= mp.kw) ? v_block[m - lo] : 0.0;
                     mini[m + 1 + j] += K[s] * (wo * width[s] * vo + wn * width[s] * vn);
@@ -178,10 +188,14 @@ int run_ahead(const Scenario& sc, unsigned seed, double* worst_out) {
             if (!bracket(ptimes, fp.tpred[j] - tau[s], &o, &n, &wo, &wn)) return 5;  // the history covers the window: always bracketed
             P_next[j + 1] += K[s] * (wo * pvel[o] + wn * pvel[n]) * width[s];
         }
-    // ---- short passes of block A towards block B ----
-    const int kw = sc.sub > 0 ? sc.sub : L;
-    for (int i0 = kw; i0 <= L; i0 += kw) {
-        const hc::MiniPass mp = hc::mini_pass_next(plA, L, i0, tau);
+    // ---- short passes of block A towards block B: windows that end at the sub-block boundaries below L - 1 and at L - 1 ----
+    int covered = 0;
+    for (int i0 = 1; i0 <= L - 1; ++i0) {
+        if (!hc::next_window_end(plA, L, i0)) continue;
+        const int kw = hc::next_window_length(plA, L, i0);
+        if (i0 - kw != covered) return 6;  // the windows tile the samples 1 .. L - 1
+        covered = i0;
+        const hc::MiniPass mp = hc::mini_pass_next(plA, L, i0, kw, tau);
         if (mp.kw != kw || mp.n_steps != L) return 6;
         for (int j = 0; j < L; ++j)
             for (int s = mp.s_cut[j]; s < mp.n_samples; ++s) {
@@ -199,16 +213,21 @@ int run_ahead(const Scenario& sc, unsigned seed, double* worst_out) {
             if (hc::mini_bracket(mp.time, mp.kw, mp.tpred[L - 1] - tau[mp.n_samples], &wo, &wn, &lo) && (wo != 0.0 || wn != 0.0)) return 7;
         }
     }
+    if (covered != L - 1) return 6;
     // ---- block B, planned from the complete history (block A's steps were taken at their predicted times) ----
     std::deque<double> knownB;
     std::vector<double> v_knownB;
     for (int i = L; i >= 1; --i) { knownB.push_back(plA.tgrid[i]); v_knownB.push_back(vA[i]); }
     for (int k = 0; k < sc.H0; ++k) { knownB.push_back(known[k]); v_knownB.push_back(v_known[k]); }
+    // block A's LAST sample is block B's own grid index 0 (own_zero): scatter launched with the plan + the first sub-block's short pass
     hc::Plan plB;
-    if (!hc::build_plan(plB, L, knownB, tau, width, sc.sub)) return 8;
+    if (!hc::build_plan(plB, L, knownB, tau, width, sc.sub, 1, true)) return 8;
     double worst = 0.0;
     std::vector<std::vector<double>> slots(L + 1, std::vector<double>(hc::kTermMax, 0.0));
     std::vector<double> mini(L + 1, 0.0);
+    vB[0] = vA[L];
+    for (int s = plB.scat_lo[0]; s <= plB.scat_hi[0]; ++s)
+        for (int t = 0; t < plB.n_tgt[0][s]; ++t) slots[plB.tgt_step[0][s][t]][plB.tgt_k[0][s][t]] = plB.tgt_coef[0][s][t] * (width[s] * K[s] * vB[0]);
     for (int m = 1; m <= L; ++m) {
         std::vector<double> times, vel;
         for (int i = m; i >= 1; --i) { times.push_back(plB.tgrid[i]); vel.push_back(vB[i]); }
@@ -261,6 +280,12 @@ int main() {
         {0.015, 0.01, 201, 330, 32, 8}, {0.01, 0.0101, 128, 140, 32, 8}, {0.01, 0.004, 128, 400, 32, 8},  {0.01, 0.02, 512, 300, 16, 8},
         {0.01, 0.01, 256, 40, 16, 8},   {0.01, 0.0101, 1001, 34, 16, 8}, {0.015, 0.0101, 1001, 18, 32, 8}, {0.01, 0.01, 64, 100, 32, 8},
         {0.01, 0.01, 256, 300, 32, 4},  {0.01, 0.0037, 256, 600, 32, 8},
+        // own_zero: the newest known sample handled by the block's own machinery (scatter with the plan / first sub-block's short pass)
+        {0.01, 0.01, 256, 300, 32, 0, true},   {0.01, 0.01, 256, 300, 16, 0, true},   {0.01, 0.007, 256, 400, 32, 0, true},
+        {0.01, 0.013, 256, 220, 16, 0, true},  {0.015, 0.01, 201, 330, 32, 0, true},  {0.01, 0.004, 128, 400, 32, 0, true},
+        {0.01, 0.01, 256, 300, 32, 8, true},   {0.01, 0.01, 256, 300, 16, 8, true},   {0.01, 0.007, 256, 400, 32, 8, true},
+        {0.01, 0.013, 256, 220, 16, 8, true},  {0.015, 0.01, 201, 330, 32, 8, true},  {0.01, 0.004, 128, 400, 32, 8, true},
+        {0.01, 0.01, 256, 300, 32, 4, true},   {0.01, 0.02, 512, 300, 16, 8, true},   {0.01, 0.01, 256, 40, 16, 8, true},
     };
     int failures = 0, planned = 0;
     for (const auto& sc : list)
@@ -268,8 +293,8 @@ int main() {
             double worst = 0.0;
             const int rc = run(sc, seed, &worst);
             if (worst >= 0.0) ++planned;
-            std::printf("dt_rirf %.4f dt_step %.4f S %4d H0 %4d L %2d sub %d seed %u : %s (worst %.2e)\n", sc.dt_rirf, sc.dt_step, sc.S, sc.H0, sc.L,
-                        sc.sub, seed, rc == 0 ? (worst < 0.0 ? "not planned" : "ok") : "FAILED", worst);
+            std::printf("dt_rirf %.4f dt_step %.4f S %4d H0 %4d L %2d sub %d%s seed %u : %s (worst %.2e, rc %d)\n", sc.dt_rirf, sc.dt_step, sc.S, sc.H0,
+                        sc.L, sc.sub, sc.own_zero ? " own_zero" : "", seed, rc == 0 ? (worst < 0.0 ? "not planned" : "ok") : "FAILED", worst, rc);
             failures += rc != 0;
         }
     std::printf("%d scenario runs, %d planned, %d failures\n", static_cast<int>(sizeof list / sizeof list[0]) * 3, planned, failures);

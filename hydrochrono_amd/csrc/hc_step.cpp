@@ -219,7 +219,8 @@ void enqueue_tail(hc_ctx* c) {
         // short passes that completed the rows stopped one sample earlier), and takes the rows if the plan comes out as predicted.
         const bool rows_ahead = clean_end && ahead_expected(c, ended);
         bool planned = make_plan(c, rows_ahead);
-        if (planned && rows_ahead && !ahead_adoptable(c, ended)) planned = make_plan(c, false);  // (not as predicted after all: an ordinary block)
+        // (not as predicted after all, or no room for the extra scatter terms: an ordinary block with a pass of its own)
+        if (rows_ahead && (!planned || !ahead_adoptable(c, ended))) planned = make_plan(c, false);
         if (planned) {
             to_background();
             if (c->plan.own_zero) {

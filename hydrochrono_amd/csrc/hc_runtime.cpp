@@ -135,6 +135,10 @@ int history_push(hc_ctx* c, double t) {
     if (r.rewound) {
         // everything already enqueued (a scatter, a pass of the abandoned plan) runs before this step's kernels on the same queue,
         // so no ring slot is overwritten under a reader; the plan of the abandoned attempt is void
+        // (the pass lane is not ordered against this step's kernels: a pass in the making -- void now -- must not read ring slots
+        // while they are overwritten; a rewind is rare, so it is simply waited for)
+        pass_lane_drain(c);
+        c->ahead.active = false;
         c->plan.valid  = false;
         c->plan.misses = 0;
         c->rewinds++;

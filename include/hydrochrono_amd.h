@@ -299,7 +299,9 @@ typedef struct hc_profile_stats {
     long long block_kernel_launches;
     double block_kernel_bytes;  /* algorithmic bytes of the last pass: sum over its steps of the share of K (and of the
                                    velocity vector) that the pass computes for that step, i.e. IRF samples s >= s_cut[j] */
-    double block_kernel_bytes_once; /* bytes the last pass has to move once: live part of K, Kex, staged vectors */
+    double block_kernel_bytes_once; /* bytes the last LAUNCH of the pass kernel has to move once: live part of K, Kex, staged vectors
+                                     * (the whole pass with the pass at block start, one slice of it under the schedule "one block
+                                     * ahead"; block_kernel_bytes is scaled the same way) */
     double step_kernel_seconds;  /* the step kernel (finalize_kernel): the one launch on the critical path of a block step; wide
                                     systems (6N >= 1024): two launches per step, near_split_kernel + finalize_kernel, both counted */
     long long step_kernel_launches;

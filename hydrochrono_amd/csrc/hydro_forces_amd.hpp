@@ -281,19 +281,20 @@ class TestHydro {
 
     // Not in the reference (it has no such notion): when the look-ahead pass of a block runs, see hc_set_pass_schedule.  This class
     // is driven by a Chrono loop, which does its own work between two force evaluations, so it selects "one block ahead" for systems
-    // with 32 MB of K and more when it is constructed (the C ABI's own default does so for wide systems only): with 30 / 100 us of
+    // with 256 MB of K and more when it is constructed (the C ABI's own default does so for wide systems only): with 30 / 100 us of
     // host work between calls a 64-body step takes 12.8 / 12.7 us instead of 17.4 / 15.6, and no step waits for a whole pass.
     void SetPassSchedule(bool one_block_ahead, int slices = 0) {
         for (hc_ctx* x : ctxs_) check(x, hc_set_pass_schedule(x, one_block_ahead ? 1 : 0, slices));
     }
-    // (HC_PASS_AHEAD in the environment keeps its say.  Systems whose whole K is below 32 MB -- the reference's own one- to three-body
-    // demos are 0.3 to 2.6 MB -- keep the library's default: their pass takes a few microseconds, there is nothing to take off the
-    // critical path, and the extra launches of the schedule would cost a back-to-back caller about a microsecond per step.)
+    // (HC_PASS_AHEAD in the environment keeps its say.  Systems whose whole K is below 256 MB -- about 30 bodies; the reference's own
+    // one- to three-body demos are 0.3 to 2.6 MB -- keep the library's default: their pass takes at most a few tens of microseconds,
+    // which any host work between the calls hides already, and the extra launches of the schedule would cost a back-to-back caller
+    // about a microsecond per step.)
     void chrono_loop_defaults() {
         if (std::getenv("HC_PASS_AHEAD") || ctxs_.empty()) return;
         int N = 0, S = 0;
         check(ctxs_[0], hc_get_sizes(ctxs_[0], &N, nullptr, &S, nullptr, nullptr, nullptr, nullptr, nullptr));
-        if (8.0 * (6.0 * N) * (6.0 * N) * S < 32e6) return;
+        if (8.0 * (6.0 * N) * (6.0 * N) * S < 256e6) return;
         for (hc_ctx* x : ctxs_) check(x, hc_set_pass_schedule(x, 1, 0));
     }
 

@@ -11,8 +11,10 @@ the body state in, all 6N hydrodynamic forces (hydrostatic - radiation + waves) 
 update costs through ComponentFunc::GetVal (src/hydro_forces.cpp:79-85,727-767): the next state depends on these forces,
 so nothing is pipelined across steps.  value = K / wall time of K consecutive calls, the look-ahead passes included (the
 timed region is phase-aligned so that it always contains a pass, however small K is); the median call is reported next to it.  Secondary figures in the same line: `device_pipelined` (hc_step_device with
-states resident in HBM, enqueued ahead -- an upper bound no Chrono loop can use) and `plain_per_step_mode`
-(look-ahead off: K streamed from HBM every step).
+states resident in HBM, enqueued ahead -- an upper bound no Chrono loop can use), `plain_per_step_mode` (look-ahead off: K streamed
+from HBM every step), `steady_state` (256 more synchronous steps), `chrono_like_loop` (hc_step with 100 us of host work between calls,
+under the default pass schedule and under "one block ahead", hc_set_pass_schedule) and `c4_rank_share` (what ONE rank of C4/8 does:
+back to back under both schedules and with 300 us of host work between calls).
 
 N > 1 (default: --scaling strong --bodies 512) -- configuration C4: ONE coupled 512-body array (K = 77.3 GB FP64,
 generated in HBM by hc_synth_fill) row-sharded over the ranks (hydrochrono_amd.parallel.body_shard).  Every rank holds the

@@ -237,6 +237,36 @@ def test_one_block_ahead_reconfiguration_and_teardown_with_a_busy_pass_lane(hydr
         gpu.close()                               # ... for the destructor to wait for
 
 
+def test_one_block_ahead_with_tapered_direct_and_per_body_excitation_grids(hydro):
+    """The passes of the schedule read the processed kernel when TaperedDirect is on, and the excitation rows of the pass in the making
+    cover bodies with excitation-IRF grids of their own (column groups of Kex): both against the oracle."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    N = 4
+    case = many_body_case(N, S=200, dt_rirf=0.01, n_exc=81, dt_exc=0.02, seed=23)
+    # bodies 2 and 3 get an excitation IRF on a grid of their own (other spacing and length)
+    other = many_body_case(N, S=200, dt_rirf=0.01, n_exc=57, dt_exc=0.03, seed=24)
+    for b in (2, 3):
+        case["bodies"][b]["ex_irf_t"] = other["bodies"][b]["ex_irf_t"]
+        case["bodies"][b]["ex_irf_f"] = other["bodies"][b]["ex_irf_f"]
+    gpu, orc = hydro.HydroForces.from_case(case), load_into_oracle(case)
+    kw = dict(WAVES, simulation_duration=7.0)
+    for h in (gpu, orc):
+        h.set_convolution_mode(1)
+        h.set_tapered_direct_options(smoothing=0, window_length=5, rirf_end_time=1.6, taper_start_percent=0.6, taper_end_percent=0.9,
+                                     taper_final_amplitude=0.1)
+        h.add_waves_irregular(**kw)
+    gpu.set_pass_schedule(1)
+    motion = PrescribedMotion(N, rest_positions(case), seed=8)
+    for n in range(450):
+        st = motion.state(0.01 * n)
+        assert relerr(gpu.step(0.01 * n, *st), orc.step(0.01 * n, *st)) <= TIGHT_TOL, f"step {n}"
+        if n % 9 == 0:
+            for g, o in zip(gpu.components(), orc.components()):
+                assert relerr(g, o) <= TIGHT_TOL, f"step {n}: components"
+    assert gpu.profile()["ahead_blocks"] >= 4
+
+
 def test_one_block_ahead_c3_size_against_flat_oracle(hydro):
     """Full-size C3 (64 bodies, S = 1024, Nf = 512) from a steady-state history: 200 steps under the schedule -- plain boundary step,
     a block with its own pass, then blocks whose rows were made ahead -- against the flat-array CPU oracle."""

@@ -404,7 +404,7 @@ def main():
         align = boundary - first
     pre = align + args.warmup
     total = pre + args.steps
-    n_all = total + n_steady + ((2 * 128 + 72) if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
+    n_all = total + n_steady + ((4 * 128 + 72) if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
     duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
     gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
@@ -580,45 +580,40 @@ def main():
         # What a Chrono loop sees: the host integrates between two force evaluations, and what a step leaves for later steps (scatter,
         # the pass of the next block) runs meanwhile.  100 us of host work between calls (a busy wait standing in for DoStepDynamics'
         # own share; the reference's whole RM3 step takes 360 us), only the calls are timed.
-        n_cl, work = 128, 100e-6
-        lat = np.zeros(n_cl)
+        n_cl, n_in = 128, 72   # timed steps per loop; run-in after a change of schedule (plain boundary step, a block with its own pass, the first block made ahead)
         pc = time.perf_counter
-        for i in range(n_cl):
-            k = k_next + i
-            a = pc()
-            rc = hc_step(ctx, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
-            b_ = pc()
-            lat[i] = b_ - a
-            if rc:
-                gpu._chk(rc)
-            while pc() - b_ < work:
-                pass
-        def gap_stats(lat_):
+
+        def gap_loop(k0, skip, work):
+            lat_ = np.zeros(n_cl)
+            for i in range(skip + n_cl):
+                k = k0 + i
+                a = pc()
+                rc = hc_step(ctx, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
+                b_ = pc()
+                if i >= skip:
+                    lat_[i - skip] = b_ - a
+                if rc:
+                    gpu._chk(rc)
+                while pc() - b_ < work:
+                    pass
             return {"mean_hc_step_us": float(lat_.mean()) * 1e6, "median_hc_step_us": float(np.median(lat_)) * 1e6,
                     "p90_hc_step_us": float(np.percentile(lat_, 90)) * 1e6, "max_hc_step_us": float(lat_.max()) * 1e6}
-        chrono_like = {"steps": n_cl, "host_work_between_calls_us": work * 1e6, **gap_stats(lat),
+        chrono_like = {"steps": n_cl, "host_work_between_calls_us": 100.0, **gap_loop(k_next, 0, 100e-6),
                        "note": "synchronous hc_step with 100 us of host work between calls: the look-ahead pass and the scatter run while the host is away"}
-        # the same loop under the pass schedule "one block ahead" (hc_set_pass_schedule): no step waits for a whole pass
         k_next += n_cl
+        short_gap = {"host_work_between_calls_us": 30.0, "pass_at_block_start": gap_loop(k_next, 0, 30e-6)}
+        k_next += n_cl
+        # the same loops under the pass schedule "one block ahead" (hc_set_pass_schedule): the pass of the next block runs beside the
+        # steps of the current one, no step waits for a whole pass
         gpu.set_pass_schedule(1)
-        n_in, lat2 = 72, np.zeros(n_cl)   # the plain boundary step, the first block (its own pass) and the first block made ahead run in
-        for i in range(n_in + n_cl):
-            k = k_next + i
-            a = pc()
-            rc = hc_step(ctx, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
-            b_ = pc()
-            if i >= n_in:
-                lat2[i - n_in] = b_ - a
-            if rc:
-                gpu._chk(rc)
-            while pc() - b_ < work:
-                pass
-        pa = gpu.profile()
-        chrono_like["pass_one_block_ahead"] = {"steps": n_cl, **gap_stats(lat2), "blocks_without_a_pass_of_their_own": int(pa["ahead_blocks"]),
-                                               "note": "hc_set_pass_schedule(ctx, 1, 0): the pass of the next block in slices (4 at this size) behind the first steps of the current one"}
-        gpu.set_pass_schedule(0)
-        k_next += n_in
+        chrono_like["pass_one_block_ahead"] = {"steps": n_cl, **gap_loop(k_next, n_in, 100e-6),
+                                               "note": "hc_set_pass_schedule(ctx, 1, 0): the pass of the next block in slices (4 at this size) on the pass lane, beside the steps of the current one"}
+        k_next += n_in + n_cl
+        short_gap["pass_one_block_ahead"] = gap_loop(k_next, 0, 30e-6)
         k_next += n_cl
+        chrono_like["pass_one_block_ahead"]["blocks_without_a_pass_of_their_own"] = int(gpu.profile()["ahead_blocks"])
+        chrono_like["with_30us_of_host_work"] = short_gap
+        gpu.set_pass_schedule(0)
     if n_pipe > 0:
         # hc_step_device, states resident in HBM, every step enqueued without waiting for the previous one's forces
         d_states = torch.tensor(states[k_next:k_next + n_pipe], device="cuda")

@@ -85,6 +85,9 @@ static int run(int N, int b0, int b1, int S, double gap_us, int schedule, int sl
 
 int main(int argc, char** argv) {
     const bool wide = argc > 1 && std::atoi(argv[1]) != 0;  // 1: the C4 rank share (9.7 GB of K) as well
+    if (argc > 3) {  // one configuration only (for a profiler): <wide> <schedule> <gap in us>
+        return wide ? run(512, 0, 64, 1024, std::atof(argv[3]), std::atoi(argv[2]), 0) : run(64, 0, 64, 1024, std::atof(argv[3]), std::atoi(argv[2]), 0);
+    }
     for (double gap : {0.0, 30.0, 100.0, 300.0})
         for (int schedule : {0, 1})
             if (run(64, 0, 64, 1024, gap, schedule, 0)) return 1;

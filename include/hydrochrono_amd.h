@@ -239,9 +239,9 @@ int hc_set_lookahead(hc_ctx* ctx, int steps);
  * that go through HIP launches, issue the same launches on the step path's own queue / stream (the same sums; a back-to-back
  * caller then pays 10-30 % for them).  No step waits for a whole pass.
  * Measured on an MI355X, mean hc_step latency of a C++ caller with 30 / 100 / 300 us of host work between calls: 64 bodies
- * 17.4 -> 12.8 / 15.6 -> 12.7 / 12.3 -> 12.5 us (p99 at 30 us: 176 -> 17 us); the 64-of-512-body shard - / 64.6 -> 28.2 /
- * 58.0 -> 18.7 us (p99 at 300 us: 1300 -> 26 us).  A caller that steps back to back has nothing to hide the pass behind and pays
- * the short passes: 18.5 -> 18.9 us and 73.9 -> 81.2 us.  Used once the history covers the IRF window; results are those of
+ * 18.9 -> 14.2 / 16.8 -> 14.1 / 14.0 -> 14.1 us (p99 at 30 us: 174 -> 19 us); the 64-of-512-body shard - / 66.8 -> 30.0 /
+ * 60.1 -> 20.7 us (p99 at 300 us: 1306 -> 26 us).  A caller that steps back to back has nothing to hide the pass behind:
+ * 19.5 -> 20.2 us at 64 bodies (the short pass towards the next block and the two queues sharing the chip), 74.7 -> 71.3 us for the shard.  Used once the history covers the IRF window; results are those of
  * schedule 0 up to the rounding of a different summation grouping (same 1e-6 contract, same tolerance on the predicted times).
  * The schedule is part of the configuration: the row shards of one array must use the same one (and the same slice count) to
  * stay bitwise equal to the unsharded context.  HC_PASS_AHEAD=0/1 (HC_PASS_SLICES=n, HC_PASS_CONCURRENT=0: no queue of its own)

@@ -342,9 +342,9 @@ void choose_conv_config(hc_ctx* c) {
 // (hc_step.cpp: pass_lane_ready): with the usual four row groups a slice has (CUs - 8 * free) / 4 chunks, in whole octets (56 on
 // an MI355X with 4 free CUs per XCD).  A function of the column count, the slice count and the device only, like every chunk length.
 // Default pass schedule (hc_set_pass_schedule): one block ahead for wide systems -- the same switch as the two-level look-ahead, a
-// function of D only.  There the pass is long (1.5 ms for a C4/8 rank) and the schedule wins for every caller: 70 -> 53 us per step
-// back to back, 58 -> 20 us with 300 us of host work between calls (profiles/r03/ahead_probe.txt).  At C3 size a caller that steps back
-// to back gains nothing (18.9 -> 18.6 us) while the pass runs in slices of lower efficiency, so the schedule stays the caller's choice.
+// function of D only.  There the pass is long (1.5 ms for a C4/8 rank) and the schedule wins for every caller: 74.7 -> 71.3 us per step
+// back to back, 60 -> 21 us with 300 us of host work between calls (profiles/r03/ahead_probe.txt).  At C3 size a caller that steps back
+// to back loses 2-4 % (19.5 -> 20.2 us) and the pass runs in slices of lower efficiency, so the schedule stays the caller's choice there.
 int default_pass_ahead(const hc_ctx* c) {
     const int forced = env_int("HC_PASS_AHEAD", -1);
     if (forced >= 0) return forced != 0 ? 1 : 0;

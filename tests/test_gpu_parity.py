@@ -637,6 +637,7 @@ def test_c3_full_size_against_oracle(c3_mode, dt, lookahead):
     orc.add_waves_irregular(**kw)
     t_hist = 20.0 - dt * np.arange(1, int(np.ceil(10.24 / dt)) + 6)  # newest first, covers the whole 10.23 s window
     v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    gpu.set_pass_schedule(0)  # (the launch counts asserted below are those of the pass at block start)
     gpu.set_history(t_hist, v_hist)
     orc.prefill_history(t_hist, v_hist)
     gpu.enable_profiling(1)
@@ -979,6 +980,7 @@ def test_lookahead_random_step_patterns(HF, seed, N, depth, sub, monkeypatch):
     case = many_body_case(N, S=80 if depth == 16 else 150, dt_rirf=0.01, n_exc=33, seed=300 + seed)
     a, b = HF.from_case(case), HF.from_case(case)
     a.set_lookahead(depth)
+    a.set_pass_schedule(0)  # the launch counts asserted below are those of the pass at block start (tests/test_gpu_ahead.py has the other schedule)
     b.set_lookahead(0)
     kw = dict(simulation_dt=0.01, simulation_duration=40.0, wave_height=1.5, wave_period=6.0, nfrequencies=24, frequency_min=0.05,
               frequency_max=0.5)

@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
     }
     const double timestep = 0.005, g = 9.81, rho = 1000.0;
     std::vector<std::shared_ptr<MockBody>> mock;
-    std::vector<std::shared_ptr<HydroBody>> bodies;
+    std::vector<std::shared_ptr<BodyView>> bodies;
     for (int b = 0; b < N; ++b) {
         mock.push_back(std::make_shared<MockBody>("body" + std::to_string(b + 1)));  // names as in the .h5
         bodies.push_back(mock.back());

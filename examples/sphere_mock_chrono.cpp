@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
     double pto_damping = 0.0;
 
     auto sphere = std::make_shared<MockBody>("body1");  // must match the .h5 body name
-    std::vector<std::shared_ptr<HydroBody>> bodies{sphere};
+    std::vector<std::shared_ptr<BodyView>> bodies{sphere};
     try {
         std::shared_ptr<WaveBase> waves;
         if (mode == "decay") {

@@ -103,6 +103,7 @@ SIGNATURES = {
     "hc_get_sizes": (C.c_int, [C.c_void_p] + [c_int_p] * 8),
     "hc_get_rirf_width": (C.c_int, [C.c_void_p, c_double_p]),
     "hc_get_rirf_effective": (C.c_int, [C.c_void_p, c_double_p]),
+    "hc_get_rirf_value": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p]),
     "hc_get_excitation_irf_resampled": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
     "hc_get_spectrum": (C.c_int, [C.c_void_p] + [c_double_p] * 5),
     "hc_get_eta_table": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),

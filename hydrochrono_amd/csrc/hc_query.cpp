@@ -69,6 +69,22 @@ int hc_get_rirf_effective(hc_ctx* c, double* out) {
     HC_API_END(c)
 }
 
+int hc_get_rirf_value(hc_ctx* c, int row_local, int col, int st, double* out) {
+    HC_API_BEGIN(c)
+    require(c->finalized && out, HC_ERR_INVALID, "not finalized or null pointer");
+    // index guards of TestHydro::GetRIRFval (src/hydro_forces.cpp:694-697): std::out_of_range there
+    require(row_local >= 0 && row_local < c->Dloc && col >= 0 && col < c->D && st >= 0 && st < c->S, HC_ERR_OUT_OF_RANGE,
+            "rirf index out of range in GetRIRFval");
+    ensure_processed(c);
+    hc::DeviceBuffer<double> series;
+    series.alloc(static_cast<size_t>(c->S));
+    hc::launch_extract_series(rad_panel(c), row_local, col, c->D, c->S, series.p, c->stream);
+    HC_HIP(hipGetLastError());
+    HC_HIP(hipMemcpyAsync(out, series.p + st, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    HC_API_END(c)
+}
+
 int hc_get_excitation_irf_resampled(hc_ctx* c, int body, double* t, double* width, double* vals) {
     HC_API_BEGIN(c)
     require(c->wave_kind == hc::kWaveIrregular, HC_ERR_INVALID, "no irregular wave model attached");

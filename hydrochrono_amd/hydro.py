@@ -224,10 +224,18 @@ class HydroForces:
         self._chk(self.lib.hc_set_lookahead(self.ctx, int(steps)))
 
     def set_pass_schedule(self, one_block_ahead, slices=0):
-        """hc_set_pass_schedule: 0 = the pass of a look-ahead block when the block starts (default), 1 = one block ahead, in
-        `slices` launches (0: chosen by the library) behind the first steps of the block before -- for callers that leave the GPU idle between force
-        evaluations for less than a pass takes."""
-        self._chk(self.lib.hc_set_pass_schedule(self.ctx, int(bool(one_block_ahead)), int(slices)))
+        """hc_set_pass_schedule: 0 = the pass of a look-ahead block when the block starts, 1 = one block ahead, in `slices` launches
+        (0: chosen by the library) behind the first steps of the block before -- for callers that leave the GPU idle between force
+        evaluations for less than a pass takes; None or -1 = the library's default, which depends on the size (wide systems,
+        D >= 1024: one block ahead; others: at block start; HC_PASS_AHEAD overrides)."""
+        mode = -1 if one_block_ahead is None or int(one_block_ahead) < 0 else int(bool(one_block_ahead))
+        self._chk(self.lib.hc_set_pass_schedule(self.ctx, mode, int(slices)))
+
+    def rirf_value(self, row_local, col, st):
+        """TestHydro::GetRIRFval(row, col, st) for a local row (src/hydro_forces.cpp:693-711)."""
+        v = C.c_double()
+        self._chk(self.lib.hc_get_rirf_value(self.ctx, int(row_local), int(col), int(st), C.byref(v)))
+        return v.value
 
     def direct_dispatch(self):
         """(active, reason): whether hc_step writes AQL packets itself instead of calling hipLaunchKernelGGL."""

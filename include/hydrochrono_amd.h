@@ -334,6 +334,9 @@ int hc_get_rirf_width(hc_ctx* ctx, double* w_S);
  * (src/hydro_forces.cpp:693-711), i.e. rho-scaled and, in TaperedDirect mode, processed (:385-535).
  * rows are local; out is [D_local][D][S].  Meant for small cases. */
 int hc_get_rirf_effective(hc_ctx* ctx, double* out_DlocalxDxS);
+/* One value of the same: TestHydro::GetRIRFval(row, col, st) (src/hydro_forces.cpp:693-711) for a LOCAL row; indices outside
+ * [0, D_local) x [0, D) x [0, S) give HC_ERR_OUT_OF_RANGE (the reference throws std::out_of_range, :694-697). */
+int hc_get_rirf_value(hc_ctx* ctx, int row_local, int col, int st, double* out);
 /* ex_irf_time_sampled_, ex_irf_width_sampled_, ex_irf_sampled_ (6 x L) of a local body (src/wave_types.cpp:572-628) */
 int hc_get_excitation_irf_resampled(hc_ctx* ctx, int body, double* t_L, double* width_L, double* vals_6xL);
 /* Bodies may carry different excitation-IRF time grids (the reference keeps one per body, src/wave_types.cpp:432-459): L of this

@@ -10,6 +10,10 @@ class ChSystem {
     long GetNumCoordsVelLevel() const { return ncoords_vel; }
     void Add(std::shared_ptr<ChLoadContainer> c) { containers.push_back(std::move(c)); }
     void AddBody(std::shared_ptr<ChBody> b);
+    void Add(std::shared_ptr<ChBody> b) { AddBody(std::move(b)); }
+    double GetChTime() const { return time; }
+    const std::vector<std::shared_ptr<ChBody>>& GetBodies() const { return bodies; }
+    void DoStepDynamics(double h);  // heave-only stand-in, defined in ChBody.h
     double time       = 0.0;
     long ncoords_vel  = 0;
     std::vector<std::shared_ptr<ChLoadContainer>> containers;

@@ -3,6 +3,9 @@
 // through ChForce -> ComponentFunc::GetVal like the reference's ForceFunc6d (src/hydro_forces.cpp:63-168), plus the added-mass
 // load through ChLoadAddedMass::LoadIntLoadResidual_Mv (hc_added_mass_mv_multi).  Stand-in Chrono headers (tests/cpp/chrono_stub).
 //   usage: shards_test <bemio.h5> <N> <states.bin> <nsteps> <dt> <n_shards> [regular|irregular|none]
+//          shards_test <case.hydro.yaml> <N> <states.bin> <nsteps> <dt> <n_shards> yaml
+// (yaml: the object comes from SetupHydroFromYAML(ReadHydroYAML(file), every body of the system, dt, 8.0, 0.5, devices) -- the
+// runner's lines, src/hydrochrono_runner/run_hydrochrono_from_yaml.cpp:440-457, with a device list)
 // states.bin: [nsteps][12N] doubles = pos | rpy | linvel | angvel per step (written by the Python test, so that the oracle sees
 // exactly the same inputs).  Prints per step the 6N totals with 17 significant digits, then "MV" and the 6N + 6 entries of R,
 // then one "PROF" line per shard.
@@ -40,7 +43,13 @@ int main(int argc, char** argv) {
     system.AddBody(extra);
     try {
         std::shared_ptr<hydroc_amd::WaveBase> waves;
-        if (mode == "regular") {
+        std::unique_ptr<hydroc_amd::TestHydro> from_yaml;
+        std::unique_ptr<hydroc_amd::ChronoHydroSystem> from_h5;
+        const std::vector<int> devices(static_cast<size_t>(G), 0);
+        if (mode == "yaml") {
+            std::vector<std::shared_ptr<ChBody>> all_bodies = system.bodies;  // the ground too: it is not in the YAML
+            from_yaml = hydroc_amd::SetupHydroFromYAML(hydroc_amd::ReadHydroYAML(argv[1]), all_bodies, dt, 8.0, 0.5, devices);
+        } else if (mode == "regular") {
             auto w = std::make_shared<hydroc_amd::RegularWave>(N);
             w->regular_wave_amplitude_ = 0.8;
             w->regular_wave_omega_     = 0.55;
@@ -61,9 +70,10 @@ int main(int argc, char** argv) {
             p.peak_enhancement_factor_ = 3.3;
             waves = std::make_shared<hydroc_amd::IrregularWaves>(p);
         }
-        hydroc_amd::ChronoHydroSystem hydro(bodies, argv[1], waves, std::vector<int>(static_cast<size_t>(G), 0));
-        if (hydro.hydro().num_shards() != G) return 3;
-        for (hc_ctx* c : hydro.hydro().contexts()) hydroc_amd::check(c, hc_enable_profiling(c, 1));
+        if (!from_yaml) from_h5 = std::make_unique<hydroc_amd::ChronoHydroSystem>(bodies, argv[1], waves, devices);
+        hydroc_amd::TestHydro& hydro = from_yaml ? *from_yaml : from_h5->hydro();
+        if (hydro.num_shards() != G) return 3;
+        for (hc_ctx* c : hydro.contexts()) hydroc_amd::check(c, hc_enable_profiling(c, 1));
         auto load = system.containers[0]->loads[0];
         load->StubUpdate(system.GetNumCoordsVelLevel());
         for (int n = 0; n < nsteps; ++n) {
@@ -91,7 +101,7 @@ int main(int argc, char** argv) {
         for (long i = 0; i < n_sys; ++i) std::printf(" %.17g", R(i));
         std::printf("\n");
         // per shard: look-ahead passes, scatter launches, AQL dispatches, HIP launches (how the kernels reached the GPU)
-        for (hc_ctx* c : hydro.hydro().contexts()) {
+        for (hc_ctx* c : hydro.contexts()) {
             hc_profile_stats p;
             hydroc_amd::check(c, hc_get_profile(c, &p));
             std::printf("PROF %lld %lld %lld %lld %d\n", p.block_kernel_launches, p.scatter_kernel_launches, p.direct_dispatches, p.hip_launches,

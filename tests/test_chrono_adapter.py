@@ -1,10 +1,14 @@
-"""The guarded Project Chrono adapter block of hydrochrono_amd/csrc/hydro_forces_amd.hpp (ChronoBody, ComponentFunc,
-ChLoadAddedMass, ChronoHydroSystem -- the counterparts of src/hydro_forces.cpp:63-168,223-234 and
-src/chloadaddedmass.cpp:27-70) compiled against minimal stand-in Chrono headers (tests/cpp/chrono_stub/, test
-infrastructure only) and driven through ChForce -> ComponentFunc::GetVal x6 per step and ChLoadAddedMass.
+"""The plugin surface a Chrono program sees (include/hydroc_amd/*.h: TestHydro(vector<shared_ptr<ChBody>>, h5, waves), ComponentFunc,
+ForceFunc6d, ChLoadAddedMass, ReadHydroYAML, SetupHydroFromYAML -- the counterparts of include/hydroc/hydro_forces.h:45-285,
+include/hydroc/chloadaddedmass.h:22-90, src/hydro_yaml_parser.h:20, src/setup_hydro_from_yaml.h:33-39) compiled against minimal
+stand-in Chrono headers (tests/cpp/chrono_stub/, test infrastructure only) and driven the way Chrono drives the reference:
+ChForce -> ComponentFunc::GetVal x 6 per body and step, ChLoadAddedMass through its Jacobian and LoadIntLoadResidual_Mv.
 
-Chrono itself is not installed in the image, so this pins nothing about Chrono -- it keeps the adapter code compiling
-and running against the interface shapes the reference uses."""
+tests/cpp/chrono_dropin_test.cpp holds the reference's own hydro lines verbatim (decay driver, regular-wave demo, the YAML
+runner's ReadHydroYAML / SetupHydroFromYAML lines); its trajectories are compared with the reference's golden files.
+
+Chrono itself is not installed in the image, so this pins nothing about Chrono -- it keeps the surface source-compatible and the
+chain behind it correct."""
 import os
 import subprocess
 
@@ -14,35 +18,158 @@ import pytest
 from cases import GOLDEN_DIR, goldens
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "tests", "cpp", "chrono_adapter_test.cpp")
 STUB = os.path.join(ROOT, "tests", "cpp", "chrono_stub")
+SPHERE_H5 = os.path.join(GOLDEN_DIR, "sphere.h5")
 
 
-def build(out, opt="-O1"):
+def build(out, name="chrono_adapter_test", opt="-O1"):
     from hydrochrono_amd import build as hb
     hb.build()
     libdir = os.path.join(ROOT, "hydrochrono_amd", "lib")
-    subprocess.run(["g++", "-std=c++17", opt, "-Wall", "-Werror", "-I", STUB, SRC, "-o", out, "-L", libdir, "-lhydrochrono_amd",
+    subprocess.run(["g++", "-std=c++17", opt, "-Wall", "-Werror", "-I", STUB, "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", out, "-L", libdir, "-lhydrochrono_amd",
                     f"-Wl,-rpath,{libdir}"], check=True)
     return out
 
 
-def test_adapter_block_compiles_and_links(tmp_path):
-    """CPU: the HYDROCHRONO_AMD_WITH_CHRONO block builds warning-free against the stand-in headers."""
-    assert os.path.exists(build(str(tmp_path / "chrono_adapter_test")))
+def need_bemio():
+    from hydrochrono_amd import build as hb
+    if not os.path.exists(hb.BEMIO_LIB):
+        pytest.skip("libhdf5 not available: BEMIO reader not built")
+
+
+@pytest.mark.parametrize("name", ["chrono_adapter_test", "chrono_dropin_test"])
+def test_adapter_block_compiles_and_links(tmp_path, name):
+    """CPU: the HYDROCHRONO_AMD_WITH_CHRONO code builds warning-free against the stand-in headers -- for the drop-in program this
+    is the source-compatibility check itself (the reference's hydro lines, only include + namespace changed)."""
+    assert os.path.exists(build(str(tmp_path / name), name))
+
+
+def test_headers_are_self_contained(tmp_path):
+    """Every header of include/hydroc_amd/ compiles on its own, with and without Chrono, in either include order."""
+    headers = ["wave_types.h", "hydro_types.h", "hydro_yaml_parser.h", "hydro_forces.h", "chloadaddedmass.h", "setup_hydro_from_yaml.h"]
+    for with_chrono in (False, True):
+        for h in headers + ["chloadaddedmass.h+hydro_forces.h"]:
+            src = tmp_path / "one.cpp"
+            src.write_text("".join(f"#include <hydroc_amd/{x}>\n" for x in h.split("+")) + "int main() { return 0; }\n")
+            cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src)]
+            if with_chrono:
+                cmd[1:1] = ["-DHYDROCHRONO_AMD_WITH_CHRONO=1", "-I", STUB]
+            subprocess.run(cmd, check=True)
+
+
+def run(exe, *args):
+    r = subprocess.run([exe, *[str(a) for a in args]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    traj = np.array([[float(x) for x in ln.split()] for ln in lines if ln[0].isdigit() or ln[0] == "-"])
+    tags = {ln.split()[0]: ln.split()[1:] for ln in lines if ln[0].isalpha()}
+    return traj, tags
 
 
 @pytest.mark.gpu
 def test_sphere_decay_through_chforce_and_added_mass_load(tmp_path):
-    from hydrochrono_amd import build as hb
-    exe = build(str(tmp_path / "chrono_adapter_test"), "-O2")
-    if not os.path.exists(hb.BEMIO_LIB):
-        pytest.skip("libhdf5 not available: BEMIO reader not built")
+    need_bemio()
+    exe = build(str(tmp_path / "chrono_adapter_test"), opt="-O2")
     ref = goldens()["decay_z_um"] * 1e-6
-    r = subprocess.run([exe, os.path.join(GOLDEN_DIR, "sphere.h5"), str(len(ref))], check=True, capture_output=True, text=True)
+    r = subprocess.run([exe, SPHERE_H5, str(len(ref))], check=True, capture_output=True, text=True)
     lines = r.stdout.strip().splitlines()
     assert lines[-1].startswith("MV_CHECK")
     assert float(lines[-1].split()[1]) <= 1e-13  # R += c*M*w through LoadIntLoadResidual_Mv == the Jacobian block times w
     z = np.array([float(line.split()[1]) for line in lines[:-1]])
     assert z.shape == ref.shape
     assert np.max(np.abs(z - ref)) <= 5.1e-7  # the reference's golden decay trajectory (6 printed decimals)
+
+
+@pytest.fixture(scope="module")
+def dropin(tmp_path_factory):
+    need_bemio()
+    return build(str(tmp_path_factory.mktemp("dropin") / "chrono_dropin_test"), "chrono_dropin_test", "-O2")
+
+
+def check_wiring(tags):
+    # two ChForce objects on the body, one load in one container, Jacobian sized for the whole system (sphere + ground = 12 rows)
+    assert tags["WIRED"] == ["2", "1", "12"]
+
+
+@pytest.mark.gpu
+def test_reference_decay_lines_reproduce_the_golden(dropin):
+    """`TestHydro hydro_forces(bodies, h5fname); hydro_forces.AddWaves(default_dont_add_waves); ... system.DoStepDynamics(timestep)`"""
+    ref = goldens()["decay_z_um"] * 1e-6
+    traj, tags = run(dropin, "decay", SPHERE_H5, len(ref))
+    check_wiring(tags)
+    assert np.allclose(traj[:, 0], 0.015 * (1 + np.arange(len(ref))), atol=1e-9)
+    assert np.max(np.abs(traj[:, 1] - ref)) <= 5.1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [1, 4, 10])
+def test_reference_regular_wave_demo_lines_reproduce_the_goldens(dropin, case):
+    """demos/sphere/demo_sphere_reg_waves.cpp:126-151 for three of its ten wave cases (all ten run through the C ABI in
+    tests/test_gpu_parity.py)."""
+    g = goldens()
+    nsteps = 6000
+    ref = g[f"reg_waves_{case}_z_um"][:nsteps] * 1e-6
+    traj, tags = run(dropin, "regular", SPHERE_H5, nsteps, repr(float(g["reg_wave_amp"][case - 1])), repr(float(g["reg_wave_omega"][case - 1])),
+                     repr(float(g["reg_wave_pto_damping"][case - 1])))
+    check_wiring(tags)
+    assert np.max(np.abs(traj[:, 1] - ref)) <= 5.1e-7
+
+
+def write_yaml(path, waves, extra=""):
+    path.write_text(f"""hydrodynamics:
+  bodies:
+    - name: body1
+      h5_file: {SPHERE_H5}
+    - name: not_in_the_system
+      h5_file: {SPHERE_H5}
+{extra}  waves:
+{waves}""")
+    return str(path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, "0"])
+def test_runner_yaml_lines_decay(dropin, tmp_path, devices):
+    """`hydro_data = ReadHydroYAML(f); ... test_hydro = SetupHydroFromYAML(hydro_data, bodies, loop_dt, sim_duration_hint, 0.0);`
+    with every body of the system handed over (the ground is not in the YAML, one YAML body is not in the system)."""
+    ref = goldens()["decay_z_um"] * 1e-6
+    y = write_yaml(tmp_path / "decay.hydro.yaml", "    type: still\n")
+    args = ["yaml", y, len(ref), -1.0, 0.0] + ([devices] if devices else [])
+    traj, tags = run(dropin, *args)
+    check_wiring(tags)
+    assert np.max(np.abs(traj[:, 1] - ref)) <= 5.1e-7
+    z = np.load(os.path.join(GOLDEN_DIR, "sphere_bemio.npz"))
+    K = z["body1/rirf_K"].reshape(6, 6, -1)
+    assert float(tags["RIRF"][0]) == float(z["rho"][0]) * K[2, 2, 1]  # GetRIRFval(2, 2, 1): rho-scaled file value
+
+
+@pytest.mark.gpu
+def test_runner_yaml_lines_regular_and_irregular(dropin, tmp_path):
+    g = goldens()
+    nsteps = 3000
+    amp, omega, c = (float(g[k][0]) for k in ("reg_wave_amp", "reg_wave_omega", "reg_wave_pto_damping"))
+    y = write_yaml(tmp_path / "reg.hydro.yaml", f"    type: regular\n    height: {2 * amp!r}\n    period: {2 * np.pi / omega!r}\n")
+    traj, tags = run(dropin, "yaml", y, nsteps, -2.0, repr(c))
+    check_wiring(tags)
+    # omega = 2 pi / (2 pi / omega) differs from the demo's literal by an ulp or two
+    assert np.max(np.abs(traj[:, 1] - g["reg_waves_1_z_um"][:nsteps] * 1e-6)) <= 1e-6
+    # irregular from YAML = Pierson-Moskowitz, nf = ceil(0.999 * 40), seed 7: not a golden case; the object answers the runner's
+    # exporter queries and the body moves
+    y = write_yaml(tmp_path / "irr.hydro.yaml", "    type: irregular\n    height: 2.0\n    period: 12.0\n    seed: 7\n")
+    traj, tags = run(dropin, "yaml", y, 600, -2.0, 0.0)
+    nf, ns, nt, ne = (int(x) for x in tags["IRREG"])
+    assert nf == ns == 40 and nt == ne and nt > 2667
+    assert np.all(np.isfinite(traj)) and np.ptp(traj[:, 1]) > 1e-3
+
+
+@pytest.mark.gpu
+def test_tapered_direct_from_yaml_changes_the_kernel(dropin, tmp_path):
+    """convolution: block of the YAML -> SetRadiationConvolutionMode / SetTaperedDirectOptions (src/setup_hydro_from_yaml.cpp:151-190)"""
+    extra = "  convolution:\n    mode: TaperedDirect\n    taper:\n      start_percent: 0.0\n      end_percent: 0.5\n"
+    y = write_yaml(tmp_path / "td.hydro.yaml", "    type: still\n", extra)
+    _, tags = run(dropin, "yaml", y, 5, -1.0, 0.0)
+    z = np.load(os.path.join(GOLDEN_DIR, "sphere_bemio.npz"))
+    raw = float(z["rho"][0]) * z["body1/rirf_K"].reshape(6, 6, -1)[2, 2, 1]
+    got = float(tags["RIRF"][0])
+    assert got != raw and abs(got) < abs(raw) * 1.0000001 and abs(got / raw - 1.0) < 1e-3  # tapered from sample 0 on: slightly below

@@ -182,6 +182,50 @@ def test_sharded_plugin_surface_through_componentfunc(tmp_path, mode):
     assert relerr(R, expect) <= 1e-13
 
 
+@pytest.mark.parametrize("waves", ["regular", "irregular"])
+def test_setup_hydro_from_yaml_with_one_and_two_shard_contexts(tmp_path, waves):
+    """The YAML runner's lines -- ReadHydroYAML, then SetupHydroFromYAML(hydro_data, every body of the system, dt, duration, ramp
+    [, devices]) (src/hydrochrono_runner/run_hydrochrono_from_yaml.cpp:440-457, src/setup_hydro_from_yaml.h:33-39) -- return an
+    object that is WIRED into the ChSystem: forces are read through ChForce -> ComponentFunc::GetVal, the added mass through the
+    load the constructor registered.  One, two and four shard contexts print the same 17 digits; totals against the oracle
+    configured the way src/setup_hydro_from_yaml.cpp:28-79 maps the YAML (regular: A = H/2, omega = 2 pi/T; irregular: PM defaults)."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    exe = _build(tmp_path, "shards_test")
+    case = four_body_case()
+    N, nsteps, dt = 4, 200, 0.005
+    h5 = os.path.join(GOLDEN_DIR, "four_body.h5")
+    wave_block = ("    type: regular\n    height: 1.6\n    period: 11.0\n" if waves == "regular"
+                  else "    type: irregular\n    height: 2.0\n    period: 6.0\n    seed: 3\n")
+    bodies = "".join(f"    - name: body{b}\n      h5_file: {h5}\n" for b in range(1, N + 1))
+    ypath = tmp_path / "array.hydro.yaml"
+    ypath.write_text(f"hydrodynamics:\n  bodies:\n{bodies}  waves:\n{wave_block}")
+    motion = PrescribedMotion(N, np.stack([b["cg"] for b in case["bodies"]]), seed=22)
+    states = np.stack([motion.packed(n * dt) for n in range(nsteps)])
+    spath = str(tmp_path / "states.bin")
+    states.tofile(spath)
+    outs = {}
+    for G in (1, 2, 4):
+        r = subprocess.run([exe, str(ypath), str(N), spath, str(nsteps), repr(dt), str(G), "yaml"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().splitlines()
+        assert sum(ln.startswith("PROF") for ln in lines) == G
+        outs[G] = [ln for ln in lines if not ln.startswith("PROF")]
+        assert len(outs[G]) == nsteps + 1 and outs[G][-1].startswith("MV")
+    assert outs[2] == outs[1] and outs[4] == outs[1]
+    orc = load_into_oracle(case)
+    orc.set_gravity([0.3, -0.2, -9.7])
+    if waves == "regular":
+        orc.add_waves_regular(0.8, 2.0 * np.pi / 11.0)
+    else:
+        orc.add_waves_irregular(simulation_dt=dt, simulation_duration=8.0, ramp_duration=0.5, wave_height=2.0, wave_period=6.0, seed=3)
+    got = np.array([[float(x) for x in ln.split()] for ln in outs[2][:-1]])
+    n3 = 3 * N
+    for n in range(nsteps):
+        st = states[n]
+        fo = orc.step(n * dt, st[:n3], st[n3:2 * n3], st[2 * n3:3 * n3], st[3 * n3:])
+        assert relerr(got[n], fo) <= TIGHT_TOL, f"step {n}"
+
+
 @pytest.mark.parametrize("mode", [(32, 1), (16, 1), (32, 0), (0, 1)], ids=["la32-aql", "la16-aql", "la32-hip", "plain-aql"])
 def test_wide_system_two_level_lookahead_against_oracle(hydro, mode, monkeypatch):
     """A WIDE system (D = 1056 >= 1024): the own-sample part of a block step is split over column slices (near_split_kernel), and the

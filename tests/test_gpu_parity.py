@@ -312,6 +312,7 @@ def test_row_sharded_contexts_concatenate(HF):
     dict(smoothing=1, window_length=2, rirf_end_time=0.031),  # effective_steps < 5
 ])
 def test_tapered_direct(HF, opts):
+    from hydrochrono_amd.hydro import HydroError
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     from hydrochrono_amd.synthetic import many_body_case, rest_positions
     case = many_body_case(2, S=150, n_exc=33, seed=11)
@@ -323,6 +324,13 @@ def test_tapered_direct(HF, opts):
     Kg = gpu.rirf_effective()
     Ko = np.array([[[orc.rirf_val(r, c, s) for s in range(150)] for c in range(12)] for r in range(12)])
     assert_close(Kg, Ko, 1e-14, "processed kernel")
+    # GetRIRFval (src/hydro_forces.cpp:693-711): one value of the same tensor; indices out of range are std::out_of_range there
+    for (r, c, s) in ((0, 0, 0), (7, 11, 149), (11, 3, 74)):
+        assert gpu.rirf_value(r, c, s) == Kg[r, c, s]
+    for bad in ((12, 0, 0), (0, 12, 0), (0, 0, 150), (-1, 0, 0)):
+        with pytest.raises(HydroError) as ei:
+            gpu.rirf_value(*bad)
+        assert ei.value.status == 2  # HC_ERR_OUT_OF_RANGE
     motion = PrescribedMotion(2, rest_positions(case), seed=4)
     drive_both(gpu, orc, motion, 0.01 * np.arange(220))
     # back to Baseline: raw kernel again

@@ -126,6 +126,7 @@ struct AheadPass {
     bool concurrent = false;             // it runs on the pass lane of the direct queue, beside the steps (ordered by signals)
     bool has_exc = false;                // it also leaves the excitation force of the next block's predicted times
     int Hcap = 0;                        // ring capacity of the history view (a re-allocated ring voids the view)
+    int head0 = 0, Hv = 0;               // newest stored slot when the view was taken, samples the view spans (incl. the virtual one)
     double t_first = 0.0, t_last = 0.0;  // predicted times of the next block's first and last step
     double rad_once = 0.0, exc_once = 0.0;
     BlockArgs args;                      // the whole launch; chunk_first / chunk_last are set per slice

@@ -180,6 +180,10 @@ void ahead_issue_slice(hc_ctx* c, hipStream_t stream, bool direct) {
     auto& ah = c->ahead;
     if (!ah.active || ah.reduced) return;
     if (ah.Hcap != c->Hcap || ah.plan_serial != c->plan_serial) { ahead_drop(c); return; }  // the ring was re-allocated under the view
+    // (defensive; ahead_begin has made the room: the samples pushed since the view was taken, and those the rest of the block will
+    // push while the slices run, stay clear of the oldest slot the view reads)
+    const int pushed = ((c->head - ah.head0) % c->Hcap + c->Hcap) % c->Hcap;
+    if (std::max(pushed, c->lookahead) + ah.Hv - 2 >= c->Hcap) { ahead_drop(c); return; }
     PassSetup ps;
     ps.b         = ah.args;
     // (buffers that may have been re-allocated since the view was taken are re-read; the ring's geometry has been checked above)
@@ -239,12 +243,26 @@ void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
     const long long chunks = (static_cast<long long>(probe.n_samples) * c->D / 8 + chunk_gp) / chunk_gp + 1;
     const size_t need = static_cast<size_t>(chunks) * L * c->Dpad;
     if (need > c->d_partials_block.n || need > c->d_partials_next.n || c->d_partials_far.n == 0) return;
+    // The view of the history this pass takes now (samples k = 0 .. Hv - 2 behind `head`) is read until its reduction, i.e. while
+    // up to L more steps push their samples into the slots after `head`: none of those slots may be one of the view's.  The ring
+    // is allocated with 64 slots beyond the IRF window, but a step below the IRF spacing fills them with kept samples (H up to
+    // Hcap before history_push grows the ring), so the room is made here when it is missing (rare: a re-allocation, like any grow).
+    {
+        const int H = static_cast<int>(c->times.size());
+        const int room_for = (H + 1) + L + 2;  // view (at most H + 1 samples incl. the virtual one) + the block's pushes + slack
+        if (c->Hcap < room_for) {
+            ring_grow(c, room_for, std::min(c->Hcap, H + static_cast<int>(c->retired.size())));
+            c->prof.ring_grows_for_pass += 1;
+        }
+    }
     const PassSetup ps = make_pass(c, with_exc, true);
     ah.args        = ps.b;
     ah.has_exc     = ps.exc_block;
     ah.rad_once    = ps.rad_once;
     ah.exc_once    = ps.exc_once;
     ah.Hcap        = c->Hcap;
+    ah.head0       = c->head;
+    ah.Hv          = ps.b.hist.H;
     ah.plan_serial = c->plan_serial;
     ah.t_first     = c->plan.tgrid[L + 1];
     ah.t_last      = c->plan.tgrid[2 * L];

@@ -317,6 +317,8 @@ typedef struct hc_profile_stats {
     long long ahead_pass_slices;   /* pass schedule "one block ahead": launches of passes of a NEXT block (counted in block_passes too) */
     long long ahead_blocks;        /* ... and blocks that started with their rows already there (no pass at block start) */
     long long pass_lane_launches;  /* passes / short passes dispatched to the pass lane of the direct queue (they run beside the steps) */
+    long long ring_grows_for_pass; /* times the history ring was re-allocated so that a pass one block ahead can read its view of the
+                                    * history while the block's steps push their samples (steps well below the IRF spacing) */
 } hc_profile_stats;
 /* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default), and around every
  * look-ahead pass (one per block) whatever the stride.  Event records perturb the launch stream by a few

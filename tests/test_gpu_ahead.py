@@ -339,3 +339,47 @@ def test_one_block_ahead_wide_system_and_row_shards(hydro, direct, monkeypatch):
         t += 0.01 if n != 150 else 0.0137
     p = full.profile()
     assert p["ahead_blocks"] >= 4 and p["mini_pass_launches"] >= 20, p
+
+
+@pytest.mark.parametrize("concurrent", ["1", "0"], ids=["pass-lane", "in-order"])
+@pytest.mark.parametrize("sub", [0, 8])
+def test_one_block_ahead_with_the_ring_nearly_full(hydro, sub, concurrent, monkeypatch):
+    """The pass one block ahead keeps reading its view of the history while the block's steps push new samples into the ring, so
+    the slots those pushes take must not belong to the view.  The ring is allocated with 64 slots beyond the IRF window; steps
+    3-6 % below the IRF spacing fill them with KEPT samples (the history grows to Hcap - 1 or - 2 without triggering a grow), and
+    a step-size change inside the window makes the older history non-uniform, so the bracket search of the pass falls back to
+    the binary search over ring_t -- the reads an overwritten slot would corrupt.  The library re-allocates the ring before it
+    takes such a view (ring_grows_for_pass); forces stay on the oracle throughout.  (With the guard disabled this small system
+    still passes the parity assertions -- its pass is one launch that ends long before the overwriting pushes arrive, and the
+    samples a next-block pass needs have aged past the overwritten ones unless the step shrank by more than L/(L - 3); the
+    guard is for wide systems whose pass is spread over the block.  What is pinned here: the room is made, and making it
+    mid-run -- a ring re-allocation under a running block -- leaves every force on the oracle.)"""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_SUB_BLOCK", str(sub))
+    monkeypatch.setenv("HC_PASS_CONCURRENT", concurrent)
+    N, S, dt_rirf = 4, 200, 0.01
+    case = many_body_case(N, S=S, dt_rirf=dt_rirf, n_exc=41, dt_exc=0.02, seed=91)
+    gpu, orc = hydro.HydroForces.from_case(case), load_into_oracle(case)
+    for h in (gpu, orc):
+        h.add_waves_none()
+    gpu.set_pass_schedule(1, 31)  # in-order mode: slice k goes out behind k pushes, the last slices read the oldest samples
+    cap0 = gpu.sizes()["Hcap"]
+    assert cap0 == S + 2 + 64
+    # steady H at step dt: (S - 1) * dt_rirf / dt + 2 (+ 1); aim two slots below the capacity
+    dt_b = (S - 1) * dt_rirf / (cap0 - 4.5)
+    dt_a = 1.5 * dt_b
+    motion = PrescribedMotion(N, rest_positions(case), seed=9)
+    t, worst, seen_tight = 0.0, 0.0, False
+    for n in range(900):
+        t += dt_a if n < 120 else dt_b  # the change lies inside the IRF window for the next ~260 steps
+        st = motion.state(t)
+        worst = max(worst, relerr(gpu.step(t, *st), orc.step(t, *st)))
+        assert worst <= TIGHT_TOL, f"step {n} (t = {t}, H = {gpu.sizes()['H']})"
+        sz = gpu.sizes()
+        seen_tight = seen_tight or (sz["Hcap"] == cap0 and sz["Hcap"] - sz["H"] < 32)
+    p, sz = gpu.profile(), gpu.sizes()
+    assert p["ahead_blocks"] >= 10, p
+    # either the history came within a block of the capacity and the library made room, or it grew earlier for the same reason
+    assert p["ring_grows_for_pass"] >= 1 and sz["Hcap"] > cap0, (p, sz, seen_tight)
+    assert p["history_rewinds"] == 0

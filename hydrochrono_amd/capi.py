@@ -42,7 +42,9 @@ class ProfileStats(C.Structure):
                 ("direct_dispatches", C.c_longlong), ("hip_launches", C.c_longlong), ("history_rewinds", C.c_longlong),
                 ("mini_pass_seconds", C.c_double), ("mini_pass_launches", C.c_longlong), ("queue_parkings", C.c_longlong),
                 ("ahead_pass_slices", C.c_longlong), ("ahead_blocks", C.c_longlong),
-                ("pass_lane_launches", C.c_longlong), ("ring_grows_for_pass", C.c_longlong)]
+                ("pass_lane_launches", C.c_longlong),
+                ("multi_doorbell_offset_last", C.c_double), ("multi_doorbell_offset_sum", C.c_double), ("multi_calls", C.c_longlong),
+                ("ring_grows_for_pass", C.c_longlong)]
 
 
 # name -> (restype, argtypes); every symbol include/hydrochrono_amd.h declares

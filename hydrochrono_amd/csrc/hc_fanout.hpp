@@ -1,0 +1,141 @@
+// hc_fanout.hpp -- the hand-off behind hc_step_multi / hc_added_mass_mv_multi: one persistent worker thread per shard context
+// beyond the first, so that ONE call of the host's time loop rings the doorbells of all G GPUs within one context's cost instead
+// of one after the other (5 us per C4/8 context: the 8th GPU used to start 40 us after the first, against a 20 us step).
+// Host only, no HIP dependency (unit-tested on CPU, under ThreadSanitizer too: tests/cpp/fanout_test.cpp).
+//
+// Protocol.  The caller publishes a job (function, argument, count n) and bumps `generation_` (release).  Worker w -- it serves
+// item w + 1; item 0 runs on the calling thread -- waits for a generation it has not seen: it spins with `pause` for `spin_us`
+// after its last job (a Chrono loop comes back within tens to hundreds of microseconds; a wake-up through the kernel would cost
+// more than the step), then sleeps on a condition variable.  It runs its item if it has one and stores the generation into its
+// `done` word (release); the caller, after its own item, spins until the `done` word of every worker shows the generation
+// (acquire).  Items must not throw.  One caller at a time: a second thread that finds the pool busy runs its items itself, in order.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#if defined(__x86_64__) || defined(__i386__)
+#include <immintrin.h>
+#define HC_FANOUT_PAUSE() _mm_pause()
+#else
+#define HC_FANOUT_PAUSE() std::this_thread::yield()
+#endif
+
+namespace hc {
+
+class FanOut {
+  public:
+    using Fn = void (*)(void* arg, int item);
+
+    explicit FanOut(int max_workers = 63, double spin_us = 1000.0) : max_workers_(max_workers), spin_us_(spin_us) {}
+    FanOut(const FanOut&)            = delete;
+    FanOut& operator=(const FanOut&) = delete;
+    ~FanOut() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_.store(true, std::memory_order_seq_cst);
+            generation_.fetch_add(1, std::memory_order_seq_cst);
+        }
+        cv_.notify_all();
+        for (auto& w : workers_)
+            if (w->th.joinable()) w->th.join();
+    }
+
+    // fn(arg, 0) on this thread, fn(arg, g) for g = 1 .. n - 1 on the workers, side by side; returns when all have returned.
+    void run(int n, Fn fn, void* arg) {
+        if (n <= 0) return;
+        bool expected = false;
+        if (n == 1 || max_workers_ <= 0 || !busy_.compare_exchange_strong(expected, true, std::memory_order_acquire)) {
+            for (int g = 0; g < n; ++g) fn(arg, g);  // nothing to share out, or another thread is using the pool
+            return;
+        }
+        const int helpers = std::min(n - 1, max_workers_);
+        ensure_workers(helpers);
+        fn_  = fn;
+        arg_ = arg;
+        n_   = helpers + 1;
+        const uint64_t gen = generation_.fetch_add(1, std::memory_order_seq_cst) + 1;
+        if (sleepers_.load(std::memory_order_seq_cst) > 0) {
+            { std::lock_guard<std::mutex> lk(m_); }  // a worker between its predicate check and its wait holds the mutex
+            cv_.notify_all();
+        }
+        fn(arg, 0);
+        for (int g = helpers + 1; g < n; ++g) fn(arg, g);  // (more items than workers allowed: the rest here)
+        // EVERY worker acknowledges every generation, also those without an item: a worker still looking at this job's fields while
+        // the next job is being published could otherwise run an item of that one twice
+        for (auto& w : workers_)
+            while (w->done.load(std::memory_order_acquire) != gen) HC_FANOUT_PAUSE();
+        busy_.store(false, std::memory_order_release);
+    }
+    template <class F>
+    void run(int n, F& f) {
+        run(n, [](void* a, int g) { (*static_cast<F*>(a))(g); }, &f);
+    }
+
+    int workers() const { return static_cast<int>(workers_.size()); }
+
+  private:
+    struct alignas(64) Worker {
+        std::thread th;
+        std::atomic<uint64_t> done{0};
+    };
+
+    void ensure_workers(int count) {
+        while (static_cast<int>(workers_.size()) < count) {
+            workers_.push_back(std::make_unique<Worker>());
+            Worker* w       = workers_.back().get();
+            const int index = static_cast<int>(workers_.size()) - 1;
+            // a new worker starts from the generation current NOW: the job that is about to be published is the first it sees
+            const uint64_t seen0 = generation_.load(std::memory_order_seq_cst);
+            w->done.store(seen0, std::memory_order_relaxed);
+            w->th = std::thread([this, w, index, seen0] { loop(w, index, seen0); });
+        }
+    }
+
+    void loop(Worker* w, int index, uint64_t seen) {
+        auto idle_since = std::chrono::steady_clock::now();
+        for (;;) {
+            // wait for a generation not seen yet: spin first, then sleep
+            uint64_t gen = generation_.load(std::memory_order_acquire);
+            unsigned spins = 0;
+            while (gen == seen) {
+                HC_FANOUT_PAUSE();
+                gen = generation_.load(std::memory_order_acquire);
+                if (gen != seen) break;
+                if ((++spins & 0x3FF) == 0 &&
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - idle_since).count() > spin_us_) {
+                    std::unique_lock<std::mutex> lk(m_);
+                    sleepers_.fetch_add(1, std::memory_order_seq_cst);
+                    cv_.wait(lk, [&] { return generation_.load(std::memory_order_seq_cst) != seen; });
+                    sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+                    gen = generation_.load(std::memory_order_acquire);
+                }
+            }
+            if (stop_.load(std::memory_order_seq_cst)) return;
+            seen = gen;
+            // the job fields were written before the generation was bumped (release / acquire through generation_)
+            if (index + 1 < n_) fn_(arg_, index + 1);
+            w->done.store(gen, std::memory_order_release);
+            idle_since = std::chrono::steady_clock::now();
+        }
+    }
+
+    const int max_workers_;
+    const double spin_us_;
+    std::vector<std::unique_ptr<Worker>> workers_;
+    std::atomic<uint64_t> generation_{0};
+    std::atomic<int> sleepers_{0};
+    std::atomic<bool> stop_{false}, busy_{false};
+    std::mutex m_;
+    std::condition_variable cv_;
+    Fn fn_     = nullptr;
+    void* arg_ = nullptr;
+    int n_     = 0;
+};
+
+}  // namespace hc

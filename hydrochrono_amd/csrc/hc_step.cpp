@@ -2,6 +2,7 @@
 // (enqueue_step / enqueue_tail), the synchronous step and its halves, the multi-context step, the device-resident step, the
 // term-only entry points, history access and the added-mass product.  All arithmetic runs in hc_kernels.hip on the GPU.
 #include "hc_internal.hpp"
+#include "hc_fanout.hpp"
 
 using namespace hc::detail;
 
@@ -703,6 +704,73 @@ void step_abort(hc_ctx* c) {
     c->pending_step = 0;
     c->tail.pending = false;
 }
+
+extern "C++" {
+// ---- several contexts in one call (hc_step_multi, hc_added_mass_mv_multi) ----------------------------------------
+// Worker threads of the fan-out (hc_fanout.hpp): HC_MULTI_THREADS = 0 keeps everything on the calling thread; HC_MULTI_SPIN_US is
+// how long an idle worker spins before it sleeps (default 1 ms: a Chrono loop comes back sooner).
+int multi_threads() {
+    static const int n = env_int("HC_MULTI_THREADS", 63);
+    return n;
+}
+hc::FanOut& fanout() {
+    static hc::FanOut pool(multi_threads(), static_cast<double>(env_int("HC_MULTI_SPIN_US", 1000)));
+    return pool;
+}
+// A worker thread serves the same context call after call and nobody else changes its current device, so it sets the device when
+// it changes only; the calling thread (item 0) shares its current device with every other entry point and sets it every time.
+void bind_device(const hc_ctx* c, int item) {
+    static thread_local int worker_device = -1;
+    if (item == 0) {
+        HC_HIP(hipSetDevice(c->device));
+    } else if (worker_device != c->device) {
+        HC_HIP(hipSetDevice(c->device));
+        worker_device = c->device;
+    }
+}
+// status and message per context; the first failure (in context order) is the call's, and every context of the group reports it
+struct MultiStatus {
+    std::vector<int> status;
+    std::vector<std::string> message;
+    explicit MultiStatus(int n) : status(static_cast<size_t>(n), HC_OK), message(static_cast<size_t>(n)) {}
+    template <class F, class A>
+    bool guarded(hc_ctx* c, int item, F&& fn, A&& on_failure) {
+        // (slot = the context's place in the call when run by the fan-out, found by its shard otherwise: failures are rare)
+        auto fail = [&](int code, const char* what) {
+            const size_t k = slot_of(c, item);
+            if (status[k] == HC_OK) { status[k] = code; message[k] = what; }
+            on_failure();
+            return false;
+        };
+        try {
+            bind_device(c, item);
+            fn();
+            return true;
+        } catch (const Error& e) {
+            return fail(e.status, e.what());
+        } catch (const std::out_of_range& e) {
+            return fail(HC_ERR_OUT_OF_RANGE, e.what());
+        } catch (const std::exception& e) {
+            return fail(HC_ERR_RUNTIME, e.what());
+        }
+    }
+    int finish(hc_ctx* const* ctxs, int n) const {
+        for (int g = 0; g < n; ++g)
+            if (status[static_cast<size_t>(g)] != HC_OK) {
+                for (int k = 0; k < n; ++k) ctxs[k]->err = message[static_cast<size_t>(g)];  // hc_last_error of any context of the group tells why
+                return status[static_cast<size_t>(g)];
+            }
+        return HC_OK;
+    }
+    std::vector<const hc_ctx*> order;  // serial path: contexts in call order
+    size_t slot_of(const hc_ctx* c, int item) {
+        if (item > 0) return static_cast<size_t>(item);
+        for (size_t k = 0; k < order.size(); ++k)
+            if (order[k] == c) return k;
+        return 0;
+    }
+};
+}  // extern "C++"
 }  // namespace
 
 int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel, double* force_out) {
@@ -812,38 +880,45 @@ int hc_step_multi(hc_ctx* const* ctxs, int n_ctx, double t, const double* pos, c
     if (!ctxs || n_ctx <= 0 || !force_out) return HC_ERR_INVALID;
     for (int g = 0; g < n_ctx; ++g)
         if (!ctxs[g]) return HC_ERR_INVALID;
-    int status = HC_OK;
-    std::string message;
-    auto guarded = [&](hc_ctx* c, auto&& fn) {
-        try {
-            HC_HIP(hipSetDevice(c->device));
-            fn();
-            return true;
-        } catch (const Error& e) {
-            if (status == HC_OK) { status = e.status; message = e.what(); }
-        } catch (const std::out_of_range& e) {
-            if (status == HC_OK) { status = HC_ERR_OUT_OF_RANGE; message = e.what(); }
-        } catch (const std::exception& e) {
-            if (status == HC_OK) { status = HC_ERR_RUNTIME; message = e.what(); }
-        }
-        step_abort(c);
-        return false;
+    MultiStatus st(n_ctx);
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto doorbell_rung = [t_entry](hc_ctx* c) {  // (the step kernel's packet is in its queue: hc_profile_stats::multi_doorbell_offset_*)
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count();
+        c->prof.multi_doorbell_offset_last = s;
+        c->prof.multi_doorbell_offset_sum += s;
+        c->prof.multi_calls += 1;
     };
+    if (n_ctx > 1 && multi_threads() > 0) {
+        // one thread per context (hc_fanout.hpp): every GPU gets its state and its step kernel at once, each thread then enqueues what
+        // later steps need on ITS context and collects ITS rows -- the last doorbell rings one context's cost after the call
+        auto item = [&](int g) {
+            hc_ctx* c = ctxs[g];
+            st.guarded(c, g, [&] {
+                require(c->N == ctxs[0]->N, HC_ERR_INVALID, "hc_step_multi: the contexts belong to different systems");
+                step_begin(c, t, pos, rpy, linvel, angvel, true);
+                doorbell_rung(c);
+                enqueue_tail(c);
+                step_end(c, force_out + static_cast<size_t>(6) * c->b0);
+            }, [&] { step_abort(c); });
+        };
+        fanout().run(n_ctx, item);
+        return st.finish(ctxs, n_ctx);
+    }
+    // one thread (HC_MULTI_THREADS=0): three phases, so that every GPU is working before the host does anything else
     std::vector<char> begun(static_cast<size_t>(n_ctx), 0);
     for (int g = 0; g < n_ctx; ++g) {
         hc_ctx* c = ctxs[g];
-        begun[g]  = guarded(c, [&] {
+        begun[g]  = st.guarded(c, 0, [&] {
             require(c->N == ctxs[0]->N, HC_ERR_INVALID, "hc_step_multi: the contexts belong to different systems");
             step_begin(c, t, pos, rpy, linvel, angvel, true);
-        });
+            doorbell_rung(c);
+        }, [&] { step_abort(c); });
     }
     for (int g = 0; g < n_ctx; ++g)
-        if (begun[g]) begun[g] = guarded(ctxs[g], [&] { enqueue_tail(ctxs[g]); });
+        if (begun[g]) begun[g] = st.guarded(ctxs[g], 0, [&] { enqueue_tail(ctxs[g]); }, [&] { step_abort(ctxs[g]); });
     for (int g = 0; g < n_ctx; ++g)
-        if (begun[g]) guarded(ctxs[g], [&] { step_end(ctxs[g], force_out + static_cast<size_t>(6) * ctxs[g]->b0); });
-    if (status != HC_OK)
-        for (int g = 0; g < n_ctx; ++g) ctxs[g]->err = message;  // hc_last_error of any context of the group tells why
-    return status;
+        if (begun[g]) st.guarded(ctxs[g], 0, [&] { step_end(ctxs[g], force_out + static_cast<size_t>(6) * ctxs[g]->b0); }, [&] { step_abort(ctxs[g]); });
+    return st.finish(ctxs, n_ctx);
 }
 
 int hc_step_device(hc_ctx* c, double t, const double* d_state, double* d_force_out, void* stream) {
@@ -1119,28 +1194,23 @@ int hc_added_mass_mv_multi(hc_ctx* const* ctxs, int n_ctx, const double* w, doub
     if (!ctxs || n_ctx <= 0) return HC_ERR_INVALID;
     for (int g = 0; g < n_ctx; ++g)
         if (!ctxs[g]) return HC_ERR_INVALID;
-    int status = HC_OK;
-    std::string message;
-    auto guarded = [&](hc_ctx* c, auto&& fn) {
-        try {
-            HC_HIP(hipSetDevice(c->device));
-            fn();
-            return true;
-        } catch (const Error& e) {
-            if (status == HC_OK) { status = e.status; message = e.what(); }
-        } catch (const std::exception& e) {
-            if (status == HC_OK) { status = HC_ERR_RUNTIME; message = e.what(); }
-        }
-        c->pending_am = 0;
-        return false;
-    };
+    MultiStatus st(n_ctx);
+    if (n_ctx > 1 && multi_threads() > 0) {
+        auto item = [&](int g) {
+            hc_ctx* c = ctxs[g];
+            st.guarded(c, g, [&] {
+                added_mass_begin(c, w, cc, R, n_sys);
+                added_mass_end(c, R);
+            }, [&] { c->pending_am = 0; });
+        };
+        fanout().run(n_ctx, item);
+        return st.finish(ctxs, n_ctx);
+    }
     std::vector<char> begun(static_cast<size_t>(n_ctx), 0);
-    for (int g = 0; g < n_ctx; ++g) begun[g] = guarded(ctxs[g], [&] { added_mass_begin(ctxs[g], w, cc, R, n_sys); });
+    for (int g = 0; g < n_ctx; ++g) begun[g] = st.guarded(ctxs[g], 0, [&] { added_mass_begin(ctxs[g], w, cc, R, n_sys); }, [&] { ctxs[g]->pending_am = 0; });
     for (int g = 0; g < n_ctx; ++g)
-        if (begun[g]) guarded(ctxs[g], [&] { added_mass_end(ctxs[g], R); });
-    if (status != HC_OK)
-        for (int g = 0; g < n_ctx; ++g) ctxs[g]->err = message;
-    return status;
+        if (begun[g]) st.guarded(ctxs[g], 0, [&] { added_mass_end(ctxs[g], R); }, [&] { ctxs[g]->pending_am = 0; });
+    return st.finish(ctxs, n_ctx);
 }
 
 }  // extern "C"

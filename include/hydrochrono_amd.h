@@ -317,6 +317,10 @@ typedef struct hc_profile_stats {
     long long ahead_pass_slices;   /* pass schedule "one block ahead": launches of passes of a NEXT block (counted in block_passes too) */
     long long ahead_blocks;        /* ... and blocks that started with their rows already there (no pass at block start) */
     long long pass_lane_launches;  /* passes / short passes dispatched to the pass lane of the direct queue (they run beside the steps) */
+    /* hc_step_multi: when this context's step kernel was handed to its GPU, measured from the entry of the call (seconds; the value
+     * of the last call, the sum over all calls and their number) -- the fan-out cost of a multi-GPU step as each GPU sees it */
+    double multi_doorbell_offset_last, multi_doorbell_offset_sum;
+    long long multi_calls;
     long long ring_grows_for_pass; /* times the history ring was re-allocated so that a pass one block ahead can read its view of the
                                     * history while the block's steps push their samples (steps well below the IRF spacing) */
 } hc_profile_stats;

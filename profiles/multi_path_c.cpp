@@ -64,6 +64,17 @@ static int run(int N, int S, int G, int reps, std::vector<double>* ref) {
     std::printf("N = %3d, S = %4d, G = %d contexts (%d with direct dispatch): hc_step_multi median %7.2f us  mean %7.2f  p10 %7.2f  p90 %7.2f | "
                 "hc_added_mass_mv_multi median %6.2f us | last forces %s the G = 1 run\n", N, S, G, direct, ts[ts.size() / 2], mean / ts.size(),
                 ts[ts.size() / 10], ts[ts.size() * 9 / 10], ta[ta.size() / 2], same ? "bitwise equal to" : "DIFFER from");
+    // when each context's step kernel was handed to its GPU, from the entry of hc_step_multi (mean over all calls): the fan-out
+    std::printf("        doorbell offsets from the entry of the call, per context (us):");
+    double worst = 0.0;
+    for (hc_ctx* c : ctxs) {
+        hc_profile_stats p;
+        hc_get_profile(c, &p);
+        const double m = p.multi_calls > 0 ? 1e6 * p.multi_doorbell_offset_sum / p.multi_calls : 0.0;
+        worst = std::max(worst, m);
+        std::printf(" %.2f", m);
+    }
+    std::printf("  -> last doorbell %.2f us after entry (HC_MULTI_THREADS=%s)\n", worst, std::getenv("HC_MULTI_THREADS") ? std::getenv("HC_MULTI_THREADS") : "default");
     for (hc_ctx* c : ctxs) hc_destroy(c);
     return same ? 0 : 1;
 }

@@ -1,0 +1,91 @@
+// CPU test of the hand-off behind hc_step_multi / hc_added_mass_mv_multi (hydrochrono_amd/csrc/hc_fanout.hpp, host only): every
+// item of every call runs exactly once, on the right thread, before the call returns -- through spinning and sleeping workers, calls
+// of changing width, a pool that grows, two threads that want the pool at once, and teardown with workers asleep / spinning.
+// Built with plain g++ (and with -fsanitize=thread by tests/test_fanout_cpu.py).
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <thread>
+#include <vector>
+
+#include "../../hydrochrono_amd/csrc/hc_fanout.hpp"
+
+static int failures = 0;
+#define CHECK(cond, ...)                          \
+    do {                                          \
+        if (!(cond)) {                            \
+            ++failures;                           \
+            std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+            std::printf(__VA_ARGS__);             \
+            std::printf("\n");                    \
+        }                                         \
+    } while (0)
+
+struct Job {
+    std::vector<long> count;        // plain (non-atomic) words, one per item: a lost hand-off or a double run shows as a wrong count
+    std::vector<std::thread::id> who;
+    long payload = 0;               // written by the caller before the call, read by every item (publication of the job)
+    std::vector<long> seen_payload;
+    explicit Job(int n) : count(n, 0), who(n), seen_payload(n, -1) {}
+};
+
+static void exercise(hc::FanOut& pool, int rounds, int max_n, int sleep_every, int sleep_us) {
+    const auto me = std::this_thread::get_id();
+    Job job(max_n);
+    std::vector<long> expect(max_n, 0);
+    for (int r = 0; r < rounds; ++r) {
+        const int n = 1 + (r * 7 + r / 3) % max_n;
+        job.payload = r;
+        auto item   = [&](int g) {
+            job.count[g] += 1;
+            job.who[g]          = std::this_thread::get_id();
+            job.seen_payload[g] = job.payload;
+        };
+        pool.run(n, item);
+        for (int g = 0; g < n; ++g) {
+            expect[g] += 1;
+            CHECK(job.count[g] == expect[g], "round %d item %d ran %ld times in all, expected %ld", r, g, job.count[g], expect[g]);
+            CHECK(job.seen_payload[g] == r, "round %d item %d saw the payload of round %ld", r, g, job.seen_payload[g]);
+        }
+        for (int g = n; g < max_n; ++g) CHECK(job.count[g] == expect[g], "round %d: item %d beyond the call's width ran", r, g);
+        CHECK(job.who[0] == me, "item 0 must run on the calling thread");
+        if (sleep_every > 0 && r % sleep_every == sleep_every - 1) std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));
+    }
+}
+
+int main() {
+    {   // spinning workers only (the spin budget is never used up)
+        hc::FanOut pool(63, 1e9);
+        exercise(pool, 20000, 8, 0, 0);
+        CHECK(pool.workers() == 7, "expected 7 workers, have %d", pool.workers());
+    }
+    {   // workers that fall asleep between calls (50 us of spinning, pauses of 300 us every few calls)
+        hc::FanOut pool(63, 50.0);
+        exercise(pool, 600, 6, 3, 300);
+    }
+    {   // fewer workers than items: the surplus runs on the caller
+        hc::FanOut pool(2, 200.0);
+        exercise(pool, 3000, 7, 0, 0);
+        CHECK(pool.workers() <= 2, "the pool grew beyond its limit");
+    }
+    {   // no workers at all
+        hc::FanOut pool(0, 200.0);
+        exercise(pool, 100, 5, 0, 0);
+        CHECK(pool.workers() == 0, "a pool of zero workers created one");
+    }
+    {   // two threads want the pool at once: whoever finds it busy runs its items itself
+        hc::FanOut pool(63, 200.0);
+        std::thread other([&] { exercise(pool, 4000, 5, 0, 0); });
+        exercise(pool, 4000, 4, 0, 0);
+        other.join();
+    }
+    {   // teardown right after a call (workers spinning) and after a pause (workers asleep)
+        for (int k = 0; k < 20; ++k) {
+            hc::FanOut pool(63, 30.0);
+            exercise(pool, 5, 4, 0, 0);
+            if (k % 2) std::this_thread::sleep_for(std::chrono::microseconds(400));
+        }
+    }
+    std::printf("fanout_test: %d failures\n", failures);
+    return failures ? 1 : 0;
+}

@@ -52,6 +52,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# rocprofv3 --kernel-trace --stats of this very command (python bench.py --gpus 1 --steps 20 --warmup 5 --no-c4-share --no-c4-one-gpu, so that
+# the pass kernel's row holds C3 launches only): roofline.frac = algorithmic_bytes_per_launch / its AverageNs / 8 TB/s
+ROOFLINE_PROFILE = "profiles/r04/c3_driver_cmd_kernel_stats.csv (rocprofv3 --kernel-trace --stats; the PMC passes behind roofline.traffic: profiles/r04/pmc_traffic.json)"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 FP64_MFMA_PEAK_TF = 78.6
 
@@ -80,6 +83,7 @@ def parse():
     ap.add_argument("--steady-steps", type=int, default=256, help="synchronous steps of the steady_state block (median + mean, SURVEY 8d: >= 200)")
     ap.add_argument("--single-process", action="store_true", help="N > 1: all shards in THIS process through hc_step_multi (no launcher needed)")
     ap.add_argument("--no-c4-share", action="store_true", help="skip the c4_rank_share secondary (one C4/8 shard on this GPU)")
+    ap.add_argument("--no-c4-one-gpu", action="store_true", help="skip the c4_one_gpu secondary (the whole 512-body array, 77 GB of K, on this GPU)")
     ap.add_argument("--exchange", choices=["host", "rccl"], default="host",
                     help="N > 1 under a launcher: how every rank gets all force rows each step.  host (default): hc_step on every rank (direct "
                          "dispatch, results on the host) and a host gather through shared-memory result buffers (hc_set_result_buffer); "
@@ -314,6 +318,73 @@ def c4_rank_share(sdt, lookahead):
     return out
 
 
+C4_ONE_GPU_FILES = ("profiles/r04/bench_c4_1gpu.json", "profiles/r03/bench_c4_1gpu.json")
+
+
+def c4_one_gpu_reference():
+    """The C4 workload (ONE coupled 512-body array) on ONE MI355X, from the committed measurement: the denominator of a strong-scaling
+    ratio for the N > 1 lines (the N = 1 line of this benchmark is C3, BASELINE.json's metric, and carries the same figure live as
+    `c4_one_gpu`)."""
+    for rel in C4_ONE_GPU_FILES:
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            try:
+                rj = json.load(open(path))
+                sec = rj.get("c4_one_gpu") or rj
+                v = sec.get("evals_per_s", sec.get("value"))
+                if v:
+                    return {"evals_per_s": float(v), "ms_per_step": float(sec["ms_per_step"]), "workload": "C4",
+                            "measured": f"{rel} (one MI355X, the same generator and step loop; committed, not measured in this run)"}
+            except Exception:
+                continue
+    return None
+
+
+def c4_one_gpu(sdt, lookahead):
+    """C4 -- the whole coupled 512-body array (K = 77.3 GB, generated in HBM) -- on THIS GPU: synchronous hc_step, so that the N > 1
+    lines of this benchmark (the same array row-sharded over N GPUs) have a one-GPU figure of the SAME workload to be divided by."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    N, warm, steps = N_BODIES_C4, 40, 96
+    motion = PrescribedMotion(N, np.zeros((N, 3)), seed=20251031)
+    nhist = int(np.ceil(S_RIRF * DT / sdt)) + 5
+    t_hist = T0 - sdt * np.arange(1, nhist + 1)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    n_all = warm + steps
+    gpu = make_shard(N, 0, N, 0, sdt, T0 + (n_all + 8) * sdt + 5.0, lookahead, t_hist, v_hist)
+    times = [T0 + k * sdt for k in range(n_all)]
+    states = [motion.state(t) for t in times]
+    gpu.enable_profiling(1)
+    for k in range(warm):
+        gpu.step(times[k], *states[k])
+    gpu.reset_profile()
+    per = np.zeros(steps)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        a = time.perf_counter()
+        gpu.step(times[warm + i], *states[warm + i])
+        per[i] = time.perf_counter() - a
+    elapsed = time.perf_counter() - t0
+    p = gpu.profile()
+    launches = max(1, p["block_kernel_launches"])
+    # a pass one block ahead goes out in slices: per block = seconds of all its launches
+    pass_s_per_block = p["block_kernel_seconds"] / max(1.0, steps / float(lookahead))
+    once_per_block = 8.0 * (6.0 * N) * (6.0 * N) * S_RIRF
+    out = {"workload": f"C4: ONE coupled synthetic {N}-body array (D = {6 * N}, K = {once_per_block / 1e9:.1f} GB FP64) on one GPU, synchronous "
+                       f"hc_step through the Python wrapper, {steps} steps after {warm}",
+           "evals_per_s": steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "median_ms_per_step": float(np.median(per)) * 1e3,
+           "max_ms_per_step": float(per.max()) * 1e3, "steps": steps, "lookahead": lookahead,
+           "pass_schedule": "one block ahead (slices on the pass lane)" if p["ahead_blocks"] > 0 else "at block start",
+           "pass_launches": int(p["block_kernel_launches"]), "pass_us_per_launch": 1e6 * p["block_kernel_seconds"] / launches,
+           "pass_ms_per_block": pass_s_per_block * 1e3,
+           "pass_frac_of_hbm_peak": (p["block_kernel_bytes_once"] / (p["block_kernel_seconds"] / launches) / 1e9 / HBM_PEAK_GBS) if p["block_kernel_seconds"] > 0 else None,
+           "per_step_us": {"pass": p["block_kernel_seconds"] / steps * 1e6, "short_passes": p["mini_pass_seconds"] / steps * 1e6,
+                           "scatter": p["scatter_kernel_seconds"] / steps * 1e6, "step_kernels": p["step_kernel_seconds"] / steps * 1e6},
+           "note": "the one-GPU figure of the workload the --gpus N > 1 lines shard (their c4_one_gpu_reference / speedup_vs_c4_one_gpu)"}
+    out.update(dispatch_info([gpu]))
+    gpu.close()
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -355,6 +426,12 @@ def main():
                           "sharding": "body-row shards, single process, host gather (SURVEY 8e drop-in variant)"},
                "single_process": info}
         out.update({k: info[k] for k in ("dispatch_mode", "dispatch_mode_reason")})
+        if args.bodies == N_BODIES_C4:
+            out["workload"] = "C4"
+            ref1 = c4_one_gpu_reference()
+            if ref1:
+                out["c4_one_gpu_reference"] = ref1
+                out["speedup_vs_c4_one_gpu"] = out["value"] / ref1["evals_per_s"]
         if ndev < G:
             out["note"] = f"only {ndev} GPU(s) visible: contexts share devices (functional run, not a scaling figure)"
         print(json.dumps(out), flush=True)
@@ -404,7 +481,7 @@ def main():
         align = boundary - first
     pre = align + args.warmup
     total = pre + args.steps
-    n_all = total + n_steady + ((4 * 128 + 72) if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
+    n_all = total + n_steady + ((4 * 128 + 72 + 3) if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
     duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
     gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
@@ -615,7 +692,13 @@ def main():
         chrono_like["with_30us_of_host_work"] = short_gap
         gpu.set_pass_schedule(0)
     if n_pipe > 0:
-        # hc_step_device, states resident in HBM, every step enqueued without waiting for the previous one's forces
+        # hc_step_device, states resident in HBM, every step enqueued without waiting for the previous one's forces.
+        # Run-in (untimed): the change of pass schedule above dropped the look-ahead plan, so the next step is a PLAIN one (all of K
+        # streamed: 190 us) followed by a pass -- 380 us that a 20-step loop would carry as 19 us per step (BENCH_r03: 26 k evals/s
+        # against 60 k in BENCH_r02, which had no schedule change in front of this loop).
+        if n_steady > 0:
+            run_sync(k_next, k_next + 3)
+            k_next += 3
         d_states = torch.tensor(states[k_next:k_next + n_pipe], device="cuda")
         d_out = torch.zeros(n_pipe, D_local, dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
@@ -731,10 +814,11 @@ def main():
             "p10_ms_per_step": float(np.percentile(timed, 10)),
             "p90_ms_per_step": float(np.percentile(timed, 90)),
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": args.scaling if (world > 1 or strong) else "n/a (C3 headline: one GPU, BASELINE.json's metric; the multi-GPU lines shard C4, see c4_one_gpu)",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "workload": "C4" if (strong and N == N_BODIES_C4) else ("C3" if N == N_BODIES else f"{N} bodies"),
             "config": {
                 "workload": (f"C4-style: ONE coupled synthetic {N}-body array row-sharded over {world} GPU(s), " if strong else
                              f"C3: synthetic {N}-body array per GPU, ") +
@@ -759,6 +843,7 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_once, "units_per_launch": units,
                 "reuse_factor": bytes_units / bytes_once if bytes_once else None,
                 "algorithmic_bytes_of_the_units": bytes_units,
+                "profile_file": ROOFLINE_PROFILE if (N == N_BODIES and not strong) else None,
                 "mean_kernel_us": conv_s * 1e6, "launches_timed": n_timed,
                 "timed_region_kernel_us": conv_s_region * 1e6, "timed_region_launches": n_region,
                 "step_kernel_us": us(prof_all["step_kernel_seconds"], prof_all["step_kernel_launches"]),
@@ -791,6 +876,12 @@ def main():
                 out["c4_rank_share"] = c4_rank_share(sdt, args.lookahead if args.lookahead > 0 else 32)
             except Exception as e:  # a secondary must not cost the run its line
                 out["c4_rank_share"] = {"error": str(e)}
+        if world == 1 and not strong and not args.no_secondary and not args.no_c4_one_gpu:
+            try:
+                gpu.close()
+                out["c4_one_gpu"] = c4_one_gpu(sdt, args.lookahead if args.lookahead > 0 else 32)
+            except Exception as e:  # a secondary must not cost the run its line
+                out["c4_one_gpu"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and case is not None:
             base, f_faithful, flat_threads = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds, sdt, duration)
             n_chk = k_next
@@ -812,17 +903,15 @@ def main():
         elif exchange is not None:
             out["gathered_rows_finite"] = bool(torch.isfinite(gathered[pre:total]).all().item())
             out["exchange_check"] = exchange_ok
-        if strong:
-            # the same coupled array on ONE GPU (committed measurement), so that a strong-scaling ratio can be formed: the N = 1
-            # line of this benchmark is the C3 case (BASELINE.json's metric), not this workload
-            ref = os.path.join(ROOT, "profiles", "r03", "bench_c4_1gpu.json")
-            if os.path.exists(ref) and N == N_BODIES_C4:
-                try:
-                    rj = json.load(open(ref))
-                    out["same_workload_on_one_gpu"] = {"evals_per_s": rj["value"], "ms_per_step": rj["ms_per_step"],
-                                                       "source": "profiles/r03/bench_c4_1gpu.json (bench.py --scaling strong --bodies 512 on one MI355X)"}
-                except Exception:
-                    pass
+        if strong and N == N_BODIES_C4:
+            # the same coupled array on ONE GPU, so that a strong-scaling ratio can be formed from this line alone: the N = 1 line of
+            # this benchmark is the C3 case (BASELINE.json's metric) and carries this workload as its `c4_one_gpu` secondary
+            ref1 = c4_one_gpu_reference()
+            if ref1 and world > 1:
+                out["c4_one_gpu_reference"] = ref1
+                out["speedup_vs_c4_one_gpu"] = out["value"] / ref1["evals_per_s"]
+            if share_gpu:
+                out["note"] = "HC_BENCH_SHARE_GPU=1: all ranks on ONE device, rows moved over gloo -- a functional run, not a scaling figure"
         print(json.dumps(out), flush=True)
     if hx is not None:
         dist.barrier()

@@ -494,6 +494,49 @@ def test_step_device_matches_host_step(HF):
     assert np.array_equal(out.cpu().numpy(), host)
 
 
+def test_pipelined_device_steps_launch_budget(HF):
+    """hc_step_device inside an established look-ahead plan costs a fixed number of launches: per step the step kernel and the
+    scatter of its sample (+ the memcpy-free result), per 32 steps one pass and its reduction -- and NO plain step (one launch that
+    streams all of K).  BENCH_r02 -> r03 showed how this drifts silently: a schedule change in front of the bench's 20-step
+    pipelined loop dropped the plan, the loop then began with a plain step + a pass (380 us at C3) and reported 26 k instead of
+    60 k evals/s.  What such a reset costs is asserted here too."""
+    import torch
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    case = many_body_case(4, S=128, n_exc=33, seed=43)
+    h = HF.from_case(case)
+    h.add_waves_none()
+    h.set_pass_schedule(0)
+    h.enable_profiling(1)  # (the per-kernel launch counters are filled from the timed launches)
+    motion = PrescribedMotion(4, rest_positions(case), seed=8)
+    nsteps = 3 * 32 + 160
+    states = torch.tensor(np.stack([motion.packed(0.01 * n) for n in range(nsteps)]), device="cuda")
+    out = torch.zeros(nsteps, 24, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def run(n0, n1):
+        for n in range(n0, n1):
+            h.step_device(0.01 * n, states[n].data_ptr(), out[n].data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+    run(0, 160)  # history longer than the IRF window, plan established
+    p0 = h.profile()
+    run(160, 160 + 64)  # two whole blocks
+    p1 = h.profile()
+    d = {k: p1[k] - p0[k] for k in ("hip_launches", "direct_dispatches", "conv_kernel_launches", "block_kernel_launches", "scatter_kernel_launches")}
+    assert d["direct_dispatches"] == 0           # a caller's stream: HIP launches (DESIGN 3.4)
+    assert d["conv_kernel_launches"] == 0, d     # no plain step inside the plan
+    assert d["block_kernel_launches"] == 2, d    # one pass per block
+    # step kernel + scatter per step, pass + reduction per block
+    assert 64 <= d["hip_launches"] <= 2 * 64 + 2 * 2, d
+    # ... and what a plan reset costs the next steps: ONE plain step, then a pass, then block steps again
+    h.set_pass_schedule(0)
+    p0 = h.profile()
+    run(160 + 64, 160 + 64 + 20)
+    p1 = h.profile()
+    assert p1["conv_kernel_launches"] - p0["conv_kernel_launches"] == 1 and p1["block_kernel_launches"] - p0["block_kernel_launches"] == 1
+
+
 def test_per_time_cache_is_shared_by_host_and_device_steps(HF):
     """One evaluation per distinct time (src/hydro_forces.cpp:742-744) whichever of hc_step / hc_step_device asks first."""
     import torch

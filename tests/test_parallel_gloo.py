@@ -231,3 +231,83 @@ def test_host_gather_through_shared_memory_two_ranks_one_gpu(N):
     res = dict(ret)
     assert res[0][0] and res[1][0]
     assert res[0][1] <= 1e-10
+
+
+# ------------------------------------------------------------------------------------------------
+# The device path of `bench.py --exchange rccl` with TWO ranks.  RCCL refuses two ranks on one device, and the box has one, so the
+# collective itself runs over gloo here; everything in front of it is the real thing: hc_step_device of a row-sharded context on a
+# CALLER'S stream, the consumer of the rows (what the all-gather is on an 8-GPU node) enqueued on the SAME stream right behind the
+# step kernel, and the next step enqueued BEFORE the host has waited for this one -- the order of bench.py's run_sync_rccl plus one
+# step of run-ahead, which is what would expose a step kernel, a scatter or a pass (they move to the context's own stream behind an
+# event, hc_step.cpp: enqueue_tail / to_background) that reads a ring slot or a result row another stream still writes.
+# RCCL with more than one rank has not run anywhere yet.
+# ------------------------------------------------------------------------------------------------
+def _dev_order_worker(rank, world, port, N, steps, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        if here not in sys.path:
+            sys.path.insert(0, here)
+        from cases import load_into_oracle
+        from hydrochrono_amd.hydro import HydroForces
+        from hydrochrono_amd.mock_chrono import PrescribedMotion
+        from hydrochrono_amd.synthetic import many_body_case, rest_positions
+        torch.cuda.set_device(0)
+        case = many_body_case(N, S=96, dt_rirf=0.01, n_exc=65, dt_exc=0.02, seed=4400 + N)
+        kw = dict(simulation_dt=0.01, simulation_duration=4.0, ramp_duration=0.5, wave_height=2.0, wave_period=6.0,
+                  frequency_min=0.05, frequency_max=0.6, nfrequencies=48, peak_enhancement_factor=3.3)
+        b0, b1 = body_shard(N, world, rank)
+        mine = HydroForces.from_case(case, device=0, body_range=(b0, b1))
+        mine.add_waves_irregular(**kw)
+        ex = ForceExchange(N, world, rank, device="cpu")
+        motion = PrescribedMotion(N, rest_positions(case), seed=5)
+        states = torch.tensor(np.stack([motion.packed(0.01 * n) for n in range(steps)]), device="cuda")
+        rows = torch.zeros(steps, ex.max_rows, dtype=torch.float64, device="cuda")       # where the step kernels write
+        landed = torch.zeros(steps, ex.max_rows, dtype=torch.float64).pin_memory()      # where the stream-ordered consumer leaves them
+        events = [torch.cuda.Event() for _ in range(steps)]
+        stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+
+        def enqueue(n):
+            mine.step_device(0.01 * n, states[n].data_ptr(), rows[n].data_ptr(), stream.cuda_stream)
+            with torch.cuda.stream(stream):
+                landed[n].copy_(rows[n], non_blocking=True)  # same stream, right behind the step kernel: the all-gather's place
+                events[n].record(stream)
+
+        full = orc = None
+        if rank == 0:
+            full = HydroForces.from_case(case, device=0)
+            full.add_waves_irregular(**kw)
+            orc = load_into_oracle(case)
+            orc.add_waves_irregular(**kw)
+        ok, worst = True, 0.0
+        enqueue(0)
+        for n in range(steps):
+            if n + 1 < steps:
+                enqueue(n + 1)          # one step of run-ahead: step n + 1 is in flight while step n's rows are collected
+            events[n].synchronize()
+            gathered = ex.gather(landed[n, : ex.rows]).numpy().copy()
+            if rank == 0:
+                st = motion.state(0.01 * n)
+                ok &= bool(np.array_equal(gathered, full.step(0.01 * n, *st)))
+                fo = orc.step(0.01 * n, *st)
+                worst = max(worst, float(np.max(np.abs(gathered - fo)) / np.max(np.abs(fo))))
+        p = mine.profile()
+        ok &= p["hip_launches"] > steps and p["direct_dispatches"] == 0  # the device path: HIP launches on the caller's stream
+        ret[rank] = (bool(ok), worst)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [6, 5])  # even and uneven shards
+def test_device_path_ordering_two_ranks_one_gpu(N):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dev_order_worker, args=(world, _free_port(), N, 140, ret), nprocs=world, join=True)
+    res = dict(ret)
+    assert res[0][0] and res[1][0]
+    assert res[0][1] <= 1e-10

@@ -168,7 +168,7 @@ struct hc_ctx {
     bool direct_ready   = false;
     std::string direct_why;  // why the direct path is not in use
     int path            = 0;
-    hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_mini16, dk_mini32, dk_added_mass, dk_step, dk_near;
+    hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_mini16, dk_mini32, dk_narrow, dk_added_mass, dk_step, dk_near;
     hc::StepTail tail;
     // split step (hc_step_begin / hc_step_end, hc_step_multi): 0 nothing begun, 1 the begun step was a cache hit (totals in
     // last_total), 2 its results arrive as tagged granules with sequence number `seq`
@@ -241,6 +241,7 @@ struct hc_ctx {
     hc::DeviceBuffer<double> d_zero_state;  // 12N zeros: the not-yet-known sample of the look-ahead pass
     int chunk_gp_ex_block = 32, nchunks_ex_block = 0;  // excitation chunks of the look-ahead launch
     int mt_mini = 2;                                    // row tiles per workgroup of the short passes (two-level form)
+    int mt_narrow = 2;                                  // ... of their narrow form (16 step columns)
     int mt_block = 4, mt_block_design = 6;              // row tiles per workgroup of the look-ahead launch (1, 2, 4, 6 or 12)
     int num_cus  = 256;                                 // compute units of the device (grid rounds of the look-ahead launch)
     int lookahead = 0;  // 0: off, else kLookahead

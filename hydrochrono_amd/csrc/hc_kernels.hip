@@ -479,12 +479,13 @@ __device__ __forceinline__ void block_exc_work(const BlockArgs& a, const int grp
 // the sub-block that has just ended count, and their times are the plan's predicted grid times handed over in the argument block
 // (mini_bracket, hc_limits.hpp -- the host-side planner test runs the same function).  No ring_t reads at all.
 template <int L, bool BYTES>
-__device__ __forceinline__ void build_mini_table(const BlockArgs& a, const int s0, const int ns, const int s_live, double* t_wo, double* t_wn,
-                                                 int* t_oo, int* t_on) {
+__device__ __forceinline__ void build_mini_table(const BlockArgs& a, const int chunk, const int s0, const int ns, const int s_live, double* t_wo,
+                                                 double* t_wn, int* t_oo, int* t_on) {
     const HistoryView& h = a.hist;
-    const int n = ns * L;
+    const int n  = ns * L;
+    const int jb = a.mini_narrow ? (int)a.mini_jbase[chunk] : 0;  // narrow form: column jj of this chunk is step jb + jj
     for (int idx = threadIdx.x; idx < n; idx += kConvThreads) {
-        const int k = idx / L, j = idx - k * L, s = s0 + k;
+        const int k = idx / L, j = jb + (idx - k * L), s = s0 + k;
         double wo = 0.0, wn = 0.0;
         int lo = 0;
         if (j < a.mini_steps && s >= a.s_cut[j] && s != a.s_defer[j] && s < s_live) {
@@ -508,10 +509,10 @@ __device__ __forceinline__ void build_mini_table(const BlockArgs& a, const int s
 }
 
 template <int L, bool BYTES>
-__device__ __forceinline__ void build_block_table(const BlockArgs& a, const int s0, const int ns, const int s_live, double* t_wo, double* t_wn,
-                                                  int* t_oo, int* t_on) {
+__device__ __forceinline__ void build_block_table(const BlockArgs& a, const int chunk, const int s0, const int ns, const int s_live, double* t_wo,
+                                                  double* t_wn, int* t_oo, int* t_on) {
     if (a.mini_kw > 0) {
-        build_mini_table<L, BYTES>(a, s0, ns, s_live, t_wo, t_wn, t_oo, t_on);
+        build_mini_table<L, BYTES>(a, chunk, s0, ns, s_live, t_wo, t_wn, t_oo, t_on);
         return;
     }
     constexpr int NE = 3;
@@ -573,7 +574,7 @@ __device__ __forceinline__ void block_rad_stream(const BlockArgs& a, const int c
     const int s0  = (gp0 * 8) / D;
     const int ns  = (min(a.F, gp1 * 8) - 1) / D - s0 + 1;
     const int s_live = a.F / D;  // F is a whole number of samples
-    build_block_table<L, false>(a, s0, ns, s_live, t_wo, t_wn, t_oo, t_on);
+    build_block_table<L, false>(a, chunk, s0, ns, s_live, t_wo, t_wn, t_oo, t_on);
     __syncthreads();
 
     dvec4 acc[NB][MT];
@@ -741,8 +742,6 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
     const int ns  = (min(a.F, gp1 * 8) - 1) / D - s0 + 1;
     const int s_live = a.F / D;
     const int Hc     = a.hist.HcapT;  // row length of the per-DoF ring
-    build_block_table<L, true>(a, s0, ns, s_live, t_wo, t_wn, t_oo, t_on);  // t_oo: byte offset of the older sample in a ring row; the newer one (slot + 1 mod Hcap, or the not-yet-known sample, whose weight is 0) follows it
-    __syncthreads();
 
     dvec4 acc[NB][MT];
 #pragma unroll
@@ -757,6 +756,9 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
 
     dvec2 kv[R][MT];
     dvec2u von[R][2][NB];  // {older, newer} sample of the bracket: adjacent entries of the lane's column (the ring row is mirrored past its end)
+
+    build_block_table<L, true>(a, chunk, s0, ns, s_live, t_wo, t_wn, t_oo, t_on);  // t_oo: byte offset of the older sample in a ring row; the newer one (slot + 1 mod Hcap, or the not-yet-known sample, whose weight is 0) follows it
+    __syncthreads();
 
     // ---- issue side ----
     int gp_i = gp0 + wave;
@@ -992,12 +994,29 @@ __global__ void __launch_bounds__(256) reduce_block_kernel(ReduceArgs a) {
     const int first = exc ? a.nchunks_rad : a.rad_first, count = exc ? a.nchunks_ex : a.nchunks_rad - a.rad_first;
     const int o     = out < n ? out : 0;
     double v = 0.0;
-    for (int c = sub; c < count; c += 8 * 16) {
-        double w[8];
+    if (a.narrow) {
+        // narrow short pass: chunk c holds [16][Dpad] partials of steps jbase[c] .. jbase[c] + 15; the chunks that do not hold this
+        // output's step add 0.0, as they do in the wide form -- same lanes, same order, bitwise the wide form's sum
+        const int j = o / a.Dpad, row = o - j * a.Dpad;
+        for (int c = sub; c < count; c += 8 * 16) {
+            double w[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] = (c + 16 * k) < count ? partials[(size_t)(first + c + 16 * k) * n + o] : 0.0;
+            for (int k = 0; k < 8; ++k) {
+                const int cc = first + c + 16 * k;
+                const int jj = (c + 16 * k) < count ? j - (int)a.jbase[cc] : -1;
+                w[k]         = (jj >= 0 && jj < 16) ? partials[((size_t)cc * 16 + jj) * a.Dpad + row] : 0.0;
+            }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v += w[k];
+            for (int k = 0; k < 8; ++k) v += w[k];
+        }
+    } else {
+        for (int c = sub; c < count; c += 8 * 16) {
+            double w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = (c + 16 * k) < count ? partials[(size_t)(first + c + 16 * k) * n + o] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += w[k];
+        }
     }
     v = lane16_sum(v);
     if (out < n && sub == 0) {
@@ -1286,6 +1305,21 @@ __global__ void __launch_bounds__(256) near_split_kernel(NearArgs a) {
     const int rt = (int)blockIdx.x / a.n_slices, sl = (int)blockIdx.x - rt * a.n_slices;
     const int D = a.D, W = 8 * a.gps_per_slice;
     const double* __restrict__ kbase = a.K.base + ((size_t)rt * a.K.ngp) * 128 + lane * 2;
+    // the K words of the first near sample (13 column groups per wave at 384-column slices) are requested before the right-hand side is
+    // staged: the kernel is on the critical path of every block step of a wide system, and its two memory round trips then overlap
+    constexpr int PRE = 13;
+    dvec2 pre[PRE];
+    int pg0 = 0, pg1 = 0;
+    if (a.n_near > 0) {
+        const int f0 = a.near[0].s * D, f1 = f0 + D;
+        pg0 = (f0 >> 3) + sl * a.gps_per_slice;
+        pg1 = min((f1 + 7) >> 3, pg0 + a.gps_per_slice);
+    }
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+        const int gp = pg0 + wave + 4 * q;
+        pre[q] = gp < pg1 ? *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128) : dvec2{0.0, 0.0};
+    }
     // stage u for the slice's columns of every near sample (columns outside the sample -> 0)
     for (int e = 0; e < a.n_near; ++e) {
         const NearEntry& ne = a.near[e];
@@ -1309,8 +1343,18 @@ __global__ void __launch_bounds__(256) near_split_kernel(NearArgs a) {
         const int f0 = a.near[e].s * D, f1 = f0 + D;
         const int g0 = (f0 >> 3) + sl * a.gps_per_slice, g1 = min((f1 + 7) >> 3, g0 + a.gps_per_slice);
         const double* __restrict__ u = U + e * W - g0 * 8;
+        int gp = g0 + wave;
+        if (e == 0) {
+#pragma unroll
+            for (int q = 0; q < PRE; ++q, gp += 4) {
+                if (gp < g1) {
+                    acc = fma(pre[q].x, u[gp * 8 + kk], acc);
+                    acc = fma(pre[q].y, u[gp * 8 + 4 + kk], acc);
+                }
+            }
+        }
 #pragma unroll 4
-        for (int gp = g0 + wave; gp < g1; gp += 4) {
+        for (; gp < g1; gp += 4) {
             const dvec2 kv = *reinterpret_cast<const dvec2*>(kbase + (size_t)gp * 128);
             acc = fma(kv.x, u[gp * 8 + kk], acc);
             acc = fma(kv.y, u[gp * 8 + 4 + kk], acc);
@@ -1360,7 +1404,7 @@ __global__ void __launch_bounds__(256) scatter_kernel(ScatterArgs a) {
     const int f0 = s * D, f1 = f0 + D;
     const int g0 = (f0 >> 3) + sl * a.gps_per_slice, g1 = min((f1 + 7) >> 3, g0 + a.gps_per_slice);
     const double* __restrict__ kbase = a.K.base + ((size_t)rt * a.K.ngp) * 128 + lane * 2;
-    constexpr int PRE = 4;
+    constexpr int PRE = 4;  // (all 13 column groups of a 384-column slice up front, or the vector straight from L2 without the LDS staging: 10.0-10.3 us against 9.4-9.6 at C4/8, round 4)
     dvec2 pre[PRE];
 #pragma unroll
     for (int q = 0; q < PRE; ++q) {

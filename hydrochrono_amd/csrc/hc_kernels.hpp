@@ -146,6 +146,13 @@ struct BlockArgs {
     // block starts at the first IRF sample it needs.  Partials are indexed by the absolute chunk number either way, so the sums
     // reduce_block_kernel forms do not depend on how the chunks were spread over launches.
     int chunk_first, chunk_last;
+    // NARROW short pass (mini_narrow != 0; depth == 16): the sub-block's kw samples reach, through ONE IRF sample, a window of only
+    // kw + 2 consecutive block steps, so a chunk (half an IRF sample) needs 16 step columns, not 32 -- the 16 columns of chunk c are the
+    // steps mini_jbase[c] .. mini_jbase[c] + 15 (of the pass's own step numbering, index into tpred / s_cut / s_defer), and its
+    // partials are [chunk][16][Dpad]; reduce_block_kernel adds them to the rows they belong to.  Half the matrix work, the
+    // B-operand gathers and the partials of the wide form, and the 16-step kernel (two or three waves per SIMD instead of one).
+    int mini_narrow;
+    unsigned char mini_jbase[kMiniChunks];
 };
 
 // near_split_kernel (wide systems): the step's own-sample part  K[rows of a tile, columns of the near samples] x u  split over
@@ -258,8 +265,11 @@ struct ReduceArgs {
     int* item_counter;
     int accumulate, j_off, j_cnt;
     int rad_first;  // first radiation chunk to add (short passes that start past IRF sample 0)
+    // narrow short pass (BlockArgs::mini_narrow): the partials of chunk c are [16][Dpad] and belong to steps jbase[c] .. jbase[c] + 15
+    int narrow, pad_;
+    unsigned char jbase[kMiniChunks];
 };
-static_assert(sizeof(ReduceArgs) == 64, "kernarg layout of reduce_block_kernel");
+static_assert(sizeof(ReduceArgs) == 72 + kMiniChunks, "kernarg layout of reduce_block_kernel");
 
 struct TaperArgs {
     Panel Kraw;

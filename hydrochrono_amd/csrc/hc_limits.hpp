@@ -11,6 +11,7 @@ constexpr int kScatterSamples = 64;  // IRF samples s < kScatterSamples can be t
 constexpr int kTargets        = 3;   // later block steps one (sample, IRF sample) result can contribute to
 
 constexpr int kSubBlock       = 8;   // steps per sub-block of the two-level form (wide systems)
+constexpr int kMiniChunks     = 256; // radiation chunks a NARROW short pass may have (one step offset per chunk travels in the argument block)
 
 #if defined(__HIPCC__)
 #define HC_HOST_DEVICE __host__ __device__

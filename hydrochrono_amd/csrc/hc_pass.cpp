@@ -376,11 +376,44 @@ void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, int ne
     require(static_cast<size_t>(b.nchunks) * L * c->Dpad <= scratch.n, HC_ERR_RUNTIME, "short pass: partials buffer too small");
     hc::ReduceArgs r{scratch.p, b.nchunks, 0, c->Dpad, L, rows_P(c, next_block), rows_E(c, next_block), b.item_counter, 1, next_block ? 0 : i0, mp.n_steps,
                      b.chunk_first};
+    // Narrow form: through ONE IRF sample the window's kw samples reach kw + 2 consecutive steps at most (the query times of
+    // consecutive steps are a step apart, like the samples), so a chunk needs 16 step columns if its samples' live steps fit a
+    // window of 16 -- always, for the in-block short passes of sub-blocks of 8 (kw <= 9); a window towards the next block spans the
+    // whole block and keeps the wide form.  The live range per IRF sample is taken generously (q inside the span of the view's
+    // times: the kernel's own bracket test decides, entries outside simply weigh 0).
+    const bool narrow_on = env_int("HC_MINI_NARROW", 1) != 0;  // (read per launch: tests switch it between contexts)
+    if (narrow_on && L == hc::kLookahead && mp.kw + 2 <= 14 && b.nchunks <= hc::kMiniChunks) {
+        bool fits = true;
+        const double t_new = mp.time[0], t_old = mp.time[mp.kw + 1];
+        for (int ch = b.chunk_first; ch < b.nchunks && fits; ++ch) {
+            const int gp0 = ch * b.chunk_gp, gp1 = std::min((b.F + 7) >> 3, gp0 + b.chunk_gp);
+            const int sa = (gp0 * 8) / c->D, sb = (std::min(b.F, gp1 * 8) - 1) / c->D;
+            int lo = hc::kLookahead, hi = -1;
+            for (int s_ = sa; s_ <= sb; ++s_)
+                for (int j = 0; j < mp.n_steps; ++j) {
+                    const double q = mp.tpred[j] - c->tau[static_cast<size_t>(s_)];
+                    if (s_ >= mp.s_cut[j] && q >= t_old && q <= t_new) {
+                        lo = std::min(lo, j);
+                        hi = std::max(hi, j);
+                    }
+                }
+            if (hi < 0) lo = 0;  // nothing live in this chunk: any window will do
+            fits = hi - lo < 16;
+            b.mini_jbase[ch] = r.jbase[ch] = static_cast<unsigned char>(lo);
+        }
+        if (fits) {
+            b.depth       = 16;
+            b.mini_narrow = r.narrow = 1;
+        }
+    }
+    const bool narrow = b.mini_narrow != 0;
+    const int mt      = narrow ? c->mt_narrow : c->mt_mini;
+    b.ngroups         = c->ntiles / mt;
     if (direct) {
         hc::BlockArgs b2;
-        const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_mini, &b2);
+        const hc::BlockLaunch l = hc::block_launch_config(b, mt, &b2);
         if (l.nblocks <= 0) return;
-        c->dq->dispatch(L == 32 ? c->dk_mini32 : c->dk_mini16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
+        c->dq->dispatch(narrow ? c->dk_narrow : (L == 32 ? c->dk_mini32 : c->dk_mini16), static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
                         direct_tag(c, hc::kEvMiniPass), 0.0, lane);
         c->dq->dispatch(c->dk_reduce, static_cast<uint32_t>(hc::reduce_block_grid(r)), 256, 0, &r, sizeof r, -1, 0.0, lane);
         c->prof.direct_dispatches += 2;
@@ -388,7 +421,7 @@ void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, int ne
         return;
     }
     hc::EventPair* ev = ev_begin(c, hc::kEvMiniPass, stream);
-    hc::launch_conv_block(b, c->mt_mini, stream);
+    hc::launch_conv_block(b, mt, stream);
     ev_end(ev, stream);
     hc::launch_reduce_block(r, stream);
     c->prof.hip_launches += 2;

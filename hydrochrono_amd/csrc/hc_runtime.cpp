@@ -286,6 +286,13 @@ void setup_panel_geometry(hc_ctx* c) {
         for (int m : {1, 2, 4, 6})
             if (m <= c->mt_block && c->ntiles % m == 0 && 48LL * (c->ntiles / m) >= 2LL * c->num_cus) m_pick = m;
         c->mt_mini = forced > 0 ? pick(c->ntiles, std::min(c->mt_block, forced)) : m_pick;
+        // ... and of their narrow form (16 step columns, two to three waves per SIMD): taller workgroups pay, as long as a short pass still
+        // has a workgroup for every CU -- 4 for a C4/8 shard (55 -> 51 us per short pass; 67 us in the wide form), 6 for C4 on one GPU
+        const int forced_n = env_int("HC_NARROW_MT", 0);
+        int n_pick = 1;
+        for (int m : {1, 2, 4, 6})
+            if (m <= c->mt_block && c->ntiles % m == 0 && 48LL * (c->ntiles / m) >= 1LL * c->num_cus) n_pick = m;
+        c->mt_narrow = forced_n > 0 ? pick(c->ntiles, std::min(c->mt_block, forced_n)) : std::max(n_pick, c->mt_mini);
     }
 }
 
@@ -610,6 +617,15 @@ void setup_direct(hc_ctx* c) {
         const hc::BlockLaunch lm = hc::block_launch_config(a, c->mt_mini, &b);  // the short passes' variant (fewer tiles per workgroup)
         std::snprintf(frag, sizeof frag, "conv_block_kernelILi%dELi%dELi%dELi%dEEEv", lm.MT, lm.R, lm.NB, lm.WPS);
         (depth == 16 ? c->dk_mini16 : c->dk_mini32) = q->find(frag);
+        if (depth == 16) {
+            const hc::BlockLaunch ln = hc::block_launch_config(a, c->mt_narrow, &b);  // the narrow short pass: the 16-step kernel with its own tile count
+            std::snprintf(frag, sizeof frag, "conv_block_kernelILi%dELi%dELi%dELi%dEEEv", ln.MT, ln.R, ln.NB, ln.WPS);
+            c->dk_narrow = q->find(frag);
+        }
+    }
+    if (!c->dk_narrow.ok() || c->dk_narrow.priv || c->dk_narrow.kernarg != sizeof(hc::BlockArgs)) {
+        c->direct_why = "the narrow short-pass variant of the pass kernel is missing from hc_kernels.co";
+        return;
     }
     if (!c->dk_mini16.ok() || !c->dk_mini32.ok() || c->dk_mini16.priv || c->dk_mini32.priv || c->dk_mini16.kernarg != sizeof(hc::BlockArgs) ||
         c->dk_mini32.kernarg != sizeof(hc::BlockArgs)) {

@@ -383,3 +383,39 @@ def test_one_block_ahead_with_the_ring_nearly_full(hydro, sub, concurrent, monke
     # either the history came within a block of the capacity and the library made room, or it grew earlier for the same reason
     assert p["ring_grows_for_pass"] >= 1 and sz["Hcap"] > cap0, (p, sz, seen_tight)
     assert p["history_rewinds"] == 0
+
+
+@pytest.mark.parametrize("direct", [1, 0], ids=["aql", "hip"])
+@pytest.mark.parametrize("schedule", [0, 1], ids=["pass-at-block-start", "one-block-ahead"])
+def test_narrow_short_pass_is_bitwise_the_wide_one(hydro, schedule, direct, monkeypatch):
+    """The in-block short passes of the two-level form run in their NARROW form by default (16 step columns per chunk, offset per
+    chunk, BlockArgs::mini_narrow): the same brackets, the same chunk sums, the same order in the reduction -- bitwise the forces of
+    the wide form (HC_MINI_NARROW=0), through uniform steps equal to / below / above the IRF spacing and a change of step size."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_DIRECT", str(direct))
+    monkeypatch.setenv("HC_SUB_BLOCK", "8")
+    N = 6
+    case = many_body_case(N, S=180, dt_rirf=0.01, n_exc=41, dt_exc=0.02, seed=415)
+    orc = load_into_oracle(case)
+    orc.add_waves_none()
+    motion = PrescribedMotion(N, rest_positions(case), seed=3)
+    times, t = [], 0.0
+    for n in range(520):
+        t += 0.01 if n < 200 else (0.0071 if n < 360 else 0.0137)
+        times.append(t)
+    runs = []
+    for narrow in ("1", "0"):
+        monkeypatch.setenv("HC_MINI_NARROW", narrow)
+        gpu = hydro.HydroForces.from_case(case)
+        gpu.add_waves_none()
+        gpu.set_pass_schedule(schedule)
+        gpu.enable_profiling(1)
+        f = np.stack([gpu.step(tt, *motion.state(tt)) for tt in times])
+        p = gpu.profile()
+        assert p["mini_pass_launches"] >= 30, p
+        runs.append(f)
+        gpu.close()
+    assert np.array_equal(runs[0], runs[1])
+    for n, tt in enumerate(times):
+        assert relerr(runs[0][n], orc.step(tt, *motion.state(tt))) <= TIGHT_TOL, f"step {n}"

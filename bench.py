@@ -442,6 +442,7 @@ def main():
     share_gpu = os.environ.get("HC_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
+        os.environ["HC_DEVICE_SHARED"] = "1"  # the library: other processes hold contexts on this device too (no queue parking, no pass lane)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -386,6 +386,13 @@ bool DirectQueue::drain(double timeout_seconds, int lane) {
     return true;
 }
 
+void DirectQueue::abandon_lane(int lane) {
+    Impl::Lane& ln = p_->lanes[lane];
+    ln.queue       = nullptr;  // leaked on purpose
+    ln.armed       = false;
+    busy_[lane]    = false;
+}
+
 uint64_t DirectQueue::signal_after(int lane) {
     Impl& p        = *p_;
     Impl::Lane& ln = p.lanes[lane];

@@ -63,6 +63,9 @@ class DirectQueue {
     bool failed(int lane = 0) const;
     std::string failure_text() const;
     bool busy(int lane = 0) const { return busy_[lane]; }
+    // A lane whose self-test dispatch never completed: its HSA queue is forgotten (not drained, not destroyed -- both would wait for
+    // the dispatch) and the lane reads as idle from now on.
+    void abandon_lane(int lane);
     static constexpr int kLanes = 3;  // 0: the step path; 1: added-mass products; 2: look-ahead passes that run beside the steps
     // Cross-lane ordering.  signal_after(lane): a barrier packet behind everything dispatched to the lane so far; the returned
     // handle completes when all of that has finished (0: no signal could be had -- the caller must not rely on ordering then).

@@ -213,11 +213,12 @@ void ahead_issue_slice(hc_ctx* c, hipStream_t stream, bool direct) {
 // kernels of the step path (a pass workgroup holds its CU's registers for its whole life, so a step kernel that finds no free CU
 // would wait for a pass workgroup to end; profiles/overlap_probe.hip).  Without the mask the lane is not used.
 bool pass_lane_ready(hc_ctx* c) {
+    // one more queue per context: only where the device is this context's alone.  Several contexts on ONE device -- of this process
+    // (contexts_on_device) or of other processes, which the launcher says with HC_DEVICE_SHARED=1: a test bed for the multi-GPU
+    // code, not a deployment -- already time-share its hardware queues; their slices stay on the step path's lane.
+    if (contexts_on_device(c->device) > 1) return false;
     if (c->pass_lane == 2) return true;
     if (c->pass_lane < 0 || !c->pass_concurrent || !c->dq || !c->direct_ready) return false;
-    // one more queue per context: only where the device is this context's alone (several contexts on ONE device -- a test bed for the
-    // multi-GPU code, not a deployment -- already time-share its hardware queues; their slices stay on the step path's lane)
-    if (contexts_on_device(c->device) > 1) return false;
     std::string why;
     const uint32_t ncu = c->dq->compute_units();
     const uint32_t keep = ncu > 8u * static_cast<uint32_t>(c->pass_free_cus) + 8 ? ncu - 8u * static_cast<uint32_t>(c->pass_free_cus) : 0;
@@ -225,7 +226,11 @@ bool pass_lane_ready(hc_ctx* c) {
     // (timed like lane 0; the same self-test as the other lanes: argument slots the host re-writes must be re-read, not served stale)
     bool ok = keep > 0 && c->dq->ensure_lane(2, &why) && c->dq->set_cu_mask(2, keep);
     if (ok) c->dq->enable_timing(2);
-    c->pass_lane = (ok && direct_selftest_rewrites(c, c->dq, 2, &abandon)) ? 2 : -1;
+    const std::string why_before = c->direct_why;
+    ok = ok && direct_selftest_rewrites(c, c->dq, 2, &abandon);
+    c->direct_why = why_before;  // (the step path's lane stays in use whatever this lane's test said)
+    if (abandon) c->dq->abandon_lane(2);  // a dispatch that never completed: the lane's queue is left alone, nothing ever waits for it again
+    c->pass_lane = ok ? 2 : -1;
     return c->pass_lane == 2;
 }
 

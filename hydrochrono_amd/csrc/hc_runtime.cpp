@@ -45,7 +45,12 @@ const char* const kVersion = "hydrochrono_amd 0.1 (gfx950)";
 namespace {
 std::atomic<int> g_contexts_on_device[64];
 }
-int contexts_on_device(int device) { return (device >= 0 && device < 64) ? g_contexts_on_device[device].load(std::memory_order_relaxed) : 0; }
+int contexts_on_device(int device) {
+    // HC_DEVICE_SHARED=1: other PROCESSES hold contexts on the devices of this one too (one-process-per-rank runs that share a GPU, a
+    // test bed) -- what the per-process counter cannot see; it counts as one more context everywhere
+    static const int others = env_int("HC_DEVICE_SHARED", 0) != 0 ? 1 : 0;
+    return ((device >= 0 && device < 64) ? g_contexts_on_device[device].load(std::memory_order_relaxed) : 0) + others;
+}
 void count_context_on_device(int device, int delta) {
     if (device >= 0 && device < 64) g_contexts_on_device[device].fetch_add(delta, std::memory_order_relaxed);
 }

@@ -378,6 +378,9 @@ int hc_finalize(hc_ctx* c) {
     c->plan                    = hc::Plan{};
     HC_HIP(hipStreamSynchronize(c->stream));
     setup_direct(c);
+    // the pass lane (its queue, CU mask and self-test: 131 synchronous dispatches) is made here, not inside the first step that
+    // starts a pass one block ahead
+    if (c->pass_ahead && c->lookahead > 0) (void)pass_lane_ready(c);
     c->finalized = true;
     HC_API_END(c)
 }

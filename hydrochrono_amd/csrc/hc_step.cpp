@@ -1027,6 +1027,7 @@ int hc_set_pass_schedule(hc_ctx* c, int one_block_ahead, int slices) {
     c->ahead.active = false;
     alloc_partials(c);
     c->plan = hc::Plan{};
+    if (c->pass_ahead && c->lookahead > 0) (void)pass_lane_ready(c);  // (created and self-tested here, off the step path)
     HC_API_END(c)
 }
 

@@ -66,7 +66,7 @@ def test_force_all_gather_world2_gloo(N):
 # all-gathered over gloo (on an 8-GPU node the same code runs one rank per GPU over RCCL, bench.py --gpus N)
 # ------------------------------------------------------------------------------------------------
 def _ctx_worker(rank, world, port, N, steps, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HC_DEVICE_SHARED="1")  # the ranks share the one GPU of the box
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys
@@ -166,7 +166,7 @@ def test_device_path_all_gather_over_rccl_one_rank():
 # kernels write -- no collective on the data path (gloo only for the barrier and the final verdict)
 # ------------------------------------------------------------------------------------------------
 def _shm_worker(rank, world, port, N, steps, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HC_DEVICE_SHARED="1")  # the ranks share the one GPU of the box
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import ctypes as C
@@ -243,7 +243,7 @@ def test_host_gather_through_shared_memory_two_ranks_one_gpu(N):
 # RCCL with more than one rank has not run anywhere yet.
 # ------------------------------------------------------------------------------------------------
 def _dev_order_worker(rank, world, port, N, steps, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HC_DEVICE_SHARED="1")  # the ranks share the one GPU of the box
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys

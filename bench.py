@@ -54,7 +54,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 # rocprofv3 --kernel-trace --stats of this very command (python bench.py --gpus 1 --steps 20 --warmup 5 --no-c4-share --no-c4-one-gpu, so that
 # the pass kernel's row holds C3 launches only): roofline.frac = algorithmic_bytes_per_launch / its AverageNs / 8 TB/s
-ROOFLINE_PROFILE = "profiles/r04/c3_driver_cmd_kernel_stats.csv (rocprofv3 --kernel-trace --stats; the PMC passes behind roofline.traffic: profiles/r04/pmc_traffic.json)"
+ROOFLINE_PROFILE = ("profiles/r04/c3_driver_cmd_kernel_stats_by_grid.csv: the row of hc::conv_block_kernel<6, 4, 2, 1> on 256 workgroups (the rocprofv3 kernel "
+                    "trace of this command with --no-c4-share --no-c4-one-gpu, one row per kernel and grid size -- the same kernel on 224 workgroups is a "
+                    "slice of the chrono_like_loop secondary); recomputed in profiles/r04/roofline_recomputed.json; PMC passes behind roofline.traffic: "
+                    "profiles/r04/pmc_traffic.json")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 FP64_MFMA_PEAK_TF = 78.6
 

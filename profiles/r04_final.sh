@@ -21,7 +21,7 @@ g++ -O2 -std=c++17 $R/profiles/multi_path_c.cpp -I $R/include -L $R/hydrochrono_
   (echo "== worker thread per context (default)"; /tmp/multi_path_c 64 1024 3000; echo "== one thread (HC_MULTI_THREADS=0)"; HC_MULTI_THREADS=0 /tmp/multi_path_c 64 1024 3000) > $O/multi_path_c.txt 2>&1
   (echo "== worker thread per context (default)"; /tmp/multi_path_c 512 1024 600; echo "== one thread (HC_MULTI_THREADS=0)"; HC_MULTI_THREADS=0 /tmp/multi_path_c 512 1024 600) > $O/multi_path_c_c4.txt 2>&1
 }
-g++ -O2 -std=c++17 $R/profiles/ahead_probe.cpp -I $R/include -L $R/hydrochrono_amd/lib -lhydrochrono_amd -Wl,-rpath,$R/hydrochrono_amd/lib -o /tmp/ahead_probe && /tmp/ahead_probe 2>/dev/null > $O/ahead_probe.txt
+g++ -O2 -std=c++17 $R/profiles/ahead_probe.cpp -I $R/include -L $R/hydrochrono_amd/lib -lhydrochrono_amd -Wl,-rpath,$R/hydrochrono_amd/lib -o /tmp/ahead_probe && /tmp/ahead_probe 1 2>/dev/null > $O/ahead_probe.txt
 g++ -O2 -std=c++17 $R/profiles/host_path_c.cpp -I $R/include -L $R/hydrochrono_amd/lib -lhydrochrono_amd -Wl,-rpath,$R/hydrochrono_amd/lib -o /tmp/host_path_c && /tmp/host_path_c 2>/dev/null > $O/host_path_c.txt
 (echo "== pass at block start (HC_PASS_AHEAD=0)"; HC_PASS_AHEAD=0 W=8 python $R/profiles/shard_probe.py; echo "== one block ahead on the pass lane (the default of wide systems)"; W=8 python $R/profiles/shard_probe.py) 2>/dev/null > $O/shard_probe_c4_rank.txt
 (echo "== pass at block start (HC_PASS_AHEAD=0)"; HC_PASS_AHEAD=0 W=1 python $R/profiles/shard_probe.py; echo "== one block ahead on the pass lane (the default of wide systems)"; W=1 python $R/profiles/shard_probe.py) 2>/dev/null > $O/shard_probe_c4_one_gpu.txt

@@ -263,7 +263,7 @@ struct hc_ctx {
     hc::DeviceBuffer<double> d_scratch;  // [4][Dloc] outputs of the term-only entry points (they must not clobber the last step)
     hc::DeviceBuffer<int> d_err;
     hc::PinnedBuffer<double> h_state, h_out, h_am;
-    hc::BarBuffer<double> bar_state;  // [2][12N] body state written by the host through the BAR (hc_step)
+    hc::BarBuffer<double> bar_state;  // [2][12N + 1] body state (+ the step's canary word) written by the host through the BAR (hc_step)
     hc::BarBuffer<double> bar_am;     // [D + Dloc] w and incoming R of hc_added_mass_mv
     hc::PinnedBuffer<unsigned long long> h_tag_am;  // [Dloc][2] its tagged result
     int am_lane = 0;  // second lane of the direct queue (added-mass products): 0 not created yet, 1 in use, -1 unusable (HIP launches)
@@ -271,6 +271,10 @@ struct hc_ctx {
     hc::PinnedBuffer<unsigned long long> h_tag_selftest;   // [2] its tagged result
     hc::DeviceBuffer<double> d_selftest;                   // [1]
     unsigned long long seq_am = 0;
+    hc::PinnedBuffer<unsigned long long> h_canary;  // 2 x [2] {canary, sequence number}: the word hc_step stored behind the state, handed back by the step kernel
+    const double* step_canary_in = nullptr;         // set by step_begin for the enqueue_step it makes (device-visible address of that word)
+    unsigned long long* step_canary_out = nullptr;
+    long long fault_stale_state_at = -1;            // HC_FAULT_STALE_STATE_AT (tests): the step with this sequence number carries the previous step's canary
     hc::PinnedBuffer<unsigned long long> h_tag;  // 2 x [Dloc][2] {total, sequence number} granules written by finalize_kernel (halves by sequence parity)
     unsigned long long seq = 0;
     unsigned long long *ext_tag_host = nullptr, *ext_tag_dev = nullptr;  // the caller's result buffer (hc_set_result_buffer), else h_tag

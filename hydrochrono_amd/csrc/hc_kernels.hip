@@ -1059,6 +1059,10 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     __shared__ double red_term[16][16];  // [term slice][row]
 
     if (a.do_push && (int)blockIdx.x == a.nblocks - 1) {  // (a.nblocks, not gridDim: the kernel takes no hidden arguments, see hc_direct.hpp)
+        if (threadIdx.x == 64 && a.canary_out) {  // first thing this workgroup does: the word the host stored behind the state goes back, tagged
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u64x2*>(a.canary_out) = u64x2{(unsigned long long)__double_as_longlong(*a.canary_in), a.seq};
+        }
         // nobody reads ring slot `head` during this step (the current sample is always taken from `state`)
         if (threadIdx.x == 0) a.ring_t[a.head] = a.t;
         double* slot = a.ring_v + (size_t)a.head * a.D;
@@ -1604,9 +1608,14 @@ __global__ void __launch_bounds__(256) added_mass_mv_kernel(const double* __rest
 // no copies, no stream synchronisation, like hc_step.
 __global__ void __launch_bounds__(256) added_mass_mv_tagged_kernel(const double* __restrict__ M, int rows, int cols,
                                                                     const double* __restrict__ w, const double* __restrict__ R_in, double c,
-                                                                    unsigned long long* __restrict__ tagged, unsigned long long seq) {
+                                                                    unsigned long long* __restrict__ tagged, unsigned long long seq,
+                                                                    const double* __restrict__ canary_in, unsigned long long* __restrict__ canary_out) {
     const int row  = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 1 && canary_out) {  // the word the host stored behind w and R goes back, tagged (see finalize_kernel)
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u64x2*>(canary_out) = u64x2{(unsigned long long)__double_as_longlong(*canary_in), seq};
+    }
     if (row >= rows) return;
     const double acc = row_dot(M + (size_t)row * cols, w, cols, lane);
     if (lane == 0) {
@@ -1617,8 +1626,10 @@ __global__ void __launch_bounds__(256) added_mass_mv_tagged_kernel(const double*
 }
 
 void launch_added_mass_mv_tagged(const double* d_M, int rows, int cols, const double* d_w, const double* d_R_in, double c,
-                                 unsigned long long* d_tagged, unsigned long long seq, hipStream_t stream) {
-    hipLaunchKernelGGL(added_mass_mv_tagged_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, d_M, rows, cols, d_w, d_R_in, c, d_tagged, seq);
+                                 unsigned long long* d_tagged, unsigned long long seq, const double* d_canary_in, unsigned long long* d_canary_out,
+                                 hipStream_t stream) {
+    hipLaunchKernelGGL(added_mass_mv_tagged_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, d_M, rows, cols, d_w, d_R_in, c, d_tagged, seq, d_canary_in,
+                       d_canary_out);
 }
 
 void launch_added_mass_mv(const double* d_M, int rows, int cols, const double* d_w, double c, double* d_R, hipStream_t stream) {

@@ -218,6 +218,11 @@ struct FinalizeArgs {
     // seq instead of synchronising the stream (one store carries value and sequence number, so no ordering is assumed).
     unsigned long long* host_tagged;  // [Dloc][2] or null
     unsigned long long seq;
+    // Proof that the kernel read THIS step's state: the host stores the step's sequence number behind the state (same buffer, same
+    // store path -- the PCIe BAR), the kernel hands the word back as one more tagged granule and the host compares (hc_step only;
+    // both null otherwise).  A GPU that served a stale copy of host-rewritten memory would show here at the step it happens.
+    const double* canary_in;
+    unsigned long long* canary_out;   // [2] {canary bits, seq}
     // history push of this step's sample into ring slot `head` (src/hydro_forces.cpp:559-574)
     int do_push, head, D;
     int nblocks;      // workgroups of the launch (set by finalize_launch_config; the last one stores the sample)
@@ -253,8 +258,10 @@ struct AddedMassArgs {
     double c;
     unsigned long long* tagged;
     unsigned long long seq;
+    const double* canary_in;          // the word the host stored behind w and R (null: none)
+    unsigned long long* canary_out;   // [2] {canary bits, seq}
 };
-static_assert(sizeof(AddedMassArgs) == 56, "kernarg layout of added_mass_mv_tagged_kernel");
+static_assert(sizeof(AddedMassArgs) == 72, "kernarg layout of added_mass_mv_tagged_kernel");
 
 // reduce_block_kernel's arguments as the kernel lays them out.  accumulate != 0 (short pass of the two-level form): the chunk sum
 // of step j is ADDED to row j_off + j of P for j < j_cnt (the rows of the block steps still to come), nothing else is touched.
@@ -336,7 +343,8 @@ void launch_eta_synthesis(const double* d_t, int nt, const double* d_amp, const 
 void launch_added_mass_mv(const double* d_M, int rows, int cols, const double* d_w, double c, double* d_R, hipStream_t stream);
 // tagged[row] = {R_in[row] + c * sum_j M[row][j] * w[j], seq} as 16-byte granules (host boundary)
 void launch_added_mass_mv_tagged(const double* d_M, int rows, int cols, const double* d_w, const double* d_R_in, double c,
-                                 unsigned long long* d_tagged, unsigned long long seq, hipStream_t stream);
+                                 unsigned long long* d_tagged, unsigned long long seq, const double* d_canary_in, unsigned long long* d_canary_out,
+                                 hipStream_t stream);
 // out[(row*D + col)*S + s] = K[row][s*D + col]  (reference indexing; diagnostics)
 void launch_unrelayout(const Panel& K, int Dloc, int D, int S, double* d_out, hipStream_t stream);
 // out[s] = K[row][s*D + col], s < S  (one series; diagnostics)

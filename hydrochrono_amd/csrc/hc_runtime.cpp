@@ -550,7 +550,7 @@ bool direct_selftest_rewrites(hc_ctx* c, hc::DirectQueue* q, int lane, bool* aba
         c->bar_selftest.p[1] = rv;
         _mm_sfence();
         const unsigned long long sq = 0xABC000ull + static_cast<unsigned long long>(lane) * 1000 + i;
-        hc::AddedMassArgs a{c->d_selftest.p, 1, 1, c->bar_selftest.p, c->bar_selftest.p + 1, cv, c->h_tag_selftest.dp, sq};
+        hc::AddedMassArgs a{c->d_selftest.p, 1, 1, c->bar_selftest.p, c->bar_selftest.p + 1, cv, c->h_tag_selftest.dp, sq, nullptr, nullptr};
         q->dispatch(c->dk_added_mass, 1, 256, 0, &a, sizeof a, -1, 0.0, lane);
         const auto t0 = std::chrono::steady_clock::now();
         bool arrived  = false;

@@ -333,8 +333,11 @@ int hc_finalize(hc_ctx* c) {
     for (auto* b : {&c->d_hs, &c->d_rad, &c->d_waves, &c->d_total}) HC_HIP(hipMemsetAsync(b->p, 0, b->n * sizeof(double), c->stream));
     c->d_err.alloc(3);  // [0] error flag of the convolution kernels, [1] work-item counter of the look-ahead pass, [2] ... of a pass on the pass lane
     HC_HIP(hipMemsetAsync(c->d_err.p, 0, 3 * sizeof(int), c->stream));
-    c->h_state.alloc(static_cast<size_t>(2) * 12 * c->N);  // two halves used alternately by hc_step, see there
-    c->bar_state.alloc(static_cast<size_t>(2) * 12 * c->N);
+    c->h_state.alloc(static_cast<size_t>(2) * (12 * c->N + 1));  // two halves used alternately by hc_step, see there (+ a canary word each)
+    c->bar_state.alloc(static_cast<size_t>(2) * (12 * c->N + 1));
+    c->h_canary.alloc(4);
+    std::memset(c->h_canary.p, 0, 4 * sizeof(unsigned long long));
+    c->fault_stale_state_at = env_int("HC_FAULT_STALE_STATE_AT", -1);
     if (c->bar_state.host_ok) {
         // trust, but verify: what the host stores through the BAR must be what a device-side copy sees
         const size_t nb = c->bar_state.n;
@@ -350,9 +353,9 @@ int hc_finalize(hc_ctx* c) {
     }
     c->h_out.alloc(static_cast<size_t>(4) * c->Dloc);
     c->h_err.alloc(1);
-    c->h_am.alloc(static_cast<size_t>(c->D) + c->Dloc);
-    c->bar_am.alloc(static_cast<size_t>(c->D) + c->Dloc);
-    c->h_tag_am.alloc(static_cast<size_t>(2) * c->Dloc);
+    c->h_am.alloc(static_cast<size_t>(c->D) + c->Dloc + 1);  // w | incoming R | the product's canary word
+    c->bar_am.alloc(static_cast<size_t>(c->D) + c->Dloc + 1);
+    c->h_tag_am.alloc(static_cast<size_t>(2) * c->Dloc + 2);  // [Dloc][2] result granules + the canary granule
     c->bar_selftest.alloc(2);
     c->h_tag_selftest.alloc(2);
     c->d_selftest.alloc(1);

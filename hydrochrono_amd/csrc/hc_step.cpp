@@ -418,6 +418,10 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
             std::fprintf(stderr, "     near s=%d a=%.6g b=%.6g c=%.6g offb=%d offc=%d\n", z.near[e].s, z.near[e].a, z.near[e].b, z.near[e].c, z.near[e].off_b, z.near[e].off_c);
     }
     z.host_tagged = host_tagged;
+    z.canary_in   = c->step_canary_in;   // (set by step_begin for this call only)
+    z.canary_out  = c->step_canary_out;
+    c->step_canary_in  = nullptr;
+    c->step_canary_out = nullptr;
     z.seq         = seq;
     z.Dloc        = c->Dloc;
     z.Dpad        = c->Dpad;
@@ -584,6 +588,34 @@ void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long lo
     }
 }
 
+// The step kernel hands back the word the host stored behind this step's state (FinalizeArgs::canary_*): it must be this step's
+// sequence number.  Anything else means the GPU read a copy of the state buffer that is older than what the host wrote through the
+// BAR -- the one assumption the agent-scope fences of the direct dispatch rest on (hc_direct.hpp), tested at start-up by
+// direct_selftest_rewrites and here at EVERY step: the step fails loudly (HC_ERR_DEVICE) instead of returning forces of an old state.
+bool canary_enabled() {
+    static const bool on = env_int("HC_STEP_CANARY", 1) != 0;  // (0: for A/B timing only -- 0.1 us of 8.7 / 11.9 us per hc_step at one / 64 bodies)
+    return on;
+}
+void check_canary(hc_ctx* c, unsigned long long seq) {
+    const volatile unsigned long long* g = c->h_canary.p + (seq & 1) * 2;
+    unsigned long long spins = 0;
+    std::chrono::steady_clock::time_point t0{};
+    while (g[1] != seq) {  // (the granule is stored by the workgroup that pushes the sample: it lands with the rows, give or take)
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFF) == 0) {
+            const auto now = std::chrono::steady_clock::now();
+            if (spins == 0x10000) t0 = now;
+            if (std::chrono::duration<double>(now - t0).count() > step_timeout_seconds()) device_lost(c, "hc_step: the state canary of the step did not arrive");
+        }
+    }
+    const unsigned long long bits = g[0];
+    double got;
+    std::memcpy(&got, &bits, sizeof got);
+    if (got != static_cast<double>(seq))
+        device_lost(c, "hc_step: the step kernel read a stale body state (canary " + std::to_string(got) + ", step " + std::to_string(seq) +
+                           "): memory the host re-writes through the PCIe BAR was not re-read by the GPU");
+}
+
 constexpr double kArmGapSeconds = 25e-6;  // a caller that stays away longer than this finds the queue parked (see step_end)
 
 unsigned long long* result_tags_dev(hc_ctx* c, unsigned long long seq) {
@@ -637,7 +669,10 @@ void step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const
     // A row-sharded context reads positions and angles of its OWN bodies only (hydrostatics), velocities of all: the other
     // bodies' pos / rpy entries are not stored (half the bytes through the BAR for each shard of a wide array).
     const int n3   = 3 * c->N;
-    const size_t o = (c->seq & 1) ? static_cast<size_t>(12) * c->N : 0;
+    const size_t o = (c->seq & 1) ? static_cast<size_t>(12) * c->N + 1 : 0;
+    // the canary: this step's sequence number as a double, stored behind the state through the same path (checked in step_end)
+    const unsigned long long seq_next = c->seq + 1;
+    const double canary = static_cast<double>((c->fault_stale_state_at >= 0 && static_cast<long long>(seq_next) == c->fault_stale_state_at) ? seq_next - 1 : seq_next);
     const size_t l0 = static_cast<size_t>(3) * c->b0, ln = static_cast<size_t>(3) * c->nloc;
     auto put = [&](double* h) {
         std::memcpy(h + l0, pos + l0, ln * sizeof(double));
@@ -650,18 +685,24 @@ void step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const
         // device memory written through the PCIe BAR: the kernels read the state locally (no PCIe read on the critical path)
         double* h = c->bar_state.p + o;
         put(h);
+        h[4 * n3] = canary;
         _mm_sfence();  // write-combined stores are globally visible before the doorbell of the launch
         d_state = h;
+        c->step_canary_in = h + 4 * n3;
     } else {
         double* h = c->h_state.p + o;
         put(h);
+        h[4 * n3] = canary;
         d_state = c->h_state.dp + o;
+        c->step_canary_in = c->h_state.dp + o + 4 * n3;
         if (c->N > c->zero_copy_max_bodies) {  // many workgroups re-read the state: one small H2D copy beats their PCIe reads
             HC_HIP(hipMemcpyAsync(c->d_state.p, h, 4 * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
             d_state = c->d_state.p;
         }
     }
     const unsigned long long seq = ++c->seq;
+    c->step_canary_out = canary_enabled() ? c->h_canary.dp + (seq & 1) * 2 : nullptr;
+    if (!canary_enabled()) c->step_canary_in = nullptr;
     // The tagged results of consecutive steps go to alternate halves of the result buffer: a reader in ANOTHER process (a caller's
     // buffer in shared memory, hc_set_result_buffer) may still be collecting step n while this process has moved on to step n + 1;
     // it cannot reach step n + 2 before every process has the rows of step n + 1, i.e. has finished with step n.
@@ -678,6 +719,7 @@ void step_end(hc_ctx* c, double* force_out) {
     if (how == 2) {
         if (c->tail.pending) enqueue_tail(c);  // (a caller that deferred the tail and never enqueued it)
         wait_tagged(c, result_tags_host(c, c->seq), c->seq, c->stream, c->last_total.data());
+        if (canary_enabled()) check_canary(c, c->seq);
         if (c->device_errors_possible) {
             quiesce_direct(c);
             check_device_flag(c);
@@ -1131,9 +1173,12 @@ void added_mass_begin(hc_ctx* c, const double* w, double cc, const double* R, in
     double* hr       = hw + c->D;
     std::memcpy(hw, w, c->D * sizeof(double));
     std::memcpy(hr, R + row0, c->Dloc * sizeof(double));
+    const unsigned long long seq = ++c->seq_am;
+    hr[c->Dloc] = static_cast<double>(seq);  // the canary: handed back by the kernel, compared in added_mass_end (see check_canary)
     if (bar) _mm_sfence();
     const double* dw = bar ? c->bar_am.p : c->h_am.dp;
-    const unsigned long long seq = ++c->seq_am;
+    const double* canary_in         = canary_enabled() ? dw + c->D + c->Dloc : nullptr;
+    unsigned long long* canary_out  = canary_enabled() ? c->h_tag_am.dp + 2 * static_cast<size_t>(c->Dloc) : nullptr;
     if (c->direct_ready && bar && c->am_lane == 0) {
         // first product of this context: the second lane (a queue of its own) is created and self-tested now
         std::string why;
@@ -1149,28 +1194,50 @@ void added_mass_begin(hc_ctx* c, const double* w, double cc, const double* R, in
     }
     if (c->direct_ready && bar && c->am_lane == 1) {
         // the second lane of the direct queue: an AQL packet instead of a HIP launch, independent of the step path's lane
-        hc::AddedMassArgs a{c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq};
+        hc::AddedMassArgs a{c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq, canary_in, canary_out};
         c->dq->dispatch(c->dk_added_mass, static_cast<uint32_t>((c->Dloc + 3) / 4), 256, 0, &a, sizeof a, -1, 0.0, 1);
         c->prof.direct_dispatches += 1;
         c->pending_am = 1;
     } else {
-        hc::launch_added_mass_mv_tagged(c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq, c->stream_am);
+        hc::launch_added_mass_mv_tagged(c->d_ainf.p, c->Dloc, c->D, dw, dw + c->D, cc, c->h_tag_am.dp, seq, canary_in, canary_out, c->stream_am);
         c->prof.hip_launches += 1;
         HC_HIP(hipGetLastError());
         c->pending_am = 2;
     }
+}
+void check_am_canary(hc_ctx* c) {
+    if (!canary_enabled()) return;
+    const volatile unsigned long long* g = c->h_tag_am.p + 2 * static_cast<size_t>(c->Dloc);
+    unsigned long long spins = 0;
+    std::chrono::steady_clock::time_point t0{};
+    while (g[1] != c->seq_am) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFF) == 0) {
+            const auto now = std::chrono::steady_clock::now();
+            if (spins == 0x10000) t0 = now;
+            if (std::chrono::duration<double>(now - t0).count() > step_timeout_seconds()) device_lost(c, "hc_added_mass_mv: the canary of the product did not arrive");
+        }
+    }
+    const unsigned long long bits = g[0];
+    double got;
+    std::memcpy(&got, &bits, sizeof got);
+    if (got != static_cast<double>(c->seq_am))
+        device_lost(c, "hc_added_mass_mv: the kernel read stale inputs (canary " + std::to_string(got) + ", product " + std::to_string(c->seq_am) +
+                           "): memory the host re-writes through the PCIe BAR was not re-read by the GPU");
 }
 void added_mass_end(hc_ctx* c, double* R) {
     const int how = c->pending_am;
     c->pending_am = 0;
     if (how == 1) {
         wait_tagged(c, c->h_tag_am.p, c->seq_am, nullptr, R + 6 * c->b0, 1);
+        check_am_canary(c);
         if (c->direct_ready && c->arm_after_am && contexts_on_device(c->device) == 1) {  // the same parking for the added-mass lane
             c->dq->arm(1);
             c->prof.queue_parkings++;
         }
     } else if (how == 2) {
         wait_tagged(c, c->h_tag_am.p, c->seq_am, c->stream_am, R + 6 * c->b0);
+        check_am_canary(c);
     }
     c->t_am_end      = std::chrono::steady_clock::now();
     c->have_t_am_end = true;

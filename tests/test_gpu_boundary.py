@@ -228,3 +228,35 @@ def test_queue_parking_between_steps_of_a_caller_that_stays_away(HF, arm, monkey
     else:
         assert parkings >= 200
     gpu.close()
+
+
+@pytest.mark.parametrize("direct", [1, 0], ids=["aql", "hip"])
+def test_every_step_proves_it_read_this_steps_state(monkeypatch, direct):
+    """hc_step stores the body state into device memory through the PCIe BAR and dispatches with agent-scope fences only, so its
+    correctness rests on the GPU re-reading memory the host re-writes.  That is self-tested when a context is finalized -- and since
+    round 4 checked at EVERY step: the host stores the step's sequence number behind the state, the step kernel hands the word back
+    as a tagged granule, step_end compares.  HC_FAULT_STALE_STATE_AT=<n> makes the host store the PREVIOUS step's word at step n
+    (what a stale read would look like): that step must fail with HC_ERR_DEVICE and the context must refuse further steps."""
+    import hydrochrono_amd.hydro as hydro
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_DIRECT", str(direct))
+    case = many_body_case(3, S=64, n_exc=33, seed=99)
+    motion = PrescribedMotion(3, rest_positions(case), seed=1)
+    monkeypatch.setenv("HC_FAULT_STALE_STATE_AT", "57")
+    bad = hydro.HydroForces.from_case(case)
+    monkeypatch.delenv("HC_FAULT_STALE_STATE_AT")
+    good = hydro.HydroForces.from_case(case)
+    for h in (bad, good):
+        h.add_waves_none()
+    for n in range(56):  # sequence numbers 1 .. 56
+        st = motion.state(0.01 * n)
+        assert np.array_equal(bad.step(0.01 * n, *st), good.step(0.01 * n, *st))
+    st = motion.state(0.56)
+    with pytest.raises(hydro.HydroError) as ei:
+        bad.step(0.56, *st)
+    assert ei.value.status == 4 and "stale body state" in str(ei.value)  # HC_ERR_DEVICE
+    with pytest.raises(hydro.HydroError) as ei:
+        bad.step(0.57, *motion.state(0.57))
+    assert ei.value.status == 4
+    good.step(0.56, *st)  # an untouched context goes on

@@ -279,6 +279,9 @@ def c4_rank_share(sdt, lookahead):
     out = {"workload": f"rows of bodies [0, {N // 8}) of the coupled {N}-body array (D_local = {gpu.D_local}, D = {6 * N}, K slice "
                        f"{p['conv_kernel_bytes'] / 1e9:.2f} GB), synchronous hc_step through the Python wrapper, {steps} steps",
            "pass_schedule": "one block ahead, on the pass lane beside the steps (the library's default for wide systems)" if p["ahead_blocks"] > 0 else "at block start",
+           "pass_schedule_note": "the default is chosen for callers that do their own work between two force evaluations (every Chrono loop): see "
+                                 "chrono_like_loop below (300 us of host work: no step waits for a pass).  Back to back, as ms_per_step is measured, the GPU is "
+                                 "busy throughout and the schedule has nothing to hide the pass behind: compare back_to_back_pass_at_block_start",
            "ms_per_step": float(per.mean()) * 1e3, "median_ms_per_step": float(np.median(per)) * 1e3, "max_ms_per_step": float(per.max()) * 1e3,
            "pass_us": pass_s * 1e6, "pass_launches": int(p["block_kernel_launches"]),
            "pass_frac_of_hbm_peak": p["block_kernel_bytes_once"] / pass_s / 1e9 / HBM_PEAK_GBS if pass_s > 0 else None,

@@ -10,6 +10,7 @@
 // `done` word (release); the caller, after its own item, spins until the `done` word of every worker shows the generation
 // (acquire).  Items must not throw.  One caller at a time: a second thread that finds the pool busy runs its items itself, in order.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -55,7 +56,14 @@ class FanOut {
             return;
         }
         const int helpers = std::min(n - 1, max_workers_);
-        ensure_workers(helpers);
+        try {
+            ensure_workers(helpers);
+        } catch (...) {  // no thread to be had: the items run here, the pool stays usable
+            while (!workers_.empty() && !workers_.back()->th.joinable()) workers_.pop_back();
+            busy_.store(false, std::memory_order_release);
+            for (int g = 0; g < n; ++g) fn(arg, g);
+            return;
+        }
         fn_  = fn;
         arg_ = arg;
         n_   = helpers + 1;

@@ -770,16 +770,17 @@ void bind_device(const hc_ctx* c, int item) {
         worker_device = c->device;
     }
 }
-// status and message per context; the first failure (in context order) is the call's, and every context of the group reports it
+// status and message per item: items run by the fan-out record their failure in their own slot, the one-thread form records in slot 0
+// (it runs the contexts in order, so the first failure it sees is the first in context order); the call reports the first slot that
+// failed, and every context of the group gets the message
 struct MultiStatus {
     std::vector<int> status;
     std::vector<std::string> message;
     explicit MultiStatus(int n) : status(static_cast<size_t>(n), HC_OK), message(static_cast<size_t>(n)) {}
     template <class F, class A>
     bool guarded(hc_ctx* c, int item, F&& fn, A&& on_failure) {
-        // (slot = the context's place in the call when run by the fan-out, found by its shard otherwise: failures are rare)
         auto fail = [&](int code, const char* what) {
-            const size_t k = slot_of(c, item);
+            const size_t k = static_cast<size_t>(item);
             if (status[k] == HC_OK) { status[k] = code; message[k] = what; }
             on_failure();
             return false;
@@ -803,13 +804,6 @@ struct MultiStatus {
                 return status[static_cast<size_t>(g)];
             }
         return HC_OK;
-    }
-    std::vector<const hc_ctx*> order;  // serial path: contexts in call order
-    size_t slot_of(const hc_ctx* c, int item) {
-        if (item > 0) return static_cast<size_t>(item);
-        for (size_t k = 0; k < order.size(); ++k)
-            if (order[k] == c) return k;
-        return 0;
     }
 };
 }  // extern "C++"

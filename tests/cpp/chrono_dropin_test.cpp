@@ -12,6 +12,7 @@
 //   usage: chrono_dropin_test decay   <sphere.h5> <nsteps>
 //          chrono_dropin_test regular <sphere.h5> <nsteps> <amplitude> <omega> <pto damping>
 //          chrono_dropin_test yaml    <case.hydro.yaml> <nsteps> <z0> <pto damping> [<device>,<device>...]
+//          chrono_dropin_test api     <sphere.h5> 0
 // Prints "t z" per step with 9 decimals, then "WIRED <forces on body1> <loads> <system matrix rows>".
 #include <cstdio>
 #include <cstdlib>
@@ -140,6 +141,52 @@ int main(int argc, char** argv) {
             std::printf("RIRF %.17g\n", test_hydro->GetRIRFval(2, 2, 1));
             return report(system, sphereBody);
         }
+        if (mode == "api") {
+            // the rest of the surface a reference program may touch: GetWave / GetForceAtTime, the Compute* entry points, GetProfileStats,
+            // the pass schedule, and what a constructor that throws leaves behind
+            std::string h5fname = argv[2];
+            sphereBody->SetName("body1");
+            sphereBody->SetPos(ChVector3d(0, 0, -2));
+            system.Add(sphereBody);
+            auto waves                     = std::make_shared<RegularWave>(1);
+            waves->regular_wave_amplitude_ = 0.5;
+            waves->regular_wave_omega_     = 1.1;
+            std::vector<std::shared_ptr<ChBody>> bodies;
+            bodies.push_back(sphereBody);
+            {
+                auto misnamed = chrono_types::make_shared<ChBody>();
+                misnamed->SetName("floater");  // no "body<k>" name: the constructor throws (std::stoi, as in the reference) and must leave nothing behind
+                system.Add(misnamed);
+                bool threw = false;
+                try {
+                    std::vector<std::shared_ptr<ChBody>> bad;
+                    bad.push_back(misnamed);
+                    TestHydro never(bad, h5fname);
+                } catch (const std::exception&) {
+                    threw = true;
+                }
+                std::printf("THROWS %d %zu\n", threw ? 1 : 0, misnamed->forces.size());
+            }
+            TestHydro hydro_forces(bodies, h5fname, waves);
+            hydro_forces.SetPassSchedule(-1);
+            hydro_forces.SetPassSchedule(1, 2);
+            hydro_forces.SetPassSchedule(0);
+            system.time = 0.75;
+            const std::vector<double> fw = hydro_forces.ComputeForceWaves(), fg = hydro_forces.GetWave()->GetForceAtTime(0.75);
+            const std::vector<double> hs = hydro_forces.ComputeForceHydrostatics();
+            const double total_z         = hydro_forces.CoordinateFuncForBody(1, 2);
+            const std::vector<double> rad = hydro_forces.ComputeForceRadiationDampingConv();  // second evaluation at this time: the reference's duplicate-time error
+            std::printf("UNREACHED %zu\n", rad.size());
+            (void)fw; (void)fg; (void)hs; (void)total_z;
+            return 3;
+        }
+    } catch (const std::runtime_error& e) {
+        if (mode == "api") {
+            std::printf("DUPLICATE %s\n", e.what());
+            return 0;
+        }
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -173,3 +173,16 @@ def test_tapered_direct_from_yaml_changes_the_kernel(dropin, tmp_path):
     raw = float(z["rho"][0]) * z["body1/rirf_K"].reshape(6, 6, -1)[2, 2, 1]
     got = float(tags["RIRF"][0])
     assert got != raw and abs(got) < abs(raw) * 1.0000001 and abs(got / raw - 1.0) < 1e-3  # tapered from sample 0 on: slightly below
+
+
+@pytest.mark.gpu
+def test_rest_of_the_surface(dropin):
+    """GetWave()->GetForceAtTime == ComputeForceWaves, SetPassSchedule(-1 | 1 | 0), a constructor that throws (a body that is not named
+    "body<k>": std::stoi, as in the reference) leaves no force on the body and no context behind, and a second radiation evaluation at one
+    time is the reference's duplicate-time std::runtime_error (src/hydro_forces.cpp:555-557)."""
+    r = subprocess.run([dropin, "api", SPHERE_H5, "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "THROWS 1 0"
+    assert lines[-1].startswith("DUPLICATE") and "twice within the same time step" in lines[-1]
+    assert not any(ln.startswith("UNREACHED") for ln in lines)

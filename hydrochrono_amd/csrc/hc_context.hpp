@@ -168,7 +168,7 @@ struct hc_ctx {
     bool direct_ready   = false;
     std::string direct_why;  // why the direct path is not in use
     int path            = 0;
-    hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_mini16, dk_mini32, dk_narrow, dk_added_mass, dk_step, dk_near;
+    hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_mini16, dk_mini32, dk_narrow, dk_wide, dk_added_mass, dk_step, dk_near;
     hc::StepTail tail;
     // split step (hc_step_begin / hc_step_end, hc_step_multi): 0 nothing begun, 1 the begun step was a cache hit (totals in
     // last_total), 2 its results arrive as tagged granules with sequence number `seq`
@@ -237,6 +237,7 @@ struct hc_ctx {
     int chunk_gp_block = 0, nchunks_block = 0;
     hc::DeviceBuffer<double> d_partials, d_partials_block, d_P, d_E;
     hc::DeviceBuffer<double> d_near_partials;  // [16][Dpad] slice partials of near_split_kernel (wide systems)
+    hc::DeviceBuffer<int> d_tile_counter;      // [ntiles] arrival counters of wide_step_kernel (zero between launches)
     hc::DeviceBuffer<double> d_Y;           // weighted scatter results per consumer step [kLookahead + 1][kTermMax][Dpad]
     hc::DeviceBuffer<double> d_zero_state;  // 12N zeros: the not-yet-known sample of the look-ahead pass
     int chunk_gp_ex_block = 32, nchunks_ex_block = 0;  // excitation chunks of the look-ahead launch

@@ -1051,35 +1051,36 @@ void launch_reduce_block(const ReduceArgs& r, hipStream_t stream) {
 // boundary the totals also leave as 16-byte {value, sequence} granules in mapped pinned memory.
 // ------------------------------------------------------------------------------------------------
 // NW = waves per workgroup (4).  Wide systems (near_slices_for(D) > 1) leave the own-sample part to near_split_kernel.
+// the workgroup that hands back the state canary and stores this step's sample into ring slot `head` (both layouts)
 template <int NW>
-__global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    double* U = reinterpret_cast<double*>(smem_raw);  // [n_near][D] right-hand sides of the near samples
-    __shared__ double red_near[NW][16];
-    __shared__ double red_term[16][16];  // [term slice][row]
-
-    if (a.do_push && (int)blockIdx.x == a.nblocks - 1) {  // (a.nblocks, not gridDim: the kernel takes no hidden arguments, see hc_direct.hpp)
-        if (threadIdx.x == 64 && a.canary_out) {  // first thing this workgroup does: the word the host stored behind the state goes back, tagged
-            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<u64x2*>(a.canary_out) = u64x2{(unsigned long long)__double_as_longlong(*a.canary_in), a.seq};
-        }
-        // nobody reads ring slot `head` during this step (the current sample is always taken from `state`)
-        if (threadIdx.x == 0) a.ring_t[a.head] = a.t;
-        double* slot = a.ring_v + (size_t)a.head * a.D;
-        for (int c = threadIdx.x; c < a.D; c += 64 * NW) {
-            const double v = state_velocity(a.state, a.N, c);
-            slot[c] = v;
-            a.ring_vT[(size_t)c * a.HcapT + a.head] = v;  // per-DoF time series for the look-ahead pass
-            if (a.head == 0) a.ring_vT[(size_t)c * a.HcapT + a.Hcap] = v;  // mirror of slot 0 behind the last slot
-        }
-        return;
+__device__ __forceinline__ void push_sample(const FinalizeArgs& a) {
+    if (threadIdx.x == 64 && a.canary_out) {  // first thing this workgroup does: the word the host stored behind the state goes back, tagged
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u64x2*>(a.canary_out) = u64x2{(unsigned long long)__double_as_longlong(*a.canary_in), a.seq};
     }
+    // nobody reads ring slot `head` during this step (the current sample is always taken from `state`)
+    if (threadIdx.x == 0) a.ring_t[a.head] = a.t;
+    double* slot = a.ring_v + (size_t)a.head * a.D;
+    for (int c = threadIdx.x; c < a.D; c += 64 * NW) {
+        const double v = state_velocity(a.state, a.N, c);
+        slot[c] = v;
+        a.ring_vT[(size_t)c * a.HcapT + a.head] = v;  // per-DoF time series for the look-ahead pass
+        if (a.head == 0) a.ring_vT[(size_t)c * a.HcapT + a.Hcap] = v;  // mirror of slot 0 behind the last slot
+    }
+}
+
+// One tile of 16 owned rows (the whole workgroup); `tile` is the workgroup's block index in finalize_kernel.  `mid` runs after everything
+// the tile needs has been REQUESTED and before anything is waited for; it returns whether this workgroup goes on (wide_step_kernel
+// contracts its column slice of the own-sample part there and goes on only if it completed the tile).  COHERENT: the slice partials
+// were written by other workgroups of this very launch, possibly on other XCDs (agent-scope atomic loads, see wide_step_kernel).
+template <int NW, bool COHERENT, class Mid>
+__device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int tile, double* U, double (*red_near)[16], double (*red_term)[16], Mid&& mid) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub  = tid & 15;
     const bool rowthread = tid < 256;         // the first four waves own the rows; further waves only stream K
     const int rit  = (tid >> 4) & 15;         // row inside the tile
-    const int row  = blockIdx.x * 16 + rit;
+    const int row  = tile * 16 + rit;
     const bool live = rowthread && row < a.Dloc;
     const int rrow  = live ? row : 0;
 
@@ -1132,7 +1133,7 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     const int kk = lane >> 4;
     constexpr int PRE = 12;  // C3: all 12 column groups a wave owns of one IRF sample
     dvec2 pre[PRE];
-    const double* __restrict__ kbase = a.nearK.base + ((size_t)blockIdx.x * a.nearK.ngp) * 128 + lane * 2;
+    const double* __restrict__ kbase = a.nearK.base + ((size_t)tile * a.nearK.ngp) * 128 + lane * 2;
     if (near_on) {
         const int f0_0 = a.near[0].s * a.D, g0_0 = f0_0 >> 3, g1_0 = (f0_0 + a.D + 7) >> 3;
 #pragma unroll
@@ -1146,13 +1147,14 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     constexpr int TPRE = kTermMax / 16;
     double ypre[TPRE];
     if (term_on) {
-        const double* __restrict__ yc = a.Yc + blockIdx.x * 16 + (tid & 15);
+        const double* __restrict__ yc = a.Yc + tile * 16 + (tid & 15);
 #pragma unroll
         for (int q = 0; q < TPRE; ++q) {
             const int k = (tid >> 4) + 16 * q;
             ypre[q]     = (rowthread && k < a.n_terms) ? yc[(size_t)k * a.Dpad] : 0.0;
         }
     }
+    if (!mid()) return;
     if (near_on) {
         // ---- the IRF samples this step contracts itself: rows of this tile x [s*D, (s+1)*D) ----
         const int D = a.D;
@@ -1210,7 +1212,15 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
         if (a.nchunks_rad > 0) rad = lane16_sum(lane_sum(0, a.nchunks_rad));
         if (a.P) rad = p_row + rad;
         if (a.n_near_slices > 0)  // own-sample part of a wide system, computed by near_split_kernel: slice `sub`, then the fixed xor tree
-            rad += lane16_sum(sub < a.n_near_slices ? a.near_partials[(size_t)sub * a.Dpad + rrow] : 0.0);
+        {
+            double part = 0.0;
+            if (sub < a.n_near_slices) {
+                const double* q = a.near_partials + (size_t)sub * a.Dpad + rrow;
+                if constexpr (COHERENT) part = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else part = *q;
+            }
+            rad += lane16_sum(part);
+        }
         if (term_on) {
             double ts = 0.0;
 #pragma unroll
@@ -1272,6 +1282,19 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     }
 }
 
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double* U = reinterpret_cast<double*>(smem_raw);  // [n_near][D] right-hand sides of the near samples
+    __shared__ double red_near[NW][16];
+    __shared__ double red_term[16][16];  // [term slice][row]
+    if (a.do_push && (int)blockIdx.x == a.nblocks - 1) {  // (a.nblocks, not gridDim: the kernel takes no hidden arguments, see hc_direct.hpp)
+        push_sample<NW>(a);
+        return;
+    }
+    finalize_tile<NW, false>(a, (int)blockIdx.x, U, red_near, red_term, [] { return true; });
+}
+
 FinalizeLaunch finalize_launch_config(FinalizeArgs& a) {
     FinalizeLaunch l;
     l.smem    = (size_t)max(0, a.n_near) * a.D * sizeof(double);
@@ -1300,13 +1323,12 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
 // here workgroup (row tile, slice) contracts the slice's columns of every near sample and leaves one partial per row; the step
 // kernel adds the slices in a fixed order.  Same right-hand side arithmetic as finalize_kernel's near part.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) near_split_kernel(NearArgs a) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    double* U = reinterpret_cast<double*>(smem_raw);  // [n_near][8 * gps_per_slice]
-    __shared__ double red[4][16];
+// slice `sl` of row tile `rt` (the whole workgroup); U: [n_near][8 * gps_per_slice] doubles of LDS.  COHERENT: the partial is read by
+// another workgroup of the same launch (agent-scope atomic store: written through to where every XCD sees it).
+template <bool COHERENT>
+__device__ __forceinline__ void near_slice(const NearArgs& a, const int rt, const int sl, double* U, double (*red)[16]) {
     const int tid = threadIdx.x, lane = tid & 63, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rt = (int)blockIdx.x / a.n_slices, sl = (int)blockIdx.x - rt * a.n_slices;
     const int D = a.D, W = 8 * a.gps_per_slice;
     const double* __restrict__ kbase = a.K.base + ((size_t)rt * a.K.ngp) * 128 + lane * 2;
     // the K words of the first near sample (13 column groups per wave at 384-column slices) are requested before the right-hand side is
@@ -1368,7 +1390,76 @@ __global__ void __launch_bounds__(256) near_split_kernel(NearArgs a) {
     acc += __shfl_xor(acc, 32, kWave);
     if (lane < 16) red[wave][lane] = acc;
     __syncthreads();
-    if (tid < 16) a.partials[(size_t)sl * a.Dpad + rt * 16 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    if (tid < 16) {
+        const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        double* q      = a.partials + (size_t)sl * a.Dpad + rt * 16 + tid;
+        if constexpr (COHERENT) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *q = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) near_split_kernel(NearArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ double red[4][16];
+    const int rt = (int)blockIdx.x / a.n_slices, sl = (int)blockIdx.x - rt * a.n_slices;
+    near_slice<false>(a, rt, sl, reinterpret_cast<double*>(smem_raw), red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wide_step_kernel: near_split_kernel and the step kernel of a wide system in ONE launch.  Workgroup (row tile, slice) first requests
+// what the tile's step kernel needs (its rows of P, its scatter terms, the hydrostatics inputs), contracts its column slice of the
+// own-sample part, leaves the partial and counts itself in at the tile's counter; the workgroup that finds itself LAST there is the
+// tile's step kernel (finalize_tile: slice partials in slice order, look-ahead part, scatter terms, hydrostatics, total, tagged store).
+// Which workgroup that is does not matter -- the slices are added in a fixed order from memory -- so the forces are bitwise those of the
+// two-launch form; what is saved is a dispatch (packet, barrier, the 4-5 us floor of a kernel) on the critical path of every block step
+// of a wide system.
+// The hand-off crosses XCDs (their L2s are not coherent with each other), and an agent-scope FENCE costs an L2 write-back and
+// invalidate per workgroup (33 us per step when it was tried, profiles/r04/ab_wide_kernels.txt).  So no fence: the 16 partials of a
+// slice are agent-scope atomic stores (global_store sc1: written through), complete before the count (s_waitcnt vmcnt(0)); the count is
+// an agent-scope atomic add; the last workgroup reads the partials with agent-scope atomic loads (global_load sc1) issued after its own
+// add has returned.  Nothing else the step kernel reads was written in this launch.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wide_step_kernel(WideStepArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ double red[4][16];
+    __shared__ double red_near[4][16];
+    __shared__ double red_term[16][16];
+    __shared__ int s_last;
+    if (a.f.do_push && (int)blockIdx.x == a.f.nblocks - 1) {
+        push_sample<4>(a.f);
+        return;
+    }
+    const int rt = (int)blockIdx.x / a.n.n_slices, sl = (int)blockIdx.x - rt * a.n.n_slices;
+    finalize_tile<4, true>(a.f, rt, nullptr, red_near, red_term, [&] {
+        near_slice<true>(a.n, rt, sl, reinterpret_cast<double*>(smem_raw), red);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial has been written through
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int arrived = __hip_atomic_fetch_add(a.tile_counter + rt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last            = arrived == a.n.n_slices - 1;
+            if (s_last) __hip_atomic_store(a.tile_counter + rt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next step
+        }
+        __syncthreads();
+        return s_last != 0;
+    });
+}
+
+WideLaunch wide_launch_config(WideStepArgs& a) {
+    WideLaunch l;
+    const NearLaunch nl = near_launch_config(a.n);
+    l.grid              = nl.grid + (a.f.do_push ? 1 : 0);
+    l.smem              = nl.smem;
+    a.f.nblocks         = l.grid;
+    a.f.near_partials   = a.n.partials;
+    a.f.n_near_slices   = a.n.n_slices;
+    a.f.n_near          = 0;
+    return l;
+}
+
+void launch_wide_step(const WideStepArgs& a0, hipStream_t stream) {
+    WideStepArgs a     = a0;
+    const WideLaunch l = wide_launch_config(a);
+    hipLaunchKernelGGL(wide_step_kernel, dim3(l.grid), dim3(256), l.smem, stream, a);
 }
 
 int near_slices_for(int D) { return D >= 1024 ? min(16, max(2, D / 384)) : 1; }

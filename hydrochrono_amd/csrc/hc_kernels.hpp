@@ -232,6 +232,14 @@ struct FinalizeArgs {
     int Hcap, HcapT;
 };
 
+// wide_step_kernel: near_split_kernel + the step kernel of a wide system in one launch (the workgroup that completes a row tile's
+// slices finishes the tile).  tile_counter: [ntiles] ints, zero between launches.
+struct WideStepArgs {
+    NearArgs n;
+    FinalizeArgs f;
+    int* tile_counter;
+};
+
 // scatter_kernel: y_s[row] = width[s] * sum_col K[row, s*D + col] * v[col] for s in [s_lo, s_lo + ns); one workgroup per
 // (row tile, sample), so nothing is left to reduce across workgroups.  Each result goes, times the interpolation weight of
 // the sample, straight into the term slots of the later block steps it contributes to: Y[tgt_off + row] = tgt_coef * y_s.
@@ -301,6 +309,11 @@ struct NearLaunch {
 // slices of the own-sample part for a system of D columns (1: the step kernel contracts it itself)
 int near_slices_for(int D);
 NearLaunch near_launch_config(NearArgs& a);  // fills n_slices / gps_per_slice
+struct WideLaunch {
+    int grid = 0;
+    size_t smem = 0;
+};
+WideLaunch wide_launch_config(WideStepArgs& a);  // fills the slice geometry, f.nblocks and f.near_partials / n_near_slices (f.n_near = 0)
 struct ScatterLaunch {
     int grid = 0;
     size_t smem = 0;
@@ -334,6 +347,7 @@ void launch_reduce_block(const ReduceArgs& r, hipStream_t stream);
 int reduce_block_grid(const ReduceArgs& r);
 void launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 void launch_near_split(const NearArgs& a, hipStream_t stream);
+void launch_wide_step(const WideStepArgs& a, hipStream_t stream);
 void launch_scatter(const ScatterArgs& a, hipStream_t stream);
 void launch_taper(const TaperArgs& a, hipStream_t stream);
 // eta[j] = sum_i amp[i] * cos(-omega[i]*t[j] + phase[i]), then the ramp rule of src/wave_types.cpp:759-769

@@ -419,6 +419,10 @@ void alloc_partials(hc_ctx* c) {
     const size_t ny = static_cast<size_t>(hc::kLookahead + 1) * hc::kTermMax * c->Dpad;
     if (c->d_Y.n < ny) c->d_Y.alloc(ny);
     if (c->d_near_partials.n < static_cast<size_t>(16) * c->Dpad) c->d_near_partials.alloc(static_cast<size_t>(16) * c->Dpad);
+    if (c->d_tile_counter.n < static_cast<size_t>(c->ntiles)) {  // arrival counters of wide_step_kernel, zero between launches
+        c->d_tile_counter.alloc(static_cast<size_t>(c->ntiles));
+        HC_HIP(hipMemset(c->d_tile_counter.p, 0, static_cast<size_t>(c->ntiles) * sizeof(int)));
+    }
 }
 
 // ---- TaperedDirect ----------------------------------------------------------------------------
@@ -600,6 +604,8 @@ void setup_direct(hc_ctx* c) {
     c->dk_finalize = q->find("finalize_kernelILi4EEEv");
     c->dk_scatter  = q->find("scatter_kernelE");
     c->dk_near     = q->find("near_split_kernelE");
+    c->dk_wide     = q->find("wide_step_kernelE");  // optional: without it a wide step is near_split_kernel + finalize_kernel
+    if (c->dk_wide.kernarg != sizeof(hc::WideStepArgs) || c->dk_wide.priv != 0) c->dk_wide = hc::DirectKernel{};
     c->dk_reduce   = q->find("reduce_block_kernelE");
     c->dk_added_mass = q->find("added_mass_mv_tagged_kernelE");  // optional: hc_added_mass_mv falls back to a HIP launch
     {   // the plain per-step convolution of this context's tiling; optional: without it plain steps go through HIP launches
@@ -656,7 +662,8 @@ void setup_direct(hc_ctx* c) {
         c->direct_why = "added_mass_mv_tagged_kernel is missing from hc_kernels.co";
         return;
     }
-    static_assert(sizeof(hc::NearArgs) <= hc::DirectQueue::kSlotBytes, "an argument block does not fit a kernarg slot of the direct queue");
+    static_assert(sizeof(hc::NearArgs) <= hc::DirectQueue::kSlotBytes && sizeof(hc::WideStepArgs) <= hc::DirectQueue::kSlotBytes,
+                  "an argument block does not fit a kernarg slot of the direct queue");
     static_assert(sizeof(hc::ScatterArgs) <= hc::DirectQueue::kSlotBytes && sizeof(hc::FinalizeArgs) <= hc::DirectQueue::kSlotBytes &&
                       sizeof(hc::BlockArgs) <= hc::DirectQueue::kSlotBytes && sizeof(hc::StepArgs) <= hc::DirectQueue::kSlotBytes,
                   "an argument block does not fit a kernarg slot of the direct queue");

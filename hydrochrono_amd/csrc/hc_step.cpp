@@ -479,6 +479,27 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         na.state    = d_state;
         na.ring_v   = c->d_ring_v.p;
         na.partials = c->d_near_partials.p;
+        // ... in ONE launch with the step kernel (wide_step_kernel: the workgroup that completes a row tile's slices finishes the tile):
+        // a dispatch less on the critical path of every block step.  HC_WIDE_FUSED=0: the two launches (same arithmetic, bitwise).
+        // Only while the launch is ONE round of workgroups (218 VGPRs: two per CU): a C4/8 shard has 24 tiles x 8 slices = 192; the
+        // whole 512-body array on one GPU has 1536, runs them in three rounds and is faster with the two launches (23 against 32 us).
+        static const bool fused_on = env_int("HC_WIDE_FUSED", 1) != 0;
+        const long long wide_wgs   = static_cast<long long>(c->ntiles) * hc::near_slices_for(c->D);
+        if (fused_on && !f.scratch_out && wide_wgs <= 2LL * c->num_cus && c->d_tile_counter.n >= static_cast<size_t>(c->ntiles) && (!direct || c->dk_wide.ok())) {
+            hc::WideStepArgs w{na, z, c->d_tile_counter.p};
+            if (direct) {
+                const hc::WideLaunch l = hc::wide_launch_config(w);
+                c->dq->dispatch(c->dk_wide, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &w, sizeof w, direct_tag(c, hc::kEvStep));
+                c->prof.direct_dispatches += 1;
+            } else {
+                hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
+                hc::launch_wide_step(w, stream);
+                ev_end(ev, stream);
+                c->prof.hip_launches += 1;
+            }
+            c->prof.wide_fused_steps += 1;
+            goto step_kernel_out;
+        }
         if (direct) {
             const hc::NearLaunch l = hc::near_launch_config(na);
             c->dq->dispatch(c->dk_near, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &na, sizeof na, direct_tag(c, hc::kEvStep));
@@ -504,6 +525,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         c->prof.hip_launches += 1;
         ev_end(ev, stream);
     }
+step_kernel_out:
 
     // ---- off the caller's critical path: what later steps need from this one (enqueue_tail) ----
     c->tail              = hc::StepTail{};

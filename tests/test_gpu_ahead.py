@@ -419,3 +419,52 @@ def test_narrow_short_pass_is_bitwise_the_wide_one(hydro, schedule, direct, monk
     assert np.array_equal(runs[0], runs[1])
     for n, tt in enumerate(times):
         assert relerr(runs[0][n], orc.step(tt, *motion.state(tt))) <= TIGHT_TOL, f"step {n}"
+
+
+@pytest.mark.parametrize("direct", [1, 0], ids=["aql", "hip"])
+def test_wide_step_in_one_launch_is_bitwise_the_two_launch_form(hydro, direct, monkeypatch):
+    """A block step of a wide system (D >= 1024) is ONE launch by default (wide_step_kernel: column slices of the own-sample part, then
+    the workgroup that arrives last at a row tile's counter runs the tile's step kernel; the hand-off across XCDs uses agent-scope atomic
+    stores / loads of the partials and no fence); HC_WIDE_FUSED=0 keeps near_split_kernel + finalize_kernel.  The slices are added in
+    slice order from memory either way: bitwise the same forces over 400 steps incl. a step-size change, and on the oracle."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_DIRECT", str(direct))
+    N = 176  # D = 1056
+    case = many_body_case(N, S=48, dt_rirf=0.02, n_exc=17, dt_exc=0.05, seed=1057)
+    orc = load_into_oracle(case)
+    kw = dict(WAVES, simulation_duration=6.0)
+    orc.add_waves_irregular(**kw)
+    motion = PrescribedMotion(N, rest_positions(case), seed=5)
+    times, t = [], 0.0
+    for n in range(400):
+        times.append(t)
+        t += 0.01 if n < 250 else 0.0073
+    import subprocess, sys, json  # the switch is read once per process: the two forms run in processes of their own
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import hydrochrono_amd.hydro as hydro\n"
+        "from hydrochrono_amd.mock_chrono import PrescribedMotion\n"
+        "from hydrochrono_amd.synthetic import many_body_case, rest_positions\n"
+        "case = many_body_case(176, S=48, dt_rirf=0.02, n_exc=17, dt_exc=0.05, seed=1057)\n"
+        "gpu = hydro.HydroForces.from_case(case)\n"
+        "gpu.add_waves_irregular(**%r)\n"
+        "motion = PrescribedMotion(176, rest_positions(case), seed=5)\n"
+        "f = np.stack([gpu.step(t, *motion.state(t)) for t in %r])\n"
+        "np.save(sys.argv[1], f)\n"
+        "print(gpu.profile()['wide_fused_steps'])\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), kw, times)
+    runs, counts = [], []
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for fused in ("1", "0"):
+            out = os.path.join(d, f"f{fused}.npy")
+            r = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, env=dict(os.environ, HC_WIDE_FUSED=fused, HC_DIRECT=str(direct)))
+            assert r.returncode == 0, r.stderr[-2000:]
+            counts.append(int(r.stdout.strip().splitlines()[-1]))
+            runs.append(np.load(out))
+    assert counts[0] >= 300 and counts[1] == 0, counts
+    assert np.array_equal(runs[0], runs[1])
+    for n, tt in enumerate(times):
+        assert relerr(runs[0][n], orc.step(tt, *motion.state(tt))) <= TIGHT_TOL, f"step {n}"

@@ -6,10 +6,13 @@
 // `using namespace hydroc_amd;` -- the wave set-up lines stay as they are (demos/sphere/demo_sphere_reg_waves.cpp:126-128,
 // tests/regression/sphere/irreg_waves/sphere_irreg_waves_test.cpp:113-122).
 //
-// Not mirrored (off the force path): GetElevation / GetVelocity / GetAcceleration (wave kinematics), the free-surface
-// mesh helpers, eta_file_path_ (undefined behaviour in the reference, src/wave_types.cpp:480-500 vs :784-785).
+// Not mirrored (off the force path): GetElevation / GetVelocity / GetAcceleration (wave kinematics), eta_file_path_
+// (undefined behaviour in the reference, src/wave_types.cpp:480-500 vs :784-785).  The mesh helper the irregular demos call
+// (SetUpWaveMesh / GetMeshFile / GetWaveMeshVelocity) is there so that they compile.
 #pragma once
 
+#include <array>
+#include <cstdio>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -130,6 +133,28 @@ class IrregularWaves : public WaveBase {  // :294-380
     std::vector<double> GetFreeSurfaceElevation() { return table(false); }
     std::vector<double> GetFreeSurfaceTime() const { return table(true); }
     std::vector<double> GetFrequenciesHz() const { return spectrum(0); }
+    // Visualisation helper the reference's irregular-wave demos call (demos/sphere/demo_sphere_irreg_waves.cpp:144-153,
+    // src/wave_types.cpp:846-864): the free-surface elevation over the simulated time as a Wavefront OBJ ribbon (x = -t, y = -10 / +10,
+    // z = eta(t)) that the demo drags past the body with GetWaveMeshVelocity().  Off the force path; written from the eta(t) table the
+    // force path uses, against the table's own time stamps (t >= 0).
+    void SetUpWaveMesh(std::string filename = "fse_mesh.obj") {
+        mesh_file_name_ = std::move(filename);
+        const std::vector<double> t = table(true), eta = table(false);
+        std::FILE* out = std::fopen(mesh_file_name_.c_str(), "w");
+        if (!out) throw std::runtime_error("SetUpWaveMesh: cannot write " + mesh_file_name_);
+        std::fprintf(out, "# free-surface elevation ribbon (hydroc_amd)\n");
+        size_t n = 0;
+        for (size_t i = 0; i < t.size(); ++i) {
+            if (t[i] < 0.0 || t[i] > params_.simulation_duration_) continue;
+            std::fprintf(out, "v %.6f %.6f %.6f\nv %.6f %.6f %.6f\n", -t[i], -10.0, eta[i], -t[i], 10.0, eta[i]);
+            ++n;
+        }
+        for (size_t i = 0; i + 1 < n; ++i)  // two triangles per step of the ribbon (OBJ indices are 1-based)
+            std::fprintf(out, "f %zu %zu %zu\nf %zu %zu %zu\n", 2 * i + 1, 2 * i + 2, 2 * i + 4, 2 * i + 1, 2 * i + 4, 2 * i + 3);
+        std::fclose(out);
+    }
+    std::string GetMeshFile() { return mesh_file_name_; }
+    std::array<double, 3> GetWaveMeshVelocity() { return {1.0, 0.0, 0.0}; }  // (an Eigen::Vector3d in the reference; ChVector3d(v[0], v[1], v[2]))
 
   private:
     std::vector<double> spectrum(int which) const {
@@ -153,6 +178,7 @@ class IrregularWaves : public WaveBase {  // :294-380
         if (!ctx_) throw std::runtime_error("IrregularWaves is not attached to a TestHydro");
     }
     IrregularWaveParams params_;
+    std::string mesh_file_name_;
 };
 
 }  // namespace hydroc_amd

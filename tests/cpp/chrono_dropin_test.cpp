@@ -137,6 +137,9 @@ int main(int argc, char** argv) {
                 auto irreg = std::static_pointer_cast<IrregularWaves>(wave_ptr);
                 std::printf("IRREG %zu %zu %zu %zu\n", irreg->GetFrequenciesHz().size(), irreg->GetSpectrum().size(),
                             irreg->GetFreeSurfaceTime().size(), irreg->GetFreeSurfaceElevation().size());
+                // the visualisation lines of demos/sphere/demo_sphere_irreg_waves.cpp:144-153
+                irreg->SetUpWaveMesh(hydro_file + ".fse_mesh.obj");
+                std::printf("MESH %s %.1f\n", irreg->GetMeshFile().c_str(), irreg->GetWaveMeshVelocity()[0]);
             }
             std::printf("RIRF %.17g\n", test_hydro->GetRIRFval(2, 2, 1));
             return report(system, sphereBody);

@@ -160,6 +160,10 @@ def test_runner_yaml_lines_regular_and_irregular(dropin, tmp_path):
     traj, tags = run(dropin, "yaml", y, 600, -2.0, 0.0)
     nf, ns, nt, ne = (int(x) for x in tags["IRREG"])
     assert nf == ns == 40 and nt == ne and nt > 2667
+    # SetUpWaveMesh / GetMeshFile / GetWaveMeshVelocity (the irregular demos' visualisation lines): a ribbon of eta(t), t in [0, 40 s]
+    mesh = open(tags["MESH"][0]).read().splitlines()
+    nv, nfaces = sum(ln.startswith("v ") for ln in mesh), sum(ln.startswith("f ") for ln in mesh)
+    assert nv == 2 * 2667 and nfaces == 2 * (2667 - 1) and float(tags["MESH"][1]) == 1.0
     assert np.all(np.isfinite(traj)) and np.ptp(traj[:, 1]) > 1e-3
 
 

@@ -767,6 +767,8 @@ void step_end(hc_ctx* c, double* force_out) {
 void step_abort(hc_ctx* c) {
     c->pending_step = 0;
     c->tail.pending = false;
+    c->step_canary_in  = nullptr;  // (a begin that threw before its enqueue_step consumed them)
+    c->step_canary_out = nullptr;
 }
 
 extern "C++" {

@@ -83,7 +83,7 @@ def build(force=False, verbose=False):
         subprocess.run(cmd, check=True)
     h5 = _find_hdf5()
     bemio_src = os.path.join(CSRC, "hc_bemio.cpp")
-    if h5 and (force or _newer(BEMIO_LIB, [bemio_src, MAIN_LIB])):
+    if h5 and (force or _newer(BEMIO_LIB, [bemio_src, os.path.join(CSRC, "hc_h5data.hpp"), MAIN_LIB])):
         inc, lib = h5
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", bemio_src, "-o", BEMIO_LIB, "-I", inc, "-I", os.path.join(ROOT, "include"),
                "-L", lib, "-lhdf5", "-L", LIBDIR, "-lhydrochrono_amd", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{lib}"]

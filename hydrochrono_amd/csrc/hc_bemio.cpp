@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/hydrochrono_amd.h"
+#include "hc_h5data.hpp"
 
 namespace {
 
@@ -88,44 +89,69 @@ void ok(hc_ctx* ctx, int rc) {
 
 }  // namespace
 
+// The file's content for body1 .. bodyN, with the shape checks of the reader (src/h5fileinfo.cpp:35-90, 287-294).
+extern "C" int hc_bemio_read(const char* path, int N, hc_h5data* out, char* err, size_t errlen) {
+    try {
+        if (N <= 0) throw H5Error("num_bodies must be positive");
+        File f(path);
+        out->rho         = read_scalar(f.id, "simulation_parameters/rho");
+        out->g           = read_scalar(f.id, "simulation_parameters/g");
+        out->water_depth = read_scalar(f.id, "simulation_parameters/water_depth");
+        out->w           = read_doubles(f.id, "simulation_parameters/w");
+        const size_t nw  = out->w.size();
+        const int D      = 6 * N;
+        out->bodies.assign(static_cast<size_t>(N), hc_h5data::Body{});
+        for (int b = 0; b < N; ++b) {
+            hc_h5data::Body& q     = out->bodies[static_cast<size_t>(b)];
+            const std::string body = "body" + std::to_string(b + 1);
+            q.disp_vol       = read_scalar(f.id, body + "/properties/disp_vol");
+            const auto cg    = read_doubles(f.id, body + "/properties/cg");
+            const auto cb    = read_doubles(f.id, body + "/properties/cb");
+            if (cg.size() < 3 || cb.size() < 3) throw H5Error(body + ": cg/cb must have 3 entries");
+            const auto lin = read_doubles(f.id, body + "/hydro_coeffs/linear_restoring_stiffness");
+            if (lin.size() != 36) throw H5Error(body + ": linear_restoring_stiffness must be 6x6");
+            for (int k = 0; k < 3; ++k) {
+                q.cg[k] = cg[static_cast<size_t>(k)];
+                q.cb[k] = cb[static_cast<size_t>(k)];
+            }
+            for (int k = 0; k < 36; ++k) q.lin[k] = lin[static_cast<size_t>(k)];
+            q.ainf = read_doubles(f.id, body + "/hydro_coeffs/added_mass/inf_freq");
+            if (q.ainf.size() != static_cast<size_t>(6) * D) throw H5Error(body + ": added_mass/inf_freq must be 6 x 6N");
+            q.rirf_t = read_doubles(f.id, body + "/hydro_coeffs/radiation_damping/impulse_response_fun/t");
+            std::vector<hsize_t> kd;
+            q.K = read_doubles(f.id, body + "/hydro_coeffs/radiation_damping/impulse_response_fun/K", &kd);
+            if (kd.size() != 3 || kd[0] != 6 || kd[1] != static_cast<hsize_t>(D) || kd[2] != q.rirf_t.size())
+                throw H5Error(body + ": impulse_response_fun/K must be {6, 6N, len(t)}");
+            q.mag   = read_doubles(f.id, body + "/hydro_coeffs/excitation/mag");
+            q.phase = read_doubles(f.id, body + "/hydro_coeffs/excitation/phase");
+            if (q.mag.size() != 6 * nw || q.phase.size() != 6 * nw) throw H5Error(body + ": excitation mag/phase must be {6,1,len(w)}");
+            q.exc_t = read_doubles(f.id, body + "/hydro_coeffs/excitation/impulse_response_fun/t");
+            q.exc_f = read_doubles(f.id, body + "/hydro_coeffs/excitation/impulse_response_fun/f");
+            if (q.exc_f.size() != 6 * q.exc_t.size()) throw H5Error(body + ": excitation impulse_response_fun/f must be {6,1,len(t)}");
+        }
+    } catch (const std::exception& e) {
+        if (err && errlen) std::snprintf(err, errlen, "%s", e.what());
+        return HC_ERR_RUNTIME;
+    }
+    return HC_OK;
+}
+
 extern "C" int hc_bemio_load(hc_ctx* ctx, const char* path, char* err, size_t errlen) {
     try {
         int N = 0;
         ok(ctx, hc_get_sizes(ctx, &N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
-        File f(path);
-        const double rho   = read_scalar(f.id, "simulation_parameters/rho");
-        const double g     = read_scalar(f.id, "simulation_parameters/g");
-        const double depth = read_scalar(f.id, "simulation_parameters/water_depth");
-        ok(ctx, hc_set_simulation_parameters(ctx, rho, g, depth));
-        const std::vector<double> w = read_doubles(f.id, "simulation_parameters/w");
-        const int D = 6 * N;
+        hc_h5data d;
+        const int rc = hc_bemio_read(path, N, &d, err, errlen);
+        if (rc != HC_OK) return rc;
+        ok(ctx, hc_set_simulation_parameters(ctx, d.rho, d.g, d.water_depth));
         for (int b = 0; b < N; ++b) {
-            const std::string body = "body" + std::to_string(b + 1);
-            const double vol = read_scalar(f.id, body + "/properties/disp_vol");
-            const auto cg    = read_doubles(f.id, body + "/properties/cg");
-            const auto cb    = read_doubles(f.id, body + "/properties/cb");
-            if (cg.size() < 3 || cb.size() < 3) throw H5Error(body + ": cg/cb must have 3 entries");
-            ok(ctx, hc_set_body_properties(ctx, b, vol, cg.data(), cb.data()));
-            const auto lin = read_doubles(f.id, body + "/hydro_coeffs/linear_restoring_stiffness");
-            if (lin.size() != 36) throw H5Error(body + ": linear_restoring_stiffness must be 6x6");
-            ok(ctx, hc_set_hydrostatic_stiffness(ctx, b, lin.data()));
-            const auto ainf = read_doubles(f.id, body + "/hydro_coeffs/added_mass/inf_freq");
-            if (ainf.size() != static_cast<size_t>(6) * D) throw H5Error(body + ": added_mass/inf_freq must be 6 x 6N");
-            ok(ctx, hc_set_added_mass_inf(ctx, b, ainf.data()));
-            const auto t = read_doubles(f.id, body + "/hydro_coeffs/radiation_damping/impulse_response_fun/t");
-            std::vector<hsize_t> kd;
-            const auto K = read_doubles(f.id, body + "/hydro_coeffs/radiation_damping/impulse_response_fun/K", &kd);
-            if (kd.size() != 3 || kd[0] != 6 || kd[1] != static_cast<hsize_t>(D) || kd[2] != t.size())
-                throw H5Error(body + ": impulse_response_fun/K must be {6, 6N, len(t)}");
-            ok(ctx, hc_set_rirf(ctx, b, t.data(), static_cast<int>(t.size()), K.data()));
-            const auto mag = read_doubles(f.id, body + "/hydro_coeffs/excitation/mag");
-            const auto ph  = read_doubles(f.id, body + "/hydro_coeffs/excitation/phase");
-            if (mag.size() != 6 * w.size() || ph.size() != 6 * w.size()) throw H5Error(body + ": excitation mag/phase must be {6,1,len(w)}");
-            ok(ctx, hc_set_excitation_rao(ctx, b, w.data(), static_cast<int>(w.size()), mag.data(), ph.data()));
-            const auto et = read_doubles(f.id, body + "/hydro_coeffs/excitation/impulse_response_fun/t");
-            const auto ef = read_doubles(f.id, body + "/hydro_coeffs/excitation/impulse_response_fun/f");
-            if (ef.size() != 6 * et.size()) throw H5Error(body + ": excitation impulse_response_fun/f must be {6,1,len(t)}");
-            ok(ctx, hc_set_excitation_irf(ctx, b, et.data(), static_cast<int>(et.size()), ef.data()));
+            const hc_h5data::Body& q = d.bodies[static_cast<size_t>(b)];
+            ok(ctx, hc_set_body_properties(ctx, b, q.disp_vol, q.cg, q.cb));
+            ok(ctx, hc_set_hydrostatic_stiffness(ctx, b, q.lin));
+            ok(ctx, hc_set_added_mass_inf(ctx, b, q.ainf.data()));
+            ok(ctx, hc_set_rirf(ctx, b, q.rirf_t.data(), static_cast<int>(q.rirf_t.size()), q.K.data()));
+            ok(ctx, hc_set_excitation_rao(ctx, b, d.w.data(), static_cast<int>(d.w.size()), q.mag.data(), q.phase.data()));
+            ok(ctx, hc_set_excitation_irf(ctx, b, q.exc_t.data(), static_cast<int>(q.exc_t.size()), q.exc_f.data()));
         }
     } catch (const std::exception& e) {
         if (err && errlen) std::snprintf(err, errlen, "%s", e.what());

@@ -1,6 +1,7 @@
 // hc_setup.cpp -- lifecycle, ingest (H5FileInfo::ReadH5Data scaling rules), hc_finalize, wave models and configuration, synthetic
 // many-body inputs: the init-time half of the C ABI.
 #include "hc_internal.hpp"
+#include "hc_h5data.hpp"
 
 using namespace hc::detail;
 
@@ -247,6 +248,103 @@ bemio_fn_t bemio_symbol(const char* name) {
     return fn;
 }
 }  // namespace
+
+// ---- the file without a device context (include/hydroc_amd/h5fileinfo.h) ----
+extern "C++" {
+namespace {
+template <class F>
+int h5_guard(F&& f) {
+    try {
+        f();
+    } catch (const Error& e) {
+        g_create_error = e.what();
+        return e.status;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return HC_ERR_RUNTIME;
+    }
+    return HC_OK;
+}
+const hc_h5data::Body& h5_body(const hc_h5data* d, int body) {
+    require(d != nullptr, HC_ERR_INVALID, "null data");
+    if (body < 0 || body >= static_cast<int>(d->bodies.size())) throw Error(HC_ERR_OUT_OF_RANGE, "body index out of range");
+    return d->bodies[static_cast<size_t>(body)];
+}
+void copy_out(double* dst, const std::vector<double>& src, double scale = 1.0) {
+    if (!dst) return;
+    for (size_t k = 0; k < src.size(); ++k) dst[k] = src[k] * scale;
+}
+}  // namespace
+}  // extern "C++"
+
+int hc_h5_read(const char* path, int num_bodies, hc_h5data** out) {
+    if (!out) return HC_ERR_INVALID;
+    *out = nullptr;
+    return h5_guard([&] {
+        require(path, HC_ERR_INVALID, "null path");
+        require(num_bodies > 0, HC_ERR_INVALID, "num_bodies must be positive");
+        using read_fn_t = int (*)(const char*, int, hc_h5data*, char*, size_t);
+        const read_fn_t fn = reinterpret_cast<read_fn_t>(bemio_symbol("hc_bemio_read"));
+        std::unique_ptr<hc_h5data> d(new hc_h5data);
+        char msg[1024] = {0};
+        const int rc = fn(path, num_bodies, d.get(), msg, sizeof msg);
+        if (rc != HC_OK) throw Error(rc, msg[0] ? std::string(msg) : std::string("cannot read ") + path);
+        *out = d.release();
+    });
+}
+
+void hc_h5_free(hc_h5data* data) { delete data; }
+
+int hc_h5_get_sizes(const hc_h5data* d, int* num_bodies, double* rho, double* g, double* water_depth, int body, int* S, int* nw, int* L) {
+    return h5_guard([&] {
+        require(d != nullptr, HC_ERR_INVALID, "null data");
+        if (num_bodies) *num_bodies = static_cast<int>(d->bodies.size());
+        if (rho) *rho = d->rho;
+        if (g) *g = d->g;
+        if (water_depth) *water_depth = d->water_depth;
+        if (S || nw || L) {
+            const hc_h5data::Body& q = h5_body(d, body);
+            if (S) *S = static_cast<int>(q.rirf_t.size());
+            if (nw) *nw = static_cast<int>(d->w.size());
+            if (L) *L = static_cast<int>(q.exc_t.size());
+        }
+    });
+}
+
+int hc_h5_get_body(const hc_h5data* d, int body, double* disp_vol, double cg[3], double cb[3], double lin[36], double* ainf_6xD, double* rirf_t_S) {
+    return h5_guard([&] {
+        const hc_h5data::Body& q = h5_body(d, body);
+        if (disp_vol) *disp_vol = q.disp_vol;
+        for (int k = 0; k < 3; ++k) {
+            if (cg) cg[k] = q.cg[k];
+            if (cb) cb[k] = q.cb[k];
+        }
+        if (lin) std::copy(q.lin, q.lin + 36, lin);
+        copy_out(ainf_6xD, q.ainf, d->rho);  // src/h5fileinfo.cpp:60-61
+        copy_out(rirf_t_S, q.rirf_t);
+    });
+}
+
+int hc_h5_get_rirf(const hc_h5data* d, int body, double* K) {
+    return h5_guard([&] { copy_out(K, h5_body(d, body).K); });
+}
+
+int hc_h5_get_excitation_rao(const hc_h5data* d, int body, double* w, double* mag, double* phase) {
+    return h5_guard([&] {
+        const hc_h5data::Body& q = h5_body(d, body);
+        copy_out(w, d->w);
+        copy_out(mag, q.mag, d->rho * d->g);  // :73-75
+        copy_out(phase, q.phase);
+    });
+}
+
+int hc_h5_get_excitation_irf(const hc_h5data* d, int body, double* t, double* f) {
+    return h5_guard([&] {
+        const hc_h5data::Body& q = h5_body(d, body);
+        copy_out(t, q.exc_t);
+        copy_out(f, q.exc_f, d->rho * d->g);  // :89-90
+    });
+}
 
 int hc_load_bemio_h5(hc_ctx* c, const char* path) {
     HC_API_BEGIN(c)

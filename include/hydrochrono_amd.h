@@ -74,6 +74,24 @@ int hc_set_excitation_irf(hc_ctx* ctx, int body, const double* t, int n, const d
 /* Reads all of the above for bodies "body1".."bodyN" from a BEMIO HDF5 file (needs libhdf5 at build
  * time, else HC_ERR_UNSUPPORTED). */
 int hc_load_bemio_h5(hc_ctx* ctx, const char* path);
+/* The same file WITHOUT a device context: H5FileInfo(path, num_bodies).ReadH5Data() (include/hydroc/h5fileinfo.h:230-260,
+ * src/h5fileinfo.cpp:27-153) for callers that only want to look at the data (the reference's tests/h5fileinfo_t01.cpp,
+ * chloadaddedmass_t01.cpp; the C++ face is include/hydroc_amd/h5fileinfo.h).  Host side only, no GPU is touched.  Values come back as the
+ * reference's HydroData holds them: added mass x rho (:60-61), excitation magnitude x rho g (:73-75), excitation IRF x rho g (:89-90);
+ * K, the stiffness matrix and everything else as in the file.  Errors: status code + hc_last_error(NULL). */
+typedef struct hc_h5data hc_h5data;
+int hc_h5_read(const char* path, int num_bodies, hc_h5data** out);
+void hc_h5_free(hc_h5data* data);
+/* S radiation samples, nw RAO frequencies, L excitation-IRF samples of (0-based) body `body`; any pointer may be NULL */
+int hc_h5_get_sizes(const hc_h5data* data, int* num_bodies, double* rho, double* g, double* water_depth, int body, int* S, int* nw, int* L);
+/* HydroData::BodyInfo (include/hydroc/h5fileinfo.h:37-47); ainf is {6, 6N} row-major, rirf_t has S entries; any pointer may be NULL */
+int hc_h5_get_body(const hc_h5data* data, int body, double* disp_vol, double cg[3], double cb[3], double lin[36], double* ainf_6xD, double* rirf_t_S);
+/* bodyK/.../impulse_response_fun/K in file order {6, 6N, S} (HydroData::GetRIRFVal(b, dof, col, s), src/h5fileinfo.cpp:321-323) */
+int hc_h5_get_rirf(const hc_h5data* data, int body, double* K_6xDxS);
+/* HydroData::RegularWaveInfo (:56-60): freq_list {nw}, magnitude {6, nw} x rho g, phase {6, nw} */
+int hc_h5_get_excitation_rao(const hc_h5data* data, int body, double* w_nw, double* mag_6xnw, double* phase_6xnw);
+/* HydroData::IrregularWaveInfo (:61-72): excitation_irf_time {L}, excitation_irf_matrix {6, L} x rho g */
+int hc_h5_get_excitation_irf(const hc_h5data* data, int body, double* t_L, double* f_6xL);
 /* End of ingest = rest of the TestHydro constructor (src/hydro_forces.cpp:176-238): trapezoid widths,
  * equilibrium, cb-cg, K re-laid-out into HBM, added-mass assembly (src/chloadaddedmass.cpp:12-25),
  * default NoWave. */

@@ -47,7 +47,7 @@ def test_adapter_block_compiles_and_links(tmp_path, name):
 
 def test_headers_are_self_contained(tmp_path):
     """Every header of include/hydroc_amd/ compiles on its own, with and without Chrono, in either include order."""
-    headers = ["wave_types.h", "hydro_types.h", "hydro_yaml_parser.h", "hydro_forces.h", "chloadaddedmass.h", "setup_hydro_from_yaml.h"]
+    headers = ["wave_types.h", "hydro_types.h", "hydro_yaml_parser.h", "hydro_forces.h", "chloadaddedmass.h", "setup_hydro_from_yaml.h", "h5fileinfo.h"]
     for with_chrono in (False, True):
         for h in headers + ["chloadaddedmass.h+hydro_forces.h"]:
             src = tmp_path / "one.cpp"

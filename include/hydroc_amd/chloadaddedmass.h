@@ -4,6 +4,7 @@
 // TestHydro constructor; included by hydro_forces.h (needs Project Chrono, or the stand-in headers of tests/cpp/chrono_stub).
 #pragma once
 
+#include "h5fileinfo.h"
 #include "hydro_forces.h"
 
 #ifdef HYDROCHRONO_AMD_WITH_CHRONO
@@ -16,6 +17,41 @@ class ChLoadAddedMass : public chrono::ChLoadCustomMultiple {
         : chrono::ChLoadCustomMultiple(bodies), hydro_(hydro), system_(system) {
         const int D  = 6 * hydro_->num_bodies();
         const auto M = hydro_->GetAddedMassMatrix();
+        infinite_added_mass_.setZero(D, D);
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) infinite_added_mass_(i, j) = M[static_cast<size_t>(i) * D + j];
+        infinite_added_mass_system_ = infinite_added_mass_;
+    }
+    // The reference's public constructor (include/hydroc/chloadaddedmass.h:33-35, src/chloadaddedmass.cpp:12-25; used on its own by
+    // tests/chloadaddedmass_t01.cpp:44-58): the per-body chunks of a file read with H5FileInfo.  The load owns a small device context
+    // that holds nothing but the stacked 6N x 6N matrix (inf_added_mass is rho-scaled already, so the context's rho is 1; its radiation
+    // kernel is two zero samples and is never evaluated), and `R += c*M*w` runs there.
+    ChLoadAddedMass(const std::vector<HydroData::BodyInfo>& user_h5_body_data, std::vector<std::shared_ptr<chrono::ChLoadable>>& bodies,
+                    chrono::ChSystem* system, int device_id = 0)
+        : chrono::ChLoadCustomMultiple(bodies), hydro_(nullptr), system_(system) {
+        const int N = static_cast<int>(user_h5_body_data.size());
+        if (N <= 0) throw std::runtime_error("ChLoadAddedMass: no body data");
+        const int D  = 6 * N;
+        hc_ctx* raw  = nullptr;
+        if (hc_create(N, device_id, &raw) != HC_OK) throw std::runtime_error(hc_last_error(nullptr));
+        own_ctx_ = std::shared_ptr<hc_ctx>(raw, [](hc_ctx* c) { hc_destroy(c); });
+        check(raw, hc_set_simulation_parameters(raw, 1.0, 9.81, 0.0));
+        const double t2[2] = {0.0, 1.0};
+        const std::vector<double> k0(static_cast<size_t>(6) * D * 2, 0.0);
+        for (int b = 0; b < N; ++b) {
+            const HydroData::BodyInfo& q = user_h5_body_data[static_cast<size_t>(b)];
+            if (q.inf_added_mass.rows() != 6 || q.inf_added_mass.cols() != D || q.cg.size() < 3 || q.cb.size() < 3 || q.lin_matrix.rows() != 6 ||
+                q.lin_matrix.cols() != 6)
+                throw std::runtime_error("ChLoadAddedMass: body data of body " + std::to_string(b) + " does not have the shapes of a " +
+                                         std::to_string(N) + "-body file");
+            check(raw, hc_set_body_properties(raw, b, q.disp_vol, q.cg.data(), q.cb.data()));
+            check(raw, hc_set_hydrostatic_stiffness(raw, b, q.lin_matrix.data()));
+            check(raw, hc_set_added_mass_inf(raw, b, q.inf_added_mass.data()));
+            check(raw, hc_set_rirf(raw, b, t2, 2, k0.data()));
+        }
+        check(raw, hc_finalize(raw));
+        std::vector<double> M(static_cast<size_t>(D) * D);
+        check(raw, hc_added_mass_matrix(raw, M.data()));
         infinite_added_mass_.setZero(D, D);
         for (int i = 0; i < D; ++i)
             for (int j = 0; j < D; ++j) infinite_added_mass_(i, j) = M[static_cast<size_t>(i) * D + j];
@@ -39,12 +75,14 @@ class ChLoadAddedMass : public chrono::ChLoadCustomMultiple {
     // :55-70: R += c * M * w
     void LoadIntLoadResidual_Mv(chrono::ChVectorDynamic<>& R, const chrono::ChVectorDynamic<>& w, const double c) override {
         if (!this->m_jacobians) return;
-        hydro_->AddedMassMv(R.data(), w.data(), c, static_cast<int>(R.size()));
+        if (hydro_) hydro_->AddedMassMv(R.data(), w.data(), c, static_cast<int>(R.size()));
+        else check(own_ctx_.get(), hc_added_mass_mv(own_ctx_.get(), w.data(), c, R.data(), static_cast<int>(R.size())));
     }
 
   private:
     bool IsStiff() override { return true; }
-    TestHydro* hydro_;
+    TestHydro* hydro_;                 // the object that read the file (the load it creates itself), or null:
+    std::shared_ptr<hc_ctx> own_ctx_;  // ... a context of the load's own (the constructor over HydroData::BodyInfo; clones share it)
     chrono::ChSystem* system_;
     chrono::ChMatrixDynamic<double> infinite_added_mass_, infinite_added_mass_system_;
 };

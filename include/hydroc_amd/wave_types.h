@@ -11,6 +11,7 @@
 // (SetUpWaveMesh / GetMeshFile / GetWaveMeshVelocity) is there so that they compile.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cstdio>
 #include <memory>
@@ -19,6 +20,7 @@
 #include <vector>
 
 #include "../hydrochrono_amd.h"
+#include "../hydrochrono_amd_host.h"
 
 namespace hydroc_amd {
 
@@ -31,6 +33,17 @@ inline void check(hc_ctx* ctx, int rc) {
 }
 
 enum class WaveMode { noWaveCIC = 0, regular = 1, irregular = 2 };  // include/hydroc/wave_types.h:40-47
+
+// The two spectrum helpers the reference's header exports (include/hydroc/wave_types.h:14-20, src/wave_types.cpp:679-715), on the host
+// routine the library itself uses for IrregularWaves (Eigen::VectorXd becomes std::vector<double>): spectral density in m^2/Hz at the
+// frequencies f (Hz), which are sorted in place first, as the reference does (:681).
+inline std::vector<double> JONSWAPSpectrumHz(std::vector<double>& f, double Hs, double Tp, double gamma = 3.3, bool is_normalized = false) {
+    std::sort(f.begin(), f.end());
+    std::vector<double> S(f.size());
+    hc_host_jonswap_spectrum_hz(f.data(), static_cast<int>(f.size()), Hs, Tp, gamma, is_normalized ? 1 : 0, S.data());
+    return S;
+}
+inline std::vector<double> PiersonMoskowitzSpectrumHz(std::vector<double>& f, double Hs, double Tp) { return JONSWAPSpectrumHz(f, Hs, Tp, 1.0, false); }
 
 class WaveBase {  // :52-79
   public:

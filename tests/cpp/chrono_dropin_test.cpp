@@ -13,6 +13,7 @@
 //          chrono_dropin_test regular <sphere.h5> <nsteps> <amplitude> <omega> <pto damping>
 //          chrono_dropin_test yaml    <case.hydro.yaml> <nsteps> <z0> <pto damping> [<device>,<device>...]
 //          chrono_dropin_test api     <sphere.h5> 0
+//          chrono_dropin_test addedmass <file.h5> <num_bodies>       (tests/chloadaddedmass_t01.cpp:44-58: the load built from HydroData)
 // Prints "t z" per step with 9 decimals, then "WIRED <forces on body1> <loads> <system matrix rows>".
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,8 @@
 #include <sstream>
 
 #define HYDROCHRONO_AMD_WITH_CHRONO 1
+#include <hydroc_amd/chloadaddedmass.h>       // reference: <hydroc/chloadaddedmass.h>
+#include <hydroc_amd/h5fileinfo.h>            // reference: <hydroc/h5fileinfo.h>
 #include <hydroc_amd/hydro_forces.h>          // reference: <hydroc/hydro_forces.h>
 #include <hydroc_amd/hydro_yaml_parser.h>     // reference: "hydro_yaml_parser.h"
 #include <hydroc_amd/setup_hydro_from_yaml.h> // reference: "setup_hydro_from_yaml.h"
@@ -143,6 +146,62 @@ int main(int argc, char** argv) {
             }
             std::printf("RIRF %.17g\n", test_hydro->GetRIRFval(2, 2, 1));
             return report(system, sphereBody);
+        }
+        if (mode == "addedmass") {
+            std::string h5fname = argv[2];
+            const size_t nBodies = static_cast<size_t>(nsteps);
+            std::vector<std::shared_ptr<ChBody>> bodies;
+            for (size_t b = 0; b < nBodies; ++b) {
+                bodies.push_back(chrono_types::make_shared<ChBody>());
+                bodies.back()->SetName("body" + std::to_string(b + 1));
+            }
+
+            HydroData infos = H5FileInfo(h5fname, static_cast<int>(nBodies)).ReadH5Data();
+
+            std::shared_ptr<ChLoadAddedMass> my_loadbodyinertia;
+
+            std::vector<std::shared_ptr<ChLoadable>> loadables;
+            for (auto& b : bodies) loadables.push_back(b);
+
+            ChSystem my_system;  // (ChSystemSMC in the reference's test)
+
+            my_loadbodyinertia = chrono_types::make_shared<ChLoadAddedMass>(infos.GetBodyInfos(), loadables, &my_system);
+
+            // ... and what Chrono then does with it, against the load a TestHydro over the same file creates for itself
+            for (auto& b : bodies) my_system.Add(b);
+            my_system.Add(ground);  // 6 more coordinates behind the hydro bodies
+            const long n = my_system.GetNumCoordsVelLevel();
+            my_loadbodyinertia->StubUpdate(n);
+            std::shared_ptr<ChLoadAddedMass> copy(my_loadbodyinertia->Clone());  // (Chrono clones loads; the clone shares the context)
+            copy->StubUpdate(n);
+            TestHydro hydro_forces(bodies, h5fname, std::make_shared<NoWave>(static_cast<int>(nBodies)));
+            auto theirs = my_system.containers.at(0)->loads.at(0);
+            theirs->StubUpdate(n);
+            ChVectorDynamic<> w(n), R1(n), R2(n), R3(n);
+            for (long i = 0; i < n; ++i) {
+                w(i)  = 0.3 * std::sin(1.0 + 0.7 * static_cast<double>(i));
+                R1(i) = R2(i) = R3(i) = 1.0 - 0.01 * static_cast<double>(i);
+            }
+            my_loadbodyinertia->LoadIntLoadResidual_Mv(R1, w, -0.6);
+            theirs->LoadIntLoadResidual_Mv(R2, w, -0.6);
+            copy->LoadIntLoadResidual_Mv(R3, w, -0.6);
+            int same_mv = 1, same_m = 1;
+            for (long i = 0; i < n; ++i) same_mv = same_mv && R1(i) == R2(i) && R1(i) == R3(i);
+            const auto& M1 = my_loadbodyinertia->m_jacobians->M;
+            const auto& M2 = theirs->m_jacobians->M;
+            for (long i = 0; i < n; ++i)
+                for (long j = 0; j < n; ++j) same_m = same_m && M1(i, j) == M2(i, j);
+            std::printf("ADDEDMASS %ld %d %d\n", static_cast<long>(M1.rows()), same_m, same_mv);
+            const long D = 6 * static_cast<long>(nBodies);
+            for (long i = 0; i < D; ++i) {
+                std::printf("ROW");
+                for (long j = 0; j < D; ++j) std::printf(" %.17g", M1(i, j));
+                std::printf("\n");
+            }
+            std::printf("MV");
+            for (long i = 0; i < n; ++i) std::printf(" %.17g", R1(i));
+            std::printf("\nEnd\n");
+            return 0;
         }
         if (mode == "api") {
             // the rest of the surface a reference program may touch: GetWave / GetForceAtTime, the Compute* entry points, GetProfileStats,

@@ -3,6 +3,7 @@
 // written to a flat file of doubles that tests/test_h5fileinfo.py compares with the committed fixtures.  No GPU involved.
 //   h5fileinfo_test <file.h5> <num_bodies> <out.bin>      |      h5fileinfo_test --errors <file.h5>
 #include <hydroc_amd/h5fileinfo.h>
+#include <hydroc_amd/wave_types.h>
 
 #include <cstdio>
 #include <cstring>
@@ -32,6 +33,15 @@ int main(int argc, char* argv[]) {
         } catch (const std::out_of_range& e) {
             std::cout << "RANGE " << e.what() << "\n";
         }
+        return 0;
+    }
+    if (argc >= 2 && std::strcmp(argv[1], "--spectrum") == 0) {
+        // the spectrum helpers of wave_types.h (include/hydroc/wave_types.h:14-20): unsorted input is sorted in place
+        std::vector<double> f = {0.31, 0.05, 0.125, 0.2, 0.08};
+        const auto pm = PiersonMoskowitzSpectrumHz(f, 2.0, 8.0);
+        const auto js = JONSWAPSpectrumHz(f, 2.0, 8.0);
+        const auto jn = JONSWAPSpectrumHz(f, 2.0, 8.0, 2.0, true);
+        for (size_t i = 0; i < f.size(); ++i) std::printf("%.17g %.17g %.17g %.17g\n", f[i], pm[i], js[i], jn[i]);
         return 0;
     }
     if (argc < 4) return 2;

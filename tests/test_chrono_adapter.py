@@ -190,3 +190,32 @@ def test_rest_of_the_surface(dropin):
     assert lines[0] == "THROWS 1 0"
     assert lines[-1].startswith("DUPLICATE") and "twice within the same time step" in lines[-1]
     assert not any(ln.startswith("UNREACHED") for ln in lines)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h5, npz, n", [("sphere.h5", "sphere_bemio.npz", 1), ("three_body.h5", "three_body_bemio.npz", 3)])
+def test_added_mass_load_built_from_hydrodata(dropin, h5, npz, n):
+    """`HydroData infos = H5FileInfo(h5fname, 2).ReadH5Data(); ... chrono_types::make_shared<ChLoadAddedMass>(infos.GetBodyInfos(),
+    loadables, &my_system);` (tests/chloadaddedmass_t01.cpp:44-58): the load on its own.  Its Jacobian block is rho x the file's
+    {6, 6N} blocks stacked (src/chloadaddedmass.cpp:12-25), bitwise the block of the load a TestHydro over the same file creates, and
+    R += c*M*w (on the GPU, through the load's own context; also through a clone) is bitwise that load's and within rounding of numpy."""
+    r = subprocess.run([dropin, "addedmass", os.path.join(GOLDEN_DIR, h5), str(n)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1] == "End"
+    D, nsys = 6 * n, 6 * n + 6
+    assert lines[0].split() == ["ADDEDMASS", str(nsys), "1", "1"]
+    M = np.array([[float(x) for x in ln.split()[1:]] for ln in lines if ln.startswith("ROW")])
+    z = np.load(os.path.join(GOLDEN_DIR, npz))
+    if "rho" in z.files:
+        rho, blocks = float(z["rho"][0]), [z["body1/added_mass_inf_freq"]]
+    else:
+        rho, blocks = float(z["simulation_parameters/rho"]), [z[f"body{b + 1}/hydro_coeffs/added_mass/inf_freq"] for b in range(n)]
+    assert np.array_equal(M, rho * np.vstack(blocks))
+    i = np.arange(nsys)
+    w, R0 = 0.3 * np.sin(1.0 + 0.7 * i), 1.0 - 0.01 * i
+    want = R0.copy()
+    want[:D] += -0.6 * (M @ w[:D])
+    got = np.array([float(x) for x in [ln for ln in lines if ln.startswith("MV")][0].split()[1:]])
+    assert np.array_equal(got[D:], R0[D:])  # coordinates behind the hydro bodies are not touched
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) <= 1e-13

@@ -100,3 +100,21 @@ def test_errors_are_the_reference_exception_types(exe):
     lines = dict(ln.split(" ", 1) for ln in r.stdout.strip().splitlines())
     assert lines["MISSING"].startswith("Unable to open/read HDF5 hydro data file: /nonexistent/dir/nothing.h5")  # src/h5fileinfo.cpp:167-179
     assert "no-throw" not in lines["TOO_MANY"] and "no-throw" not in lines["RANGE"]
+
+
+def test_spectrum_helpers(exe):
+    """PiersonMoskowitzSpectrumHz / JONSWAPSpectrumHz of hydroc_amd/wave_types.h against the formulas of src/wave_types.cpp:679-715
+    (S_PM = 1.25 Tp^-4 (Hs/2)^2 f^-5 exp(-1.25 Tp^-4 f^-4); x gamma^exp(-(f Tp - 1)^2 / (2 sigma^2)), sigma = 0.07 up to 1/Tp, 0.09
+    above; optional x (1 - 0.287 ln gamma)); the frequency vector comes back sorted."""
+    r = subprocess.run([exe, "--spectrum"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    a = np.array([[float(x) for x in ln.split()] for ln in r.stdout.strip().splitlines()])
+    f = a[:, 0]
+    assert list(f) == sorted([0.31, 0.05, 0.125, 0.2, 0.08])
+    Hs, Tp = 2.0, 8.0
+    pm = 1.25 * Tp ** -4 * (Hs / 2) ** 2 * f ** -5.0 * np.exp(-1.25 * Tp ** -4 * f ** -4.0)
+    sigma = np.where(f <= 1 / Tp, 0.07, 0.09)
+    peak = np.exp(-(f * Tp - 1) ** 2 / (2 * sigma ** 2))
+    assert np.allclose(a[:, 1], pm, rtol=1e-14, atol=0)
+    assert np.allclose(a[:, 2], pm * 3.3 ** peak, rtol=1e-14, atol=0)
+    assert np.allclose(a[:, 3], pm * 2.0 ** peak * (1 - 0.287 * np.log(2.0)), rtol=1e-14, atol=0)

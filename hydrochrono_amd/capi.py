@@ -44,7 +44,7 @@ class ProfileStats(C.Structure):
                 ("ahead_pass_slices", C.c_longlong), ("ahead_blocks", C.c_longlong),
                 ("pass_lane_launches", C.c_longlong),
                 ("multi_doorbell_offset_last", C.c_double), ("multi_doorbell_offset_sum", C.c_double), ("multi_calls", C.c_longlong),
-                ("wide_fused_steps", C.c_longlong), ("ring_grows_for_pass", C.c_longlong)]
+                ("slot_state_steps", C.c_longlong), ("wide_fused_steps", C.c_longlong), ("ring_grows_for_pass", C.c_longlong)]
 
 
 # name -> (restype, argtypes); every symbol include/hydrochrono_amd.h declares

@@ -168,6 +168,8 @@ struct hc_ctx {
     bool direct_ready   = false;
     std::string direct_why;  // why the direct path is not in use
     int path            = 0;
+    hc::DirectKernel dk_finalize_slot;  // finalize_kernel<4, true>: the body state behind the argument block (hc_step.cpp: HostState)
+    bool slot_state = false;            // ... in use for this context (HC_SLOT_STATE, systems of up to kSlotStateMaxBodies bodies)
     hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_mini16, dk_mini32, dk_narrow, dk_wide, dk_added_mass, dk_step, dk_near;
     hc::StepTail tail;
     // split step (hc_step_begin / hc_step_end, hc_step_multi): 0 nothing begun, 1 the begun step was a cache hit (totals in

@@ -237,13 +237,13 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
 
     // kernarg ring in device memory the host can store into (same fault-free probe as BarBuffer, hc_runtime.cpp)
     void* q            = nullptr;
-    const size_t bytes = static_cast<size_t>(Impl::kSlots) * kSlotBytes * kLanes;
+    const size_t bytes = static_cast<size_t>(Impl::kSlots) * kSlotStride * kLanes;
     if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
         return fail("no fine-grained device memory for the kernel arguments");
     }
     p.ring_all = static_cast<char*>(q);
-    for (int l = 0; l < kLanes; ++l) p.lanes[l].ring = p.ring_all + static_cast<size_t>(l) * Impl::kSlots * kSlotBytes;
+    for (int l = 0; l < kLanes; ++l) p.lanes[l].ring = p.ring_all + static_cast<size_t>(l) * Impl::kSlots * kSlotStride;
     bool host_ok = false;
     const int fz = open("/dev/zero", O_RDONLY), fn = open("/dev/null", O_WRONLY);
     if (fz >= 0 && fn >= 0)
@@ -304,15 +304,16 @@ DirectKernel DirectQueue::find(const std::string& fragment) const {
 }
 
 void DirectQueue::dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t wg_size, uint32_t dyn_lds, const void* args, size_t arg_bytes,
-                           int timed_tag, double timed_aux, int lane) {
+                           int timed_tag, double timed_aux, int lane, FillExtra fill_extra, void* fill_user) {
     Impl& p            = *p_;
     Impl::Lane& ln     = p.lanes[lane];
     if (arg_bytes > kSlotBytes || k.kernarg > kSlotBytes || arg_bytes > std::max<size_t>(k.kernarg, 1))
         throw std::length_error("DirectQueue::dispatch: the argument block does not fit the kernel's kernarg segment / a ring slot");
     if (failed(lane)) throw std::runtime_error("DirectQueue::dispatch: the queue is in the error state: " + failure_text());
     const uint64_t idx = p.reserve(ln);
-    char* slot         = ln.ring + (idx & (Impl::kSlots - 1)) * kSlotBytes;
+    char* slot         = ln.ring + (idx & (Impl::kSlots - 1)) * kSlotStride;
     std::memcpy(slot, args, arg_bytes);
+    if (fill_extra) fill_extra(slot + kSlotBytes, fill_user);
     if (k.kernarg > arg_bytes) std::memset(slot + arg_bytes, 0, std::min<size_t>(k.kernarg, kSlotBytes) - arg_bytes);
     _mm_sfence();  // write-combined stores through the BAR are globally visible before the doorbell
     auto* pkt = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(ln.queue->base_address) + (idx & (ln.queue->size - 1));

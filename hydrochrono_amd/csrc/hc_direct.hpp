@@ -45,8 +45,13 @@ class DirectQueue {
     // is reported by collect() with this tag.
     // lane: which of the object's independent queues (0: the step path; 1: the added-mass product, which must never wait behind
     // work the step path still runs; 2: look-ahead passes that run beside the steps, see signal_after / wait_for / set_cu_mask).
+    // fill_extra: called with the host address of the kExtraBytes that FOLLOW the slot's argument block (same memory, same store path);
+    // a kernel built for it finds them at its kernarg segment pointer + kSlotBytes -- an address it knows before it has loaded a single
+    // argument, so it can request what the host put there together with its arguments instead of after them (the step kernel's body
+    // state, hc_step.cpp).
+    using FillExtra = void (*)(char* extra, void* user);
     void dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t wg_size, uint32_t dyn_lds, const void* args, size_t arg_bytes,
-                  int timed_tag = -1, double timed_aux = 0.0, int lane = 0);
+                  int timed_tag = -1, double timed_aux = 0.0, int lane = 0, FillExtra fill_extra = nullptr, void* fill_user = nullptr);
     // Parks the lane's packet processor on a barrier packet that waits for a signal; the next dispatch() releases it right after
     // its packet is in the queue.  A queue that has sat EMPTY for more than a few tens of microseconds takes about 6 us longer from
     // doorbell to kernel start (12.2 against 6.0 us launch-to-result for a small kernel after >= 100 us of idle,
@@ -83,7 +88,9 @@ class DirectQueue {
     void collect(const std::function<void(int, double, double)>& sink);
     size_t timed_pending() const;
 
-    static constexpr size_t kSlotBytes = 4096;  // kernarg bytes per dispatch (the largest argument block is the scatter's 2.6 KB)
+    static constexpr size_t kSlotBytes  = 4096;   // kernarg bytes per dispatch (the largest argument block is the scatter's 2.6 KB)
+    static constexpr size_t kExtraBytes = 12288;  // ... followed by room for data the kernel addresses relative to its kernarg pointer
+    static constexpr size_t kSlotStride = kSlotBytes + kExtraBytes;
 
   private:
     struct Impl;

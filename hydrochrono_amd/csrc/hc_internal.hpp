@@ -102,8 +102,13 @@ struct StepFlags {
     bool hs = true, rad = true, waves = true;
     bool scratch_out = false;  // term-only entry points: outputs go to scratch buffers, the last step's components stay
 };
+// The caller's state of a synchronous step, as handed to hc_step (host pointers, valid for the call), and the canary word of the step.
+struct HostState {
+    const double *pos, *rpy, *linvel, *angvel;
+    double canary;
+};
 void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f,
-                  unsigned long long* host_tagged = nullptr, unsigned long long seq = 0, bool defer_tail = false);
+                  unsigned long long* host_tagged = nullptr, unsigned long long seq = 0, bool defer_tail = false, const HostState* host_state = nullptr);
 void enqueue_tail(hc_ctx* c);
 
 // ---- hc_step.cpp helpers the passes use ----

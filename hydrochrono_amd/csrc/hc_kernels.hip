@@ -96,6 +96,31 @@ void launch_extract_series(const Panel& K, int row, int col, int D, int S, doubl
 // ------------------------------------------------------------------------------------------------
 // History access and the bracket search shared by both convolution kernels.
 // ------------------------------------------------------------------------------------------------
+// The argument block of a kernel on the step's critical path, requested whole at entry.  The compiler loads arguments where it needs
+// them, a cache line's worth at a time with a wait each -- the step kernel ran through five such scalar-cache misses one after the other
+// before its first K word was requested, and an argument block of the direct path lies in uncached device memory (hc_direct.hpp).  One
+// word of every 64-byte line, all in flight at once, and ONE wait (the empty asm statement is their only use: it needs them all in
+// registers at the same time); the argument loads that follow hit the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void touch_args() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int* kp = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int n = (BYTES + 63) / 64;
+    static_assert(n <= 48, "touch_args: argument block too large");
+    constexpr int groups = (n + 15) / 16;
+    int w[16 * groups];
+#pragma unroll
+    for (int i = 0; i < 16 * groups; ++i) w[i] = kp[16 * (i < n ? i : 0)];
+    __builtin_amdgcn_sched_barrier(0);  // (whatever the caller requested before stays in front of the wait)
+#pragma unroll
+    for (int g = 0; g < groups; ++g) {
+        const int* v = w + 16 * g;
+        asm volatile("" ::"s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]), "s"(v[8]), "s"(v[9]), "s"(v[10]), "s"(v[11]),
+                     "s"(v[12]), "s"(v[13]), "s"(v[14]), "s"(v[15]));
+    }
+#endif
+}
+
 __device__ __forceinline__ double state_velocity(const double* __restrict__ state, int N, int col) {
     const int b = col / 6, d = col - 6 * b;
     return d < 3 ? state[6 * N + 3 * b + d] : state[9 * N + 3 * b + (d - 3)];
@@ -239,6 +264,7 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
     Bracket* tab = reinterpret_cast<Bracket*>(rhs + a.rhs_capacity);
     double* wtab = reinterpret_cast<double*>(tab + a.max_steps_per_chunk);
     __shared__ double red[kConvThreads / kWave][MT][16];
+    touch_args<sizeof(StepArgs)>();
 
     // block index -> (chunk, row group): the row groups of one chunk stage the same right-hand side, so they get block
     // indices congruent mod 8 (same XCD under round-robin placement) and close together: [octet of chunks][group][chunk % 8]
@@ -1052,17 +1078,19 @@ void launch_reduce_block(const ReduceArgs& r, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // NW = waves per workgroup (4).  Wide systems (near_slices_for(D) > 1) leave the own-sample part to near_split_kernel.
 // the workgroup that hands back the state canary and stores this step's sample into ring slot `head` (both layouts)
-template <int NW>
-__device__ __forceinline__ void push_sample(const FinalizeArgs& a) {
+// SLOT: the state lies behind the kernel's argument block (st, layout of hc_limits.hpp: kSlotArgBytes), not at a.state.
+template <int NW, bool SLOT = false>
+__device__ __forceinline__ void push_sample(const FinalizeArgs& a, const double* __restrict__ st = nullptr) {
     if (threadIdx.x == 64 && a.canary_out) {  // first thing this workgroup does: the word the host stored behind the state goes back, tagged
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<u64x2*>(a.canary_out) = u64x2{(unsigned long long)__double_as_longlong(*a.canary_in), a.seq};
+        const double word = SLOT ? st[12 * a.N] : *a.canary_in;
+        *reinterpret_cast<u64x2*>(a.canary_out) = u64x2{(unsigned long long)__double_as_longlong(word), a.seq};
     }
     // nobody reads ring slot `head` during this step (the current sample is always taken from `state`)
     if (threadIdx.x == 0) a.ring_t[a.head] = a.t;
     double* slot = a.ring_v + (size_t)a.head * a.D;
     for (int c = threadIdx.x; c < a.D; c += 64 * NW) {
-        const double v = state_velocity(a.state, a.N, c);
+        const double v = SLOT ? st[c] : state_velocity(a.state, a.N, c);
         slot[c] = v;
         a.ring_vT[(size_t)c * a.HcapT + a.head] = v;  // per-DoF time series for the look-ahead pass
         if (a.head == 0) a.ring_vT[(size_t)c * a.HcapT + a.Hcap] = v;  // mirror of slot 0 behind the last slot
@@ -1073,8 +1101,12 @@ __device__ __forceinline__ void push_sample(const FinalizeArgs& a) {
 // the tile needs has been REQUESTED and before anything is waited for; it returns whether this workgroup goes on (wide_step_kernel
 // contracts its column slice of the own-sample part there and goes on only if it completed the tile).  COHERENT: the slice partials
 // were written by other workgroups of this very launch, possibly on other XCDs (agent-scope atomic loads, see wide_step_kernel).
-template <int NW, bool COHERENT, class Mid>
-__device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int tile, double* U, double (*red_near)[16], double (*red_term)[16], Mid&& mid) {
+// SLOT: the state lies behind the argument block (st) and the velocities of columns tid, tid + 256, tid + 512 were requested before the
+// first argument was looked at (ev0..ev2); 6N <= 768 (kSlotStateMaxBodies).
+template <int NW, bool COHERENT, bool SLOT, class Mid>
+__device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int tile, double* U, double (*red_near)[16], double (*red_term)[16], Mid&& mid,
+                                              const double* __restrict__ st = nullptr, double ev0 = 0.0, double ev1 = 0.0, double ev2 = 0.0) {
+    static_assert(!SLOT || NW == 4, "the early loads assume 256 work-items");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub  = tid & 15;
@@ -1111,8 +1143,8 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
         if (a.do_rad && a.P) p_row = a.P[rrow];
         if (a.do_waves && a.wave_mode == 2 && a.E) e_row = a.E[rrow];
         if (a.do_hs) {
-            const double* pos = a.state + 3 * b;
-            const double* rpy = a.state + 3 * a.N + 3 * b;
+            const double* pos = SLOT ? st + 6 * a.N + 3 * b : a.state + 3 * b;
+            const double* rpy = SLOT ? st + 9 * a.N + 3 * b : a.state + 3 * a.N + 3 * b;
             const double* cg  = a.cg + 3 * bl;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -1160,9 +1192,10 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
         const int D = a.D;
         for (int e = 0; e < a.n_near; ++e) {
             const NearEntry& ne = a.near[e];
-            for (int col = tid; col < D; col += 64 * NW) {
+            int k = 0;
+            for (int col = tid; col < D; col += 64 * NW, ++k) {
                 double u = 0.0;
-                if (ne.a != 0.0) u = ne.a * state_velocity(a.state, a.N, col);
+                if (ne.a != 0.0) u = ne.a * (SLOT ? (k == 0 ? ev0 : (k == 1 ? ev1 : ev2)) : state_velocity(a.state, a.N, col));
                 if (ne.b != 0.0) u = fma(ne.b, a.ring_v_ro[ne.off_b + col], u);
                 if (ne.c != 0.0) u = fma(ne.c, a.ring_v_ro[ne.off_c + col], u);
                 U[e * D + col] = u;
@@ -1282,18 +1315,37 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
     }
 }
 
-template <int NW>
+// SLOT (direct dispatch of hc_step for systems of up to kSlotStateMaxBodies bodies): the host has stored the body state behind the
+// argument block, so its address is known from the kernarg segment pointer alone and the velocities every work-item stages are
+// requested at once -- in flight together with the argument loads instead of one memory round trip behind them (the state and the
+// arguments both live in fine-grained device memory the host writes through the BAR: uncached reads of about a microsecond each).
+template <int NW, bool SLOT>
 __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double* U = reinterpret_cast<double*>(smem_raw);  // [n_near][D] right-hand sides of the near samples
     __shared__ double red_near[NW][16];
     __shared__ double red_term[16][16];  // [term slice][row]
+    const double* __restrict__ st = nullptr;
+    double ev0 = 0.0, ev1 = 0.0, ev2 = 0.0;
+    if constexpr (SLOT) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        st = (const double*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kSlotArgBytes);
+#endif
+        ev0 = st[threadIdx.x];  // (always inside the slot's kSlotStateDoubles, whatever D is)
+        ev1 = st[threadIdx.x + 256];
+        ev2 = st[threadIdx.x + 512];
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);  // (the requests go out BEFORE the first wait for an argument, not behind it)
+#endif
+    }
+    touch_args<sizeof(FinalizeArgs)>();
     if (a.do_push && (int)blockIdx.x == a.nblocks - 1) {  // (a.nblocks, not gridDim: the kernel takes no hidden arguments, see hc_direct.hpp)
-        push_sample<NW>(a);
+        push_sample<NW, SLOT>(a, st);
         return;
     }
-    finalize_tile<NW, false>(a, (int)blockIdx.x, U, red_near, red_term, [] { return true; });
+    finalize_tile<NW, false, SLOT>(a, (int)blockIdx.x, U, red_near, red_term, [] { return true; }, st, ev0, ev1, ev2);
 }
+template __global__ void finalize_kernel<4, true>(FinalizeArgs);
 
 FinalizeLaunch finalize_launch_config(FinalizeArgs& a) {
     FinalizeLaunch l;
@@ -1310,11 +1362,11 @@ void launch_finalize(const FinalizeArgs& a0, hipStream_t stream) {
     if (l.smem > 64 * 1024) {
         static size_t granted = 0;
         if (l.smem > granted) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.smem);
             granted = l.smem;
         }
     }
-    hipLaunchKernelGGL((finalize_kernel<4>), dim3(l.grid), dim3(256), l.smem, stream, a);
+    hipLaunchKernelGGL((finalize_kernel<4, false>), dim3(l.grid), dim3(256), l.smem, stream, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1401,6 +1453,7 @@ __device__ __forceinline__ void near_slice(const NearArgs& a, const int rt, cons
 __global__ void __launch_bounds__(256) near_split_kernel(NearArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ double red[4][16];
+    touch_args<sizeof(NearArgs)>();
     const int rt = (int)blockIdx.x / a.n_slices, sl = (int)blockIdx.x - rt * a.n_slices;
     near_slice<false>(a, rt, sl, reinterpret_cast<double*>(smem_raw), red);
 }
@@ -1425,12 +1478,13 @@ __global__ void __launch_bounds__(256) wide_step_kernel(WideStepArgs a) {
     __shared__ double red_near[4][16];
     __shared__ double red_term[16][16];
     __shared__ int s_last;
+    touch_args<sizeof(WideStepArgs)>();
     if (a.f.do_push && (int)blockIdx.x == a.f.nblocks - 1) {
         push_sample<4>(a.f);
         return;
     }
     const int rt = (int)blockIdx.x / a.n.n_slices, sl = (int)blockIdx.x - rt * a.n.n_slices;
-    finalize_tile<4, true>(a.f, rt, nullptr, red_near, red_term, [&] {
+    finalize_tile<4, true, false>(a.f, rt, nullptr, red_near, red_term, [&] {
         near_slice<true>(a.n, rt, sl, reinterpret_cast<double*>(smem_raw), red);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial has been written through
         __syncthreads();
@@ -1491,6 +1545,7 @@ __global__ void __launch_bounds__(256) scatter_kernel(ScatterArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double* vs = reinterpret_cast<double*>(smem_raw);  // [8 * gps_per_slice]: the slice's columns of the sample's velocities
     __shared__ double red[4][16];
+    touch_args<sizeof(ScatterArgs)>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4;
     const int rt = (int)blockIdx.x % a.K.ntiles, rest = (int)blockIdx.x / a.K.ntiles;
     const int si = rest / a.n_slices, sl = rest - si * a.n_slices;

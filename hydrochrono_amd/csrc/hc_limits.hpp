@@ -13,6 +13,12 @@ constexpr int kTargets        = 3;   // later block steps one (sample, IRF sampl
 constexpr int kSubBlock       = 8;   // steps per sub-block of the two-level form (wide systems)
 constexpr int kMiniChunks     = 256; // radiation chunks a NARROW short pass may have (one step offset per chunk travels in the argument block)
 
+// The step kernel's body state behind its argument block (direct dispatch, hc_direct.hpp: kSlotBytes / kExtraBytes): at byte
+// kSlotArgBytes from the kernarg segment pointer, in the order [velocities by DoF column 6N | positions 3N | angles 3N | canary word].
+constexpr int kSlotArgBytes      = 4096;
+constexpr int kSlotStateDoubles  = 1536;  // kExtraBytes / 8
+constexpr int kSlotStateMaxBodies = 127;  // 12 N + 1 doubles fit, and 6 N <= 3 x 256: three early loads per work-item cover every column
+
 #if defined(__HIPCC__)
 #define HC_HOST_DEVICE __host__ __device__
 #else

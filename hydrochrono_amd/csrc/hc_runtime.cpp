@@ -601,11 +601,14 @@ void setup_direct(hc_ctx* c) {
     std::unique_ptr<hc::DirectQueue> q(new hc::DirectQueue);
     std::string why;
     if (!q->init(c->device, library_dir() + "/hc_kernels.co", &why)) { c->direct_why = why; return; }
-    c->dk_finalize = q->find("finalize_kernelILi4EEEv");
+    c->dk_finalize = q->find("finalize_kernelILi4ELb0EEEv");
+    c->dk_finalize_slot = q->find("finalize_kernelILi4ELb1EEEv");  // optional: the step kernel that finds the body state behind its arguments
     c->dk_scatter  = q->find("scatter_kernelE");
     c->dk_near     = q->find("near_split_kernelE");
     c->dk_wide     = q->find("wide_step_kernelE");  // optional: without it a wide step is near_split_kernel + finalize_kernel
     if (c->dk_wide.kernarg != sizeof(hc::WideStepArgs) || c->dk_wide.priv != 0) c->dk_wide = hc::DirectKernel{};
+    if (c->dk_finalize_slot.kernarg != sizeof(hc::FinalizeArgs) || c->dk_finalize_slot.priv != 0) c->dk_finalize_slot = hc::DirectKernel{};
+    c->slot_state = env_int("HC_SLOT_STATE", 1) != 0 && c->dk_finalize_slot.ok() && c->N <= hc::kSlotStateMaxBodies;
     c->dk_reduce   = q->find("reduce_block_kernelE");
     c->dk_added_mass = q->find("added_mass_mv_tagged_kernelE");  // optional: hc_added_mass_mv falls back to a HIP launch
     {   // the plain per-step convolution of this context's tiling; optional: without it plain steps go through HIP launches
@@ -662,6 +665,9 @@ void setup_direct(hc_ctx* c) {
         c->direct_why = "added_mass_mv_tagged_kernel is missing from hc_kernels.co";
         return;
     }
+    static_assert(hc::kSlotArgBytes == hc::DirectQueue::kSlotBytes && hc::kSlotStateDoubles * sizeof(double) == hc::DirectQueue::kExtraBytes &&
+                      12 * hc::kSlotStateMaxBodies + 1 <= hc::kSlotStateDoubles && 6 * hc::kSlotStateMaxBodies <= 768,
+                  "the state behind the step kernel's arguments: hc_limits.hpp and hc_direct.hpp must agree");
     static_assert(sizeof(hc::NearArgs) <= hc::DirectQueue::kSlotBytes && sizeof(hc::WideStepArgs) <= hc::DirectQueue::kSlotBytes,
                   "an argument block does not fit a kernarg slot of the direct queue");
     static_assert(sizeof(hc::ScatterArgs) <= hc::DirectQueue::kSlotBytes && sizeof(hc::FinalizeArgs) <= hc::DirectQueue::kSlotBytes &&

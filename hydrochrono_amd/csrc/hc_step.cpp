@@ -9,6 +9,12 @@ using namespace hc::detail;
 namespace hc {
 namespace detail {
 
+// (the per-step canary, see check_canary below)
+bool canary_enabled() {
+    static const bool on = env_int("HC_STEP_CANARY", 1) != 0;  // (0: for A/B timing only -- 0.1 us of 8.7 / 11.9 us per hc_step at one / 64 bodies)
+    return on;
+}
+
 // ---- the step ---------------------------------------------------------------------------------
 // the excitation-window tests of check_wave_ready as a predicate (for predicted step times)
 bool wave_window_ok(const hc_ctx* c, double t) {
@@ -254,8 +260,71 @@ void enqueue_tail(hc_ctx* c) {
 // (device) and host_tagged (mapped pinned granules) may be null.
 // defer_tail: the caller enqueues the work later steps need itself (enqueue_tail) -- hc_step_multi, after all shard contexts
 // have their step kernels on the way.
+// The classic home of a synchronous step's state: device memory written through the PCIe BAR (fallback: mapped pinned memory the
+// kernels read over PCIe), two halves used alternately -- hc_step returns as soon as the totals have arrived, while the workgroup that
+// stores the step's sample into the ring may still be reading the state, so the next call must not overwrite it.  (The kernels of step
+// n + 1 run after those of step n, and step n + 2 starts only after the totals of step n + 1 have arrived: two halves are enough.)
+// A row-sharded context reads positions and angles of its OWN bodies only (hydrostatics), velocities of all: the other bodies' pos / rpy
+// entries are not stored (half the bytes through the BAR for each shard of a wide array).  `seq`: the step's sequence number.
+const double* stage_host_state(hc_ctx* c, const HostState& hs, unsigned long long seq) {
+    const int n3   = 3 * c->N;
+    const size_t o = (seq & 1) ? 0 : static_cast<size_t>(12) * c->N + 1;
+    const size_t l0 = static_cast<size_t>(3) * c->b0, ln = static_cast<size_t>(3) * c->nloc;
+    auto put = [&](double* h) {
+        std::memcpy(h + l0, hs.pos + l0, ln * sizeof(double));
+        std::memcpy(h + n3 + l0, hs.rpy + l0, ln * sizeof(double));
+        std::memcpy(h + 2 * n3, hs.linvel, n3 * sizeof(double));
+        std::memcpy(h + 3 * n3, hs.angvel, n3 * sizeof(double));
+    };
+    const double* d_state;
+    if (c->bar_state.host_ok) {
+        // device memory written through the PCIe BAR: the kernels read the state locally (no PCIe read on the critical path)
+        double* h = c->bar_state.p + o;
+        put(h);
+        h[4 * n3] = hs.canary;
+        _mm_sfence();  // write-combined stores are globally visible before the doorbell of the launch
+        d_state = h;
+        c->step_canary_in = h + 4 * n3;
+    } else {
+        double* h = c->h_state.p + o;
+        put(h);
+        h[4 * n3] = hs.canary;
+        d_state = c->h_state.dp + o;
+        c->step_canary_in = c->h_state.dp + o + 4 * n3;
+        if (c->N > c->zero_copy_max_bodies) {  // many workgroups re-read the state: one small H2D copy beats their PCIe reads
+            HC_HIP(hipMemcpyAsync(c->d_state.p, h, 4 * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            d_state = c->d_state.p;
+        }
+    }
+    if (!canary_enabled()) c->step_canary_in = nullptr;
+    return d_state;
+}
+
+// ... and its place behind the argument block of the step kernel (DirectQueue::FillExtra; layout of hc_limits.hpp: velocities by DoF
+// column, positions, angles, canary word).  Every dispatch has a slot of its own, so nothing is overwritten under a reader.
+struct SlotStateFill {
+    const hc_ctx* c;
+    const HostState* hs;
+};
+void fill_slot_state(char* extra, void* user) {
+    const SlotStateFill& w = *static_cast<const SlotStateFill*>(user);
+    const int N = w.c->N, n3 = 3 * N;
+    double* h = reinterpret_cast<double*>(extra);
+    for (int b = 0; b < N; ++b) {
+        std::memcpy(h + 6 * b, w.hs->linvel + 3 * b, 3 * sizeof(double));
+        std::memcpy(h + 6 * b + 3, w.hs->angvel + 3 * b, 3 * sizeof(double));
+    }
+    const size_t l0 = static_cast<size_t>(3) * w.c->b0, ln = static_cast<size_t>(3) * w.c->nloc;
+    std::memcpy(h + 2 * n3 + l0, w.hs->pos + l0, ln * sizeof(double));
+    std::memcpy(h + 3 * n3 + l0, w.hs->rpy + l0, ln * sizeof(double));
+    h[4 * n3] = w.hs->canary;
+}
+
+// host_state (hc_step): the caller's state has NOT been stored anywhere yet (d_state is null).  A step whose one kernel is the step
+// kernel of the direct path takes it behind that kernel's argument block (fill_slot_state); every other step stores it the classic way
+// first (stage_host_state) -- decided here, where the step's shape is known.
 void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f,
-                  unsigned long long* host_tagged, unsigned long long seq, bool defer_tail) {
+                  unsigned long long* host_tagged, unsigned long long seq, bool defer_tail, const HostState* host_state) {
     require(!c->tail.pending, HC_ERR_INVALID, "a step begun with hc_step_begin has not been completed (hc_step_end)");
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     const bool irregular = c->wave_kind == hc::kWaveIrregular;
@@ -324,9 +393,15 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         quiesce_direct(c);
         c->path = 1;
     }
+    // (a state still in the caller's hands goes to its classic place as soon as a kernel other than the direct step kernel wants it)
+    auto staged_state = [&]() {
+        if (!d_state && host_state) d_state = stage_host_state(c, *host_state, seq);
+        return d_state;
+    };
+    if (!host_state || !direct || !c->slot_state) staged_state();
     if ((run_rad && !block) || nchunks_ex > 0) {
         hc::HistoryView hv{};
-        hv.state   = d_state;
+        hv.state   = staged_state();
         hv.N       = c->N;
         hv.D       = c->D;
         hv.t       = t;
@@ -418,16 +493,13 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
             std::fprintf(stderr, "     near s=%d a=%.6g b=%.6g c=%.6g offb=%d offc=%d\n", z.near[e].s, z.near[e].a, z.near[e].b, z.near[e].c, z.near[e].off_b, z.near[e].off_c);
     }
     z.host_tagged = host_tagged;
-    z.canary_in   = c->step_canary_in;   // (set by step_begin for this call only)
-    z.canary_out  = c->step_canary_out;
-    c->step_canary_in  = nullptr;
+    z.canary_out  = c->step_canary_out;  // (set by step_begin for this call only; canary_in goes with the state, below)
     c->step_canary_out = nullptr;
     z.seq         = seq;
     z.Dloc        = c->Dloc;
     z.Dpad        = c->Dpad;
     z.N           = c->N;
     z.b0          = c->b0;
-    z.state       = d_state;
     z.lin         = c->d_lin.p;
     z.cg          = c->d_cg.p;
     z.cb_m_cg     = c->d_cbmcg.p;
@@ -466,7 +538,13 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     z.ring_vT       = c->d_ring_vT.p;
     z.Hcap          = c->Hcap;
     z.HcapT         = c->HcapT;
+    auto state_into_args = [&]() {  // the classic state pointer (and the canary word behind it) into the step kernel's arguments
+        z.state            = staged_state();
+        z.canary_in        = c->step_canary_in;
+        c->step_canary_in  = nullptr;
+    };
     if (z.n_near > 0 && hc::near_slices_for(c->D) > 1) {
+        state_into_args();
         // wide system: the own-sample part is split over column slices by a kernel of its own (hundreds of workgroups instead of one
         // per row tile); the step kernel adds the slice partials
         hc::NearArgs na{};
@@ -476,7 +554,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         na.N      = c->N;
         na.n_near = z.n_near;
         for (int e = 0; e < z.n_near; ++e) na.near[e] = z.near[e];
-        na.state    = d_state;
+        na.state    = z.state;
         na.ring_v   = c->d_ring_v.p;
         na.partials = c->d_near_partials.p;
         // ... in ONE launch with the step kernel (wide_step_kernel: the workgroup that completes a row tile's slices finishes the tile):
@@ -515,11 +593,22 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         z.n_near_slices = na.n_slices;
         z.n_near        = 0;
     }
-    if (direct) {
+    if (direct && !d_state && host_state && c->slot_state) {
+        // the step's ONE kernel, and nobody has needed the state so far: it travels behind the kernel's arguments, where the kernel
+        // can ask for it before it has read a single argument (finalize_kernel<4, true>)
+        SlotStateFill fill{c, host_state};
+        const hc::FinalizeLaunch l = hc::finalize_launch_config(z);
+        c->dq->dispatch(c->dk_finalize_slot, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &z, sizeof z, direct_tag(c, hc::kEvStep), 0.0, 0,
+                        fill_slot_state, &fill);
+        c->prof.direct_dispatches += 1;
+        c->prof.slot_state_steps += 1;
+    } else if (direct) {
+        if (!z.state) state_into_args();
         const hc::FinalizeLaunch l = hc::finalize_launch_config(z);
         c->dq->dispatch(c->dk_finalize, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &z, sizeof z, direct_tag(c, hc::kEvStep));
         c->prof.direct_dispatches += 1;
     } else {
+        if (!z.state) state_into_args();
         hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
         hc::launch_finalize(z, stream);
         c->prof.hip_launches += 1;
@@ -614,10 +703,6 @@ void wait_tagged(hc_ctx* c, const unsigned long long* granules, unsigned long lo
 // sequence number.  Anything else means the GPU read a copy of the state buffer that is older than what the host wrote through the
 // BAR -- the one assumption the agent-scope fences of the direct dispatch rest on (hc_direct.hpp), tested at start-up by
 // direct_selftest_rewrites and here at EVERY step: the step fails loudly (HC_ERR_DEVICE) instead of returning forces of an old state.
-bool canary_enabled() {
-    static const bool on = env_int("HC_STEP_CANARY", 1) != 0;  // (0: for A/B timing only -- 0.1 us of 8.7 / 11.9 us per hc_step at one / 64 bodies)
-    return on;
-}
 void check_canary(hc_ctx* c, unsigned long long seq) {
     const volatile unsigned long long* g = c->h_canary.p + (seq & 1) * 2;
     unsigned long long spins = 0;
@@ -680,55 +765,21 @@ void step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const
     c->have_prev = true;
     c->have_prev_device = false;  // d_total is about to be replaced (or left stale by a step that throws)
     std::fill(c->last_total.begin(), c->last_total.end(), 0.0);  // the reference zero-fills total_force_ before the terms (:749-751)
-    // Boundary without copy launches or stream synchronisation: the host stores the state doubles straight into device
-    // memory through the PCIe BAR (fallback: mapped pinned memory the kernels read over PCIe), finalize_kernel stores the
-    // totals straight into mapped pinned memory, tagged with this step's sequence number; one kernel launch for a step
-    // inside a block.
-    // The state buffer has two halves used alternately: this call returns as soon as the totals have arrived, while the
-    // workgroup that stores the step's sample into the ring may still be reading the state -- the next call must not
-    // overwrite it.  (The kernels of step n+1 run after those of step n, and step n+2 starts only after the totals of
-    // step n+1 have arrived, so two halves are enough.)
-    // A row-sharded context reads positions and angles of its OWN bodies only (hydrostatics), velocities of all: the other
-    // bodies' pos / rpy entries are not stored (half the bytes through the BAR for each shard of a wide array).
-    const int n3   = 3 * c->N;
-    const size_t o = (c->seq & 1) ? static_cast<size_t>(12) * c->N + 1 : 0;
+    // Boundary without copy launches or stream synchronisation: the host stores the state doubles straight into device memory through
+    // the PCIe BAR -- behind the step kernel's arguments, or into the context's state buffer (enqueue_step decides: stage_host_state,
+    // fill_slot_state) --, finalize_kernel stores the totals straight into mapped pinned memory, tagged with this step's sequence
+    // number; one kernel launch for a step inside a block.
     // the canary: this step's sequence number as a double, stored behind the state through the same path (checked in step_end)
     const unsigned long long seq_next = c->seq + 1;
-    const double canary = static_cast<double>((c->fault_stale_state_at >= 0 && static_cast<long long>(seq_next) == c->fault_stale_state_at) ? seq_next - 1 : seq_next);
-    const size_t l0 = static_cast<size_t>(3) * c->b0, ln = static_cast<size_t>(3) * c->nloc;
-    auto put = [&](double* h) {
-        std::memcpy(h + l0, pos + l0, ln * sizeof(double));
-        std::memcpy(h + n3 + l0, rpy + l0, ln * sizeof(double));
-        std::memcpy(h + 2 * n3, linvel, n3 * sizeof(double));
-        std::memcpy(h + 3 * n3, angvel, n3 * sizeof(double));
-    };
-    const double* d_state;
-    if (c->bar_state.host_ok) {
-        // device memory written through the PCIe BAR: the kernels read the state locally (no PCIe read on the critical path)
-        double* h = c->bar_state.p + o;
-        put(h);
-        h[4 * n3] = canary;
-        _mm_sfence();  // write-combined stores are globally visible before the doorbell of the launch
-        d_state = h;
-        c->step_canary_in = h + 4 * n3;
-    } else {
-        double* h = c->h_state.p + o;
-        put(h);
-        h[4 * n3] = canary;
-        d_state = c->h_state.dp + o;
-        c->step_canary_in = c->h_state.dp + o + 4 * n3;
-        if (c->N > c->zero_copy_max_bodies) {  // many workgroups re-read the state: one small H2D copy beats their PCIe reads
-            HC_HIP(hipMemcpyAsync(c->d_state.p, h, 4 * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            d_state = c->d_state.p;
-        }
-    }
+    HostState hs{pos, rpy, linvel, angvel,
+                 static_cast<double>((c->fault_stale_state_at >= 0 && static_cast<long long>(seq_next) == c->fault_stale_state_at) ? seq_next - 1 : seq_next)};
+    c->step_canary_in = nullptr;
     const unsigned long long seq = ++c->seq;
     c->step_canary_out = canary_enabled() ? c->h_canary.dp + (seq & 1) * 2 : nullptr;
-    if (!canary_enabled()) c->step_canary_in = nullptr;
     // The tagged results of consecutive steps go to alternate halves of the result buffer: a reader in ANOTHER process (a caller's
     // buffer in shared memory, hc_set_result_buffer) may still be collecting step n while this process has moved on to step n + 1;
     // it cannot reach step n + 2 before every process has the rows of step n + 1, i.e. has finished with step n.
-    enqueue_step(c, t, d_state, nullptr, c->stream, StepFlags{}, result_tags_dev(c, seq), seq, defer_tail);
+    enqueue_step(c, t, nullptr, nullptr, c->stream, StepFlags{}, result_tags_dev(c, seq), seq, defer_tail, &hs);
     c->pending_step = 2;
     c->pending_t    = t;
 }

@@ -70,7 +70,7 @@ def test_kernel_code_object_is_built_next_to_the_library():
     assert os.path.exists(hb.KERNEL_CO), "run __graft_entry__.build()"
     blob = open(hb.KERNEL_CO, "rb").read()
     assert blob[:4] == b"\x7fELF" and len(blob) > 100_000
-    for name in (b"finalize_kernelILi4E", b"scatter_kernelE", b"reduce_block_kernelE", b"conv_block_kernelILi6ELi4ELi2ELi1E",
+    for name in (b"finalize_kernelILi4ELb0E", b"finalize_kernelILi4ELb1E", b"scatter_kernelE", b"reduce_block_kernelE", b"conv_block_kernelILi6ELi4ELi2ELi1E",
                  b"conv_block_kernelILi6ELi3ELi1ELi2E", b"conv_step_kernelILi4ELi2E", b"added_mass_mv_tagged_kernelE",
                  b"conv_block_kernelILi4ELi4ELi1ELi2E", b"near_split_kernelE", b"wide_step_kernelE"):
         assert name in blob, name

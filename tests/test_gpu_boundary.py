@@ -260,3 +260,46 @@ def test_every_step_proves_it_read_this_steps_state(monkeypatch, direct):
         bad.step(0.57, *motion.state(0.57))
     assert ei.value.status == 4
     good.step(0.56, *st)  # an untouched context goes on
+
+
+@pytest.mark.parametrize("N, sharded", [(1, False), (6, False), (6, True), (127, False), (130, False)], ids=["1-body", "6-bodies", "6-bodies-row-shards", "127-bodies", "130-bodies-classic"])
+def test_state_behind_the_step_kernels_arguments_is_bitwise_the_classic_path(monkeypatch, N, sharded):
+    """On the direct path a step that is ONE kernel takes its body state behind that kernel's argument block (a slot of the kernarg
+    ring holds 4 KB of arguments + 12 KB the kernel addresses from its kernarg segment pointer: finalize_kernel<4, true> requests its
+    velocities before it has read a single argument -- hc_step.cpp: fill_slot_state, hc_limits.hpp: kSlotArgBytes).  Systems of up to
+    127 bodies; steps with a kernel in front of the step kernel (plain steps, wide systems) and HC_SLOT_STATE=0 store the state in the
+    context's buffer as before.  Same arithmetic from the same values: bitwise the forces of the classic path over blocks, plain steps
+    (irregular step sizes), a step back in time and the per-step canary; row shards take their own bodies' positions only."""
+    import hydrochrono_amd.hydro as hydro
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_DIRECT", "1")
+    case = many_body_case(N, S=128 if N > 100 else 96, dt_rirf=0.01, n_exc=21, dt_exc=0.02, seed=500 + N)
+    motion = PrescribedMotion(N, rest_positions(case), seed=2)
+    times, t = [], 0.0
+    for n in range(260):
+        t += 0.01 if (n < 150 or n > 190) else 0.004 + 0.0007 * (n % 11)  # blocks, then irregular steps (plain), then blocks again
+        times.append(t)
+    times[230] = times[226]  # a step back in time
+    times = times[:231] + [times[230] + 0.01 * (k + 1) for k in range(30)]
+    runs, counts = [], []
+    for slot in ("1", "0"):
+        monkeypatch.setenv("HC_SLOT_STATE", slot)
+        if sharded:
+            parts = [hydro.HydroForces.from_case(case, body_range=(0, 2)), hydro.HydroForces.from_case(case, body_range=(2, 6))]
+        else:
+            parts = [hydro.HydroForces.from_case(case)]
+        for h in parts:
+            h.add_waves_regular(0.4, 0.9)
+        f = np.stack([np.concatenate([h.step(tt, *motion.state(tt)) for h in parts]) for tt in times])
+        runs.append(f)
+        counts.append([h.profile()["slot_state_steps"] for h in parts])
+        for h in parts:
+            h.close()
+    assert np.array_equal(runs[0], runs[1])
+    assert all(c == 0 for c in counts[1])
+    if N <= 127:
+        assert all(c >= 150 for c in counts[0]), counts  # the block steps
+        assert all(c < len(times) for c in counts[0]), counts  # ... but not the plain ones
+    else:
+        assert all(c == 0 for c in counts[0])

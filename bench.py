@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline time budget")
     ap.add_argument("--steady-steps", type=int, default=256, help="synchronous steps of the steady_state block (median + mean, SURVEY 8d: >= 200)")
     ap.add_argument("--single-process", action="store_true", help="N > 1: all shards in THIS process through hc_step_multi (no launcher needed)")
+    ap.add_argument("--python-loop", action="store_true", help="N = 1: time hc_step calls issued one by one from the Python interpreter (rounds 1-4a) "
+                                                             "instead of the library's own loop hc_step_many")
     ap.add_argument("--no-c4-share", action="store_true", help="skip the c4_rank_share secondary (one C4/8 shard on this GPU)")
     ap.add_argument("--no-c4-one-gpu", action="store_true", help="skip the c4_one_gpu secondary (the whole 512-body array, 77 GB of K, on this GPU)")
     ap.add_argument("--exchange", choices=["host", "rccl"], default="host",
@@ -488,7 +490,8 @@ def main():
         align = boundary - first
     pre = align + args.warmup
     total = pre + args.steps
-    n_all = total + n_steady + ((4 * 128 + 72 + 3) if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
+    n_py = 128 if (n_steady > 0 and not args.python_loop) else 0
+    n_all = total + n_steady + n_py + ((4 * 128 + 72 + 3) if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
     duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
     gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
@@ -501,6 +504,7 @@ def main():
     gpu.set_history(t_hist, v_hist)
 
     times = [T0 + k * sdt for k in range(n_all)]
+    times_np = np.array(times, dtype=np.float64)
     states = np.ascontiguousarray(np.stack([motion.packed(t) for t in times]))  # [n_all][12N] = pos | rpy | linvel | angvel
     forces = np.zeros((n_all, D_local))
     n3 = 3 * N
@@ -583,7 +587,10 @@ def main():
 
     def run_sync(k0, k1):
         """K synchronous evaluations: state from host memory in, forces in host memory out, one call after the other."""
-        if exchange is None:
+        if exchange is None and not args.python_loop:
+            # the library's own prescribed-motion loop: hc_step k0 .. k1 - 1 one after the other, no interpreter between the calls
+            gpu.step_many(times_np[k0:k1], states[k0:k1], forces[k0:k1], per_step[k0:k1])
+        elif exchange is None:
             pc = time.perf_counter
             for k in range(k0, k1):
                 a = pc()
@@ -657,6 +664,22 @@ def main():
                   "p10_ms_per_step": float(np.percentile(ps, 10)), "p90_ms_per_step": float(np.percentile(ps, 90)),
                   "note": "synchronous hc_step calls right after the timed region (same context, same history), passes included"}
         k_next += n_steady
+    python_loop = None
+    if n_py > 0:
+        # the same synchronous calls issued one by one from the interpreter (how rounds 1-4a timed `value`): 4 blocks, passes included
+        pc = time.perf_counter
+        t_p = pc()
+        for k in range(k_next, k_next + n_py):
+            a = pc()
+            rc = hc_step(ctx, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
+            per_step[k] = pc() - a
+            if rc:
+                gpu._chk(rc)
+        t_p = pc() - t_p
+        pp = per_step[k_next:k_next + n_py] * 1e3
+        python_loop = {"steps": n_py, "evals_per_s": n_py / t_p, "mean_ms_per_step": t_p / n_py * 1e3, "median_ms_per_step": float(np.median(pp)),
+                       "note": "hc_step through a ctypes prototype, one call per interpreter iteration (bench.py --python-loop makes this the timed region)"}
+        k_next += n_py
     prof_all = gpu.profile()  # warm-up + timed region + steady-state block
     gpu.enable_profiling(False)
     chrono_like = None
@@ -843,6 +866,9 @@ def main():
                               "body-row shards of one coupled array + RCCL all-gather of forces every step") if strong else
                              "one independent farm per GPU, no data-path collective") if world > 1 else "single GPU",
             },
+            "caller": ("hc_step_many: the C ABI's prescribed-motion loop -- K synchronous hc_step calls, host state in, host forces out, issued by "
+                       "compiled code like the reference's C++ callers (secondary python_loop: the same calls from the interpreter)"
+                       if (world == 1 and exchange is None and not args.python_loop) else "one hc_step (or begin / gather / end) per Python call"),
             "dispatch_mode": dinfo["dispatch_mode"] if (world == 1 or args.exchange == "host") else "HIP launches on the rank's stream (hc_step_device) + RCCL all-gather",
             "exchange": (args.exchange if world > 1 else None),
             "dispatch_mode_reason": dinfo["dispatch_mode_reason"],
@@ -870,6 +896,8 @@ def main():
         }
         if steady is not None:
             out["steady_state"] = steady
+        if python_loop is not None:
+            out["python_loop"] = python_loop
         if chrono_like is not None:
             out["chrono_like_loop"] = chrono_like
         if pipelined is not None:

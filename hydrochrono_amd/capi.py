@@ -106,6 +106,7 @@ SIGNATURES = {
     "hc_get_rirf_width": (C.c_int, [C.c_void_p, c_double_p]),
     "hc_get_rirf_effective": (C.c_int, [C.c_void_p, c_double_p]),
     "hc_get_rirf_value": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p]),
+    "hc_step_many": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_int_p]),
     "hc_h5_read": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "hc_h5_free": (None, [C.c_void_p]),
     "hc_h5_get_sizes": (C.c_int, [C.c_void_p, c_int_p, c_double_p, c_double_p, c_double_p, C.c_int, c_int_p, c_int_p, c_int_p]),

@@ -897,6 +897,26 @@ int hc_step(hc_ctx* c, double t, const double* pos, const double* rpy, const dou
     HC_API_END(c)
 }
 
+int hc_step_many(hc_ctx* c, int n, const double* t_n, const double* states, double* forces, double* seconds_n, int* done) {
+    if (done) *done = 0;
+    if (!c) return HC_ERR_INVALID;
+    if (n <= 0) return HC_OK;
+    if (!t_n || !states || !forces) {
+        c->err = "null pointer";
+        return HC_ERR_INVALID;
+    }
+    const size_t n3 = static_cast<size_t>(3) * c->N, dl = static_cast<size_t>(c->Dloc);
+    for (int k = 0; k < n; ++k) {
+        const double* st = states + static_cast<size_t>(k) * 4 * n3;
+        const auto a     = std::chrono::steady_clock::now();
+        const int rc     = hc_step(c, t_n[k], st, st + n3, st + 2 * n3, st + 3 * n3, forces + static_cast<size_t>(k) * dl);
+        if (seconds_n) seconds_n[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+        if (rc != HC_OK) return rc;
+        if (done) *done = k + 1;
+    }
+    return HC_OK;
+}
+
 int hc_step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel) {
     HC_API_BEGIN_HOT(c)
     try {

@@ -185,6 +185,25 @@ class HydroForces:
             self._chk(rc)
         return out
 
+    def step_many(self, times, states, forces=None, seconds=None):
+        """hc_step_many: one synchronous hc_step per row -- times [n], states [n][12N] packed pos | rpy | linvel | angvel
+        (mock_chrono.PrescribedMotion.packed), both float64 C-contiguous -- in ONE call of the C ABI (a prescribed-motion driver's loop
+        without an interpreter between the steps).  Returns (forces [n][D_local], seconds per call [n]); a failing step raises after
+        the rows before it have been filled."""
+        times = np.ascontiguousarray(times, dtype=np.float64)
+        states = np.ascontiguousarray(states, dtype=np.float64)
+        n = times.size
+        if states.shape != (n, 12 * self.N):
+            raise ValueError(f"states must be [{n}][{12 * self.N}]")
+        forces = np.empty((n, self.D_local)) if forces is None else forces
+        seconds = np.empty(n) if seconds is None else seconds
+        assert forces.flags.c_contiguous and seconds.flags.c_contiguous and forces.shape == (n, self.D_local) and seconds.shape == (n,)
+        done = C.c_int(0)
+        rc = self.lib.hc_step_many(self.ctx, n, _dp(times), _dp(states), _dp(forces), _dp(seconds), C.byref(done))
+        if rc:
+            self._chk(rc)
+        return forces, seconds
+
     def step_device(self, t, state_ptr, out_ptr, stream_ptr=None):
         """state_ptr / out_ptr: integer device addresses (e.g. torch.Tensor.data_ptr()).
 

@@ -190,6 +190,12 @@ int hc_step(hc_ctx* ctx, double t, const double* pos, const double* rpy, const d
  * the context in between.  Same cache and error rules as hc_step (a failure of either half leaves nothing pending). */
 int hc_step_begin(hc_ctx* ctx, double t, const double* pos, const double* rpy, const double* linvel, const double* angvel);
 int hc_step_end(hc_ctx* ctx, double* force_out);
+/* A prescribed-motion driver's loop ("the build's own counterpart is a mock Chrono loop"): n synchronous evaluations one
+ * after the other -- hc_step(ctx, t_n[k], state k, force k) for k = 0 .. n-1 with state k the packed block
+ * [pos 3N | rpy 3N | linvel 3N | angvel 3N] at states_nx12N + 12N*k and force k the D_local totals at forces_nxDlocal + D_local*k.
+ * seconds_n (may be NULL) receives the wall time of every call (std::chrono::steady_clock around hc_step).  Stops at the first failing
+ * step and returns its status; *done (may be NULL) is the number of steps completed.  Same results as n calls of hc_step: it is n calls. */
+int hc_step_many(hc_ctx* ctx, int n, const double* t_n, const double* states_nx12N, double* forces_nxDlocal, double* seconds_n, int* done);
 /* Multi-GPU inside ONE host process -- the reference is one C++ object in one Chrono process (src/hydro_forces.cpp:170-242),
  * evaluated by one call per time (:727-767); SURVEY 8e, drop-in variant.  ctxs[0..n_ctx) are row-sharded contexts of the same
  * N-body system (hc_create_sharded, any devices, any split of the bodies); the call stores the state into every context and

@@ -364,6 +364,36 @@ def test_cache_duplicate_time_and_first_step(HF):
     assert ei.value.status == 1 and "twice within the same time step" in str(ei.value)
 
 
+def test_step_many_is_the_same_calls_in_one(HF):
+    """hc_step_many (the C ABI's prescribed-motion loop, what bench.py times): n hc_step calls in one -- bitwise the forces of n
+    separate calls incl. a repeated time (cached) and a change of step size, per-call wall times filled, a failing step (the excitation
+    window ends) reported with its status after the rows before it have been delivered."""
+    from hydrochrono_amd.hydro import HydroError
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    case = many_body_case(4, S=80, dt_rirf=0.01, n_exc=33, dt_exc=0.02, seed=77)
+    motion = PrescribedMotion(4, rest_positions(case), seed=6)
+    kw = dict(simulation_dt=0.01, simulation_duration=3.0, ramp_duration=1.0, wave_height=2.5, wave_period=8.0, frequency_min=0.02, frequency_max=0.5,
+              nfrequencies=48, peak_enhancement_factor=3.3)
+    a, b = HF.from_case(case), HF.from_case(case)
+    for h in (a, b):
+        h.add_waves_irregular(**kw)
+    times = [0.01 * (k + 1) for k in range(150)] + [1.5] + [1.5 + 0.0065 * (k + 1) for k in range(40)]
+    states = np.stack([motion.packed(t) for t in times])
+    forces, seconds = a.step_many(times, states)
+    assert forces.shape == (len(times), 24) and np.all(seconds > 0) and np.all(seconds < 1.0)
+    for k, t in enumerate(times):
+        assert np.array_equal(forces[k], b.step(t, *motion.state(t))), f"step {k}"
+    assert a.sizes()["H"] == b.sizes()["H"]
+    # beyond the free-surface table: the call stops at the failing step (src/wave_types.cpp:826-840) and says which status
+    late = [1.9, 2.0, 400.0, 400.1]
+    out = np.full((4, 24), np.nan)
+    with pytest.raises(HydroError) as ei:
+        a.step_many(late, np.stack([motion.packed(t) for t in late]), out, np.zeros(4))
+    assert "excitation" in str(ei.value).lower() or ei.value.status != 0
+    assert np.all(np.isfinite(out[:2])) and np.all(np.isnan(out[3]))
+
+
 def test_wave_model_errors(HF):
     from hydrochrono_amd.hydro import HydroError
     from hydrochrono_amd.synthetic import many_body_case

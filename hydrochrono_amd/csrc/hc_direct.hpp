@@ -89,7 +89,7 @@ class DirectQueue {
     size_t timed_pending() const;
 
     static constexpr size_t kSlotBytes  = 4096;   // kernarg bytes per dispatch (the largest argument block is the scatter's 2.6 KB)
-    static constexpr size_t kExtraBytes = 12288;  // ... followed by room for data the kernel addresses relative to its kernarg pointer
+    static constexpr size_t kExtraBytes = 16384;  // ... followed by room for data the kernel addresses relative to its kernarg pointer
     static constexpr size_t kSlotStride = kSlotBytes + kExtraBytes;
 
   private:

@@ -1102,10 +1102,10 @@ __device__ __forceinline__ void push_sample(const FinalizeArgs& a, const double*
 // contracts its column slice of the own-sample part there and goes on only if it completed the tile).  COHERENT: the slice partials
 // were written by other workgroups of this very launch, possibly on other XCDs (agent-scope atomic loads, see wide_step_kernel).
 // SLOT: the state lies behind the argument block (st) and the velocities of columns tid, tid + 256, tid + 512 were requested before the
-// first argument was looked at (ev0..ev2); 6N <= 768 (kSlotStateMaxBodies).
+// first argument was looked at (ev0..ev3); 6N <= 1024 (kSlotStateMaxBodies).
 template <int NW, bool COHERENT, bool SLOT, class Mid>
 __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int tile, double* U, double (*red_near)[16], double (*red_term)[16], Mid&& mid,
-                                              const double* __restrict__ st = nullptr, double ev0 = 0.0, double ev1 = 0.0, double ev2 = 0.0) {
+                                              const double* __restrict__ st = nullptr, double ev0 = 0.0, double ev1 = 0.0, double ev2 = 0.0, double ev3 = 0.0) {
     static_assert(!SLOT || NW == 4, "the early loads assume 256 work-items");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1195,7 +1195,7 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
             int k = 0;
             for (int col = tid; col < D; col += 64 * NW, ++k) {
                 double u = 0.0;
-                if (ne.a != 0.0) u = ne.a * (SLOT ? (k == 0 ? ev0 : (k == 1 ? ev1 : ev2)) : state_velocity(a.state, a.N, col));
+                if (ne.a != 0.0) u = ne.a * (SLOT ? (k == 0 ? ev0 : (k == 1 ? ev1 : (k == 2 ? ev2 : ev3))) : state_velocity(a.state, a.N, col));
                 if (ne.b != 0.0) u = fma(ne.b, a.ring_v_ro[ne.off_b + col], u);
                 if (ne.c != 0.0) u = fma(ne.c, a.ring_v_ro[ne.off_c + col], u);
                 U[e * D + col] = u;
@@ -1326,7 +1326,7 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     __shared__ double red_near[NW][16];
     __shared__ double red_term[16][16];  // [term slice][row]
     const double* __restrict__ st = nullptr;
-    double ev0 = 0.0, ev1 = 0.0, ev2 = 0.0;
+    double ev0 = 0.0, ev1 = 0.0, ev2 = 0.0, ev3 = 0.0;
     if constexpr (SLOT) {
 #if defined(__HIP_DEVICE_COMPILE__)
         st = (const double*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kSlotArgBytes);
@@ -1334,6 +1334,7 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
         ev0 = st[threadIdx.x];  // (always inside the slot's kSlotStateDoubles, whatever D is)
         ev1 = st[threadIdx.x + 256];
         ev2 = st[threadIdx.x + 512];
+        ev3 = st[threadIdx.x + 768];
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_sched_barrier(0);  // (the requests go out BEFORE the first wait for an argument, not behind it)
 #endif
@@ -1343,7 +1344,7 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
         push_sample<NW, SLOT>(a, st);
         return;
     }
-    finalize_tile<NW, false, SLOT>(a, (int)blockIdx.x, U, red_near, red_term, [] { return true; }, st, ev0, ev1, ev2);
+    finalize_tile<NW, false, SLOT>(a, (int)blockIdx.x, U, red_near, red_term, [] { return true; }, st, ev0, ev1, ev2, ev3);
 }
 template __global__ void finalize_kernel<4, true>(FinalizeArgs);
 

@@ -16,8 +16,9 @@ constexpr int kMiniChunks     = 256; // radiation chunks a NARROW short pass may
 // The step kernel's body state behind its argument block (direct dispatch, hc_direct.hpp: kSlotBytes / kExtraBytes): at byte
 // kSlotArgBytes from the kernarg segment pointer, in the order [velocities by DoF column 6N | positions 3N | angles 3N | canary word].
 constexpr int kSlotArgBytes      = 4096;
-constexpr int kSlotStateDoubles  = 1536;  // kExtraBytes / 8
-constexpr int kSlotStateMaxBodies = 127;  // 12 N + 1 doubles fit, and 6 N <= 3 x 256: three early loads per work-item cover every column
+constexpr int kSlotStateDoubles  = 2048;  // kExtraBytes / 8
+constexpr int kSlotStateMaxBodies = 170;  // 12 N + 1 doubles fit, and 6 N <= 4 x 256: four early loads per work-item cover every column
+                                          // (every system whose step is ONE launch: wide systems begin at 6 N = 1024)
 
 #if defined(__HIPCC__)
 #define HC_HOST_DEVICE __host__ __device__

@@ -666,7 +666,7 @@ void setup_direct(hc_ctx* c) {
         return;
     }
     static_assert(hc::kSlotArgBytes == hc::DirectQueue::kSlotBytes && hc::kSlotStateDoubles * sizeof(double) == hc::DirectQueue::kExtraBytes &&
-                      12 * hc::kSlotStateMaxBodies + 1 <= hc::kSlotStateDoubles && 6 * hc::kSlotStateMaxBodies <= 768,
+                      12 * hc::kSlotStateMaxBodies + 1 <= hc::kSlotStateDoubles && 6 * hc::kSlotStateMaxBodies <= 1024,
                   "the state behind the step kernel's arguments: hc_limits.hpp and hc_direct.hpp must agree");
     static_assert(sizeof(hc::NearArgs) <= hc::DirectQueue::kSlotBytes && sizeof(hc::WideStepArgs) <= hc::DirectQueue::kSlotBytes,
                   "an argument block does not fit a kernarg slot of the direct queue");

@@ -346,7 +346,7 @@ typedef struct hc_profile_stats {
     double multi_doorbell_offset_last, multi_doorbell_offset_sum;
     long long multi_calls;
     long long slot_state_steps;    /* steps whose body state travelled behind the step kernel's argument block (direct dispatch, one-launch steps
-                                    * of systems of up to 127 bodies): the kernel requests it together with its arguments, not after them */
+                                    * of systems of up to 170 bodies, i.e. every system that is not wide): the kernel requests it together with its arguments, not after them */
     long long wide_fused_steps;    /* block steps of a wide system (6N >= 1024) whose own-sample slices and step kernel went out as ONE launch (wide_step_kernel) */
     long long ring_grows_for_pass; /* times the history ring was re-allocated so that a pass one block ahead can read its view of the
                                     * history while the block's steps push their samples (steps well below the IRF spacing) */

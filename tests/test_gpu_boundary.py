@@ -262,12 +262,12 @@ def test_every_step_proves_it_read_this_steps_state(monkeypatch, direct):
     good.step(0.56, *st)  # an untouched context goes on
 
 
-@pytest.mark.parametrize("N, sharded", [(1, False), (6, False), (6, True), (127, False), (130, False)], ids=["1-body", "6-bodies", "6-bodies-row-shards", "127-bodies", "130-bodies-classic"])
+@pytest.mark.parametrize("N, sharded", [(1, False), (6, False), (6, True), (127, False), (170, False), (171, False)], ids=["1-body", "6-bodies", "6-bodies-row-shards", "127-bodies", "170-bodies", "171-bodies-wide-classic"])
 def test_state_behind_the_step_kernels_arguments_is_bitwise_the_classic_path(monkeypatch, N, sharded):
     """On the direct path a step that is ONE kernel takes its body state behind that kernel's argument block (a slot of the kernarg
-    ring holds 4 KB of arguments + 12 KB the kernel addresses from its kernarg segment pointer: finalize_kernel<4, true> requests its
+    ring holds 4 KB of arguments + 16 KB the kernel addresses from its kernarg segment pointer: finalize_kernel<4, true> requests its
     velocities before it has read a single argument -- hc_step.cpp: fill_slot_state, hc_limits.hpp: kSlotArgBytes).  Systems of up to
-    127 bodies; steps with a kernel in front of the step kernel (plain steps, wide systems) and HC_SLOT_STATE=0 store the state in the
+    170 bodies (every system that is not wide); steps with a kernel in front of the step kernel (plain steps, wide systems) and HC_SLOT_STATE=0 store the state in the
     context's buffer as before.  Same arithmetic from the same values: bitwise the forces of the classic path over blocks, plain steps
     (irregular step sizes), a step back in time and the per-step canary; row shards take their own bodies' positions only."""
     import hydrochrono_amd.hydro as hydro
@@ -298,7 +298,7 @@ def test_state_behind_the_step_kernels_arguments_is_bitwise_the_classic_path(mon
             h.close()
     assert np.array_equal(runs[0], runs[1])
     assert all(c == 0 for c in counts[1])
-    if N <= 127:
+    if N <= 170:
         assert all(c >= 150 for c in counts[0]), counts  # the block steps
         assert all(c < len(times) for c in counts[0]), counts  # ... but not the plain ones
     else:

@@ -1546,7 +1546,8 @@ __global__ void __launch_bounds__(256) scatter_kernel(ScatterArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double* vs = reinterpret_cast<double*>(smem_raw);  // [8 * gps_per_slice]: the slice's columns of the sample's velocities
     __shared__ double red[4][16];
-    touch_args<sizeof(ScatterArgs)>();
+    // (no touch_args here: a workgroup needs the head of the 2.6 KB block and ONE row of its target tables; requesting all 41 lines
+    // cost 0.5-0.8 us per launch at C4/8, profiles/r04/c4_rank_share_kernel_stats_by_grid.csv before / after)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4;
     const int rt = (int)blockIdx.x % a.K.ntiles, rest = (int)blockIdx.x / a.K.ntiles;
     const int si = rest / a.n_slices, sl = rest - si * a.n_slices;

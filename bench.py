@@ -77,7 +77,7 @@ def parse():
                     help="default: strong (one coupled array sharded over the ranks) when N > 1, else the single-GPU C3 case")
     ap.add_argument("--profile-stride", type=int, default=17, help="HIP-event sampling stride for the per-step launches (co-prime "
                     "with the 16-step look-ahead period); every look-ahead pass, the roofline kernel, is timed regardless")
-    ap.add_argument("--lookahead", type=int, default=32, help="steps per look-ahead block (16 or 32); 0: plain per-step evaluation (K streamed every step)")
+    ap.add_argument("--lookahead", type=int, default=32, help="steps per look-ahead block (16 or 32; 64: the experimental depth of profiles/r05); 0: plain per-step evaluation (K streamed every step)")
     ap.add_argument("--step-dt", type=float, default=DT, help="caller's step size (default = the IRF grid spacing, the common "
                     "case; e.g. 0.007 makes every IRF sample a true interpolation, SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -484,7 +484,7 @@ def main():
     # max(1, ~K/lookahead) passes -- pessimistic for K < lookahead, neutral for K >> lookahead.
     align = 0
     if args.lookahead > 0:
-        Lb = 16 if args.lookahead <= 16 else 32
+        Lb = 16 if args.lookahead <= 16 else (32 if args.lookahead <= 32 else 64)
         first = args.warmup + args.steps // 2          # earliest step index the boundary (a multiple of Lb) may have
         boundary = ((first + Lb - 1) // Lb) * Lb
         align = boundary - first

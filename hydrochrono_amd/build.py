@@ -1,8 +1,13 @@
 """Build recipe for the native libraries (hipcc, gfx950 only).  Used by __graft_entry__.build() and `python -m hydrochrono_amd.build`.
 
-  hydrochrono_amd/lib/libhydrochrono_amd.so   C ABI + HIP kernels (include/hydrochrono_amd.h)
+  hydrochrono_amd/lib/libhydrochrono_amd.so   C ABI + HIP kernels (include/hydrochrono_amd.h): the RELEASE library
   hydrochrono_amd/lib/hc_kernels.co           the kernels as a stand-alone gfx950 code object (direct AQL dispatch of the step path)
-  hydrochrono_amd/lib/libhc_bemio.so          optional BEMIO-HDF5 reader (only where libhdf5 is installed)
+  hydrochrono_amd/lib/libhc_bemio.so          optional BEMIO-HDF5 reader / result-file writer (only where libhdf5 is installed); depends on
+                                              neither flavour of the main library
+  hydrochrono_amd/lib/libhydrochrono_amd_tuning.so + hc_kernels_tuning.co
+                                              the same sources with -DHC_TUNING: the sweep / A-B / fault-injection switches (HC_TUNE_INT
+                                              in csrc/hc_internal.hpp) and the kernel variants that were measured and not taken
+                                              (EXPERIMENTS.md).  The tests that need such a switch load this one (capi.use_flavor).
 """
 import os
 import shutil
@@ -14,12 +19,14 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 MAIN_LIB = os.path.join(LIBDIR, "libhydrochrono_amd.so")
+TUNING_LIB = os.path.join(LIBDIR, "libhydrochrono_amd_tuning.so")
 BEMIO_LIB = os.path.join(LIBDIR, "libhc_bemio.so")
 
 SOURCES = ["hc_kernels.hip", "hc_runtime.cpp", "hc_step.cpp", "hc_pass.cpp", "hc_setup.cpp", "hc_query.cpp", "hc_direct.cpp", "hc_host_math.cpp", "hc_yaml.cpp",
            "hc_eta_fft.cpp"]
 KERNEL_CO = os.path.join(LIBDIR, "hc_kernels.co")  # the same kernels as a stand-alone code object, for the direct AQL dispatch (hc_direct.hpp)
-HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_internal.hpp", "hc_host_math.hpp", "hc_limits.hpp", "hc_plan.hpp", "hc_history.hpp", "hc_direct.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h"),
+TUNING_CO = os.path.join(LIBDIR, "hc_kernels_tuning.co")
+HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_internal.hpp", "hc_host_math.hpp", "hc_limits.hpp", "hc_plan.hpp", "hc_history.hpp", "hc_direct.hpp", "hc_fanout.hpp", "hc_h5data.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h"),
            os.path.join(ROOT, "include", "hydrochrono_amd_host.h"), os.path.join(ROOT, "include", "hydrochrono_amd_yaml.h")]
 
 
@@ -49,17 +56,24 @@ def _find_hdf5():
     return None
 
 
-def build(force=False, verbose=False):
-    os.makedirs(LIBDIR, exist_ok=True)
+def _build_flavor(lib, kernel_co, objdir, defines, force, verbose):
+    """One flavour of the main library: one object per source, compiled side by side (the kernels take most of the time), one link,
+    and the kernels once more as a stand-alone code object.  Returns the processes still running (the code object's compile)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    if force or _newer(MAIN_LIB, deps):
-        # one object per source, compiled side by side (the kernels take most of the time), then one link
-        objdir = os.path.join(LIBDIR, "obj")
+    headers = [d for d in deps if d.endswith((".hpp", ".h"))]
+    kernel_src = os.path.join(CSRC, "hc_kernels.hip")
+    pending = []
+    if force or _newer(kernel_co, [kernel_src] + headers):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "--no-gpu-bundle-output", "-Wno-unused-result"] + defines + [
+            "-I", os.path.join(ROOT, "include"), kernel_src, "-o", kernel_co]
+        if verbose:
+            print(" ".join(cmd))
+        pending.append((cmd, subprocess.Popen(cmd)))
+    if force or _newer(lib, deps):
         os.makedirs(objdir, exist_ok=True)
-        base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
+        base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-result"] + defines + ["-I", os.path.join(ROOT, "include")]
         objs = [os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o") for src in srcs]
-        headers = [d for d in deps if d.endswith((".hpp", ".h"))]
         todo = [(src, obj) for src, obj in zip(srcs, objs) if force or _newer(obj, [src] + headers)]
         procs = []
         for src, obj in todo:
@@ -70,23 +84,27 @@ def build(force=False, verbose=False):
         for cmd, pr in procs:
             if pr.wait() != 0:
                 raise subprocess.CalledProcessError(pr.returncode, cmd)
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", MAIN_LIB, "-ldl", "-lrocfft", "-lhsa-runtime64"]
+        # -Bsymbolic: the library's calls of its own entry points stay inside it whichever flavour was loaded first
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic"] + objs + ["-o", lib, "-ldl", "-lrocfft", "-lhsa-runtime64"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
-    kernel_src = os.path.join(CSRC, "hc_kernels.hip")
-    if force or _newer(KERNEL_CO, [kernel_src] + [d for d in deps if d.endswith((".hpp", ".h"))]):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "--no-gpu-bundle-output", "-Wno-unused-result",
-               "-I", os.path.join(ROOT, "include"), kernel_src, "-o", KERNEL_CO]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+    return pending
+
+
+def build(force=False, verbose=False, tuning=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    pending = _build_flavor(MAIN_LIB, KERNEL_CO, os.path.join(LIBDIR, "obj"), [], force, verbose)
+    if tuning:
+        pending += _build_flavor(TUNING_LIB, TUNING_CO, os.path.join(LIBDIR, "obj_tuning"), ["-DHC_TUNING"], force, verbose)
+    for cmd, pr in pending:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     h5 = _find_hdf5()
     bemio_src = os.path.join(CSRC, "hc_bemio.cpp")
-    if h5 and (force or _newer(BEMIO_LIB, [bemio_src, os.path.join(CSRC, "hc_h5data.hpp"), MAIN_LIB])):
+    if h5 and (force or _newer(BEMIO_LIB, [bemio_src, os.path.join(CSRC, "hc_h5data.hpp")])):
         inc, lib = h5
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", bemio_src, "-o", BEMIO_LIB, "-I", inc, "-I", os.path.join(ROOT, "include"),
-               "-L", lib, "-lhdf5", "-L", LIBDIR, "-lhydrochrono_amd", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{lib}"]
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", bemio_src, "-o", BEMIO_LIB, "-I", inc, "-L", lib, "-lhdf5", f"-Wl,-rpath,{lib}"]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd)
@@ -96,4 +114,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, tuning="--no-tuning" not in sys.argv))

@@ -8,6 +8,9 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libhydrochrono_amd.so")
+# the same sources built with -DHC_TUNING (hydrochrono_amd/build.py): reads the sweep / A-B / fault-injection switches of
+# csrc/hc_internal.hpp (HC_TUNE_INT) and holds the kernel variants that were measured and not taken; loaded by tests and probes only
+TUNING_LIB_PATH = os.path.join(_PKG, "lib", "libhydrochrono_amd_tuning.so")
 
 HC_OK, HC_ERR_RUNTIME, HC_ERR_OUT_OF_RANGE, HC_ERR_INVALID, HC_ERR_DEVICE, HC_ERR_UNSUPPORTED = range(6)
 
@@ -44,7 +47,8 @@ class ProfileStats(C.Structure):
                 ("ahead_pass_slices", C.c_longlong), ("ahead_blocks", C.c_longlong),
                 ("pass_lane_launches", C.c_longlong),
                 ("multi_doorbell_offset_last", C.c_double), ("multi_doorbell_offset_sum", C.c_double), ("multi_calls", C.c_longlong),
-                ("slot_state_steps", C.c_longlong), ("wide_fused_steps", C.c_longlong), ("ring_grows_for_pass", C.c_longlong)]
+                ("slot_state_steps", C.c_longlong), ("wide_fused_steps", C.c_longlong),
+                ("schedule_blocks_ahead", C.c_longlong), ("schedule_blocks_at_start", C.c_longlong), ("ring_grows_for_pass", C.c_longlong)]
 
 
 # name -> (restype, argtypes); every symbol include/hydrochrono_amd.h declares
@@ -148,32 +152,61 @@ SIGNATURES.update({
                                                     C.POINTER(C.c_void_p), c_int_p, c_int_p, C.c_char_p, C.c_size_t]),
 })
 
-_lib = None
-_step_raw = None
+_libs = {}        # flavour -> loaded library
+_step_raws = {}   # flavour -> hc_step bound with integer arguments
+_flavor = "tuning" if os.environ.get("HYDROCHRONO_AMD_FLAVOR", "release") == "tuning" else "release"  # (subprocesses of tests / sweeps)
 
 
-def step_raw():
+def flavor():
+    return _flavor
+
+
+class use_flavor:
+    """`with capi.use_flavor("tuning"):` -- objects created inside (HydroForces, ...) bind to libhydrochrono_amd_tuning.so and keep it
+    for their lifetime; the release library stays the default outside.  Both may be loaded in one process: they share nothing but
+    the HIP runtime (each is linked -Bsymbolic and loaded RTLD_LOCAL)."""
+
+    def __init__(self, name):
+        if name not in ("release", "tuning"):
+            raise ValueError(name)
+        self.name = name
+
+    def __enter__(self):
+        global _flavor
+        self.prev, _flavor = _flavor, self.name
+        return load()
+
+    def __exit__(self, *exc):
+        global _flavor
+        _flavor = self.prev
+        return False
+
+
+def step_raw(lib=None):
     """hc_step bound with integer (address) arguments: skips the per-call ctypes pointer conversions."""
-    global _step_raw
-    if _step_raw is None:
+    lib = lib or load()
+    fn = _step_raws.get(id(lib))
+    if fn is None:
         proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
-        _step_raw = proto(("hc_step", load()))
-    return _step_raw
+        fn = _step_raws[id(lib)] = proto(("hc_step", lib))
+    return fn
 
 
-def load():
-    """Load libhydrochrono_amd.so; raises if it has not been built (no fallback)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(which=None):
+    """Load libhydrochrono_amd.so (or, inside use_flavor("tuning") / with which="tuning", its tuning build); raises if it has not
+    been built (no fallback)."""
+    which = which or _flavor
+    if which in _libs:
+        return _libs[which]
+    path = LIB_PATH if which == "release" else TUNING_LIB_PATH
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build the HIP extension first (python -m hydrochrono_amd.build, or "
+            f"{path} is missing: build the HIP extension first (python -m hydrochrono_amd.build, or "
             "__graft_entry__.build()).  The hydro-force path has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[which] = lib
     return lib

@@ -1,8 +1,9 @@
-// hc_bemio.cpp -- BEMIO-HDF5 ingest (libhc_bemio.so; optional, needs libhdf5).
+// hc_bemio.cpp -- BEMIO-HDF5 reader / result-file writer (libhc_bemio.so; optional, needs libhdf5).
 //
-// Reads exactly the datasets H5FileInfo::ReadH5Data reads (src/h5fileinfo.cpp:35-90) for body1..bodyN and hands
-// them, unscaled, to the raw-array setters of the C ABI, which apply the reference's rho / rho*g scaling.
-// HDF5 C API only; dataset element order is the file's row-major order, as the setters expect.
+// Reads exactly the datasets H5FileInfo::ReadH5Data reads (src/h5fileinfo.cpp:35-90) for body1..bodyN, unscaled: the caller
+// (hc_setup.cpp: hc_load_bemio_h5, hc_h5_read) hands them to the raw-array setters of the C ABI, which apply the reference's
+// rho / rho*g scaling.  HDF5 C API only; dataset element order is the file's row-major order, as the setters expect.
+// The library calls nothing of libhydrochrono_amd.so: data in, data out (either flavour of the main library loads it).
 #include <hdf5.h>
 
 #include <cmath>
@@ -13,8 +14,9 @@
 #include <string>
 #include <vector>
 
-#include "../../include/hydrochrono_amd.h"
 #include "hc_h5data.hpp"
+
+namespace { constexpr int HC_OK = 0, HC_ERR_RUNTIME = 1; }  // (status values of include/hydrochrono_amd.h)
 
 namespace {
 
@@ -83,52 +85,57 @@ double read_scalar(hid_t file, const std::string& name) {
     return v;
 }
 
-void ok(hc_ctx* ctx, int rc) {
-    if (rc != HC_OK) throw H5Error(hc_last_error(ctx));
+// body<b + 1> of an N-body file; with_K = false leaves the radiation IRF tensor {6, 6N, S} unread (q.K empty; q.rirf_t is read)
+void read_body(hid_t file, int N, int b, size_t nw, bool with_K, hc_h5data::Body& q) {
+    const int D            = 6 * N;
+    const std::string body = "body" + std::to_string(b + 1);
+    q.disp_vol       = read_scalar(file, body + "/properties/disp_vol");
+    const auto cg    = read_doubles(file, body + "/properties/cg");
+    const auto cb    = read_doubles(file, body + "/properties/cb");
+    if (cg.size() < 3 || cb.size() < 3) throw H5Error(body + ": cg/cb must have 3 entries");
+    const auto lin = read_doubles(file, body + "/hydro_coeffs/linear_restoring_stiffness");
+    if (lin.size() != 36) throw H5Error(body + ": linear_restoring_stiffness must be 6x6");
+    for (int k = 0; k < 3; ++k) {
+        q.cg[k] = cg[static_cast<size_t>(k)];
+        q.cb[k] = cb[static_cast<size_t>(k)];
+    }
+    for (int k = 0; k < 36; ++k) q.lin[k] = lin[static_cast<size_t>(k)];
+    q.ainf = read_doubles(file, body + "/hydro_coeffs/added_mass/inf_freq");
+    if (q.ainf.size() != static_cast<size_t>(6) * D) throw H5Error(body + ": added_mass/inf_freq must be 6 x 6N");
+    q.rirf_t = read_doubles(file, body + "/hydro_coeffs/radiation_damping/impulse_response_fun/t");
+    q.K.clear();
+    if (with_K) {
+        std::vector<hsize_t> kd;
+        q.K = read_doubles(file, body + "/hydro_coeffs/radiation_damping/impulse_response_fun/K", &kd);
+        if (kd.size() != 3 || kd[0] != 6 || kd[1] != static_cast<hsize_t>(D) || kd[2] != q.rirf_t.size())
+            throw H5Error(body + ": impulse_response_fun/K must be {6, 6N, len(t)}");
+    }
+    q.mag   = read_doubles(file, body + "/hydro_coeffs/excitation/mag");
+    q.phase = read_doubles(file, body + "/hydro_coeffs/excitation/phase");
+    if (q.mag.size() != 6 * nw || q.phase.size() != 6 * nw) throw H5Error(body + ": excitation mag/phase must be {6,1,len(w)}");
+    q.exc_t = read_doubles(file, body + "/hydro_coeffs/excitation/impulse_response_fun/t");
+    q.exc_f = read_doubles(file, body + "/hydro_coeffs/excitation/impulse_response_fun/f");
+    if (q.exc_f.size() != 6 * q.exc_t.size()) throw H5Error(body + ": excitation impulse_response_fun/f must be {6,1,len(t)}");
+}
+
+void read_header(hid_t file, hc_h5data* out) {
+    out->rho         = read_scalar(file, "simulation_parameters/rho");
+    out->g           = read_scalar(file, "simulation_parameters/g");
+    out->water_depth = read_scalar(file, "simulation_parameters/water_depth");
+    out->w           = read_doubles(file, "simulation_parameters/w");
 }
 
 }  // namespace
 
-// The file's content for body1 .. bodyN, with the shape checks of the reader (src/h5fileinfo.cpp:35-90, 287-294).
+// The file's content for body1 .. bodyN, with the shape checks of the reader (src/h5fileinfo.cpp:35-90, 287-294): everything at
+// once -- the host-side view of a file (H5FileInfo / HydroData, include/hydroc_amd/h5fileinfo.h).
 extern "C" int hc_bemio_read(const char* path, int N, hc_h5data* out, char* err, size_t errlen) {
     try {
         if (N <= 0) throw H5Error("num_bodies must be positive");
         File f(path);
-        out->rho         = read_scalar(f.id, "simulation_parameters/rho");
-        out->g           = read_scalar(f.id, "simulation_parameters/g");
-        out->water_depth = read_scalar(f.id, "simulation_parameters/water_depth");
-        out->w           = read_doubles(f.id, "simulation_parameters/w");
-        const size_t nw  = out->w.size();
-        const int D      = 6 * N;
+        read_header(f.id, out);
         out->bodies.assign(static_cast<size_t>(N), hc_h5data::Body{});
-        for (int b = 0; b < N; ++b) {
-            hc_h5data::Body& q     = out->bodies[static_cast<size_t>(b)];
-            const std::string body = "body" + std::to_string(b + 1);
-            q.disp_vol       = read_scalar(f.id, body + "/properties/disp_vol");
-            const auto cg    = read_doubles(f.id, body + "/properties/cg");
-            const auto cb    = read_doubles(f.id, body + "/properties/cb");
-            if (cg.size() < 3 || cb.size() < 3) throw H5Error(body + ": cg/cb must have 3 entries");
-            const auto lin = read_doubles(f.id, body + "/hydro_coeffs/linear_restoring_stiffness");
-            if (lin.size() != 36) throw H5Error(body + ": linear_restoring_stiffness must be 6x6");
-            for (int k = 0; k < 3; ++k) {
-                q.cg[k] = cg[static_cast<size_t>(k)];
-                q.cb[k] = cb[static_cast<size_t>(k)];
-            }
-            for (int k = 0; k < 36; ++k) q.lin[k] = lin[static_cast<size_t>(k)];
-            q.ainf = read_doubles(f.id, body + "/hydro_coeffs/added_mass/inf_freq");
-            if (q.ainf.size() != static_cast<size_t>(6) * D) throw H5Error(body + ": added_mass/inf_freq must be 6 x 6N");
-            q.rirf_t = read_doubles(f.id, body + "/hydro_coeffs/radiation_damping/impulse_response_fun/t");
-            std::vector<hsize_t> kd;
-            q.K = read_doubles(f.id, body + "/hydro_coeffs/radiation_damping/impulse_response_fun/K", &kd);
-            if (kd.size() != 3 || kd[0] != 6 || kd[1] != static_cast<hsize_t>(D) || kd[2] != q.rirf_t.size())
-                throw H5Error(body + ": impulse_response_fun/K must be {6, 6N, len(t)}");
-            q.mag   = read_doubles(f.id, body + "/hydro_coeffs/excitation/mag");
-            q.phase = read_doubles(f.id, body + "/hydro_coeffs/excitation/phase");
-            if (q.mag.size() != 6 * nw || q.phase.size() != 6 * nw) throw H5Error(body + ": excitation mag/phase must be {6,1,len(w)}");
-            q.exc_t = read_doubles(f.id, body + "/hydro_coeffs/excitation/impulse_response_fun/t");
-            q.exc_f = read_doubles(f.id, body + "/hydro_coeffs/excitation/impulse_response_fun/f");
-            if (q.exc_f.size() != 6 * q.exc_t.size()) throw H5Error(body + ": excitation impulse_response_fun/f must be {6,1,len(t)}");
-        }
+        for (int b = 0; b < N; ++b) read_body(f.id, N, b, out->w.size(), true, out->bodies[static_cast<size_t>(b)]);
     } catch (const std::exception& e) {
         if (err && errlen) std::snprintf(err, errlen, "%s", e.what());
         return HC_ERR_RUNTIME;
@@ -136,22 +143,20 @@ extern "C" int hc_bemio_read(const char* path, int N, hc_h5data* out, char* err,
     return HC_OK;
 }
 
-extern "C" int hc_bemio_load(hc_ctx* ctx, const char* path, char* err, size_t errlen) {
+// One body at a time, for the ingest into a device context (hc_load_bemio_h5): the caller reads body b, hands it to the setters and
+// lets go of it before it asks for the next, so that the host never holds more than one body's {6, 6N, S} tensor -- all bodies at
+// once are (6N)^2 S doubles, tens of gigabytes for a few hundred bodies, and every shard context of a row-sharded system reads the
+// file.  body < 0: the simulation parameters only (out->rho, g, water_depth, w).  with_K = 0: without the radiation IRF tensor (a
+// shard context needs it for the bodies it owns only).
+extern "C" int hc_bemio_read_body(const char* path, int N, int body, int with_K, hc_h5data* out, char* err, size_t errlen) {
     try {
-        int N = 0;
-        ok(ctx, hc_get_sizes(ctx, &N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
-        hc_h5data d;
-        const int rc = hc_bemio_read(path, N, &d, err, errlen);
-        if (rc != HC_OK) return rc;
-        ok(ctx, hc_set_simulation_parameters(ctx, d.rho, d.g, d.water_depth));
-        for (int b = 0; b < N; ++b) {
-            const hc_h5data::Body& q = d.bodies[static_cast<size_t>(b)];
-            ok(ctx, hc_set_body_properties(ctx, b, q.disp_vol, q.cg, q.cb));
-            ok(ctx, hc_set_hydrostatic_stiffness(ctx, b, q.lin));
-            ok(ctx, hc_set_added_mass_inf(ctx, b, q.ainf.data()));
-            ok(ctx, hc_set_rirf(ctx, b, q.rirf_t.data(), static_cast<int>(q.rirf_t.size()), q.K.data()));
-            ok(ctx, hc_set_excitation_rao(ctx, b, d.w.data(), static_cast<int>(d.w.size()), q.mag.data(), q.phase.data()));
-            ok(ctx, hc_set_excitation_irf(ctx, b, q.exc_t.data(), static_cast<int>(q.exc_t.size()), q.exc_f.data()));
+        if (N <= 0 || body >= N) throw H5Error("body index out of range");
+        File f(path);
+        read_header(f.id, out);
+        out->bodies.clear();
+        if (body >= 0) {
+            out->bodies.assign(1, hc_h5data::Body{});
+            read_body(f.id, N, body, out->w.size(), with_K != 0, out->bodies[0]);
         }
     } catch (const std::exception& e) {
         if (err && errlen) std::snprintf(err, errlen, "%s", e.what());
@@ -204,13 +209,11 @@ void write_vector(hid_t group, const char* name, const std::vector<double>& v) {
 
 }  // namespace
 
-extern "C" int hc_bemio_export_irregular(hc_ctx* ctx, const char* path, char* err, size_t errlen) {
+extern "C" int hc_bemio_export_irregular(const char* path, const double* f_hz, const double* S_f, int nf, const double* t_eta, const double* eta_t, int nt,
+                                         char* err, size_t errlen) {
     try {
-        int nf = 0, nt = 0;
-        ok(ctx, hc_get_sizes(ctx, nullptr, nullptr, nullptr, nullptr, &nf, &nt, nullptr, nullptr));
-        std::vector<double> f(nf), S(nf), t(nt), eta(nt);
-        if (nf) ok(ctx, hc_get_spectrum(ctx, f.data(), S.data(), nullptr, nullptr, nullptr));
-        if (nt) ok(ctx, hc_get_eta_table(ctx, t.data(), eta.data()));
+        const std::vector<double> f(f_hz, f_hz + (nf > 0 ? nf : 0)), S(S_f, S_f + (nf > 0 ? nf : 0)), t(t_eta, t_eta + (nt > 0 ? nt : 0)),
+            eta(eta_t, eta_t + (nt > 0 ? nt : 0));
         H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);
         hid_t file = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
         if (file < 0) file = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);

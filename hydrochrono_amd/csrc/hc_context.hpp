@@ -170,7 +170,7 @@ struct hc_ctx {
     int path            = 0;
     hc::DirectKernel dk_finalize_slot;  // finalize_kernel<4, true>: the body state behind the argument block (hc_step.cpp: HostState)
     bool slot_state = false;            // ... in use for this context (HC_SLOT_STATE, systems of up to kSlotStateMaxBodies bodies)
-    hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_mini16, dk_mini32, dk_narrow, dk_wide, dk_added_mass, dk_step, dk_near;
+    hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_block64, dk_mini16, dk_mini32, dk_narrow, dk_wide, dk_added_mass, dk_step, dk_near;
     hc::StepTail tail;
     // split step (hc_step_begin / hc_step_end, hc_step_multi): 0 nothing begun, 1 the begun step was a cache hit (totals in
     // last_total), 2 its results arrive as tagged granules with sequence number `seq`
@@ -245,14 +245,24 @@ struct hc_ctx {
     int chunk_gp_ex_block = 32, nchunks_ex_block = 0;  // excitation chunks of the look-ahead launch
     int mt_mini = 2;                                    // row tiles per workgroup of the short passes (two-level form)
     int mt_narrow = 2;                                  // ... of their narrow form (16 step columns)
+    int mt_block64 = 3;                                 // ... of the experimental depth-64 pass (HC_BLOCK64_MT: 3, 4 or 6)
     int mt_block = 4, mt_block_design = 6;              // row tiles per workgroup of the look-ahead launch (1, 2, 4, 6 or 12)
     int num_cus  = 256;                                 // compute units of the device (grid rounds of the look-ahead launch)
-    int lookahead = 0;  // 0: off, else kLookahead
+    int lookahead = 0;  // 0: off, else 16, 32 (kDepthDefault) or 64 (experimental, hc_set_lookahead)
     hc::Plan plan;
     unsigned long long plan_serial = 0;  // counts the plans made
     // pass schedule (hc_set_pass_schedule): 0 = the pass of a block when the block starts, 1 = one block ahead, in `pass_slices`
-    // launches between the steps of the block before.  d_P / d_E hold two blocks of rows; pe_cur = the half of the current block.
+    // launches between the steps of the block before, 2 = adaptive (the default): per block, from the caller's gaps between the
+    // synchronous steps of the block before (hc_pass.cpp: schedule_ahead_for_next_block).  d_P / d_E hold two blocks of rows;
+    // pe_cur = the half of the current block.
     int pass_ahead = 0, pass_slices = 8, pe_cur = 0;
+    bool ahead_now = false;        // adaptive: the rule's last answer (starts as the static choice by size: wide systems run ahead)
+    int gap_seen = 0, gap_long = 0, gap_long_lo = 0;  // gaps measured since the last decision; how many of them were longer than
+                                   // gap_threshold (it takes a majority of these to GO ahead) / than 0.6 of it (... to STAY ahead)
+    double gap_threshold = 4e-6;   // seconds (HC_PASS_AHEAD_GAP_US; wide systems: 0, see hc_setup.cpp)
+    double gap_hint = -1.0;        // hc_step_multi: the gap its calling thread measured for the whole group (< 0: none, measure here)
+    std::chrono::steady_clock::time_point t_multi_end{};  // (kept on the group's first context) end of the last hc_step_multi
+    bool have_t_multi_end = false;
     hc::AheadPass ahead;
     hc::DeviceBuffer<double> d_partials_far;  // partial sums of the pass in the making (the short passes keep d_partials_block)
     hc::DeviceBuffer<double> d_partials_next; // ... and of the short passes towards the next block when they run on the pass lane

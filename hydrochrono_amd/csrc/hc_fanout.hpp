@@ -9,6 +9,17 @@
 // more than the step), then sleeps on a condition variable.  It runs its item if it has one and stores the generation into its
 // `done` word (release); the caller, after its own item, spins until the `done` word of every worker shows the generation
 // (acquire).  Items must not throw.  One caller at a time: a second thread that finds the pool busy runs its items itself, in order.
+//
+// Which thread runs an item matters to the caller (hc_step.cpp: bind_device caches the current HIP device per WORKER thread only):
+// besides item 0, the calling thread also runs items when the pool is busy, when no thread could be created, and the items beyond
+// `max_workers`.  on_worker_thread() says which kind of thread the item is on.
+//
+// fork(): the child has the pool's bookkeeping but none of its threads.  run() compares the process id with the one the workers were
+// created under; in a child it forgets the inherited workers (their objects are leaked -- there is nothing to join) and their
+// synchronisation objects (a mutex copied while a worker held it would stay locked for ever) and starts afresh.
+//
+// Host cost: a worker that has just served a call spins for `spin_us` before it sleeps, i.e. a host that calls more often than that
+// keeps n - 1 cores busy for the whole run (hydrochrono_amd: HC_MULTI_SPIN_US, INTEGRATION.md has the measured trade-off).
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -19,6 +30,8 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 #if defined(__x86_64__) || defined(__i386__)
 #include <immintrin.h>
@@ -33,23 +46,32 @@ class FanOut {
   public:
     using Fn = void (*)(void* arg, int item);
 
-    explicit FanOut(int max_workers = 63, double spin_us = 1000.0) : max_workers_(max_workers), spin_us_(spin_us) {}
+    explicit FanOut(int max_workers = 63, double spin_us = 1000.0)
+        : max_workers_(max_workers), spin_us_(spin_us), sync_(std::make_unique<Sync>()), pid_(::getpid()) {}
     FanOut(const FanOut&)            = delete;
     FanOut& operator=(const FanOut&) = delete;
     ~FanOut() {
+        if (::getpid() != pid_) {  // a forked child: the threads belong to the parent
+            forget_inherited_workers();
+            return;
+        }
         {
-            std::lock_guard<std::mutex> lk(m_);
+            std::lock_guard<std::mutex> lk(sync_->m);
             stop_.store(true, std::memory_order_seq_cst);
             generation_.fetch_add(1, std::memory_order_seq_cst);
         }
-        cv_.notify_all();
+        sync_->cv.notify_all();
         for (auto& w : workers_)
             if (w->th.joinable()) w->th.join();
     }
 
+    // true on a thread of a FanOut pool (any pool), false on every other thread -- the calling thread included, whichever items it runs
+    static bool on_worker_thread() { return is_worker(); }
+
     // fn(arg, 0) on this thread, fn(arg, g) for g = 1 .. n - 1 on the workers, side by side; returns when all have returned.
     void run(int n, Fn fn, void* arg) {
         if (n <= 0) return;
+        if (::getpid() != pid_) after_fork();
         bool expected = false;
         if (n == 1 || max_workers_ <= 0 || !busy_.compare_exchange_strong(expected, true, std::memory_order_acquire)) {
             for (int g = 0; g < n; ++g) fn(arg, g);  // nothing to share out, or another thread is using the pool
@@ -69,8 +91,8 @@ class FanOut {
         n_   = helpers + 1;
         const uint64_t gen = generation_.fetch_add(1, std::memory_order_seq_cst) + 1;
         if (sleepers_.load(std::memory_order_seq_cst) > 0) {
-            { std::lock_guard<std::mutex> lk(m_); }  // a worker between its predicate check and its wait holds the mutex
-            cv_.notify_all();
+            { std::lock_guard<std::mutex> lk(sync_->m); }  // a worker between its predicate check and its wait holds the mutex
+            sync_->cv.notify_all();
         }
         fn(arg, 0);
         for (int g = helpers + 1; g < n; ++g) fn(arg, g);  // (more items than workers allowed: the rest here)
@@ -92,6 +114,31 @@ class FanOut {
         std::thread th;
         std::atomic<uint64_t> done{0};
     };
+    struct Sync {
+        std::mutex m;
+        std::condition_variable cv;
+    };
+    static bool& is_worker() {
+        static thread_local bool flag = false;
+        return flag;
+    }
+
+    // (child of a fork) the inherited Worker objects describe threads this process does not have: their std::thread members must be
+    // neither joined nor destroyed as joinable, so the objects are leaked; the same for the mutex / condition variable
+    void forget_inherited_workers() {
+        for (auto& w : workers_) (void)w.release();
+        workers_.clear();
+        (void)sync_.release();
+    }
+    void after_fork() {
+        forget_inherited_workers();
+        sync_ = std::make_unique<Sync>();
+        generation_.store(0, std::memory_order_seq_cst);
+        sleepers_.store(0, std::memory_order_seq_cst);
+        busy_.store(false, std::memory_order_seq_cst);
+        stop_.store(false, std::memory_order_seq_cst);
+        pid_ = ::getpid();
+    }
 
     void ensure_workers(int count) {
         while (static_cast<int>(workers_.size()) < count) {
@@ -106,6 +153,8 @@ class FanOut {
     }
 
     void loop(Worker* w, int index, uint64_t seen) {
+        is_worker() = true;
+        Sync* const sy = sync_.get();  // (lives as long as the pool does in this process)
         auto idle_since = std::chrono::steady_clock::now();
         for (;;) {
             // wait for a generation not seen yet: spin first, then sleep
@@ -117,9 +166,9 @@ class FanOut {
                 if (gen != seen) break;
                 if ((++spins & 0x3FF) == 0 &&
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - idle_since).count() > spin_us_) {
-                    std::unique_lock<std::mutex> lk(m_);
+                    std::unique_lock<std::mutex> lk(sy->m);
                     sleepers_.fetch_add(1, std::memory_order_seq_cst);
-                    cv_.wait(lk, [&] { return generation_.load(std::memory_order_seq_cst) != seen; });
+                    sy->cv.wait(lk, [&] { return generation_.load(std::memory_order_seq_cst) != seen; });
                     sleepers_.fetch_sub(1, std::memory_order_seq_cst);
                     gen = generation_.load(std::memory_order_acquire);
                 }
@@ -139,8 +188,8 @@ class FanOut {
     std::atomic<uint64_t> generation_{0};
     std::atomic<int> sleepers_{0};
     std::atomic<bool> stop_{false}, busy_{false};
-    std::mutex m_;
-    std::condition_variable cv_;
+    std::unique_ptr<Sync> sync_;
+    pid_t pid_;
     Fn fn_     = nullptr;
     void* arg_ = nullptr;
     int n_     = 0;

@@ -81,6 +81,17 @@ void ev_end(hc::EventPair* ev, hipStream_t stream);
 bool profiling_tool_attached();
 int direct_tag(const hc_ctx* c, int kind);
 int env_int(const char* name, int fallback);
+// Environment switches.  The RELEASE library reads the operational ones only (env_int: HC_DIRECT, HC_ARM, HC_PASS_AHEAD,
+// HC_PASS_AHEAD_GAP_US, HC_PASS_CONCURRENT, HC_DEVICE_SHARED, HC_MULTI_THREADS, HC_MULTI_SPIN_US; HC_STEP_TIMEOUT_S in hc_step.cpp --
+// INTEGRATION.md lists them; tests/test_capi_exports.py checks the list against the strings of the built library).  Everything that
+// exists for sweeps, A/B runs and fault injection -- tile counts, chunk lengths, kernel variants, the canary switch -- is read by the
+// TUNING build only (-DHC_TUNING: libhydrochrono_amd_tuning.so + hc_kernels_tuning.co, which the tests that need a knob load);
+// in the release build the macro is its default and the name does not exist.
+#ifdef HC_TUNING
+#define HC_TUNE_INT(name, fallback) ::hc::detail::env_int(name, fallback)
+#else
+#define HC_TUNE_INT(name, fallback) (fallback)
+#endif
 void setup_panel_geometry(hc_ctx* c);
 hc::Panel rad_panel(const hc_ctx* c);
 void choose_conv_config(hc_ctx* c);
@@ -90,6 +101,9 @@ int far_chunk_gp(const hc_ctx* c);
 int far_chunks_per_slice(const hc_ctx* c);
 int default_pass_slices(const hc_ctx* c);
 int default_pass_ahead(const hc_ctx* c);
+bool pass_ahead_size_ok(const hc_ctx* c);
+bool pass_ahead_possible(const hc_ctx* c);
+void reset_schedule_state(hc_ctx* c);
 void ensure_processed(hc_ctx* c);
 void check_device_flag(hc_ctx* c);
 void stage_state(hc_ctx* c, const double* pos, const double* rpy, const double* linvel, const double* angvel);

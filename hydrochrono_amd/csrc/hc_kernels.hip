@@ -350,18 +350,25 @@ __global__ void __launch_bounds__(kConvThreads) conv_step_kernel(StepArgs a) {
 
 template <int MT>
 static void launch_conv_step_mt(const StepArgs& a, int unroll, int nblocks, size_t smem, hipStream_t stream) {
-    if (unroll == 1) hipLaunchKernelGGL((conv_step_kernel<MT, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-    else if (unroll == 3) hipLaunchKernelGGL((conv_step_kernel<MT, 3>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
-    else hipLaunchKernelGGL((conv_step_kernel<MT, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
+#ifdef HC_TUNING  // (unroll factors 1 and 3: sweeps only)
+    if (unroll == 1) { hipLaunchKernelGGL((conv_step_kernel<MT, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, a); return; }
+    if (unroll == 3) { hipLaunchKernelGGL((conv_step_kernel<MT, 3>), dim3(nblocks), dim3(kConvThreads), smem, stream, a); return; }
+#endif
+    (void)unroll;
+    hipLaunchKernelGGL((conv_step_kernel<MT, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, a);
 }
 
 StepLaunch step_launch_config(const StepArgs& a, int mt) {
     StepLaunch l;
     l.nblocks = ((a.nchunks_rad + a.nchunks_ex + 7) >> 3) * 8 * a.ngroups;  // octets of chunks (kernel's block mapping)
+#ifdef HC_TUNING
     static const int unroll = [] {
-        const char* e = std::getenv("HC_CONV_UNROLL");  // tuning experiments only
+        const char* e = std::getenv("HC_CONV_UNROLL");
         return e ? std::atoi(e) : 2;
     }();
+#else
+    constexpr int unroll = 2;
+#endif
     l.smem = (size_t)a.rhs_capacity * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * (sizeof(Bracket) + sizeof(double));
     l.MT   = (mt == 4 || mt == 2) ? mt : 1;
     l.U    = (unroll == 1 || unroll == 3) ? unroll : 2;
@@ -842,6 +849,22 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
     load_weights();
     auto consume = [&](const int slot) {
         if (gp_c < gp1) {  // scalar branch around the matrix work of fragments past the end (no loads inside)
+            if constexpr (NB > 2) {
+                // Depth 64 is bound by the matrix pipe, not by HBM, and a wave alone on its SIMD issues in order: with all B operands
+                // formed first (what the scheduler makes of the form below) the pipe runs dry during those 16 vector instructions of
+                // every fragment (SQ counters, profiles/r05: matrix pipe busy 0.77).  So each B operand is formed right behind the
+                // MFMAs of the group before -- in their shadow -- and nothing may move across the group boundaries.
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int tb = 0; tb < NB; ++tb) {
+                        const double u = fma(cwo[tb], von[slot][h][tb].x, cwn[tb] * von[slot][h][tb].y);  // (the expression of the other depths: rounds alike)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[tb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(h == 0 ? kv[slot][m].x : kv[slot][m].y, u, acc[tb][m], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            } else {
             double u[2][NB];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -855,6 +878,7 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
             for (int tb = 0; tb < NB; ++tb)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[tb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[slot][m].y, u[1][tb], acc[tb][m], 0, 0, 0);
+            }
         }
         gp_c += 4;
         cb_c += 32;
@@ -914,8 +938,13 @@ __global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs
     if (chunk >= (a.chunk_last > 0 ? a.chunk_last : a.nchunks)) return;
 
     // the per-DoF ring must be addressable with 32-bit byte offsets for the scalar-base form (4 GB: far beyond any real history)
-    if ((a.hist.D & 7) == 0 && (size_t)a.hist.D * a.hist.HcapT < ((size_t)1 << 28)) block_rad_stream_uni<MT, R, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
-    else block_rad_stream<MT, (NB > 1) ? 2 : R, NB, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+    if constexpr (NB > 2) {
+        // depth 64 (experimental): the uniform form only -- the host selects this depth for D % 8 == 0 systems
+        block_rad_stream_uni<MT, R, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+    } else {
+        if ((a.hist.D & 7) == 0 && (size_t)a.hist.D * a.hist.HcapT < ((size_t)1 << 28)) block_rad_stream_uni<MT, R, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+        else block_rad_stream<MT, (NB > 1) ? 2 : R, NB, false>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
+    }
     // The excitation force depends on time only: its work items over Kex (a fraction of a percent of K) for the predicted times ride
     // at the end of radiation workgroups, so the launch keeps its number of workgroups (grid rounds on the chip).  An item is
     // (excitation chunk, block of 16 steps, group of MTE row tiles) and takes about 8 us of dependent loads (free-surface table
@@ -952,7 +981,8 @@ template <int MT, int R, int R32 = R + 1>
 static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, hipStream_t stream) {
     static size_t granted16 = 0, granted32 = 0;
     if (b.depth == 32) {
-        static const int v32 = [] { const char* e = std::getenv("HC_BLOCK_V32"); return e ? std::atoi(e) : 0; }();  // tuning runs only
+#ifdef HC_TUNING  // variants of the depth-32 pass measured and not taken (EXPERIMENTS.md): the tuning build keeps them selectable
+        static const int v32 = [] { const char* e = std::getenv("HC_BLOCK_V32"); return e ? std::atoi(e) : 0; }();
         if constexpr (MT == 4) {
             if (v32 == 1) { hipLaunchKernelGGL((conv_block_kernel<4, 3, 2, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
             if (v32 == 2) { hipLaunchKernelGGL((conv_block_kernel<4, 4, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
@@ -963,6 +993,7 @@ static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, h
             if (v32 == 5) { hipLaunchKernelGGL((conv_block_kernel<6, 3, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
             if (v32 == 6) { hipLaunchKernelGGL((conv_block_kernel<6, 6, 2, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
         }
+#endif
         allow_dynamic_lds(conv_block_kernel<MT, R32, 2>, smem, granted32);
         hipLaunchKernelGGL((conv_block_kernel<MT, R32, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
     } else {
@@ -970,6 +1001,23 @@ static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, h
         hipLaunchKernelGGL((conv_block_kernel<MT, R, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b);
     }
 }
+
+#ifdef HC_TUNING
+// depth 64 (NB = 4; tuning build only -- measured in round 5 and not taken, EXPERIMENTS.md): MT row tiles per workgroup x R fragments in
+// flight, both from the environment for the sweep of profiles/r05 (HC_BLOCK64_R; the tile count comes with the launch)
+static int block64_R() {
+    static const int r = [] { const char* e = std::getenv("HC_BLOCK64_R"); const int v = e ? std::atoi(e) : 4; return (v == 3 || v == 5) ? v : 4; }();
+    return r;
+}
+template <int MT>
+static void launch_conv_block64_mt(const BlockArgs& b, int nblocks, size_t smem, hipStream_t stream) {
+    static size_t granted[3] = {0, 0, 0};
+    const int R = block64_R();
+    if (R == 3) { allow_dynamic_lds(conv_block_kernel<MT, 3, 4, 1>, smem, granted[0]); hipLaunchKernelGGL((conv_block_kernel<MT, 3, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); }
+    else if (R == 5) { allow_dynamic_lds(conv_block_kernel<MT, 5, 4, 1>, smem, granted[2]); hipLaunchKernelGGL((conv_block_kernel<MT, 5, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); }
+    else { allow_dynamic_lds(conv_block_kernel<MT, 4, 4, 1>, smem, granted[1]); hipLaunchKernelGGL((conv_block_kernel<MT, 4, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); }
+}
+#endif
 
 BlockLaunch block_launch_config(const BlockArgs& a, int mt, BlockArgs* b) {
     BlockLaunch l;
@@ -979,7 +1027,18 @@ BlockLaunch block_launch_config(const BlockArgs& a, int mt, BlockArgs* b) {
     b->lds_front_doubles = max(4 * kUWave, 4 * mt * 256);  // [wave][tile][16x16] reduction buffer / per-wave U sub-tiles
     l.smem    = (size_t)b->lds_front_doubles * sizeof(double) + (size_t)max(1, a.max_steps_per_chunk) * b->depth * 24;
     // template arguments of the kernel this (mt, depth) runs: conv_block_kernel<MT, R, NB, WPS>
-    l.MT  = (mt == 12 || mt == 6 || mt == 4 || mt == 2) ? mt : 1;
+#ifdef HC_TUNING
+    if (a.depth == 64) {
+        l.MT  = (mt == 6 || mt == 4 || mt == 3) ? mt : 3;
+        l.NB  = 4;
+        l.R   = block64_R();
+        l.WPS = 1;
+        return l;
+    }
+    l.MT  = (mt == 12 || mt == 6 || mt == 4 || mt == 2) ? mt : 1;  // (12 tiles per workgroup: HC_BLOCK_MT=12, measured and not taken)
+#else
+    l.MT  = (mt == 6 || mt == 4 || mt == 2) ? mt : 1;
+#endif
     const int R16 = (l.MT == 12 || l.MT == 6) ? 3 : 4;
     l.NB  = a.depth == 32 ? 2 : 1;
     l.R   = a.depth == 32 ? (l.MT == 12 ? 2 : R16 + 1) : R16;
@@ -993,8 +1052,16 @@ void launch_conv_block(const BlockArgs& a, int mt, hipStream_t stream) {
     const int nblocks   = l.nblocks;
     const size_t smem   = l.smem;
     if (nblocks <= 0) return;
-    if (mt == 12) launch_conv_block_mt<12, 3, 2>(b, nblocks, smem, stream);
-    else if (mt == 6) launch_conv_block_mt<6, 3>(b, nblocks, smem, stream);
+#ifdef HC_TUNING
+    if (b.depth == 64) {
+        if (mt == 6) launch_conv_block64_mt<6>(b, nblocks, smem, stream);
+        else if (mt == 4) launch_conv_block64_mt<4>(b, nblocks, smem, stream);
+        else launch_conv_block64_mt<3>(b, nblocks, smem, stream);
+        return;
+    }
+    if (mt == 12) { launch_conv_block_mt<12, 3, 2>(b, nblocks, smem, stream); return; }
+#endif
+    if (mt == 6) launch_conv_block_mt<6, 3>(b, nblocks, smem, stream);
     else if (mt == 4) launch_conv_block_mt<4, 4>(b, nblocks, smem, stream);
     else if (mt == 2) launch_conv_block_mt<2, 4>(b, nblocks, smem, stream);
     else launch_conv_block_mt<1, 4>(b, nblocks, smem, stream);

@@ -4,10 +4,12 @@
 
 namespace hc {
 
-constexpr int kLookahead = 32;  // most future steps one blocked pass covers (1 or 2 blocks of 16 = N dimension of v_mfma_f64_16x16x4_f64)
+constexpr int kLookahead = 64;  // most future steps one blocked pass covers (1, 2 or 4 blocks of 16 = N dimension of v_mfma_f64_16x16x4_f64);
+                                // the shipped depths are 16 and 32, 64 is the experimental single-level form of hc_set_lookahead(ctx, 64)
+constexpr int kDepthDefault = 32;  // the look-ahead depth of a fresh context (hc_set_lookahead)
 constexpr int kNearMax        = 8;   // IRF samples a step contracts itself (own sample + a deferred one)
 constexpr int kTermMax        = 192; // term slots a step adds (scatter results; x column slices for wide systems)
-constexpr int kScatterSamples = 64;  // IRF samples s < kScatterSamples can be targets of a scatter
+constexpr int kScatterSamples = 80;  // IRF samples s < kScatterSamples can be targets of a scatter
 constexpr int kTargets        = 3;   // later block steps one (sample, IRF sample) result can contribute to
 
 constexpr int kSubBlock       = 8;   // steps per sub-block of the two-level form (wide systems)

@@ -85,7 +85,7 @@ PassSetup make_pass(hc_ctx* c, bool with_exc, bool next_block) {
     b.width = c->d_width.p;
     // The excitation force depends on time only, so the pass also evaluates it for the 16 predicted times (extra chunks
     // over Kex in the same launch) -- provided every predicted time passes the window tests a real step would have to pass.
-    static const bool exc_in_block = env_int("HC_EXC_IN_BLOCK", 1) != 0;
+    static const bool exc_in_block = HC_TUNE_INT("HC_EXC_IN_BLOCK", 1) != 0;
     bool exc_block = exc_in_block && with_exc && c->wave_kind == hc::kWaveIrregular && c->nchunks_ex_block > 0;
     for (int j = 0; j < L && exc_block; ++j) exc_block = wave_window_ok(c, b.tpred[j]);
     ps.exc_block  = exc_block;
@@ -97,7 +97,7 @@ PassSetup make_pass(hc_ctx* c, bool with_exc, bool next_block) {
     b.Dpad        = c->Dpad;
     b.error_flag  = c->d_err.p;
     b.item_counter = c->d_err.p + 1;
-    b.ngroups     = c->ntiles / c->mt_block;
+    b.ngroups     = c->ntiles / (L == 64 ? c->mt_block64 : c->mt_block);
     // algorithmic bytes: summed over the steps of the block, step j's share of K and of the velocity vector from s_cut[j]
     // on ...; what the launch has to move once: the live part of K, Kex and the staged vectors
     double samples = 0.0;
@@ -107,7 +107,7 @@ PassSetup make_pass(hc_ctx* c, bool with_exc, bool next_block) {
     ps.bytes_steps = rad_16 + exc_16;
     ps.rad_once    = 8.0 * (static_cast<double>(c->Dloc) * b.F + b.F);
     ps.exc_once    = exc_block ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
-    if (env_int("HC_DEBUG_PLAN", 0) != 0) {
+    if (HC_TUNE_INT("HC_DEBUG_PLAN", 0) != 0) {
         std::fprintf(stderr, "[hc] pass%s t0=%.6f dt=%.17g Hv=%d F/D=%d nchunks=%d exc=%d\n     s_cut:", next_block ? " (next block)" : "", pl.tgrid[0], pl.dt, Hv,
                      b.F / c->D, b.nchunks, (int)exc_block);
         for (int j = 0; j < L; ++j) std::fprintf(stderr, " %d", b.s_cut[j]);
@@ -131,19 +131,20 @@ void issue_pass_chunks(hc_ctx* c, const PassSetup& ps, int first, int last, bool
     c->prof.block_kernel_bytes      = ps.bytes_steps * (rad_once + exc_once) / std::max(1.0, ps.rad_once + ps.exc_once);
     c->prof.block_kernel_bytes_once = rad_once + exc_once;
     const double exc_share = exc_once / std::max(1.0, rad_once + exc_once);
-    const int L = c->lookahead;
+    const int L  = c->lookahead;
+    const int mt = L == 64 ? c->mt_block64 : c->mt_block;
     if (direct) {
         hc::BlockArgs b2;
-        const hc::BlockLaunch l = hc::block_launch_config(b, c->mt_block, &b2);
+        const hc::BlockLaunch l = hc::block_launch_config(b, mt, &b2);
         if (l.nblocks <= 0) return;
-        c->dq->dispatch(L == 32 ? c->dk_block32 : c->dk_block16, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
+        c->dq->dispatch(L == 64 ? c->dk_block64 : (L == 32 ? c->dk_block32 : c->dk_block16), static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &b2, sizeof b2,
                         direct_tag(c, hc::kEvPass), exc_share, lane);
         c->prof.direct_dispatches += 1;
         if (lane == 2) c->prof.pass_lane_launches += 1;
         return;
     }
     hc::EventPair* ev = ev_begin(c, hc::kEvPass, stream, exc_share);
-    hc::launch_conv_block(b, c->mt_block, stream);
+    hc::launch_conv_block(b, mt, stream);
     ev_end(ev, stream);
     c->prof.hip_launches += 1;
 }
@@ -175,6 +176,37 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
 // `pass_slices` times shorter than those of the ordinary pass (far_chunk_gp); the chunk partials of all slices are added by ONE
 // reduction after the last slice, in chunk order -- the sums do not depend on how the chunks were spread over launches.
 void ahead_drop(hc_ctx* c) { c->ahead.active = false; }
+
+// The adaptive schedule's state as a fresh context has it: no gaps seen, the static choice by size as the first answer (wide systems
+// -- the same switch as the two-level form -- run ahead: their pass is long and the schedule costs a back-to-back caller nothing).
+void reset_schedule_state(hc_ctx* c) {
+    c->gap_seen = c->gap_long = c->gap_long_lo = 0;
+    c->gap_hint  = -1.0;
+    c->ahead_now = hc::near_slices_for(c->D) > 1;
+}
+
+// Does the pass of the block AFTER the one that starts now run one block ahead?  Schedule 0 / 1: as selected.  Adaptive: by majority
+// over the gaps the caller left between its synchronous steps since the last decision (step_begin counts them: the time from the
+// end of one hc_step / hc_step_multi to the begin of the next, whatever the caller did in between -- integrate, call the added-mass
+// product, nothing).  More than half of them longer than gap_threshold: the caller is away between steps, the pass goes beside them;
+// else it steps back to back and the pass runs at block start, unsliced.  Decided per block, from at least a quarter block of gaps;
+// callers that never wait for a step (hc_step_device) leave no gaps and keep the first answer.  A majority, not a mean: one long
+// pause (the host printing a line, the OS taking the core) does not flip a tight loop, and a test that changes its regime at a fixed
+// step gets the same decisions run after run.  With hysteresis: it takes a majority above the threshold to go ahead and a majority
+// below 0.6 of it to come back, so a caller whose gaps sit at the threshold (where the two schedules cost the same,
+// profiles/r05/ahead_probe_fine_gaps.txt) does not pay for a change of schedule every other block (the block after a change to
+// "ahead" runs two passes: its own and the next one's).
+bool schedule_ahead_for_next_block(hc_ctx* c) {
+    if (c->pass_ahead == 0 || c->lookahead > 32) return false;  // (the experimental depth 64: pass at block start only)
+    if (c->pass_ahead == 1) return true;
+    if (!pass_ahead_size_ok(c)) return false;
+    if (c->gap_seen >= std::max(4, c->lookahead / 4)) {
+        c->ahead_now = 2 * (c->ahead_now ? c->gap_long_lo : c->gap_long) > c->gap_seen;
+        c->gap_seen = c->gap_long = c->gap_long_lo = 0;
+    }
+    (c->ahead_now ? c->prof.schedule_blocks_ahead : c->prof.schedule_blocks_at_start) += 1;
+    return c->ahead_now;
+}
 
 void ahead_issue_slice(hc_ctx* c, hipStream_t stream, bool direct) {
     auto& ah = c->ahead;
@@ -238,7 +270,7 @@ void ahead_begin(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
     auto& ah = c->ahead;
     ah.active = false;
     const int L = c->lookahead;
-    if (!c->pass_ahead || L <= 0 || !hc::far_pass_allowed(c->plan, L, c->times, c->tau)) return;
+    if (L <= 0 || !schedule_ahead_for_next_block(c) || !hc::far_pass_allowed(c->plan, L, c->times, c->tau)) return;
     // the short passes towards the next block must fit the partials buffer (they stream up to twice the reach of the in-block ones;
     // the first window reaches furthest)
     int first_end = 1;
@@ -386,8 +418,8 @@ void launch_mini_pass(hc_ctx* c, int i0, hipStream_t stream, bool direct, int ne
     // window of 16 -- always, for the in-block short passes of sub-blocks of 8 (kw <= 9); a window towards the next block spans the
     // whole block and keeps the wide form.  The live range per IRF sample is taken generously (q inside the span of the view's
     // times: the kernel's own bracket test decides, entries outside simply weigh 0).
-    const bool narrow_on = env_int("HC_MINI_NARROW", 1) != 0;  // (read per launch: tests switch it between contexts)
-    if (narrow_on && L == hc::kLookahead && mp.kw + 2 <= 14 && b.nchunks <= hc::kMiniChunks) {
+    const bool narrow_on = HC_TUNE_INT("HC_MINI_NARROW", 1) != 0;  // (read per launch: tests switch it between contexts)
+    if (narrow_on && L == 32 && mp.kw + 2 <= 14 && b.nchunks <= hc::kMiniChunks) {
         bool fits = true;
         const double t_new = mp.time[0], t_old = mp.time[mp.kw + 1];
         for (int ch = b.chunk_first; ch < b.nchunks && fits; ++ch) {

@@ -16,7 +16,7 @@ void hc::BarBuffer<T>::alloc(size_t count) {
     n       = 0;
     host_ok = false;
     if (count == 0) return;
-    static const bool disabled = [] { const char* e = std::getenv("HC_NO_BAR_STATE"); return e && std::atoi(e) != 0; }();
+    static const bool disabled = HC_TUNE_INT("HC_NO_BAR_STATE", 0) != 0;
     if (disabled) return;
     void* q = nullptr;
     if (hipExtMallocWithFlags(&q, count * sizeof(T), hipDeviceMallocFinegrained) != hipSuccess) {
@@ -264,7 +264,7 @@ void setup_panel_geometry(hc_ctx* c) {
     c->Dpad   = c->ntiles * 16;
     c->ngp    = static_cast<int>((static_cast<long long>(c->S) * c->D + 7) / 8);
     c->mt     = (c->ntiles % 4 == 0) ? 4 : ((c->ntiles % 2 == 0) ? 2 : 1);
-    const int want = env_int("HC_CONV_MT", 0);
+    const int want = HC_TUNE_INT("HC_CONV_MT", 0);
     if ((want == 1 || want == 2 || want == 4) && c->ntiles % want == 0) c->mt = want;
     c->ngroups = c->ntiles / c->mt;
     // Look-ahead pass: as many row tiles per workgroup as the tile count allows -- every workgroup of a chunk forms the same
@@ -277,7 +277,7 @@ void setup_panel_geometry(hc_ctx* c) {
         return 1;
     };
     const int tiles_full  = (c->D + 15) / 16;
-    const int limit       = env_int("HC_BLOCK_MT", 6);
+    const int limit       = HC_TUNE_INT("HC_BLOCK_MT", 6);
     c->mt_block_design    = pick(tiles_full, limit);
     c->mt_block           = pick(c->ntiles, c->mt_block_design);
     // Short passes of the two-level form stream a few tens of IRF samples only: with the pass's tall workgroups (6 tiles x half a
@@ -286,14 +286,14 @@ void setup_panel_geometry(hc_ctx* c) {
     // Tiles per workgroup = the largest that still leaves about two workgroups per CU (a short pass has roughly 48 chunks of half a
     // sample): 2 for a C4/8 shard (24 tiles: 76 -> 68 us per short pass), 6 for C4 on one GPU (192 tiles: 377 us; 422 with 2).
     {
-        const int forced = env_int("HC_MINI_MT", 0);
+        const int forced = HC_TUNE_INT("HC_MINI_MT", 0);
         int m_pick = 1;
         for (int m : {1, 2, 4, 6})
             if (m <= c->mt_block && c->ntiles % m == 0 && 48LL * (c->ntiles / m) >= 2LL * c->num_cus) m_pick = m;
         c->mt_mini = forced > 0 ? pick(c->ntiles, std::min(c->mt_block, forced)) : m_pick;
         // ... and of their narrow form (16 step columns, two to three waves per SIMD): taller workgroups pay, as long as a short pass still
         // has a workgroup for every CU -- 4 for a C4/8 shard (55 -> 51 us per short pass; 67 us in the wide form), 6 for C4 on one GPU
-        const int forced_n = env_int("HC_NARROW_MT", 0);
+        const int forced_n = HC_TUNE_INT("HC_NARROW_MT", 0);
         int n_pick = 1;
         for (int m : {1, 2, 4, 6})
             if (m <= c->mt_block && c->ntiles % m == 0 && 48LL * (c->ntiles / m) >= 1LL * c->num_cus) n_pick = m;
@@ -314,7 +314,7 @@ void choose_conv_config(hc_ctx* c) {
     // finalize_kernel has half as many partials to add); a chunk is a whole number of 8-column groups.  Like the pass
     // below, the chunk length is a function of the column count only (row groups of the UNSHARDED system), so row-sharded
     // contexts add their partial sums in the same order as the unsharded one (bitwise equal results).
-    const int target_wgs       = std::max(1, env_int("HC_CONV_TARGET_WGS", 8 * c->num_cus));
+    const int target_wgs       = std::max(1, HC_TUNE_INT("HC_CONV_TARGET_WGS", 8 * c->num_cus));
     const long long rows_full  = std::max<long long>(1, (((c->D + 15) / 16) + 3) / 4);
     long long nch              = std::max<long long>({1, target_wgs / rows_full, c->num_cus / 2});
     long long gps        = (c->ngp + nch - 1) / nch;
@@ -328,14 +328,15 @@ void choose_conv_config(hc_ctx* c) {
     // half).  The chunk length depends on the column count only -- never on how many rows this context owns -- so that
     // row-sharded contexts add their partial sums in the same order as the unsharded one (bitwise equal results).
     long long bgps;
-    const int forced = env_int("HC_BLOCK_CHUNK_GP", 0);
+    const int forced = HC_TUNE_INT("HC_BLOCK_CHUNK_GP", 0);
     if (forced > 0) {
         bgps = std::max(8, forced);
         bgps = std::max<long long>(bgps, (c->ngp + 255) / 256);
     } else {
         // row groups of the UNSHARDED system (6 tiles each): few of them (small systems) need more chunks to fill a round.
         // Two workgroups fit on a CU at depth 16, one at depth 32 (twice the accumulators).
-        const long long groups_full = std::max<long long>(1, ((c->D + 15) / 16 + c->mt_block_design - 1) / c->mt_block_design);
+        const int mt_design         = c->lookahead > 32 ? c->mt_block64 : c->mt_block_design;
+        const long long groups_full = std::max<long long>(1, ((c->D + 15) / 16 + mt_design - 1) / mt_design);
         const long long slots       = ((c->lookahead > 16 || c->mt_block_design > 6) ? 1LL : 2LL) * c->num_cus;
         const long long nch_target  = std::max<long long>(slots / 4, (slots + groups_full - 1) / groups_full);
         bgps                       = (c->ngp + nch_target - 1) / nch_target;
@@ -353,22 +354,38 @@ void choose_conv_config(hc_ctx* c) {
 // own, and the round is that of the PASS LANE, whose queue leaves pass_free_cus compute units of every XCD to the step kernels
 // (hc_step.cpp: pass_lane_ready): with the usual four row groups a slice has (CUs - 8 * free) / 4 chunks, in whole octets (56 on
 // an MI355X with 4 free CUs per XCD).  A function of the column count, the slice count and the device only, like every chunk length.
-// Default pass schedule (hc_set_pass_schedule): one block ahead for wide systems -- the same switch as the two-level look-ahead, a
-// function of D only.  There the pass is long (1.5 ms for a C4/8 rank) and the schedule wins for every caller: 74.7 -> 71.3 us per step
-// back to back, 60 -> 21 us with 300 us of host work between calls (profiles/r03/ahead_probe.txt).  At C3 size a caller that steps back
-// to back loses 2-4 % (19.5 -> 20.2 us) and the pass runs in slices of lower efficiency, so the schedule stays the caller's choice there.
+// Default pass schedule (hc_set_pass_schedule): ADAPTIVE (2) at every size -- per block, from the gaps the caller leaves between
+// its synchronous steps (hc_pass.cpp: schedule_ahead_for_next_block).  A caller that steps back to back has nothing to hide the pass
+// behind and is best served by the pass at block start (C3: 18.4 against 19-20 us per step; the slices also run at 0.62 of the HBM
+// peak against 0.78 unsliced); a caller that stays away between two force evaluations -- every Chrono loop -- never waits for a pass
+// when it runs one block ahead (C3, 30 us of host work: 18.9 -> 14.2 us mean, worst step 183 -> 22 us; a C4/8 rank, 300 us:
+// 60 -> 21 us).  HC_PASS_AHEAD=0/1 pins new contexts to one schedule.
 int default_pass_ahead(const hc_ctx* c) {
+    (void)c;
     const int forced = env_int("HC_PASS_AHEAD", -1);
     if (forced >= 0) return forced != 0 ? 1 : 0;
-    return hc::near_slices_for(c->D) > 1 ? 1 : 0;
+    return 2;
 }
+
+// The adaptive schedule considers "one block ahead" only where a pass is long enough to matter: 256 MB of (unsharded) K and more,
+// i.e. passes of 40 us and up.  Below that (the reference's own one- to three-body demos: 0.3 - 2.6 MB) the pass takes a few
+// microseconds, any gap that would select the schedule hides it anyway, and the schedule's extra launches would sit between the
+// steps of a caller that comes back within microseconds (one body: 8.9 -> 10.1 us per step).  A function of D and S only: the
+// row shards of one array answer alike.
+bool pass_ahead_size_ok(const hc_ctx* c) {
+    const double floor_bytes = 1e6 * HC_TUNE_INT("HC_PASS_AHEAD_MIN_MB", 256);  // (tests run the rule on small systems with 0; read per call: once per block)
+    return 8.0 * static_cast<double>(c->D) * c->D * c->S >= floor_bytes;
+}
+
+// may a pass one block ahead ever run under the selected schedule (buffers, pass lane)?
+bool pass_ahead_possible(const hc_ctx* c) { return c->pass_ahead == 1 || (c->pass_ahead == 2 && pass_ahead_size_ok(c)); }
 
 // Default slice count: slices of roughly 320 MB of the UNSHARDED K (a slice then takes 50-200 us on one GPU or on a row shard), between
 // 2 and 8 -- 4 at C3 (each launch has a fixed cost of about 11 us there: 8 slices make the pass 283 us instead of 192, 4 make it 234),
 // 8 for C4.  A function of the system's size only, never of the rows a context owns.
 int default_pass_slices(const hc_ctx* c) {
-    const int forced = env_int("HC_PASS_SLICES", 0);
-    if (forced > 0) return std::min(forced, hc::kLookahead - 1);
+    const int forced = HC_TUNE_INT("HC_PASS_SLICES", 0);
+    if (forced > 0) return std::min(forced, hc::kDepthDefault - 1);
     const double bytes = 8.0 * static_cast<double>(c->D) * c->D * c->S;
     return std::max(2, std::min(8, static_cast<int>(std::ceil(bytes / 320e6))));
 }
@@ -392,7 +409,7 @@ void choose_exc_config(hc_ctx* c) {
         c->nchunks_ex_block = 0;
         return;
     }
-    c->chunk_gp_ex = std::max(4, env_int("HC_EXC_CHUNK_GP", 8));  // short chunks: the excitation side is latency-bound
+    c->chunk_gp_ex = std::max(4, HC_TUNE_INT("HC_EXC_CHUNK_GP", 8));  // short chunks: the excitation side is latency-bound
     c->nchunks_ex  = (c->ngp_ex + c->chunk_gp_ex - 1) / c->chunk_gp_ex;
     c->chunk_gp_ex_block = 16;  // one 16-group sub-tile of the look-ahead kernel per work item (the items are dealt one per workgroup)
     c->nchunks_ex_block  = (c->ngp_ex + c->chunk_gp_ex_block - 1) / c->chunk_gp_ex_block;
@@ -405,13 +422,14 @@ void alloc_partials(hc_ctx* c) {
     // in-block brackets reach further -- in chunks of at least half a sample)
     // (pass schedule "one block ahead": its short passes towards the next block reach twice as far, and the pass in the making keeps
     // a buffer of its own while the short passes of the current block use this one)
-    const int mini_chunks = (c->pass_ahead ? 4 : 2) * hc::kScatterSamples + 2;
+    const bool ahead_bufs = pass_ahead_possible(c);
+    const int mini_chunks = (ahead_bufs ? 4 : 2) * hc::kScatterSamples + 2;
     const size_t nb = static_cast<size_t>(std::max(c->nchunks_block + c->nchunks_ex_block, mini_chunks)) * hc::kLookahead * c->Dpad;
     if (c->d_partials_block.n < nb) c->d_partials_block.alloc(nb);
     const size_t nfar = static_cast<size_t>((c->ngp + far_chunk_gp(c) - 1) / far_chunk_gp(c) + c->nchunks_ex_block) * hc::kLookahead * c->Dpad;
-    if (c->pass_ahead && c->d_partials_far.n < nfar) c->d_partials_far.alloc(nfar);
+    if (ahead_bufs && c->d_partials_far.n < nfar) c->d_partials_far.alloc(nfar);
     const size_t nnext = static_cast<size_t>(mini_chunks) * hc::kLookahead * c->Dpad;
-    if (c->pass_ahead && c->d_partials_next.n < nnext) c->d_partials_next.alloc(nnext);
+    if (ahead_bufs && c->d_partials_next.n < nnext) c->d_partials_next.alloc(nnext);
     // two blocks of rows each: the current block's and (pass schedule "one block ahead") the next one's
     const size_t npe = static_cast<size_t>(2 * hc::kLookahead) * c->Dpad;
     if (c->d_P.n < npe) c->d_P.alloc(npe);
@@ -593,14 +611,19 @@ bool direct_selftest_rewrites(hc_ctx* c, hc::DirectQueue* q, int lane, bool* aba
 // Direct AQL dispatch for the synchronous step path (hc_direct.hpp).  Optional: when anything it needs is missing -- the code
 // object next to the library, a host-addressable BAR, one of the kernels of this configuration -- the HIP launches stay in use
 // and hc_last_error-style diagnostics keep the reason (HC_DEBUG_PLAN prints it).  Still the GPU path either way.
+#ifdef HC_TUNING
+static const char* const kKernelObjectName = "/hc_kernels_tuning.co";
+#else
+static const char* const kKernelObjectName = "/hc_kernels.co";
+#endif
 void setup_direct(hc_ctx* c) {
     c->direct_ready = false;
     if (env_int("HC_DIRECT", 1) == 0) { c->direct_why = "disabled by HC_DIRECT=0"; return; }
-    if (std::getenv("HC_BLOCK_V32")) { c->direct_why = "HC_BLOCK_V32 selects a tuning variant of the pass"; return; }
+    if (HC_TUNE_INT("HC_BLOCK_V32", 0) != 0) { c->direct_why = "HC_BLOCK_V32 selects a tuning variant of the pass"; return; }
     if (!c->bar_state.host_ok || !c->bar_am.host_ok || !c->bar_selftest.host_ok) { c->direct_why = "the device's memory is not host-addressable"; return; }
     std::unique_ptr<hc::DirectQueue> q(new hc::DirectQueue);
     std::string why;
-    if (!q->init(c->device, library_dir() + "/hc_kernels.co", &why)) { c->direct_why = why; return; }
+    if (!q->init(c->device, library_dir() + kKernelObjectName, &why)) { c->direct_why = why; return; }
     c->dk_finalize = q->find("finalize_kernelILi4ELb0EEEv");
     c->dk_finalize_slot = q->find("finalize_kernelILi4ELb1EEEv");  // optional: the step kernel that finds the body state behind its arguments
     c->dk_scatter  = q->find("scatter_kernelE");
@@ -608,7 +631,7 @@ void setup_direct(hc_ctx* c) {
     c->dk_wide     = q->find("wide_step_kernelE");  // optional: without it a wide step is near_split_kernel + finalize_kernel
     if (c->dk_wide.kernarg != sizeof(hc::WideStepArgs) || c->dk_wide.priv != 0) c->dk_wide = hc::DirectKernel{};
     if (c->dk_finalize_slot.kernarg != sizeof(hc::FinalizeArgs) || c->dk_finalize_slot.priv != 0) c->dk_finalize_slot = hc::DirectKernel{};
-    c->slot_state = env_int("HC_SLOT_STATE", 1) != 0 && c->dk_finalize_slot.ok() && c->N <= hc::kSlotStateMaxBodies;
+    c->slot_state = HC_TUNE_INT("HC_SLOT_STATE", 1) != 0 && c->dk_finalize_slot.ok() && c->N <= hc::kSlotStateMaxBodies;
     c->dk_reduce   = q->find("reduce_block_kernelE");
     c->dk_added_mass = q->find("added_mass_mv_tagged_kernelE");  // optional: hc_added_mass_mv falls back to a HIP launch
     {   // the plain per-step convolution of this context's tiling; optional: without it plain steps go through HIP launches
@@ -637,6 +660,18 @@ void setup_direct(hc_ctx* c) {
             c->dk_narrow = q->find(frag);
         }
     }
+#ifdef HC_TUNING
+    {   // the depth-64 pass of the tuning build (optional)
+        hc::BlockArgs a{}, b{};
+        a.depth   = 64;
+        a.ngroups = 1;
+        const hc::BlockLaunch l = hc::block_launch_config(a, c->mt_block64, &b);
+        char frag[96];
+        std::snprintf(frag, sizeof frag, "conv_block_kernelILi%dELi%dELi%dELi%dEEEv", l.MT, l.R, l.NB, l.WPS);
+        c->dk_block64 = q->find(frag);
+        if (c->dk_block64.kernarg != sizeof(hc::BlockArgs) || c->dk_block64.priv != 0) c->dk_block64 = hc::DirectKernel{};
+    }
+#endif
     if (!c->dk_narrow.ok() || c->dk_narrow.priv || c->dk_narrow.kernarg != sizeof(hc::BlockArgs)) {
         c->direct_why = "the narrow short-pass variant of the pass kernel is missing from hc_kernels.co";
         return;
@@ -698,7 +733,7 @@ void setup_direct(hc_ctx* c) {
     c->dq           = q.release();
     c->direct_ready = true;
     c->direct_why.clear();
-    if (env_int("HC_DEBUG_PLAN", 0) != 0) std::fprintf(stderr, "[hc] direct AQL dispatch in use for the step path\n");
+    if (HC_TUNE_INT("HC_DEBUG_PLAN", 0) != 0) std::fprintf(stderr, "[hc] direct AQL dispatch in use for the step path\n");
 }
 
 }  // namespace detail

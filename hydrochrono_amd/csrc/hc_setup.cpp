@@ -166,10 +166,11 @@ int hc_set_added_mass_inf(hc_ctx* c, int body, const double* A) {
     HC_API_END(c)
 }
 
-int hc_set_rirf(hc_ctx* c, int body, const double* t, int S, const double* K) {
-    HC_API_BEGIN(c)
+namespace {
+// (K may be null for a body this context does not own: only the time vector of such a body is looked at)
+void set_rirf(hc_ctx* c, int body, const double* t, int S, const double* K) {
     check_body(c, body);
-    require(t && K && S > 0, HC_ERR_INVALID, "null pointer or empty IRF");
+    require(t && S > 0 && (K || !is_local(c, body)), HC_ERR_INVALID, "null pointer or empty IRF");
     require(c->have_sim, HC_ERR_INVALID, "set simulation parameters first (rho scales the radiation IRF)");
     require(!c->finalized, HC_ERR_INVALID, "context already finalized");
     if (c->S == 0) {
@@ -195,6 +196,13 @@ int hc_set_rirf(hc_ctx* c, int body, const double* t, int S, const double* K) {
         HC_HIP(hipStreamSynchronize(c->stream));
         c->proc_ready = false;
     }
+}
+}  // namespace
+
+int hc_set_rirf(hc_ctx* c, int body, const double* t, int S, const double* K) {
+    HC_API_BEGIN(c)
+    require(K != nullptr, HC_ERR_INVALID, "null pointer or empty IRF");
+    set_rirf(c, body, t, S, K);
     HC_API_END(c)
 }
 
@@ -231,8 +239,7 @@ int hc_set_excitation_irf(hc_ctx* c, int body, const double* t, int n, const dou
 
 namespace {
 // The HDF5 code lives in libhc_bemio.so (built only where libhdf5 exists) next to this library.
-using bemio_fn_t = int (*)(hc_ctx*, const char*, char*, size_t);
-bemio_fn_t bemio_symbol(const char* name) {
+void* bemio_symbol(const char* name) {
     Dl_info info;
     std::string dir = ".";
     if (dladdr(reinterpret_cast<void*>(&hc_version), &info) && info.dli_fname) {
@@ -243,7 +250,7 @@ bemio_fn_t bemio_symbol(const char* name) {
     const std::string lib = dir + "/libhc_bemio.so";
     void* h = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!h) throw Error(HC_ERR_UNSUPPORTED, std::string("HDF5 support not available: ") + dlerror());
-    bemio_fn_t fn = reinterpret_cast<bemio_fn_t>(dlsym(h, name));
+    void* fn = dlsym(h, name);
     if (!fn) throw Error(HC_ERR_UNSUPPORTED, std::string("libhc_bemio.so lacks ") + name);
     return fn;
 }
@@ -346,12 +353,34 @@ int hc_h5_get_excitation_irf(const hc_h5data* d, int body, double* t, double* f)
     });
 }
 
+// Body by body: the reader hands over one body's datasets at a time and they are released before the next is read, so
+// the host holds at most one {6, 6N, S} tensor -- not all N of them ((6N)^2 S doubles) -- and a row-shard context does not read the
+// tensors of the bodies it does not own at all (every shard context of a system reads the file).
 int hc_load_bemio_h5(hc_ctx* c, const char* path) {
     HC_API_BEGIN(c)
     require(path, HC_ERR_INVALID, "null path");
-    char msg[1024] = {0};
-    const int rc = bemio_symbol("hc_bemio_load")(c, path, msg, sizeof msg);
-    if (rc != HC_OK) throw Error(rc, msg[0] ? std::string(msg) : c->err);
+    using read_fn_t = int (*)(const char*, int, int, int, hc_h5data*, char*, size_t);
+    const read_fn_t read_body = reinterpret_cast<read_fn_t>(bemio_symbol("hc_bemio_read_body"));
+    auto chk = [&](int rc) {
+        if (rc != HC_OK) throw Error(rc, c->err);
+    };
+    for (int b = -1; b < c->N; ++b) {
+        hc_h5data d;
+        char msg[1024] = {0};
+        const int rc = read_body(path, c->N, b, (b >= 0 && is_local(c, b)) ? 1 : 0, &d, msg, sizeof msg);
+        if (rc != HC_OK) throw Error(rc, msg[0] ? std::string(msg) : std::string("cannot read ") + path);
+        if (b < 0) {
+            chk(hc_set_simulation_parameters(c, d.rho, d.g, d.water_depth));
+            continue;
+        }
+        const hc_h5data::Body& q = d.bodies[0];
+        chk(hc_set_body_properties(c, b, q.disp_vol, q.cg, q.cb));
+        chk(hc_set_hydrostatic_stiffness(c, b, q.lin));
+        chk(hc_set_added_mass_inf(c, b, q.ainf.data()));
+        set_rirf(c, b, q.rirf_t.data(), static_cast<int>(q.rirf_t.size()), q.K.empty() ? nullptr : q.K.data());
+        chk(hc_set_excitation_rao(c, b, d.w.data(), static_cast<int>(d.w.size()), q.mag.data(), q.phase.data()));
+        chk(hc_set_excitation_irf(c, b, q.exc_t.data(), static_cast<int>(q.exc_t.size()), q.exc_f.data()));
+    }
     HC_API_END(c)
 }
 
@@ -359,8 +388,12 @@ int hc_export_irregular_inputs_h5(hc_ctx* c, const char* path) {
     HC_API_BEGIN(c)
     require(path, HC_ERR_INVALID, "null path");
     require(c->wave_kind == hc::kWaveIrregular || c->wave_kind == hc::kWaveSpectral, HC_ERR_INVALID, "no irregular wave model attached");
+    using export_fn_t = int (*)(const char*, const double*, const double*, int, const double*, const double*, int, char*, size_t);
+    const export_fn_t fn = reinterpret_cast<export_fn_t>(bemio_symbol("hc_bemio_export_irregular"));
+    // what SimulationExporter::WriteIrregularInputs writes (src/simulation_exporter.cpp:365-393): spectrum and free-surface table
     char msg[1024] = {0};
-    const int rc = bemio_symbol("hc_bemio_export_irregular")(c, path, msg, sizeof msg);
+    const int rc = fn(path, c->spec_f.data(), c->spec_S.data(), static_cast<int>(c->spec_f.size()), c->eta_t.data(), c->eta.data(),
+                      static_cast<int>(c->eta_t.size()), msg, sizeof msg);
     if (rc != HC_OK) throw Error(rc, msg[0] ? std::string(msg) : c->err);
     HC_API_END(c)
 }
@@ -412,12 +445,20 @@ int hc_finalize(hc_ctx* c) {
     c->have_prev = c->have_prev_device = false;
     c->prev_time = c->prev_time_device = -1.0;
     {
-        const int want = env_int("HC_LOOKAHEAD", 32);
-        c->lookahead   = want <= 0 ? 0 : (want <= 16 ? 16 : hc::kLookahead);
+        const int want = HC_TUNE_INT("HC_LOOKAHEAD", 32);
+        c->lookahead   = want <= 0 ? 0 : (want <= 16 ? 16 : hc::kDepthDefault);
+        c->mt_block64  = HC_TUNE_INT("HC_BLOCK64_MT", 3);
+        if (c->mt_block64 != 3 && c->mt_block64 != 4 && c->mt_block64 != 6) c->mt_block64 = 3;
         c->pass_ahead  = default_pass_ahead(c);  // hc_set_pass_schedule
         c->pass_slices = default_pass_slices(c);
+        // the gap beyond which "one block ahead" pays (profiles/r05/ahead_probe_fine_gaps.txt): C3 -- 0 - 3 us: the schedules within
+        // noise of each other (17.4 / 18.6 / 17.4 / 16.9 at block start, 18.8 / 18.6 / 16.8 / 17.6 ahead), 5 us: 18.4 against 17.0,
+        // 8 us: 18.1 against 14.8, 20 us: 16.8 against 11.9 us per step; a C4/8 rank -- ahead wins at every gap, back to back included
+        // (70.1 against 68.6 us, worst step 1.58 against 0.33 ms; 10 us: 70.2 against 60.9), so wide systems run ahead whatever the caller does
+        c->gap_threshold = 1e-6 * std::max(0, env_int("HC_PASS_AHEAD_GAP_US", hc::near_slices_for(c->D) > 1 ? 0 : 4));
+        reset_schedule_state(c);
         c->pass_concurrent = env_int("HC_PASS_CONCURRENT", 1) != 0;
-        c->pass_free_cus   = std::max(1, std::min(16, env_int("HC_PASS_FREE_CUS", 4)));
+        c->pass_free_cus   = std::max(1, std::min(16, HC_TUNE_INT("HC_PASS_FREE_CUS", 4)));
         c->ahead.active = false;
     }
     // GEMV scratch
@@ -435,7 +476,7 @@ int hc_finalize(hc_ctx* c) {
     c->bar_state.alloc(static_cast<size_t>(2) * (12 * c->N + 1));
     c->h_canary.alloc(4);
     std::memset(c->h_canary.p, 0, 4 * sizeof(unsigned long long));
-    c->fault_stale_state_at = env_int("HC_FAULT_STALE_STATE_AT", -1);
+    c->fault_stale_state_at = HC_TUNE_INT("HC_FAULT_STALE_STATE_AT", -1);
     if (c->bar_state.host_ok) {
         // trust, but verify: what the host stores through the BAR must be what a device-side copy sees
         const size_t nb = c->bar_state.n;
@@ -466,7 +507,7 @@ int hc_finalize(hc_ctx* c) {
     c->d_scratch.alloc(static_cast<size_t>(4) * c->Dloc);
     c->d_zero_state.alloc(static_cast<size_t>(12) * c->N);
     HC_HIP(hipMemsetAsync(c->d_zero_state.p, 0, c->d_zero_state.n * sizeof(double), c->stream));
-    c->zero_copy_max_bodies = env_int("HC_ZERO_COPY_BODIES", 64);
+    c->zero_copy_max_bodies = HC_TUNE_INT("HC_ZERO_COPY_BODIES", 64);
     c->arm_mode             = std::min(2, std::max(0, env_int("HC_ARM", 1)));  // 0 never, 1 adaptive, 2 always: parking of the direct queue between steps
     // default wave model: NoWave for all bodies (the reference's default NoWave() covers one body only and is
     // read out of bounds for N > 1, src/hydro_forces.cpp:758-760; that overread is deliberately not reproduced)
@@ -475,13 +516,13 @@ int hc_finalize(hc_ctx* c) {
     choose_exc_config(c);
     alloc_partials(c);
     c->prof.conv_kernel_bytes  = 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
-    c->prof.block_kernel_bytes = hc::kLookahead * c->prof.conv_kernel_bytes;
+    c->prof.block_kernel_bytes = hc::kDepthDefault * c->prof.conv_kernel_bytes;
     c->plan                    = hc::Plan{};
     HC_HIP(hipStreamSynchronize(c->stream));
     setup_direct(c);
     // the pass lane (its queue, CU mask and self-test: 131 synchronous dispatches) is made here, not inside the first step that
     // starts a pass one block ahead
-    if (c->pass_ahead && c->lookahead > 0) (void)pass_lane_ready(c);
+    if (pass_ahead_possible(c) && c->lookahead > 0) (void)pass_lane_ready(c);
     c->finalized = true;
     HC_API_END(c)
 }
@@ -698,7 +739,7 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     alloc_partials(c);
     c->prof.conv_kernel_bytes = 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D +
                                        static_cast<double>(c->Dloc) * L + L);
-    c->prof.block_kernel_bytes = hc::kLookahead * 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
+    c->prof.block_kernel_bytes = hc::kDepthDefault * 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
     HC_HIP(hipStreamSynchronize(c->stream));
     HC_API_END(c)
 }

@@ -11,7 +11,7 @@ namespace detail {
 
 // (the per-step canary, see check_canary below)
 bool canary_enabled() {
-    static const bool on = env_int("HC_STEP_CANARY", 1) != 0;  // (0: for A/B timing only -- 0.1 us of 8.7 / 11.9 us per hc_step at one / 64 bodies)
+    static const bool on = HC_TUNE_INT("HC_STEP_CANARY", 1) != 0;  // (0: for A/B timing only -- 0.1 us of 8.7 / 11.9 us per hc_step at one / 64 bodies)
     return on;
 }
 
@@ -113,7 +113,7 @@ int plan_step(hc_ctx* c, double t, int H) {
 // Wide systems (the same switch as the split own-sample kernel: a function of D only, so that row shards plan alike) use the
 // two-level form: their scatter launches would re-read (L/2) * K/S bytes from HBM every step.
 int plan_sub_block(const hc_ctx* c) {
-    const int forced = env_int("HC_SUB_BLOCK", -1);  // tests / tuning runs: 0 = single level, 4 / 8 = sub-block size
+    const int forced = HC_TUNE_INT("HC_SUB_BLOCK", -1);  // tests / tuning runs: 0 = single level, 4 / 8 = sub-block size
     if (forced >= 0) return forced;
     return hc::near_slices_for(c->D) > 1 ? hc::kSubBlock : 0;
 }
@@ -485,7 +485,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         z.n_terms = pl.n_terms[m];
         z.Yc      = c->d_Y.p + static_cast<size_t>(m) * hc::kTermMax * c->Dpad;
     }
-    static const bool dbg = env_int("HC_DEBUG_PLAN", 0) != 0;
+    static const bool dbg = HC_TUNE_INT("HC_DEBUG_PLAN", 0) != 0;
     if (dbg) {
         std::fprintf(stderr, "[hc] t=%.6f H=%d m=%d n_near=%d n_terms=%d sd=%d nchunks_rad=%d nchunks_ex=%d head=%d\n", t, H, m, z.n_near, z.n_terms,
                      block ? c->plan.s_defer[m - 1] : -2, nchunks_rad, nchunks_ex, c->head);
@@ -561,7 +561,7 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         // a dispatch less on the critical path of every block step.  HC_WIDE_FUSED=0: the two launches (same arithmetic, bitwise).
         // Only while the launch is ONE round of workgroups (218 VGPRs: two per CU): a C4/8 shard has 24 tiles x 8 slices = 192; the
         // whole 512-body array on one GPU has 1536, runs them in three rounds and is faster with the two launches (23 against 32 us).
-        static const bool fused_on = env_int("HC_WIDE_FUSED", 1) != 0;
+        static const bool fused_on = HC_TUNE_INT("HC_WIDE_FUSED", 1) != 0;
         const long long wide_wgs   = static_cast<long long>(c->ntiles) * hc::near_slices_for(c->D);
         if (fused_on && !f.scratch_out && wide_wgs <= 2LL * c->num_cus && c->d_tile_counter.n >= static_cast<size_t>(c->ntiles) && (!direct || c->dk_wide.ok())) {
             hc::WideStepArgs w{na, z, c->d_tile_counter.p};
@@ -739,6 +739,8 @@ void step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(pos && rpy && linvel && angvel, HC_ERR_INVALID, "null pointer");
     require(c->pending_step == 0, HC_ERR_INVALID, "the step begun before has not been completed (hc_step_end)");
+    const double gap_hint = c->gap_hint;  // (for this call only, whatever becomes of it)
+    c->gap_hint           = -1.0;
     if (c->lost) throw Error(HC_ERR_DEVICE, "the device stopped answering in an earlier step: " + c->direct_why);
     if (c->have_prev && t == c->prev_time) {  // src/hydro_forces.cpp:742-744
         c->pending_step = 1;
@@ -754,12 +756,20 @@ void step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const
         c->pending_step = 1;
         return;
     }
-    // how long was the caller away?  (decides whether the queue is parked on a barrier after this step, see step_end)
-    if (c->arm_mode == 1) {
-        const auto now    = std::chrono::steady_clock::now();
-        c->arm_after_step = c->have_t_step_end && std::chrono::duration<double>(now - c->t_step_end).count() > kArmGapSeconds;
-    } else {
-        c->arm_after_step = c->arm_mode == 2;
+    // how long was the caller away?  Decides whether the queue is parked on a barrier after this step (step_end) and feeds the
+    // adaptive pass schedule (hc_pass.cpp: schedule_ahead_for_next_block).  hc_step_multi hands every context of its group the gap
+    // ITS caller saw (gap_hint), so that the shards of one array count the same gaps and decide alike.
+    {
+        const auto now = std::chrono::steady_clock::now();
+        double gap     = -1.0;
+        if (gap_hint >= 0.0) gap = gap_hint;
+        else if (c->have_t_step_end) gap = std::chrono::duration<double>(now - c->t_step_end).count();
+        if (gap >= 0.0) {
+            c->gap_seen += 1;
+            c->gap_long += gap > c->gap_threshold ? 1 : 0;
+            c->gap_long_lo += gap > 0.6 * c->gap_threshold ? 1 : 0;
+        }
+        c->arm_after_step = c->arm_mode == 2 || (c->arm_mode == 1 && gap > kArmGapSeconds);
     }
     c->prev_time = t;  // :747 (set before the terms are computed, so a throwing step is not retried)
     c->have_prev = true;
@@ -825,20 +835,24 @@ void step_abort(hc_ctx* c) {
 extern "C++" {
 // ---- several contexts in one call (hc_step_multi, hc_added_mass_mv_multi) ----------------------------------------
 // Worker threads of the fan-out (hc_fanout.hpp): HC_MULTI_THREADS = 0 keeps everything on the calling thread; HC_MULTI_SPIN_US is
-// how long an idle worker spins before it sleeps (default 1 ms: a Chrono loop comes back sooner).
+// how long an idle worker spins before it sleeps.  While it spins it holds a host core at 100 % -- n_ctx - 1 cores for the whole run of
+// a host that calls more often than the spin time, beside Chrono's own OpenMP threads -- and once it sleeps the next call pays a futex
+// wake-up: 200 us by default (round 4: 1 ms), measured in profiles/r05/multi_spin.txt.
 int multi_threads() {
     static const int n = env_int("HC_MULTI_THREADS", 63);
     return n;
 }
 hc::FanOut& fanout() {
-    static hc::FanOut pool(multi_threads(), static_cast<double>(env_int("HC_MULTI_SPIN_US", 1000)));
+    static hc::FanOut pool(multi_threads(), static_cast<double>(env_int("HC_MULTI_SPIN_US", 200)));
     return pool;
 }
-// A worker thread serves the same context call after call and nobody else changes its current device, so it sets the device when
-// it changes only; the calling thread (item 0) shares its current device with every other entry point and sets it every time.
-void bind_device(const hc_ctx* c, int item) {
+// A worker thread of the fan-out serves the same context call after call and nobody else changes its current device, so it sets the
+// device when it changes only.  Every other thread sets it every time: the calling thread shares its current device with every other
+// entry point, and it runs more than item 0 -- the items beyond HC_MULTI_THREADS, and all of them when another thread holds the pool
+// or no worker thread could be created (hc_fanout.hpp) -- so the cache is keyed on the KIND OF THREAD, not on the item.
+void bind_device(const hc_ctx* c) {
     static thread_local int worker_device = -1;
-    if (item == 0) {
+    if (!hc::FanOut::on_worker_thread()) {
         HC_HIP(hipSetDevice(c->device));
     } else if (worker_device != c->device) {
         HC_HIP(hipSetDevice(c->device));
@@ -861,7 +875,7 @@ struct MultiStatus {
             return false;
         };
         try {
-            bind_device(c, item);
+            bind_device(c);
             fn();
             return true;
         } catch (const Error& e) {
@@ -1013,6 +1027,24 @@ int hc_step_multi(hc_ctx* const* ctxs, int n_ctx, double t, const double* pos, c
         if (!ctxs[g]) return HC_ERR_INVALID;
     MultiStatus st(n_ctx);
     const auto t_entry = std::chrono::steady_clock::now();
+    // the gap the caller left since its last call, measured ONCE for the group (kept on its first context): every shard counts the
+    // same gaps, so the adaptive pass schedule decides alike on all of them and their rows stay those of one schedule
+    // (a call that only re-reads the per-time cache -- Chrono's other 6N - 1 callbacks of a time -- is no step: it neither counts nor
+    // moves the mark)
+    const bool evaluates = !(ctxs[0]->have_prev && t == ctxs[0]->prev_time);
+    if (evaluates && ctxs[0]->have_t_multi_end) {
+        const double gap = std::chrono::duration<double>(t_entry - ctxs[0]->t_multi_end).count();
+        for (int g = 0; g < n_ctx; ++g) ctxs[g]->gap_hint = gap;
+    }
+    struct MarkEnd {
+        hc_ctx* c;
+        bool on;
+        ~MarkEnd() {
+            if (!on) return;
+            c->t_multi_end      = std::chrono::steady_clock::now();
+            c->have_t_multi_end = true;
+        }
+    } mark_end{ctxs[0], evaluates};
     auto doorbell_rung = [t_entry](hc_ctx* c) {  // (the step kernel's packet is in its queue: hc_profile_stats::multi_doorbell_offset_*)
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count();
         c->prof.multi_doorbell_offset_last = s;
@@ -1141,7 +1173,13 @@ int hc_set_lookahead(hc_ctx* c, int steps) {
     HC_API_BEGIN(c)
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     HC_HIP(hipDeviceSynchronize());  // a pass of the previous depth may still be running
-    c->lookahead = steps <= 0 ? 0 : (steps <= 16 ? 16 : hc::kLookahead);
+    c->lookahead = steps <= 0 ? 0 : (steps <= 16 ? 16 : (steps <= 32 ? 32 : 64));
+#ifndef HC_TUNING
+    if (c->lookahead == 64) c->lookahead = 32;  // (depth 64 exists in the tuning build only: measured in round 5 and not taken, EXPERIMENTS.md)
+#endif
+    // depth 64 (tuning build, profiles/r05): the single-level form of D % 8 == 0 systems with the pass at block start, direct or not
+    if (c->lookahead == 64 && ((c->D & 7) != 0 || c->D < 32 || hc::near_slices_for(c->D) > 1 || c->ntiles % c->mt_block64 != 0 ||
+                               (c->direct_ready && !c->dk_block64.ok()))) c->lookahead = 32;
     choose_conv_config(c);  // the pass chunking depends on the depth
     alloc_partials(c);
     c->plan      = hc::Plan{};
@@ -1153,12 +1191,13 @@ int hc_set_pass_schedule(hc_ctx* c, int one_block_ahead, int slices) {
     HC_API_BEGIN(c)
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     HC_HIP(hipDeviceSynchronize());  // a pass in the making may still be running
-    c->pass_ahead   = one_block_ahead < 0 ? default_pass_ahead(c) : (one_block_ahead ? 1 : 0);
-    c->pass_slices  = slices > 0 ? std::min(slices, hc::kLookahead - 1) : default_pass_slices(c);
+    c->pass_ahead   = one_block_ahead < 0 ? default_pass_ahead(c) : (one_block_ahead ? 1 : 0);  // (< 0: adaptive unless HC_PASS_AHEAD pins it)
+    reset_schedule_state(c);
+    c->pass_slices  = slices > 0 ? std::min(slices, hc::kDepthDefault - 1) : default_pass_slices(c);
     c->ahead.active = false;
     alloc_partials(c);
     c->plan = hc::Plan{};
-    if (c->pass_ahead && c->lookahead > 0) (void)pass_lane_ready(c);  // (created and self-tested here, off the step path)
+    if (pass_ahead_possible(c) && c->lookahead > 0) (void)pass_lane_ready(c);  // (created and self-tested here, off the step path)
     HC_API_END(c)
 }
 

@@ -180,7 +180,7 @@ class HydroForces:
              for x in (pos, rpy, linvel, angvel)]
         out = np.empty(self.D_local)
         # raw addresses through a c_void_p prototype: this call sits in per-step loops
-        rc = capi.step_raw()(self.ctx, t, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, out.ctypes.data)
+        rc = capi.step_raw(self.lib)(self.ctx, t, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, out.ctypes.data)
         if rc:
             self._chk(rc)
         return out
@@ -197,7 +197,11 @@ class HydroForces:
             raise ValueError(f"states must be [{n}][{12 * self.N}]")
         forces = np.empty((n, self.D_local)) if forces is None else forces
         seconds = np.empty(n) if seconds is None else seconds
-        assert forces.flags.c_contiguous and seconds.flags.c_contiguous and forces.shape == (n, self.D_local) and seconds.shape == (n,)
+        # the C side writes n * D_local and n doubles through these pointers: anything but a writeable C-contiguous float64 array of
+        # exactly that shape would be a heap overflow (or a silently ignored result), so refuse it -- also under python -O
+        for name, arr, shape in (("forces", forces, (n, self.D_local)), ("seconds", seconds, (n,))):
+            if not isinstance(arr, np.ndarray) or arr.dtype != np.float64 or arr.shape != shape or not arr.flags.c_contiguous or not arr.flags.writeable:
+                raise ValueError(f"{name} must be a writeable C-contiguous float64 array of shape {shape}")
         done = C.c_int(0)
         rc = self.lib.hc_step_many(self.ctx, n, _dp(times), _dp(states), _dp(forces), _dp(seconds), C.byref(done))
         if rc:
@@ -245,8 +249,9 @@ class HydroForces:
     def set_pass_schedule(self, one_block_ahead, slices=0):
         """hc_set_pass_schedule: 0 = the pass of a look-ahead block when the block starts, 1 = one block ahead, in `slices` launches
         (0: chosen by the library) behind the first steps of the block before -- for callers that leave the GPU idle between force
-        evaluations for less than a pass takes; None or -1 = the library's default, which depends on the size (wide systems,
-        D >= 1024: one block ahead; others: at block start; HC_PASS_AHEAD overrides)."""
+        evaluations for less than a pass takes; None or -1 = the library's default: ADAPTIVE -- per block, from the gaps the caller
+        left between the synchronous steps of the block before (back to back: at block start; away for more than a few
+        microseconds: one block ahead; systems below 256 MB of K always at block start; HC_PASS_AHEAD=0/1 pins it)."""
         mode = -1 if one_block_ahead is None or int(one_block_ahead) < 0 else int(bool(one_block_ahead))
         self._chk(self.lib.hc_set_pass_schedule(self.ctx, mode, int(slices)))
 

@@ -229,11 +229,11 @@ class TestHydro {
         for (hc_ctx* x : ctxs_) check(x, hc_set_diagnostics_output_directory(x, dir.c_str()));
     }
 
-    // Not in the reference (it has no such notion): when the look-ahead pass of a block runs, see hc_set_pass_schedule.  This class
-    // is driven by a Chrono loop, which does its own work between two force evaluations, so the constructors that CREATE the
-    // contexts select "one block ahead" for systems with 256 MB of K and more (the C ABI's own default does so for wide systems
-    // only): with 30 / 100 us of host work between calls a 64-body step takes 12.8 / 12.7 us instead of 17.4 / 15.6, and no step
-    // waits for a whole pass.  one_block_ahead < 0 hands the choice back to the library.
+    // Not in the reference (it has no such notion): when the look-ahead pass of a block runs, see hc_set_pass_schedule.  The contexts
+    // come with the library's ADAPTIVE schedule (one_block_ahead < 0): a Chrono loop, which does its own work between two force
+    // evaluations, gets the pass of every block one block ahead, beside the steps (64 bodies, 30 / 100 us of host work between calls:
+    // 12.8 / 12.7 us per step instead of 17.4 / 15.6, and no step waits for a whole pass); a driver that steps back to back gets it at
+    // block start.  0 / 1 pin a schedule.
     void SetPassSchedule(int one_block_ahead, int slices = 0) {
         for (hc_ctx* x : ctxs_) check(x, hc_set_pass_schedule(x, one_block_ahead < 0 ? -1 : (one_block_ahead ? 1 : 0), slices));
     }
@@ -335,7 +335,6 @@ class TestHydro {
                 check(c, hc_finalize(c));
             }
             ctx_ = ctxs_[0];
-            chrono_loop_defaults();
             if (!waves) waves = std::make_shared<NoWave>(static_cast<unsigned>(num_bodies_));
             AddWaves(std::move(waves));
         } catch (...) {
@@ -356,17 +355,6 @@ class TestHydro {
             std::string temp = b->GetName();
             body_numbers_.push_back(std::stoi(temp.erase(0, 4)));
         }
-    }
-    // (HC_PASS_AHEAD in the environment keeps its say.  Systems whose whole K is below 256 MB -- about 30 bodies; the reference's own
-    // one- to three-body demos are 0.3 to 2.6 MB -- keep the library's default: their pass takes at most a few tens of microseconds,
-    // which any host work between the calls hides already, and the extra launches of the schedule would cost a back-to-back caller
-    // about a microsecond per step.)
-    void chrono_loop_defaults() {
-        if (std::getenv("HC_PASS_AHEAD") || ctxs_.empty()) return;
-        int N = 0, S = 0;
-        check(ctxs_[0], hc_get_sizes(ctxs_[0], &N, nullptr, &S, nullptr, nullptr, nullptr, nullptr, nullptr));
-        if (8.0 * (6.0 * N) * (6.0 * N) * S < 256e6) return;
-        for (hc_ctx* x : ctxs_) check(x, hc_set_pass_schedule(x, 1, 0));
     }
     void gather_state() {
 #ifdef HYDROCHRONO_AMD_WITH_CHRONO

@@ -252,8 +252,14 @@ int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
  * contract 1e-6).  Wide systems (6N >= 1024) use a two-level form: sub-blocks of 8 steps with a short pass over the head of K
  * after each.  steps = 0 disables it (every step streams K), 1..16 selects blocks of 16, more blocks of 32. */
 int hc_set_lookahead(hc_ctx* ctx, int steps);
-/* When the pass of a look-ahead block runs (one_block_ahead < 0: the library's default for the system's size -- 1 for wide
- * systems, 6N >= 1024, else 0).  one_block_ahead = 0: when the block starts.  A caller that comes back before the pass has
+/* When the pass of a look-ahead block runs.  one_block_ahead < 0 (the default of every context): ADAPTIVE -- the library counts,
+ * per block, how many of the gaps between the caller's synchronous steps (end of one hc_step / hc_step_multi to the begin of the
+ * next) were longer than a few microseconds (HC_PASS_AHEAD_GAP_US, default 4) and runs the pass of the following block at block
+ * start when the caller steps back to back, one block ahead when it is away between steps -- as a Chrono loop is; systems below
+ * 256 MB of K (6N * 6N * S * 8 bytes) always run it at block start (their pass takes microseconds).  hc_step_multi measures the
+ * gap once for its group of contexts, so the shards of one array decide alike.  The decisions are counted in
+ * hc_profile_stats::schedule_blocks_ahead / schedule_blocks_at_start.
+ * one_block_ahead = 0: when the block starts.  A caller that comes back before the pass has
  * finished waits for it on the first step of the block (190 us at 64 bodies; 1.55 ms for the 64-body row shard of a 512-body
  * array); a caller that stays away longer than that never notices it.  one_block_ahead = 1: the pass of the NEXT block is computed
  * from the history known when the current block starts, in `slices` launches (<= 0: chosen from the size of K, 2 .. 8) issued
@@ -268,8 +274,9 @@ int hc_set_lookahead(hc_ctx* ctx, int steps);
  * 19.5 -> 20.2 us at 64 bodies (the short pass towards the next block and the two queues sharing the chip), 74.7 -> 71.3 us for the shard.  Used once the history covers the IRF window; results are those of
  * schedule 0 up to the rounding of a different summation grouping (same 1e-6 contract, same tolerance on the predicted times).
  * The schedule is part of the configuration: the row shards of one array must use the same one (and the same slice count) to
- * stay bitwise equal to the unsharded context.  HC_PASS_AHEAD=0/1 (HC_PASS_SLICES=n, HC_PASS_CONCURRENT=0: no queue of its own)
- * in the environment set the default of new contexts. */
+ * stay bitwise equal to the unsharded context -- pin it (0 or 1) where that matters across separately driven contexts; under the
+ * adaptive schedule two runs agree to rounding (1e-15), not bit for bit, when their callers' gaps differ.
+ * HC_PASS_AHEAD=0/1 (HC_PASS_SLICES=n, HC_PASS_CONCURRENT=0: no queue of its own) in the environment pin the default of new contexts. */
 int hc_set_pass_schedule(hc_ctx* ctx, int one_block_ahead, int slices);
 /* How hc_step hands its kernels to the GPU.  1: as AQL packets written straight into an HSA queue of the library's own (kernel
  * arguments stored through the PCIe BAR) -- the default when the stand-alone code object hc_kernels.co lies next to the library,
@@ -348,6 +355,9 @@ typedef struct hc_profile_stats {
     long long slot_state_steps;    /* steps whose body state travelled behind the step kernel's argument block (direct dispatch, one-launch steps
                                     * of systems of up to 170 bodies, i.e. every system that is not wide): the kernel requests it together with its arguments, not after them */
     long long wide_fused_steps;    /* block steps of a wide system (6N >= 1024) whose own-sample slices and step kernel went out as ONE launch (wide_step_kernel) */
+    long long schedule_blocks_ahead, schedule_blocks_at_start; /* look-ahead blocks at whose start the pass schedule answered "the pass of
+                                    * the NEXT block runs one block ahead" / "at block start" (hc_set_pass_schedule; under the adaptive
+                                    * schedule this is the rule's answer block by block) */
     long long ring_grows_for_pass; /* times the history ring was re-allocated so that a pass one block ahead can read its view of the
                                     * history while the block's steps push their samples (steps well below the IRF spacing) */
 } hc_profile_stats;

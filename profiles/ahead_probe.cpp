@@ -75,9 +75,9 @@ static int run(int N, int b0, int b1, int S, double gap_us, int schedule, int sl
     double mean = 0;
     for (double v : ts) mean += v;
     mean /= ts.size();
-    std::printf("rows of %3d of %3d bodies, gap %3.0f us, schedule %d: hc_step mean %7.2f us  median %7.2f  p90 %7.2f  p99 %8.2f  max %8.2f   (blocks without a pass of their own: %lld, slices %lld, on the pass lane %lld)\n",
+    std::printf("rows of %3d of %3d bodies, gap %3.0f us, schedule %2d: hc_step mean %7.2f us  median %7.2f  p90 %7.2f  p99 %8.2f  max %8.2f   (blocks without a pass of their own: %lld, slices %lld, on the pass lane %lld; schedule answers ahead / at start: %lld / %lld)\n",
                 b1 - b0, N, gap_us, schedule, mean, ts[ts.size() / 2], ts[ts.size() * 9 / 10], ts[ts.size() * 99 / 100], ts.back(), p.ahead_blocks,
-                p.ahead_pass_slices, p.pass_lane_launches);
+                p.ahead_pass_slices, p.pass_lane_launches, p.schedule_blocks_ahead, p.schedule_blocks_at_start);
     (void)slices_report;
     hc_destroy(c);
     return 0;
@@ -88,12 +88,24 @@ int main(int argc, char** argv) {
     if (argc > 3) {  // one configuration only (for a profiler): <wide> <schedule> <gap in us>
         return wide ? run(512, 0, 64, 1024, std::atof(argv[3]), std::atoi(argv[2]), 0) : run(64, 0, 64, 1024, std::atof(argv[3]), std::atoi(argv[2]), 0);
     }
+    // schedule -1 = the library's default (adaptive: per block from the caller's gaps, hc_set_pass_schedule)
+    const bool fine = std::getenv("FINE_GAPS") != nullptr;  // the crossover between the two schedules (threshold of the adaptive rule)
+    if (fine) {
+        for (double gap : {0.0, 1.0, 2.0, 3.0, 5.0, 8.0, 12.0, 20.0})
+            for (int schedule : {0, 1, -1})
+                if (run(64, 0, 64, 1024, gap, schedule, 0)) return 1;
+        if (wide)
+            for (double gap : {0.0, 2.0, 5.0, 10.0, 20.0})
+                for (int schedule : {0, 1, -1})
+                    if (run(512, 0, 64, 1024, gap, schedule, 0)) return 1;
+        return 0;
+    }
     for (double gap : {0.0, 30.0, 100.0, 300.0})
-        for (int schedule : {0, 1})
+        for (int schedule : {0, 1, -1})
             if (run(64, 0, 64, 1024, gap, schedule, 0)) return 1;
     if (wide)
         for (double gap : {0.0, 10.0, 100.0, 300.0, 1000.0})
-            for (int schedule : {0, 1})
+            for (int schedule : {0, 1, -1})
                 if (run(512, 0, 64, 1024, gap, schedule, 0)) return 1;
     return 0;
 }

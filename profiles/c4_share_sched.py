@@ -18,8 +18,8 @@ v_hist = np.stack([motion.velocity6(t) for t in t_hist])
 nsteps = 72 + int(os.environ.get('NT', 256))
 times = [B.T0 + k * B.DT for k in range(nsteps)]
 states = [motion.state(t) for t in times]
-for waves in (False,):
-    for sched in (0, 1):
+for waves in (False, True):
+    for sched in (0, 1, -1):
         gpu = HydroForces(N, device=0, body_range=(0, 64))
         gpu.synth_fill(20251031, B.S_RIRF, B.DT, int(os.environ.get('NEXC', B.N_EXC)), B.DT)
         gpu.finalize()
@@ -44,5 +44,5 @@ for waves in (False,):
         if len(lat) >= 512:
             print("   per 128 steps:", " ".join(f"{lat[i:i + 128].mean():.1f}" for i in range(0, len(lat), 128)))
         p = gpu.profile()
-        print(f"waves {waves} schedule {sched}: mean {lat.mean():6.1f} us median {np.median(lat):6.1f} p90 {np.percentile(lat, 90):6.1f} p99 {np.percentile(lat, 99):7.1f} max {lat.max():7.1f}  ahead blocks {p['ahead_blocks']} pass-lane launches {p['pass_lane_launches']}", flush=True)
+        print(f"waves {waves} schedule {sched}: mean {lat.mean():6.1f} us median {np.median(lat):6.1f} p90 {np.percentile(lat, 90):6.1f} p99 {np.percentile(lat, 99):7.1f} max {lat.max():7.1f}  ahead blocks {p['ahead_blocks']} pass-lane launches {p['pass_lane_launches']} answers ahead/start {p['schedule_blocks_ahead']}/{p['schedule_blocks_at_start']}", flush=True)
         gpu.close()

@@ -2,6 +2,8 @@
 // row-sharded over G contexts of THIS process (all on GPU 0 of this box), no waves, prescribed motion, steady-state history.
 //   g++ -O2 -std=c++17 profiles/multi_path_c.cpp -I include -L hydrochrono_amd/lib -lhydrochrono_amd -Wl,-rpath,$PWD/hydrochrono_amd/lib -o /tmp/multi_path_c
 //   /tmp/multi_path_c [N = 64] [S = 1024] [reps = 3000]
+// GAP_US=<us>: host work (a busy wait) between the calls, as a Chrono loop has it -- with HC_MULTI_SPIN_US this shows what a worker
+// thread that has gone to sleep costs the next call (profiles/r05/multi_spin.txt); ONLY_G=<G>: one group size only.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -50,6 +52,12 @@ static int run(int N, int S, int G, int reps, std::vector<double>* ref) {
         hc_added_mass_mv_multi(ctxs.data(), G, aw.data(), 1.0, aR.data(), D);
         const double b2 = now_us();
         if (n >= warm) { ts.push_back(b - a); ta.push_back(b2 - a2); }
+        static const double gap_us = std::getenv("GAP_US") ? std::atof(std::getenv("GAP_US")) : 0.0;
+        if (gap_us > 0.0 && n >= warm - 64) {
+            const double g0 = now_us();
+            while (now_us() - g0 < gap_us) {
+            }
+        }
     }
     last = out;
     bool same = true;
@@ -82,7 +90,8 @@ static int run(int N, int S, int G, int reps, std::vector<double>* ref) {
 int main(int argc, char** argv) {
     const int N = argc > 1 ? std::atoi(argv[1]) : 64, S = argc > 2 ? std::atoi(argv[2]) : 1024, reps = argc > 3 ? std::atoi(argv[3]) : 3000;
     std::vector<double> ref;
+    const int only = std::getenv("ONLY_G") ? std::atoi(std::getenv("ONLY_G")) : 0;
     for (int G : {1, 2, 4, 8})
-        if (G <= N && run(N, S, G, reps, &ref)) return 1;
+        if (G <= N && (only == 0 || only == G) && run(N, S, G, reps, &ref)) return 1;  // (ONLY_G: no G = 1 reference, the comparison is with itself)
     return 0;
 }

@@ -43,7 +43,7 @@ with tempfile.TemporaryDirectory() as d:
     for fused in ("1", "0"):
         out = os.path.join(d, f"f{fused}.npy")
         r = subprocess.run([sys.executable, os.path.abspath(__file__), str(nsteps), "child", out], capture_output=True, text=True,
-                           env=dict(os.environ, HC_WIDE_FUSED=fused))
+                           env=dict(os.environ, HC_WIDE_FUSED=fused, HYDROCHRONO_AMD_FLAVOR="tuning"))
         if r.returncode != 0:
             print(r.stderr[-3000:])
             sys.exit(1)

@@ -29,3 +29,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def tuning_build():
+    """The test runs against libhydrochrono_amd_tuning.so (the same sources with -DHC_TUNING, hydrochrono_amd/build.py): the sweep /
+    A-B / fault-injection switches it sets in the environment (HC_SUB_BLOCK, HC_MINI_NARROW, HC_WIDE_FUSED, HC_SLOT_STATE,
+    HC_FAULT_STALE_STATE_AT, HC_PASS_AHEAD_MIN_MB, ...) and the kernel variants that were measured and not taken exist there only;
+    the release library reads none of them.  Objects created inside the test keep that library for their lifetime."""
+    from hydrochrono_amd import capi
+    with capi.use_flavor("tuning"):
+        yield

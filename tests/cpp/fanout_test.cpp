@@ -8,6 +8,9 @@
 #include <thread>
 #include <vector>
 
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include "../../hydrochrono_amd/csrc/hc_fanout.hpp"
 
 static int failures = 0;
@@ -86,6 +89,64 @@ int main() {
             if (k % 2) std::this_thread::sleep_for(std::chrono::microseconds(400));
         }
     }
+    {   // which kind of thread an item is on: workers say so, the calling thread never does -- not for item 0, not for the items
+        // beyond the pool's limit, not for the items of a call that found the pool busy (hc_step.cpp: bind_device relies on it)
+        hc::FanOut pool(2, 200.0);
+        const auto me = std::this_thread::get_id();
+        std::vector<int> on_worker(7, -1);
+        std::vector<std::thread::id> who(7);
+        auto item = [&](int g) {
+            on_worker[g] = hc::FanOut::on_worker_thread() ? 1 : 0;
+            who[g]       = std::this_thread::get_id();
+        };
+        for (int r = 0; r < 50; ++r) {
+            pool.run(7, item);
+            for (int g = 0; g < 7; ++g) {
+                const bool mine = who[g] == me;
+                CHECK(on_worker[g] == (mine ? 0 : 1), "item %d: on_worker_thread() = %d on %s thread", g, on_worker[g], mine ? "the calling" : "a worker");
+                CHECK(mine == (g == 0 || g > 2), "item %d ran on the wrong kind of thread", g);
+            }
+        }
+        CHECK(!hc::FanOut::on_worker_thread(), "the calling thread claims to be a worker");
+        hc::FanOut none(0, 200.0);
+        none.run(3, item);
+        for (int g = 0; g < 3; ++g) CHECK(on_worker[g] == 0 && who[g] == me, "a pool without workers ran item %d elsewhere", g);
+    }
+#if !defined(__SANITIZE_THREAD__)  // (ThreadSanitizer refuses new threads after a multi-threaded fork)
+    {   // fork(): the child inherits the pool's bookkeeping but not its threads -- its first call must not wait for workers that do
+        // not exist, and its teardown must not join them
+        hc::FanOut pool(63, 1e9);
+        exercise(pool, 200, 5, 0, 0);
+        CHECK(pool.workers() == 4, "expected 4 workers before the fork, have %d", pool.workers());
+        std::fflush(stdout);
+        const pid_t child = fork();
+        if (child == 0) {
+            alarm(20);  // a hang ends the child with SIGALRM
+            int bad = 0;
+            {
+                std::vector<long> count(6, 0);
+                auto item = [&](int g) { count[g] += 1; };
+                for (int r = 0; r < 300; ++r) pool.run(6, item);
+                for (int g = 0; g < 6; ++g) bad += count[g] != 300;
+                bad += pool.workers() != 5;
+            }
+            _exit(bad ? 3 : 0);  // (no static destructors in the child; a pool with automatic storage is covered below)
+        }
+        int status = -1;
+        CHECK(child > 0 && waitpid(child, &status, 0) == child, "waitpid failed");
+        CHECK(WIFEXITED(status) && WEXITSTATUS(status) == 0, "the forked child did not finish its calls (status 0x%x)", status);
+        exercise(pool, 200, 5, 0, 0);  // the parent's pool is untouched
+        std::fflush(stdout);
+        const pid_t child2 = fork();
+        if (child2 == 0) {
+            alarm(20);
+            pool.~FanOut();  // teardown in a child that never used the pool: nothing to join
+            _exit(0);
+        }
+        CHECK(child2 > 0 && waitpid(child2, &status, 0) == child2, "waitpid failed");
+        CHECK(WIFEXITED(status) && WEXITSTATUS(status) == 0, "teardown of an inherited pool in a forked child failed (status 0x%x)", status);
+    }
+#endif
     std::printf("fanout_test: %d failures\n", failures);
     return failures ? 1 : 0;
 }

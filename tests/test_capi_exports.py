@@ -70,11 +70,66 @@ def test_kernel_code_object_is_built_next_to_the_library():
     assert os.path.exists(hb.KERNEL_CO), "run __graft_entry__.build()"
     blob = open(hb.KERNEL_CO, "rb").read()
     assert blob[:4] == b"\x7fELF" and len(blob) > 100_000
+    assert os.path.exists(hb.TUNING_CO) and os.path.exists(hb.TUNING_LIB), "the tuning build is missing: run __graft_entry__.build()"
     for name in (b"finalize_kernelILi4ELb0E", b"finalize_kernelILi4ELb1E", b"scatter_kernelE", b"reduce_block_kernelE", b"conv_block_kernelILi6ELi4ELi2ELi1E",
                  b"conv_block_kernelILi6ELi3ELi1ELi2E", b"conv_step_kernelILi4ELi2E", b"added_mass_mv_tagged_kernelE",
                  b"conv_block_kernelILi4ELi4ELi1ELi2E", b"near_split_kernelE", b"wide_step_kernelE"):
         assert name in blob, name
     assert os.path.getmtime(hb.KERNEL_CO) >= os.path.getmtime(os.path.join(hb.CSRC, "hc_kernels.hip"))
+
+
+OPERATIONAL_SWITCHES = {"HC_DIRECT", "HC_ARM", "HC_PASS_AHEAD", "HC_PASS_AHEAD_GAP_US", "HC_PASS_CONCURRENT", "HC_DEVICE_SHARED", "HC_MULTI_THREADS",
+                        "HC_MULTI_SPIN_US", "HC_STEP_TIMEOUT_S"}
+
+
+def _hc_names(path):
+    blob = open(path, "rb").read()
+    return {m.decode() for m in re.findall(rb"(?<![A-Za-z0-9_])(HC_[A-Z][A-Z0-9_]+)\x00", blob)}
+
+
+def test_release_library_reads_operational_switches_only():
+    """The shipped library knows nine environment variables, all operational and all listed in INTEGRATION.md; every sweep / A-B /
+    fault-injection switch lives in the tuning build (-DHC_TUNING) only.  Checked on the strings of the built binaries: a name
+    that is not in the release library cannot be read by it."""
+    from hydrochrono_amd import build as hb
+    names = _hc_names(hb.MAIN_LIB)
+    env_like = {n for n in names if not n.startswith(("HC_ERR", "HC_OK", "HC_API", "HC_HIP", "HC_HOST", "HC_FANOUT", "HC_TUNE"))}
+    assert env_like == OPERATIONAL_SWITCHES, sorted(env_like ^ OPERATIONAL_SWITCHES)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in OPERATIONAL_SWITCHES:
+        assert n in doc, f"{n} is read by the release library but not documented in INTEGRATION.md"
+    tuning = _hc_names(hb.TUNING_LIB)
+    for n in ("HC_SUB_BLOCK", "HC_MINI_NARROW", "HC_WIDE_FUSED", "HC_SLOT_STATE", "HC_STEP_CANARY", "HC_FAULT_STALE_STATE_AT", "HC_BLOCK_MT", "HC_BLOCK_V32"):
+        assert n in tuning and n not in names, n
+
+
+def _kernel_notes(path):
+    import subprocess
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        import pytest
+        pytest.skip("llvm-readelf not found")
+    txt = subprocess.run([readelf, "--notes", path], capture_output=True, text=True, check=True).stdout
+    out = {}
+    for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", txt, re.S):
+        out[m.group(1)] = (int(m.group(2)), int(m.group(3)), int(m.group(4)))
+    return out
+
+
+def test_release_code_object_has_no_spills_no_scratch_and_no_rejected_variants():
+    """Every kernel of the shipped code object keeps its registers (no spilled VGPR, no scratch: a kernel with scratch cannot go to
+    the direct queue at all), and the variants that were measured and not taken -- 12 row tiles per pass workgroup (148 spilled
+    VGPRs at depth 32), the depth-64 pass, the HC_BLOCK_V32 / unroll sweeps -- are not in it (they live in the tuning build)."""
+    from hydrochrono_amd import build as hb
+    rel = _kernel_notes(hb.KERNEL_CO)
+    assert len(rel) >= 20
+    for name, (scratch, vgpr, spills) in rel.items():
+        assert scratch == 0 and spills == 0, (name, scratch, spills)
+    assert not any("conv_block_kernelILi12E" in n for n in rel), "the 12-tile pass variant ships"
+    assert not any(re.search(r"conv_block_kernelILi\dELi\dELi4E", n) for n in rel), "a depth-64 pass variant ships"
+    assert not any(re.search(r"conv_step_kernelILi\dELi[13]E", n) for n in rel), "an unroll-sweep variant of the plain kernel ships"
+    tun = _kernel_notes(hb.TUNING_CO)
+    assert len(tun) > len(rel) and any(re.search(r"conv_block_kernelILi\dELi\dELi4E", n) for n in tun)
 
 
 def test_wait_result_buffer_is_host_only():

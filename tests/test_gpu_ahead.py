@@ -34,7 +34,7 @@ def relerr(a, b):
 @pytest.mark.parametrize("direct", [1, 0], ids=["aql", "hip"])
 @pytest.mark.parametrize("lookahead,sub", [(32, 0), (16, 0), (32, 8), (16, 8), (32, 4)], ids=["la32", "la16", "la32-sub8", "la16-sub8", "la32-sub4"])
 @pytest.mark.parametrize("N,dt", [(2, 0.01), (3, 0.007), (4, 0.013), (8, 0.01)])
-def test_one_block_ahead_against_oracle(hydro, N, dt, lookahead, sub, direct, monkeypatch):
+def test_one_block_ahead_against_oracle(hydro, N, dt, lookahead, sub, direct, monkeypatch, tuning_build):
     """Small systems, both look-ahead forms (single level; sub-blocks forced with HC_SUB_BLOCK), both dispatch paths, step sizes
     equal to, below and above the IRF spacing; irregular waves (the excitation rows travel with the pass in the making)."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
@@ -73,7 +73,7 @@ def test_one_block_ahead_against_oracle(hydro, N, dt, lookahead, sub, direct, mo
 
 @pytest.mark.parametrize("slices", [1, 3, 16, 31])
 @pytest.mark.parametrize("sub", [0, 8])
-def test_one_block_ahead_slice_counts(hydro, slices, sub, monkeypatch):
+def test_one_block_ahead_slice_counts(hydro, slices, sub, monkeypatch, tuning_build):
     """The number of launches the pass in the making is spread over (and with it its chunk length) is the caller's choice."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     from hydrochrono_amd.synthetic import many_body_case, rest_positions
@@ -96,7 +96,7 @@ def test_one_block_ahead_slice_counts(hydro, slices, sub, monkeypatch):
 
 
 @pytest.mark.parametrize("sub", [0, 8])
-def test_one_block_ahead_without_the_pass_lane(hydro, sub, monkeypatch):
+def test_one_block_ahead_without_the_pass_lane(hydro, sub, monkeypatch, tuning_build):
     """HC_PASS_CONCURRENT=0: the slices and the short passes towards the next block stay on the step path's lane (what contexts
     that share a device do) -- the same arithmetic, bitwise the forces of a context that uses the pass lane."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
@@ -343,7 +343,7 @@ def test_one_block_ahead_wide_system_and_row_shards(hydro, direct, monkeypatch):
 
 @pytest.mark.parametrize("concurrent", ["1", "0"], ids=["pass-lane", "in-order"])
 @pytest.mark.parametrize("sub", [0, 8])
-def test_one_block_ahead_with_the_ring_nearly_full(hydro, sub, concurrent, monkeypatch):
+def test_one_block_ahead_with_the_ring_nearly_full(hydro, sub, concurrent, monkeypatch, tuning_build):
     """The pass one block ahead keeps reading its view of the history while the block's steps push new samples into the ring, so
     the slots those pushes take must not belong to the view.  The ring is allocated with 64 slots beyond the IRF window; steps
     3-6 % below the IRF spacing fill them with KEPT samples (the history grows to Hcap - 1 or - 2 without triggering a grow), and
@@ -387,7 +387,7 @@ def test_one_block_ahead_with_the_ring_nearly_full(hydro, sub, concurrent, monke
 
 @pytest.mark.parametrize("direct", [1, 0], ids=["aql", "hip"])
 @pytest.mark.parametrize("schedule", [0, 1], ids=["pass-at-block-start", "one-block-ahead"])
-def test_narrow_short_pass_is_bitwise_the_wide_one(hydro, schedule, direct, monkeypatch):
+def test_narrow_short_pass_is_bitwise_the_wide_one(hydro, schedule, direct, monkeypatch, tuning_build):
     """The in-block short passes of the two-level form run in their NARROW form by default (16 step columns per chunk, offset per
     chunk, BlockArgs::mini_narrow): the same brackets, the same chunk sums, the same order in the reduction -- bitwise the forces of
     the wide form (HC_MINI_NARROW=0), through uniform steps equal to / below / above the IRF spacing and a change of step size."""
@@ -422,7 +422,7 @@ def test_narrow_short_pass_is_bitwise_the_wide_one(hydro, schedule, direct, monk
 
 
 @pytest.mark.parametrize("direct", [1, 0], ids=["aql", "hip"])
-def test_wide_step_in_one_launch_is_bitwise_the_two_launch_form(hydro, direct, monkeypatch):
+def test_wide_step_in_one_launch_is_bitwise_the_two_launch_form(hydro, direct, monkeypatch, tuning_build):
     """A block step of a wide system (D >= 1024) is ONE launch by default (wide_step_kernel: column slices of the own-sample part, then
     the workgroup that arrives last at a row tile's counter runs the tile's step kernel; the hand-off across XCDs uses agent-scope atomic
     stores / loads of the partials and no fence); HC_WIDE_FUSED=0 keeps near_split_kernel + finalize_kernel.  The slices are added in
@@ -460,7 +460,7 @@ def test_wide_step_in_one_launch_is_bitwise_the_two_launch_form(hydro, direct, m
     with tempfile.TemporaryDirectory() as d:
         for fused in ("1", "0"):
             out = os.path.join(d, f"f{fused}.npy")
-            r = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, env=dict(os.environ, HC_WIDE_FUSED=fused, HC_DIRECT=str(direct)))
+            r = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, env=dict(os.environ, HC_WIDE_FUSED=fused, HC_DIRECT=str(direct), HYDROCHRONO_AMD_FLAVOR="tuning"))
             assert r.returncode == 0, r.stderr[-2000:]
             counts.append(int(r.stdout.strip().splitlines()[-1]))
             runs.append(np.load(out))
@@ -468,3 +468,90 @@ def test_wide_step_in_one_launch_is_bitwise_the_two_launch_form(hydro, direct, m
     assert np.array_equal(runs[0], runs[1])
     for n, tt in enumerate(times):
         assert relerr(runs[0][n], orc.step(tt, *motion.state(tt))) <= TIGHT_TOL, f"step {n}"
+
+
+# ---- the adaptive schedule (hc_set_pass_schedule(ctx, -1), the default) ---------------------------------------------------------
+def test_adaptive_schedule_follows_the_callers_gaps_c3_size(hydro):
+    """C3 size under the DEFAULT schedule: a caller that steps back to back (hc_step_many: the C ABI's own loop, no interpreter
+    between the calls) gets the pass at block start, the same caller with an interpreter's work between its calls (tens of
+    microseconds: more than the rule's 4 us) gets it one block ahead, and back again -- 0 -> gaps -> 0 in one run, every step against
+    the flat oracle.  The counters show the rule's answer block by block."""
+    import bench as B
+    import oracle as orc_mod
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    case = many_body_case(64, S=B.S_RIRF, dt_rirf=B.DT, n_exc=B.N_EXC, dt_exc=B.DT, seed=20251031)
+    gpu = hydro.HydroForces.from_case(case)
+    motion = PrescribedMotion(64, rest_positions(case), seed=20251031)
+    kw = dict(B.WAVES, simulation_dt=B.DT, simulation_duration=B.T0 + 12.0)
+    gpu.add_waves_irregular(num_bodies=64, **kw)
+    orc_mod.set_num_threads(min(64, os.cpu_count() or 1))
+    orc = load_into_oracle(case)
+    orc.add_waves_irregular(**kw)
+    nhist = B.S_RIRF + 5
+    t_hist = B.T0 - B.DT * np.arange(1, nhist + 1)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    gpu.set_history(t_hist, v_hist)
+    orc.prefill_history(t_hist, v_hist)
+    orc.flat_prepare()
+    phases = [("tight", 192), ("gaps", 160), ("tight", 192)]
+    n0, worst, answers = 0, 0.0, []
+    for kind, count in phases:
+        before = gpu.profile()
+        times = B.T0 + B.DT * np.arange(n0, n0 + count)
+        if kind == "tight":
+            forces, _ = gpu.step_many(times, np.stack([motion.packed(t) for t in times]))
+        else:
+            forces = np.stack([gpu.step(t, *motion.state(t)) for t in times])
+        for t, f in zip(times, forces):
+            e = relerr(f, orc.flat_step(t, *motion.state(t)))
+            worst = max(worst, e)
+            assert e <= 1e-10, f"{kind} phase, t = {t}"
+        after = gpu.profile()
+        answers.append((kind, after["schedule_blocks_ahead"] - before["schedule_blocks_ahead"],
+                        after["schedule_blocks_at_start"] - before["schedule_blocks_at_start"], after["ahead_blocks"] - before["ahead_blocks"]))
+        n0 += count
+    print(f"adaptive schedule at C3 size: worst relative error {worst:.2e}; (phase, answers ahead, answers at start, blocks that started with rows made ahead): {answers}")
+    # a decision belongs to the gaps of the block BEFORE it: one block of either phase may still carry the previous phase's answer
+    (_, a0, s0, _), (_, a1, s1, r1), (_, a2, s2, _) = answers
+    assert s0 >= 5 and a0 == 0, answers      # 64 bodies are not a wide system: the first answer is "at block start"
+    assert a1 >= 3 and s1 <= 1 and r1 >= 2, answers
+    assert s2 >= 4 and a2 <= 1, answers
+    assert gpu.direct_dispatch()[0]
+
+
+def test_adaptive_schedule_row_shards_decide_alike(hydro, monkeypatch, tuning_build):
+    """The rule on a small system (size floor off, threshold raised to 2 ms so that an interpreter's loop counts as back to back and
+    a 4 ms sleep as a gap): an unsharded context and three row shards behind hc_step_multi, driven through the same
+    0 -> gaps -> 0 pattern.  hc_step_multi measures the gap once for its group, so every shard answers like the others -- and like
+    the unsharded context: rows bitwise equal; both against the oracle."""
+    import time
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_PASS_AHEAD_MIN_MB", "0")
+    monkeypatch.setenv("HC_PASS_AHEAD_GAP_US", "2000")
+    N = 6
+    case = many_body_case(N, S=200, dt_rirf=0.01, n_exc=41, dt_exc=0.02, seed=505)
+    kw = dict(WAVES, simulation_duration=8.0)
+    one, grp, orc = hydro.HydroForces.from_case(case), hydro.HydroGroup.from_case(case, 3), load_into_oracle(case)
+    for h in (one, grp, orc):
+        h.add_waves_irregular(**kw)
+    motion = PrescribedMotion(N, rest_positions(case), seed=N)
+    slow = lambda n: 330 <= n < 460 or 560 <= n < 600  # noqa: E731
+    for n in range(700):
+        t = 0.01 * n
+        st = motion.state(t)
+        f1 = one.step(t, *st)
+        if slow(n):
+            time.sleep(0.004)
+        fg = grp.step(t, *st)
+        if slow(n):
+            time.sleep(0.004)
+        assert np.array_equal(f1, fg), f"step {n}: the shards' rows differ from the unsharded context's"
+        assert relerr(f1, orc.step(t, *st)) <= TIGHT_TOL, f"step {n}"
+    p1 = one.profile()
+    assert p1["schedule_blocks_ahead"] >= 4 and p1["schedule_blocks_at_start"] >= 8 and p1["ahead_blocks"] >= 3, p1
+    for h in grp.shards:
+        p = h.profile()
+        assert (p["schedule_blocks_ahead"], p["schedule_blocks_at_start"], p["ahead_blocks"]) == \
+               (p1["schedule_blocks_ahead"], p1["schedule_blocks_at_start"], p1["ahead_blocks"]), (p, p1)

@@ -231,7 +231,7 @@ def test_queue_parking_between_steps_of_a_caller_that_stays_away(HF, arm, monkey
 
 
 @pytest.mark.parametrize("direct", [1, 0], ids=["aql", "hip"])
-def test_every_step_proves_it_read_this_steps_state(monkeypatch, direct):
+def test_every_step_proves_it_read_this_steps_state(monkeypatch, direct, tuning_build):
     """hc_step stores the body state into device memory through the PCIe BAR and dispatches with agent-scope fences only, so its
     correctness rests on the GPU re-reading memory the host re-writes.  That is self-tested when a context is finalized -- and since
     round 4 checked at EVERY step: the host stores the step's sequence number behind the state, the step kernel hands the word back
@@ -263,7 +263,7 @@ def test_every_step_proves_it_read_this_steps_state(monkeypatch, direct):
 
 
 @pytest.mark.parametrize("N, sharded", [(1, False), (6, False), (6, True), (127, False), (170, False), (171, False)], ids=["1-body", "6-bodies", "6-bodies-row-shards", "127-bodies", "170-bodies", "171-bodies-wide-classic"])
-def test_state_behind_the_step_kernels_arguments_is_bitwise_the_classic_path(monkeypatch, N, sharded):
+def test_state_behind_the_step_kernels_arguments_is_bitwise_the_classic_path(monkeypatch, N, sharded, tuning_build):
     """On the direct path a step that is ONE kernel takes its body state behind that kernel's argument block (a slot of the kernarg
     ring holds 4 KB of arguments + 16 KB the kernel addresses from its kernarg segment pointer: finalize_kernel<4, true> requests its
     velocities before it has read a single argument -- hc_step.cpp: fill_slot_state, hc_limits.hpp: kSlotArgBytes).  Systems of up to

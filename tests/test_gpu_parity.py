@@ -232,6 +232,27 @@ def test_multibody_parity(HF, N, dt, mode, monkeypatch):
         assert p["block_kernel_launches"] == 0 and p["conv_kernel_launches"] >= 400, p
 
 
+@pytest.mark.parametrize("direct", [1, 0], ids=["aql", "hip"])
+@pytest.mark.parametrize("N,dt", [(8, 0.01), (8, 0.007), (16, 0.01)])
+def test_depth64_experimental_pass_against_oracle(HF, N, dt, direct, monkeypatch, tuning_build):
+    """hc_set_lookahead(64): the experimental depth-64 pass (NB = 4 blocks of 16 steps per streamed K word, profiles/r05) in the
+    single-level form with the pass at block start -- totals and components against the oracle through several blocks."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    case = many_body_case(N, S=257, dt_rirf=0.01, n_exc=301, dt_exc=0.02, seed=640 + N)
+    case["g_sys"] = [0.3, -0.2, -9.7]
+    gpu, orc = make_gpu_mode(HF, case, (64, direct), monkeypatch), load_into_oracle(case)
+    kw = dict(simulation_dt=dt, simulation_duration=8.0, ramp_duration=1.0, wave_height=2.5, wave_period=8.0,
+              frequency_min=0.02, frequency_max=0.5, nfrequencies=128, peak_enhancement_factor=3.3, seed=1)
+    gpu.add_waves_irregular(**kw)
+    orc.add_waves_irregular(**kw)
+    motion = PrescribedMotion(N, rest_positions(case), seed=N)
+    gpu.enable_profiling(1)
+    drive_both(gpu, orc, motion, dt * np.arange(560))
+    p = assert_mode_was_used(gpu, (64, direct), 560)
+    assert 560 // 64 - 2 <= p["block_kernel_launches"] <= 560 // 64 + 2 and p["scatter_kernel_launches"] >= 450, p
+
+
 def test_multibody_regular_wave_phase_indexing(HF):
     """The reference indexes the regular-wave phase by DoF only (body-0 phases for every body, src/wave_types.cpp:323)."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
@@ -1051,7 +1072,7 @@ def test_c4_size_array_properties_on_one_gpu(HF):
 
 @pytest.mark.parametrize("depth,sub", [(16, 0), (32, 0), (32, 8), (16, 8), (32, 4)])  # sub > 0: the two-level form of wide systems, forced here
 @pytest.mark.parametrize("seed,N", [(1, 2), (2, 2), (3, 2), (4, 8)])  # N = 8: the scalar-tracker (D % 8 == 0) pass form
-def test_lookahead_random_step_patterns(HF, seed, N, depth, sub, monkeypatch):
+def test_lookahead_random_step_patterns(HF, seed, N, depth, sub, monkeypatch, tuning_build):
     """Randomised stepping patterns (uniform stretches of random length and step size, jittered stretches, abrupt changes):
     look-ahead and plain evaluation of the same inputs must agree to rounding whatever the planner decides."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion

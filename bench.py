@@ -88,6 +88,7 @@ def parse():
     ap.add_argument("--python-loop", action="store_true", help="N = 1: time hc_step calls issued one by one from the Python interpreter (rounds 1-4a) "
                                                              "instead of the library's own loop hc_step_many")
     ap.add_argument("--no-c4-share", action="store_true", help="skip the c4_rank_share secondary (one C4/8 shard on this GPU)")
+    ap.add_argument("--no-small-configs", action="store_true", help="skip the c2_two_body / c5_one_body_2048 / added_mass_mv secondaries (each beside its CPU figure)")
     ap.add_argument("--no-c4-one-gpu", action="store_true", help="skip the c4_one_gpu secondary (the whole 512-body array, 77 GB of K, on this GPU)")
     ap.add_argument("--exchange", choices=["host", "rccl"], default="host",
                     help="N > 1 under a launcher: how every rank gets all force rows each step.  host (default): hc_step on every rank (direct "
@@ -324,6 +325,150 @@ def c4_rank_share(sdt, lookahead):
     out["chrono_like_loop"] = loops
     gpu.close()
     return out
+
+
+def small_system(name, case, poses, waves_kw, sdt, nsteps, what):
+    """A BASELINE.json config that is a parity case rather than the headline (C2, C5 -- synthetic stand-ins, the reference's
+    rm3.h5 / deepcwind.h5 are missing blobs): synchronous hc_step from a steady-state history through the C ABI's own loop
+    (hc_step_many), beside the CPU oracle on this box's cores -- reference-faithful at ONE thread and at its best thread count, and
+    the optimised flat variant.  For systems this small the GPU step is a PCIe round trip; SURVEY 8d (iii): "CPU may win; report honestly"."""
+    import oracle as orc_mod
+    from cases import load_into_oracle
+    from hydrochrono_amd.hydro import HydroForces
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    N = case["N"]
+    gpu, orc = HydroForces.from_case(case), load_into_oracle(case)
+    gpu.add_waves_irregular(**waves_kw)
+    orc.add_waves_irregular(**waves_kw)
+    motion = PrescribedMotion(N, poses, seed=12)
+    span = float(np.asarray(case["bodies"][0]["rirf_t"])[-1])
+    nhist = int(np.ceil(span / sdt)) + 5
+    t0 = nhist * sdt + 1.0
+    t_hist = t0 - sdt * np.arange(1, nhist + 1)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    gpu.set_history(t_hist, v_hist)
+    orc.prefill_history(t_hist, v_hist)
+    n_warm = 72
+    times = t0 + sdt * np.arange(n_warm + nsteps)
+    states = np.stack([motion.packed(t) for t in times])
+    forces, secs = gpu.step_many(times, states)
+    lat = secs[n_warm:] * 1e6
+    cores = os.cpu_count() or 1
+    k = [0]
+    f_orc = []
+
+    def timed(fn, n, keep):
+        d = []
+        for _ in range(n):
+            t = times[k[0]]
+            st = motion.state(t)
+            a = time.perf_counter()
+            f = fn(t, *st)
+            d.append(time.perf_counter() - a)
+            if keep:
+                f_orc.append(f)
+            k[0] += 1
+        return d
+    sweep = {}
+    for th in sorted({1, min(cores, 4), min(cores, 16), min(cores, 64)}):
+        orc_mod.set_num_threads(th)
+        sweep[th] = float(np.median(timed(orc.step, 12, True))) * 1e6
+    best = min(sweep, key=sweep.get)
+    flat = {}
+    for th in sorted({1, min(cores, 16)}):
+        orc_mod.set_num_threads(th)
+        orc.flat_prepare()
+        flat[th] = float(np.median(timed(orc.flat_step, 12, False)[2:])) * 1e6
+    n_chk = len(f_orc)
+    p = gpu.profile()
+    out = {"workload": what, "bodies": N, "steps": nsteps, "step_dt": sdt,
+           "gpu_hc_step_us": {"median": float(np.median(lat)), "mean": float(lat.mean()), "p90": float(np.percentile(lat, 90)), "max": float(lat.max())},
+           "evals_per_s": 1e6 / float(lat.mean()),
+           "cpu_oracle_us": {"faithful_one_thread": sweep[1], "faithful_best": sweep[best], "faithful_best_threads": best,
+                             "faithful_threads_sweep": {str(th): v for th, v in sweep.items()},
+                             "flat_one_thread": flat[1], "flat_best": min(flat.values()), "flat_best_threads": min(flat, key=flat.get),
+                             "sample": "12 steps per thread count (median), the steps the GPU ran"},
+           "gpu_vs_cpu": {"vs_faithful_one_thread": sweep[1] / float(lat.mean()), "vs_faithful_best": sweep[best] / float(lat.mean()),
+                          "vs_flat_best": min(flat.values()) / float(lat.mean())},
+           "parity_max_rel_err_vs_oracle": max_rel_err(forces[:n_chk], np.stack(f_orc)), "parity_steps": n_chk,
+           "lookahead_blocks_used": int(p["block_kernel_launches"]) > 0}
+    out.update(dispatch_info([gpu]))
+    gpu.close()
+    return out
+
+
+def c2_two_body():
+    from hydrochrono_amd.synthetic import many_body_case
+    case = many_body_case(2, S=1001, dt_rirf=0.015, n_exc=1001, dt_exc=0.125, seed=2)
+    case["bodies"][0]["cg"], case["bodies"][1]["cg"] = np.array([0.0, 0.0, -0.72]), np.array([0.0, 0.0, -21.29])  # demos/rm3 poses
+    for b in case["bodies"]:
+        b["cb"] = b["cg"] + np.array([0.0, 0.0, 0.3])
+    kw = dict(simulation_dt=0.01, simulation_duration=40.0, ramp_duration=5.0, wave_height=2.5, wave_period=8.0, frequency_min=0.02,
+              frequency_max=0.5, nfrequencies=512, peak_enhancement_factor=3.3, seed=1)
+    return small_system("c2", case, np.stack([b["cg"] for b in case["bodies"]]), kw, 0.01, 320,
+                        "C2 stand-in (SURVEY 8d; rm3.h5 is a missing blob): two coupled bodies with rm3's poses, K [2][6][12][1001] on the sphere's IRF grid "
+                        "(0..15 s @ 0.015), irregular JONSWAP Hs 2.5 / Tp 8 / gamma 3.3 / 512 components, dt 0.01 (every IRF sample a true interpolation)")
+
+
+def c5_one_body_2048():
+    from hydrochrono_amd.synthetic import many_body_case
+    case = many_body_case(1, S=401, dt_rirf=0.05, n_exc=401, dt_exc=0.25, seed=5)
+    kw = dict(simulation_dt=0.08, simulation_duration=1000.0, ramp_duration=20.0, wave_height=6.0, wave_period=10.0, frequency_min=0.01,
+              frequency_max=0.6, nfrequencies=2048, peak_enhancement_factor=2.0, seed=4)
+    return small_system("c5", case, [case["bodies"][0]["cg"]], kw, 0.08, 320,
+                        "C5 stand-in (SURVEY 8d; deepcwind.h5 is a missing blob): one body, dt 0.08, 1000 s, 2048 wave components (the free-surface table "
+                        "synthesised on the GPU by the direct FP64 sum; the rocFFT variant is checked in tests/test_gpu_parity.py)")
+
+
+ADDED_MASS_HOST_MAX_DOFS = 96  # include/hydroc_amd/chloadaddedmass.h: kHostProductMaxDofs
+
+
+def added_mass_product():
+    """hc_added_mass_mv (Chrono's LoadIntLoadResidual_Mv, src/chloadaddedmass.cpp:55-70: one Eigen `R += c M w` on the host) at
+    D = 6 / 12 / 96 / 384 / 3072: the GPU round trip per call beside the oracle's host loop -- and with it the size below which the
+    C++ binding (include/hydroc_amd/chloadaddedmass.h) keeps the product on the host copy of the matrix it already holds."""
+    import oracle as orc_mod
+    from hydrochrono_amd import capi
+    from hydrochrono_amd.hydro import HydroForces
+    lib = capi.load()
+    mv = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int)(("hc_added_mass_mv", lib))
+    rows = {}
+    for N in (1, 2, 16, 64, 512):
+        D = 6 * N
+        gpu = HydroForces(N, device=0)
+        gpu.synth_fill(20251031, 8, DT, 0, DT)
+        gpu.finalize()
+        M = gpu.added_mass_matrix()
+        rng = np.random.default_rng(N)
+        w = rng.standard_normal(D)
+        R = np.zeros(D)
+        reps = 400 if N <= 64 else 120
+        lat = np.zeros(reps)
+        for i in range(40 + reps):
+            R[:] = 0.0
+            a = time.perf_counter()
+            rc = mv(gpu.ctx, w.ctypes.data, 0.5, R.ctypes.data, D)
+            b = time.perf_counter()
+            if rc:
+                raise RuntimeError(lib.hc_last_error(gpu.ctx).decode())
+            if i >= 40:
+                lat[i - 40] = b - a
+        cpu_s, R_cpu = orc_mod.dense_mv_seconds(M, w, 0.5, max(3, int(1e8 / (D * D))))
+        R_ref = 0.5 * (M @ w)
+        rows[str(D)] = {"bodies": N, "gpu_us_per_call": {"median": float(np.median(lat)) * 1e6, "mean": float(lat.mean()) * 1e6},
+                        "cpu_oracle_us_per_call_one_thread": cpu_s * 1e6, "gpu_over_cpu": float(np.median(lat)) / cpu_s,
+                        "max_rel_err": float(np.max(np.abs(R - R_ref)) / np.max(np.abs(R_ref)))}
+        gpu.close()
+    ds = sorted(int(d) for d in rows)
+    gpu_wins = [d for d in ds if rows[str(d)]["gpu_over_cpu"] < 1.0]
+    return {"rows_by_D": rows, "crossover": {"host_wins_up_to_D": max([d for d in ds if rows[str(d)]["gpu_over_cpu"] >= 1.0], default=None),
+                                             "gpu_wins_from_D": min(gpu_wins, default=None)},
+            "binding_threshold": {"kHostProductMaxDofs": ADDED_MASS_HOST_MAX_DOFS,
+                                  "meaning": "hydroc_amd::ChLoadAddedMass::LoadIntLoadResidual_Mv keeps the product on its host copy of the matrix "
+                                             "for 6N <= this and calls hc_added_mass_mv (the GPU) above it; the C ABI entry is always the GPU"},
+            "note": "GPU: hc_added_mass_mv through a ctypes prototype with integer arguments (about 1 us of interpreter per call included), "
+                    "synchronous: w and R in through the PCIe BAR, one kernel on a queue of its own, tagged result back; "
+                    "CPU: the oracle's row-times-vector loop (-O2, one thread, matrix warm in cache for D <= 384)"}
 
 
 C4_ONE_GPU_FILES = ("profiles/r04/bench_c4_1gpu.json", "profiles/r03/bench_c4_1gpu.json")
@@ -920,6 +1065,14 @@ def main():
                 out["c4_one_gpu"] = c4_one_gpu(sdt, args.lookahead if args.lookahead > 0 else 32)
             except Exception as e:  # a secondary must not cost the run its line
                 out["c4_one_gpu"] = {"error": str(e)}
+        if world == 1 and not strong and not args.no_secondary and not args.no_small_configs:
+            # BASELINE.json's other single-GPU configs and the added-mass product, each beside its CPU figure (the device to themselves)
+            gpu.close()
+            for key, fn in (("c2_two_body", c2_two_body), ("c5_one_body_2048", c5_one_body_2048), ("added_mass_mv", added_mass_product)):
+                try:
+                    out[key] = fn()
+                except Exception as e:  # a secondary must not cost the run its line
+                    out[key] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and case is not None:
             base, f_faithful, flat_threads = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds, sdt, duration)
             n_chk = k_next

@@ -240,6 +240,7 @@ struct hc_ctx {
     hc::DeviceBuffer<double> d_partials, d_partials_block, d_P, d_E;
     hc::DeviceBuffer<double> d_near_partials;  // [16][Dpad] slice partials of near_split_kernel (wide systems)
     hc::DeviceBuffer<int> d_tile_counter;      // [ntiles] arrival counters of wide_step_kernel (zero between launches)
+    bool tile_counter_suspect = false;         // a step failed after it may have dispatched a wide_step_kernel: the counters are cleared before the next one
     hc::DeviceBuffer<double> d_Y;           // weighted scatter results per consumer step [kLookahead + 1][kTermMax][Dpad]
     hc::DeviceBuffer<double> d_zero_state;  // 12N zeros: the not-yet-known sample of the look-ahead pass
     int chunk_gp_ex_block = 32, nchunks_ex_block = 0;  // excitation chunks of the look-ahead launch

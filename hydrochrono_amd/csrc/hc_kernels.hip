@@ -1539,6 +1539,13 @@ __global__ void __launch_bounds__(256) near_split_kernel(NearArgs a) {
 // slice are agent-scope atomic stores (global_store sc1: written through), complete before the count (s_waitcnt vmcnt(0)); the count is
 // an agent-scope atomic add; the last workgroup reads the partials with agent-scope atomic loads (global_load sc1) issued after its own
 // add has returned.  Nothing else the step kernel reads was written in this launch.
+// This is the fence-free hand-off MI355X_MICROARCH.md lists as measured on gfx950 ("ONE lane of each storing workgroup, for ALL that
+// workgroup's stores: an agent-scope atomic add ... the workgroup whose add came last, told by the value its add returned"; stores and
+// loads all sc1, every storing wave drained, a workgroup barrier on both sides) -- not an architectural guarantee of the memory model.
+// The library runs on gfx950 only (hc_create refuses every other device), the suite keeps the bitwise A/B against the two-launch form
+// with its ordinary kernel boundary (test_wide_step_in_one_launch_is_bitwise_the_two_launch_form, tuning build: HC_WIDE_FUSED=0), and
+// profiles/soak_wide_fused.py soaks it.  The counters are re-zeroed by the last arriver; a launch that was cut short would leave
+// them non-zero, so the host clears them before the next fused step whenever a step has failed (hc_step.cpp: tile_counter_suspect).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) wide_step_kernel(WideStepArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];

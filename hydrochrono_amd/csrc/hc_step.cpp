@@ -564,6 +564,15 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         static const bool fused_on = HC_TUNE_INT("HC_WIDE_FUSED", 1) != 0;
         const long long wide_wgs   = static_cast<long long>(c->ntiles) * hc::near_slices_for(c->D);
         if (fused_on && !f.scratch_out && wide_wgs <= 2LL * c->num_cus && c->d_tile_counter.n >= static_cast<size_t>(c->ntiles) && (!direct || c->dk_wide.ok())) {
+            if (c->tile_counter_suspect) {
+                // A step failed after its kernels may have gone out (step_abort): a wide_step_kernel that was cut short leaves its
+                // tiles' arrival counters non-zero, and no workgroup of a later launch would find itself last.  Everything the
+                // context has in flight is waited for, then the counters start from zero again.
+                quiesce_direct(c);
+                HC_HIP(hipStreamSynchronize(c->stream));
+                HC_HIP(hipMemset(c->d_tile_counter.p, 0, c->d_tile_counter.n * sizeof(int)));
+                c->tile_counter_suspect = false;
+            }
             hc::WideStepArgs w{na, z, c->d_tile_counter.p};
             if (direct) {
                 const hc::WideLaunch l = hc::wide_launch_config(w);
@@ -828,6 +837,7 @@ void step_end(hc_ctx* c, double* force_out) {
 void step_abort(hc_ctx* c) {
     c->pending_step = 0;
     c->tail.pending = false;
+    c->tile_counter_suspect = c->d_tile_counter.n > 0;  // (see enqueue_step: the fused wide step's arrival counters)
     c->step_canary_in  = nullptr;  // (a begin that threw before its enqueue_step consumed them)
     c->step_canary_out = nullptr;
 }

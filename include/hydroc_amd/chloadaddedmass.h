@@ -1,6 +1,10 @@
 // hydroc_amd/chloadaddedmass.h -- ChLoadAddedMass of the reference (include/hydroc/chloadaddedmass.h:22-90,
 // src/chloadaddedmass.cpp:12-70): the rho-scaled 6N x 6N infinite-frequency added mass as a stiff ChLoadCustomMultiple.  The
-// Jacobian block comes from hc_added_mass_matrix, `R += c*M*w` runs on the GPU (hc_added_mass_mv / _multi).  Created by the
+// Jacobian block comes from hc_added_mass_matrix.  `R += c*M*w` (Chrono's LoadIntLoadResidual_Mv, at least once per step) runs on the
+// GPU (hc_added_mass_mv / _multi) for systems of more than kHostProductMaxDofs coordinates and on this object's own host copy of
+// the matrix -- the one it keeps for the Jacobian -- below: a GPU product is a PCIe round trip of 5.3 - 9.6 us whatever its size
+// (6 x 6 to 384 x 384), the reference's host product takes 0.02 us at 6 x 6, 0.07 at 12 x 12, 4 at 96 x 96 and 85 at 384 x 384
+// (bench.py: added_mass_mv; MEASURED.md).  The C ABI entry itself always runs on the GPU.  Created by the
 // TestHydro constructor; included by hydro_forces.h (needs Project Chrono, or the stand-in headers of tests/cpp/chrono_stub).
 #pragma once
 
@@ -12,6 +16,8 @@ namespace hydroc_amd {
 
 class ChLoadAddedMass : public chrono::ChLoadCustomMultiple {
   public:
+    // 6N up to which LoadIntLoadResidual_Mv multiplies on the host (16 bodies; bench.py reports the measured crossover beside it)
+    static constexpr int kHostProductMaxDofs = 96;
     // (the reference's constructor takes the per-body file data, :12-25; here the matrix is asked from the object that read the file)
     ChLoadAddedMass(TestHydro* hydro, std::vector<std::shared_ptr<chrono::ChLoadable>>& bodies, chrono::ChSystem* system)
         : chrono::ChLoadCustomMultiple(bodies), hydro_(hydro), system_(system) {
@@ -75,12 +81,27 @@ class ChLoadAddedMass : public chrono::ChLoadCustomMultiple {
     // :55-70: R += c * M * w
     void LoadIntLoadResidual_Mv(chrono::ChVectorDynamic<>& R, const chrono::ChVectorDynamic<>& w, const double c) override {
         if (!this->m_jacobians) return;
+        const int D = static_cast<int>(infinite_added_mass_.rows());
+        if (D <= host_product_limit_ && R.size() >= D && w.size() >= D) {
+            // small system: the product on the host copy (src/chloadaddedmass.cpp:70 is the same Eigen expression on the system-sized
+            // matrix, whose rows and columns beyond 6N are zero)
+            for (int i = 0; i < D; ++i) {
+                double s = 0.0;
+                for (int j = 0; j < D; ++j) s += infinite_added_mass_(i, j) * w(j);
+                R(i) += c * s;
+            }
+            return;
+        }
         if (hydro_) hydro_->AddedMassMv(R.data(), w.data(), c, static_cast<int>(R.size()));
         else check(own_ctx_.get(), hc_added_mass_mv(own_ctx_.get(), w.data(), c, R.data(), static_cast<int>(R.size())));
     }
 
+    // Not in the reference: up to how many coordinates the product stays on the host (default kHostProductMaxDofs; 0 = always the GPU)
+    void SetHostProductLimit(int dofs) { host_product_limit_ = dofs; }
+
   private:
     bool IsStiff() override { return true; }
+    int host_product_limit_ = kHostProductMaxDofs;
     TestHydro* hydro_;                 // the object that read the file (the load it creates itself), or null:
     std::shared_ptr<hc_ctx> own_ctx_;  // ... a context of the load's own (the constructor over HydroData::BodyInfo; clones share it)
     chrono::ChSystem* system_;

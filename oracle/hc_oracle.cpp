@@ -1352,6 +1352,17 @@ int orc_added_mass_mv(orc_ctx* c, double* R, const double* w, double cc, int n_s
     ORC_CATCH(c)
 }
 
+// The same product without a hydro object, `reps` times over (bench.py: the CPU figure beside hc_added_mass_mv at sizes for which no
+// oracle case is built; src/chloadaddedmass.cpp:55-70 is one Eigen `R += c * M * w`): M [D][D] row-major, R is accumulated into.
+void orc_dense_mv(const double* M, int D, const double* w, double cc, double* R, int reps) {
+    for (int r = 0; r < reps; ++r)
+        for (int i = 0; i < D; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < D; ++j) s += M[size_t(i) * D + j] * w[j];
+            R[i] += cc * s;
+        }
+}
+
 // ---- building blocks exposed for known-answer tests of the restated third-party arithmetic
 void orc_linspaced(int n, double lo, double hi, double* out) {
     auto v = orc::LinSpaced(n, lo, hi);

@@ -5,6 +5,7 @@
 // build image; these headers exist so that the guarded adapter code is compiled and driven by a test instead of rotting.
 // They pin nothing about Chrono's behaviour.
 #pragma once
+#include <cmath>
 #include <cstddef>
 #include <memory>
 #include <string>
@@ -20,23 +21,26 @@ std::shared_ptr<T> make_shared(A&&... a) {
 
 namespace chrono {
 
-struct ChVector3d {
-    double v[3] = {0, 0, 0};
+struct ChVector3d {  // ref: src/hydro_forces.cpp:279
+    double v[3] = {0, 0, 0};  // stub-only state
     ChVector3d() = default;
-    ChVector3d(double a, double b, double c) : v{a, b, c} {}
-    double x() const { return v[0]; }
-    double y() const { return v[1]; }
-    double z() const { return v[2]; }
+    ChVector3d(double a, double b, double c) : v{a, b, c} {}  // ref: demos/sphere/demo_sphere_reg_waves.cpp:57 (driver)
+    double x() const { return v[0]; }  // ref: src/hydro_forces.cpp:284
+    double y() const { return v[1]; }  // ref: src/hydro_forces.cpp:285
+    double z() const { return v[2]; }  // ref: src/hydro_forces.cpp:286
+    double Length() const { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }  // ref: src/hydro_forces.cpp:269
 };
 
-struct ChQuaterniond {
-    ChVector3d cardan;  // the stub stores the angles directly
-    ChVector3d GetCardanAnglesXYZ() const { return cardan; }
+struct ChQuaterniond {  // (the type of ChBody::GetRot(), src/hydro_forces.cpp:280)
+    ChVector3d cardan;  // stub-only state: the stub stores the angles directly
+    ChVector3d GetCardanAnglesXYZ() const { return cardan; }  // ref: src/hydro_forces.cpp:280
 };
 
-// just enough of an Eigen-like dynamic matrix / vector for ChLoadAddedMass
+// just enough of an Eigen-like dynamic matrix / vector for ChLoadAddedMass (in Chrono both are Eigen::Matrix types: the members
+// below are Eigen's API, used by the reference at src/chloadaddedmass.cpp:16-20,37,48 -- setZero, block, rows, size -- and, for
+// element access and raw storage, by the binding: operator(), data(), cols())
 template <class T = double>
-class ChMatrixDynamic {
+class ChMatrixDynamic {  // ref: include/hydroc/chloadaddedmass.h:86
   public:
     struct Block {
         ChMatrixDynamic& m;
@@ -65,7 +69,7 @@ class ChMatrixDynamic {
 };
 
 template <class T = double>
-class ChVectorDynamic {
+class ChVectorDynamic {  // ref: include/hydroc/chloadaddedmass.h:82
   public:
     ChVectorDynamic() = default;
     explicit ChVectorDynamic(long n) : d_(n, T(0)) {}
@@ -79,7 +83,7 @@ class ChVectorDynamic {
     std::vector<T> d_;
 };
 
-class ChState {};
-class ChStateDelta {};
+class ChState {};       // ref: include/hydroc/chloadaddedmass.h:54
+class ChStateDelta {};  // ref: include/hydroc/chloadaddedmass.h:55
 
 }  // namespace chrono

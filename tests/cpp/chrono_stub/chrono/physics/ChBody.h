@@ -1,23 +1,23 @@
-// TEST INFRASTRUCTURE ONLY (see chrono/core/ChStubTypes.h).
+// TEST INFRASTRUCTURE ONLY (see chrono/core/ChStubTypes.h).  Every declaration cites the reference line that uses it.
 #pragma once
 #include "chrono/physics/ChForce.h"
 #include "chrono/physics/ChLoad.h"
 #include "chrono/physics/ChSystem.h"
 namespace chrono {
-class ChBody : public ChLoadable {
+class ChBody : public ChLoadable {  // ref: include/hydroc/hydro_forces.h:104
   public:
-    void SetName(const std::string& n) { name_ = n; }
-    void SetPos(const ChVector3d& p) { pos = p; }
-    void SetMass(double m) { mass = m; }
-    double GetMass() const { return mass; }
-    const std::string& GetName() const { return name_; }
-    double GetChTime() const { return system_ ? system_->time : 0.0; }
-    ChVector3d GetPos() const { return pos; }
-    ChQuaterniond GetRot() const { return rot; }
-    ChVector3d GetPosDt() const { return pos_dt; }
-    ChVector3d GetAngVelParent() const { return angvel; }
-    void AddForce(std::shared_ptr<ChForce> f) { forces.push_back(std::move(f)); }
-    ChSystem* GetSystem() const { return system_; }
+    void SetName(const std::string& n) { name_ = n; }   // ref: demos/sphere/demo_sphere_reg_waves.cpp:98 (driver)
+    void SetPos(const ChVector3d& p) { pos = p; }       // ref: demos/sphere/demo_sphere_reg_waves.cpp:73 (driver)
+    void SetMass(double m) { mass = m; }                // ref: demos/sphere/demo_sphere_reg_waves.cpp:100 (driver)
+    const std::string& GetName() const { return name_; }                 // ref: src/hydro_forces.cpp:106
+    double GetChTime() const { return system_ ? system_->time : 0.0; }   // ref: src/hydro_forces.cpp:550
+    ChVector3d GetPos() const { return pos; }                            // ref: src/hydro_forces.cpp:279
+    ChQuaterniond GetRot() const { return rot; }                         // ref: src/hydro_forces.cpp:280
+    ChVector3d GetPosDt() const { return pos_dt; }                       // ref: src/hydro_forces.cpp:567
+    ChVector3d GetAngVelParent() const { return angvel; }                // ref: src/hydro_forces.cpp:568
+    void AddForce(std::shared_ptr<ChForce> f) { forces.push_back(std::move(f)); }  // ref: src/hydro_forces.cpp:166
+    ChSystem* GetSystem() const { return system_; }                      // ref: src/hydro_forces.cpp:231
+    // stub-only state (set and read by the tests)
     ChVector3d pos, pos_dt, angvel;
     ChQuaterniond rot;
     std::vector<std::shared_ptr<ChForce>> forces;

@@ -96,9 +96,16 @@ int main(int argc, char** argv) {
             w(i) = 0.1 * (i + 1) - 0.7;
             R(i) = 1.0 + 0.01 * i;
         }
+        ChVectorDynamic<> R_host = R;
+        load->SetHostProductLimit(0);  // the product of every shard on its GPU (hc_added_mass_mv_multi), whatever the size
         load->LoadIntLoadResidual_Mv(R, w, 0.5);
         std::printf("MV");
         for (long i = 0; i < n_sys; ++i) std::printf(" %.17g", R(i));
+        std::printf("\n");
+        load->SetHostProductLimit(hydroc_amd::ChLoadAddedMass::kHostProductMaxDofs);  // the default: small systems multiply on the host copy
+        load->LoadIntLoadResidual_Mv(R_host, w, 0.5);
+        std::printf("MVHOST");
+        for (long i = 0; i < n_sys; ++i) std::printf(" %.17g", R_host(i));
         std::printf("\n");
         // per shard: look-ahead passes, scatter launches, AQL dispatches, HIP launches (how the kernels reached the GPU)
         for (hc_ctx* c : hydro.contexts()) {

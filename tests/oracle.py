@@ -244,6 +244,22 @@ class Oracle:
 
 
 # ---- free functions (restated third-party arithmetic) ----
+def dense_mv_seconds(M, w, c, reps):
+    """Seconds per product of the oracle's `R += c * M * w` loop (src/chloadaddedmass.cpp:55-70) on an arbitrary D x D matrix."""
+    import time
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    D = w.size
+    R = np.zeros(D)
+    L = lib()
+    L.orc_dense_mv.restype = None
+    L.orc_dense_mv.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
+    L.orc_dense_mv(M.ctypes.data, D, w.ctypes.data, float(c), R.ctypes.data, max(1, reps // 10))  # warm
+    a = time.perf_counter()
+    L.orc_dense_mv(M.ctypes.data, D, w.ctypes.data, float(c), R.ctypes.data, reps)
+    return (time.perf_counter() - a) / reps, R
+
+
 def linspaced(n, lo, hi):
     out = np.empty(n)
     lib().orc_linspaced(C.c_int(n), C.c_double(lo), C.c_double(hi), _p(out))

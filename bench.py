@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--python-loop", action="store_true", help="N = 1: time hc_step calls issued one by one from the Python interpreter (rounds 1-4a) "
                                                              "instead of the library's own loop hc_step_many")
     ap.add_argument("--no-c4-share", action="store_true", help="skip the c4_rank_share secondary (one C4/8 shard on this GPU)")
+    ap.add_argument("--stub-context", action="store_true", help="TEST ONLY (tests/test_parallel_gloo.py): run the N > 1 control flow on CPU over gloo with "
+                    "tests/stub_context.StubShard in place of the GPU contexts -- no physics, no timings worth reading")
     ap.add_argument("--no-small-configs", action="store_true", help="skip the c2_two_body / c5_one_body_2048 / added_mass_mv secondaries (each beside its CPU figure)")
     ap.add_argument("--no-c4-one-gpu", action="store_true", help="skip the c4_one_gpu secondary (the whole 512-body array, 77 GB of K, on this GPU)")
     ap.add_argument("--exchange", choices=["host", "rccl"], default="host",
@@ -252,76 +254,84 @@ def run_group_sync(N, G, devices, sdt, lookahead, warm, steps, motion=None):
 
 def c4_rank_share(sdt, lookahead):
     """What ONE rank of C4/8 does, on this GPU: the rows of bodies [0, 64) of the coupled 512-body array (K slice 9.66 GB),
-    synchronous hc_step.  A driver-run figure for multi-GPU readiness while no 8-GPU node is available."""
+    synchronous hc_step.  A driver-run figure for multi-GPU readiness while no 8-GPU node is available.  ms_per_step is measured
+    under the library's DEFAULT pass schedule (adaptive; for a wide system that is "one block ahead" at every caller gap) after a
+    run-in of three blocks -- the first block under a new schedule runs two passes, its own and the next one's -- and each pinned
+    schedule follows, back to back and with 300 us of host work between the calls."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
-    N, warm, steps = N_BODIES_C4, 40, 128
+    N, warm, steps = N_BODIES_C4, 104, 256
     n_gap, n_in, gap, n_prof = 96, 72, 300e-6, 96  # the gap loops and the profiled stretch below
     motion = PrescribedMotion(N, np.zeros((N, 3)), seed=20251031)
     nhist = int(np.ceil(S_RIRF * DT / sdt)) + 5
     t_hist = T0 - sdt * np.arange(1, nhist + 1)
     v_hist = np.stack([motion.velocity6(t) for t in t_hist])
-    n_all = warm + steps + n_prof + 3 * (n_gap + n_in)
+    n_all = warm + steps + n_prof + 3 * (n_gap + n_in) + 2 * (n_in + steps)
     gpu = make_shard(N, 0, N // 8, 0, sdt, T0 + (n_all + 8) * sdt + 5.0, lookahead, t_hist, v_hist)
     times = [T0 + k * sdt for k in range(n_all)]
     states = [motion.state(t) for t in times]
-    for k in range(warm):
-        gpu.step(times[k], *states[k])
-    per = []
-    for k in range(warm, warm + steps):
-        a = time.perf_counter()
-        gpu.step(times[k], *states[k])
-        per.append(time.perf_counter() - a)
-    per = np.array(per)
+    pos = [0]
+
+    def back_to_back(skip, n):
+        lat = np.zeros(n)
+        for i in range(skip + n):
+            k = pos[0] + i
+            a = time.perf_counter()
+            gpu.step(times[k], *states[k])
+            if i >= skip:
+                lat[i - skip] = time.perf_counter() - a
+        pos[0] += skip + n
+        return lat
+    per = back_to_back(warm, steps)
+    p_def = gpu.profile()
     # the per-kernel figures come from a stretch of their own with the library's kernel timing on (it costs the loop a few us per step)
     gpu.enable_profiling(1)
     gpu.reset_profile()
-    for k in range(warm + steps, warm + steps + n_prof):
-        gpu.step(times[k], *states[k])
+    back_to_back(0, n_prof)
     p = gpu.profile()
+    gpu.enable_profiling(False)
     pass_s = p["block_kernel_seconds"] / max(1, p["block_kernel_launches"])
     out = {"workload": f"rows of bodies [0, {N // 8}) of the coupled {N}-body array (D_local = {gpu.D_local}, D = {6 * N}, K slice "
-                       f"{p['conv_kernel_bytes'] / 1e9:.2f} GB), synchronous hc_step through the Python wrapper, {steps} steps",
-           "pass_schedule": "one block ahead, on the pass lane beside the steps (the library's default for wide systems)" if p["ahead_blocks"] > 0 else "at block start",
-           "pass_schedule_note": "the default is chosen for callers that do their own work between two force evaluations (every Chrono loop): see "
-                                 "chrono_like_loop below (300 us of host work: no step waits for a pass).  Back to back, as ms_per_step is measured, the GPU is "
-                                 "busy throughout and the schedule has nothing to hide the pass behind: compare back_to_back_pass_at_block_start",
+                       f"{p['conv_kernel_bytes'] / 1e9:.2f} GB), synchronous hc_step through the Python wrapper, {steps} steps after {warm}",
+           "pass_schedule": "adaptive (the library's default): " + ("one block ahead, on the pass lane beside the steps" if p["ahead_blocks"] > 0 else "at block start"),
+           "schedule_answers": {"one_block_ahead": int(p_def["schedule_blocks_ahead"]), "at_block_start": int(p_def["schedule_blocks_at_start"])},
            "ms_per_step": float(per.mean()) * 1e3, "median_ms_per_step": float(np.median(per)) * 1e3, "max_ms_per_step": float(per.max()) * 1e3,
            "pass_us": pass_s * 1e6, "pass_launches": int(p["block_kernel_launches"]),
            "pass_frac_of_hbm_peak": p["block_kernel_bytes_once"] / pass_s / 1e9 / HBM_PEAK_GBS if pass_s > 0 else None,
+           "pass_frac_note": "under \"one block ahead\" a launch is one slice of the pass, on 224 of the 256 CUs, sharing HBM with the step path's kernels: "
+                             "its own rate is not the figure of merit there, the wall time per step is (compare back_to_back_pass_at_block_start)",
            "per_step_us": {"pass": p["block_kernel_seconds"] / n_prof * 1e6, "short_passes": p["mini_pass_seconds"] / n_prof * 1e6,
                            "scatter": p["scatter_kernel_seconds"] / n_prof * 1e6, "step_kernels": p["step_kernel_seconds"] / n_prof * 1e6}}
     out.update(dispatch_info([gpu]))
-    # a caller that leaves the GPU idle between two force evaluations (300 us of host work: a busy wait), under both pass schedules
-    gpu.enable_profiling(False)
+    # back to back with each schedule pinned (same run-in)
+    for name, sched in (("back_to_back_pass_at_block_start", 0), ("back_to_back_pass_one_block_ahead", 1)):
+        gpu.set_pass_schedule(sched)
+        lat = back_to_back(n_in, steps)
+        out[name] = {"ms_per_step": float(lat.mean()) * 1e3, "median_ms_per_step": float(np.median(lat)) * 1e3, "max_ms_per_step": float(lat.max()) * 1e3, "steps": steps}
 
-    def gap_loop(k0, n_skip, n):
+    # a caller that leaves the GPU idle between two force evaluations (300 us of host work: a busy wait): default and pinned schedules
+    def gap_loop(n_skip, n):
         lat = np.zeros(n)
         for i in range(n_skip + n):
+            k = pos[0] + i
             a = time.perf_counter()
-            gpu.step(times[k0 + i], *states[k0 + i])
+            gpu.step(times[k], *states[k])
             b = time.perf_counter()
             if i >= n_skip:
                 lat[i - n_skip] = b - a
             while time.perf_counter() - b < gap:
                 pass
+        pos[0] += n_skip + n
         return {"mean_step_us": float(lat.mean()) * 1e6, "median_step_us": float(np.median(lat)) * 1e6,
                 "p90_step_us": float(np.percentile(lat, 90)) * 1e6, "max_step_us": float(lat.max()) * 1e6}
-    k0 = warm + steps + n_prof
     loops = {"host_work_between_calls_us": gap * 1e6, "steps": n_gap}
+    gpu.set_pass_schedule(-1)
+    loops["adaptive_default"] = gap_loop(n_in, n_gap)
     gpu.set_pass_schedule(0)
-    loops["pass_at_block_start"] = gap_loop(k0, n_in, n_gap)
+    loops["pass_at_block_start"] = gap_loop(n_in, n_gap)
     gpu.set_pass_schedule(1)
-    loops["pass_one_block_ahead"] = gap_loop(k0 + n_in + n_gap, n_in, n_gap)
-    loops["pass_one_block_ahead"]["blocks_without_a_pass_of_their_own"] = int(gpu.profile()["ahead_blocks"])
-    # ... and back to back under the schedule the default is not
-    gpu.set_pass_schedule(0)
-    lat0 = []
-    for i in range(n_in + n_gap):
-        a = time.perf_counter()
-        gpu.step(times[k0 + 2 * (n_in + n_gap) + i], *states[k0 + 2 * (n_in + n_gap) + i])
-        if i >= n_in:
-            lat0.append(time.perf_counter() - a)
-    out["back_to_back_pass_at_block_start"] = {"ms_per_step": float(np.mean(lat0)) * 1e3, "max_ms_per_step": float(np.max(lat0)) * 1e3, "steps": n_gap}
+    a0 = int(gpu.profile()["ahead_blocks"])
+    loops["pass_one_block_ahead"] = gap_loop(n_in, n_gap)
+    loops["pass_one_block_ahead"]["blocks_without_a_pass_of_their_own"] = int(gpu.profile()["ahead_blocks"]) - a0
     out["chrono_like_loop"] = loops
     gpu.close()
     return out
@@ -391,7 +401,7 @@ def small_system(name, case, poses, waves_kw, sdt, nsteps, what):
            "gpu_vs_cpu": {"vs_faithful_one_thread": sweep[1] / float(lat.mean()), "vs_faithful_best": sweep[best] / float(lat.mean()),
                           "vs_flat_best": min(flat.values()) / float(lat.mean())},
            "parity_max_rel_err_vs_oracle": max_rel_err(forces[:n_chk], np.stack(f_orc)), "parity_steps": n_chk,
-           "lookahead_blocks_used": int(p["block_kernel_launches"]) > 0}
+           "aql_dispatches": int(p["direct_dispatches"]), "hip_launches": int(p["hip_launches"])}
     out.update(dispatch_info([gpu]))
     gpu.close()
     return out
@@ -559,10 +569,19 @@ def main():
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     from hydrochrono_amd.synthetic import many_body_case, rest_positions
 
-    if not torch.cuda.is_available():
+    stub = bool(args.stub_context)
+    if stub:
+        # the N > 1 control flow without a GPU: CPU tensors, gloo, tests/stub_context.StubShard instead of the library's contexts
+        if world < 2 or not strong:
+            sys.exit("--stub-context is the CPU rehearsal of the multi-rank (--scaling strong) flow only")
+        from stub_context import StubShard
+        HydroForces = StubShard  # noqa: N806
+        args.no_secondary = False
+    elif not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hydro-force path has no CPU fallback")
     sdt = args.step_dt
-    ndev = torch.cuda.device_count()
+    ndev = 0 if stub else torch.cuda.device_count()
+    cuda_sync = (lambda: None) if stub else torch.cuda.synchronize
 
     if single:
         # ---- ONE process, G contexts, hc_step_multi: the multi-GPU path of a Chrono host through the C ABI ----
@@ -592,11 +611,12 @@ def main():
 
     # HC_BENCH_SHARE_GPU=1 (functional test of the N > 1 code path on a one-GPU box): all ranks use device 0 and the
     # force all-gather goes over gloo instead of RCCL.  Never used for reported numbers.
-    share_gpu = os.environ.get("HC_BENCH_SHARE_GPU") == "1"
-    if share_gpu:
+    share_gpu = os.environ.get("HC_BENCH_SHARE_GPU") == "1" or stub
+    if share_gpu and not stub:
         local_rank = 0
         os.environ["HC_DEVICE_SHARED"] = "1"  # the library: other processes hold contexts on this device too (no queue parking, no pass lane)
-    torch.cuda.set_device(local_rank)
+    if not stub:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
@@ -636,7 +656,7 @@ def main():
     pre = align + args.warmup
     total = pre + args.steps
     n_py = 128 if (n_steady > 0 and not args.python_loop) else 0
-    n_all = total + n_steady + n_py + ((4 * 128 + 72 + 3) if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
+    n_all = total + n_steady + n_py + ((3 * (72 + 128) + 3 * 128 + 3) if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
     duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
     gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
@@ -654,7 +674,7 @@ def main():
     forces = np.zeros((n_all, D_local))
     n3 = 3 * N
     # raw entry point: integer addresses straight through (the timed loop is the C-ABI call and nothing else)
-    hc_step = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(
+    hc_step = None if stub else C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(
         ("hc_step", capi.load()))
     ctx = gpu.ctx
     sp = [states.ctypes.data + k * states.strides[0] for k in range(n_all)]
@@ -664,8 +684,10 @@ def main():
     # An explicit stream for everything torch enqueues (copies, the RCCL all-gather) and for hc_step_device: the legacy default
     # stream has handle 0, which hc_step_device reads as "the context's own non-blocking stream" -- torch work would not be
     # ordered against the step kernels there.
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
+    stream = None if stub else torch.cuda.Stream()
+    if stream is not None:
+        torch.cuda.set_stream(stream)
+    stream_handle = stream.cuda_stream if stream is not None else 0
     hx = None
     n_other = 0  # steps of the exchange mode that is NOT `value`, run after the timed region as a secondary
     if exchange is not None:
@@ -673,7 +695,7 @@ def main():
         n_other = 0 if args.no_secondary else 16 + args.steps
         n_dev = total if args.exchange == "rccl" else n_other           # steps that go through the device path
         k_dev0 = 0 if args.exchange == "rccl" else total
-        d_states = torch.tensor(states[k_dev0:k_dev0 + n_dev], device="cuda")
+        d_states = torch.tensor(states[k_dev0:k_dev0 + n_dev], device="cpu" if stub else "cuda")
         state_ptrs = {k_dev0 + k: d_states.data_ptr() + k * d_states.stride(0) * 8 for k in range(n_dev)}
         # host-gather steps land in host memory (where the integrator wants them); the RCCL path gathers on the device
         gathered = torch.zeros(total + n_other, 6 * N, dtype=torch.float64, device="cpu" if (share_gpu or args.exchange == "host") else "cuda")
@@ -681,16 +703,19 @@ def main():
         g_dev = torch.zeros(n_dev, 6 * N, dtype=torch.float64, device="cpu" if share_gpu else "cuda")  # rows [k - k_dev0] of the device path
         # this rank's rows as the kernel left them: the step kernel writes them here and the all-gather sends them from here (no
         # staging copy on the stream between the two)
-        own_rows = torch.zeros(total + n_other, exchange.max_rows, dtype=torch.float64, device="cuda")
+        own_rows = torch.zeros(total + n_other, exchange.max_rows, dtype=torch.float64, device="cpu" if stub else "cuda")
         own_ptrs = [own_rows.data_ptr() + k * own_rows.stride(0) * 8 for k in range(total + n_other)]
         own_host = np.zeros((total + n_other, D_local))
         direct_gather = exchange.even and not share_gpu  # equal shards: the collective writes the step's row of g_dev itself
         hx = HostExchange(gpu, N, world, rank, tag=f"hc_bench_{os.environ.get('MASTER_PORT', '0')}")
         dist.barrier()
         hx.attach()
-        hc_begin = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(("hc_step_begin", capi.load()))
-        hc_end = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)(("hc_step_end", capi.load()))
-        torch.cuda.synchronize()
+        if stub:
+            hc_begin, hc_end = gpu.begin_raw, gpu.end_raw
+        else:
+            hc_begin = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(("hc_step_begin", capi.load()))
+            hc_end = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)(("hc_step_end", capi.load()))
+        cuda_sync()
 
     def run_sync_host(k0, k1):
         """Coupled array over several ranks, host gather: every rank hands its shard's step to its GPU (hc_step_begin: state through
@@ -717,10 +742,11 @@ def main():
         pc = time.perf_counter
         for k in range(k0, k1):
             a = pc()
-            gpu.step_device(times[k], state_ptrs[k], own_ptrs[k], stream.cuda_stream)
+            gpu.step_device(times[k], state_ptrs[k], own_ptrs[k], stream_handle)
             row = g_dev[k - k_dev0]
-            if share_gpu:  # functional mode on one GPU: gloo moves the rows
-                stream.synchronize()
+            if share_gpu:  # functional mode on one GPU (or none): gloo moves the rows
+                if stream is not None:
+                    stream.synchronize()
                 row.copy_(exchange.gather(own_rows[k, : exchange.rows].cpu()))
             elif direct_gather:
                 dist.all_gather_into_tensor(row, own_rows[k], group=exchange.group)
@@ -756,14 +782,15 @@ def main():
     gpu.enable_profiling(args.profile_stride)
     gpu.reset_profile()
     run_sync(0, pre)
-    torch.cuda.synchronize()
+    cuda_sync()
     prof_pre = gpu.profile()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    cuda_sync()
     t_start = time.perf_counter()
     run_sync(pre, total)
-    torch.cuda.synchronize()
+    cuda_sync()
+    elapsed_own = time.perf_counter() - t_start  # this rank's own time, before it waits for the slowest
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
@@ -784,7 +811,7 @@ def main():
         if args.exchange == "host":
             own_ok = bool(np.array_equal(gathered_np[:total, 6 * b0_:6 * b1_], own_host[:total]))
         else:
-            own_ok = bool(torch.equal(gathered[:total, 6 * b0_:6 * b1_].to("cuda"), own_rows[:total, : exchange.rows]))
+            own_ok = bool(torch.equal(gathered[:total, 6 * b0_:6 * b1_].to(own_rows.device), own_rows[:total, : exchange.rows]))
         dev_ = "cpu" if share_gpu else "cuda"
         bits = gathered[:total].contiguous().view(torch.int64).to(dev_)
         csum = (bits & 0xFFFFFFFF).sum(dim=1) + (bits >> 32).sum(dim=1)  # per-step checksum, exact in int64
@@ -795,6 +822,21 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         exchange_ok = {"own_rows_bitwise_on_every_rank": bool(flag.item() == 1), "all_ranks_hold_the_same_vectors": bool(torch.equal(lo, hi)),
                        "steps_checked": int(total)}
+
+    # ---- N > 1: what every rank saw, so that ONE run on a multi-GPU node yields the diagnosis (which rank is slow, and in which kernel) ----
+    per_rank = None
+    if world > 1:
+        mine = per_step[pre:total] * 1e3
+        nst = max(1, args.steps)
+        me = {"rank": rank, "device": (-1 if stub else local_rank), "rows": int(D_local), "ms_per_step_own_loop": elapsed_own / nst * 1e3,
+              "median_ms_per_step": float(np.median(mine)), "p90_ms_per_step": float(np.percentile(mine, 90)), "max_ms_per_step": float(mine.max()),
+              "kernel_us_per_step": {"pass": prof["block_kernel_seconds"] / nst * 1e6, "short_passes": prof["mini_pass_seconds"] / nst * 1e6,
+                                     "scatter": prof["scatter_kernel_seconds"] / nst * 1e6, "step_kernels": prof["step_kernel_seconds"] / nst * 1e6,
+                                     "note": "the per-step launches are sampled (--profile-stride), every pass is timed"},
+              "passes_in_timed_region": int(prof["block_kernel_launches"]), "blocks_with_rows_made_ahead": int(prof["ahead_blocks"]),
+              "aql_dispatches": int(prof["direct_dispatches"]), "hip_launches": int(prof["hip_launches"])}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, me)
 
     # ---- secondary figures (not `value`) ----
     steady = pipelined = plain = None
@@ -850,22 +892,34 @@ def main():
                     pass
             return {"mean_hc_step_us": float(lat_.mean()) * 1e6, "median_hc_step_us": float(np.median(lat_)) * 1e6,
                     "p90_hc_step_us": float(np.percentile(lat_, 90)) * 1e6, "max_hc_step_us": float(lat_.max()) * 1e6}
-        chrono_like = {"steps": n_cl, "host_work_between_calls_us": 100.0, **gap_loop(k_next, 0, 100e-6),
+        # Under the library's DEFAULT schedule -- adaptive: the rule sees the gaps of a block and puts the next pass one block ahead
+        # (run-in: the boundary step, the block whose gaps are counted, the first block made ahead) ...
+        p0 = gpu.profile()
+        chrono_like = {"steps": n_cl, "host_work_between_calls_us": 100.0, "pass_schedule": "adaptive (the library's default, hc_set_pass_schedule(ctx, -1, 0))",
+                       **gap_loop(k_next, n_in, 100e-6),
                        "note": "synchronous hc_step with 100 us of host work between calls: the look-ahead pass and the scatter run while the host is away"}
+        k_next += n_in + n_cl
+        short_gap = {"host_work_between_calls_us": 30.0, "adaptive_default": gap_loop(k_next, 0, 30e-6)}
         k_next += n_cl
-        short_gap = {"host_work_between_calls_us": 30.0, "pass_at_block_start": gap_loop(k_next, 0, 30e-6)}
+        p1 = gpu.profile()
+        chrono_like["schedule_answers"] = {"one_block_ahead": int(p1["schedule_blocks_ahead"] - p0["schedule_blocks_ahead"]),
+                                           "at_block_start": int(p1["schedule_blocks_at_start"] - p0["schedule_blocks_at_start"]),
+                                           "blocks_that_started_with_rows_made_ahead": int(p1["ahead_blocks"] - p0["ahead_blocks"])}
+        # ... and with each schedule pinned
+        gpu.set_pass_schedule(0)
+        chrono_like["pass_at_block_start"] = {"steps": n_cl, **gap_loop(k_next, n_in, 100e-6), "note": "hc_set_pass_schedule(ctx, 0, 0)"}
+        k_next += n_in + n_cl
+        short_gap["pass_at_block_start"] = gap_loop(k_next, 0, 30e-6)
         k_next += n_cl
-        # the same loops under the pass schedule "one block ahead" (hc_set_pass_schedule): the pass of the next block runs beside the
-        # steps of the current one, no step waits for a whole pass
         gpu.set_pass_schedule(1)
         chrono_like["pass_one_block_ahead"] = {"steps": n_cl, **gap_loop(k_next, n_in, 100e-6),
                                                "note": "hc_set_pass_schedule(ctx, 1, 0): the pass of the next block in slices (4 at this size) on the pass lane, beside the steps of the current one"}
         k_next += n_in + n_cl
         short_gap["pass_one_block_ahead"] = gap_loop(k_next, 0, 30e-6)
         k_next += n_cl
-        chrono_like["pass_one_block_ahead"]["blocks_without_a_pass_of_their_own"] = int(gpu.profile()["ahead_blocks"])
+        chrono_like["pass_one_block_ahead"]["blocks_without_a_pass_of_their_own"] = int(gpu.profile()["ahead_blocks"] - p1["ahead_blocks"])
         chrono_like["with_30us_of_host_work"] = short_gap
-        gpu.set_pass_schedule(0)
+        gpu.set_pass_schedule(-1)
     if n_pipe > 0:
         # hc_step_device, states resident in HBM, every step enqueued without waiting for the previous one's forces.
         # Run-in (untimed): the change of pass schedule above dropped the look-ahead plan, so the next step is a PLAIN one (all of K
@@ -917,11 +971,11 @@ def main():
         run_o = run_sync_rccl if other == "rccl" else run_sync_host
         try:  # a secondary must not cost the run its line (the RCCL variant has never run with more than one rank: no multi-GPU node so far)
             run_o(total, total + 16)
-            torch.cuda.synchronize()
+            cuda_sync()
             dist.barrier()
             t_o = time.perf_counter()
             run_o(total + 16, total + n_other)
-            torch.cuda.synchronize()
+            cuda_sync()
             dist.barrier()
             t_o = time.perf_counter() - t_o
             tt = torch.tensor([t_o], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
@@ -929,6 +983,8 @@ def main():
             n_o = n_other - 16
             other_exchange = {"exchange": other, "evals_per_s": n_o / float(tt.item()), "ms_per_step": float(tt.item()) / n_o * 1e3,
                               "median_ms_per_step": float(np.median(per_step[total + 16:total + n_other])) * 1e3, "steps": n_o,
+                              "collective_backend": dist.get_backend(exchange.group), "collective_world_size": dist.get_world_size(exchange.group),
+                              "rccl_world_size": dist.get_world_size(exchange.group) if dist.get_backend(exchange.group) == "nccl" else None,
                               "note": ("hc_step_device (HIP launches on the rank's stream) + RCCL all-gather of the rows on the device + stream synchronise"
                                        if other == "rccl" else "hc_step on every rank + host gather through shared-memory result buffers")}
         except Exception as e:  # noqa: BLE001
@@ -936,7 +992,7 @@ def main():
 
     # ---- N > 1 under a launcher: the single-process C-ABI mode as a secondary, run by rank 0 while the others wait ----
     single_sec = None
-    if world > 1 and strong and not args.no_secondary:
+    if world > 1 and strong and not args.no_secondary and not stub:
         dist.barrier()
         if rank == 0:
             try:
@@ -1039,6 +1095,14 @@ def main():
             },
             "term_seconds": {k: prof[k] for k in ("hydrostatics_seconds", "radiation_seconds", "waves_seconds")},
         }
+        if per_rank is not None:
+            # one line per rank: which rank was slow, and in which kernel (the collective above is over the control plane, after the timed region)
+            out["per_rank"] = per_rank
+            own = [r["ms_per_step_own_loop"] for r in per_rank]
+            out["per_rank_ms_per_step"] = {"min": min(own), "max": max(own), "slowest_rank": int(np.argmax(own)),
+                                           "note": "each rank's own loop time / steps (before it waits for the others); `ms_per_step` is the max over ranks incl. the closing barrier"}
+        if stub:
+            out["stub_context"] = "tests/stub_context.StubShard: the multi-rank control flow on CPU over gloo, no GPU, no physics -- NOT a measurement"
         if steady is not None:
             out["steady_state"] = steady
         if python_loop is not None:

@@ -28,9 +28,7 @@ class HostExchange:
         fd = os.open(self.paths[rank], os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
         os.ftruncate(fd, self.sizes[rank])
         self._map(rank, fd)
-        rc = self.lib.hc_set_result_buffer(gpu.ctx, self.addrs[rank], self.sizes[rank])
-        if rc:
-            raise RuntimeError(self.lib.hc_last_error(gpu.ctx).decode())
+        gpu.set_result_buffer(self.addrs[rank], self.sizes[rank])
         self._wait = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_ulonglong, C.c_void_p, C.c_double)(("hc_wait_result_buffer", self.lib))
 
     def _map(self, r, fd):
@@ -45,9 +43,7 @@ class HostExchange:
                 self._map(r, os.open(self.paths[r], os.O_RDWR))
 
     def sequence(self):
-        s = C.c_ulonglong()
-        self.lib.hc_step_sequence(self.gpu.ctx, C.byref(s))
-        return s.value
+        return self.gpu.step_sequence()
 
     def gather_into(self, seq, out_addr, timeout=20.0):
         """Rows of every shard of step `seq` into the 6N doubles at out_addr (own shard first: it is the one to arrive first)."""
@@ -62,7 +58,7 @@ class HostExchange:
         return out
 
     def close(self):
-        self.lib.hc_set_result_buffer(self.gpu.ctx, None, 0)
+        self.gpu.set_result_buffer(None, 0)
         self.addrs = [0] * self.world
         for m in self.maps:
             if m is not None:

@@ -208,6 +208,17 @@ class HydroForces:
             self._chk(rc)
         return forces, seconds
 
+    def set_result_buffer(self, addr, size):
+        """hc_set_result_buffer: the tagged {value, sequence} granules of hc_step go to caller memory at `addr` (e.g. a shared-memory
+        segment other processes map, host_exchange.HostExchange); None / 0 hands the buffer back to the library."""
+        self._chk(self.lib.hc_set_result_buffer(self.ctx, addr or None, int(size)))
+
+    def step_sequence(self):
+        """hc_step_sequence: the sequence number of the step begun last (what its granules are tagged with)."""
+        s = C.c_ulonglong()
+        self.lib.hc_step_sequence(self.ctx, C.byref(s))
+        return s.value
+
     def step_device(self, t, state_ptr, out_ptr, stream_ptr=None):
         """state_ptr / out_ptr: integer device addresses (e.g. torch.Tensor.data_ptr()).
 

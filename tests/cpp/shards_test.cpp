@@ -97,12 +97,14 @@ int main(int argc, char** argv) {
             R(i) = 1.0 + 0.01 * i;
         }
         ChVectorDynamic<> R_host = R;
-        load->SetHostProductLimit(0);  // the product of every shard on its GPU (hc_added_mass_mv_multi), whatever the size
+        auto added_mass = std::dynamic_pointer_cast<hydroc_amd::ChLoadAddedMass>(load);
+        if (!added_mass) throw std::runtime_error("the registered load is not a ChLoadAddedMass");
+        added_mass->SetHostProductLimit(0);  // the product of every shard on its GPU (hc_added_mass_mv_multi), whatever the size
         load->LoadIntLoadResidual_Mv(R, w, 0.5);
         std::printf("MV");
         for (long i = 0; i < n_sys; ++i) std::printf(" %.17g", R(i));
         std::printf("\n");
-        load->SetHostProductLimit(hydroc_amd::ChLoadAddedMass::kHostProductMaxDofs);  // the default: small systems multiply on the host copy
+        added_mass->SetHostProductLimit(hydroc_amd::ChLoadAddedMass::kHostProductMaxDofs);  // the default: small systems multiply on the host copy
         load->LoadIntLoadResidual_Mv(R_host, w, 0.5);
         std::printf("MVHOST");
         for (long i = 0; i < n_sys; ++i) std::printf(" %.17g", R_host(i));

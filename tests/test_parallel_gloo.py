@@ -311,3 +311,41 @@ def test_device_path_ordering_two_ranks_one_gpu(N):
     res = dict(ret)
     assert res[0][0] and res[1][0]
     assert res[0][1] <= 1e-10
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py --gpus 8 under torch.distributed.run has never met eight ranks (the pool's boxes have one GPU): its whole N > 1 control flow
+# runs here on CPU over gloo with a stub context (tests/stub_context.py: no physics) -- rendezvous, uneven body-row shards, the
+# shared-memory result buffers and their tagged granules, host gather, the device-path all-gather as the other exchange mode,
+# the after-run exchange check, the per-rank diagnostics and the JSON line -- so that argument and buffer-shape bugs are found here.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("exchange,bodies", [("host", 44), ("rccl", 40)])
+def test_bench_multi_rank_control_flow_world8_stub(exchange, bodies):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    world = 8
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "24", "--warmup", "5",
+           "--stub-context", "--bodies", str(bodies), "--exchange", exchange]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 24 and d["scaling"] == "strong" and d["exchange"] == exchange and "stub_context" in d
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["exchange_check"] == {"own_rows_bitwise_on_every_rank": True, "all_ranks_hold_the_same_vectors": True, "steps_checked": d["exchange_check"]["steps_checked"]}
+    # every rank reported, with the rows of ITS shard (44 bodies: four shards of 6 and four of 5 bodies)
+    from hydrochrono_amd.parallel_split import body_shard
+    assert [p["rank"] for p in d["per_rank"]] == list(range(world))
+    assert [p["rows"] for p in d["per_rank"]] == [6 * (b1 - b0) for b0, b1 in (body_shard(bodies, world, r) for r in range(world))]
+    for p in d["per_rank"]:
+        assert set(p["kernel_us_per_step"]) >= {"pass", "short_passes", "scatter", "step_kernels"} and p["ms_per_step_own_loop"] > 0
+    assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"] and 0 <= d["per_rank_ms_per_step"]["slowest_rank"] < world
+    # the exchange mode that is not `value` ran on all ranks too, and says how many ranks its collective spanned
+    o = d["other_exchange_mode"]
+    assert "error" not in o, o
+    assert o["exchange"] == ("rccl" if exchange == "host" else "host") and o["collective_world_size"] == world and o["collective_backend"] == "gloo"
+    assert o["rccl_world_size"] is None  # (gloo here; on GPUs this is the RCCL communicator's size)

@@ -52,12 +52,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# rocprofv3 --kernel-trace --stats of this very command (python bench.py --gpus 1 --steps 20 --warmup 5 --no-c4-share --no-c4-one-gpu, so that
-# the pass kernel's row holds C3 launches only): roofline.frac = algorithmic_bytes_per_launch / its AverageNs / 8 TB/s
-ROOFLINE_PROFILE = ("profiles/r04/c3_driver_cmd_kernel_stats_by_grid.csv: the row of hc::conv_block_kernel<6, 4, 2, 1> on 256 workgroups (the rocprofv3 kernel "
-                    "trace of this command with --no-c4-share --no-c4-one-gpu, one row per kernel and grid size -- the same kernel on 224 workgroups is a "
-                    "slice of the chrono_like_loop secondary); recomputed in profiles/r04/roofline_recomputed.json; PMC passes behind roofline.traffic: "
-                    "profiles/r04/pmc_traffic.json")
+# rocprofv3 --kernel-trace --stats of this very command (python bench.py --gpus 1 --steps 20 --warmup 5 --no-c4-share --no-c4-one-gpu
+# --no-small-configs, so that the pass kernel's row holds C3 launches only): roofline.frac = algorithmic_bytes_per_launch / its AverageNs / 8 TB/s
+ROOFLINE_PROFILE = ("profiles/r05/c3_driver_cmd_kernel_stats_by_grid.csv: the row of hc::conv_block_kernel<6, 4, 2, 1> on 256 workgroups (the rocprofv3 kernel "
+                    "trace of this command with --no-c4-share --no-c4-one-gpu --no-small-configs, one row per kernel and grid size -- the same kernel on 224 "
+                    "workgroups is a slice of the chrono_like_loop secondary); recomputed in profiles/r05/roofline_recomputed.json; PMC passes behind "
+                    "roofline.traffic: profiles/r05/pmc_traffic.json")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 FP64_MFMA_PEAK_TF = 78.6
 
@@ -481,7 +481,7 @@ def added_mass_product():
                     "CPU: the oracle's row-times-vector loop (-O2, one thread, matrix warm in cache for D <= 384)"}
 
 
-C4_ONE_GPU_FILES = ("profiles/r04/bench_c4_1gpu.json", "profiles/r03/bench_c4_1gpu.json")
+C4_ONE_GPU_FILES = ("profiles/r05/bench_c4_1gpu.json", "profiles/r04/bench_c4_1gpu.json", "profiles/r03/bench_c4_1gpu.json")
 
 
 def c4_one_gpu_reference():
@@ -656,7 +656,7 @@ def main():
     pre = align + args.warmup
     total = pre + args.steps
     n_py = 128 if (n_steady > 0 and not args.python_loop) else 0
-    n_all = total + n_steady + n_py + ((3 * (72 + 128) + 3 * 128 + 3) if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
+    n_all = total + n_steady + n_py + ((2 * (72 + 128) + (104 + 128) + 3 * 128 + 3) if n_steady > 0 else 0) + n_pipe + n_plain + 16 + ((16 + args.steps) if world > 1 else 0)
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
     duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
     gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
@@ -875,6 +875,7 @@ def main():
         # the pass of the next block) runs meanwhile.  100 us of host work between calls (a busy wait standing in for DoStepDynamics'
         # own share; the reference's whole RM3 step takes 360 us), only the calls are timed.
         n_cl, n_in = 128, 72   # timed steps per loop; run-in after a change of schedule (plain boundary step, a block with its own pass, the first block made ahead)
+        n_in_adaptive = 104    # ... and one more block for the adaptive rule: it counts a block of gaps before it answers
         pc = time.perf_counter
 
         def gap_loop(k0, skip, work):
@@ -896,9 +897,9 @@ def main():
         # (run-in: the boundary step, the block whose gaps are counted, the first block made ahead) ...
         p0 = gpu.profile()
         chrono_like = {"steps": n_cl, "host_work_between_calls_us": 100.0, "pass_schedule": "adaptive (the library's default, hc_set_pass_schedule(ctx, -1, 0))",
-                       **gap_loop(k_next, n_in, 100e-6),
+                       **gap_loop(k_next, n_in_adaptive, 100e-6),
                        "note": "synchronous hc_step with 100 us of host work between calls: the look-ahead pass and the scatter run while the host is away"}
-        k_next += n_in + n_cl
+        k_next += n_in_adaptive + n_cl
         short_gap = {"host_work_between_calls_us": 30.0, "adaptive_default": gap_loop(k_next, 0, 30e-6)}
         k_next += n_cl
         p1 = gpu.profile()

@@ -1,5 +1,5 @@
-"""Turns the raw output of profiles/r04_final.sh (gpurun_out/r04final/) into the committed summaries under profiles/r04/.
-Usage: python profiles/collect_r04.py [gpurun_out/r04final]"""
+"""Turns the raw output of profiles/r04_final.sh / r05_final.sh (gpurun_out/r0Nfinal/) into the committed summaries under profiles/r0N/.
+Usage: python profiles/collect_r04.py [gpurun_out/r04final] [r04]"""
 import csv
 import glob
 import json
@@ -10,7 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04final")
-DST = os.path.join(ROOT, "profiles", "r04")
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r04"
+DST = os.path.join(ROOT, "profiles", ROUND)
 os.makedirs(DST, exist_ok=True)
 
 
@@ -69,7 +70,7 @@ if f32 and w32:
     t = json.load(open(tpath)) if os.path.exists(tpath) else {}
     t.update({"block32_FETCH_SIZE_KB_raw": f32["mean_KB"], "block32_WRITE_SIZE_KB": w32["mean_KB"],
               "block32_hbm_bytes_per_launch": 1024.0 * (2 * f32["mean_KB"] + w32["mean_KB"]),
-              "block32_source": "profiles/r04_final.sh -> collect_r04.py (round 4 kernels)"})
+              "block32_source": f"profiles/{ROUND}_final.sh -> collect_r04.py ({ROUND} kernels)"})
     json.dump(t, open(tpath, "w"), indent=1)
 # rocprofv3's stats file aggregates by kernel NAME; the driver command's chrono_like_loop secondary also runs the pass in slices (pass
 # schedule "one block ahead": same kernel, 224 workgroups instead of 256, a quarter of the bytes), so the name's row mixes both.  The

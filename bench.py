@@ -12,9 +12,13 @@ update costs through ComponentFunc::GetVal (src/hydro_forces.cpp:79-85,727-767):
 so nothing is pipelined across steps.  value = K / wall time of K consecutive calls, the look-ahead passes included (the
 timed region is phase-aligned so that it always contains a pass, however small K is); the median call is reported next to it.  Secondary figures in the same line: `device_pipelined` (hc_step_device with
 states resident in HBM, enqueued ahead -- an upper bound no Chrono loop can use), `plain_per_step_mode` (look-ahead off: K streamed
-from HBM every step), `steady_state` (256 more synchronous steps), `chrono_like_loop` (hc_step with 100 us of host work between calls,
-under the default pass schedule and under "one block ahead", hc_set_pass_schedule) and `c4_rank_share` (what ONE rank of C4/8 does:
-back to back under both schedules and with 300 us of host work between calls).
+from HBM every step), `steady_state` (256 more synchronous steps), `chrono_like_loop` (hc_step with 100 / 30 us of host work between
+calls under the library's default pass schedule -- adaptive, hc_set_pass_schedule(ctx, -1, 0) -- and under each pinned schedule),
+`c4_rank_share` (what ONE rank of C4/8 does: back to back and with 300 us of host work between calls, default and pinned schedules),
+`c4_one_gpu` (the whole C4 array on this GPU: the one-GPU figure of the workload the N > 1 lines shard), `c2_two_body` and
+`c5_one_body_2048` (BASELINE.json's other single-GPU configs, synthetic stand-ins, each beside the CPU oracle at one thread and at its
+best thread count) and `added_mass_mv` (hc_added_mass_mv per call at 6 ... 3072 coordinates beside the host product, and the size
+below which the C++ binding keeps the product on the host).  MEASURED.md indexes the committed figures of the round.
 
 N > 1 (default: --scaling strong --bodies 512) -- configuration C4: ONE coupled 512-body array (K = 77.3 GB FP64,
 generated in HBM by hc_synth_fill) row-sharded over the ranks (hydrochrono_amd.parallel.body_shard).  Every rank holds the
@@ -22,8 +26,10 @@ full 6N force vector ON THE HOST before the next step starts (where a Chrono int
 synchronous hc_step path on its shard and collects all shards' rows straight from the shared-memory result buffers the GPUs
 write (--exchange host, the default: SURVEY 8e "outputs -> host gather"); --exchange rccl all-gathers the rows on the device
 over RCCL instead (hc_step_device + all_gather_into_tensor + stream synchronise); the mode not chosen is reported as a
-secondary.  value = K / max-over-ranks time.  `--scaling weak` runs independent 64-body farms instead (replicas, no
-data-path collective).  `--scaling strong` also runs on one GPU (77 GB fits in 288 GB).
+secondary.  value = K / max-over-ranks time; `per_rank` lists every rank's own loop time and kernel split (pass / short passes /
+scatter / step kernels), so that one run on a multi-GPU node says which rank was slow and where.  `--scaling weak` runs independent
+64-body farms instead (replicas, no data-path collective).  `--scaling strong` also runs on one GPU (77 GB fits in 288 GB).
+`--stub-context` rehearses this whole flow on CPU over gloo with tests/stub_context.StubShard (tests only: no GPU, no physics).
 
 N > 1 in ONE process (`python bench.py --gpus N` without a launcher, or `--single-process` under one): the same coupled array
 row-sharded over N contexts of this process, one per visible GPU (all on GPU 0 when the box has fewer: a functional mode), evaluated
@@ -54,10 +60,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 # rocprofv3 --kernel-trace --stats of this very command (python bench.py --gpus 1 --steps 20 --warmup 5 --no-c4-share --no-c4-one-gpu
 # --no-small-configs, so that the pass kernel's row holds C3 launches only): roofline.frac = algorithmic_bytes_per_launch / its AverageNs / 8 TB/s
-ROOFLINE_PROFILE = ("profiles/r05/c3_driver_cmd_kernel_stats_by_grid.csv: the row of hc::conv_block_kernel<6, 4, 2, 1> on 256 workgroups (the rocprofv3 kernel "
-                    "trace of this command with --no-c4-share --no-c4-one-gpu --no-small-configs, one row per kernel and grid size -- the same kernel on 224 "
-                    "workgroups is a slice of the chrono_like_loop secondary); recomputed in profiles/r05/roofline_recomputed.json; PMC passes behind "
-                    "roofline.traffic: profiles/r05/pmc_traffic.json")
+ROOFLINE_PROFILE = ("profiles/r05/c3_driver_cmd_kernel_stats_by_grid.csv, row hc::conv_block_kernel<6, 4, 2, 1> on 256 workgroups "
+                    "(MEASURED.md: recomputing roofline.frac); PMC: profiles/r05/pmc_traffic.json")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 FP64_MFMA_PEAK_TF = 78.6
 
@@ -148,8 +152,7 @@ def cpu_baseline(case, motion, t_hist, v_hist, budget_s, step_dt, duration):
     best_flat = min(flat_sweep, key=flat_sweep.get)
     med_flat = flat_sweep[best_flat]
     info = {"value": 1.0 / med, "unit": "evals/s", "cores": best, "kind": "port", "ms_per_step": med * 1e3,
-            "sample": f"{n_more} consecutive steady-state steps of the same workload (median), reference-faithful oracle "
-                      f"-O2 -fopenmp, OMP threads = {best} (best of sweep); box has {cores} logical cores",
+            "sample": f"{n_more} steady-state steps (median), faithful oracle -O2 -fopenmp, {best} threads (best of sweep; {cores} logical cores)",
             "threads_sweep_ms": {str(th): v * 1e3 for th, v in sweep.items()},
             "single_thread_ms": single_ms,
             "optimized_port": {"value": 1.0 / med_flat, "unit": "evals/s", "cores": best_flat, "ms_per_step": med_flat * 1e3,
@@ -297,8 +300,7 @@ def c4_rank_share(sdt, lookahead):
            "ms_per_step": float(per.mean()) * 1e3, "median_ms_per_step": float(np.median(per)) * 1e3, "max_ms_per_step": float(per.max()) * 1e3,
            "pass_us": pass_s * 1e6, "pass_launches": int(p["block_kernel_launches"]),
            "pass_frac_of_hbm_peak": p["block_kernel_bytes_once"] / pass_s / 1e9 / HBM_PEAK_GBS if pass_s > 0 else None,
-           "pass_frac_note": "under \"one block ahead\" a launch is one slice of the pass, on 224 of the 256 CUs, sharing HBM with the step path's kernels: "
-                             "its own rate is not the figure of merit there, the wall time per step is (compare back_to_back_pass_at_block_start)",
+           "pass_frac_note": "one block ahead: a launch is a slice on 224 CUs beside the step kernels; judge by ms_per_step",
            "per_step_us": {"pass": p["block_kernel_seconds"] / n_prof * 1e6, "short_passes": p["mini_pass_seconds"] / n_prof * 1e6,
                            "scatter": p["scatter_kernel_seconds"] / n_prof * 1e6, "step_kernels": p["step_kernel_seconds"] / n_prof * 1e6}}
     out.update(dispatch_info([gpu]))
@@ -416,8 +418,7 @@ def c2_two_body():
     kw = dict(simulation_dt=0.01, simulation_duration=40.0, ramp_duration=5.0, wave_height=2.5, wave_period=8.0, frequency_min=0.02,
               frequency_max=0.5, nfrequencies=512, peak_enhancement_factor=3.3, seed=1)
     return small_system("c2", case, np.stack([b["cg"] for b in case["bodies"]]), kw, 0.01, 320,
-                        "C2 stand-in (SURVEY 8d; rm3.h5 is a missing blob): two coupled bodies with rm3's poses, K [2][6][12][1001] on the sphere's IRF grid "
-                        "(0..15 s @ 0.015), irregular JONSWAP Hs 2.5 / Tp 8 / gamma 3.3 / 512 components, dt 0.01 (every IRF sample a true interpolation)")
+                        "C2 stand-in (rm3.h5 is a missing blob): 2 bodies, S 1001 @ 0.015 s, JONSWAP Hs 2.5 / Tp 8 / gamma 3.3 / nf 512, dt 0.01")
 
 
 def c5_one_body_2048():
@@ -426,8 +427,7 @@ def c5_one_body_2048():
     kw = dict(simulation_dt=0.08, simulation_duration=1000.0, ramp_duration=20.0, wave_height=6.0, wave_period=10.0, frequency_min=0.01,
               frequency_max=0.6, nfrequencies=2048, peak_enhancement_factor=2.0, seed=4)
     return small_system("c5", case, [case["bodies"][0]["cg"]], kw, 0.08, 320,
-                        "C5 stand-in (SURVEY 8d; deepcwind.h5 is a missing blob): one body, dt 0.08, 1000 s, 2048 wave components (the free-surface table "
-                        "synthesised on the GPU by the direct FP64 sum; the rocFFT variant is checked in tests/test_gpu_parity.py)")
+                        "C5 stand-in (deepcwind.h5 is a missing blob): 1 body, dt 0.08, 1000 s, nf 2048 (eta table by the direct FP64 sum)")
 
 
 ADDED_MASS_HOST_MAX_DOFS = 96  # include/hydroc_amd/chloadaddedmass.h: kHostProductMaxDofs
@@ -474,11 +474,8 @@ def added_mass_product():
     return {"rows_by_D": rows, "crossover": {"host_wins_up_to_D": max([d for d in ds if rows[str(d)]["gpu_over_cpu"] >= 1.0], default=None),
                                              "gpu_wins_from_D": min(gpu_wins, default=None)},
             "binding_threshold": {"kHostProductMaxDofs": ADDED_MASS_HOST_MAX_DOFS,
-                                  "meaning": "hydroc_amd::ChLoadAddedMass::LoadIntLoadResidual_Mv keeps the product on its host copy of the matrix "
-                                             "for 6N <= this and calls hc_added_mass_mv (the GPU) above it; the C ABI entry is always the GPU"},
-            "note": "GPU: hc_added_mass_mv through a ctypes prototype with integer arguments (about 1 us of interpreter per call included), "
-                    "synchronous: w and R in through the PCIe BAR, one kernel on a queue of its own, tagged result back; "
-                    "CPU: the oracle's row-times-vector loop (-O2, one thread, matrix warm in cache for D <= 384)"}
+                                  "meaning": "the C++ binding multiplies on its host copy for 6N <= this; the C ABI entry is always the GPU"},
+            "note": "GPU: synchronous hc_added_mass_mv through ctypes (~1 us of interpreter included); CPU: the oracle's loop, -O2, one thread"}
 
 
 C4_ONE_GPU_FILES = ("profiles/r05/bench_c4_1gpu.json", "profiles/r04/bench_c4_1gpu.json", "profiles/r03/bench_c4_1gpu.json")
@@ -849,7 +846,7 @@ def main():
         ps = per_step[k_next:k_next + n_steady] * 1e3
         steady = {"steps": n_steady, "evals_per_s": n_steady / t_s, "mean_ms_per_step": t_s / n_steady * 1e3, "median_ms_per_step": float(np.median(ps)),
                   "p10_ms_per_step": float(np.percentile(ps, 10)), "p90_ms_per_step": float(np.percentile(ps, 90)),
-                  "note": "synchronous hc_step calls right after the timed region (same context, same history), passes included"}
+                  "note": "synchronous hc_step calls right after the timed region, passes included"}
         k_next += n_steady
     python_loop = None
     if n_py > 0:
@@ -865,7 +862,7 @@ def main():
         t_p = pc() - t_p
         pp = per_step[k_next:k_next + n_py] * 1e3
         python_loop = {"steps": n_py, "evals_per_s": n_py / t_p, "mean_ms_per_step": t_p / n_py * 1e3, "median_ms_per_step": float(np.median(pp)),
-                       "note": "hc_step through a ctypes prototype, one call per interpreter iteration (bench.py --python-loop makes this the timed region)"}
+                       "note": "hc_step through ctypes, one call per interpreter iteration"}
         k_next += n_py
     prof_all = gpu.profile()  # warm-up + timed region + steady-state block
     gpu.enable_profiling(False)
@@ -898,7 +895,7 @@ def main():
         p0 = gpu.profile()
         chrono_like = {"steps": n_cl, "host_work_between_calls_us": 100.0, "pass_schedule": "adaptive (the library's default, hc_set_pass_schedule(ctx, -1, 0))",
                        **gap_loop(k_next, n_in_adaptive, 100e-6),
-                       "note": "synchronous hc_step with 100 us of host work between calls: the look-ahead pass and the scatter run while the host is away"}
+                       "note": "100 us of host work (a busy wait) between synchronous hc_step calls; only the calls are timed"}
         k_next += n_in_adaptive + n_cl
         short_gap = {"host_work_between_calls_us": 30.0, "adaptive_default": gap_loop(k_next, 0, 30e-6)}
         k_next += n_cl
@@ -914,7 +911,7 @@ def main():
         k_next += n_cl
         gpu.set_pass_schedule(1)
         chrono_like["pass_one_block_ahead"] = {"steps": n_cl, **gap_loop(k_next, n_in, 100e-6),
-                                               "note": "hc_set_pass_schedule(ctx, 1, 0): the pass of the next block in slices (4 at this size) on the pass lane, beside the steps of the current one"}
+                                               "note": "hc_set_pass_schedule(ctx, 1, 0)"}
         k_next += n_in + n_cl
         short_gap["pass_one_block_ahead"] = gap_loop(k_next, 0, 30e-6)
         k_next += n_cl
@@ -940,8 +937,7 @@ def main():
         tp = time.perf_counter() - tp
         forces[k_next:k_next + n_pipe] = d_out.cpu().numpy()
         pipelined = {"evals_per_s": n_pipe / tp, "ms_per_step": tp / n_pipe * 1e3, "steps": n_pipe,
-                     "note": "hc_step_device enqueued ahead of the GPU, states and forces resident in HBM; not usable by a Chrono "
-                             "loop (its next state needs these forces on the host)"}
+                     "note": "hc_step_device enqueued ahead of the GPU (not usable by a Chrono loop)"}
         k_next += n_pipe
     if n_plain > 0:
         gpu.set_lookahead(0)
@@ -1030,8 +1026,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(f"block{units}_hbm_bytes_per_launch" if units > 1 else "hbm_bytes_per_launch")
-                traffic_src = "profiles/conv_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
-                              "gfx950 x2 read correction; not collected in this run)"
+                traffic_src = "profiles/conv_traffic.json (committed --pmc FETCH_SIZE x2 + WRITE_SIZE passes; not collected in this run)"
             except Exception:
                 traffic = None
         us = lambda sec, n: 1e6 * sec / max(1, n)  # noqa: E731
@@ -1068,8 +1063,7 @@ def main():
                               "body-row shards of one coupled array + RCCL all-gather of forces every step") if strong else
                              "one independent farm per GPU, no data-path collective") if world > 1 else "single GPU",
             },
-            "caller": ("hc_step_many: the C ABI's prescribed-motion loop -- K synchronous hc_step calls, host state in, host forces out, issued by "
-                       "compiled code like the reference's C++ callers (secondary python_loop: the same calls from the interpreter)"
+            "caller": ("hc_step_many (the C ABI's own loop of K synchronous hc_step calls)"
                        if (world == 1 and exchange is None and not args.python_loop) else "one hc_step (or begin / gather / end) per Python call"),
             "dispatch_mode": dinfo["dispatch_mode"] if (world == 1 or args.exchange == "host") else "HIP launches on the rank's stream (hc_step_device) + RCCL all-gather",
             "exchange": (args.exchange if world > 1 else None),
@@ -1088,11 +1082,8 @@ def main():
                 "scatter_kernel_us": us(prof_all["scatter_kernel_seconds"], prof_all["scatter_kernel_launches"]),
                 "fp64_TFLOPs": (2.0 * (bytes_units / 8.0) / conv_s / 1e12) if conv_s > 0 else None,
                 "fp64_frac_of_mfma_peak": (2.0 * (bytes_units / 8.0) / conv_s / 1e12 / FP64_MFMA_PEAK_TF) if conv_s > 0 else None,
-                "note": ("achieved = bytes one launch must move once (live K + Kex + staged vectors) / mean duration of every launch of the "
-                         "run's synchronous phases (warm-up, timed region, steady-state block), timed by the completion signals of the "
-                         f"library's own dispatches (HIP events when it launches through HIP); the launch serves {units} steps (SURVEY 8d "
-                         "bytes of those steps = algorithmic_bytes_of_the_units, reuse_factor x)")
-                        if units > 1 else "one launch = one step",
+                "note": (f"achieved = K-once bytes of a launch / mean duration of every pass of the run (completion signals); a launch serves {units} steps"
+                         if units > 1 else "one launch = one step"),
             },
             "term_seconds": {k: prof[k] for k in ("hydrostatics_seconds", "radiation_seconds", "waves_seconds")},
         }

@@ -4,12 +4,21 @@
 
 namespace hc {
 
-constexpr int kLookahead = 64;  // most future steps one blocked pass covers (1, 2 or 4 blocks of 16 = N dimension of v_mfma_f64_16x16x4_f64);
-                                // the shipped depths are 16 and 32, 64 is the experimental single-level form of hc_set_lookahead(ctx, 64)
+// most future steps one blocked pass covers (blocks of 16 = N dimension of v_mfma_f64_16x16x4_f64) and the IRF samples s < kScatterSamples
+// that can be targets of a scatter.  The shipped depths are 16 and 32; the tuning build (-DHC_TUNING) also holds the depth-64 pass that
+// was measured in round 5 and not taken (EXPERIMENTS.md), which needs room for 64 steps and a scatter reach of 66 samples.  The
+// capacities size the plan (reset at every block boundary on the host), the argument blocks (stored through the BAR at every
+// dispatch) and the term / partial buffers, so the release build keeps the small ones.
+#ifdef HC_TUNING
+constexpr int kLookahead      = 64;
+constexpr int kScatterSamples = 80;
+#else
+constexpr int kLookahead      = 32;
+constexpr int kScatterSamples = 64;
+#endif
 constexpr int kDepthDefault = 32;  // the look-ahead depth of a fresh context (hc_set_lookahead)
 constexpr int kNearMax        = 8;   // IRF samples a step contracts itself (own sample + a deferred one)
 constexpr int kTermMax        = 192; // term slots a step adds (scatter results; x column slices for wide systems)
-constexpr int kScatterSamples = 80;  // IRF samples s < kScatterSamples can be targets of a scatter
 constexpr int kTargets        = 3;   // later block steps one (sample, IRF sample) result can contribute to
 
 constexpr int kSubBlock       = 8;   // steps per sub-block of the two-level form (wide systems)

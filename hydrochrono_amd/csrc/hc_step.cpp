@@ -1197,6 +1197,54 @@ int hc_set_lookahead(hc_ctx* c, int steps) {
     HC_API_END(c)
 }
 
+#ifdef HC_TUNING
+// Tuning build only (profiles/pass_depth_probe.py): the pass kernel of depth 16 / 32 / 64 over this context's K, `reps` launches timed
+// with HIP events, for the predicted steps that would follow the newest history sample -- also for contexts whose step path has no
+// plan at that depth (a wide system at depth 64), so that the depth-64 pass can be measured at C4-rank size.  The context's
+// look-ahead state is dropped; call hc_set_lookahead afterwards.
+int hc_tuning_time_pass(hc_ctx* c, int depth, int reps, double* mean_us, double* bytes_once) {
+    HC_API_BEGIN(c)
+    require(c->finalized && mean_us, HC_ERR_INVALID, "bad arguments");
+    require(depth == 16 || depth == 32 || depth == 64, HC_ERR_INVALID, "depth must be 16, 32 or 64");
+    require(c->times.size() >= 2 && (c->D & 7) == 0, HC_ERR_INVALID, "needs a history of two samples and D % 8 == 0");
+    require(depth < 64 || c->ntiles % c->mt_block64 == 0, HC_ERR_INVALID, "row tiles not divisible by HC_BLOCK64_MT");
+    HC_HIP(hipDeviceSynchronize());
+    c->lookahead = depth;
+    choose_conv_config(c);
+    alloc_partials(c);
+    c->ahead.active = false;
+    auto& pl   = c->plan;
+    pl         = hc::Plan{};
+    const double t0 = c->times[0], dt = c->times[0] - c->times[1];
+    pl.dt      = dt;
+    for (int j = 0; j <= 2 * depth + 1; ++j) pl.tgrid[j] = (j == 0) ? t0 : t0 + j * dt;
+    for (int m = 1; m <= depth; ++m) {  // (the pass's share of block step m, as build_plan defines it)
+        int sc = 0;
+        while (sc < c->S && !(pl.tgrid[m] - c->tau[static_cast<size_t>(sc)] <= pl.tgrid[1])) ++sc;
+        pl.s_cut[m - 1]   = sc;
+        pl.s_defer[m - 1] = -1;
+    }
+    const PassSetup ps = make_pass(c, false, false);
+    hipEvent_t a, b;
+    HC_HIP(hipEventCreate(&a));
+    HC_HIP(hipEventCreate(&b));
+    const int mt = depth == 64 ? c->mt_block64 : c->mt_block;
+    hc::launch_conv_block(ps.b, mt, c->stream);  // warm
+    HC_HIP(hipEventRecord(a, c->stream));
+    for (int r = 0; r < std::max(1, reps); ++r) hc::launch_conv_block(ps.b, mt, c->stream);
+    HC_HIP(hipEventRecord(b, c->stream));
+    HC_HIP(hipEventSynchronize(b));
+    float ms = 0.0f;
+    HC_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *mean_us = 1e3 * ms / std::max(1, reps);
+    if (bytes_once) *bytes_once = ps.rad_once;
+    c->plan = hc::Plan{};
+    HC_API_END(c)
+}
+#endif
+
 int hc_set_pass_schedule(hc_ctx* c, int one_block_ahead, int slices) {
     HC_API_BEGIN(c)
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");

@@ -447,3 +447,34 @@ def test_wide_system_soak_two_level_vs_plain(hydro):
     assert worst <= 1e-10, worst
     p = a.profile()
     assert p["block_kernel_launches"] >= 60 and p["mini_pass_launches"] >= 150 and p["history_rewinds"] == 4, p
+
+
+@pytest.mark.parametrize("threads", ["1", "2"])
+def test_step_multi_with_fewer_worker_threads_than_contexts(threads):
+    """HC_MULTI_THREADS < n_ctx - 1: the calling thread then runs the surplus items as well as item 0, and the HIP device
+    it has current is whatever its last item set -- the device cache of the fan-out is keyed on the kind of thread, not on the item.
+    Five shard contexts, one or two workers (items 2 .. 4 or 3 .. 4 on the caller): hc_step_multi and hc_added_mass_mv_multi call
+    after call, bitwise the unsharded context.  (One device here; the CPU test tests/cpp/fanout_test.cpp pins which thread runs what.)"""
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from hydrochrono_amd import hydro\n"
+        "from hydrochrono_amd.mock_chrono import PrescribedMotion\n"
+        "from hydrochrono_amd.synthetic import many_body_case, rest_positions\n"
+        "N = 5\n"
+        "case = many_body_case(N, S=120, dt_rirf=0.01, n_exc=33, dt_exc=0.02, seed=77)\n"
+        "full, group = hydro.HydroForces.from_case(case), hydro.HydroGroup.from_case(case, 5)\n"
+        "for h in (full, group): h.add_waves_none()\n"
+        "motion = PrescribedMotion(N, rest_positions(case), seed=3)\n"
+        "w = np.linspace(-1.0, 1.0, 6 * N); R0 = np.linspace(0.5, 1.5, 6 * N)\n"
+        "for n in range(260):\n"
+        "    st = motion.state(0.01 * n)\n"
+        "    assert np.array_equal(full.step(0.01 * n, *st), group.step(0.01 * n, *st)), n\n"
+        "    if n %% 13 == 0: assert np.array_equal(full.added_mass_mv(R0, w, 0.5), group.added_mass_mv(R0, w, 0.5)), n\n"
+        "print('calls', group.shards[4].profile()['multi_calls'])\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HC_MULTI_THREADS=threads))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.strip().splitlines()[-1] == "calls 260", r.stdout[-500:]

@@ -253,6 +253,43 @@ def test_depth64_experimental_pass_against_oracle(HF, N, dt, direct, monkeypatch
     assert 560 // 64 - 2 <= p["block_kernel_launches"] <= 560 // 64 + 2 and p["scatter_kernel_launches"] >= 450, p
 
 
+def test_depth64_experimental_pass_c3_full_size_against_flat_oracle(HF, tuning_build):
+    """The depth-64 pass at the size it was measured at (profiles/r05/depth64_sweep.txt): C3 from a steady-state history, 200 steps =
+    the plain boundary step, three whole depth-64 blocks and the start of a fourth, every step against the flat CPU oracle."""
+    import bench as B
+    import oracle as orc_mod
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    case = many_body_case(64, S=B.S_RIRF, dt_rirf=B.DT, n_exc=B.N_EXC, dt_exc=B.DT, seed=20251031)
+    gpu = HF.from_case(case)
+    motion = PrescribedMotion(64, rest_positions(case), seed=20251031)
+    kw = dict(B.WAVES, simulation_dt=B.DT, simulation_duration=B.T0 + 8.0)
+    gpu.add_waves_irregular(num_bodies=64, **kw)
+    gpu.set_lookahead(64)
+    orc_mod.set_num_threads(min(64, os.cpu_count() or 1))
+    orc = load_into_oracle(case)
+    orc.add_waves_irregular(**kw)
+    nhist = B.S_RIRF + 5
+    t_hist = B.T0 - B.DT * np.arange(1, nhist + 1)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    gpu.set_history(t_hist, v_hist)
+    orc.prefill_history(t_hist, v_hist)
+    orc.flat_prepare()
+    gpu.enable_profiling(1)
+    worst = 0.0
+    for n in range(200):
+        t = B.T0 + n * B.DT
+        st = motion.state(t)
+        fg, fo = gpu.step(t, *st), orc.flat_step(t, *st)
+        e = float(np.max(np.abs(fg - fo)) / np.max(np.abs(fo)))
+        worst = max(worst, e)
+        assert e <= 1e-10, f"step {n}"
+    p = gpu.profile()
+    assert p["block_kernel_launches"] == 4 and p["conv_kernel_launches"] == 1 and p["scatter_kernel_launches"] >= 190, p
+    print(f"C3 at depth 64: worst relative error {worst:.2e} over 200 steps, {p['block_kernel_launches']} passes")
+    gpu.close()
+
+
 def test_multibody_regular_wave_phase_indexing(HF):
     """The reference indexes the regular-wave phase by DoF only (body-0 phases for every body, src/wave_types.cpp:323)."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion

@@ -1230,15 +1230,29 @@ int hc_tuning_time_pass(hc_ctx* c, int depth, int reps, double* mean_us, double*
     HC_HIP(hipEventCreate(&b));
     const int mt = depth == 64 ? c->mt_block64 : c->mt_block;
     hc::launch_conv_block(ps.b, mt, c->stream);  // warm
-    HC_HIP(hipEventRecord(a, c->stream));
-    for (int r = 0; r < std::max(1, reps); ++r) hc::launch_conv_block(ps.b, mt, c->stream);
-    HC_HIP(hipEventRecord(b, c->stream));
-    HC_HIP(hipEventSynchronize(b));
-    float ms = 0.0f;
-    HC_HIP(hipEventElapsedTime(&ms, a, b));
+    HC_HIP(hipStreamSynchronize(c->stream));
+    // every launch timed on its own, with `pause` of idle GPU in front of it (HC_TUNING_PASS_PAUSE_US, default 0 = back to back): passes
+    // that follow each other without a break run under sustained matrix-pipe + HBM load, which the chip answers with a lower clock;
+    // in the product a pass comes once per block
+    const int pause_us = env_int("HC_TUNING_PASS_PAUSE_US", 0);
+    double total_ms = 0.0;
+    for (int r = 0; r < std::max(1, reps); ++r) {
+        if (pause_us > 0) {
+            const auto t0_ = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0_).count() < pause_us) {
+            }
+        }
+        HC_HIP(hipEventRecord(a, c->stream));
+        hc::launch_conv_block(ps.b, mt, c->stream);
+        HC_HIP(hipEventRecord(b, c->stream));
+        HC_HIP(hipEventSynchronize(b));
+        float ms = 0.0f;
+        HC_HIP(hipEventElapsedTime(&ms, a, b));
+        total_ms += ms;
+    }
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
-    *mean_us = 1e3 * ms / std::max(1, reps);
+    *mean_us = 1e3 * total_ms / std::max(1, reps);
     if (bytes_once) *bytes_once = ps.rad_once;
     c->plan = hc::Plan{};
     HC_API_END(c)

@@ -1,7 +1,8 @@
 """The pass kernel alone at depth 16 / 32 / 64 (tuning build: hc_tuning_time_pass) over the K of C3 (64 bodies) and of one C4/8 rank
 (rows of 64 of 512 bodies, 9.69 GB): mean launch time by HIP events, bytes the launch moves once, the rates against the HBM and FP64 MFMA
 peaks.  HC_BLOCK64_MT / HC_BLOCK64_R select the depth-64 variant (default here: 6 / 3, the fastest of profiles/r05/depth64_sweep.txt).
-Run under rocprofv3 --kernel-trace --stats for the kernel rows."""
+HC_TUNING_PASS_PAUSE_US=<us> leaves the GPU idle for that long in front of every launch (default 0: the launches follow each other,
+i.e. sustained matrix-pipe + HBM load).  Run under rocprofv3 --kernel-trace --stats for the kernel rows."""
 import ctypes as C
 import os
 import sys

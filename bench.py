@@ -435,7 +435,7 @@ ADDED_MASS_HOST_MAX_DOFS = 96  # include/hydroc_amd/chloadaddedmass.h: kHostProd
 
 def added_mass_product():
     """hc_added_mass_mv (Chrono's LoadIntLoadResidual_Mv, src/chloadaddedmass.cpp:55-70: one Eigen `R += c M w` on the host) at
-    D = 6 / 12 / 96 / 384 / 3072: the GPU round trip per call beside the oracle's host loop -- and with it the size below which the
+    D = 6 / 12 / 96 / 192 / 288 / 384 / 3072: the GPU round trip per call beside the oracle's host loop -- and with it the size below which the
     C++ binding (include/hydroc_amd/chloadaddedmass.h) keeps the product on the host copy of the matrix it already holds."""
     import oracle as orc_mod
     from hydrochrono_amd import capi
@@ -443,7 +443,7 @@ def added_mass_product():
     lib = capi.load()
     mv = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int)(("hc_added_mass_mv", lib))
     rows = {}
-    for N in (1, 2, 16, 64, 512):
+    for N in (1, 2, 16, 32, 48, 64, 512):
         D = 6 * N
         gpu = HydroForces(N, device=0)
         gpu.synth_fill(20251031, 8, DT, 0, DT)

@@ -203,7 +203,9 @@ void enqueue_tail(hc_ctx* c) {
             pass_lane_drain(c);
         }
     }
-    if (scatter_now) {
+    static const bool skip_scatter = HC_TUNE_INT("HC_SKIP_SCATTER", 0) != 0;  // (tuning build: timing bound only -- the forces are wrong)
+    if (scatter_now && skip_scatter) {
+    } else if (scatter_now) {
         to_background();
         launch_scatter_of(c, m, bs, direct);
     } else if (block && c->plan.sub > 0 && m < c->lookahead && m % c->plan.sub == 0 && c->plan.mini_s_hi[m] >= 0) {

@@ -250,7 +250,8 @@ int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
  * costs speed, never accuracy.  A step whose time is accepted is evaluated on the PREDICTED time grid (t0 + m*dt), so its
  * interpolation weights differ from those of the caller's t by at most that tolerance / dt relative (1e-15 .. 1e-12 observed;
  * contract 1e-6).  Wide systems (6N >= 1024) use a two-level form: sub-blocks of 8 steps with a short pass over the head of K
- * after each.  steps = 0 disables it (every step streams K), 1..16 selects blocks of 16, more blocks of 32. */
+ * after each.  steps = 0 disables it (every step streams K), 1..16 selects blocks of 16, more blocks of 32 (a depth-64 pass exists in
+ * the tuning build only: measured and not taken, EXPERIMENTS.md). */
 int hc_set_lookahead(hc_ctx* ctx, int steps);
 /* When the pass of a look-ahead block runs.  one_block_ahead < 0 (the default of every context): ADAPTIVE -- the library counts,
  * per block, how many of the gaps between the caller's synchronous steps (end of one hc_step / hc_step_multi to the begin of the

@@ -14,6 +14,11 @@ os.makedirs(DST, exist_ok=True)
 for pat in ("*.txt", "*.csv", "pass_pmc_depth*.json", "pmc_*.json", "bench_default*.json", "bench_driver*.json", "roofline*.json"):
     for f in glob.glob(os.path.join(SRC, pat)):
         shutil.copy(f, DST)
+# functional multi-context / multi-rank runs on the ONE GPU (profiles/r05_multi_functional.sh): the JSON line only
+for f in glob.glob(os.path.join(SRC, "bench_c4_*_one_gpu.json")) + glob.glob(os.path.join(SRC, "bench_c4_*share_gpu*.json")):
+    lines = [ln for ln in open(f) if ln.startswith("{")]
+    if lines:
+        open(os.path.join(DST, os.path.basename(f)), "w").write(lines[-1])
 peak = os.path.join(ROOT, "gpurun_out", "r05_mfma_f64_peak.txt")
 if os.path.exists(peak):
     shutil.copy(peak, os.path.join(DST, "mfma_f64_peak.txt"))

@@ -918,6 +918,159 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
     }
 }
 
+#ifdef HC_TUNING
+// Depth 64, second form (tuning build; EXPERIMENTS.md): the first form above issues the MT + 2*NB loads of a fragment and their address
+// arithmetic in one run behind the fragment's 8*MT MFMAs, and a wave alone on its SIMD issues in order -- the counters of profiles/r05 show
+// that run (about 600 cycles per fragment of 3072 matrix-pipe cycles) exposed, not hidden: only what is issued within the 64 cycles of
+// the last MFMA runs in its shadow.  Here the loads of the fragment NS - 1 ahead go out one at a time BETWEEN the MFMAs of the fragment
+// being consumed (one load behind every MT/2 MFMAs), into a register slot that is not being read (NS slots, NS - 1 fragments in flight).
+template <int MT, int NS, int NB>
+__device__ __forceinline__ void block_rad_stream_il(const BlockArgs& a, const int chunk, const int grp, double* red, double* t_wo, double* t_wn,
+                                                    int* t_oo, int* t_on) {
+    constexpr int L = 16 * NB;
+    static_assert(MT % 2 == 0 && MT + 2 * NB <= 4 * NB, "one load behind every half group of MFMAs");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kk = lane >> 4, jstep = lane & 15;
+    const int D = a.hist.D;
+    const int gp0 = chunk * a.chunk_gp;
+    const int gp1 = min((a.F + 7) >> 3, gp0 + a.chunk_gp);
+    const int s0  = (gp0 * 8) / D;
+    const int ns  = (min(a.F, gp1 * 8) - 1) / D - s0 + 1;
+    const int s_live = a.F / D;
+    const int Hc     = a.hist.HcapT;
+
+    dvec4 acc[NB][MT];
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[tb][m] = dvec4{0.0, 0.0, 0.0, 0.0};
+    const char* __restrict__ kb    = reinterpret_cast<const char*>(a.K.base) + ((size_t)(grp * MT) * a.K.ngp) * 1024;
+    const size_t tile_bytes        = (size_t)a.K.ngp * 1024;
+    const unsigned lane16          = (unsigned)lane * 16u;
+    const char* __restrict__ ringb = reinterpret_cast<const char*>(a.hist.ring_vT);
+    const unsigned col_bytes       = (unsigned)Hc * 8u;
+
+    dvec2 kv[NS][MT];
+    dvec2u von[NS][2][NB];
+
+    build_block_table<L, true>(a, chunk, s0, ns, s_live, t_wo, t_wn, t_oo, t_on);
+    __syncthreads();
+
+    // ---- issue side ----
+    int gp_i = gp0 + wave;
+    int s_i = (gp_i * 8) / D, cb_i = gp_i * 8 - s_i * D;
+    unsigned cby = (unsigned)(cb_i + kk) * col_bytes;
+    unsigned boo[NB];
+    auto load_offsets = [&]() {
+        const int ks  = s_i - s0;
+        const bool in = ks >= 0 && ks < ns;
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) boo[tb] = (unsigned)t_oo[(in ? ks : 0) * L + 16 * tb + jstep];
+    };
+    load_offsets();
+    // load number k of the fragment at the issue-side trackers: K tiles first (the long latency), then the gathers
+    auto issue_part = [&](const int slot, const int k, const char* __restrict__ kg) {
+        if (k < MT) kv[slot][k] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kg + k * tile_bytes + lane16));
+        else if (k < MT + 2 * NB) {
+            const int q = k - MT, h = q / NB, tb = q % NB;
+            von[slot][h][tb] = *reinterpret_cast<const dvec2u*>(ringb + (cby + (unsigned)(4 * h) * col_bytes + boo[tb]));
+        }
+    };
+    auto issue_advance = [&]() {
+        gp_i += 4;
+        cb_i += 32;
+        cby += 32u * col_bytes;
+        if (cb_i >= D) {
+            do {
+                cb_i -= D;
+                cby -= (unsigned)D * col_bytes;
+                ++s_i;
+            } while (cb_i >= D);
+            load_offsets();
+        }
+    };
+
+    // ---- consume side ----
+    int gp_c = gp0 + wave;
+    int s_c = (gp_c * 8) / D, cb_c = gp_c * 8 - s_c * D;
+    double cwo[NB], cwn[NB];
+    auto load_weights = [&]() {
+        const int ks  = s_c - s0;
+        const bool in = ks >= 0 && ks < ns;
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) {
+            const int k = (in ? ks : 0) * L + 16 * tb + jstep;
+            cwo[tb]     = in ? t_wo[k] : 0.0;
+            cwn[tb]     = in ? t_wn[k] : 0.0;
+        }
+    };
+    load_weights();
+
+    const int nfrag = (gp1 - gp0 - wave + 3) / 4;
+#pragma unroll
+    for (int r = 0; r < NS - 1; ++r) {
+        const char* __restrict__ kg = kb + (size_t)min(gp_i, gp1 - 1) * 1024;
+#pragma unroll
+        for (int k = 0; k < MT + 2 * NB; ++k) issue_part(r, k, kg);
+        issue_advance();
+    }
+    for (int i = 0; i < nfrag; i += NS) {
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            constexpr int H = MT / 2;
+            const int is = (r + NS - 1) % NS;  // free: consumed in the step before
+            const char* __restrict__ kg = kb + (size_t)min(gp_i, gp1 - 1) * 1024;  // past the end of the chunk: the last column group again (never consumed)
+            if (gp_c < gp1) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int tb = 0; tb < NB; ++tb) {
+                        const double u = fma(cwo[tb], von[r][h][tb].x, cwn[tb] * von[r][h][tb].y);  // (the expression of the other depths: rounds alike)
+#pragma unroll
+                        for (int m = 0; m < H; ++m) acc[tb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(h == 0 ? kv[r][m].x : kv[r][m].y, u, acc[tb][m], 0, 0, 0);
+                        issue_part(is, 2 * (h * NB + tb), kg);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int m = H; m < MT; ++m) acc[tb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(h == 0 ? kv[r][m].x : kv[r][m].y, u, acc[tb][m], 0, 0, 0);
+                        issue_part(is, 2 * (h * NB + tb) + 1, kg);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            } else {
+#pragma unroll
+                for (int k = 0; k < MT + 2 * NB; ++k) issue_part(is, k, kg);
+            }
+            issue_advance();
+            gp_c += 4;
+            cb_c += 32;
+            if (cb_c >= D) {
+                do {
+                    cb_c -= D;
+                    ++s_c;
+                } while (cb_c >= D);
+                load_weights();
+            }
+        }
+    }
+
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb) {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((size_t)wave * MT + m) * 256 + (kk + 4 * r) * 16 + jstep] = acc[tb][m][r];
+        __syncthreads();
+        for (int idx = tid; idx < MT * 256; idx += kConvThreads) {
+            const int m = idx >> 8, el = idx & 255, row = el >> 4, j = el & 15;
+            const double v = ((red[(0 * MT + m) * 256 + el] + red[(1 * MT + m) * 256 + el]) + red[(2 * MT + m) * 256 + el]) + red[(3 * MT + m) * 256 + el];
+            a.partials[((size_t)chunk * L + 16 * tb + j) * a.Dpad + (grp * MT + m) * 16 + row] = v;
+        }
+    }
+}
+#endif
+
 template <int MT, int R, int NB, int WPS = ((NB == 1 && MT <= 6) ? 2 : 1)>
 __global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs a) {
     // dynamic LDS: [front: cross-wave reduction buffer / U tiles of the excitation items][bracket table, SoA: wo', wn', off_older, off_newer]
@@ -940,6 +1093,10 @@ __global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs
     // the per-DoF ring must be addressable with 32-bit byte offsets for the scalar-base form (4 GB: far beyond any real history)
     if constexpr (NB > 2) {
         // depth 64 (experimental): the uniform form only -- the host selects this depth for D % 8 == 0 systems
+#ifdef HC_TUNING
+        if constexpr (R >= 10 && MT % 2 == 0) block_rad_stream_il<MT, R - 8, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);  // R = 11 / 12: the interleaved form with 3 / 4 slots
+        else
+#endif
         block_rad_stream_uni<MT, R, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
     } else {
         if ((a.hist.D & 7) == 0 && (size_t)a.hist.D * a.hist.HcapT < ((size_t)1 << 28)) block_rad_stream_uni<MT, R, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
@@ -1006,13 +1163,17 @@ static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, h
 // depth 64 (NB = 4; tuning build only -- measured in round 5 and not taken, EXPERIMENTS.md): MT row tiles per workgroup x R fragments in
 // flight, both from the environment for the sweep of profiles/r05 (HC_BLOCK64_R; the tile count comes with the launch)
 static int block64_R() {
-    static const int r = [] { const char* e = std::getenv("HC_BLOCK64_R"); const int v = e ? std::atoi(e) : 4; return (v == 3 || v == 5) ? v : 4; }();
+    static const int r = [] { const char* e = std::getenv("HC_BLOCK64_R"); const int v = e ? std::atoi(e) : 4; return (v == 3 || v == 5 || v == 11 || v == 12) ? v : 4; }();
     return r;
 }
 template <int MT>
 static void launch_conv_block64_mt(const BlockArgs& b, int nblocks, size_t smem, hipStream_t stream) {
-    static size_t granted[3] = {0, 0, 0};
+    static size_t granted[5] = {0, 0, 0, 0, 0};
     const int R = block64_R();
+    if constexpr (MT % 2 == 0) {
+        if (R == 11) { allow_dynamic_lds(conv_block_kernel<MT, 11, 4, 1>, smem, granted[3]); hipLaunchKernelGGL((conv_block_kernel<MT, 11, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+        if (R == 12) { allow_dynamic_lds(conv_block_kernel<MT, 12, 4, 1>, smem, granted[4]); hipLaunchKernelGGL((conv_block_kernel<MT, 12, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+    }
     if (R == 3) { allow_dynamic_lds(conv_block_kernel<MT, 3, 4, 1>, smem, granted[0]); hipLaunchKernelGGL((conv_block_kernel<MT, 3, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); }
     else if (R == 5) { allow_dynamic_lds(conv_block_kernel<MT, 5, 4, 1>, smem, granted[2]); hipLaunchKernelGGL((conv_block_kernel<MT, 5, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); }
     else { allow_dynamic_lds(conv_block_kernel<MT, 4, 4, 1>, smem, granted[1]); hipLaunchKernelGGL((conv_block_kernel<MT, 4, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); }
@@ -1031,7 +1192,7 @@ BlockLaunch block_launch_config(const BlockArgs& a, int mt, BlockArgs* b) {
     if (a.depth == 64) {
         l.MT  = (mt == 6 || mt == 4 || mt == 3) ? mt : 3;
         l.NB  = 4;
-        l.R   = block64_R();
+        l.R   = (block64_R() >= 10 && l.MT % 2) ? 4 : block64_R();
         l.WPS = 1;
         return l;
     }

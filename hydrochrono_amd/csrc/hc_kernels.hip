@@ -924,7 +924,7 @@ __device__ __forceinline__ void block_rad_stream_uni(const BlockArgs& a, const i
 // that run (about 600 cycles per fragment of 3072 matrix-pipe cycles) exposed, not hidden: only what is issued within the 64 cycles of
 // the last MFMA runs in its shadow.  Here the loads of the fragment NS - 1 ahead go out one at a time BETWEEN the MFMAs of the fragment
 // being consumed (one load behind every MT/2 MFMAs), into a register slot that is not being read (NS slots, NS - 1 fragments in flight).
-template <int MT, int NS, int NB>
+template <int MT, int NS, int NB, int VAR = 0>
 __device__ __forceinline__ void block_rad_stream_il(const BlockArgs& a, const int chunk, const int grp, double* red, double* t_wo, double* t_wn,
                                                     int* t_oo, int* t_on) {
     constexpr int L = 16 * NB;
@@ -961,6 +961,7 @@ __device__ __forceinline__ void block_rad_stream_il(const BlockArgs& a, const in
     int gp_i = gp0 + wave;
     int s_i = (gp_i * 8) / D, cb_i = gp_i * 8 - s_i * D;
     unsigned cby = (unsigned)(cb_i + kk) * col_bytes;
+    const unsigned cby0 = cby;
     unsigned boo[NB];
     auto load_offsets = [&]() {
         const int ks  = s_i - s0;
@@ -970,11 +971,19 @@ __device__ __forceinline__ void block_rad_stream_il(const BlockArgs& a, const in
     };
     load_offsets();
     // load number k of the fragment at the issue-side trackers: K tiles first (the long latency), then the gathers
-    auto issue_part = [&](const int slot, const int k, const char* __restrict__ kg) {
-        if (k < MT) kv[slot][k] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kg + k * tile_bytes + lane16));
-        else if (k < MT + 2 * NB) {
+    // VAR > 0 (timing bounds of EXPERIMENTS.md, results wrong): 1 = the loop issues no gathers, 2 = no loads at all, 3 = MFMAs only
+    auto issue_part = [&](const int slot, const int k, const char* __restrict__ kg, const bool in_loop = false) {
+        if (in_loop && (VAR == 2 || VAR == 3)) return;
+        if (in_loop && VAR == 1 && k >= MT) return;
+        // VAR 4: the gathers stay on the chunk's first 8 columns (cache hits); 5: K loads without the non-temporal hint; 6: the K loads of a
+        // fragment from 6 KB in a row (one stream per wave instead of MT) -- timing bounds as well
+        if (k < MT) {
+            if constexpr (VAR == 5) kv[slot][k] = *reinterpret_cast<const dvec2*>(kg + k * tile_bytes + lane16);
+            else if constexpr (VAR == 6) kv[slot][k] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kb + ((size_t)(kg - kb) * MT + k * 1024 + lane16)));
+            else kv[slot][k] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(kg + k * tile_bytes + lane16));
+        } else if (k < MT + 2 * NB) {
             const int q = k - MT, h = q / NB, tb = q % NB;
-            von[slot][h][tb] = *reinterpret_cast<const dvec2u*>(ringb + (cby + (unsigned)(4 * h) * col_bytes + boo[tb]));
+            von[slot][h][tb] = *reinterpret_cast<const dvec2u*>(ringb + ((VAR == 4 ? cby0 : cby) + (unsigned)(4 * h) * col_bytes + boo[tb]));
         }
     };
     auto issue_advance = [&]() {
@@ -1027,19 +1036,19 @@ __device__ __forceinline__ void block_rad_stream_il(const BlockArgs& a, const in
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int tb = 0; tb < NB; ++tb) {
-                        const double u = fma(cwo[tb], von[r][h][tb].x, cwn[tb] * von[r][h][tb].y);  // (the expression of the other depths: rounds alike)
+                        const double u = VAR == 3 ? cwo[tb] : fma(cwo[tb], von[r][h][tb].x, cwn[tb] * von[r][h][tb].y);  // (the expression of the other depths: rounds alike)
 #pragma unroll
                         for (int m = 0; m < H; ++m) acc[tb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(h == 0 ? kv[r][m].x : kv[r][m].y, u, acc[tb][m], 0, 0, 0);
-                        issue_part(is, 2 * (h * NB + tb), kg);
+                        issue_part(is, 2 * (h * NB + tb), kg, true);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int m = H; m < MT; ++m) acc[tb][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(h == 0 ? kv[r][m].x : kv[r][m].y, u, acc[tb][m], 0, 0, 0);
-                        issue_part(is, 2 * (h * NB + tb) + 1, kg);
+                        issue_part(is, 2 * (h * NB + tb) + 1, kg, true);
                         __builtin_amdgcn_sched_barrier(0);
                     }
             } else {
 #pragma unroll
-                for (int k = 0; k < MT + 2 * NB; ++k) issue_part(is, k, kg);
+                for (int k = 0; k < MT + 2 * NB; ++k) issue_part(is, k, kg, true);
             }
             issue_advance();
             gp_c += 4;
@@ -1094,7 +1103,8 @@ __global__ void __launch_bounds__(kConvThreads, WPS) conv_block_kernel(BlockArgs
     if constexpr (NB > 2) {
         // depth 64 (experimental): the uniform form only -- the host selects this depth for D % 8 == 0 systems
 #ifdef HC_TUNING
-        if constexpr (R >= 10 && MT % 2 == 0) block_rad_stream_il<MT, R - 8, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);  // R = 11 / 12: the interleaved form with 3 / 4 slots
+        if constexpr (R >= 13 && MT % 2 == 0) block_rad_stream_il<MT, 3, NB, R - 12>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);  // R = 13 ... 18: timing bounds (wrong results)
+        else if constexpr (R >= 10 && MT % 2 == 0) block_rad_stream_il<MT, R - 8, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);  // R = 11 / 12: the interleaved form with 3 / 4 slots
         else
 #endif
         block_rad_stream_uni<MT, R, NB>(a, chunk, grp, front, t_wo, t_wn, t_oo, t_on);
@@ -1163,16 +1173,31 @@ static void launch_conv_block_mt(const BlockArgs& b, int nblocks, size_t smem, h
 // depth 64 (NB = 4; tuning build only -- measured in round 5 and not taken, EXPERIMENTS.md): MT row tiles per workgroup x R fragments in
 // flight, both from the environment for the sweep of profiles/r05 (HC_BLOCK64_R; the tile count comes with the launch)
 static int block64_R() {
-    static const int r = [] { const char* e = std::getenv("HC_BLOCK64_R"); const int v = e ? std::atoi(e) : 4; return (v == 3 || v == 5 || v == 11 || v == 12) ? v : 4; }();
+    static const int r = [] { const char* e = std::getenv("HC_BLOCK64_R"); const int v = e ? std::atoi(e) : 4; return (v == 2 || v == 3 || v == 5 || (v >= 11 && v <= 18)) ? v : 4; }();
     return r;
 }
 template <int MT>
 static void launch_conv_block64_mt(const BlockArgs& b, int nblocks, size_t smem, hipStream_t stream) {
     static size_t granted[5] = {0, 0, 0, 0, 0};
     const int R = block64_R();
+    if constexpr (MT == 3) {
+        // two workgroups per CU (two waves per SIMD, 256 registers each): the matrix pipe of a SIMD is fed by two instruction streams
+        static size_t g3 = 0;
+        if (R == 2) { allow_dynamic_lds(conv_block_kernel<3, 2, 4, 2>, smem, g3); hipLaunchKernelGGL((conv_block_kernel<3, 2, 4, 2>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+    }
     if constexpr (MT % 2 == 0) {
         if (R == 11) { allow_dynamic_lds(conv_block_kernel<MT, 11, 4, 1>, smem, granted[3]); hipLaunchKernelGGL((conv_block_kernel<MT, 11, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
         if (R == 12) { allow_dynamic_lds(conv_block_kernel<MT, 12, 4, 1>, smem, granted[4]); hipLaunchKernelGGL((conv_block_kernel<MT, 12, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+        if constexpr (MT == 6) {
+            static size_t g2[3] = {0, 0, 0};
+            if (R == 13) { allow_dynamic_lds(conv_block_kernel<MT, 13, 4, 1>, smem, g2[0]); hipLaunchKernelGGL((conv_block_kernel<MT, 13, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            if (R == 14) { allow_dynamic_lds(conv_block_kernel<MT, 14, 4, 1>, smem, g2[1]); hipLaunchKernelGGL((conv_block_kernel<MT, 14, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            if (R == 15) { allow_dynamic_lds(conv_block_kernel<MT, 15, 4, 1>, smem, g2[2]); hipLaunchKernelGGL((conv_block_kernel<MT, 15, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            static size_t g3[3] = {0, 0, 0};
+            if (R == 16) { allow_dynamic_lds(conv_block_kernel<MT, 16, 4, 1>, smem, g3[0]); hipLaunchKernelGGL((conv_block_kernel<MT, 16, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            if (R == 17) { allow_dynamic_lds(conv_block_kernel<MT, 17, 4, 1>, smem, g3[1]); hipLaunchKernelGGL((conv_block_kernel<MT, 17, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+            if (R == 18) { allow_dynamic_lds(conv_block_kernel<MT, 18, 4, 1>, smem, g3[2]); hipLaunchKernelGGL((conv_block_kernel<MT, 18, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); return; }
+        }
     }
     if (R == 3) { allow_dynamic_lds(conv_block_kernel<MT, 3, 4, 1>, smem, granted[0]); hipLaunchKernelGGL((conv_block_kernel<MT, 3, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); }
     else if (R == 5) { allow_dynamic_lds(conv_block_kernel<MT, 5, 4, 1>, smem, granted[2]); hipLaunchKernelGGL((conv_block_kernel<MT, 5, 4, 1>), dim3(nblocks), dim3(kConvThreads), smem, stream, b); }
@@ -1192,8 +1217,8 @@ BlockLaunch block_launch_config(const BlockArgs& a, int mt, BlockArgs* b) {
     if (a.depth == 64) {
         l.MT  = (mt == 6 || mt == 4 || mt == 3) ? mt : 3;
         l.NB  = 4;
-        l.R   = (block64_R() >= 10 && l.MT % 2) ? 4 : block64_R();
-        l.WPS = 1;
+        l.R   = ((block64_R() >= 10 && l.MT % 2) || (block64_R() >= 13 && l.MT != 6) || (block64_R() == 2 && l.MT != 3)) ? 4 : block64_R();
+        l.WPS = l.R == 2 ? 2 : 1;
         return l;
     }
     l.MT  = (mt == 12 || mt == 6 || mt == 4 || mt == 2) ? mt : 1;  // (12 tiles per workgroup: HC_BLOCK_MT=12, measured and not taken)

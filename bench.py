@@ -63,6 +63,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 ROOFLINE_PROFILE = ("profiles/r05/c3_driver_cmd_kernel_stats_by_grid.csv, row hc::conv_block_kernel<6, 4, 2, 1> on 256 workgroups "
                     "(MEASURED.md: recomputing roofline.frac); PMC: profiles/r05/pmc_traffic.json")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+HBM_STREAM_CEILING_GBS = 6300.0  # what a pure dwordx4 load stream reaches on this chip (profiles/r05/mfma_vmem_probe.txt: 6.30-6.38 TB/s; the guide: 6.29)
 FP64_MFMA_PEAK_TF = 78.6
 
 WAVES = dict(simulation_dt=0.01, simulation_duration=60.0, ramp_duration=0.0, wave_height=2.0, wave_period=8.0,
@@ -1071,7 +1072,8 @@ def main():
             "aql_dispatches": dinfo["aql_dispatches"], "hip_launches": dinfo["hip_launches"],
             "roofline": {
                 "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "frac": achieved / HBM_PEAK_GBS, "frac_of_stream_ceiling": achieved / HBM_STREAM_CEILING_GBS, "stream_ceiling": HBM_STREAM_CEILING_GBS,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_once, "units_per_launch": units,
                 "reuse_factor": bytes_units / bytes_once if bytes_once else None,
                 "algorithmic_bytes_of_the_units": bytes_units,

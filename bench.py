@@ -505,7 +505,7 @@ def c4_one_gpu(sdt, lookahead):
     """C4 -- the whole coupled 512-body array (K = 77.3 GB, generated in HBM) -- on THIS GPU: synchronous hc_step, so that the N > 1
     lines of this benchmark (the same array row-sharded over N GPUs) have a one-GPU figure of the SAME workload to be divided by."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion
-    N, warm, steps = N_BODIES_C4, 40, 96
+    N, warm, steps = N_BODIES_C4, 104, 256  # (steady state: a 96-step window after 40 caught less than its share of the passes, 0.43 against 0.51 ms per step)
     motion = PrescribedMotion(N, np.zeros((N, 3)), seed=20251031)
     nhist = int(np.ceil(S_RIRF * DT / sdt)) + 5
     t_hist = T0 - sdt * np.arange(1, nhist + 1)

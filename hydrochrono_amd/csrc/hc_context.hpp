@@ -260,7 +260,7 @@ struct hc_ctx {
     bool ahead_now = false;        // adaptive: the rule's last answer (starts as the static choice by size: wide systems run ahead)
     int gap_seen = 0, gap_long = 0, gap_long_lo = 0;  // gaps measured since the last decision; how many of them were longer than
                                    // gap_threshold (it takes a majority of these to GO ahead) / than 0.6 of it (... to STAY ahead)
-    double gap_threshold = 4e-6;   // seconds (HC_PASS_AHEAD_GAP_US; wide systems: 0, see hc_setup.cpp)
+    double gap_threshold = 4e-6;   // seconds (HC_PASS_AHEAD_GAP_US; wide systems: 0 up to 12 GB of K in the context, then a tenth of the pass's cost per step, hc_setup.cpp)
     double gap_hint = -1.0;        // hc_step_multi: the gap its calling thread measured for the whole group (< 0: none, measure here)
     std::chrono::steady_clock::time_point t_multi_end{};  // (kept on the group's first context) end of the last hc_step_multi
     bool have_t_multi_end = false;

@@ -177,12 +177,12 @@ void launch_pass(hc_ctx* c, hipStream_t stream, bool with_exc, bool direct) {
 // reduction after the last slice, in chunk order -- the sums do not depend on how the chunks were spread over launches.
 void ahead_drop(hc_ctx* c) { c->ahead.active = false; }
 
-// The adaptive schedule's state as a fresh context has it: no gaps seen, the static choice by size as the first answer (wide systems
-// -- the same switch as the two-level form -- run ahead: their pass is long and the schedule costs a back-to-back caller nothing).
+// The adaptive schedule's state as a fresh context has it: no gaps seen, and as the first answer what a caller without gaps gets --
+// "ahead" exactly where the threshold is zero (wide systems whose slice of K is small enough for latency-bound step kernels, hc_setup.cpp).
 void reset_schedule_state(hc_ctx* c) {
     c->gap_seen = c->gap_long = c->gap_long_lo = 0;
     c->gap_hint  = -1.0;
-    c->ahead_now = hc::near_slices_for(c->D) > 1;
+    c->ahead_now = hc::near_slices_for(c->D) > 1 && c->gap_threshold <= 0.0;
 }
 
 // Does the pass of the block AFTER the one that starts now run one block ahead?  Schedule 0 / 1: as selected.  Adaptive: by majority

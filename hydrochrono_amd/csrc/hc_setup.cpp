@@ -454,8 +454,18 @@ int hc_finalize(hc_ctx* c) {
         // the gap beyond which "one block ahead" pays (profiles/r05/ahead_probe_fine_gaps.txt): C3 -- 0 - 3 us: the schedules within
         // noise of each other (17.4 / 18.6 / 17.4 / 16.9 at block start, 18.8 / 18.6 / 16.8 / 17.6 ahead), 5 us: 18.4 against 17.0,
         // 8 us: 18.1 against 14.8, 20 us: 16.8 against 11.9 us per step; a C4/8 rank -- ahead wins at every gap, back to back included
-        // (70.1 against 68.6 us, worst step 1.58 against 0.33 ms; 10 us: 70.2 against 60.9), so wide systems run ahead whatever the caller does
-        c->gap_threshold = 1e-6 * std::max(0, env_int("HC_PASS_AHEAD_GAP_US", hc::near_slices_for(c->D) > 1 ? 0 : 4));
+        // (70.1 against 68.6 us, worst step 1.58 against 0.33 ms; 10 us: 70.2 against 60.9): the kernels of its step path are latency-bound
+        // and run beside the pass for free.  Larger slices of a wide system (profiles/r05/ahead_probe_shard_sizes.txt: rows of 128 / 256 /
+        // 512 of 512 bodies, K slices of 19 / 39 / 77 GB) have bandwidth-bound step kernels that only share the memory with a sliced pass:
+        // back to back the pass at block start wins by 4-6 %, "ahead" from gaps of 10-20 / 10-20 / 50-100 us on -- about a tenth of what the
+        // pass costs per step.  So: wide and at most 12 GB of K in this context: 0; wide and larger: a tenth of (K bytes / 32 steps / 6.3 TB/s);
+        // otherwise 4 us.
+        {
+            const double k_local = 8.0 * static_cast<double>(c->Dloc) * c->D * c->S;
+            int def_us = 4;
+            if (hc::near_slices_for(c->D) > 1) def_us = k_local <= 12e9 ? 0 : static_cast<int>(0.1 * k_local / hc::kDepthDefault / 6.3e12 * 1e6 + 0.5);
+            c->gap_threshold = 1e-6 * std::max(0, env_int("HC_PASS_AHEAD_GAP_US", def_us));
+        }
         reset_schedule_state(c);
         c->pass_concurrent = env_int("HC_PASS_CONCURRENT", 1) != 0;
         c->pass_free_cus   = std::max(1, std::min(16, HC_TUNE_INT("HC_PASS_FREE_CUS", 4)));

@@ -255,7 +255,8 @@ int hc_compute_waves(hc_ctx* ctx, double t, double* waves_out);
 int hc_set_lookahead(hc_ctx* ctx, int steps);
 /* When the pass of a look-ahead block runs.  one_block_ahead < 0 (the default of every context): ADAPTIVE -- the library counts,
  * per block, how many of the gaps between the caller's synchronous steps (end of one hc_step / hc_step_multi to the begin of the
- * next) were longer than a few microseconds (HC_PASS_AHEAD_GAP_US, default 4) and runs the pass of the following block at block
+ * next) were longer than a threshold (HC_PASS_AHEAD_GAP_US; default 4 us, for wide systems 0 up to 12 GB of K in the context and a
+ * tenth of the pass's cost per step above that) and runs the pass of the following block at block
  * start when the caller steps back to back, one block ahead when it is away between steps -- as a Chrono loop is; systems below
  * 256 MB of K (6N * 6N * S * 8 bytes) always run it at block start (their pass takes microseconds).  hc_step_multi measures the
  * gap once for its group of contexts, so the shards of one array decide alike.  The decisions are counted in

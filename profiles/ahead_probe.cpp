@@ -89,6 +89,13 @@ int main(int argc, char** argv) {
         return wide ? run(512, 0, 64, 1024, std::atof(argv[3]), std::atoi(argv[2]), 0) : run(64, 0, 64, 1024, std::atof(argv[3]), std::atoi(argv[2]), 0);
     }
     // schedule -1 = the library's default (adaptive: per block from the caller's gaps, hc_set_pass_schedule)
+    if (const char* sr = std::getenv("SHARD_ROWS")) {  // bigger row shards of the 512-body array (128 / 256 / 512 bodies): where does "ahead" begin to pay?
+        const int rows = std::atoi(sr);
+        for (double gap : {0.0, 5.0, 10.0, 20.0, 50.0, 100.0})
+            for (int schedule : {0, 1})
+                if (run(512, 0, rows, 1024, gap, schedule, 0)) return 1;
+        return 0;
+    }
     const bool fine = std::getenv("FINE_GAPS") != nullptr;  // the crossover between the two schedules (threshold of the adaptive rule)
     if (fine) {
         for (double gap : {0.0, 1.0, 2.0, 3.0, 5.0, 8.0, 12.0, 20.0})

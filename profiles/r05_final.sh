@@ -11,7 +11,7 @@ python $R/bench.py > $O/bench_c3_default.json 2> $O/bench_c3_default.err
 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_c3_driver_cmd.json 2>/dev/null
 python $R/bench.py --lookahead 16 --no-cpu-baseline --no-c4-share --no-c4-one-gpu --no-small-configs > $O/bench_c3_depth16.json 2>/dev/null
 python $R/bench.py --step-dt 0.007 --no-secondary > $O/bench_c3_stepdt0.007.json 2>/dev/null
-python $R/bench.py --scaling strong --bodies 512 --steps 96 --warmup 33 --no-secondary > $O/bench_c4_1gpu.json 2>/dev/null
+python $R/bench.py --scaling strong --bodies 512 --steps 256 --warmup 104 --no-secondary > $O/bench_c4_1gpu.json 2>/dev/null
 g++ -O2 -std=c++17 $R/profiles/ahead_probe.cpp -I $R/include -L $R/hydrochrono_amd/lib -lhydrochrono_amd -Wl,-rpath,$R/hydrochrono_amd/lib -o /tmp/ahead_probe && /tmp/ahead_probe 1 2>/dev/null > $O/ahead_probe.txt
 g++ -O2 -std=c++17 $R/profiles/host_path_c.cpp -I $R/include -L $R/hydrochrono_amd/lib -lhydrochrono_amd -Wl,-rpath,$R/hydrochrono_amd/lib -o /tmp/host_path_c && /tmp/host_path_c 2>/dev/null > $O/host_path_c.txt
 g++ -O2 -std=c++17 $R/profiles/multi_path_c.cpp -I $R/include -L $R/hydrochrono_amd/lib -lhydrochrono_amd -Wl,-rpath,$R/hydrochrono_amd/lib -pthread -o /tmp/multi_path_c && {

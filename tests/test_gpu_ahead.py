@@ -558,3 +558,49 @@ def test_adaptive_schedule_row_shards_decide_alike(hydro, monkeypatch, tuning_bu
         p = h.profile()
         assert (p["schedule_blocks_ahead"], p["schedule_blocks_at_start"], p["ahead_blocks"]) == \
                (p1["schedule_blocks_ahead"], p1["schedule_blocks_at_start"], p1["ahead_blocks"]), (p, p1)
+
+
+def test_adaptive_schedule_of_a_wide_system_goes_by_the_size_of_its_slice(hydro):
+    """Wide systems (6N >= 1024) under the DEFAULT schedule, back to back through the C ABI's own loop: the rows of 64 of 512 bodies
+    (a C4/8 rank, 9.7 GB of K: latency-bound step kernels, threshold 0) answer "one block ahead" from the first block on; the rows of
+    128 bodies (a C4/4 rank, 19.4 GB: threshold a tenth of the pass's cost per step, about 10 us) answer "at block start" -- and
+    "ahead" as soon as the caller leaves 300 us between its calls (profiles/r05/ahead_probe_shard_sizes.txt).  The rows the two
+    shards share agree to rounding."""
+    import time
+    import bench as B
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    N = B.N_BODIES_C4
+    motion = PrescribedMotion(N, np.zeros((N, 3)), seed=20251031)
+    nhist = B.S_RIRF + 5
+    t_hist = B.T0 - B.DT * np.arange(1, nhist + 1)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    nsteps = 160
+    times = B.T0 + B.DT * np.arange(2 * nsteps)
+    states = np.stack([motion.packed(t) for t in times])
+    rows = {}
+    for nb in (64, 128):
+        gpu = B.make_shard(N, 0, nb, 0, B.DT, B.T0 + 20.0, 32, t_hist, v_hist)
+        f_tight, _ = gpu.step_many(times[:nsteps], states[:nsteps])
+        p0 = gpu.profile()
+        f_gaps = []
+        for k in range(nsteps, 2 * nsteps):
+            f_gaps.append(gpu.step(times[k], *motion.state(times[k])))
+            b = time.perf_counter()
+            while time.perf_counter() - b < 300e-6:
+                pass
+        p1 = gpu.profile()
+        rows[nb] = np.concatenate([f_tight, np.stack(f_gaps)])
+        tight = (p0["schedule_blocks_ahead"], p0["schedule_blocks_at_start"])
+        gaps = (p1["schedule_blocks_ahead"] - p0["schedule_blocks_ahead"], p1["schedule_blocks_at_start"] - p0["schedule_blocks_at_start"])
+        print(f"rows of {nb} of {N} bodies: answers (ahead, at start) back to back {tight}, with 300 us between the calls {gaps}")
+        if nb == 64:
+            assert tight[0] >= 4 and tight[1] == 0, tight
+        else:
+            assert tight[1] >= 4 and tight[0] == 0, tight
+        assert gaps[0] >= 3 and gaps[1] <= 1, gaps  # (a decision belongs to the gaps of the block before it)
+        assert gpu.direct_dispatch()[0]
+        gpu.close()
+    # (the two schedules group the chunks of K differently: the rows the shards share agree to rounding, not bitwise)
+    worst = max(relerr(a, b) for a, b in zip(rows[64], rows[128][:, :6 * 64]))
+    print(f"rows shared by the two shards, different schedules: worst relative difference {worst:.2e}")
+    assert worst <= 1e-12, worst

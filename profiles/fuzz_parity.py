@@ -1,0 +1,154 @@
+"""Randomised differential run of the HIP path against the CPU oracle through the C ABI (tuning build: the knobs that force the wide
+machinery onto small systems are read from the environment).  Each case draws: bodies 1..9, IRF samples 8..260, IRF spacing, the
+caller's stepping pattern (uniform stretches on random step sizes -- equal to, below and above the IRF spacing --, jittered stretches,
+repeated times = cache hits), the wave model (none / regular / irregular), the convolution mode (Baseline / TaperedDirect), the look-ahead
+depth (0 / 16 / 32), the pass schedule (adaptive / at block start / one block ahead, with the size floor off), the sub-block size of the
+two-level form (default / 0 / 4 / 8), direct dispatch or HIP launches, one context or 2-3 row shards behind hc_step_multi, a pre-filled
+history or a cold start, gravity.  Every step's total and its three components against the oracle, each at 1e-9 relative to its own largest
+entry; a failure prints the case's seed and stops.   python profiles/fuzz_parity.py [seconds = 300] [first seed = 1]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+os.environ.setdefault("HYDROCHRONO_AMD_FLAVOR", "tuning")
+os.environ["HC_PASS_AHEAD_MIN_MB"] = "0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401,E402
+from cases import load_into_oracle  # noqa: E402
+from hydrochrono_amd.hydro import HydroForces, HydroGroup  # noqa: E402
+from hydrochrono_amd.mock_chrono import PrescribedMotion  # noqa: E402
+from hydrochrono_amd.synthetic import many_body_case, rest_positions  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+TOL = 1e-9
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def one_case(seed):
+    rng = np.random.default_rng(seed)
+    N = int(rng.choice([1, 1, 2, 2, 3, 4, 5, 8, 9]))
+    S = int(rng.integers(8, 260))
+    if rng.random() < 0.02:  # now and then a genuinely wide system (6N >= 1024: column slices, fused wide step, two-level form by default)
+        N, S = int(rng.choice([171, 176, 192])), int(rng.integers(12, 40))
+    dt_r = float(rng.choice([0.01, 0.015, 0.02, 0.0125]))
+    n_exc = int(rng.choice([21, 33, 65]))
+    nw = int(rng.choice([16, 40]))
+    case = many_body_case(N, S=S, dt_rirf=dt_r, n_exc=n_exc, dt_exc=float(rng.choice([0.02, 0.05])), nw=nw, seed=1000 + seed)
+    if rng.random() < 0.5:
+        case["g_sys"] = [float(rng.normal() * 0.3), float(rng.normal() * 0.3), -9.81 + float(rng.normal() * 0.2)]
+    lookahead = int(rng.choice([0, 16, 32, 32]))
+    sched = int(rng.choice([-1, 0, 1, 1]))
+    sub = int(rng.choice([-1, -1, 0, 4, 8]))
+    direct = int(rng.random() < 0.7)
+    shards = int(rng.choice([1, 1, 1, 2, 3])) if N >= 3 else 1
+    wave = str(rng.choice(["none", "regular", "irregular", "irregular"]))
+    mode = int(rng.random() < 0.2)  # 1: TaperedDirect
+    cold = rng.random() < 0.3
+    os.environ["HC_SUB_BLOCK"] = str(sub)
+    os.environ["HC_DIRECT"] = str(direct)
+    desc = (f"seed {seed}: N {N} S {S} dt_rirf {dt_r} lookahead {lookahead} schedule {sched} sub {sub} direct {direct} shards {shards} "
+            f"waves {wave} mode {mode} cold {int(cold)}")
+    gpu = HydroGroup.from_case(case, shards) if shards > 1 else HydroForces.from_case(case)
+    orc = load_into_oracle(case)
+    base_dt = float(rng.choice([dt_r, dt_r, 0.7 * dt_r, 1.3 * dt_r, 0.5 * dt_r, 0.01]))
+    n_steps = int(rng.integers(150, 420)) if N < 100 else int(rng.integers(80, 160))
+    span = S * dt_r
+    t0 = 0.0 if cold else span + 1.0 + float(rng.uniform(0, 1))
+    dur = t0 + n_steps * 2.2 * max(base_dt, dt_r) + 10.0
+    if mode == 1:
+        opts = dict(smoothing=int(rng.choice([0, 1])), window_length=5, rirf_end_time=float(rng.uniform(0.5, 1.0) * span),
+                    taper_start_percent=float(rng.uniform(0.5, 0.9)), taper_end_percent=1.0, taper_final_amplitude=float(rng.choice([0.0, 0.1])))
+        for h in (gpu, orc):
+            h.set_convolution_mode(1)
+            h.set_tapered_direct_options(**opts)
+    if wave == "none":
+        for h in (gpu, orc):
+            h.add_waves_none()
+    elif wave == "regular":
+        amp, om = float(rng.uniform(0.1, 1.0)), float(rng.uniform(0.1, 0.045 * nw))  # inside the BEM frequency list (0.05 .. 0.05 nw)
+        for h in (gpu, orc):
+            h.add_waves_regular(amp, om)
+    else:
+        kw = dict(simulation_dt=base_dt, simulation_duration=dur, ramp_duration=float(rng.choice([0.0, 2.0])), wave_height=float(rng.uniform(0.5, 3.0)),
+                  wave_period=float(rng.uniform(5.0, 11.0)), frequency_min=0.02, frequency_max=0.5, nfrequencies=int(rng.choice([16, 64])),
+                  peak_enhancement_factor=float(rng.choice([1.0, 3.3])), seed=int(rng.integers(1, 9)))
+        for h in (gpu, orc):
+            h.add_waves_irregular(**kw)
+    gpu.set_lookahead(lookahead)
+    gpu.set_pass_schedule(sched)
+    gpu.enable_profiling(1 if seed % 4 == 0 else 1000000)  # (the launch counters below: passes are always counted, the per-step launches only when timed)
+    motion = PrescribedMotion(N, rest_positions(case), seed=seed)
+    if not cold:
+        nh = int(np.ceil(span / base_dt)) + 4
+        th = t0 - base_dt * np.arange(1, nh + 1)
+        vh = np.stack([motion.velocity6(t) for t in th])
+        gpu.set_history(th, vh)
+        orc.prefill_history(th, vh)
+    # the caller's times
+    times, t = [], t0
+    while len(times) < n_steps:
+        kind = rng.random()
+        n = int(rng.integers(3, 90))
+        if kind < 0.6:
+            d = base_dt
+            seq = [d] * n
+        elif kind < 0.8:
+            d = float(rng.choice([dt_r, 0.7 * dt_r, 1.3 * dt_r, 2.0 * dt_r, 0.4 * dt_r]))
+            seq = [d] * n
+        else:
+            seq = list(rng.uniform(0.4 * base_dt, 1.8 * base_dt, n))
+        for d in seq:
+            times.append(t)
+            if rng.random() < 0.03:
+                times.append(t)  # the same time again: a cache hit (src/hydro_forces.cpp:742-744)
+            t += d
+    times = times[:n_steps]
+    worst = 0.0
+    for k, tt in enumerate(times):
+        st = motion.state(tt)
+        fg = gpu.step(tt, *st)
+        fo = orc.step(tt, *st)
+        e = relerr(fg, fo)
+        if e <= TOL:  # the three components, each relative to ITS OWN largest entry (a radiation error must not hide behind the hydrostatics)
+            for a, b in zip(gpu.components(), orc.components()):
+                sc = float(np.max(np.abs(b)))
+                if sc > 0.0:
+                    e = max(e, float(np.max(np.abs(a - b))) / sc)
+                elif np.any(a != 0.0):
+                    e = 1.0
+        worst = max(worst, e)
+        if not e <= TOL:
+            print(f"FAIL {desc}: step {k} t {tt!r}: relative error {e:.3e}", flush=True)
+            return False, desc, worst, None
+    prof = (gpu.shards[0] if shards > 1 else gpu).profile()
+    gpu.close()
+    orc.close()
+    return True, desc, worst, np.array([prof["block_kernel_launches"], prof["mini_pass_launches"], prof["ahead_blocks"], prof["scatter_kernel_launches"],
+                                        prof["conv_kernel_launches"], prof["direct_dispatches"], prof["hip_launches"]], dtype=np.int64)
+
+
+t_end = time.time() + budget
+n_ok, worst_all, passes = 0, 0.0, np.zeros(7, dtype=np.int64)
+while time.time() < t_end:
+    ok, desc, worst, npass = one_case(seed)
+    if not ok:
+        sys.exit(1)
+    n_ok += 1
+    worst_all = max(worst_all, worst)
+    passes += npass
+    if n_ok % 200 == 0:
+        print(f"{n_ok} cases ok (last: {desc}; worst so far {worst_all:.2e})", flush=True)
+    seed += 1
+from hydrochrono_amd import capi  # noqa: E402
+print(f"library: {capi.load().hc_version().decode()}, flavour {os.environ['HYDROCHRONO_AMD_FLAVOR']}")
+print(f"fuzz ok: {n_ok} cases, seeds up to {seed - 1}, worst relative error {worst_all:.2e}; launches over all cases (first shard of a group): passes {passes[0]}, "
+      f"short passes {passes[1]} and scatters {passes[3]} (counted in every fourth case only), blocks that started with rows made ahead {passes[2]}, plain per-step kernels {passes[4]}; "
+      f"AQL dispatches {passes[5]}, HIP launches {passes[6]}")

@@ -537,6 +537,18 @@ int hc_finalize(hc_ctx* c) {
     HC_API_END(c)
 }
 
+// The wave model is about to change: excitation rows a look-ahead pass has precomputed belong to the previous model -- those of the
+// current block (Plan::has_exc) AND those of the pass one block ahead, whether its rows are complete already (the next block would adopt
+// them, hc_step.cpp: plan.has_exc = ahead.has_exc) or its last slice, which carries the excitation work items with the OLD tables in
+// its arguments, is still to be issued.  The radiation rows stay valid.  (Found by profiles/fuzz_parity.py, seed 40: a wave model
+// redrawn under "one block ahead" gave the next block the old model's excitation force.)
+static void drop_lookahead_excitation(hc_ctx* c) {
+    c->plan.has_exc        = false;
+    c->ahead.has_exc       = false;
+    c->ahead.exc_once      = 0.0;
+    c->ahead.args.nchunks_ex = 0;
+}
+
 // ---- configuration ----------------------------------------------------------------------------
 int hc_set_gravity(hc_ctx* c, const double g[3]) {
     HC_API_BEGIN(c)
@@ -547,7 +559,7 @@ int hc_set_gravity(hc_ctx* c, const double g[3]) {
 
 int hc_set_wave_none(hc_ctx* c, int num_bodies_arg) {
     HC_API_BEGIN(c)
-    c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
+    drop_lookahead_excitation(c);
     HC_HIP(hipDeviceSynchronize());  // the tables replaced below may be in use by steps on a caller's stream
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(num_bodies_arg >= 0, HC_ERR_INVALID, "negative body count");
@@ -559,7 +571,7 @@ int hc_set_wave_none(hc_ctx* c, int num_bodies_arg) {
 
 int hc_set_wave_regular(hc_ctx* c, int num_bodies_arg, double amplitude, double omega) {
     HC_API_BEGIN(c)
-    c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
+    drop_lookahead_excitation(c);
     HC_HIP(hipDeviceSynchronize());  // the tables replaced below may be in use by steps on a caller's stream
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(num_bodies_arg >= 1 && num_bodies_arg <= c->N, HC_ERR_OUT_OF_RANGE, "regular wave created for more bodies than the hydro data holds");
@@ -615,7 +627,7 @@ void hc_irregular_wave_params_default(hc_irregular_wave_params* p) {
 
 int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     HC_API_BEGIN(c)
-    c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
+    drop_lookahead_excitation(c);
     HC_HIP(hipDeviceSynchronize());  // the tables replaced below may be in use by steps on a caller's stream
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(pp, HC_ERR_INVALID, "null parameters");
@@ -756,7 +768,7 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
 
 int hc_set_wave_irregular_spectral(hc_ctx* c, const hc_irregular_wave_params* pp) {
     HC_API_BEGIN(c)
-    c->plan.has_exc = false;  // excitation rows precomputed by a look-ahead pass belong to the previous wave model
+    drop_lookahead_excitation(c);
     HC_HIP(hipDeviceSynchronize());  // the tables replaced below may be in use by steps on a caller's stream
     require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
     require(pp, HC_ERR_INVALID, "null parameters");

@@ -4,7 +4,8 @@ caller's stepping pattern (uniform stretches on random step sizes -- equal to, b
 repeated times = cache hits), the wave model (none / regular / irregular), the convolution mode (Baseline / TaperedDirect), the look-ahead
 depth (0 / 16 / 32), the pass schedule (adaptive / at block start / one block ahead, with the size floor off), the sub-block size of the
 two-level form (default / 0 / 4 / 8), direct dispatch or HIP launches, one context or 2-3 row shards behind hc_step_multi, a pre-filled
-history or a cold start, gravity.  Every step's total and its three components against the oracle, each at 1e-9 relative to its own largest
+history or a cold start, gravity -- and, between two steps now and then, a change of depth / schedule / wave model / taper options, the kept
+history taken out and injected again, or an added-mass product.  Every step's total and its three components against the oracle, each at 1e-9 relative to its own largest
 entry; a failure prints the case's seed and stops.   python profiles/fuzz_parity.py [seconds = 300] [first seed = 1]"""
 import os
 import sys
@@ -69,19 +70,21 @@ def one_case(seed):
         for h in (gpu, orc):
             h.set_convolution_mode(1)
             h.set_tapered_direct_options(**opts)
-    if wave == "none":
-        for h in (gpu, orc):
-            h.add_waves_none()
-    elif wave == "regular":
-        amp, om = float(rng.uniform(0.1, 1.0)), float(rng.uniform(0.1, 0.045 * nw))  # inside the BEM frequency list (0.05 .. 0.05 nw)
-        for h in (gpu, orc):
-            h.add_waves_regular(amp, om)
-    else:
-        kw = dict(simulation_dt=base_dt, simulation_duration=dur, ramp_duration=float(rng.choice([0.0, 2.0])), wave_height=float(rng.uniform(0.5, 3.0)),
-                  wave_period=float(rng.uniform(5.0, 11.0)), frequency_min=0.02, frequency_max=0.5, nfrequencies=int(rng.choice([16, 64])),
-                  peak_enhancement_factor=float(rng.choice([1.0, 3.3])), seed=int(rng.integers(1, 9)))
-        for h in (gpu, orc):
-            h.add_waves_irregular(**kw)
+    def draw_waves(kind):
+        if kind == "none":
+            for h in (gpu, orc):
+                h.add_waves_none()
+        elif kind == "regular":
+            amp, om = float(rng.uniform(0.1, 1.0)), float(rng.uniform(0.1, 0.045 * nw))  # inside the BEM frequency list (0.05 .. 0.05 nw)
+            for h in (gpu, orc):
+                h.add_waves_regular(amp, om)
+        else:
+            kw = dict(simulation_dt=base_dt, simulation_duration=dur, ramp_duration=float(rng.choice([0.0, 2.0])), wave_height=float(rng.uniform(0.5, 3.0)),
+                      wave_period=float(rng.uniform(5.0, 11.0)), frequency_min=0.02, frequency_max=0.5, nfrequencies=int(rng.choice([16, 64])),
+                      peak_enhancement_factor=float(rng.choice([1.0, 3.3])), seed=int(rng.integers(1, 9)))
+            for h in (gpu, orc):
+                h.add_waves_irregular(**kw)
+    draw_waves(wave)
     gpu.set_lookahead(lookahead)
     gpu.set_pass_schedule(sched)
     gpu.enable_profiling(1 if seed % 4 == 0 else 1000000)  # (the launch counters below: passes are always counted, the per-step launches only when timed)
@@ -112,7 +115,36 @@ def one_case(seed):
             t += d
     times = times[:n_steps]
     worst = 0.0
+    events = 0
+    first = gpu.shards[0] if shards > 1 else gpu
     for k, tt in enumerate(times):
+        if k > 0 and rng.random() < 0.02 and tt > times[k - 1]:
+            # something changes between two force evaluations, at an arbitrary place in a look-ahead block
+            ev = int(rng.integers(0, 6))
+            events += 1
+            if os.environ.get("FUZZ_VERBOSE"):
+                print(f"   event {ev} before step {k} (t = {tt!r})", flush=True)
+            if ev == 0:
+                gpu.set_lookahead(int(rng.choice([0, 16, 32])))
+            elif ev == 1:
+                gpu.set_pass_schedule(int(rng.choice([-1, 0, 1])))
+            elif ev == 2:
+                draw_waves(str(rng.choice(["none", "regular", "irregular"])))
+            elif ev == 3:  # the kept history taken out and injected again into both (a restart from a checkpoint)
+                th_, vh_ = first.get_history()
+                gpu.set_history(th_, vh_)
+                orc.prefill_history(th_, vh_)
+            elif ev == 4 and mode == 1:
+                opts = dict(smoothing=int(rng.choice([0, 1])), window_length=5, rirf_end_time=float(rng.uniform(0.5, 1.0) * span),
+                            taper_start_percent=float(rng.uniform(0.5, 0.9)), taper_end_percent=1.0, taper_final_amplitude=float(rng.choice([0.0, 0.1])))
+                for h in (gpu, orc):
+                    h.set_tapered_direct_options(**opts)
+            else:  # Chrono's added-mass product between two steps (its own queue lane)
+                wv = rng.normal(size=6 * N + 3)
+                rg, ro = gpu.added_mass_mv(np.ones(6 * N + 3), wv, 0.7), orc.added_mass_mv(np.ones(6 * N + 3), wv, 0.7)
+                if not relerr(rg, ro) <= 1e-12:
+                    print(f"FAIL {desc}: added-mass product before step {k}: {relerr(rg, ro):.3e}", flush=True)
+                    return False, desc, worst, None
         st = motion.state(tt)
         fg = gpu.step(tt, *st)
         fo = orc.step(tt, *st)
@@ -127,6 +159,10 @@ def one_case(seed):
         worst = max(worst, e)
         if not e <= TOL:
             print(f"FAIL {desc}: step {k} t {tt!r}: relative error {e:.3e}", flush=True)
+            if os.environ.get("FUZZ_VERBOSE"):
+                for name, a, b in zip(("hs", "rad", "waves"), gpu.components(), orc.components()):
+                    print(f"   {name}: max |gpu - oracle| {np.max(np.abs(a - b)):.3e}, max |oracle| {np.max(np.abs(b)):.3e}")
+                print(f"   total: max |gpu - oracle| {np.max(np.abs(fg - fo)):.3e}, max |oracle| {np.max(np.abs(fo)):.3e}; history kept: gpu {len(first.get_history()[0])}, oracle {orc.history_size()}")
             return False, desc, worst, None
     prof = (gpu.shards[0] if shards > 1 else gpu).profile()
     gpu.close()

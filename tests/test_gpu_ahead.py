@@ -604,3 +604,60 @@ def test_adaptive_schedule_of_a_wide_system_goes_by_the_size_of_its_slice(hydro)
     worst = max(relerr(a, b) for a, b in zip(rows[64], rows[128][:, :6 * 64]))
     print(f"rows shared by the two shards, different schedules: worst relative difference {worst:.2e}")
     assert worst <= 1e-12, worst
+
+
+def test_wave_model_change_while_the_next_blocks_rows_are_made_ahead(hydro, monkeypatch, tuning_build):
+    """Under "one block ahead" the pass of the NEXT block also leaves that block's excitation rows -- computed with the wave model of the
+    moment.  A model that changes in the middle of a block must not reach the next block through them (profiles/fuzz_parity.py, seed 40:
+    it did), whether the pass in the making is complete by then or its last slice -- the one with the excitation work items -- is still
+    to be issued: irregular -> other irregular -> regular -> none -> irregular, each change a few steps into a block, every step and
+    its components against the oracle."""
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_PASS_AHEAD_MIN_MB", "0")
+    case = many_body_case(4, S=191, dt_rirf=0.015, n_exc=65, dt_exc=0.05, nw=40, seed=1040)
+    dt = 0.015
+    for lookahead, slices in ((32, 0), (16, 0), (32, 12)):  # (12 slices: the last one goes out late in the block)
+        gpu, orc = hydro.HydroForces.from_case(case), load_into_oracle(case)
+        kw1 = dict(simulation_dt=dt, simulation_duration=30.0, wave_height=1.5, wave_period=7.0, nfrequencies=32, frequency_min=0.02, frequency_max=0.5, seed=1)
+        kw2 = dict(simulation_dt=dt, simulation_duration=30.0, wave_height=2.6, wave_period=9.5, nfrequencies=64, frequency_min=0.02, frequency_max=0.5, seed=5,
+                   peak_enhancement_factor=3.3)
+        for h in (gpu, orc):
+            h.add_waves_irregular(**kw1)
+        gpu.set_lookahead(lookahead)
+        gpu.set_pass_schedule(1, slices)
+        motion = PrescribedMotion(4, rest_positions(case), seed=40)
+        span = 191 * 0.015
+        nh = int(np.ceil(span / dt)) + 4
+        t0 = span + 1.0
+        th = t0 - dt * np.arange(1, nh + 1)
+        vh = np.stack([motion.velocity6(t) for t in th])
+        gpu.set_history(th, vh)
+        orc.prefill_history(th, vh)
+        n = [0]
+
+        def run(steps):
+            for _ in range(steps):
+                t = t0 + n[0] * dt
+                st = motion.state(t)
+                assert relerr(gpu.step(t, *st), orc.step(t, *st)) <= TIGHT_TOL, f"lookahead {lookahead}, step {n[0]}"
+                for g, o in zip(gpu.components(), orc.components()):
+                    sc = max(float(np.max(np.abs(o))), 1e-300)
+                    assert float(np.max(np.abs(g - o))) / sc <= 1e-9 or float(np.max(np.abs(o))) == 0.0 and not np.any(g), f"lookahead {lookahead}, components of step {n[0]}"
+                n[0] += 1
+        run(2 * lookahead + 5)                      # rows are being made ahead; 4 steps into a block
+        for h in (gpu, orc):
+            h.add_waves_irregular(**kw2)
+        run(lookahead + lookahead // 2)             # through the next block start (the adopted rows) and on
+        for h in (gpu, orc):
+            h.add_waves_regular(0.4, 1.3)
+        run(lookahead + 3)
+        for h in (gpu, orc):
+            h.add_waves_none()
+        run(lookahead + 7)
+        for h in (gpu, orc):
+            h.add_waves_irregular(**kw1)
+        run(2 * lookahead)
+        p = gpu.profile()
+        assert p["ahead_blocks"] >= 4, p
+        gpu.close()

@@ -87,7 +87,7 @@ def one_case(seed):
     draw_waves(wave)
     gpu.set_lookahead(lookahead)
     gpu.set_pass_schedule(sched)
-    gpu.enable_profiling(1 if seed % 4 == 0 else 1000000)  # (the launch counters below: passes are always counted, the per-step launches only when timed)
+    gpu.enable_profiling(1 if (seed % 4 == 0 or os.environ.get('FUZZ_TRACE')) else 1000000)  # (the launch counters below: passes are always counted, the per-step launches only when timed)
     motion = PrescribedMotion(N, rest_positions(case), seed=seed)
     if not cold:
         nh = int(np.ceil(span / base_dt)) + 4
@@ -157,6 +157,11 @@ def one_case(seed):
                 elif np.any(a != 0.0):
                     e = 1.0
         worst = max(worst, e)
+        if os.environ.get("FUZZ_TRACE") and k >= int(os.environ["FUZZ_TRACE"]):
+            pq = first.profile()
+            print(f"   step {k} t {tt!r} dt {tt - times[k - 1] if k else 0.0:.6f} err {e:.2e}; passes {pq['block_kernel_launches']} plain {pq['conv_kernel_launches']} "
+                  f"adopted {pq['ahead_blocks']} slices {pq['ahead_pass_slices']} answers {pq['schedule_blocks_ahead']}/{pq['schedule_blocks_at_start']} "
+                  f"short {pq['mini_pass_launches']} scatters {pq['scatter_kernel_launches']}", flush=True)
         if not e <= TOL:
             print(f"FAIL {desc}: step {k} t {tt!r}: relative error {e:.3e}", flush=True)
             if os.environ.get("FUZZ_VERBOSE"):

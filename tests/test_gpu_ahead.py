@@ -617,13 +617,15 @@ def test_wave_model_change_while_the_next_blocks_rows_are_made_ahead(hydro, monk
     monkeypatch.setenv("HC_PASS_AHEAD_MIN_MB", "0")
     case = many_body_case(4, S=191, dt_rirf=0.015, n_exc=65, dt_exc=0.05, nw=40, seed=1040)
     dt = 0.015
-    for lookahead, slices in ((32, 0), (16, 0), (32, 12)):  # (12 slices: the last one goes out late in the block)
+    for lookahead, slices, start_without_waves in ((32, 0, False), (16, 0, False), (32, 12, False), (32, 0, True)):  # (12 slices: the last one goes out late in the block)
         gpu, orc = hydro.HydroForces.from_case(case), load_into_oracle(case)
         kw1 = dict(simulation_dt=dt, simulation_duration=30.0, wave_height=1.5, wave_period=7.0, nfrequencies=32, frequency_min=0.02, frequency_max=0.5, seed=1)
         kw2 = dict(simulation_dt=dt, simulation_duration=30.0, wave_height=2.6, wave_period=9.5, nfrequencies=64, frequency_min=0.02, frequency_max=0.5, seed=5,
                    peak_enhancement_factor=3.3)
         for h in (gpu, orc):
-            h.add_waves_irregular(**kw1)
+            # (start_without_waves: the first irregular model then arrives in the middle of a block with a pass in the making, and needs
+            # a larger partials buffer than that pass is using -- seed 2037 of the fuzz run)
+            h.add_waves_none() if start_without_waves else h.add_waves_irregular(**kw1)
         gpu.set_lookahead(lookahead)
         gpu.set_pass_schedule(1, slices)
         motion = PrescribedMotion(4, rest_positions(case), seed=40)
@@ -661,3 +663,4 @@ def test_wave_model_change_while_the_next_blocks_rows_are_made_ahead(hydro, monk
         p = gpu.profile()
         assert p["ahead_blocks"] >= 4, p
         gpu.close()
+        orc.close()

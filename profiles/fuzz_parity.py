@@ -5,7 +5,7 @@ repeated times = cache hits), the wave model (none / regular / irregular), the c
 depth (0 / 16 / 32), the pass schedule (adaptive / at block start / one block ahead, with the size floor off), the sub-block size of the
 two-level form (default / 0 / 4 / 8), direct dispatch or HIP launches, one context or 2-3 row shards behind hc_step_multi, a pre-filled
 history or a cold start, gravity -- and, between two steps now and then, a change of depth / schedule / wave model / taper options, the kept
-history taken out and injected again, or an added-mass product.  Every step's total and its three components against the oracle, each at 1e-9 relative to its own largest
+history taken out and injected again, an added-mass product, or a step back in time (a rejected step).  Every step's total and its three components against the oracle, each at 1e-9 relative to its own largest
 entry; a failure prints the case's seed and stops.   python profiles/fuzz_parity.py [seconds = 300] [first seed = 1]"""
 import os
 import sys
@@ -89,12 +89,14 @@ def one_case(seed):
     gpu.set_pass_schedule(sched)
     gpu.enable_profiling(1 if (seed % 4 == 0 or os.environ.get('FUZZ_TRACE')) else 1000000)  # (the launch counters below: passes are always counted, the per-step launches only when timed)
     motion = PrescribedMotion(N, rest_positions(case), seed=seed)
+    log = []  # (t, velocity) of the samples pushed so far, oldest first: what the oracle is rebuilt from after a step back in time
     if not cold:
         nh = int(np.ceil(span / base_dt)) + 4
         th = t0 - base_dt * np.arange(1, nh + 1)
         vh = np.stack([motion.velocity6(t) for t in th])
         gpu.set_history(th, vh)
         orc.prefill_history(th, vh)
+        log = [(float(a), b) for a, b in zip(th[::-1], vh[::-1])]
     # the caller's times
     times, t = [], t0
     while len(times) < n_steps:
@@ -117,10 +119,12 @@ def one_case(seed):
     worst = 0.0
     events = 0
     first = gpu.shards[0] if shards > 1 else gpu
-    for k, tt in enumerate(times):
-        if k > 0 and rng.random() < 0.02 and tt > times[k - 1]:
+    offset, t_prev, rewinds = 0.0, None, 0
+    for k in range(len(times)):
+        tt = times[k] - offset
+        if k > 0 and rng.random() < 0.02 and tt > t_prev:
             # something changes between two force evaluations, at an arbitrary place in a look-ahead block
-            ev = int(rng.integers(0, 6))
+            ev = int(rng.integers(0, 7))
             events += 1
             if os.environ.get("FUZZ_VERBOSE"):
                 print(f"   event {ev} before step {k} (t = {tt!r})", flush=True)
@@ -134,6 +138,18 @@ def one_case(seed):
                 th_, vh_ = first.get_history()
                 gpu.set_history(th_, vh_)
                 orc.prefill_history(th_, vh_)
+                log = [(float(a), b.copy()) for a, b in zip(th_[::-1], vh_[::-1])]
+            elif ev == 6 and k > 5 and len(log) > 8:
+                # a rejected step: the caller comes back at an EARLIER time (at most a few samples back: what the retired-sample slack
+                # of the ring covers exactly); the library drops the newer samples itself, the oracle is rebuilt from the log
+                tt = t_prev - float(rng.uniform(0.3, 2.6)) * max(t_prev - log[-2][0], 1e-4) if log[-1][0] == t_prev else tt
+                if tt < t_prev:
+                    offset = times[k] - tt
+                    while log and log[-1][0] >= tt:
+                        log.pop()
+                    keep = log[-700:]
+                    orc.prefill_history(np.array([a for a, _ in reversed(keep)]), np.stack([b for _, b in reversed(keep)]))
+                    rewinds += 1
             elif ev == 4 and mode == 1:
                 opts = dict(smoothing=int(rng.choice([0, 1])), window_length=5, rirf_end_time=float(rng.uniform(0.5, 1.0) * span),
                             taper_start_percent=float(rng.uniform(0.5, 0.9)), taper_end_percent=1.0, taper_final_amplitude=float(rng.choice([0.0, 0.1])))
@@ -148,6 +164,10 @@ def one_case(seed):
         st = motion.state(tt)
         fg = gpu.step(tt, *st)
         fo = orc.step(tt, *st)
+        if t_prev is None or tt != t_prev:
+            log.append((tt, motion.velocity6(tt)))
+            log = log[-900:]
+        t_prev = tt
         e = relerr(fg, fo)
         if e <= TOL:  # the three components, each relative to ITS OWN largest entry (a radiation error must not hide behind the hydrostatics)
             for a, b in zip(gpu.components(), orc.components()):
@@ -159,7 +179,7 @@ def one_case(seed):
         worst = max(worst, e)
         if os.environ.get("FUZZ_TRACE") and k >= int(os.environ["FUZZ_TRACE"]):
             pq = first.profile()
-            print(f"   step {k} t {tt!r} dt {tt - times[k - 1] if k else 0.0:.6f} err {e:.2e}; passes {pq['block_kernel_launches']} plain {pq['conv_kernel_launches']} "
+            print(f"   step {k} t {tt!r} err {e:.2e}; passes {pq['block_kernel_launches']} plain {pq['conv_kernel_launches']} "
                   f"adopted {pq['ahead_blocks']} slices {pq['ahead_pass_slices']} answers {pq['schedule_blocks_ahead']}/{pq['schedule_blocks_at_start']} "
                   f"short {pq['mini_pass_launches']} scatters {pq['scatter_kernel_launches']}", flush=True)
         if not e <= TOL:
@@ -170,6 +190,9 @@ def one_case(seed):
                 print(f"   total: max |gpu - oracle| {np.max(np.abs(fg - fo)):.3e}, max |oracle| {np.max(np.abs(fo)):.3e}; history kept: gpu {len(first.get_history()[0])}, oracle {orc.history_size()}")
             return False, desc, worst, None
     prof = (gpu.shards[0] if shards > 1 else gpu).profile()
+    if prof["history_rewinds"] != rewinds:
+        print(f"FAIL {desc}: {rewinds} steps back in time, the library counted {prof['history_rewinds']}", flush=True)
+        return False, desc, worst, None
     gpu.close()
     orc.close()
     return True, desc, worst, np.array([prof["block_kernel_launches"], prof["mini_pass_launches"], prof["ahead_blocks"], prof["scatter_kernel_launches"],

@@ -5,7 +5,8 @@ repeated times = cache hits), the wave model (none / regular / irregular), the c
 depth (0 / 16 / 32), the pass schedule (adaptive / at block start / one block ahead, with the size floor off), the sub-block size of the
 two-level form (default / 0 / 4 / 8), direct dispatch or HIP launches, one context or 2-3 row shards behind hc_step_multi, a pre-filled
 history or a cold start, gravity -- and, between two steps now and then, a change of depth / schedule / wave model / taper options, the kept
-history taken out and injected again, an added-mass product, or a step back in time (a rejected step).  Every step's total and its three components against the oracle, each at 1e-9 relative to its own largest
+history taken out and injected again, an added-mass product, a step back in time (a rejected step), a reset of the history or of the profiling stride; in a quarter of the
+unsharded cases a third of the steps go through hc_step_device on a caller's stream.  Every step's total and its three components against the oracle, each at 1e-9 relative to its own largest
 entry; a failure prints the case's seed and stops.   python profiles/fuzz_parity.py [seconds = 300] [first seed = 1]"""
 import os
 import sys
@@ -55,8 +56,12 @@ def one_case(seed):
     cold = rng.random() < 0.3
     os.environ["HC_SUB_BLOCK"] = str(sub)
     os.environ["HC_DIRECT"] = str(direct)
+    os.environ["HC_SLOT_STATE"] = str(int(rng.random() < 0.8))   # the step kernel's state behind its argument block, or in the context's buffer
+    os.environ["HC_MINI_NARROW"] = str(int(rng.random() < 0.7))  # narrow / wide form of the short passes
+    slices = int(rng.choice([0, 0, 1, 3, 7, 12]))
+    dev_mix = shards == 1 and rng.random() < 0.25                # some of the steps through hc_step_device on a caller's stream
     desc = (f"seed {seed}: N {N} S {S} dt_rirf {dt_r} lookahead {lookahead} schedule {sched} sub {sub} direct {direct} shards {shards} "
-            f"waves {wave} mode {mode} cold {int(cold)}")
+            f"waves {wave} mode {mode} cold {int(cold)} slices {slices} dev {int(dev_mix)} slot {os.environ['HC_SLOT_STATE']} narrow {os.environ['HC_MINI_NARROW']}")
     gpu = HydroGroup.from_case(case, shards) if shards > 1 else HydroForces.from_case(case)
     orc = load_into_oracle(case)
     base_dt = float(rng.choice([dt_r, dt_r, 0.7 * dt_r, 1.3 * dt_r, 0.5 * dt_r, 0.01]))
@@ -86,7 +91,7 @@ def one_case(seed):
                 h.add_waves_irregular(**kw)
     draw_waves(wave)
     gpu.set_lookahead(lookahead)
-    gpu.set_pass_schedule(sched)
+    gpu.set_pass_schedule(sched, slices)
     gpu.enable_profiling(1 if (seed % 4 == 0 or os.environ.get('FUZZ_TRACE')) else 1000000)  # (the launch counters below: passes are always counted, the per-step launches only when timed)
     motion = PrescribedMotion(N, rest_positions(case), seed=seed)
     log = []  # (t, velocity) of the samples pushed so far, oldest first: what the oracle is rebuilt from after a step back in time
@@ -120,11 +125,14 @@ def one_case(seed):
     events = 0
     first = gpu.shards[0] if shards > 1 else gpu
     offset, t_prev, rewinds = 0.0, None, 0
+    if dev_mix:
+        stream = torch.cuda.Stream()
+        d_out = torch.zeros(6 * N, dtype=torch.float64, device="cuda")
     for k in range(len(times)):
         tt = times[k] - offset
         if k > 0 and rng.random() < 0.02 and tt > t_prev:
             # something changes between two force evaluations, at an arbitrary place in a look-ahead block
-            ev = int(rng.integers(0, 7))
+            ev = int(rng.integers(0, 9))
             events += 1
             if os.environ.get("FUZZ_VERBOSE"):
                 print(f"   event {ev} before step {k} (t = {tt!r})", flush=True)
@@ -139,6 +147,12 @@ def one_case(seed):
                 gpu.set_history(th_, vh_)
                 orc.prefill_history(th_, vh_)
                 log = [(float(a), b.copy()) for a, b in zip(th_[::-1], vh_[::-1])]
+            elif ev == 7:  # the history thrown away on both sides: a cold start in the middle of a run
+                gpu.reset_history()
+                orc.prefill_history(np.zeros(0), np.zeros((0, 6 * N)))
+                log = []
+            elif ev == 8:
+                gpu.enable_profiling(int(rng.choice([1, 3, 1000000])))
             elif ev == 6 and k > 5 and len(log) > 8:
                 # a rejected step: the caller comes back at an EARLIER time (at most a few samples back: what the retired-sample slack
                 # of the ring covers exactly); the library drops the newer samples itself, the oracle is rebuilt from the log
@@ -162,7 +176,14 @@ def one_case(seed):
                     print(f"FAIL {desc}: added-mass product before step {k}: {relerr(rg, ro):.3e}", flush=True)
                     return False, desc, worst, None
         st = motion.state(tt)
-        fg = gpu.step(tt, *st)
+        if dev_mix and rng.random() < 0.3:
+            d_st = torch.tensor(motion.packed(tt), device="cuda")
+            torch.cuda.synchronize()
+            gpu.step_device(tt, d_st.data_ptr(), d_out.data_ptr(), stream.cuda_stream)
+            stream.synchronize()
+            fg = d_out.cpu().numpy()
+        else:
+            fg = gpu.step(tt, *st)
         fo = orc.step(tt, *st)
         if t_prev is None or tt != t_prev:
             log.append((tt, motion.velocity6(tt)))

@@ -46,6 +46,8 @@ def one_case(seed):
         N, S = int(rng.choice([28, 30, 32, 36, 40])), int(rng.integers(1000, 1150))  # 8 (6N)^2 S >= 256 MB
     elif rng.random() < float(os.environ.get("FUZZ_WIDE", "0.02")):  # now and then (FUZZ_WIDE=1: always) a genuinely wide system (6N >= 1024: column slices, fused wide step, two-level form by default)
         N, S = int(rng.choice([171, 172, 176, 180, 192, 200])), int(rng.integers(12, 48) if rng.random() < 0.3 else rng.integers(70, 110))  # (S >= 70: room for look-ahead blocks)
+    if os.environ.get("FUZZ_SHARDS") and N < 3:  # (FUZZ_SHARDS=1: every case behind hc_step_multi, 2-4 row shards)
+        N = int(rng.choice([3, 4, 5, 8, 9]))
     dt_r = float(rng.choice([0.01, 0.015, 0.02, 0.0125]))
     n_exc = int(rng.choice([21, 33, 65]))
     nw = int(rng.choice([16, 40]))
@@ -57,6 +59,8 @@ def one_case(seed):
     sub = int(rng.choice([-1, -1, 0, 4, 8]))
     direct = int(rng.random() < 0.7)
     shards = int(rng.choice([1, 1, 1, 2, 3])) if N >= 3 else 1
+    if os.environ.get("FUZZ_SHARDS"):
+        shards = int(rng.choice([2, 3, 4])) if N >= 4 else 2
     wave = str(rng.choice(["none", "regular", "irregular", "irregular"]))
     mode = int(rng.random() < 0.2)  # 1: TaperedDirect
     cold = rng.random() < 0.3
@@ -70,7 +74,7 @@ def one_case(seed):
             f"waves {wave} mode {mode} cold {int(cold)} slices {slices} dev {int(dev_mix)} slot {os.environ['HC_SLOT_STATE']} narrow {os.environ['HC_MINI_NARROW']}")
     gpu = HydroGroup.from_case(case, shards) if shards > 1 else HydroForces.from_case(case)
     orc = load_into_oracle(case)
-    base_dt = float(rng.choice([dt_r, dt_r, 0.7 * dt_r, 1.3 * dt_r, 0.5 * dt_r, 0.01]))
+    base_dt = float(rng.choice([dt_r, dt_r, dt_r, 0.7 * dt_r, 1.3 * dt_r, 0.5 * dt_r, 0.01, 0.2 * dt_r, 3.0 * dt_r]))  # (0.2: the ring grows; 3.0: blocks would span the window)
     n_steps = int(rng.integers(150, 420)) if N < 20 else int(rng.integers(80, 160))
     span = S * dt_r
     t0 = 0.0 if cold else span + 1.0 + float(rng.uniform(0, 1))

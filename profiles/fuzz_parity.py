@@ -5,7 +5,8 @@ repeated times = cache hits), the wave model (none / regular / irregular), the c
 depth (0 / 16 / 32), the pass schedule (adaptive / at block start / one block ahead, with the size floor off), the sub-block size of the
 two-level form (default / 0 / 4 / 8), direct dispatch or HIP launches, one context or 2-3 row shards behind hc_step_multi, a pre-filled
 history or a cold start, gravity -- and, between two steps now and then, a change of depth / schedule / wave model / taper options, the kept
-history taken out and injected again, an added-mass product, a step back in time (a rejected step), a reset of the history or of the profiling stride; in a quarter of the
+history taken out and injected again, an added-mass product, a step back in time (a rejected step), a reset of the history or of the profiling stride, the
+diagnostic entry points (hc_compute_hydrostatics / hc_compute_waves), a switch Baseline <-> TaperedDirect; in a quarter of the
 unsharded cases a third of the steps go through hc_step_device on a caller's stream.  Every step's total and its three components against the oracle, each at 1e-9 relative to its own largest
 entry; a failure prints the case's seed and stops.   python profiles/fuzz_parity.py [seconds = 300] [first seed = 1]"""
 import os
@@ -142,7 +143,7 @@ def one_case(seed):
         tt = times[k] - offset
         if k > 0 and rng.random() < 0.02 and tt > t_prev:
             # something changes between two force evaluations, at an arbitrary place in a look-ahead block
-            ev = int(rng.integers(0, 9))
+            ev = int(rng.integers(0, 11))
             events += 1
             if os.environ.get("FUZZ_VERBOSE"):
                 print(f"   event {ev} before step {k} (t = {tt!r})", flush=True)
@@ -157,6 +158,25 @@ def one_case(seed):
                 gpu.set_history(th_, vh_)
                 orc.prefill_history(th_, vh_)
                 log = [(float(a), b.copy()) for a, b in zip(th_[::-1], vh_[::-1])]
+            elif ev == 9 and shards == 1 and k > 0:
+                # the diagnostic entry points in the middle of a block: the hydrostatic and wave terms alone, for the state / time of the
+                # step before -- they must reproduce that step's components and leave the look-ahead state alone
+                st_p = motion.state(t_prev)
+                hs_d, wv_d = gpu.compute_hydrostatics(st_p[0], st_p[1]), gpu.compute_waves(t_prev)
+                hs_o, _, wv_o = orc.components()
+                for nm, a_, b_ in (("hydrostatics", hs_d, hs_o), ("waves", wv_d, wv_o)):
+                    sc = float(np.max(np.abs(b_)))
+                    if (sc > 0.0 and float(np.max(np.abs(a_ - b_))) / sc > TOL) or (sc == 0.0 and np.any(a_ != 0.0)):
+                        print(f"FAIL {desc}: hc_compute_{nm} before step {k}", flush=True)
+                        return False, desc, worst, None
+            elif ev == 10:  # Baseline <-> TaperedDirect in the middle of a run
+                mode = 1 - mode
+                opts = dict(smoothing=int(rng.choice([0, 1])), window_length=5, rirf_end_time=float(rng.uniform(0.5, 1.0) * span),
+                            taper_start_percent=float(rng.uniform(0.5, 0.9)), taper_end_percent=1.0, taper_final_amplitude=float(rng.choice([0.0, 0.1])))
+                for h in (gpu, orc):
+                    h.set_convolution_mode(mode)
+                    if mode == 1:
+                        h.set_tapered_direct_options(**opts)
             elif ev == 7:  # the history thrown away on both sides: a cold start in the middle of a run
                 gpu.reset_history()
                 orc.prefill_history(np.zeros(0), np.zeros((0, 6 * N)))

@@ -259,7 +259,7 @@ def run_group_sync(N, G, devices, sdt, lookahead, warm, steps, motion=None):
 def c4_rank_share(sdt, lookahead):
     """What ONE rank of C4/8 does, on this GPU: the rows of bodies [0, 64) of the coupled 512-body array (K slice 9.66 GB),
     synchronous hc_step.  A driver-run figure for multi-GPU readiness while no 8-GPU node is available.  ms_per_step is measured
-    under the library's DEFAULT pass schedule (adaptive; for a wide system that is "one block ahead" at every caller gap) after a
+    under the library's DEFAULT pass schedule (adaptive; for a wide system with at most 12 GB of K in the context that is "one block ahead" at every caller gap) after a
     run-in of three blocks -- the first block under a new schedule runs two passes, its own and the next one's -- and each pinned
     schedule follows, back to back and with 300 us of host work between the calls."""
     from hydrochrono_amd.mock_chrono import PrescribedMotion

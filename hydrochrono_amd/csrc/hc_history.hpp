@@ -62,9 +62,12 @@ inline HistoryAdvance history_advance(std::deque<double>& times, std::deque<doub
         times.pop_back();
     }
     r.H = static_cast<int>(times.size());
-    // retired samples live in the slots behind the oldest kept one for as long as the ring has room
-    while (!retired.empty() && (static_cast<int>(retired.size()) > kRewindSlack || r.H + static_cast<int>(retired.size()) > Hcap)) retired.pop_back();
-    if (r.H > Hcap) {
+    // Retired samples live in the slots behind the oldest kept one: the newest kRewindSlack of them, and the ring makes room for them --
+    // a caller whose step is well below the IRF spacing keeps more samples than the IRF has (H ~ S * dt_rirf / dt), and a ring that was
+    // just large enough for those had no slot left for a retired one: a step back in time then found nothing to re-admit and the
+    // oldest bracket of the window was missing (profiles/fuzz_parity.py, seed 1000148: 0.5 % of the radiation force).
+    while (static_cast<int>(retired.size()) > kRewindSlack) retired.pop_back();
+    if (r.H + static_cast<int>(retired.size()) > Hcap) {
         r.grow      = true;
         r.grow_need = r.H + kRewindSlack;
         r.grow_have = r.H - 1 + static_cast<int>(retired.size());

@@ -380,8 +380,9 @@ def test_one_block_ahead_with_the_ring_nearly_full(hydro, sub, concurrent, monke
         seen_tight = seen_tight or (sz["Hcap"] == cap0 and sz["Hcap"] - sz["H"] < 32)
     p, sz = gpu.profile(), gpu.sizes()
     assert p["ahead_blocks"] >= 10, p
-    # either the history came within a block of the capacity and the library made room, or it grew earlier for the same reason
-    assert p["ring_grows_for_pass"] >= 1 and sz["Hcap"] > cap0, (p, sz, seen_tight)
+    # the ring was re-allocated under a running block: by the pass's guard, or -- since the ring also keeps room for the samples the prune
+    # rule has retired (a step back in time re-admits them, hc_history.hpp) -- by the history rule before the guard had to
+    assert sz["Hcap"] > cap0, (p, sz, seen_tight)
     assert p["history_rewinds"] == 0
 
 

@@ -97,6 +97,7 @@ def parse():
                     "tests/stub_context.StubShard in place of the GPU contexts -- no physics, no timings worth reading")
     ap.add_argument("--no-small-configs", action="store_true", help="skip the c2_two_body / c5_one_body_2048 / added_mass_mv secondaries (each beside its CPU figure)")
     ap.add_argument("--no-c4-one-gpu", action="store_true", help="skip the c4_one_gpu secondary (the whole 512-body array, 77 GB of K, on this GPU)")
+    ap.add_argument("--no-init", action="store_true", help="skip the `init` block (BEMIO ingest of a C3-size file, irregular-wave set-up, TaperedDirect build: each stage timed beside its bound)")
     ap.add_argument("--exchange", choices=["host", "rccl"], default="host",
                     help="N > 1 under a launcher: how every rank gets all force rows each step.  host (default): hc_step on every rank (direct "
                          "dispatch, results on the host) and a host gather through shared-memory result buffers (hc_set_result_buffer); "
@@ -185,10 +186,11 @@ def max_rel_err(a, b):
     return float(np.max(np.max(np.abs(a - b), axis=1) / np.maximum(np.max(np.abs(b), axis=1), 1e-300)))
 
 
-def make_shard(N, b0, b1, device, sdt, duration, lookahead, t_hist, v_hist):
+def make_shard(N, b0, b1, device, sdt, duration, lookahead, t_hist, v_hist, cls=None):
     """One row shard of the synthetic coupled N-body array (K generated in HBM), waves attached, history pre-filled."""
-    from hydrochrono_amd.hydro import HydroForces
-    gpu = HydroForces(N, device=device, body_range=(b0, b1))
+    if cls is None:
+        from hydrochrono_amd.hydro import HydroForces as cls  # noqa: N813
+    gpu = cls(N, device=device, body_range=(b0, b1))
     gpu.synth_fill(20251031, S_RIRF, DT, N_EXC, DT)
     gpu.finalize()
     gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
@@ -205,9 +207,90 @@ def dispatch_info(shards):
             "dispatch_mode_reason": sorted({m[1] for m in modes})}
 
 
-def run_group_sync(N, G, devices, sdt, lookahead, warm, steps, motion=None):
-    """ONE process, G row-shard contexts (devices[g]), `steps` synchronous hc_step_multi calls after `warm` untimed ones
-    (host state in, the gathered 6N forces out on the host).  Returns (dict, forces[steps][6N])."""
+def kterm_mean(units):
+    """Term slots a block step reads on average (one per earlier step of the block whose sample reaches it: (units - 1) / 2)."""
+    return (units - 1) / 2.0
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_rccl_ranks(args, G, ndev):
+    """`python bench.py --gpus G` without a launcher is ONE process (hc_step_multi, host gather): no collective runs in it.  So that the
+    same command also answers "did RCCL see G ranks", this process -- BEFORE it makes a single GPU call -- starts the launcher form as a
+    child (`python -m torch.distributed.run --nproc-per-node G bench.py --exchange rccl --no-secondary`, one rank per GPU, all-gather
+    of the force rows over RCCL every step), waits for it and attaches its line.  With fewer GPUs than ranks the child runs in the
+    functional mode (HC_BENCH_SHARE_GPU=1: all ranks on device 0, rows over gloo)."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    if ndev < G:
+        env["HC_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={G}", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__), "--gpus", str(G), "--steps", str(args.steps), "--warmup", str(args.warmup), "--exchange", "rccl", "--no-secondary",
+           "--lookahead", str(args.lookahead), "--step-dt", str(args.step_dt)] + (["--bodies", str(args.bodies)] if args.bodies else []) + (
+               ["--stub-context"] if args.stub_context else [])
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("HC_BENCH_CHILD_TIMEOUT_S", "1500")))
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"the launcher child did not finish: {e}", "command": " ".join(cmd[1:])}
+    line = None
+    for ln in reversed(r.stdout.strip().splitlines()):
+        if ln.startswith("{"):
+            try:
+                line = json.loads(ln)
+                break
+            except Exception:  # noqa: BLE001
+                continue
+    if line is None:
+        return {"error": "the launcher child printed no JSON line", "returncode": r.returncode, "stderr_tail": r.stderr[-600:], "command": " ".join(cmd[1:])}
+    keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "median_ms_per_step", "passes_in_timed_region", "exchange", "exchange_check",
+            "collective_backend", "collective_world_size", "rccl_world_size", "per_rank_ms_per_step", "pass_schedule_pinned_for_all_ranks", "note", "stub_context")
+    out = {k: line[k] for k in keep if k in line}
+    out["per_rank"] = [{k: r_[k] for k in ("rank", "device", "rows", "ms_per_step_own_loop", "median_ms_per_step", "passes_in_timed_region") if k in r_}
+                       for r_ in line.get("per_rank", [])]
+    out["wall_seconds"] = time.perf_counter() - t0
+    out["command"] = "python -m torch.distributed.run --nnodes=1 --nproc-per-node=%d ... bench.py --gpus %d --exchange rccl --no-secondary" % (G, G)
+    out["functional_mode_one_device"] = ndev < G
+    return out
+
+
+def block_alignment(lookahead, warm, steps):
+    """Untimed steps in front of the warm-up that put a look-ahead block boundary into the middle of the timed region (one look-ahead
+    pass serves a block and is paid by the first step of the next: a short region could fall between two passes)."""
+    if lookahead <= 0:
+        return 0
+    Lb = 16 if lookahead <= 16 else 32
+    first = warm + steps // 2
+    return ((first + Lb - 1) // Lb) * Lb - first
+
+
+def shard_view(p, nst, rows, b0, b1, device):
+    """One shard's kernel split over the timed region (hc_profile_stats deltas): the `per_rank` schema of the launcher lines."""
+    pass_s = p["block_kernel_seconds"] / max(1, p["block_kernel_launches"])
+    return {"bodies": [b0, b1], "device": device, "rows": rows,
+            "kernel_us_per_step": {"pass": p["block_kernel_seconds"] / nst * 1e6, "short_passes": p["mini_pass_seconds"] / nst * 1e6,
+                                   "scatter": p["scatter_kernel_seconds"] / nst * 1e6, "step_kernels": p["step_kernel_seconds"] / nst * 1e6,
+                                   "note": "the per-step launches are sampled (every 17th step), every pass is timed"},
+            "passes_in_timed_region": int(p["block_kernel_launches"]), "blocks_with_rows_made_ahead": int(p["ahead_blocks"]),
+            "pass_us_per_launch": pass_s * 1e6, "pass_bytes_once": p["block_kernel_bytes_once"],
+            "pass_frac_of_hbm_peak": (p["block_kernel_bytes_once"] / pass_s / 1e9 / HBM_PEAK_GBS) if pass_s > 0 else None,
+            "doorbell_offset_us_mean": (1e6 * p["multi_doorbell_offset_sum"] / p["multi_calls"]) if p["multi_calls"] else None,
+            "aql_dispatches": int(p["direct_dispatches"]), "hip_launches": int(p["hip_launches"])}
+
+
+def run_group_sync(N, G, devices, sdt, lookahead, warm, steps, motion=None, check_steps=0, stub_cls=None):
+    """ONE process, G row-shard contexts (devices[g]), `steps` synchronous hc_step_multi calls after an alignment stretch and `warm`
+    untimed ones (host state in, the gathered 6N forces out on the host).  check_steps > 0: afterwards a SECOND set of shard contexts
+    (same data, same history) takes the first check_steps states one shard at a time through its own hc_step, and the rows must be
+    those hc_step_multi gathered (`exchange_check`).  Returns (dict, forces[steps][6N])."""
     from hydrochrono_amd import capi
     from hydrochrono_amd.hydro import HydroGroup
     from hydrochrono_amd.mock_chrono import PrescribedMotion
@@ -216,15 +299,28 @@ def run_group_sync(N, G, devices, sdt, lookahead, warm, steps, motion=None):
     nhist = int(np.ceil(S_RIRF * DT / sdt)) + 5
     t_hist = T0 - sdt * np.arange(1, nhist + 1)
     v_hist = np.stack([motion.velocity6(t) for t in t_hist])
-    n_all = warm + steps
+    align = block_alignment(lookahead, warm, steps)
+    pre = align + warm
+    n_all = pre + steps
     duration = max(WAVES["simulation_duration"], T0 + (n_all + 8) * sdt + 5.0)
-    shards = [make_shard(N, *body_shard(N, G, g), devices[g], sdt, duration, lookahead, t_hist, v_hist) for g in range(G)]
-    grp = HydroGroup(shards)
+    bounds = [body_shard(N, G, g) for g in range(G)]
+    shards = [make_shard(N, *bounds[g], devices[g], sdt, duration, lookahead, t_hist, v_hist, cls=stub_cls) for g in range(G)]
     times = [T0 + k * sdt for k in range(n_all)]
     states = np.ascontiguousarray(np.stack([motion.packed(t) for t in times]))
     forces = np.zeros((n_all, 6 * N))
     n3 = 3 * N
-    step = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(("hc_step_multi", capi.load()))
+    if stub_cls is None:
+        grp = HydroGroup(shards)
+        ctxs = grp._ctxs
+        step = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(("hc_step_multi", capi.load()))
+    else:
+        grp, ctxs = None, None  # (CPU rehearsal, tests only: the stub shards one after the other stand in for hc_step_multi)
+
+        def step(_c, _g, t, p_pos, p_rpy, p_lin, p_ang, out_addr):
+            for h in shards:
+                h.begin_raw(h.ctx, t, p_pos, p_rpy, p_lin, p_ang)
+                h.end_raw(h.ctx, out_addr + 8 * 6 * h.b0)
+            return 0
     sp = [states.ctypes.data + k * states.strides[0] for k in range(n_all)]
     fp = [forces.ctypes.data + k * forces.strides[0] for k in range(n_all)]
     per = np.zeros(n_all)
@@ -233,27 +329,54 @@ def run_group_sync(N, G, devices, sdt, lookahead, warm, steps, motion=None):
     def run(k0, k1):
         for k in range(k0, k1):
             a = pc()
-            rc = step(grp._ctxs, G, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
+            rc = step(ctxs, G, times[k], sp[k], sp[k] + 8 * n3, sp[k] + 16 * n3, sp[k] + 24 * n3, fp[k])
             per[k] = pc() - a
             if rc:
                 raise RuntimeError(capi.load().hc_last_error(shards[0].ctx).decode())
 
-    run(0, warm)
     for h in shards:
         h.enable_profiling(17)
+    run(0, pre)
+    for h in shards:
         h.reset_profile()
     t0 = pc()
-    run(warm, n_all)
+    run(pre, n_all)
     elapsed = pc() - t0
     profs = [h.profile() for h in shards]
-    info = {"evals_per_s": steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "median_ms_per_step": float(np.median(per[warm:])) * 1e3,
-            "p90_ms_per_step": float(np.percentile(per[warm:], 90)) * 1e3, "steps": steps, "contexts": G, "devices": list(devices),
-            "bodies": N, "lookahead": lookahead,
-            "pass_us_max_over_shards": max(1e6 * p["block_kernel_seconds"] / max(1, p["block_kernel_launches"]) for p in profs),
+    views = [shard_view(profs[g], steps, shards[g].D_local, *bounds[g], devices[g]) for g in range(G)]
+    fr = [v["pass_frac_of_hbm_peak"] for v in views if v["pass_frac_of_hbm_peak"]]
+    info = {"evals_per_s": steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "median_ms_per_step": float(np.median(per[pre:])) * 1e3,
+            "p90_ms_per_step": float(np.percentile(per[pre:], 90)) * 1e3, "max_ms_per_step": float(per[pre:].max()) * 1e3, "steps": steps, "warmup": warm,
+            "alignment_steps": align, "contexts": G, "devices": list(devices), "bodies": N, "lookahead": shards[0].schedule()["lookahead"],
+            "passes_in_timed_region": max(v["passes_in_timed_region"] for v in views),
+            "pass_us_max_over_shards": max(v["pass_us_per_launch"] for v in views),
+            "roofline": {"bound": "hbm", "kernel": "hc::conv_block_kernel (the look-ahead pass of each shard)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac_max_over_shards": max(fr) if fr else None, "frac_min_over_shards": min(fr) if fr else None,
+                         "achieved_max": max(fr) * HBM_PEAK_GBS if fr else None, "achieved_min": min(fr) * HBM_PEAK_GBS if fr else None,
+                         "units_per_launch": shards[0].schedule()["lookahead"],
+                         "note": "per shard: bytes a launch of its pass moves once / mean duration of its launches in the timed region; a pass made one block "
+                                 "ahead goes out in slices (each launch a slice on the CU-masked pass lane): judge those shards by ms_per_step"},
+            "per_shard": views,
             "aql_dispatches": int(sum(p["direct_dispatches"] for p in profs)), "hip_launches": int(sum(p["hip_launches"] for p in profs))}
     info.update(dispatch_info(shards))
-    grp.close()
-    return info, forces[warm:]
+    if grp is not None:
+        grp.close()
+    if check_steps > 0:
+        # the exchange of this mode is the host gather inside hc_step_multi: its rows against each shard's own hc_step on the same states
+        n_chk = min(check_steps, n_all)
+        worst, bitwise = 0.0, True
+        for g in range(G):
+            h = make_shard(N, *bounds[g], devices[g], sdt, duration, lookahead, t_hist, v_hist, cls=stub_cls)
+            own = np.stack([h.step(times[k], *motion.state(times[k])) for k in range(n_chk)])
+            got = forces[:n_chk, 6 * bounds[g][0]:6 * bounds[g][1]]
+            bitwise = bitwise and bool(np.array_equal(own, got))
+            worst = max(worst, max_rel_err(got, own))
+            h.close()
+        info["exchange_check"] = {"rows_of_hc_step_multi_equal_each_shards_own_hc_step": bool(worst <= 1e-12), "bitwise": bitwise, "max_rel_diff": worst,
+                                  "steps_checked": n_chk, "finite": bool(np.isfinite(forces).all()),
+                                  "note": "a second set of shard contexts, each stepped alone through hc_step from the same history; under the adaptive pass "
+                                          "schedule two runs agree to rounding (bitwise with the schedule pinned, tests/test_gpu_multi.py)"}
+    return info, forces[pre:]
 
 
 def c4_rank_share(sdt, lookahead):
@@ -305,6 +428,7 @@ def c4_rank_share(sdt, lookahead):
            "per_step_us": {"pass": p["block_kernel_seconds"] / n_prof * 1e6, "short_passes": p["mini_pass_seconds"] / n_prof * 1e6,
                            "scatter": p["scatter_kernel_seconds"] / n_prof * 1e6, "step_kernels": p["step_kernel_seconds"] / n_prof * 1e6}}
     out.update(dispatch_info([gpu]))
+    out["synth_fill"] = synth_view(gpu)
     # back to back with each schedule pinned (same run-in)
     for name, sched in (("back_to_back_pass_at_block_start", 0), ("back_to_back_pass_one_block_ahead", 1)):
         gpu.set_pass_schedule(sched)
@@ -479,6 +603,172 @@ def added_mass_product():
             "note": "GPU: synchronous hc_added_mass_mv through ctypes (~1 us of interpreter included); CPU: the oracle's loop, -O2, one thread"}
 
 
+PCIE_GEN5_X16_GBS = 63.0  # what a x16 PCIe 5.0 link carries (MI355X_MICROARCH.md: host link); the pinned-copy rate of this box is measured live
+
+
+def _rate(nbytes, sec):
+    return (nbytes / sec / 1e9) if sec and sec > 0 else None
+
+
+def _ingest_view(st, file_bytes=None):
+    """hc_init_stats of a context as GB/s per stage, each beside its bound."""
+    out = {"rirf_h2d": {"seconds": st["rirf_h2d_seconds"], "bytes": st["rirf_h2d_bytes"], "GBps": _rate(st["rirf_h2d_bytes"], st["rirf_h2d_seconds"]),
+                        "bound": "PCIe host link (pageable source: the runtime stages it through pinned buffers)"},
+           "relayout_rirf_kernel": {"seconds": st["rirf_relayout_seconds"], "bytes_read_and_written": st["rirf_relayout_bytes"],
+                                    "GBps": _rate(st["rirf_relayout_bytes"], st["rirf_relayout_seconds"]),
+                                    "frac_of_hbm_peak": (_rate(st["rirf_relayout_bytes"], st["rirf_relayout_seconds"]) or 0.0) / HBM_PEAK_GBS, "bound": "hbm"},
+           "hc_finalize": {"seconds": st["finalize_seconds"], "of_which_direct_dispatch_setup_and_selftests": st["direct_setup_seconds"]}}
+    if st["h5_read_seconds"] > 0:
+        out["hdf5_read"] = {"seconds": st["h5_read_seconds"], "bytes": st["h5_read_bytes"], "GBps": _rate(st["h5_read_bytes"], st["h5_read_seconds"]),
+                            "file_bytes": file_bytes, "bound": "libhdf5 contiguous dataset reads from the page cache (the file was written a moment ago)"}
+    return out
+
+
+def _wave_view(st, oracle_s=None):
+    nt, nf = st["wave_eta_samples"], st["wave_eta_components"]
+    out = {"total_seconds": st["wave_total_seconds"], "resample_excitation_irf_seconds": st["wave_resample_seconds"],
+           "spectrum_phases_wavenumber_seconds": st["wave_spectrum_seconds"],
+           "eta_synthesis": {"seconds": st["wave_eta_seconds"], "mode": "rocFFT chirp-z" if st["wave_eta_mode"] == 1 else "direct FP64 sum (eta_kernel)",
+                             "nt": int(nt), "nf": int(nf), "component_evaluations_per_s": (nt * nf / st["wave_eta_seconds"]) if st["wave_eta_seconds"] > 0 else None},
+           "uploads_and_kex_relayout": {"seconds": st["wave_upload_seconds"], "bytes": st["wave_upload_bytes"]}}
+    if oracle_s is not None:
+        out["cpu_oracle_seconds_one_thread"] = oracle_s
+    return out
+
+
+def synth_view(gpu):
+    """hc_synth_fill of a context: the generator kernel writes K once (counter-based values computed in registers)."""
+    st = gpu.init_stats()
+    gb = _rate(st["synth_bytes"], st["synth_seconds"])
+    return {"synth_rirf_kernel_seconds": st["synth_seconds"], "bytes_written": st["synth_bytes"], "GBps": gb, "frac_of_hbm_peak": (gb or 0.0) / HBM_PEAK_GBS,
+            "bound": "hbm (write stream)", "hc_finalize_seconds": st["finalize_seconds"]}
+
+
+def _diff_stats(b, a):
+    return {k: (b[k] - a[k]) if k.endswith(("_seconds", "_bytes")) else b[k] for k in b}
+
+
+def init_block(case, c3_wave_stats, sdt, duration):
+    """The INIT half of the path, timed stage by stage beside its bound and beside the CPU oracle's init (SURVEY 7 hard part (vii)):
+    (a) hc_load_bemio_h5 of a C3-size BEMIO file written to /tmp by the committed generator (tests/golden/make_multibody_bemio.py), forces
+    checked bitwise against the raw-setter ingest of the same arrays; (b) hc_set_wave_irregular at C3 (direct sum and rocFFT) and at the
+    sphere-irregular size (nt 56 668 x nf 1 000); (c) the TaperedDirect build at C3.  (d), hc_synth_fill at C4, rides in c4_one_gpu."""
+    import importlib.util
+    import tempfile
+    import torch
+    import oracle as orc_mod
+    from cases import load_into_oracle
+    from hydrochrono_amd.hydro import HydroForces
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    N = case["N"]
+    out = {}
+    # the host link of THIS box: a pinned 256 MB copy
+    try:
+        hsrc = torch.empty(32 * 1024 * 1024, dtype=torch.float64).pin_memory()
+        ddst = torch.empty_like(hsrc, device="cuda")
+        ddst.copy_(hsrc, non_blocking=True)
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        for _ in range(4):
+            ddst.copy_(hsrc, non_blocking=True)
+        torch.cuda.synchronize()
+        pinned = 4 * hsrc.numel() * 8 / (time.perf_counter() - a) / 1e9
+        del hsrc, ddst
+    except Exception:  # noqa: BLE001
+        pinned = None
+    out["host_link"] = {"pinned_h2d_GBps_measured": pinned, "pcie_gen5_x16_GBps": PCIE_GEN5_X16_GBS}
+    # ---- (a) BEMIO ingest at C3 size ----
+    path = os.path.join(tempfile.gettempdir(), f"hc_bench_c3_{os.getpid()}.h5")
+    ing = {}
+    try:
+        spec = importlib.util.spec_from_file_location("make_multibody_bemio", os.path.join(ROOT, "tests", "golden", "make_multibody_bemio.py"))
+        mm = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mm)
+        a = time.perf_counter()
+        mm.write_bemio(case, [(path, False)])
+        ing["file"] = {"bytes": os.path.getsize(path), "written_in_seconds": time.perf_counter() - a,
+                       "generator": "tests/golden/make_multibody_bemio.py: write_bemio (the arrays of the C3 case; datasets of src/h5fileinfo.cpp:41-90)"}
+        a = time.perf_counter()
+        g = HydroForces(N)
+        g.load_bemio_h5(path)
+        t_load = time.perf_counter() - a
+        g.finalize()
+        t_all = time.perf_counter() - a
+        st_file = g.init_stats()
+        ing["hc_load_bemio_h5"] = {"seconds": t_load, "then_hc_finalize_seconds": t_all - t_load, **_ingest_view(st_file, ing["file"]["bytes"])}
+        a = time.perf_counter()
+        ref = HydroForces.from_case(case)
+        t_raw = time.perf_counter() - a
+        ing["raw_setters_same_arrays"] = {"seconds_including_finalize": t_raw, **_ingest_view(ref.init_stats())}
+        a = time.perf_counter()
+        orc = load_into_oracle(case)
+        ing["cpu_oracle_ingest_seconds"] = time.perf_counter() - a
+        ing["cpu_oracle_ingest_note"] = "the oracle's setters + construct(): rho / rho*g scaling and the nested-vector copies of the reference's H5FileInfo, no file I/O"
+        # same forces from the file as from the arrays, bit for bit
+        motion = PrescribedMotion(N, rest_positions(case), seed=7)
+        for h in (g, ref):
+            h.add_waves_regular(0.5, 0.8)
+        same = True
+        for k in range(24):
+            st = motion.state(0.01 * (k + 1))
+            same = same and bool(np.array_equal(g.step(0.01 * (k + 1), *st), ref.step(0.01 * (k + 1), *st)))
+        ing["forces_from_file_bitwise_equal_to_raw_setters"] = {"steps": 24, "equal": same}
+        out["bemio_ingest_c3"] = ing
+        # ---- (b) irregular waves at C3: the main context's own call (direct sum) and the rocFFT form on the context read from the file ----
+        waves = {"c3_direct_sum": _wave_view(c3_wave_stats)}
+        kw = dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration)
+        s0 = g.init_stats()
+        g.set_eta_synthesis(1)
+        g.add_waves_irregular(**kw)
+        waves["c3_rocfft"] = _wave_view(_diff_stats(g.init_stats(), s0))
+        orc_mod.set_num_threads(1)
+        a = time.perf_counter()
+        orc.add_waves_irregular(**{k: v for k, v in kw.items() if k != "num_bodies"})
+        waves["c3_direct_sum"]["cpu_oracle_seconds_one_thread"] = time.perf_counter() - a
+        g.close()
+        del orc
+        # ---- (c) TaperedDirect build at C3 (the first step under the mode runs taper_kernel over all of K) ----
+        ref.set_convolution_mode(1)
+        st = motion.state(0.01 * 26)
+        ref.step(0.01 * 26, *st)
+        sr = ref.init_stats()
+        gb = _rate(sr["taper_bytes"], sr["taper_seconds"])
+        out["tapered_direct_build_c3"] = {"taper_kernel_seconds": sr["taper_seconds"], "bytes_read_and_written": sr["taper_bytes"], "GBps": gb,
+                                          "frac_of_hbm_peak": (gb or 0.0) / HBM_PEAK_GBS, "bound": "hbm",
+                                          "note": "SG-5 smoothing + half-cosine taper of every (row, column) series (src/hydro_forces.cpp:385-535), K read once and written once"}
+        ref.close()
+    except Exception as e:  # noqa: BLE001
+        out["bemio_ingest_c3"] = {**ing, "error": str(e)}
+        waves = {"c3_direct_sum": _wave_view(c3_wave_stats)}
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    # ---- (b') the sphere-irregular size: one body, nt 56 668, nf 1 000 (src/wave_types.cpp:717-774; demos/sphere irregular) ----
+    try:
+        c1 = many_body_case(1, S=401, dt_rirf=0.05, n_exc=401, dt_exc=0.05, seed=3)
+        kw1 = dict(simulation_dt=0.015, simulation_duration=850.0, ramp_duration=60.0, wave_height=2.0, wave_period=12.0, frequency_min=0.001,
+                   frequency_max=1.0, nfrequencies=1000, peak_enhancement_factor=1.0, seed=1)
+        for mode, key in ((0, "sphere_irregular_size_direct_sum"), (1, "sphere_irregular_size_rocfft")):
+            h = HydroForces.from_case(c1)
+            h.set_eta_synthesis(mode)
+            s0 = h.init_stats()
+            h.add_waves_irregular(**kw1)
+            waves[key] = _wave_view(_diff_stats(h.init_stats(), s0))
+            h.close()
+        o1 = load_into_oracle(c1)
+        orc_mod.set_num_threads(1)
+        a = time.perf_counter()
+        o1.add_waves_irregular(**kw1)
+        waves["sphere_irregular_size_direct_sum"]["cpu_oracle_seconds_one_thread"] = time.perf_counter() - a
+    except Exception as e:  # noqa: BLE001
+        waves["sphere_irregular_size_error"] = str(e)
+    out["irregular_waves"] = waves
+    return out
+
+
 C4_ONE_GPU_FILES = ("profiles/r05/bench_c4_1gpu.json", "profiles/r04/bench_c4_1gpu.json", "profiles/r03/bench_c4_1gpu.json")
 
 
@@ -542,6 +832,7 @@ def c4_one_gpu(sdt, lookahead):
                            "scatter": p["scatter_kernel_seconds"] / steps * 1e6, "step_kernels": p["step_kernel_seconds"] / steps * 1e6},
            "note": "the one-GPU figure of the workload the --gpus N > 1 lines shard (their c4_one_gpu_reference / speedup_vs_c4_one_gpu)"}
     out.update(dispatch_info([gpu]))
+    out["synth_fill"] = synth_view(gpu)
     gpu.close()
     return out
 
@@ -560,6 +851,11 @@ def main():
     if args.bodies is None:
         args.bodies = N_BODIES_C4 if strong else N_BODIES
 
+    rccl_child = None
+    if single and not args.no_secondary and not args.single_process:
+        # (before this process touches the GPU: the child gets the devices to itself; counting devices does not initialise them)
+        import torch as _t
+        rccl_child = spawn_rccl_ranks(args, args.gpus, args.gpus if args.stub_context else _t.cuda.device_count())
     import torch
     import torch.distributed as dist
     from hydrochrono_amd import capi
@@ -570,7 +866,7 @@ def main():
     stub = bool(args.stub_context)
     if stub:
         # the N > 1 control flow without a GPU: CPU tensors, gloo, tests/stub_context.StubShard instead of the library's contexts
-        if world < 2 or not strong:
+        if (world < 2 and not single) or not strong:
             sys.exit("--stub-context is the CPU rehearsal of the multi-rank (--scaling strong) flow only")
         from stub_context import StubShard
         HydroForces = StubShard  # noqa: N806
@@ -584,16 +880,24 @@ def main():
     if single:
         # ---- ONE process, G contexts, hc_step_multi: the multi-GPU path of a Chrono host through the C ABI ----
         G = args.gpus
-        devices = [g % ndev for g in range(G)]
-        info, _ = run_group_sync(args.bodies, G, devices, sdt, args.lookahead, args.warmup + 32, args.steps)
+        devices = [g % max(1, ndev) for g in range(G)]
+        info, _ = run_group_sync(args.bodies, G, devices, sdt, args.lookahead, args.warmup, args.steps, check_steps=0 if args.no_secondary else 40,
+                                 stub_cls=HydroForces if stub else None)
         out = {"metric": "hydro-force evals/sec (all bodies)", "value": info["evals_per_s"], "unit": "evals/s", "n_gpus": G, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": info["ms_per_step"], "median_ms_per_step": info["median_ms_per_step"],
+               "warmup": args.warmup, "alignment_steps": info["alignment_steps"], "passes_in_timed_region": info["passes_in_timed_region"],
+               "ms_per_step": info["ms_per_step"], "median_ms_per_step": info["median_ms_per_step"],
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"C4-style: ONE coupled synthetic {args.bodies}-body array row-sharded over {G} contexts of ONE process "
                                       f"(devices {devices}; {ndev} visible), one hc_step_multi per step: state stored into every context, "
                                       "all step kernels dispatched, host-side gather of the force rows; no collective",
-                          "bodies": args.bodies, "irf_samples": S_RIRF, "wave_components": WAVES["nfrequencies"], "lookahead": args.lookahead,
+                          "bodies": args.bodies, "irf_samples": S_RIRF, "wave_components": WAVES["nfrequencies"], "lookahead": info["lookahead"],
                           "sharding": "body-row shards, single process, host gather (SURVEY 8e drop-in variant)"},
+               "exchange": "host gather inside hc_step_multi (no collective)",
+               "roofline": info.pop("roofline"), "per_shard": info.pop("per_shard"), "exchange_check": info.pop("exchange_check", None),
+               "cpu_baseline": None,
+               "cpu_baseline_note": "not timed for the sharded workload: the CPU oracle at C4 size (512 bodies, 77 GB of K) does not fit a bounded sample; the N = 1 "
+                                    "line times it on the C3 workload (BASELINE.json's metric)",
+               "rccl_ranks": rccl_child,
                "single_process": info}
         out.update({k: info[k] for k in ("dispatch_mode", "dispatch_mode_reason")})
         if args.bodies == N_BODIES_C4:
@@ -602,7 +906,10 @@ def main():
             if ref1:
                 out["c4_one_gpu_reference"] = ref1
                 out["speedup_vs_c4_one_gpu"] = out["value"] / ref1["evals_per_s"]
-        if ndev < G:
+                out["speedup_note"] = "the reference is a 256-step steady-state run; this line's timed region is aligned to hold its share of passes"
+        if stub:
+            out["stub_context"] = "tests/stub_context.StubShard: the control flow on CPU, no GPU, no physics -- NOT a measurement"
+        elif ndev < G:
             out["note"] = f"only {ndev} GPU(s) visible: contexts share devices (functional run, not a scaling figure)"
         print(json.dumps(out), flush=True)
         return
@@ -638,6 +945,22 @@ def main():
         gpu = HydroForces.from_case(case, device=local_rank)
         motion = PrescribedMotion(N, rest_positions(case), seed=20251031 + rank)
         exchange = None  # independent farms: nothing to exchange
+    gpu.set_lookahead(args.lookahead)
+    eff_lookahead = gpu.schedule()["lookahead"]  # (what this build of the library made of --lookahead: the release library holds 16 and 32)
+    if eff_lookahead != args.lookahead and args.lookahead > 0:
+        if rank == 0:
+            print(f"bench.py: --lookahead {args.lookahead} is not in this build of the library (HYDROCHRONO_AMD_FLAVOR=tuning holds the depth-64 pass): "
+                  f"running depth {eff_lookahead}", file=sys.stderr)
+        args.lookahead = eff_lookahead
+    pinned_schedule = None
+    if world > 1 and strong:
+        # ONE pass schedule for the row shards of one array: under the adaptive default every process would judge its own caller's gaps, the
+        # ranks could answer differently block by block (different summation grouping: rows no longer bitwise those of the unsharded array)
+        # and pay their passes on different steps, while every step waits for the slowest rank.  Rank 0's answer, pinned on all.
+        box = [gpu.schedule()["ahead_now"] if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        pinned_schedule = int(box[0])
+        gpu.set_pass_schedule(pinned_schedule)
     n_steady = args.steady_steps if (world == 1 and not args.no_secondary) else 0
     n_pipe = 0 if (args.no_secondary or world > 1) else args.steps
     n_plain = 0 if (args.no_secondary or world > 1 or args.lookahead == 0) else max(20, args.steps // 8)
@@ -647,7 +970,7 @@ def main():
     # max(1, ~K/lookahead) passes -- pessimistic for K < lookahead, neutral for K >> lookahead.
     align = 0
     if args.lookahead > 0:
-        Lb = 16 if args.lookahead <= 16 else (32 if args.lookahead <= 32 else 64)
+        Lb = 16 if args.lookahead <= 16 else (32 if args.lookahead <= 32 else 64)  # (the depth the library runs, read back above)
         first = args.warmup + args.steps // 2          # earliest step index the boundary (a multiple of Lb) may have
         boundary = ((first + Lb - 1) // Lb) * Lb
         align = boundary - first
@@ -658,7 +981,7 @@ def main():
     # the wave model is built for the caller's step size; the free-surface table must cover every step of this run
     duration = max(WAVES["simulation_duration"], T0 + n_all * sdt + 5.0)
     gpu.add_waves_irregular(**dict(WAVES, num_bodies=N, simulation_dt=sdt, simulation_duration=duration))
-    gpu.set_lookahead(args.lookahead)
+    c3_wave_stats = gpu.init_stats() if (world == 1 and not stub and not strong) else None  # (the `init` block: this call's stages at C3)
     D_local = gpu.D_local
 
     nhist = int(np.ceil(S_RIRF * DT / sdt)) + 5
@@ -1031,6 +1354,34 @@ def main():
             except Exception:
                 traffic = None
         us = lambda sec, n: 1e6 * sec / max(1, n)  # noqa: E731
+        # ---- the WHOLE step against the memory (SURVEY 8d's per-step byte model is superseded: K leaves HBM once per `units` steps) ----
+        step_fig = None
+        if blocked and world == 1 and not strong:
+            per_sample = 8.0 * D_local * 6 * N  # one IRF sample's block of K for this context's rows
+            ratio = sdt / DT
+            reach_mean = (units - 1) / 2.0 * ratio + (0.0 if abs(ratio - 1.0) < 1e-9 else 1.0)  # IRF samples a scatter launch streams, block average
+            n_own = 1 if abs(ratio - 1.0) < 1e-9 else 2
+            parts = {"pass_share": bytes_once / units, "scatter": per_sample * reach_mean, "own_samples_in_the_step_kernel": per_sample * n_own,
+                     "terms_and_rows": 8.0 * (kterm_mean(units) + 4) * D_local}
+            step_bytes = float(sum(parts.values()))
+            mean_s, med_s = ms * 1e-3, float(np.median(timed)) * 1e-3
+            pmc = None
+            ppath = os.path.join(ROOT, "profiles", "r06", "pmc_step_traffic.json")
+            if os.path.exists(ppath):
+                try:
+                    pmc = json.load(open(ppath)).get("hbm_bytes_per_steady_state_step")
+                except Exception:  # noqa: BLE001
+                    pmc = None
+            step_fig = {"bound": "PCIe round trip + the step kernel's dependent chain (profiles/r06/step_stage_clock.txt), not bandwidth",
+                        "step_traffic_bytes": step_bytes, "step_traffic_parts": parts,
+                        "step_traffic_bytes_pmc": pmc, "step_traffic_pmc_source": "profiles/r06/pmc_step_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)" if pmc else None,
+                        "step_GBps_at_mean": step_bytes / mean_s / 1e9, "step_frac_of_hbm_peak_at_mean": step_bytes / mean_s / 1e9 / HBM_PEAK_GBS,
+                        "step_GBps_at_median": step_bytes / med_s / 1e9, "step_frac_of_hbm_peak_at_median": step_bytes / med_s / 1e9 / HBM_PEAK_GBS,
+                        "survey_8d_bytes_per_step": prof_all["conv_kernel_bytes"],
+                        "reuse_over_survey_model": prof_all["conv_kernel_bytes"] / step_bytes,
+                        "note": "algorithmic bytes of ONE steady-state step: the pass's K-once bytes / steps per pass + what the scatter behind the step streams "
+                                "(block average) + the step kernel's own IRF samples + term slots; SURVEY 8d's model (all of K every step) is what "
+                                "plain_per_step_mode runs"}
         out = {
             "metric": "hydro-force evals/sec (all bodies)",
             "value": (1 if strong else world) * args.steps / elapsed,
@@ -1068,6 +1419,10 @@ def main():
                        if (world == 1 and exchange is None and not args.python_loop) else "one hc_step (or begin / gather / end) per Python call"),
             "dispatch_mode": dinfo["dispatch_mode"] if (world == 1 or args.exchange == "host") else "HIP launches on the rank's stream (hc_step_device) + RCCL all-gather",
             "exchange": (args.exchange if world > 1 else None),
+            "pass_schedule_pinned_for_all_ranks": ({0: "at block start", 1: "one block ahead"}.get(pinned_schedule) if pinned_schedule is not None else None),
+            "collective_backend": (dist.get_backend(exchange.group) if exchange is not None else None),
+            "collective_world_size": (dist.get_world_size(exchange.group) if exchange is not None else None),
+            "rccl_world_size": (dist.get_world_size(exchange.group) if (exchange is not None and dist.get_backend(exchange.group) == "nccl") else None),
             "dispatch_mode_reason": dinfo["dispatch_mode_reason"],
             "aql_dispatches": dinfo["aql_dispatches"], "hip_launches": dinfo["hip_launches"],
             "roofline": {
@@ -1084,6 +1439,7 @@ def main():
                 "scatter_kernel_us": us(prof_all["scatter_kernel_seconds"], prof_all["scatter_kernel_launches"]),
                 "fp64_TFLOPs": (2.0 * (bytes_units / 8.0) / conv_s / 1e12) if conv_s > 0 else None,
                 "fp64_frac_of_mfma_peak": (2.0 * (bytes_units / 8.0) / conv_s / 1e12 / FP64_MFMA_PEAK_TF) if conv_s > 0 else None,
+                "whole_step": step_fig,
                 "note": (f"achieved = K-once bytes of a launch / mean duration of every pass of the run (completion signals); a launch serves {units} steps"
                          if units > 1 else "one launch = one step"),
             },
@@ -1131,6 +1487,15 @@ def main():
                     out[key] = fn()
                 except Exception as e:  # a secondary must not cost the run its line
                     out[key] = {"error": str(e)}
+        if world == 1 and not strong and not args.no_secondary and not args.no_init and case is not None and c3_wave_stats is not None:
+            try:
+                gpu.close()
+                out["init"] = init_block(case, c3_wave_stats, sdt, duration)
+                for key in ("c4_one_gpu", "c4_rank_share"):
+                    if isinstance(out.get(key), dict) and "synth_fill" in out[key]:
+                        out["init"].setdefault("synth_fill", {})[key] = out[key]["synth_fill"]
+            except Exception as e:  # a secondary must not cost the run its line
+                out["init"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and case is not None:
             base, f_faithful, flat_threads = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds, sdt, duration)
             n_chk = k_next

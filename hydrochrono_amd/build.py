@@ -24,6 +24,9 @@ BEMIO_LIB = os.path.join(LIBDIR, "libhc_bemio.so")
 
 SOURCES = ["hc_kernels.hip", "hc_runtime.cpp", "hc_step.cpp", "hc_pass.cpp", "hc_setup.cpp", "hc_query.cpp", "hc_direct.cpp", "hc_host_math.cpp", "hc_yaml.cpp",
            "hc_eta_fft.cpp"]
+# kernel-argument preload: the leading scalar / pointer arguments of a kernel arrive in scalar registers with the wave (finalize_pre_kernel,
+# hc_kernels.hip); kernels whose first argument is a struct are unaffected
+PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
 KERNEL_CO = os.path.join(LIBDIR, "hc_kernels.co")  # the same kernels as a stand-alone code object, for the direct AQL dispatch (hc_direct.hpp)
 TUNING_CO = os.path.join(LIBDIR, "hc_kernels_tuning.co")
 HEADERS = ["hc_kernels.hpp", "hc_context.hpp", "hc_internal.hpp", "hc_host_math.hpp", "hc_limits.hpp", "hc_plan.hpp", "hc_history.hpp", "hc_direct.hpp", "hc_fanout.hpp", "hc_h5data.hpp", os.path.join(ROOT, "include", "hydrochrono_amd.h"),
@@ -65,7 +68,7 @@ def _build_flavor(lib, kernel_co, objdir, defines, force, verbose):
     kernel_src = os.path.join(CSRC, "hc_kernels.hip")
     pending = []
     if force or _newer(kernel_co, [kernel_src] + headers):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "--no-gpu-bundle-output", "-Wno-unused-result"] + defines + [
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "--no-gpu-bundle-output", "-Wno-unused-result"] + PRELOAD + defines + [
             "-I", os.path.join(ROOT, "include"), kernel_src, "-o", kernel_co]
         if verbose:
             print(" ".join(cmd))

@@ -48,7 +48,18 @@ class ProfileStats(C.Structure):
                 ("pass_lane_launches", C.c_longlong),
                 ("multi_doorbell_offset_last", C.c_double), ("multi_doorbell_offset_sum", C.c_double), ("multi_calls", C.c_longlong),
                 ("slot_state_steps", C.c_longlong), ("wide_fused_steps", C.c_longlong),
-                ("schedule_blocks_ahead", C.c_longlong), ("schedule_blocks_at_start", C.c_longlong), ("ring_grows_for_pass", C.c_longlong)]
+                ("schedule_blocks_ahead", C.c_longlong), ("schedule_blocks_at_start", C.c_longlong), ("ring_grows_for_pass", C.c_longlong),
+                ("hot_steps", C.c_longlong)]
+
+
+class InitStats(C.Structure):
+    _fields_ = [("h5_read_seconds", C.c_double), ("h5_read_bytes", C.c_double), ("rirf_h2d_seconds", C.c_double), ("rirf_h2d_bytes", C.c_double),
+                ("rirf_relayout_seconds", C.c_double), ("rirf_relayout_bytes", C.c_double), ("finalize_seconds", C.c_double),
+                ("direct_setup_seconds", C.c_double), ("wave_resample_seconds", C.c_double), ("wave_spectrum_seconds", C.c_double),
+                ("wave_eta_seconds", C.c_double), ("wave_eta_samples", C.c_longlong), ("wave_eta_components", C.c_longlong),
+                ("wave_eta_mode", C.c_int), ("pad_", C.c_int), ("wave_upload_seconds", C.c_double), ("wave_upload_bytes", C.c_double),
+                ("wave_total_seconds", C.c_double), ("taper_seconds", C.c_double), ("taper_bytes", C.c_double),
+                ("synth_seconds", C.c_double), ("synth_bytes", C.c_double)]
 
 
 # name -> (restype, argtypes); every symbol include/hydrochrono_amd.h declares
@@ -96,6 +107,7 @@ SIGNATURES = {
     "hc_compute_waves": (C.c_int, [C.c_void_p, C.c_double, c_double_p]),
     "hc_set_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
     "hc_set_pass_schedule": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "hc_get_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "hc_direct_dispatch_active": (C.c_int, [C.c_void_p]),
     "hc_dispatch_mode_reason": (C.c_char_p, [C.c_void_p]),
     "hc_reset_history": (C.c_int, [C.c_void_p]),
@@ -105,6 +117,7 @@ SIGNATURES = {
     "hc_added_mass_mv": (C.c_int, [C.c_void_p, c_double_p, C.c_double, c_double_p, C.c_int]),
     "hc_enable_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hc_get_profile": (C.c_int, [C.c_void_p, C.POINTER(ProfileStats)]),
+    "hc_get_init_stats": (C.c_int, [C.c_void_p, C.POINTER(InitStats)]),
     "hc_reset_profile": (C.c_int, [C.c_void_p]),
     "hc_get_sizes": (C.c_int, [C.c_void_p] + [c_int_p] * 8),
     "hc_get_rirf_width": (C.c_int, [C.c_void_p, c_double_p]),

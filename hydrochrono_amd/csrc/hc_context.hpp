@@ -167,8 +167,13 @@ struct hc_ctx {
     hc::DirectQueue* dq = nullptr;
     bool direct_ready   = false;
     std::string direct_why;  // why the direct path is not in use
+    std::string direct_how = "direct AQL dispatch";  // ... or how it is (where the runtime put the packet ring, hc_dispatch_mode_reason)
     int path            = 0;
     hc::DirectKernel dk_finalize_slot;  // finalize_kernel<4, true>: the body state behind the argument block (hc_step.cpp: HostState)
+    hc::DirectKernel dk_finalize_pre;   // finalize_pre_kernel<4>: the same with its first loads' addresses preloaded into scalar registers
+    bool step_preload = false;          // ... in use for this context (tuning build, HC_STEP_PRELOAD=1: measured and not taken, EXPERIMENTS.md)
+    hc::DirectKernel dk_step_hot[2];    // step_hot_kernel<1>, <2>: the common block step with a compact argument block (hc_kernels.hpp: StepHotArgs)
+    bool step_hot = false;              // ... in use for this context
     bool slot_state = false;            // ... in use for this context (HC_SLOT_STATE, systems of up to kSlotStateMaxBodies bodies)
     hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_block64, dk_mini16, dk_mini32, dk_narrow, dk_wide, dk_added_mass, dk_step, dk_near;
     hc::StepTail tail;
@@ -296,6 +301,16 @@ struct hc_ctx {
     int zero_copy_max_bodies = 64;                // hc_step: kernels read the state from mapped pinned memory up to this size
     hc::PinnedBuffer<int> h_err;
     bool device_errors_possible = false;  // radiation IRF times < 0 (the only way a per-step query can leave its bracket)
+
+#ifdef HC_TUNING
+    // stage clock of the step kernel (HC_STEP_STAMPS=1; hc_tuning_step_stamps): device rows [kStampSteps][kStampWGs][kStampStages] and
+    // the host's own stamps of the same steps {entry of hc_step, doorbell of the step kernel, totals seen}, HSA system ticks
+    bool stamps_on = false;
+    hc::DeviceBuffer<unsigned long long> d_stamps;
+    unsigned long long host_stamps[hc::kStampSteps][4] = {};
+#endif
+
+    hc_init_stats init{};  // what the init half cost, stage by stage (hc_get_init_stats)
 
     // profiling
     bool profiling = false;

@@ -3,6 +3,7 @@
 
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <hsa/amd_hsa_signal.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 #include <unistd.h>
@@ -98,6 +99,10 @@ struct DirectQueue::Impl {
         bool have_drain_sig = false;
         hsa_signal_t gate{};  // what the parked barrier packet of arm() waits for (1: closed, 0: open)
         bool have_gate = false, armed = false;
+        // Tuning experiment (HC_ARM_DEVICE_GATE, EXPERIMENTS.md round 6; null in the shipped library): the same gate once more, as a
+        // signal record of our own in fine-grained DEVICE memory written through the BAR -- the runtime keeps its signals in host memory,
+        // so a packet processor parked on `gate` polls across PCIe.
+        volatile amd_signal_t* dev_gate = nullptr;
     } lanes[DirectQueue::kLanes];
     char* ring_all = nullptr;
     uint64_t ticks_per_second = 0;
@@ -122,6 +127,13 @@ struct DirectQueue::Impl {
         while (idx >= kSlots && hsa_queue_load_read_index_scacquire(queue) + kSlots < idx + 2 && !((++spins & 0xFFFF) == 0 && ln.error.load() != 0)) _mm_pause();
         return idx;
     }
+    static void open_gate(Lane& ln) {
+        if (ln.dev_gate) {  // the record the packet processor polls locally first, then the runtime's
+            ln.dev_gate->value = 0;
+            _mm_sfence();
+        }
+        hsa_signal_store_screlease(ln.gate, 0);
+    }
     void publish(Lane& ln, void* packet, uint16_t header, uint16_t setup, uint64_t idx) {
         hsa_queue_t* queue = ln.queue;
         // header + setup go last, in one 32-bit release store: the packet processor must not see a half-written packet
@@ -135,6 +147,20 @@ namespace {
 // asynchronous queue errors arrive here on a runtime thread (the queue is then inactive: its packets never complete)
 void on_queue_error(hsa_status_t status, hsa_queue_t*, void* data) {
     static_cast<std::atomic<int>*>(data)->store(status == HSA_STATUS_SUCCESS ? -1 : static_cast<int>(status), std::memory_order_release);
+}
+}  // namespace
+
+namespace {
+// 0 (what ships): the parked packet waits for the runtime's signal only.  Tuning build, HC_ARM_DEVICE_GATE=1: a barrier-OR over the
+// runtime's signal and a signal record of our own in device memory; 2: a barrier-AND on the device-side record alone.  Measured in
+// round 6 and not taken (EXPERIMENTS.md): the OR packet is slower than the plain one, not faster.
+int use_device_gate() {
+#ifdef HC_TUNING
+    static const int mode = [] { const char* e = std::getenv("HC_ARM_DEVICE_GATE"); return e ? std::atoi(e) : 0; }();
+    return mode;
+#else
+    return 0;
+#endif
 }
 }  // namespace
 
@@ -155,7 +181,7 @@ DirectQueue::~DirectQueue() {
     for (int l = 0; l < kLanes; ++l) {
         if (p.lanes[l].queue) {
             if (p.lanes[l].armed) {  // open the gate: nothing may stay parked in a queue that is about to go
-                hsa_signal_store_screlease(p.lanes[l].gate, 0);
+                Impl::open_gate(p.lanes[l]);
                 p.lanes[l].armed = false;
                 busy_[l]         = true;
             }
@@ -237,7 +263,8 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
 
     // kernarg ring in device memory the host can store into (same fault-free probe as BarBuffer, hc_runtime.cpp)
     void* q            = nullptr;
-    const size_t bytes = static_cast<size_t>(Impl::kSlots) * kSlotStride * kLanes;
+    const size_t ring_bytes = static_cast<size_t>(Impl::kSlots) * kSlotStride * kLanes;
+    const size_t bytes      = ring_bytes + 4096;  // + one page for the lanes' device-side gate records
     if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
         return fail("no fine-grained device memory for the kernel arguments");
@@ -251,6 +278,16 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
     if (fz >= 0) close(fz);
     if (fn >= 0) close(fn);
     if (!host_ok) return fail("device memory is not host-addressable (no large BAR): kernel arguments cannot be stored directly");
+    if (use_device_gate()) {
+        for (int l = 0; l < kLanes; ++l) {
+            volatile amd_signal_t* g = reinterpret_cast<volatile amd_signal_t*>(p.ring_all + ring_bytes + static_cast<size_t>(l) * 256);
+            std::memset(const_cast<amd_signal_t*>(g), 0, sizeof(amd_signal_t));
+            g->kind  = AMD_SIGNAL_KIND_USER;
+            g->value = 0;
+            p.lanes[l].dev_gate = g;
+        }
+        _mm_sfence();
+    }
     return true;
 }
 
@@ -283,11 +320,20 @@ void DirectQueue::arm(int lane) {
     Impl::Lane& ln = p.lanes[lane];
     if (!ln.queue || !ln.have_gate || ln.armed || failed(lane)) return;
     hsa_signal_store_relaxed(ln.gate, 1);
+    if (ln.dev_gate) {
+        ln.dev_gate->value = 1;
+        _mm_sfence();  // (in device memory before the packet that waits for it)
+    }
     const uint64_t idx = p.reserve(ln);
     auto* pkt = reinterpret_cast<hsa_barrier_and_packet_t*>(ln.queue->base_address) + (idx & (ln.queue->size - 1));
     std::memset(reinterpret_cast<char*>(pkt) + 4, 0, sizeof(*pkt) - 4);
-    pkt->dep_signal[0]    = ln.gate;
-    const uint16_t header = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER);
+    // barrier-AND of one signal, or (tuning experiment) barrier-OR of the two gates: released by whichever opens first
+    const bool dev_only = ln.dev_gate && use_device_gate() == 2;
+    if (dev_only) pkt->dep_signal[0].handle = reinterpret_cast<uint64_t>(ln.dev_gate);
+    else pkt->dep_signal[0] = ln.gate;
+    if (ln.dev_gate && !dev_only) pkt->dep_signal[1].handle = reinterpret_cast<uint64_t>(ln.dev_gate);
+    const uint16_t type   = (ln.dev_gate && !dev_only) ? HSA_PACKET_TYPE_BARRIER_OR : HSA_PACKET_TYPE_BARRIER_AND;
+    const uint16_t header = (type << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER);
     p.publish(ln, pkt, header, 0, idx);
     ln.armed = true;
 }
@@ -304,7 +350,7 @@ DirectKernel DirectQueue::find(const std::string& fragment) const {
 }
 
 void DirectQueue::dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t wg_size, uint32_t dyn_lds, const void* args, size_t arg_bytes,
-                           int timed_tag, double timed_aux, int lane, FillExtra fill_extra, void* fill_user) {
+                           int timed_tag, double timed_aux, int lane, FillExtra fill_extra, void* fill_user, bool no_acquire) {
     Impl& p            = *p_;
     Impl::Lane& ln     = p.lanes[lane];
     if (arg_bytes > kSlotBytes || k.kernarg > kSlotBytes || arg_bytes > std::max<size_t>(k.kernarg, 1))
@@ -347,11 +393,11 @@ void DirectQueue::dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t 
     // agent-scope fences: the inputs the host writes (state, arguments) live in fine-grained memory, which the GPU does not
     // cache, and results for the host leave through the end-of-kernel release
     const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                            (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                            ((no_acquire ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                             (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     p.publish(ln, pkt, header, 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS, idx);
     if (ln.armed) {  // the packet processor is parked on the barrier of arm(): open the gate now that the packet is in the queue
-        hsa_signal_store_screlease(ln.gate, 0);
+        Impl::open_gate(ln);
         ln.armed = false;
     }
     busy_[lane] = true;
@@ -361,7 +407,7 @@ bool DirectQueue::drain(double timeout_seconds, int lane) {
     Impl& p        = *p_;
     Impl::Lane& ln = p.lanes[lane];
     if (ln.queue && ln.armed) {  // a parked barrier would hold the drain packet back for ever
-        hsa_signal_store_screlease(ln.gate, 0);
+        Impl::open_gate(ln);
         ln.armed    = false;
         busy_[lane] = true;
     }
@@ -423,7 +469,7 @@ uint64_t DirectQueue::signal_after(int lane) {
                             (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     p.publish(ln, pkt, header, 0, idx);
     if (ln.armed) {
-        hsa_signal_store_screlease(ln.gate, 0);
+        Impl::open_gate(ln);
         ln.armed = false;
     }
     busy_[lane] = true;
@@ -443,7 +489,7 @@ void DirectQueue::wait_for(int lane, uint64_t handle) {
                             (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     p.publish(ln, pkt, header, 0, idx);
     if (ln.armed) {
-        hsa_signal_store_screlease(ln.gate, 0);
+        Impl::open_gate(ln);
         ln.armed = false;
     }
     busy_[lane] = true;
@@ -469,6 +515,28 @@ bool DirectQueue::set_cu_mask(int lane, uint32_t keep) {
 }
 
 size_t DirectQueue::timed_pending() const { return p_->timed.size(); }
+
+uint64_t DirectQueue::system_ticks() const {
+    uint64_t t = 0;
+    (void)hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP, &t);
+    return t;
+}
+uint64_t DirectQueue::gpu_to_system(uint64_t gpu_ticks) const {
+    uint64_t t = 0;
+    if (hsa_amd_profiling_convert_tick_to_system_domain(p_->agent, gpu_ticks, &t) != HSA_STATUS_SUCCESS) return 0;
+    return t;
+}
+uint64_t DirectQueue::system_ticks_per_second() const { return p_->ticks_per_second; }
+
+int DirectQueue::ring_in_device_memory(int lane) const {
+    const Impl::Lane& ln = p_->lanes[lane];
+    if (!ln.queue || !ln.queue->base_address) return -1;
+    hsa_amd_pointer_info_t info{};
+    info.size = sizeof(info);
+    if (hsa_amd_pointer_info(ln.queue->base_address, &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS) return -1;
+    if (info.type != HSA_EXT_POINTER_TYPE_HSA) return -1;
+    return info.agentOwner.handle == p_->agent.handle ? 1 : 0;
+}
 
 void DirectQueue::collect(const std::function<void(int, double, double)>& sink) {
     Impl& p = *p_;

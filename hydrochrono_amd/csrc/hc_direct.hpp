@@ -50,8 +50,11 @@ class DirectQueue {
     // argument, so it can request what the host put there together with its arguments instead of after them (the step kernel's body
     // state, hc_step.cpp).
     using FillExtra = void (*)(char* extra, void* user);
+    // no_acquire (tuning experiment, EXPERIMENTS.md round 6): the packet carries no acquire fence (the caches are not invalidated in
+    // front of the kernel); the release fence stays.
     void dispatch(const DirectKernel& k, uint32_t workgroups, uint32_t wg_size, uint32_t dyn_lds, const void* args, size_t arg_bytes,
-                  int timed_tag = -1, double timed_aux = 0.0, int lane = 0, FillExtra fill_extra = nullptr, void* fill_user = nullptr);
+                  int timed_tag = -1, double timed_aux = 0.0, int lane = 0, FillExtra fill_extra = nullptr, void* fill_user = nullptr,
+                  bool no_acquire = false);
     // Parks the lane's packet processor on a barrier packet that waits for a signal; the next dispatch() releases it right after
     // its packet is in the queue.  A queue that has sat EMPTY for more than a few tens of microseconds takes about 6 us longer from
     // doorbell to kernel start (12.2 against 6.0 us launch-to-result for a small kernel after >= 100 us of idle,
@@ -87,6 +90,15 @@ class DirectQueue {
     // Reports (tag, seconds, aux) of every timed dispatch since the last call (waits for them).
     void collect(const std::function<void(int, double, double)>& sink);
     size_t timed_pending() const;
+    // Clocks (diagnostics: the step kernel's stage clock, hc_tuning_step_stamps).  system_ticks(): the HSA system timestamp now;
+    // gpu_to_system(): a value of the GPU's constant clock (s_memrealtime) in that domain; both in units of 1 / system_ticks_per_second().
+    uint64_t system_ticks() const;
+    uint64_t gpu_to_system(uint64_t gpu_ticks) const;
+    uint64_t system_ticks_per_second() const;
+    // Where the runtime put the lane's AQL packet ring: 1 device memory (the packet processor fetches packets locally: 1.4-1.9 us less
+    // from doorbell to kernel start than over PCIe, profiles/r06/queue_dev_mem_ab.txt), 0 host memory, -1 unknown.  The runtime decides
+    // when it is initialised (HSA_ALLOCATE_QUEUE_DEV_MEM, requested by this library at load time -- hc_runtime.cpp).
+    int ring_in_device_memory(int lane = 0) const;
 
     static constexpr size_t kSlotBytes  = 4096;   // kernarg bytes per dispatch (the largest argument block is the scatter's 2.6 KB)
     static constexpr size_t kExtraBytes = 16384;  // ... followed by room for data the kernel addresses relative to its kernarg pointer

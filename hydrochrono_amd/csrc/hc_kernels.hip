@@ -1329,6 +1329,41 @@ void launch_reduce_block(const ReduceArgs& r, hipStream_t stream) {
 // 263-322,758-760; src/wave_types.cpp:315-327).  All sums run in a fixed order (bitwise reproducible).  For the host
 // boundary the totals also leave as 16-byte {value, sequence} granules in mapped pinned memory.
 // ------------------------------------------------------------------------------------------------
+// Stage clock (tuning build): where a workgroup's time goes between kernel entry and the last store -- the 100 MHz constant clock
+// (s_memrealtime) read at fixed points of the program; a wave passes a point once everything in front of it has been waited for, so
+// the differences are the lengths of the dependent hops.  Kept in scalar registers until the workgroup's last store has been
+// acknowledged, then stored by work-item 0 (nothing is added to the memory traffic of the stages themselves).  The release build
+// compiles the marks away.
+//   0 entry   1 arguments in registers   2 every load requested   3 right-hand side in LDS (state arrived)   4 barrier passed
+//   5 contraction done (K arrived)   6 reduction visible (second barrier)   7 totals formed   8 stores issued   9 stores acknowledged
+#ifdef HC_TUNING
+struct StageClock {
+    unsigned long long t[kStampStages] = {};
+    template <int K>
+    __device__ __forceinline__ void mark() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);
+        t[K] = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    __device__ __forceinline__ void store(unsigned long long* stamps) const {
+        if (stamps && threadIdx.x == 0 && blockIdx.x < kStampWGs) {
+#pragma unroll
+            for (int k = 0; k < kStampStages; ++k) stamps[blockIdx.x * kStampStages + k] = t[k];
+        }
+    }
+};
+#define HC_MARK(sc, K) (sc).template mark<K>()
+#define HC_STAMPS(a) ((a).stamps)
+#else
+struct StageClock {
+    __device__ __forceinline__ void store(unsigned long long*) const {}
+};
+#define HC_MARK(sc, K) ((void)0)
+#define HC_STAMPS(a) (static_cast<unsigned long long*>(nullptr))
+#endif
+
 // NW = waves per workgroup (4).  Wide systems (near_slices_for(D) > 1) leave the own-sample part to near_split_kernel.
 // the workgroup that hands back the state canary and stores this step's sample into ring slot `head` (both layouts)
 // SLOT: the state lies behind the kernel's argument block (st, layout of hc_limits.hpp: kSlotArgBytes), not at a.state.
@@ -1356,9 +1391,16 @@ __device__ __forceinline__ void push_sample(const FinalizeArgs& a, const double*
 // were written by other workgroups of this very launch, possibly on other XCDs (agent-scope atomic loads, see wide_step_kernel).
 // SLOT: the state lies behind the argument block (st) and the velocities of columns tid, tid + 256, tid + 512 were requested before the
 // first argument was looked at (ev0..ev3); 6N <= 1024 (kSlotStateMaxBodies).
-template <int NW, bool COHERENT, bool SLOT, class Mid>
+// EARLY (finalize_pre_kernel): the first K words of the wave and the scatter results were requested at kernel entry, from addresses the
+// packet processor had put into scalar registers (kernel-argument preload) -- `early` holds them.
+struct EarlyLoads {
+    dvec2 pre[12];
+    double ypre[kTermMax / 16];
+};
+template <int NW, bool COHERENT, bool SLOT, bool EARLY = false, class Mid>
 __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int tile, double* U, double (*red_near)[16], double (*red_term)[16], Mid&& mid,
-                                              const double* __restrict__ st = nullptr, double ev0 = 0.0, double ev1 = 0.0, double ev2 = 0.0, double ev3 = 0.0) {
+                                              StageClock& sc, const double* __restrict__ st = nullptr, double ev0 = 0.0, double ev1 = 0.0, double ev2 = 0.0,
+                                              double ev3 = 0.0, const EarlyLoads* early = nullptr) {
     static_assert(!SLOT || NW == 4, "the early loads assume 256 work-items");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1417,9 +1459,13 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
     // first wait.
     const int kk = lane >> 4;
     constexpr int PRE = 12;  // C3: all 12 column groups a wave owns of one IRF sample
+    static_assert(PRE == sizeof(EarlyLoads::pre) / sizeof(dvec2), "EarlyLoads::pre");
     dvec2 pre[PRE];
     const double* __restrict__ kbase = a.nearK.base + ((size_t)tile * a.nearK.ngp) * 128 + lane * 2;
-    if (near_on) {
+    if constexpr (EARLY) {
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) pre[q] = early->pre[q];
+    } else if (near_on) {
         const int f0_0 = a.near[0].s * a.D, g0_0 = f0_0 >> 3, g1_0 = (f0_0 + a.D + 7) >> 3;
 #pragma unroll
         for (int q = 0; q < PRE; ++q) {
@@ -1431,7 +1477,10 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
     // (Yc[k][row]); thread (slice = tid >> 4, row = tid & 15) requests terms slice, slice + 16, ... here, before the first wait
     constexpr int TPRE = kTermMax / 16;
     double ypre[TPRE];
-    if (term_on) {
+    if constexpr (EARLY) {
+#pragma unroll
+        for (int q = 0; q < TPRE; ++q) ypre[q] = early->ypre[q];
+    } else if (term_on) {
         const double* __restrict__ yc = a.Yc + tile * 16 + (tid & 15);
 #pragma unroll
         for (int q = 0; q < TPRE; ++q) {
@@ -1439,6 +1488,7 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
             ypre[q]     = (rowthread && k < a.n_terms) ? yc[(size_t)k * a.Dpad] : 0.0;
         }
     }
+    HC_MARK(sc, 2);
     if (!mid()) return;
     if (near_on) {
         // ---- the IRF samples this step contracts itself: rows of this tile x [s*D, (s+1)*D) ----
@@ -1454,7 +1504,9 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
                 U[e * D + col] = u;
             }
         }
+        HC_MARK(sc, 3);
         __syncthreads();
+        HC_MARK(sc, 4);
         double acc = 0.0;
         for (int e = 0; e < a.n_near; ++e) {
             const int f0 = a.near[e].s * D, f1 = f0 + D;
@@ -1483,6 +1535,10 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
         }
         acc += __shfl_xor(acc, 16, kWave);
         acc += __shfl_xor(acc, 32, kWave);
+#ifdef HC_TUNING
+        asm volatile("" ::"v"(acc));  // (the mark below stands behind the contraction's last use of a K word)
+#endif
+        HC_MARK(sc, 5);
         if (lane < 16) red_near[wave][lane] = acc;
     }
     if (term_on) {
@@ -1492,6 +1548,7 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
         if (rowthread) red_term[tid >> 4][tid & 15] = tacc;
     }
     if (near_on || term_on) __syncthreads();
+    HC_MARK(sc, 6);
 
     double rad = 0.0, wav = 0.0;
     if (a.do_rad) {
@@ -1557,6 +1614,10 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
         hs += add;
     }
     const double total = hs - rad + wav;  // src/hydro_forces.cpp:758-760
+#ifdef HC_TUNING
+    asm volatile("" ::"v"(total));
+#endif
+    HC_MARK(sc, 7);
     a.hs[row]    = hs;
     a.rad[row]   = rad;
     a.waves[row] = wav;
@@ -1566,6 +1627,16 @@ __device__ __forceinline__ void finalize_tile(const FinalizeArgs& a, const int t
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
         *reinterpret_cast<u64x2*>(a.host_tagged + 2 * (size_t)row) = u64x2{(unsigned long long)__double_as_longlong(total), a.seq};
     }
+#ifdef HC_TUNING
+    if (HC_STAMPS(a)) {
+        HC_MARK(sc, 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (stores count in vmcnt on gfx9: the totals have been acknowledged)
+#endif
+        HC_MARK(sc, 9);
+        sc.store(HC_STAMPS(a));
+    }
+#endif
 }
 
 // SLOT (direct dispatch of hc_step for systems of up to kSlotStateMaxBodies bodies): the host has stored the body state behind the
@@ -1580,6 +1651,8 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
     __shared__ double red_term[16][16];  // [term slice][row]
     const double* __restrict__ st = nullptr;
     double ev0 = 0.0, ev1 = 0.0, ev2 = 0.0, ev3 = 0.0;
+    StageClock sc;
+    HC_MARK(sc, 0);
     if constexpr (SLOT) {
 #if defined(__HIP_DEVICE_COMPILE__)
         st = (const double*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kSlotArgBytes);
@@ -1593,13 +1666,442 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
 #endif
     }
     touch_args<sizeof(FinalizeArgs)>();
+    HC_MARK(sc, 1);
     if (a.do_push && (int)blockIdx.x == a.nblocks - 1) {  // (a.nblocks, not gridDim: the kernel takes no hidden arguments, see hc_direct.hpp)
         push_sample<NW, SLOT>(a, st);
+#ifdef HC_TUNING
+        if (HC_STAMPS(a)) {  // the workgroup that stores the sample: entry, arguments, stores issued, stores acknowledged
+            HC_MARK(sc, 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            HC_MARK(sc, 9);
+            sc.store(HC_STAMPS(a));
+        }
+#endif
         return;
     }
-    finalize_tile<NW, false, SLOT>(a, (int)blockIdx.x, U, red_near, red_term, [] { return true; }, st, ev0, ev1, ev2, ev3);
+    finalize_tile<NW, false, SLOT>(a, (int)blockIdx.x, U, red_near, red_term, [] { return true; }, sc, st, ev0, ev1, ev2, ev3);
 }
 template __global__ void finalize_kernel<4, true>(FinalizeArgs);
+
+// finalize_pre_kernel: finalize_kernel<4, true> whose first dependent hop is gone.  The step kernel's chain is  arguments -> K words /
+// scatter results -> right-hand side -> contraction -> totals: two memory round trips before the first multiply, the first of them to
+// uncached memory (the argument slot the host has just written through the BAR).  The ten leading kernel arguments below are
+// PRELOADED -- the packet processor reads them from the argument block while it sets the dispatch up and the waves start with them in
+// scalar registers (-mllvm -amdgpu-kernarg-preload-count, kernel descriptor field kernarg_preload_length; a firmware that does not
+// preload runs the compiler's compatibility prologue, which loads them first) -- so the K words of the wave, the scatter results and
+// the body state are all requested by the kernel's first instructions, together with the rest of the argument block:
+//   kfirst = K's panel base + the first column group of the step's own IRF sample (near[0]); ngroups = its column groups (0: none);
+//   yc / n_terms / dpad = FinalizeArgs::Yc, n_terms (0 when the step has no radiation term), Dpad; ngp = row-tile stride in groups;
+//   ntiles = row tiles of the context (the workgroup behind them stores the sample and requests nothing).
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) finalize_pre_kernel(const double* __restrict__ kfirst, const double* __restrict__ yc, int ngp, int ngroups, int n_terms,
+                                                                int dpad, int ntiles, int pad_, FinalizeArgs a) {
+    static_assert(NW == 4, "the early loads assume 256 work-items");
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double* U = reinterpret_cast<double*>(smem_raw);
+    __shared__ double red_near[NW][16];
+    __shared__ double red_term[16][16];
+    StageClock sc;
+    HC_MARK(sc, 0);
+    const double* __restrict__ st = nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+    st = (const double*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kSlotArgBytes);
+#endif
+    const double ev0 = st[threadIdx.x], ev1 = st[threadIdx.x + 256], ev2 = st[threadIdx.x + 512], ev3 = st[threadIdx.x + 768];
+    EarlyLoads el;
+    {
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), tile = (int)blockIdx.x;
+        const bool tile_wg = tile < ntiles;
+        const double* __restrict__ kb = kfirst + ((size_t)(tile_wg ? tile : 0) * ngp) * 128 + lane * 2;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int gp = wave + NW * q;
+            el.pre[q]    = (tile_wg && gp < ngroups) ? *reinterpret_cast<const dvec2*>(kb + (size_t)gp * 128) : dvec2{0.0, 0.0};
+        }
+        const double* __restrict__ y = yc + (tile_wg ? tile : 0) * 16 + (tid & 15);
+#pragma unroll
+        for (int q = 0; q < kTermMax / 16; ++q) {
+            const int k = (tid >> 4) + 16 * q;
+            el.ypre[q]  = (tile_wg && k < n_terms) ? y[(size_t)k * dpad] : 0.0;
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);  // (all of the above goes out BEFORE the first wait for an argument)
+#endif
+    touch_args<sizeof(FinalizeArgs) + 40>();
+    HC_MARK(sc, 1);
+    (void)pad_;
+    if (a.do_push && (int)blockIdx.x == a.nblocks - 1) {
+        push_sample<NW, true>(a, st);
+#ifdef HC_TUNING
+        if (HC_STAMPS(a)) {
+            HC_MARK(sc, 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            HC_MARK(sc, 9);
+            sc.store(HC_STAMPS(a));
+        }
+#endif
+        return;
+    }
+    finalize_tile<NW, false, true, true>(a, (int)blockIdx.x, U, red_near, red_term, [] { return true; }, sc, st, ev0, ev1, ev2, ev3, &el);
+}
+template __global__ void finalize_pre_kernel<4>(const double*, const double*, int, int, int, int, int, int, FinalizeArgs);
+
+// ------------------------------------------------------------------------------------------------
+// step_hot_kernel<NE>: the step kernel of the common block step (StepHotArgs, hc_kernels.hpp), written around what the stage clock of
+// finalize_kernel<4, true> showed (profiles/r06/step_stage_clock.txt): of the 4.8 us a tile workgroup lived, 0.3 were the argument
+// block, 1.2 the one memory round trip the step needs (K words, scatter results, state) -- and 3.3 were round trips the CODE made one
+// after the other: scalar loads of single arguments with a wait each (the argument slot is uncached memory: 0.1-0.3 us per trip), a
+// wait for the positions in front of the K requests (an eager subtraction), a full drain in the middle of the term loads (a register
+// re-used as an address).  Here
+//   * every argument is a scalar register after ONE wait (the compact block is requested whole, then pinned: no argument is loaded twice);
+//   * every global load of the step is issued right behind it, unconditionally (indices clamped to something valid, the values masked
+//     afterwards), so nothing is waited for until all requests are out and the waits are counted exactly;
+//   * nothing else changes: the same products and sums in the same order as finalize_kernel (bitwise the same forces; the tuning
+//     build keeps the A/B switch HC_STEP_HOT, tests/test_gpu_boundary.py).
+// One workgroup per tile of 16 rows + one that stores the sample; 256 work-items; dynamic LDS NE * D doubles.
+// ------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HC_PIN_S(x) asm volatile("" : "+s"(x))
+#else
+#define HC_PIN_S(x) ((void)0)
+#endif
+// Loads the compiler neither moves nor counts: the step kernel's requests go out in exactly this order, at exactly this place, and
+// are waited for by hand (hot_wait<N>: at most N of them still in flight, oldest first; hot_pin ties the values to the wait).  The
+// optimiser would otherwise sink a load into the branch that uses it -- behind a barrier, one memory round trip later.
+__device__ __forceinline__ void hot_ld(double& d, const double* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+#else
+    d = *p;
+#endif
+}
+__device__ __forceinline__ void hot_ld2(dvec2& d, const double* p) {  // 16 bytes at 8-byte alignment
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+#else
+    d = dvec2{p[0], p[1]};
+#endif
+}
+// ... and their scalar-base forms: address = base (scalar register pair) + byte offset (one 32-bit vector register) + immediate
+template <int IMM = 0>
+__device__ __forceinline__ void hot_lds(double& d, const double* sbase, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+#else
+    d = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sbase) + voff + IMM);
+#endif
+}
+template <int IMM = 0>
+__device__ __forceinline__ void hot_lds2(dvec2& d, const double* sbase, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+#else
+    const double* q = reinterpret_cast<const double*>(reinterpret_cast<const char*>(sbase) + voff + IMM);
+    d               = dvec2{q[0], q[1]};
+#endif
+}
+template <int N>
+__device__ __forceinline__ void hot_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+template <class T>
+__device__ __forceinline__ void hot_pin(T& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+}
+
+template <int NE>
+__global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double* U = reinterpret_cast<double*>(smem_raw);  // [NE][D]
+    __shared__ double red_near[4][16];
+    __shared__ double red_term[16][16];
+    StageClock sc;
+    (void)sc;
+    HC_MARK(sc, 0);
+    const double* __restrict__ st = nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+    st = (const double*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kSlotArgBytes);
+#endif
+    const int tid = threadIdx.x;
+    double ev[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hot_ld(ev[k], st + tid + 256 * k);  // (inside the slot whatever D is)
+    // ---- the arguments the loads need: the first part of the block, whole, ONE wait ----
+    const double* kf0 = a.kfirst[0];
+    const double* kf1 = a.kfirst[NE - 1];
+    const double *Yc = a.Yc, *P = a.P, *E = a.E, *lin = a.lin, *cg = a.cg, *cbm = a.cb_m_cg, *vol = a.disp_vol, *regm = a.reg_mag;
+    int ngp = a.ngp, ng0 = a.ng[0], ng1 = a.ng[NE - 1], n_terms = a.n_terms, Dpad = a.Dpad, Dloc = a.Dloc, N = a.N, b0 = a.b0, ntiles = a.ntiles;
+    HC_PIN_S(kf0); HC_PIN_S(kf1); HC_PIN_S(Yc); HC_PIN_S(P); HC_PIN_S(E); HC_PIN_S(lin); HC_PIN_S(cg); HC_PIN_S(cbm); HC_PIN_S(vol); HC_PIN_S(regm);
+    HC_PIN_S(ngp); HC_PIN_S(ng0); HC_PIN_S(ng1); HC_PIN_S(n_terms); HC_PIN_S(Dpad); HC_PIN_S(Dloc); HC_PIN_S(N); HC_PIN_S(b0); HC_PIN_S(ntiles);
+    HC_MARK(sc, 1);
+
+    if ((int)blockIdx.x >= ntiles) {
+        // ---- the workgroup that hands back the state canary and stores this step's sample into ring slot `head` (push_sample) ----
+        const int D = a.D;
+        const double t = a.t;
+        const unsigned long long seq = a.seq;
+        unsigned long long *canary_out = a.canary_out, *stamps = a.stamps;
+        (void)stamps;
+        double word = 0.0;
+        if (canary_out) hot_ld(word, st + 12 * N);
+        hot_wait<0>();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hot_pin(ev[k]);
+        hot_pin(word);
+        if (tid == 64 && canary_out) {
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u64x2*>(canary_out) = u64x2{(unsigned long long)__double_as_longlong(word), seq};
+        }
+        const int head = a.head, Hcap = a.Hcap, HcapT = a.HcapT;
+        if (tid == 0) a.ring_t[head] = t;
+        double* slot = a.ring_v + (size_t)head * D;
+        double* vT   = a.ring_vT;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = tid + 256 * k;
+            if (c < D) {
+                slot[c] = ev[k];
+                vT[(size_t)c * HcapT + head] = ev[k];
+                if (head == 0) vT[(size_t)c * HcapT + Hcap] = ev[k];
+            }
+        }
+#ifdef HC_TUNING
+        if (stamps) {
+            HC_MARK(sc, 8);
+            hot_wait<0>();
+            HC_MARK(sc, 9);
+            sc.store(stamps);
+        }
+#endif
+        return;
+    }
+
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), sub = tid & 15, rit = (tid >> 4) & 15, kk = lane >> 4;
+    const int tile = (int)blockIdx.x, row = tile * 16 + rit;
+    const bool live = row < Dloc;
+    const int rrow = live ? row : 0, bl = rrow / 6, i = rrow - 6 * bl, b = b0 + bl;
+    // ---- every load of the step, unconditionally (clamped indices; masked where the values are used), in the order their values are
+    //      needed: what the hydrostatic and wave terms take first (they are formed while the K words are still on their way) ----
+    constexpr int PRE  = 12;  // C3: all 12 column groups a wave owns of one IRF sample
+    constexpr int TPRE = kTermMax / 16;
+    constexpr int kLoadsBehindTerms1 = NE * PRE + TPRE;  // K words and scatter results: requested last, waited for last
+    double p_row, e_raw, V, rmag, pos2, rpy2, cg2, r2;
+    dvec2 pos01, rpy01, cg01, r01, k01, k23, k45;
+    {
+        const unsigned row_off = (unsigned)rrow * 8u, b3_off = (unsigned)b * 24u, bl3_off = (unsigned)bl * 24u, lin_off = (unsigned)(36 * bl + 6 * i) * 8u,
+                       bl_off = (unsigned)bl * 8u;
+        const double *st_pos = st + 6 * N, *st_rpy = st + 9 * N;
+        hot_lds2(pos01, st_pos, b3_off);
+        hot_lds<16>(pos2, st_pos, b3_off);
+        hot_lds2(rpy01, st_rpy, b3_off);
+        hot_lds<16>(rpy2, st_rpy, b3_off);
+        hot_lds2(cg01, cg, bl3_off);
+        hot_lds<16>(cg2, cg, bl3_off);
+        hot_lds2(r01, cbm, bl3_off);
+        hot_lds<16>(r2, cbm, bl3_off);
+        hot_lds2(k01, lin, lin_off);
+        hot_lds2<16>(k23, lin, lin_off);
+        hot_lds2<32>(k45, lin, lin_off);
+        hot_lds(V, vol, bl_off);
+        hot_lds(rmag, regm, row_off);
+        hot_lds(p_row, P, row_off);
+        hot_lds(e_raw, E, row_off);
+    }
+    dvec2 pre[NE][PRE];
+    {
+        // K words: the wave's column groups wave, wave + 4, ... of own sample e -- one scalar base per load, the lane's 16 bytes as the offset
+        const unsigned lane_off = (unsigned)lane * 16u;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const double* __restrict__ kb = (e == 0 ? kf0 : kf1) + ((size_t)tile * ngp) * 128;
+            const int ng = e == 0 ? ng0 : ng1;
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) {
+                const int gp = wave + 4 * q;
+                hot_lds2(pre[e][q], kb + (size_t)(gp < ng ? gp : 0) * 128, lane_off);
+            }
+        }
+    }
+    double ypre[TPRE];
+    {
+        // term slots tid >> 4, + 16, ... of the step (all kTermMax slots of a step exist: the ones past n_terms are read and masked)
+        const unsigned y_off = ((unsigned)(tid & 15) + (unsigned)(tid >> 4) * (unsigned)Dpad) * 8u;
+        const double* __restrict__ y = Yc + tile * 16;
+#pragma unroll
+        for (int q = 0; q < TPRE; ++q) hot_lds(ypre[q], y + (size_t)(16 * q) * Dpad, y_off);
+    }
+    HC_MARK(sc, 2);
+    // ---- the rest of the arguments, while the loads are in flight (read through a pointer the compiler cannot see through, so that
+    //      these requests are not hoisted in front of the loads above, where they would compete for the scalar registers) ----
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) StepHotArgs* HotArgsPtr;  // (constant address space: scalar loads)
+    HotArgsPtr a2 = (HotArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    HC_PIN_S(a2);
+#else
+    const StepHotArgs* a2 = &a;
+#endif
+    int off0 = a2->off[0], off1 = a2->off[NE - 1], D = a2->D, wave_mode = a2->wave_mode, has_E = a2->has_E;
+    double a0 = a2->a[0], a1 = a2->a[NE - 1];
+    double rho = a2->rho, gx = a2->gx, gy = a2->gy, gz = a2->gz, t = a2->t, reg_amp = a2->reg_amplitude, reg_omega = a2->reg_omega;
+    double ph0 = a2->reg_phase[0], ph1 = a2->reg_phase[1], ph2 = a2->reg_phase[2], ph3 = a2->reg_phase[3], ph4 = a2->reg_phase[4], ph5 = a2->reg_phase[5];
+    unsigned long long seq = a2->seq;
+    double *o_hs = a2->hs, *o_rad = a2->rad, *o_waves = a2->waves, *o_total = a2->total;
+    unsigned long long *tagged = a2->host_tagged, *stamps = a2->stamps;
+    (void)stamps;
+    HC_PIN_S(off0); HC_PIN_S(off1); HC_PIN_S(D); HC_PIN_S(wave_mode); HC_PIN_S(has_E); HC_PIN_S(a0); HC_PIN_S(a1);
+    HC_PIN_S(rho); HC_PIN_S(gx); HC_PIN_S(gy); HC_PIN_S(gz); HC_PIN_S(t); HC_PIN_S(reg_amp); HC_PIN_S(reg_omega);
+    HC_PIN_S(ph0); HC_PIN_S(ph1); HC_PIN_S(ph2); HC_PIN_S(ph3); HC_PIN_S(ph4); HC_PIN_S(ph5); HC_PIN_S(seq);
+    HC_PIN_S(o_hs); HC_PIN_S(o_rad); HC_PIN_S(o_waves); HC_PIN_S(o_total); HC_PIN_S(tagged); HC_PIN_S(stamps);
+
+    // ---- state and tables are in (requested first): right-hand sides of the own samples u = a_e * v_state into LDS, and the
+    //      hydrostatic / wave terms of the row while the K words are still in flight ----
+    hot_wait<kLoadsBehindTerms1>();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hot_pin(ev[k]);
+    hot_pin(p_row); hot_pin(e_raw); hot_pin(V); hot_pin(rmag); hot_pin(pos2); hot_pin(rpy2); hot_pin(cg2); hot_pin(r2);
+    hot_pin(pos01); hot_pin(rpy01); hot_pin(cg01); hot_pin(r01); hot_pin(k01); hot_pin(k23); hot_pin(k45);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const double ae = e == 0 ? a0 : a1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int col = tid + 256 * k;
+            if (col < D) U[e * D + col] = (ae != 0.0) ? ae * ev[k] : 0.0;
+        }
+    }
+    HC_MARK(sc, 3);
+    double wav = 0.0, hs;
+    {
+        if (wave_mode == 2) wav = has_E ? e_raw : 0.0;
+        if (wave_mode == 1) {
+            const double ph = i == 0 ? ph0 : (i == 1 ? ph1 : (i == 2 ? ph2 : (i == 3 ? ph3 : (i == 4 ? ph4 : ph5))));
+            wav = rmag * reg_amp * cos(reg_omega * t + ph);  // RegularWave::GetForceAtTime (src/wave_types.cpp:315-327)
+        }
+        // ComputeForceHydrostatics (src/hydro_forces.cpp:263-322)
+        const double posv[3] = {pos01.x, pos01.y, pos2}, rpyv[3] = {rpy01.x, rpy01.y, rpy2}, cgv[3] = {cg01.x, cg01.y, cg2}, r[3] = {r01.x, r01.y, r2};
+        const double krow[6] = {k01.x, k01.y, k23.x, k23.y, k45.x, k45.y};
+        double dq[6];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            dq[j]     = posv[j] - cgv[j];
+            dq[3 + j] = rpyv[j] - 0.0;
+        }
+        double ssum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) ssum += krow[j] * dq[j];
+        const double glen = sqrt(gx * gx + gy * gy + gz * gz);
+        hs                = -(rho * glen) * ssum;
+        const double fbx = rho * (-gx) * V, fby = rho * (-gy) * V, fbz = rho * (-gz) * V;
+        double add;
+        switch (i) {
+            case 0: add = fbx; break;
+            case 1: add = fby; break;
+            case 2: add = fbz; break;
+            case 3: add = r[1] * fbz - r[2] * fby; break;
+            case 4: add = r[2] * fbx - r[0] * fbz; break;
+            default: add = r[0] * fby - r[1] * fbx; break;
+        }
+        hs += add;
+    }
+    hot_pin(hs);  // (formed HERE, in the shadow of the K words, not behind the last barrier)
+    hot_pin(wav);
+    __syncthreads();
+    HC_MARK(sc, 4);
+    hot_wait<0>();
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) hot_pin(pre[e][q]);
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int ng = e == 0 ? ng0 : ng1, off = e == 0 ? off0 : off1;
+        const double* __restrict__ u = U + e * D;  // column c of the sample = lane column 8 * gp + kk (+ 4) - off, groups counted from the sample's first
+        int gp = wave;
+#pragma unroll
+        for (int q = 0; q < PRE; ++q, gp += 4) {
+            if (gp < ng) {
+                const int ca = gp * 8 + kk - off, cb = ca + 4;
+                const double u0 = (ca >= 0 && ca < D) ? u[ca] : 0.0, u1 = (cb >= 0 && cb < D) ? u[cb] : 0.0;
+                acc = fma(pre[e][q].x, u0, acc);
+                acc = fma(pre[e][q].y, u1, acc);
+            }
+        }
+        const double* __restrict__ kb = (e == 0 ? kf0 : kf1) + ((size_t)tile * ngp) * 128 + lane * 2;
+#pragma unroll 4
+        for (; gp < ng; gp += 4) {  // (more than 384 columns)
+            const dvec2 kv = *reinterpret_cast<const dvec2*>(kb + (size_t)gp * 128);
+            const int ca = gp * 8 + kk - off, cb = ca + 4;
+            const double u0 = (ca >= 0 && ca < D) ? u[ca] : 0.0, u1 = (cb >= 0 && cb < D) ? u[cb] : 0.0;
+            acc = fma(kv.x, u0, acc);
+            acc = fma(kv.y, u1, acc);
+        }
+    }
+    acc += __shfl_xor(acc, 16, kWave);
+    acc += __shfl_xor(acc, 32, kWave);
+#ifdef HC_TUNING
+    asm volatile("" ::"v"(acc));
+#endif
+    HC_MARK(sc, 5);
+    if (lane < 16) red_near[wave][lane] = acc;
+    {
+#pragma unroll
+        for (int q = 0; q < TPRE; ++q) hot_pin(ypre[q]);
+        double tacc = 0.0;
+#pragma unroll
+        for (int q = 0; q < TPRE; ++q) tacc += ((tid >> 4) + 16 * q < n_terms) ? ypre[q] : 0.0;  // ascending term index within the slice
+        red_term[tid >> 4][tid & 15] = tacc;
+    }
+    __syncthreads();
+    HC_MARK(sc, 6);
+    if (!(live && sub == 0)) return;
+
+    double rad = p_row + 0.0;
+    if (n_terms > 0) {
+        double ts = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ts += red_term[q][rit];
+        rad += ts;
+    }
+    {
+        double ns_ = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) ns_ += red_near[w][rit];
+        rad += ns_;
+    }
+    const double total = hs - rad + wav;  // src/hydro_forces.cpp:758-760
+#ifdef HC_TUNING
+    asm volatile("" ::"v"(total));
+#endif
+    HC_MARK(sc, 7);
+    o_hs[row]    = hs;
+    o_rad[row]   = rad;
+    o_waves[row] = wav;
+    o_total[row] = total;
+    if (tagged) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u64x2*>(tagged + 2 * (size_t)row) = u64x2{(unsigned long long)__double_as_longlong(total), seq};
+    }
+#ifdef HC_TUNING
+    if (stamps) {
+        HC_MARK(sc, 8);
+        hot_wait<0>();
+        HC_MARK(sc, 9);
+        sc.store(stamps);
+    }
+#endif
+}
+template __global__ void step_hot_kernel<1>(StepHotArgs);
+template __global__ void step_hot_kernel<2>(StepHotArgs);
 
 FinalizeLaunch finalize_launch_config(FinalizeArgs& a) {
     FinalizeLaunch l;
@@ -1745,6 +2247,7 @@ __global__ void __launch_bounds__(256) wide_step_kernel(WideStepArgs a) {
         return;
     }
     const int rt = (int)blockIdx.x / a.n.n_slices, sl = (int)blockIdx.x - rt * a.n.n_slices;
+    StageClock sc;  // (the host leaves FinalizeArgs::stamps null for this kernel)
     finalize_tile<4, true, false>(a.f, rt, nullptr, red_near, red_term, [&] {
         near_slice<true>(a.n, rt, sl, reinterpret_cast<double*>(smem_raw), red);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial has been written through
@@ -1756,7 +2259,7 @@ __global__ void __launch_bounds__(256) wide_step_kernel(WideStepArgs a) {
         }
         __syncthreads();
         return s_last != 0;
-    });
+    }, sc);
 }
 
 WideLaunch wide_launch_config(WideStepArgs& a) {

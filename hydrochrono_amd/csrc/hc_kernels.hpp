@@ -230,6 +230,50 @@ struct FinalizeArgs {
     double* ring_v;
     double* ring_vT;  // [D][HcapT] transposed copy (entry [Hcap] mirrors slot 0)
     int Hcap, HcapT;
+#ifdef HC_TUNING
+    // stage clock (profiles/step_stamps_probe.cpp): [workgroup][kStampStages] s_memrealtime values of this launch, or null
+    unsigned long long* stamps;
+#endif
+};
+
+// finalize_pre_kernel's arguments as the kernel lays them out: ten preloaded words in front of the step kernel's argument block
+// (hc_kernels.hip; filled by hc_step.cpp: enqueue_step)
+struct FinalizePreArgs {
+    const double* kfirst;
+    const double* yc;
+    int ngp, ngroups, n_terms, dpad, ntiles, pad_;
+    FinalizeArgs a;
+};
+static_assert(offsetof(FinalizePreArgs, a) == 40, "kernarg layout of finalize_pre_kernel");
+
+// step_hot_kernel: the step kernel of the COMMON block step -- a step inside a look-ahead block of a system that is not wide, direct
+// dispatch with the body state behind the arguments, the step's own IRF samples weighted against its own velocity only (NE = 1 or 2 of
+// them), no plain partials, no spectral wave mode -- with a compact argument block of its own.  Everything finalize_kernel<4, true>
+// does for such a step, bit for bit (hc_step.cpp: enqueue_step decides; HC_STEP_HOT=0 in the tuning build keeps the general kernel).
+struct StepHotArgs {
+    // ---- first part: what the kernel needs to issue its loads (requested whole, one wait) ----
+    const double* kfirst[2];  // K's panel base + the first column group of own IRF sample e (row tile 0)
+    const double* Yc;         // [n_terms][Dpad] scatter results for this step
+    const double* P;          // look-ahead row of this step
+    const double* E;          // excitation row of this step (has_E), else any valid address
+    const double *lin, *cg, *cb_m_cg, *disp_vol, *reg_mag;
+    int ngp;                  // column groups per row tile of the panel
+    int ng[2];                // column groups of own sample e
+    int n_terms, Dpad, Dloc, N, b0, ntiles, pad0_;
+    // ---- second part: requested while the loads are in flight ----
+    int off[2];               // first column of own sample e inside its first group (s * D - 8 * (s * D / 8))
+    int D, wave_mode, has_E, pad1_;
+    double a[2];              // weight x trapezoid width of own sample e
+    double rho, gx, gy, gz, t, reg_amplitude, reg_omega;
+    double reg_phase[6];
+    unsigned long long seq;
+    double *hs, *rad, *waves, *total;
+    unsigned long long* host_tagged;
+    unsigned long long* canary_out;
+    unsigned long long* stamps;  // stage clock rows (tuning build), else null
+    // the workgroup behind the row tiles stores the sample (ring slot `head`)
+    double *ring_t, *ring_v, *ring_vT;
+    int head, Hcap, HcapT, pad2_;
 };
 
 // wide_step_kernel: near_split_kernel + the step kernel of a wide system in one launch (the workgroup that completes a row tile's

@@ -21,6 +21,12 @@ constexpr int kNearMax        = 8;   // IRF samples a step contracts itself (own
 constexpr int kTermMax        = 192; // term slots a step adds (scatter results; x column slices for wide systems)
 constexpr int kTargets        = 3;   // later block steps one (sample, IRF sample) result can contribute to
 
+// Stage clock of the step kernel (tuning build only: FinalizeArgs::stamps, hc_tuning_step_stamps): one row of kStampStages 100 MHz
+// s_memrealtime values per workgroup of a launch, for the last kStampSteps steps.
+constexpr int kStampStages    = 12;
+constexpr int kStampWGs       = 32;
+constexpr int kStampSteps     = 64;
+
 constexpr int kSubBlock       = 8;   // steps per sub-block of the two-level form (wide systems)
 constexpr int kMiniChunks     = 256; // radiation chunks a NARROW short pass may have (one step offset per chunk travels in the argument block)
 

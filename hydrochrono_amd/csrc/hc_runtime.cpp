@@ -518,8 +518,19 @@ void ensure_processed(hc_ctx* c) {
     a.tc_index        = tc_index;
     a.tc_end          = tc_end;
     a.final_amplitude = c->taper.taper_final_amplitude;
-    hc::launch_taper(a, c->stream);
-    HC_HIP(hipGetLastError());
+    {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timed = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventRecord(e0, c->stream) == hipSuccess;
+        hc::launch_taper(a, c->stream);
+        HC_HIP(hipGetLastError());
+        float ms = 0.0f;
+        if (timed && hipEventRecord(e1, c->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        c->init.taper_seconds += 1e-3 * static_cast<double>(ms);  // (hc_init_stats)
+        c->init.taper_bytes += 2.0 * 8.0 * static_cast<double>(c->dK.n);
+    }
     HC_HIP(hipStreamSynchronize(c->stream));
     c->proc_ready = true;
     c->plan.valid = false;
@@ -622,6 +633,17 @@ static const char* const kKernelObjectName = "/hc_kernels_tuning.co";
 #else
 static const char* const kKernelObjectName = "/hc_kernels.co";
 #endif
+// The packet processor fetches AQL packets from the queue's ring; by default the HSA runtime puts that ring into HOST memory (a PCIe
+// read in front of every dispatch), with HSA_ALLOCATE_QUEUE_DEV_MEM=1 into device memory: 1.4-1.9 us less from doorbell to kernel start,
+// i.e. per synchronous hc_step and per hc_added_mass_mv (profiles/r06/queue_dev_mem_ab.txt: 8.47 -> 7.06 us at one body, 12.3 -> 10.5 us
+// at 64).  The runtime reads the variable once, when it is initialised, so the library asks for it when it is LOADED -- before main() of
+// a program linked against it, before the first HIP call of an interpreter that imports it first.  A host that initialises HIP earlier
+// sets the variable itself; HC_QUEUE_DEV_MEM=0 leaves the runtime's default alone; a value the host has set is kept.
+__attribute__((constructor)) static void request_device_memory_queue_rings() {
+    if (env_int("HC_QUEUE_DEV_MEM", 1) == 0) return;
+    (void)setenv("HSA_ALLOCATE_QUEUE_DEV_MEM", "1", 0);
+}
+
 void setup_direct(hc_ctx* c) {
     c->direct_ready = false;
     if (env_int("HC_DIRECT", 1) == 0) { c->direct_why = "disabled by HC_DIRECT=0"; return; }
@@ -638,6 +660,14 @@ void setup_direct(hc_ctx* c) {
     if (c->dk_wide.kernarg != sizeof(hc::WideStepArgs) || c->dk_wide.priv != 0) c->dk_wide = hc::DirectKernel{};
     if (c->dk_finalize_slot.kernarg != sizeof(hc::FinalizeArgs) || c->dk_finalize_slot.priv != 0) c->dk_finalize_slot = hc::DirectKernel{};
     c->slot_state = HC_TUNE_INT("HC_SLOT_STATE", 1) != 0 && c->dk_finalize_slot.ok() && c->N <= hc::kSlotStateMaxBodies;
+    c->dk_finalize_pre = q->find("finalize_pre_kernelILi4EEEv");  // optional
+    if (c->dk_finalize_pre.kernarg != sizeof(hc::FinalizePreArgs) || c->dk_finalize_pre.priv != 0) c->dk_finalize_pre = hc::DirectKernel{};
+    c->step_preload = c->slot_state && c->dk_finalize_pre.ok() && HC_TUNE_INT("HC_STEP_PRELOAD", 0) != 0;
+    c->dk_step_hot[0] = q->find("step_hot_kernelILi1EEEv");  // optional: without them the general step kernel runs every step
+    c->dk_step_hot[1] = q->find("step_hot_kernelILi2EEEv");
+    for (auto& k : c->dk_step_hot)
+        if (k.kernarg != sizeof(hc::StepHotArgs) || k.priv != 0) k = hc::DirectKernel{};
+    c->step_hot = c->slot_state && c->dk_step_hot[0].ok() && c->dk_step_hot[1].ok() && HC_TUNE_INT("HC_STEP_HOT", 1) != 0;
     c->dk_reduce   = q->find("reduce_block_kernelE");
     c->dk_added_mass = q->find("added_mass_mv_tagged_kernelE");  // optional: hc_added_mass_mv falls back to a HIP launch
     {   // the plain per-step convolution of this context's tiling; optional: without it plain steps go through HIP launches
@@ -739,6 +769,13 @@ void setup_direct(hc_ctx* c) {
     c->dq           = q.release();
     c->direct_ready = true;
     c->direct_why.clear();
+    {
+        const int where = c->dq->ring_in_device_memory(0);
+        c->direct_how   = where == 1 ? "direct AQL dispatch (packet ring in device memory)"
+                          : where == 0 ? "direct AQL dispatch (packet ring in HOST memory: the HSA runtime was initialised before this library could ask for a ring in "
+                                         "device memory, or HC_QUEUE_DEV_MEM=0 -- about 1.5 us more per synchronous step, see INTEGRATION.md)"
+                                       : "direct AQL dispatch";
+    }
     if (HC_TUNE_INT("HC_DEBUG_PLAN", 0) != 0) std::fprintf(stderr, "[hc] direct AQL dispatch in use for the step path\n");
 }
 

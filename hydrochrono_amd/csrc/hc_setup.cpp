@@ -6,6 +6,27 @@
 using namespace hc::detail;
 
 namespace {
+// init-time stopwatches (hc_init_stats): host wall clock, and HIP events around a kernel on the context's stream
+double seconds_since(const std::chrono::steady_clock::time_point& t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+struct KernelTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    explicit KernelTimer(hipStream_t stream) : s(stream) {
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; (void)hipGetLastError(); return; }
+        (void)hipEventRecord(a, s);
+    }
+    double stop() {  // seconds between construction and now on the stream (waits for the stream)
+        float ms = 0.0f;
+        if (a && b && hipEventRecord(b, s) == hipSuccess && hipEventSynchronize(b) == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
+        else (void)hipStreamSynchronize(s);
+        (void)hipGetLastError();
+        return 1e-3 * static_cast<double>(ms);
+    }
+    ~KernelTimer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
 
 // CreateSpectrum (src/wave_types.cpp:643-676): frequencies, PM/JONSWAP densities, trapezoid widths, mt19937 phases,
 // wavenumbers, plus the component amplitude sqrt(2 S df) and angular frequency of GetEtaIrregular (:39-40).
@@ -190,9 +211,19 @@ void set_rirf(hc_ctx* c, int body, const double* t, int S, const double* K) {
     for (int j = 0; j < S; ++j)
         if (t[j] < 0.0) c->device_errors_possible = true;  // a query t - tau could then exceed t (reference: throws at :370)
     if (is_local(c, body)) {
+        const double bytes = static_cast<double>(6) * c->D * S * sizeof(double);
+        const auto t0 = std::chrono::steady_clock::now();
         HC_HIP(hipMemcpyAsync(c->d_stage.p, K, static_cast<size_t>(6) * c->D * S * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        hc::launch_relayout_rirf(c->d_stage.p, c->dK.p, c->ngp, c->D, S, 6 * (body - c->b0), c->rho, c->stream);
-        HC_HIP(hipGetLastError());
+        HC_HIP(hipStreamSynchronize(c->stream));
+        c->init.rirf_h2d_seconds += seconds_since(t0);
+        c->init.rirf_h2d_bytes += bytes;
+        {
+            KernelTimer kt(c->stream);
+            hc::launch_relayout_rirf(c->d_stage.p, c->dK.p, c->ngp, c->D, S, 6 * (body - c->b0), c->rho, c->stream);
+            HC_HIP(hipGetLastError());
+            c->init.rirf_relayout_seconds += kt.stop();
+            c->init.rirf_relayout_bytes += 2.0 * bytes;
+        }
         HC_HIP(hipStreamSynchronize(c->stream));
         c->proc_ready = false;
     }
@@ -367,8 +398,15 @@ int hc_load_bemio_h5(hc_ctx* c, const char* path) {
     for (int b = -1; b < c->N; ++b) {
         hc_h5data d;
         char msg[1024] = {0};
+        const auto t_read = std::chrono::steady_clock::now();
         const int rc = read_body(path, c->N, b, (b >= 0 && is_local(c, b)) ? 1 : 0, &d, msg, sizeof msg);
         if (rc != HC_OK) throw Error(rc, msg[0] ? std::string(msg) : std::string("cannot read ") + path);
+        c->init.h5_read_seconds += seconds_since(t_read);
+        if (b >= 0 && !d.bodies.empty()) {
+            const hc_h5data::Body& qb = d.bodies[0];
+            c->init.h5_read_bytes += 8.0 * static_cast<double>(qb.K.size() + qb.ainf.size() + qb.rirf_t.size() + qb.mag.size() + qb.phase.size() + qb.exc_t.size() +
+                                                               qb.exc_f.size() + d.w.size() + 43);
+        }
         if (b < 0) {
             chk(hc_set_simulation_parameters(c, d.rho, d.g, d.water_depth));
             continue;
@@ -403,6 +441,7 @@ int hc_finalize(hc_ctx* c) {
     require(!c->finalized, HC_ERR_INVALID, "context already finalized");
     require(c->have_sim, HC_ERR_INVALID, "simulation parameters missing");
     require(c->S > 0, HC_ERR_INVALID, "radiation IRF missing");
+    const auto t_finalize = std::chrono::steady_clock::now();
     for (int b = c->b0; b < c->b1; ++b) {
         const auto& bd = c->bodies[b];
         require(bd.have_props && bd.have_lin && bd.have_ainf && bd.have_rirf, HC_ERR_INVALID,
@@ -468,7 +507,7 @@ int hc_finalize(hc_ctx* c) {
         }
         reset_schedule_state(c);
         c->pass_concurrent = env_int("HC_PASS_CONCURRENT", 1) != 0;
-        c->pass_free_cus   = std::max(1, std::min(16, HC_TUNE_INT("HC_PASS_FREE_CUS", 4)));
+        c->pass_free_cus   = std::max(1, std::min(28, HC_TUNE_INT("HC_PASS_FREE_CUS", 4)));
         c->ahead.active = false;
     }
     // GEMV scratch
@@ -529,10 +568,13 @@ int hc_finalize(hc_ctx* c) {
     c->prof.block_kernel_bytes = hc::kDepthDefault * c->prof.conv_kernel_bytes;
     c->plan                    = hc::Plan{};
     HC_HIP(hipStreamSynchronize(c->stream));
+    const auto t_direct = std::chrono::steady_clock::now();
     setup_direct(c);
     // the pass lane (its queue, CU mask and self-test: 131 synchronous dispatches) is made here, not inside the first step that
     // starts a pass one block ahead
     if (pass_ahead_possible(c) && c->lookahead > 0) (void)pass_lane_ready(c);
+    c->init.direct_setup_seconds += seconds_since(t_direct);
+    c->init.finalize_seconds += seconds_since(t_finalize);
     c->finalized = true;
     HC_API_END(c)
 }
@@ -665,6 +707,7 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
             groups.push_back(g);
         }
     }
+    const auto t_call = std::chrono::steady_clock::now();
     // ResampleIRF (src/wave_types.cpp:572-606), per group
     std::vector<double> ex_tau, ex_width;
     int L = 0;
@@ -691,8 +734,11 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
             std::copy(r.begin() + static_cast<size_t>(d) * g.L, r.begin() + static_cast<size_t>(d + 1) * g.L,
                       vals.begin() + static_cast<size_t>(6 * bl + d) * L + g.off);
     }
+    c->init.wave_resample_seconds += seconds_since(t_call);
     // CreateSpectrum (:643-676)
+    const auto t_spec = std::chrono::steady_clock::now();
     Spectrum sp = build_spectrum(c, p);
+    c->init.wave_spectrum_seconds += seconds_since(t_spec);
     const int nf = sp.nf;
     std::vector<double>&f = sp.f, &Sd = sp.S, &dfv = sp.df, &phase = sp.phase, &kk = sp.k, &amp = sp.amp, &omg = sp.omega;
     // CreateFreeSurfaceElevation (:717-774): the min/max scan over every body's resampled grid = over the groups' ends
@@ -711,17 +757,31 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     require(nt >= 2, HC_ERR_INVALID, "free-surface table too short");
 
     hc::DeviceBuffer<double> d_amp, d_omg, d_ph;
+    const auto t_up = std::chrono::steady_clock::now();
     d_amp.upload(amp, c->stream);
     d_omg.upload(omg, c->stream);
     d_ph.upload(phase, c->stream);
     c->d_eta_t.upload(eta_t, c->stream);
     c->d_eta.alloc(nt);
-    if (c->eta_mode == 1 && nf >= 2) {
-        hc::eta_synthesis_fft(eta_t, amp, omg, phase, p.ramp_duration, c->d_eta_t.p, c->d_eta.p, c->stream);  // rocFFT chirp-z
-    } else {
-        hc::launch_eta_synthesis(c->d_eta_t.p, nt, d_amp.p, d_omg.p, d_ph.p, nf, p.ramp_duration, c->d_eta.p, c->stream);
+    double up_s = seconds_since(t_up);
+    {
+        const auto t_eta = std::chrono::steady_clock::now();
+        if (c->eta_mode == 1 && nf >= 2) {
+            hc::eta_synthesis_fft(eta_t, amp, omg, phase, p.ramp_duration, c->d_eta_t.p, c->d_eta.p, c->stream);  // rocFFT chirp-z (host set-up + plans + kernels)
+            HC_HIP(hipGetLastError());
+            HC_HIP(hipStreamSynchronize(c->stream));
+            c->init.wave_eta_seconds += seconds_since(t_eta);
+        } else {
+            KernelTimer kt(c->stream);
+            hc::launch_eta_synthesis(c->d_eta_t.p, nt, d_amp.p, d_omg.p, d_ph.p, nf, p.ramp_duration, c->d_eta.p, c->stream);
+            HC_HIP(hipGetLastError());
+            c->init.wave_eta_seconds += kt.stop();
+        }
+        c->init.wave_eta_samples    = nt;
+        c->init.wave_eta_components = nf;
+        c->init.wave_eta_mode       = (c->eta_mode == 1 && nf >= 2) ? 1 : 0;
     }
-    HC_HIP(hipGetLastError());
+    const auto t_up2 = std::chrono::steady_clock::now();
     std::vector<double> eta(nt);
     HC_HIP(hipMemcpyAsync(eta.data(), c->d_eta.p, nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HC_HIP(hipStreamSynchronize(c->stream));
@@ -738,6 +798,8 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
     }
     c->d_ex_tau.upload(ex_tau, c->stream);
     c->d_ex_width.upload(ex_width, c->stream);
+    c->init.wave_upload_seconds += up_s + seconds_since(t_up2);
+    c->init.wave_upload_bytes += 8.0 * (3.0 * nf + 3.0 * nt + 2.0 * static_cast<double>(c->Dloc) * L + 2.0 * L);
     c->irr = p;
     c->L = L;
     c->Lpad = Lpad;
@@ -763,6 +825,7 @@ int hc_set_wave_irregular(hc_ctx* c, const hc_irregular_wave_params* pp) {
                                        static_cast<double>(c->Dloc) * L + L);
     c->prof.block_kernel_bytes = hc::kDepthDefault * 8.0 * (static_cast<double>(c->Dloc) * c->S * c->D + static_cast<double>(c->S) * c->D);
     HC_HIP(hipStreamSynchronize(c->stream));
+    c->init.wave_total_seconds += seconds_since(t_call);
     HC_API_END(c)
 }
 
@@ -875,8 +938,13 @@ int hc_synth_fill(hc_ctx* c, unsigned long long seed, int S, double dt_rirf, int
     for (int s = 0; s < S; ++s) c->tau[s] = s * dt_rirf;
     setup_panel_geometry(c);
     c->dK.alloc(hc::panel_doubles(c->ntiles, c->ngp));
-    hc::launch_synth_rirf(c->dK.p, c->ntiles, c->ngp, c->Dloc, c->D, S, 6 * c->b0, dt_rirf, seed, c->rho, c->stream);
-    HC_HIP(hipGetLastError());
+    {
+        KernelTimer kt(c->stream);
+        hc::launch_synth_rirf(c->dK.p, c->ntiles, c->ngp, c->Dloc, c->D, S, 6 * c->b0, dt_rirf, seed, c->rho, c->stream);
+        HC_HIP(hipGetLastError());
+        c->init.synth_seconds += kt.stop();
+        c->init.synth_bytes += 8.0 * static_cast<double>(c->dK.n);
+    }
     // small per-body tables from the same counter-based stream, on the host
     auto mix = [](uint64_t x) {
         x += 0x9E3779B97F4A7C15ull;
@@ -928,6 +996,12 @@ int hc_synth_fill(hc_ctx* c, unsigned long long seed, int S, double dt_rirf, int
     }
     HC_HIP(hipStreamSynchronize(c->stream));
     HC_API_END(c)
+}
+
+int hc_get_init_stats(const hc_ctx* c, hc_init_stats* out) {
+    if (!c || !out) return HC_ERR_INVALID;
+    *out = c->init;
+    return HC_OK;
 }
 
 }  // extern "C"

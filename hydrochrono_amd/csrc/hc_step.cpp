@@ -381,6 +381,17 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     // Where this step's kernels go: the direct queue (hc_direct.hpp) when the step comes from hc_step and needs no plain
     // convolution launch -- the steady state of a look-ahead run -- else the HIP stream.  Nothing orders the two against each
     // other on the device, so the side that was used last is drained at a switch.
+    if (c->tile_counter_suspect) {
+        // A step failed after its kernels may have gone out (step_abort): a wide_step_kernel that was cut short leaves its tiles'
+        // arrival counters non-zero, and no workgroup of a later launch would find itself last.  Everything the context has in
+        // flight is waited for, then the counters start from zero again.  BEFORE the routing decision below: quiesce_direct leaves
+        // the context on the HIP side (path 1), and a step that then goes out on the direct queue must find path == 2 when it waits
+        // (wait_tagged asks the stream otherwise, finds it idle and declares the device lost).
+        quiesce_direct(c);
+        HC_HIP(hipStreamSynchronize(c->stream));
+        HC_HIP(hipMemset(c->d_tile_counter.p, 0, c->d_tile_counter.n * sizeof(int)));
+        c->tile_counter_suspect = false;
+    }
     const bool direct = c->direct_ready && host_tagged && stream == c->stream && !f.scratch_out &&
                         (c->dk_step.ok() || !((run_rad && !block) || nchunks_ex > 0)) &&
                         !(c->profiling && profiling_tool_attached());  // the library's own timings under a tool: HIP events
@@ -566,15 +577,6 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         static const bool fused_on = HC_TUNE_INT("HC_WIDE_FUSED", 1) != 0;
         const long long wide_wgs   = static_cast<long long>(c->ntiles) * hc::near_slices_for(c->D);
         if (fused_on && !f.scratch_out && wide_wgs <= 2LL * c->num_cus && c->d_tile_counter.n >= static_cast<size_t>(c->ntiles) && (!direct || c->dk_wide.ok())) {
-            if (c->tile_counter_suspect) {
-                // A step failed after its kernels may have gone out (step_abort): a wide_step_kernel that was cut short leaves its
-                // tiles' arrival counters non-zero, and no workgroup of a later launch would find itself last.  Everything the
-                // context has in flight is waited for, then the counters start from zero again.
-                quiesce_direct(c);
-                HC_HIP(hipStreamSynchronize(c->stream));
-                HC_HIP(hipMemset(c->d_tile_counter.p, 0, c->d_tile_counter.n * sizeof(int)));
-                c->tile_counter_suspect = false;
-            }
             hc::WideStepArgs w{na, z, c->d_tile_counter.p};
             if (direct) {
                 const hc::WideLaunch l = hc::wide_launch_config(w);
@@ -609,10 +611,77 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         // can ask for it before it has read a single argument (finalize_kernel<4, true>)
         SlotStateFill fill{c, host_state};
         const hc::FinalizeLaunch l = hc::finalize_launch_config(z);
+#ifdef HC_TUNING
+        if (c->stamps_on && l.grid <= hc::kStampWGs) {
+            if (c->d_stamps.n == 0) {
+                c->d_stamps.alloc(static_cast<size_t>(hc::kStampSteps) * hc::kStampWGs * hc::kStampStages);
+                HC_HIP(hipMemset(c->d_stamps.p, 0, c->d_stamps.n * sizeof(unsigned long long)));
+            }
+            z.stamps = c->d_stamps.p + (seq % hc::kStampSteps) * hc::kStampWGs * hc::kStampStages;
+        }
+#endif
+        // The common block step -- the step's own IRF samples against its own velocity only, look-ahead row and scatter results there,
+        // no plain partials -- goes to the step kernel written for exactly that (step_hot_kernel: compact argument block, every load
+        // requested up front); everything else keeps the general one.  Same arithmetic in the same order (bitwise the same forces).
+        bool hot = c->step_hot && block && z.P && z.Yc && z.nchunks_rad == 0 && z.nchunks_ex == 0 && z.n_near_slices == 0 && (z.n_near == 1 || z.n_near == 2) &&
+                   z.do_hs && z.do_rad && z.do_waves && !z.user_out && z.wave_mode != hc::kWaveSpectral && (z.wave_mode != hc::kWaveIrregular || z.E) &&
+                   (z.wave_mode != hc::kWaveRegular || z.reg_mag);
+        for (int e = 0; hot && e < z.n_near; ++e) hot = z.near[e].b == 0.0 && z.near[e].c == 0.0;
+        if (hot) {
+            hc::StepHotArgs h{};
+            for (int e = 0; e < 2; ++e) {
+                const hc::NearEntry& ne = z.near[std::min(e, z.n_near - 1)];
+                const int f0 = ne.s * c->D, g0 = f0 >> 3, g1 = (f0 + c->D + 7) >> 3;
+                h.kfirst[e] = z.nearK.base + static_cast<size_t>(g0) * 128;
+                h.ng[e]     = g1 - g0;
+                h.off[e]    = f0 - 8 * g0;
+                h.a[e]      = ne.a;
+            }
+            h.Yc = z.Yc; h.P = z.P; h.E = z.E ? z.E : z.P;
+            h.lin = z.lin; h.cg = z.cg; h.cb_m_cg = z.cb_m_cg; h.disp_vol = z.disp_vol;
+            h.reg_mag = z.reg_mag ? z.reg_mag : z.P;
+            h.ngp = z.nearK.ngp; h.n_terms = z.n_terms; h.Dpad = z.Dpad; h.Dloc = z.Dloc; h.N = z.N; h.b0 = z.b0; h.ntiles = c->ntiles;
+            h.D = c->D; h.wave_mode = z.wave_mode; h.has_E = z.E ? 1 : 0;
+            h.rho = z.rho; h.gx = z.gx; h.gy = z.gy; h.gz = z.gz; h.t = z.t; h.reg_amplitude = z.reg_amplitude; h.reg_omega = z.reg_omega;
+            for (int i = 0; i < 6; ++i) h.reg_phase[i] = z.reg_phase[i];
+            h.seq = z.seq; h.hs = z.hs; h.rad = z.rad; h.waves = z.waves; h.total = z.total; h.host_tagged = z.host_tagged; h.canary_out = z.canary_out;
+            h.ring_t = z.ring_t; h.ring_v = z.ring_v; h.ring_vT = z.ring_vT; h.head = z.head; h.Hcap = z.Hcap; h.HcapT = z.HcapT;
+#ifdef HC_TUNING
+            h.stamps = z.stamps;
+#endif
+            const size_t lds = static_cast<size_t>(z.n_near) * c->D * sizeof(double);
+            static const bool no_acquire = HC_TUNE_INT("HC_STEP_NO_ACQUIRE", 0) != 0;  // (tuning experiment: timing only, EXPERIMENTS.md round 6)
+            c->dq->dispatch(c->dk_step_hot[z.n_near - 1], static_cast<uint32_t>(c->ntiles + 1), 256, static_cast<uint32_t>(lds), &h, sizeof h, direct_tag(c, hc::kEvStep), 0.0,
+                            0, fill_slot_state, &fill, no_acquire);
+            c->prof.hot_steps += 1;
+        } else if (c->step_preload) {
+            // the addresses of the step kernel's first loads in front of its argument block, where the packet processor preloads them
+            hc::FinalizePreArgs pz{};
+            const bool near_on = z.do_rad && z.n_near > 0;
+            const int f0 = near_on ? z.near[0].s * c->D : 0, g0 = f0 >> 3, g1 = (f0 + c->D + 7) >> 3;
+            pz.kfirst  = z.nearK.base + static_cast<size_t>(near_on ? g0 : 0) * 128;
+            pz.ngroups = near_on ? g1 - g0 : 0;
+            pz.ngp     = z.nearK.ngp;
+            pz.yc      = z.Yc;
+            pz.n_terms = (z.do_rad && z.Yc) ? z.n_terms : 0;
+            pz.dpad    = c->Dpad;
+            pz.ntiles  = c->ntiles;
+            pz.a       = z;
+            c->dq->dispatch(c->dk_finalize_pre, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &pz, sizeof pz, direct_tag(c, hc::kEvStep), 0.0, 0,
+                            fill_slot_state, &fill);
+        } else
         c->dq->dispatch(c->dk_finalize_slot, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &z, sizeof z, direct_tag(c, hc::kEvStep), 0.0, 0,
                         fill_slot_state, &fill);
         c->prof.direct_dispatches += 1;
         c->prof.slot_state_steps += 1;
+#ifdef HC_TUNING
+        if (z.stamps) {
+            c->host_stamps[seq % hc::kStampSteps][1] = c->dq->system_ticks();  // doorbell of the step kernel
+            c->host_stamps[seq % hc::kStampSteps][3] = static_cast<unsigned long long>(l.grid);
+        } else if (c->stamps_on) {
+            c->host_stamps[seq % hc::kStampSteps][3] = 0;
+        }
+#endif
     } else if (direct) {
         if (!z.state) state_into_args();
         const hc::FinalizeLaunch l = hc::finalize_launch_config(z);
@@ -796,6 +865,12 @@ void step_begin(hc_ctx* c, double t, const double* pos, const double* rpy, const
                  static_cast<double>((c->fault_stale_state_at >= 0 && static_cast<long long>(seq_next) == c->fault_stale_state_at) ? seq_next - 1 : seq_next)};
     c->step_canary_in = nullptr;
     const unsigned long long seq = ++c->seq;
+#ifdef HC_TUNING
+    if (c->stamps_on && c->dq) {
+        c->host_stamps[seq % hc::kStampSteps][0] = c->dq->system_ticks();  // (a few hundred ns after the call's entry: the cache rules are behind us)
+        c->host_stamps[seq % hc::kStampSteps][3] = 0;
+    }
+#endif
     c->step_canary_out = canary_enabled() ? c->h_canary.dp + (seq & 1) * 2 : nullptr;
     // The tagged results of consecutive steps go to alternate halves of the result buffer: a reader in ANOTHER process (a caller's
     // buffer in shared memory, hc_set_result_buffer) may still be collecting step n while this process has moved on to step n + 1;
@@ -813,6 +888,9 @@ void step_end(hc_ctx* c, double* force_out) {
     if (how == 2) {
         if (c->tail.pending) enqueue_tail(c);  // (a caller that deferred the tail and never enqueued it)
         wait_tagged(c, result_tags_host(c, c->seq), c->seq, c->stream, c->last_total.data());
+#ifdef HC_TUNING
+        if (c->stamps_on && c->dq) c->host_stamps[c->seq % hc::kStampSteps][2] = c->dq->system_ticks();  // every row's granule has arrived
+#endif
         if (canary_enabled()) check_canary(c, c->seq);
         if (c->device_errors_possible) {
             quiesce_direct(c);
@@ -1200,6 +1278,39 @@ int hc_set_lookahead(hc_ctx* c, int steps) {
 }
 
 #ifdef HC_TUNING
+// Tuning build only (profiles/step_stamps_probe.cpp): the stage clock of the step kernel.  hc_tuning_enable_step_stamps switches it on;
+// hc_tuning_step_stamps hands out, for step `seq` (one of the last kStampSteps), the host's stamps {begin of the step, doorbell of the
+// step kernel, totals seen} and the [workgroups][kStampStages] stage times of the step kernel's workgroups, all in microseconds after
+// the host's begin stamp (GPU clock converted to the HSA system clock by the runtime, hsa_amd_profiling_convert_tick_to_system_domain).
+// Returns HC_ERR_INVALID for a step that was not one direct dispatch of finalize_kernel<4, true> (no stamps were taken).
+int hc_tuning_enable_step_stamps(hc_ctx* c, int on) {
+    HC_API_BEGIN(c)
+    c->stamps_on = on != 0;
+    HC_API_END(c)
+}
+int hc_tuning_step_stamps(hc_ctx* c, unsigned long long seq, double* host_us3, double* wg_us, int* n_wg, int* n_stage) {
+    HC_API_BEGIN(c)
+    require(host_us3 && wg_us && n_wg && n_stage && c->dq, HC_ERR_INVALID, "bad arguments");
+    require(seq <= c->seq && seq + hc::kStampSteps > c->seq && c->d_stamps.n > 0, HC_ERR_INVALID, "no stamps of that step are kept");
+    const unsigned long long* hsx = c->host_stamps[seq % hc::kStampSteps];
+    const int grid = static_cast<int>(hsx[3]);
+    require(grid > 0, HC_ERR_INVALID, "that step did not go out as one direct dispatch of the slot-state step kernel");
+    HC_HIP(hipDeviceSynchronize());
+    std::vector<unsigned long long> raw(static_cast<size_t>(hc::kStampWGs) * hc::kStampStages);
+    HC_HIP(hipMemcpy(raw.data(), c->d_stamps.p + (seq % hc::kStampSteps) * raw.size(), raw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const double us_per_tick = 1e6 / static_cast<double>(std::max<uint64_t>(1, c->dq->system_ticks_per_second()));
+    const double t0          = static_cast<double>(hsx[0]);
+    for (int k = 0; k < 3; ++k) host_us3[k] = (static_cast<double>(hsx[k]) - t0) * us_per_tick;
+    for (int w = 0; w < grid; ++w)
+        for (int k = 0; k < hc::kStampStages; ++k) {
+            const unsigned long long g = raw[static_cast<size_t>(w) * hc::kStampStages + k];
+            wg_us[w * hc::kStampStages + k] = g ? (static_cast<double>(c->dq->gpu_to_system(g)) - t0) * us_per_tick : -1.0;
+        }
+    *n_wg    = grid;
+    *n_stage = hc::kStampStages;
+    HC_API_END(c)
+}
+
 // Tuning build only (profiles/pass_depth_probe.py): the pass kernel of depth 16 / 32 / 64 over this context's K, `reps` launches timed
 // with HIP events, for the predicted steps that would follow the newest history sample -- also for contexts whose step path has no
 // plan at that depth (a wide system at depth 64), so that the depth-64 pass can be measured at C4-rank size.  The context's
@@ -1275,11 +1386,20 @@ int hc_set_pass_schedule(hc_ctx* c, int one_block_ahead, int slices) {
     HC_API_END(c)
 }
 
+int hc_get_schedule(const hc_ctx* c, int* lookahead, int* pass_schedule, int* ahead_now, int* slices) {
+    if (!c) return HC_ERR_INVALID;
+    if (lookahead) *lookahead = c->lookahead;
+    if (pass_schedule) *pass_schedule = c->pass_ahead == 2 ? -1 : c->pass_ahead;
+    if (ahead_now) *ahead_now = c->pass_ahead == 2 ? (c->ahead_now ? 1 : 0) : c->pass_ahead;
+    if (slices) *slices = c->pass_slices;
+    return HC_OK;
+}
+
 int hc_direct_dispatch_active(const hc_ctx* c) { return (c && c->direct_ready) ? 1 : 0; }
 const char* hc_dispatch_mode_reason(const hc_ctx* c) {
     if (!c) return "no context";
     if (!c->finalized) return "hc_finalize has not been called";
-    return c->direct_ready ? "direct AQL dispatch" : c->direct_why.c_str();
+    return c->direct_ready ? c->direct_how.c_str() : c->direct_why.c_str();
 }
 
 int hc_reset_history(hc_ctx* c) {

@@ -266,6 +266,13 @@ class HydroForces:
         mode = -1 if one_block_ahead is None or int(one_block_ahead) < 0 else int(bool(one_block_ahead))
         self._chk(self.lib.hc_set_pass_schedule(self.ctx, mode, int(slices)))
 
+    def schedule(self):
+        """hc_get_schedule: {"lookahead": 0 | 16 | 32 (what hc_set_lookahead made of its argument), "pass_schedule": -1 adaptive | 0 | 1,
+        "ahead_now": the adaptive rule's current answer, "slices"}."""
+        v = [C.c_int() for _ in range(4)]
+        self._chk(self.lib.hc_get_schedule(self.ctx, *[C.byref(x) for x in v]))
+        return dict(zip(("lookahead", "pass_schedule", "ahead_now", "slices"), (x.value for x in v)))
+
     def rirf_value(self, row_local, col, st):
         """TestHydro::GetRIRFval(row, col, st) for a local row (src/hydro_forces.cpp:693-711)."""
         v = C.c_double()
@@ -320,6 +327,12 @@ class HydroForces:
         p = capi.ProfileStats()
         self._chk(self.lib.hc_get_profile(self.ctx, C.byref(p)))
         return {k: getattr(p, k) for k, _ in capi.ProfileStats._fields_}
+
+    def init_stats(self):
+        """hc_get_init_stats: what the init half of the path cost this context, stage by stage (seconds and bytes)."""
+        st = capi.InitStats()
+        self._chk(self.lib.hc_get_init_stats(self.ctx, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_ if k != "pad_"}
 
     def rirf_width(self):
         w = np.empty(self.sizes()["S"])

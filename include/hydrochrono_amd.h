@@ -278,8 +278,16 @@ int hc_set_lookahead(hc_ctx* ctx, int steps);
  * The schedule is part of the configuration: the row shards of one array must use the same one (and the same slice count) to
  * stay bitwise equal to the unsharded context -- pin it (0 or 1) where that matters across separately driven contexts; under the
  * adaptive schedule two runs agree to rounding (1e-15), not bit for bit, when their callers' gaps differ.
- * HC_PASS_AHEAD=0/1 (HC_PASS_SLICES=n, HC_PASS_CONCURRENT=0: no queue of its own) in the environment pin the default of new contexts. */
+ * HC_PASS_AHEAD=0/1 in the environment pins the default of new contexts (HC_PASS_CONCURRENT=0: no queue of its own); the slice count
+ * is set through this call only.
+ * REPRODUCIBILITY: with the schedule pinned (0 or 1) a run is bitwise repeatable whatever the caller's timing; under the adaptive
+ * default it is repeatable to rounding ("Reproducibility"). */
 int hc_set_pass_schedule(hc_ctx* ctx, int one_block_ahead, int slices);
+/* What is in force: the look-ahead depth (0, 16 or 32: hc_set_lookahead clamps what it is given to what this build of the library
+ * holds), the pass schedule (-1 adaptive, 0 at block start, 1 one block ahead), under the adaptive schedule the rule's current answer
+ * (1: the next pass goes one block ahead), and the slice count of a pass made ahead.  Any pointer may be NULL.  For hosts that drive
+ * the row shards of one array from several processes and want them to run ONE schedule: read it on one rank, pin it on all. */
+int hc_get_schedule(const hc_ctx* ctx, int* lookahead, int* pass_schedule, int* ahead_now, int* slices);
 /* How hc_step hands its kernels to the GPU.  1: as AQL packets written straight into an HSA queue of the library's own (kernel
  * arguments stored through the PCIe BAR) -- the default when the stand-alone code object hc_kernels.co lies next to the library,
  * the device's memory is host-addressable and the start-up self-tests pass (a dispatch completes; memory and argument slots the
@@ -362,6 +370,8 @@ typedef struct hc_profile_stats {
                                     * schedule this is the rule's answer block by block) */
     long long ring_grows_for_pass; /* times the history ring was re-allocated so that a pass one block ahead can read its view of the
                                     * history while the block's steps push their samples (steps well below the IRF spacing) */
+    long long hot_steps;           /* of slot_state_steps: block steps that went to the step kernel of the common case (step_hot_kernel: the
+                                    * step's own IRF samples against its own velocity only, no plain partials, no spectral wave mode) */
 } hc_profile_stats;
 /* HIP events around the kernels of every `on`-th step (on = 1: every step; 0: off, the default), and around every
  * look-ahead pass (one per block) whatever the stride.  Event records perturb the launch stream by a few
@@ -369,6 +379,28 @@ typedef struct hc_profile_stats {
 int hc_enable_profiling(hc_ctx* ctx, int on);
 int hc_get_profile(hc_ctx* ctx, hc_profile_stats* out);
 int hc_reset_profile(hc_ctx* ctx);
+
+/* What the INIT half of the path cost this context (seconds of host wall clock unless stated; GPU kernels by HIP events), stage by
+ * stage, with the bytes each stage has to move -- so that a host (and bench.py's `init` block) can put every stage beside its
+ * bound: the HDF5 reads beside the file size, the staging copies beside the PCIe rate, the re-layout / TaperedDirect / generator
+ * kernels beside the HBM rate, the free-surface synthesis beside the FP64 rate.  Accumulated since hc_create. */
+typedef struct hc_init_stats {
+    double h5_read_seconds, h5_read_bytes;             /* hc_load_bemio_h5: HDF5 reads (datasets this context reads) */
+    double rirf_h2d_seconds, rirf_h2d_bytes;           /* radiation IRF tensors {6, 6N, S} per owned body, pageable host memory -> HBM staging */
+    double rirf_relayout_seconds, rirf_relayout_bytes; /* relayout_rirf_kernel: file order -> panel layout, rho folded in (bytes read + written) */
+    double finalize_seconds;                           /* hc_finalize: widths, hydrostatic tables, added mass, buffers, direct-dispatch set-up + self-tests */
+    double direct_setup_seconds;                       /* ... of which the direct-dispatch set-up (code object, queues, self-tests) */
+    double wave_resample_seconds;                      /* hc_set_wave_irregular: excitation-IRF resample (LinSpaced + cubic B-spline, host) */
+    double wave_spectrum_seconds;                      /* ... spectrum, phases, wavenumbers (host) */
+    double wave_eta_seconds;                           /* ... free-surface table on the GPU: eta_kernel (direct FP64 sum) or the rocFFT chirp-z form */
+    long long wave_eta_samples, wave_eta_components;   /* nt, nf of that table */
+    int wave_eta_mode, pad_;                           /* 0 direct sum, 1 rocFFT */
+    double wave_upload_seconds, wave_upload_bytes;     /* ... Kex re-layout, table uploads, read-back of eta */
+    double wave_total_seconds;                         /* ... the whole call */
+    double taper_seconds, taper_bytes;                 /* TaperedDirect preprocessing (taper_kernel; bytes read + written) */
+    double synth_seconds, synth_bytes;                 /* hc_synth_fill: the generator kernel (bytes written) */
+} hc_init_stats;
+int hc_get_init_stats(const hc_ctx* ctx, hc_init_stats* out);
 
 /* Sizes: S radiation samples, L resampled excitation samples, nf wave components, nt eta samples,
  * H current history length, Hcap ring capacity. Any pointer may be NULL. */

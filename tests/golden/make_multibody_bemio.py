@@ -82,9 +82,10 @@ int main(int argc, char** argv) {
 '''
 
 
-def write_case(N, seed, stem, vlen_copy):
-    S, nw, n_exc = 32, 16, 33
-    case = many_body_case(N, S=S, dt_rirf=0.02, n_exc=n_exc, dt_exc=0.05, nw=nw, seed=seed)
+def bemio_records(case):
+    """The datasets of a BEMIO file for `case` (hydrochrono_amd.synthetic.many_body_case layout), in file order:
+    [(name, array | str)] and the same arrays flat by name."""
+    N = case["N"]
     recs, flat = [], {}
 
     def num(name, arr, shape):
@@ -96,9 +97,11 @@ def write_case(N, seed, stem, vlen_copy):
     num("/simulation_parameters/g", [case["g"]], ())
     recs.append(("/simulation_parameters/water_depth", "infinite"))
     w = case["bodies"][0]["w"]
+    nw = len(w)
     num("/simulation_parameters/w", w, (nw, 1))
     for b, bd in enumerate(case["bodies"]):
         p = f"/body{b + 1}"
+        S, n_exc = len(bd["rirf_t"]), len(bd["ex_irf_t"])
         num(p + "/properties/disp_vol", [bd["disp_vol"]], ())
         num(p + "/properties/body_number", [b + 1.0], ())
         num(p + "/properties/cg", bd["cg"], (3,))
@@ -111,6 +114,14 @@ def write_case(N, seed, stem, vlen_copy):
         num(p + "/hydro_coeffs/excitation/phase", bd["ex_phase"], (6, 1, nw))
         num(p + "/hydro_coeffs/excitation/impulse_response_fun/t", bd["ex_irf_t"], (n_exc,))
         num(p + "/hydro_coeffs/excitation/impulse_response_fun/f", bd["ex_irf_f"], (6, 1, n_exc))
+    return recs, flat
+
+
+def write_bemio(case, paths_vlen):
+    """Writes `case` as BEMIO HDF5 files: paths_vlen = [(path, variable-length water-depth string?)].  Needs gcc and libhdf5 (the small C
+    writer above is built in a temporary directory; /opt/conda holds HDF5 in this image).  Any size: bench.py's `init` block writes the
+    C3-size file (64 bodies x 1024 IRF samples, 1.2 GB) to /tmp with it.  Returns the flat arrays."""
+    recs, flat = bemio_records(case)
     with tempfile.TemporaryDirectory() as tmp:
         spec, src, exe = (os.path.join(tmp, x) for x in ("spec.bin", "w.c", "w"))
         with open(spec, "wb") as f:
@@ -118,12 +129,20 @@ def write_case(N, seed, stem, vlen_copy):
                 if isinstance(a, str):
                     f.write(f"{name}\n-1 {len(a)}\n".encode() + a.encode())
                 else:
-                    f.write((name + "\n" + " ".join([str(a.ndim)] + [str(d) for d in a.shape]) + "\n").encode() + a.tobytes())
+                    f.write((name + "\n" + " ".join([str(a.ndim)] + [str(d) for d in a.shape]) + "\n").encode())
+                    f.write(memoryview(a).cast("B") if a.ndim else a.tobytes())
         open(src, "w").write(WRITER)
         subprocess.run(["gcc", "-O1", src, "-o", exe, "-I/opt/conda/include", "-L/opt/conda/lib", "-lhdf5", "-Wl,-rpath,/opt/conda/lib"], check=True)
-        subprocess.run([exe, spec, os.path.join(HERE, stem + ".h5"), "0"], check=True)
-        if vlen_copy:
-            subprocess.run([exe, spec, os.path.join(HERE, stem + "_vlen.h5"), "1"], check=True)
+        for path, vlen in paths_vlen:
+            subprocess.run([exe, spec, path, "1" if vlen else "0"], check=True)
+    return flat
+
+
+def write_case(N, seed, stem, vlen_copy):
+    S, nw, n_exc = 32, 16, 33
+    case = many_body_case(N, S=S, dt_rirf=0.02, n_exc=n_exc, dt_exc=0.05, nw=nw, seed=seed)
+    paths = [(os.path.join(HERE, stem + ".h5"), False)] + ([(os.path.join(HERE, stem + "_vlen.h5"), True)] if vlen_copy else [])
+    flat = write_bemio(case, paths)
     np.savez_compressed(os.path.join(HERE, stem + "_bemio.npz"), **flat)
     print(f"wrote {stem}.h5, {stem}_bemio.npz" + (f", {stem}_vlen.h5" if vlen_copy else ""))
 

@@ -49,6 +49,13 @@ class StubShard:
         if rc:
             raise RuntimeError(f"stub context: status {rc}")
 
+    def schedule(self):
+        return {"lookahead": self.lookahead, "pass_schedule": -1, "ahead_now": 0, "slices": 4}
+
+    def step(self, t, pos, rpy, linvel, angvel):
+        state = np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in (pos, rpy, linvel, angvel)])
+        return fake_forces(t, state, self.rows)
+
     def sizes(self):
         return {"N": self.N, "n_local": self.b1 - self.b0, "S": 1024, "L": 1023, "nf": 512, "nt": 0, "H": 0, "Hcap": 0}
 

@@ -665,3 +665,50 @@ def test_wave_model_change_while_the_next_blocks_rows_are_made_ahead(hydro, monk
         assert p["ahead_blocks"] >= 4, p
         gpu.close()
         orc.close()
+
+
+@pytest.mark.parametrize("schedule", [0, 1], ids=["pass_at_block_start", "pass_one_block_ahead"])
+def test_pinned_schedule_is_bitwise_repeatable_whatever_the_callers_timing_c3_size(hydro, schedule):
+    """The reproducibility contract (reference: a run is repeatable at a fixed thread count, "deterministic
+    combine", src/hydro_forces.cpp:641-647).  Under the adaptive DEFAULT the pass schedule follows the caller's gaps, the two schedules
+    group the chunks of K differently, and two runs with different caller timing agree to rounding only.  With the schedule PINNED
+    (hc_set_pass_schedule(ctx, 0 | 1, 0)) nothing the library computes depends on when the caller calls: the same states give the same
+    bits -- here at C3 size, 544 steps, one run back to back through the C ABI's own loop and one with 0 ... 120 us of host work
+    (busy waits of changing length) between the calls."""
+    import time
+    import bench as B
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    case = many_body_case(64, S=B.S_RIRF, dt_rirf=B.DT, n_exc=B.N_EXC, dt_exc=B.DT, seed=20251031)
+    motion = PrescribedMotion(64, rest_positions(case), seed=20251031)
+    kw = dict(B.WAVES, simulation_dt=B.DT, simulation_duration=B.T0 + 12.0)
+    nhist = B.S_RIRF + 5
+    t_hist = B.T0 - B.DT * np.arange(1, nhist + 1)
+    v_hist = np.stack([motion.velocity6(t) for t in t_hist])
+    n = 544
+    times = B.T0 + B.DT * np.arange(n)
+    states = np.stack([motion.packed(t) for t in times])
+    runs, made_ahead = [], []
+    for gaps in (False, True):
+        gpu = hydro.HydroForces.from_case(case)
+        gpu.add_waves_irregular(num_bodies=64, **kw)
+        gpu.set_pass_schedule(schedule)
+        gpu.set_history(t_hist, v_hist)
+        if not gaps:
+            forces, _ = gpu.step_many(times, states)
+        else:
+            rng = np.random.default_rng(5)
+            forces = np.empty((n, gpu.D_local))
+            for k, t in enumerate(times):
+                forces[k] = gpu.step(t, *motion.state(t))
+                stop = time.perf_counter() + float(rng.choice([0.0, 5e-6, 30e-6, 120e-6]))
+                while time.perf_counter() < stop:
+                    pass
+        p = gpu.profile()
+        made_ahead.append(int(p["ahead_blocks"]))
+        assert (p["schedule_blocks_ahead"] == 0) if schedule == 0 else (p["schedule_blocks_at_start"] == 0), p  # the pin held
+        runs.append(forces)
+        gpu.close()
+    assert np.array_equal(runs[0], runs[1])
+    if schedule == 1:
+        assert min(made_ahead) >= 10, made_ahead  # blocks did start with rows made one block ahead, in both runs

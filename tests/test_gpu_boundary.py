@@ -303,3 +303,94 @@ def test_state_behind_the_step_kernels_arguments_is_bitwise_the_classic_path(mon
         assert all(c < len(times) for c in counts[0]), counts  # ... but not the plain ones
     else:
         assert all(c == 0 for c in counts[0])
+
+
+@pytest.mark.parametrize("N, waves, dt", [(1, "regular", 0.01), (3, "irregular", 0.01), (6, "none", 0.007), (64, "irregular", 0.01), (64, "regular", 0.007), (170, "none", 0.01)],
+                         ids=["1-body-regular", "3-bodies-irregular", "6-bodies-two-own-samples", "64-bodies-irregular", "64-bodies-regular-two-own-samples", "170-bodies"])
+def test_step_kernel_of_the_common_block_step_is_bitwise_the_general_one(monkeypatch, N, waves, dt, tuning_build):
+    """step_hot_kernel (hc_kernels.hip; round 6) takes the block steps of the common shape -- the step's own IRF samples against its
+    own velocity only, look-ahead row and scatter results there, state behind the arguments -- with a compact argument block and every
+    load requested up front.  Same products and sums in the same order: bitwise the forces (and the three components) of
+    finalize_kernel<4, true> (HC_STEP_HOT=0), over blocks with one own sample (dt = IRF spacing) and two (dt below it), column counts
+    that are and are not multiples of 8, every wave model that is eligible, plain steps in between and a step back in time."""
+    import hydrochrono_amd.hydro as hydro
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_DIRECT", "1")
+    case = many_body_case(N, S=128 if N > 100 else 96, dt_rirf=0.01, n_exc=21, dt_exc=0.02, seed=900 + N)
+    motion = PrescribedMotion(N, rest_positions(case), seed=3)
+    times, t = [], 0.0
+    for n in range(240):
+        t += dt if (n < 140 or n > 170) else 0.004 + 0.0007 * (n % 11)  # blocks, then irregular steps (plain), then blocks again
+        times.append(t)
+    times[215] = times[211]  # a step back in time
+    times = times[:216] + [times[215] + dt * (k + 1) for k in range(24)]
+    runs, hot = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HC_STEP_HOT", flag)
+        h = hydro.HydroForces.from_case(case)
+        if waves == "regular":
+            h.add_waves_regular(0.4, 0.9)
+        elif waves == "irregular":
+            h.add_waves_irregular(simulation_dt=dt, simulation_duration=8.0, ramp_duration=0.5, wave_height=2.0, wave_period=6.0, frequency_min=0.05,
+                                  frequency_max=0.6, nfrequencies=40, peak_enhancement_factor=3.3)
+        rows = []
+        for tt in times:
+            f = h.step(tt, *motion.state(tt))
+            rows.append(np.concatenate([f] + list(h.components())))
+        runs.append(np.stack(rows))
+        p = h.profile()
+        hot.append((p["hot_steps"], p["slot_state_steps"]))
+        h.close()
+    assert np.array_equal(runs[0], runs[1])
+    # the block steps went to the kernel under test (not the first S steps: while the history is shorter than the IRF window one IRF
+    # sample per step is left to the step with its whole bracket, which the general kernel takes; not the plain steps in between)
+    assert hot[1][0] == 0 and hot[0][0] >= 40, hot
+    assert hot[0][0] <= hot[0][1]
+
+
+def test_a_failed_step_of_a_wide_context_leaves_the_next_steps_on_the_direct_path(monkeypatch):
+    """Round-5 advisor finding: after a step that failed (step_abort marks the arrival counters of the fused wide step as suspect) the
+    recovery -- everything in flight waited for, counters cleared -- ran AFTER the step had been routed to the direct queue and left
+    the context marked as "on the HIP side" while its kernel went out as an AQL packet: the step's wait then asked an idle stream,
+    could declare the device lost on a slow step, and the queue was not parked.  The recovery now runs before the routing decision.
+    Seen from outside: with HC_ARM=2 every direct step parks its queue once -- also the step right after a failed one -- and the forces
+    are those of a context that never failed."""
+    import ctypes as C
+    import hydrochrono_amd.hydro as hydro
+    from hydrochrono_amd import capi
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_DIRECT", "1")
+    monkeypatch.setenv("HC_ARM", "2")
+    N = 171  # wide: 6N >= 1024
+    case = many_body_case(N, S=96, dt_rirf=0.01, n_exc=21, dt_exc=0.02, seed=77)  # (an IRF long enough for look-ahead blocks to form)
+    motion = PrescribedMotion(N, rest_positions(case), seed=5)
+    times = [0.01 * (k + 1) for k in range(190)]
+    k_fail = 160
+
+    def run(fail):
+        h = hydro.HydroForces.from_case(case)
+        h.add_waves_regular(0.3, 0.8)
+        rows, parks = [], []
+        for k, t in enumerate(times):
+            if fail and k == k_fail:
+                st = motion.state(t + 0.005)
+                out = np.zeros(h.D_local)
+                rc = capi.step_raw(h.lib)(h.ctx, t + 0.005, None, st[1].ctypes.data, st[2].ctypes.data, st[3].ctypes.data, out.ctypes.data)
+                assert rc != 0  # null pointer: the step is refused before anything is enqueued, and aborted
+            rows.append(h.step(t, *motion.state(t)))
+            parks.append(h.profile()["queue_parkings"])
+        fused = h.profile()["wide_fused_steps"]
+        direct = h.direct_dispatch()[0]
+        h.close()
+        return np.stack(rows), np.array(parks), fused, direct
+
+    ref, _, _, _ = run(False)
+    got, parks, fused, direct = run(True)
+    if not direct:
+        pytest.skip("direct dispatch not available on this box")
+    assert fused > 50  # the fused wide step is what runs here
+    assert np.array_equal(ref, got)
+    d = np.diff(parks)
+    assert np.all(d[k_fail - 1:k_fail + 10] == 1), d[k_fail - 3:k_fail + 12]  # the step right after the failure parked its queue like every other

@@ -349,3 +349,41 @@ def test_bench_multi_rank_control_flow_world8_stub(exchange, bodies):
     assert "error" not in o, o
     assert o["exchange"] == ("rccl" if exchange == "host" else "host") and o["collective_world_size"] == world and o["collective_backend"] == "gloo"
     assert o["rccl_world_size"] is None  # (gloo here; on GPUs this is the RCCL communicator's size)
+
+
+def test_bench_no_launcher_gpus8_line_is_first_contact_proof_stub():
+    """`python bench.py --gpus 8` WITHOUT a launcher -- what a driver may run on an 8-GPU node -- is one process (hc_step_multi over eight
+    shard contexts, host gather).  Its line must stand on its own at first contact: the timed region aligned to a look-ahead block
+    boundary, `roofline` and `per_shard` kernel splits, `passes_in_timed_region`, an `exchange_check` (rows of hc_step_multi against each
+    shard's own hc_step), `cpu_baseline: null` with the reason -- and `rccl_ranks`: the launcher form started as a CHILD process before
+    this one touches a GPU (one rank per GPU, RCCL all-gather of the rows every step; gloo here), so that the one command also says
+    whether RCCL saw eight ranks.  Rehearsed on CPU with the stub context (no physics)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    world, bodies = 8, 44
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "24", "--warmup", "5", "--stub-context", "--bodies", str(bodies)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(env, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 24 and d["warmup"] == 5 and d["scaling"] == "strong" and d["value"] > 0
+    # the timed region: 5 warm-up steps behind an alignment stretch that puts a block boundary into its middle
+    assert (d["alignment_steps"] + 5 + 12) % 32 == 0 and "passes_in_timed_region" in d
+    from hydrochrono_amd.parallel_split import body_shard
+    assert [p["rows"] for p in d["per_shard"]] == [6 * (b1 - b0) for b0, b1 in (body_shard(bodies, world, g) for g in range(world))]
+    for p in d["per_shard"]:
+        assert set(p["kernel_us_per_step"]) >= {"pass", "short_passes", "scatter", "step_kernels"} and "pass_frac_of_hbm_peak" in p
+    assert d["roofline"]["bound"] == "hbm" and {"frac_max_over_shards", "frac_min_over_shards", "units_per_launch"} <= set(d["roofline"])
+    ec = d["exchange_check"]
+    assert ec["rows_of_hc_step_multi_equal_each_shards_own_hc_step"] is True and ec["steps_checked"] > 0 and ec["finite"] is True
+    assert d["cpu_baseline"] is None and "C4" in d["cpu_baseline_note"]
+    rr = d["rccl_ranks"]
+    assert "error" not in rr, rr
+    assert rr["n_gpus"] == world and rr["exchange"] == "rccl" and rr["collective_world_size"] == world and rr["collective_backend"] == "gloo"
+    assert rr["exchange_check"]["own_rows_bitwise_on_every_rank"] is True and rr["exchange_check"]["all_ranks_hold_the_same_vectors"] is True
+    assert [p["rank"] for p in rr["per_rank"]] == list(range(world)) and rr["ms_per_step"] > 0
+    assert rr["pass_schedule_pinned_for_all_ranks"] in ("at block start", "one block ahead")

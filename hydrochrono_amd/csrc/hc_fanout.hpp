@@ -16,7 +16,9 @@
 //
 // fork(): the child has the pool's bookkeeping but none of its threads.  run() compares the process id with the one the workers were
 // created under; in a child it forgets the inherited workers (their objects are leaked -- there is nothing to join) and their
-// synchronisation objects (a mutex copied while a worker held it would stay locked for ever) and starts afresh.
+// synchronisation objects (a mutex copied while a worker held it would stay locked for ever) and starts afresh.  Several threads of
+// the child may enter run() at once: the one that swaps the recorded process id for a marker does the re-initialisation, the others
+// run their items themselves meanwhile (the pool is not theirs yet) -- nothing of the pool is touched outside that one thread.
 //
 // Host cost: a worker that has just served a call spins for `spin_us` before it sleeps, i.e. a host that calls more often than that
 // keeps n - 1 cores busy for the whole run (hydrochrono_amd: HC_MULTI_SPIN_US, INTEGRATION.md has the measured trade-off).
@@ -51,7 +53,7 @@ class FanOut {
     FanOut(const FanOut&)            = delete;
     FanOut& operator=(const FanOut&) = delete;
     ~FanOut() {
-        if (::getpid() != pid_) {  // a forked child: the threads belong to the parent
+        if (::getpid() != pid_.load(std::memory_order_acquire)) {  // a forked child: the threads belong to the parent
             forget_inherited_workers();
             return;
         }
@@ -71,7 +73,16 @@ class FanOut {
     // fn(arg, 0) on this thread, fn(arg, g) for g = 1 .. n - 1 on the workers, side by side; returns when all have returned.
     void run(int n, Fn fn, void* arg) {
         if (n <= 0) return;
-        if (::getpid() != pid_) after_fork();
+        const pid_t me = ::getpid();
+        pid_t owner    = pid_.load(std::memory_order_acquire);
+        if (owner != me) {
+            if (owner != kReinitialising && pid_.compare_exchange_strong(owner, kReinitialising, std::memory_order_acq_rel)) {
+                after_fork(me);  // (ends by recording `me`)
+            } else {
+                for (int g = 0; g < n; ++g) fn(arg, g);  // another thread of this child is re-initialising the pool right now
+                return;
+            }
+        }
         bool expected = false;
         if (n == 1 || max_workers_ <= 0 || !busy_.compare_exchange_strong(expected, true, std::memory_order_acquire)) {
             for (int g = 0; g < n; ++g) fn(arg, g);  // nothing to share out, or another thread is using the pool
@@ -130,14 +141,14 @@ class FanOut {
         workers_.clear();
         (void)sync_.release();
     }
-    void after_fork() {
+    void after_fork(pid_t me) {
         forget_inherited_workers();
         sync_ = std::make_unique<Sync>();
         generation_.store(0, std::memory_order_seq_cst);
         sleepers_.store(0, std::memory_order_seq_cst);
         busy_.store(false, std::memory_order_seq_cst);
         stop_.store(false, std::memory_order_seq_cst);
-        pid_ = ::getpid();
+        pid_.store(me, std::memory_order_release);
     }
 
     void ensure_workers(int count) {
@@ -189,7 +200,8 @@ class FanOut {
     std::atomic<int> sleepers_{0};
     std::atomic<bool> stop_{false}, busy_{false};
     std::unique_ptr<Sync> sync_;
-    pid_t pid_;
+    static constexpr pid_t kReinitialising = -1;  // (no process has this id)
+    std::atomic<pid_t> pid_;
     Fn fn_     = nullptr;
     void* arg_ = nullptr;
     int n_     = 0;

@@ -322,36 +322,53 @@ void fill_slot_state(char* extra, void* user) {
     h[4 * n3] = w.hs->canary;
 }
 
+// ---- one evaluation = StepJob: what enqueue_step decides once, and the pieces that act on it -----------------------------------
+// The four shapes of a step (round-5 review: one 330-line function held all of them):
+//   plain          no look-ahead block (first steps, a time off the predicted grid, look-ahead off): conv_step_kernel over all live
+//                  columns of K (+ the excitation chunks), then the step kernel adds the chunk partials        launch_plain_convolution
+//   block step     inside a block: ONE step kernel -- own IRF samples, look-ahead row, scatter results          add_block_part,
+//                  (step_hot_kernel for the common shape, finalize_kernel otherwise)                            dispatch_step_kernel
+//   wide           6N >= 1024: the own-sample part split over column slices, fused with the step kernel
+//                  (wide_step_kernel) or as near_split_kernel + finalize_kernel                                 dispatch_wide_step
+//   device path    hc_step_device (state and result in HBM, a caller's stream): the same launches through HIP  (direct == false)
 // host_state (hc_step): the caller's state has NOT been stored anywhere yet (d_state is null).  A step whose one kernel is the step
 // kernel of the direct path takes it behind that kernel's argument block (fill_slot_state); every other step stores it the classic way
-// first (stage_host_state) -- decided here, where the step's shape is known.
-void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f,
-                  unsigned long long* host_tagged, unsigned long long seq, bool defer_tail, const HostState* host_state) {
-    require(!c->tail.pending, HC_ERR_INVALID, "a step begun with hc_step_begin has not been completed (hc_step_end)");
-    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
-    const bool irregular = c->wave_kind == hc::kWaveIrregular;
-    if (f.waves) check_wave_ready(c, t);
-    profile_begin_step(c);
+// first (stage_host_state) -- decided where the step's shape is known.
+struct StepJob {
+    hc_ctx* c;
+    double t;
+    const double* d_state;
+    double* d_user_out;
+    hipStream_t stream;
+    StepFlags f;
+    unsigned long long* host_tagged;
+    unsigned long long seq;
+    const HostState* host_state;
     int H = 0, m = 0;
-    if (f.rad) {
-        ensure_processed(c);
-        H = history_push(c, t);
-        m = plan_step(c, t, H);
+    bool run_rad = false, run_exc = false, block = false, direct = false, caller_waits = false;
+    const double *P_row = nullptr, *E_row = nullptr;
+    int nchunks_rad = 0, nchunks_ex = 0;
+    StepViews vw{};
+    // (a state still in the caller's hands goes to its classic place as soon as a kernel other than the direct step kernel wants it)
+    const double* staged_state() {
+        if (!d_state && host_state) d_state = stage_host_state(c, *host_state, seq);
+        return d_state;
     }
-    const bool run_rad = f.rad && H >= 2;  // "Nothing to convolve with if we don't yet have at least 2 time points" (:580)
-    const bool run_exc = f.waves && irregular;
-    const StepViews vw = make_views(c);
-    const bool block   = run_rad && m > 0;
-    // A caller's stream that is idle now belongs to a caller that waits for every step (the force exchange of a row-sharded
-    // array): the work later steps need then goes to the context's own stream, see below.  A caller that runs ahead of the GPU
-    // (stream still busy) gets everything on its stream in order -- the two event hops per step would only slow it down.
-    bool caller_waits = false;
-    if (stream != c->stream && f.rad && c->lookahead > 0) {
+};
+
+// A caller's stream that is idle now belongs to a caller that waits for every step (the force exchange of a row-sharded array): the
+// work later steps need then goes to the context's own stream (enqueue_tail).  A caller that runs ahead of the GPU (stream still busy)
+// gets everything on its stream in order -- the two event hops per step would only slow it down.  And: the steps of a context normally
+// stay on one stream; when they move, this step is ordered behind the previous one with an event.
+void order_streams(StepJob& j) {
+    hc_ctx* c = j.c;
+    const hipStream_t stream = j.stream;
+    if (stream != c->stream && j.f.rad && c->lookahead > 0) {
         if (c->busy_caller_steps > 0) {
             --c->busy_caller_steps;  // found busy a moment ago: do not pay for the query on every step of a caller that runs ahead
         } else {
             const hipError_t q = hipStreamQuery(stream);
-            caller_waits       = q == hipSuccess;
+            j.caller_waits     = q == hipSuccess;
             if (q != hipSuccess) {
                 (void)hipGetLastError();
                 c->busy_caller_steps = 15;
@@ -359,28 +376,25 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         }
     }
     if (c->have_last_stream && c->last_stream != stream) {
-        // The steps of a context normally stay on one stream (the velocity ring is updated in stream order).  When they
-        // move -- hc_step after hc_step_device on a caller's stream, or the reverse -- this step is ordered behind the
-        // previous one with an event.  A caller's stream may have been destroyed since (after a synchronise): then there is
-        // nothing left to wait for.
+        // hc_step after hc_step_device on a caller's stream, or the reverse.  A caller's stream may have been destroyed since (after a
+        // synchronise): then there is nothing left to wait for.
         if (hipEventRecord(c->ev_fin, c->last_stream) == hipSuccess) HC_HIP(hipStreamWaitEvent(stream, c->ev_fin, 0));
         else (void)hipGetLastError();
     }
     c->last_stream      = stream;
     c->have_last_stream = true;
     if (c->bg_pending) {
-        // the scatter / pass of the previous step ran on the context's own stream (see below): this step's kernels need them
+        // the scatter / pass of the previous step ran on the context's own stream: this step's kernels need them
         if (stream != c->stream) HC_HIP(hipStreamWaitEvent(stream, c->ev_bg, 0));
         c->bg_pending = false;
     }
-    const double* P_row = block ? rows_P(c, false) + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
-    const double* E_row = (block && run_exc && c->plan.has_exc) ? rows_E(c, false) + static_cast<size_t>(m - 1) * c->Dpad : nullptr;
+}
 
-    // plain step: all live columns of K, plus the excitation chunks unless a pass has left the excitation force
-    int nchunks_rad = 0, nchunks_ex = (run_exc && !E_row) ? c->nchunks_ex : 0;
-    // Where this step's kernels go: the direct queue (hc_direct.hpp) when the step comes from hc_step and needs no plain
-    // convolution launch -- the steady state of a look-ahead run -- else the HIP stream.  Nothing orders the two against each
-    // other on the device, so the side that was used last is drained at a switch.
+// Where this step's kernels go: the direct queue (hc_direct.hpp) when the step comes from hc_step and needs no plain convolution
+// launch the direct queue cannot take -- the steady state of a look-ahead run -- else the HIP stream.  Nothing orders the two against
+// each other on the device, so the side that was used last is drained at a switch.
+void route_step(StepJob& j) {
+    hc_ctx* c = j.c;
     if (c->tile_counter_suspect) {
         // A step failed after its kernels may have gone out (step_abort): a wide_step_kernel that was cut short leaves its tiles'
         // arrival counters non-zero, and no workgroup of a later launch would find itself last.  Everything the context has in
@@ -392,123 +406,121 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
         HC_HIP(hipMemset(c->d_tile_counter.p, 0, c->d_tile_counter.n * sizeof(int)));
         c->tile_counter_suspect = false;
     }
-    const bool direct = c->direct_ready && host_tagged && stream == c->stream && !f.scratch_out &&
-                        (c->dk_step.ok() || !((run_rad && !block) || nchunks_ex > 0)) &&
-                        !(c->profiling && profiling_tool_attached());  // the library's own timings under a tool: HIP events
-    if (direct && c->path != 2) {
+    j.direct = c->direct_ready && j.host_tagged && j.stream == c->stream && !j.f.scratch_out &&
+               (c->dk_step.ok() || !((j.run_rad && !j.block) || j.nchunks_ex > 0)) &&
+               !(c->profiling && profiling_tool_attached());  // the library's own timings under a tool: HIP events
+    if (j.direct && c->path != 2) {
         // switching from HIP launches to the direct queue: everything the HIP side still runs must have finished.  A preceding
-        // step on a caller's stream (hc_step_device) has been ordered in front of c->stream by the ev_fin wait above, and what it
-        // left on the context's own stream (ev_bg) runs there too, so draining c->stream covers both.
+        // step on a caller's stream (hc_step_device) has been ordered in front of c->stream by the ev_fin wait of order_streams, and
+        // what it left on the context's own stream (ev_bg) runs there too, so draining c->stream covers both.
         HC_HIP(hipStreamSynchronize(c->stream));
         c->bg_pending = false;
         c->path       = 2;
-    } else if (!direct) {
+    } else if (!j.direct) {
         quiesce_direct(c);
         c->path = 1;
     }
-    // (a state still in the caller's hands goes to its classic place as soon as a kernel other than the direct step kernel wants it)
-    auto staged_state = [&]() {
-        if (!d_state && host_state) d_state = stage_host_state(c, *host_state, seq);
-        return d_state;
-    };
-    if (!host_state || !direct || !c->slot_state) staged_state();
-    if ((run_rad && !block) || nchunks_ex > 0) {
-        hc::HistoryView hv{};
-        hv.state   = staged_state();
-        hv.N       = c->N;
-        hv.D       = c->D;
-        hv.t       = t;
-        hv.ring_t  = c->d_ring_t.p;
-        hv.ring_v  = c->d_ring_v.p;
-        hv.head    = c->head;
-        hv.H       = H;
-        hv.Hcap    = c->Hcap;
-        hv.HcapT   = c->HcapT;
-        hv.dt_hint = (H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
-        hc::StepArgs a{};
-        a.K       = rad_panel(c);
-        a.F_limit = (run_rad && !block) ? std::min(c->S, live_samples(c, t)) * c->D : 0;
-        a.chunk_gp = c->chunk_gp;
-        nchunks_rad           = ((a.F_limit + 7) / 8 + a.chunk_gp - 1) / a.chunk_gp;
-        a.nchunks_rad         = nchunks_rad;
-        a.max_steps_per_chunk = (a.chunk_gp * 8) / c->D + 2;
-        a.rhs_capacity        = 8 * std::max(a.chunk_gp, c->chunk_gp_ex);
-        a.hist                = hv;
-        a.tau                 = c->d_tau.p;
-        a.width               = c->d_width.p;
-        a.Kex                 = vw.kex;
-        a.ex                  = vw.ex;
-        a.chunk_gp_ex         = c->chunk_gp_ex;
-        a.nchunks_ex          = nchunks_ex;
-        a.partials            = c->d_partials.p;
-        a.Dpad                = c->Dpad;
-        a.ngroups             = c->ngroups;
-        a.error_flag          = c->d_err.p;
-        const double rad_b = 8.0 * (static_cast<double>(c->Dloc) * a.F_limit + a.F_limit);
-        const double exc_b = nchunks_ex > 0 ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
-        const int kind     = nchunks_rad > 0 ? hc::kEvConvPlain : hc::kEvConvExc;
-        const double share = exc_b / std::max(1.0, rad_b + exc_b);
-        if (direct) {
-            const hc::StepLaunch l = hc::step_launch_config(a, c->mt);
-            if (l.nblocks > 0) {
-                c->dq->dispatch(c->dk_step, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &a, sizeof a, direct_tag(c, kind), share);
-                c->prof.direct_dispatches += 1;
-            }
-        } else {
-            hc::EventPair* ev = ev_begin(c, kind, stream, share);
-            hc::launch_conv_step(a, c->mt, stream);
-            c->prof.hip_launches += 1;
-            ev_end(ev, stream);
-        }
-    }
+}
 
-    hc::FinalizeArgs z{};
-    z.partials    = c->d_partials.p;
-    z.nchunks_rad = nchunks_rad;
-    z.nchunks_ex  = nchunks_ex;
-    z.P           = P_row;
-    z.E           = E_row;
-    if (block) {
-        const auto& pl = c->plan;
-        z.nearK     = rad_panel(c);
-        z.ring_v_ro = c->d_ring_v.p;
-        for (int e = 0; e < pl.n_own[m]; ++e) {
-            hc::NearEntry& ne = z.near[z.n_near++];
-            ne   = hc::NearEntry{};
-            ne.s = pl.own_s[m][e];
-            ne.a = pl.own_a[m][e];
+// plain step: all live columns of K, plus the excitation chunks unless a pass has left the excitation force
+void launch_plain_convolution(StepJob& j) {
+    hc_ctx* c = j.c;
+    hc::HistoryView hv{};
+    hv.state   = j.staged_state();
+    hv.N       = c->N;
+    hv.D       = c->D;
+    hv.t       = j.t;
+    hv.ring_t  = c->d_ring_t.p;
+    hv.ring_v  = c->d_ring_v.p;
+    hv.head    = c->head;
+    hv.H       = j.H;
+    hv.Hcap    = c->Hcap;
+    hv.HcapT   = c->HcapT;
+    hv.dt_hint = (j.H >= 2 && c->times[0] > c->times[1]) ? (c->times[0] - c->times[1]) : 1.0;
+    hc::StepArgs a{};
+    a.K       = rad_panel(c);
+    a.F_limit = (j.run_rad && !j.block) ? std::min(c->S, live_samples(c, j.t)) * c->D : 0;
+    a.chunk_gp = c->chunk_gp;
+    j.nchunks_rad         = ((a.F_limit + 7) / 8 + a.chunk_gp - 1) / a.chunk_gp;
+    a.nchunks_rad         = j.nchunks_rad;
+    a.max_steps_per_chunk = (a.chunk_gp * 8) / c->D + 2;
+    a.rhs_capacity        = 8 * std::max(a.chunk_gp, c->chunk_gp_ex);
+    a.hist                = hv;
+    a.tau                 = c->d_tau.p;
+    a.width               = c->d_width.p;
+    a.Kex                 = j.vw.kex;
+    a.ex                  = j.vw.ex;
+    a.chunk_gp_ex         = c->chunk_gp_ex;
+    a.nchunks_ex          = j.nchunks_ex;
+    a.partials            = c->d_partials.p;
+    a.Dpad                = c->Dpad;
+    a.ngroups             = c->ngroups;
+    a.error_flag          = c->d_err.p;
+    const double rad_b = 8.0 * (static_cast<double>(c->Dloc) * a.F_limit + a.F_limit);
+    const double exc_b = j.nchunks_ex > 0 ? 8.0 * (static_cast<double>(c->Dloc) * c->L + c->L) : 0.0;
+    const int kind     = j.nchunks_rad > 0 ? hc::kEvConvPlain : hc::kEvConvExc;
+    const double share = exc_b / std::max(1.0, rad_b + exc_b);
+    if (j.direct) {
+        const hc::StepLaunch l = hc::step_launch_config(a, c->mt);
+        if (l.nblocks > 0) {
+            c->dq->dispatch(c->dk_step, static_cast<uint32_t>(l.nblocks), 256, static_cast<uint32_t>(l.smem), &a, sizeof a, direct_tag(c, kind), share);
+            c->prof.direct_dispatches += 1;
         }
-        const int sd = pl.s_defer[m - 1];
-        if (sd >= 0) {
-            // the IRF sample the pass left to this step: its whole bracket, with the caller's time and the history as it is
-            hc::Bracket br{};
-            if (host_bracket(c, t - c->tau[sd], H, &br) && (br.wo != 0.0 || br.wn != 0.0)) {
-                hc::NearEntry& ne = z.near[z.n_near++];
-                ne       = hc::NearEntry{};
-                ne.s     = sd;
-                ne.off_b = br.off_older;
-                ne.b     = br.wo * c->width[sd];
-                if (br.off_newer < 0) ne.a = br.wn * c->width[sd];
-                else {
-                    ne.off_c = br.off_newer;
-                    ne.c     = br.wn * c->width[sd];
-                }
+    } else {
+        hc::EventPair* ev = ev_begin(c, kind, j.stream, share);
+        hc::launch_conv_step(a, c->mt, j.stream);
+        c->prof.hip_launches += 1;
+        ev_end(ev, j.stream);
+    }
+}
+
+// A step inside a look-ahead block: the IRF samples it contracts itself (its own sample's, and the one sample per step the pass could
+// not decide ahead of time while the history is shorter than the IRF window), and the scatter results of the block's earlier steps.
+void add_block_part(const StepJob& j, hc::FinalizeArgs& z) {
+    hc_ctx* c      = j.c;
+    const auto& pl = c->plan;
+    const int m    = j.m;
+    z.nearK     = rad_panel(c);
+    z.ring_v_ro = c->d_ring_v.p;
+    for (int e = 0; e < pl.n_own[m]; ++e) {
+        hc::NearEntry& ne = z.near[z.n_near++];
+        ne   = hc::NearEntry{};
+        ne.s = pl.own_s[m][e];
+        ne.a = pl.own_a[m][e];
+    }
+    const int sd = pl.s_defer[m - 1];
+    if (sd >= 0) {
+        // the IRF sample the pass left to this step: its whole bracket, with the caller's time and the history as it is
+        hc::Bracket br{};
+        if (host_bracket(c, j.t - c->tau[sd], j.H, &br) && (br.wo != 0.0 || br.wn != 0.0)) {
+            hc::NearEntry& ne = z.near[z.n_near++];
+            ne       = hc::NearEntry{};
+            ne.s     = sd;
+            ne.off_b = br.off_older;
+            ne.b     = br.wo * c->width[sd];
+            if (br.off_newer < 0) ne.a = br.wn * c->width[sd];
+            else {
+                ne.off_c = br.off_newer;
+                ne.c     = br.wn * c->width[sd];
             }
         }
-        z.n_terms = pl.n_terms[m];
-        z.Yc      = c->d_Y.p + static_cast<size_t>(m) * hc::kTermMax * c->Dpad;
     }
-    static const bool dbg = HC_TUNE_INT("HC_DEBUG_PLAN", 0) != 0;
-    if (dbg) {
-        std::fprintf(stderr, "[hc] t=%.6f H=%d m=%d n_near=%d n_terms=%d sd=%d nchunks_rad=%d nchunks_ex=%d head=%d\n", t, H, m, z.n_near, z.n_terms,
-                     block ? c->plan.s_defer[m - 1] : -2, nchunks_rad, nchunks_ex, c->head);
-        for (int e = 0; e < z.n_near; ++e)
-            std::fprintf(stderr, "     near s=%d a=%.6g b=%.6g c=%.6g offb=%d offc=%d\n", z.near[e].s, z.near[e].a, z.near[e].b, z.near[e].c, z.near[e].off_b, z.near[e].off_c);
-    }
-    z.host_tagged = host_tagged;
-    z.canary_out  = c->step_canary_out;  // (set by step_begin for this call only; canary_in goes with the state, below)
+    z.n_terms = pl.n_terms[m];
+    z.Yc      = c->d_Y.p + static_cast<size_t>(m) * hc::kTermMax * c->Dpad;
+}
+
+// the step kernel's arguments that do not depend on the step's shape
+void fill_step_args(StepJob& j, hc::FinalizeArgs& z) {
+    hc_ctx* c     = j.c;
+    z.partials    = c->d_partials.p;
+    z.nchunks_rad = j.nchunks_rad;
+    z.nchunks_ex  = j.nchunks_ex;
+    z.P           = j.P_row;
+    z.E           = j.E_row;
+    z.host_tagged = j.host_tagged;
+    z.canary_out  = c->step_canary_out;  // (set by step_begin for this call only; canary_in goes with the state)
     c->step_canary_out = nullptr;
-    z.seq         = seq;
+    z.seq         = j.seq;
     z.Dloc        = c->Dloc;
     z.Dpad        = c->Dpad;
     z.N           = c->N;
@@ -533,17 +545,17 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     z.spec_omega    = c->d_spec_omega.p;
     z.spec_phi      = c->d_spec_phi.p;
     z.spec_ramp     = c->irr.ramp_duration;
-    z.t             = t;
-    z.do_hs         = f.hs;
-    z.do_rad        = run_rad;
-    z.do_waves      = f.waves;
-    double* out4    = f.scratch_out ? c->d_scratch.p : nullptr;
+    z.t             = j.t;
+    z.do_hs         = j.f.hs;
+    z.do_rad        = j.run_rad;
+    z.do_waves      = j.f.waves;
+    double* out4    = j.f.scratch_out ? c->d_scratch.p : nullptr;
     z.hs            = out4 ? out4 : c->d_hs.p;
     z.rad           = out4 ? out4 + c->Dloc : c->d_rad.p;
     z.waves         = out4 ? out4 + 2 * c->Dloc : c->d_waves.p;
     z.total         = out4 ? out4 + 3 * c->Dloc : c->d_total.p;
-    z.user_out      = d_user_out;
-    z.do_push       = f.rad ? 1 : 0;
+    z.user_out      = j.d_user_out;
+    z.do_push       = j.f.rad ? 1 : 0;
     z.head          = c->head;
     z.D             = c->D;
     z.ring_t        = c->d_ring_t.p;
@@ -551,65 +563,110 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
     z.ring_vT       = c->d_ring_vT.p;
     z.Hcap          = c->Hcap;
     z.HcapT         = c->HcapT;
-    auto state_into_args = [&]() {  // the classic state pointer (and the canary word behind it) into the step kernel's arguments
-        z.state            = staged_state();
-        z.canary_in        = c->step_canary_in;
-        c->step_canary_in  = nullptr;
-    };
-    if (z.n_near > 0 && hc::near_slices_for(c->D) > 1) {
-        state_into_args();
-        // wide system: the own-sample part is split over column slices by a kernel of its own (hundreds of workgroups instead of one
-        // per row tile); the step kernel adds the slice partials
-        hc::NearArgs na{};
-        na.K      = z.nearK;
-        na.D      = c->D;
-        na.Dpad   = c->Dpad;
-        na.N      = c->N;
-        na.n_near = z.n_near;
-        for (int e = 0; e < z.n_near; ++e) na.near[e] = z.near[e];
-        na.state    = z.state;
-        na.ring_v   = c->d_ring_v.p;
-        na.partials = c->d_near_partials.p;
-        // ... in ONE launch with the step kernel (wide_step_kernel: the workgroup that completes a row tile's slices finishes the tile):
-        // a dispatch less on the critical path of every block step.  HC_WIDE_FUSED=0: the two launches (same arithmetic, bitwise).
-        // Only while the launch is ONE round of workgroups (218 VGPRs: two per CU): a C4/8 shard has 24 tiles x 8 slices = 192; the
-        // whole 512-body array on one GPU has 1536, runs them in three rounds and is faster with the two launches (23 against 32 us).
-        static const bool fused_on = HC_TUNE_INT("HC_WIDE_FUSED", 1) != 0;
-        const long long wide_wgs   = static_cast<long long>(c->ntiles) * hc::near_slices_for(c->D);
-        if (fused_on && !f.scratch_out && wide_wgs <= 2LL * c->num_cus && c->d_tile_counter.n >= static_cast<size_t>(c->ntiles) && (!direct || c->dk_wide.ok())) {
-            hc::WideStepArgs w{na, z, c->d_tile_counter.p};
-            if (direct) {
-                const hc::WideLaunch l = hc::wide_launch_config(w);
-                c->dq->dispatch(c->dk_wide, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &w, sizeof w, direct_tag(c, hc::kEvStep));
-                c->prof.direct_dispatches += 1;
-            } else {
-                hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
-                hc::launch_wide_step(w, stream);
-                ev_end(ev, stream);
-                c->prof.hip_launches += 1;
-            }
-            c->prof.wide_fused_steps += 1;
-            goto step_kernel_out;
-        }
-        if (direct) {
-            const hc::NearLaunch l = hc::near_launch_config(na);
-            c->dq->dispatch(c->dk_near, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &na, sizeof na, direct_tag(c, hc::kEvStep));
+}
+
+// the classic state pointer (and the canary word behind it) into the step kernel's arguments
+void state_into_args(StepJob& j, hc::FinalizeArgs& z) {
+    z.state              = j.staged_state();
+    z.canary_in          = j.c->step_canary_in;
+    j.c->step_canary_in  = nullptr;
+}
+
+// Wide system (6N >= 1024): the own-sample part is split over column slices by a kernel of its own (hundreds of workgroups instead of
+// one per row tile) and the step kernel adds the slice partials -- in ONE launch where that is one round of workgroups
+// (wide_step_kernel: the workgroup that completes a row tile's slices finishes the tile; returns true: the step is out), else as
+// near_split_kernel here and the step kernel behind it (returns false: z is set up for it).
+bool dispatch_wide_step(StepJob& j, hc::FinalizeArgs& z) {
+    hc_ctx* c = j.c;
+    state_into_args(j, z);
+    hc::NearArgs na{};
+    na.K      = z.nearK;
+    na.D      = c->D;
+    na.Dpad   = c->Dpad;
+    na.N      = c->N;
+    na.n_near = z.n_near;
+    for (int e = 0; e < z.n_near; ++e) na.near[e] = z.near[e];
+    na.state    = z.state;
+    na.ring_v   = c->d_ring_v.p;
+    na.partials = c->d_near_partials.p;
+    // HC_WIDE_FUSED=0: the two launches (same arithmetic, bitwise).  Fused only while the launch is ONE round of workgroups (218 VGPRs:
+    // two per CU): a C4/8 shard has 24 tiles x 8 slices = 192; the whole 512-body array on one GPU has 1536, runs them in three rounds
+    // and is faster with the two launches (23 against 32 us).
+    static const bool fused_on = HC_TUNE_INT("HC_WIDE_FUSED", 1) != 0;
+    const long long wide_wgs   = static_cast<long long>(c->ntiles) * hc::near_slices_for(c->D);
+    if (fused_on && !j.f.scratch_out && wide_wgs <= 2LL * c->num_cus && c->d_tile_counter.n >= static_cast<size_t>(c->ntiles) && (!j.direct || c->dk_wide.ok())) {
+        hc::WideStepArgs w{na, z, c->d_tile_counter.p};
+        if (j.direct) {
+            const hc::WideLaunch l = hc::wide_launch_config(w);
+            c->dq->dispatch(c->dk_wide, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &w, sizeof w, direct_tag(c, hc::kEvStep));
             c->prof.direct_dispatches += 1;
         } else {
-            hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
-            hc::launch_near_split(na, stream);
-            ev_end(ev, stream);
+            hc::EventPair* ev = ev_begin(c, hc::kEvStep, j.stream);
+            hc::launch_wide_step(w, j.stream);
+            ev_end(ev, j.stream);
             c->prof.hip_launches += 1;
-            (void)hc::near_launch_config(na);
         }
-        z.near_partials = c->d_near_partials.p;
-        z.n_near_slices = na.n_slices;
-        z.n_near        = 0;
+        c->prof.wide_fused_steps += 1;
+        return true;
     }
-    if (direct && !d_state && host_state && c->slot_state) {
-        // the step's ONE kernel, and nobody has needed the state so far: it travels behind the kernel's arguments, where the kernel
-        // can ask for it before it has read a single argument (finalize_kernel<4, true>)
-        SlotStateFill fill{c, host_state};
+    if (j.direct) {
+        const hc::NearLaunch l = hc::near_launch_config(na);
+        c->dq->dispatch(c->dk_near, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &na, sizeof na, direct_tag(c, hc::kEvStep));
+        c->prof.direct_dispatches += 1;
+    } else {
+        hc::EventPair* ev = ev_begin(c, hc::kEvStep, j.stream);
+        hc::launch_near_split(na, j.stream);
+        ev_end(ev, j.stream);
+        c->prof.hip_launches += 1;
+        (void)hc::near_launch_config(na);
+    }
+    z.near_partials = c->d_near_partials.p;
+    z.n_near_slices = na.n_slices;
+    z.n_near        = 0;
+    return false;
+}
+
+// The common block step -- the step's own IRF samples against its own velocity only, look-ahead row and scatter results there, no
+// plain partials -- goes to the step kernel written for exactly that (step_hot_kernel: compact argument block, every load requested
+// up front); everything else keeps the general one.  Same arithmetic in the same order (bitwise the same forces).
+bool hot_step_eligible(const StepJob& j, const hc::FinalizeArgs& z) {
+    bool hot = j.c->step_hot && j.block && z.P && z.Yc && z.nchunks_rad == 0 && z.nchunks_ex == 0 && z.n_near_slices == 0 && (z.n_near == 1 || z.n_near == 2) &&
+               z.do_hs && z.do_rad && z.do_waves && !z.user_out && z.wave_mode != hc::kWaveSpectral && (z.wave_mode != hc::kWaveIrregular || z.E) &&
+               (z.wave_mode != hc::kWaveRegular || z.reg_mag);
+    for (int e = 0; hot && e < z.n_near; ++e) hot = z.near[e].b == 0.0 && z.near[e].c == 0.0;
+    return hot;
+}
+hc::StepHotArgs hot_step_args(const hc_ctx* c, const hc::FinalizeArgs& z) {
+    hc::StepHotArgs h{};
+    for (int e = 0; e < 2; ++e) {
+        const hc::NearEntry& ne = z.near[std::min(e, z.n_near - 1)];
+        const int f0 = ne.s * c->D, g0 = f0 >> 3, g1 = (f0 + c->D + 7) >> 3;
+        h.kfirst[e] = z.nearK.base + static_cast<size_t>(g0) * 128;
+        h.ng[e]     = g1 - g0;
+        h.off[e]    = f0 - 8 * g0;
+        h.a[e]      = ne.a;
+    }
+    h.Yc = z.Yc; h.P = z.P; h.E = z.E ? z.E : z.P;
+    h.lin = z.lin; h.cg = z.cg; h.cb_m_cg = z.cb_m_cg; h.disp_vol = z.disp_vol;
+    h.reg_mag = z.reg_mag ? z.reg_mag : z.P;
+    h.ngp = z.nearK.ngp; h.n_terms = z.n_terms; h.Dpad = z.Dpad; h.Dloc = z.Dloc; h.N = z.N; h.b0 = z.b0; h.ntiles = c->ntiles;
+    h.D = c->D; h.wave_mode = z.wave_mode; h.has_E = z.E ? 1 : 0;
+    h.rho = z.rho; h.gx = z.gx; h.gy = z.gy; h.gz = z.gz; h.t = z.t; h.reg_amplitude = z.reg_amplitude; h.reg_omega = z.reg_omega;
+    for (int i = 0; i < 6; ++i) h.reg_phase[i] = z.reg_phase[i];
+    h.seq = z.seq; h.hs = z.hs; h.rad = z.rad; h.waves = z.waves; h.total = z.total; h.host_tagged = z.host_tagged; h.canary_out = z.canary_out;
+    h.ring_t = z.ring_t; h.ring_v = z.ring_v; h.ring_vT = z.ring_vT; h.head = z.head; h.Hcap = z.Hcap; h.HcapT = z.HcapT;
+#ifdef HC_TUNING
+    h.stamps = z.stamps;
+#endif
+    return h;
+}
+
+// The step kernel itself.  On the direct path, when nobody has needed the state so far (the step's ONE kernel): it travels behind the
+// kernel's arguments, where the kernel can ask for it before it has read a single argument (step_hot_kernel / finalize_kernel<4, true>).
+void dispatch_step_kernel(StepJob& j, hc::FinalizeArgs& z) {
+    hc_ctx* c = j.c;
+    if (j.direct && !j.d_state && j.host_state && c->slot_state) {
+        SlotStateFill fill{c, j.host_state};
         const hc::FinalizeLaunch l = hc::finalize_launch_config(z);
 #ifdef HC_TUNING
         if (c->stamps_on && l.grid <= hc::kStampWGs) {
@@ -617,45 +674,18 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
                 c->d_stamps.alloc(static_cast<size_t>(hc::kStampSteps) * hc::kStampWGs * hc::kStampStages);
                 HC_HIP(hipMemset(c->d_stamps.p, 0, c->d_stamps.n * sizeof(unsigned long long)));
             }
-            z.stamps = c->d_stamps.p + (seq % hc::kStampSteps) * hc::kStampWGs * hc::kStampStages;
+            z.stamps = c->d_stamps.p + (j.seq % hc::kStampSteps) * hc::kStampWGs * hc::kStampStages;
         }
 #endif
-        // The common block step -- the step's own IRF samples against its own velocity only, look-ahead row and scatter results there,
-        // no plain partials -- goes to the step kernel written for exactly that (step_hot_kernel: compact argument block, every load
-        // requested up front); everything else keeps the general one.  Same arithmetic in the same order (bitwise the same forces).
-        bool hot = c->step_hot && block && z.P && z.Yc && z.nchunks_rad == 0 && z.nchunks_ex == 0 && z.n_near_slices == 0 && (z.n_near == 1 || z.n_near == 2) &&
-                   z.do_hs && z.do_rad && z.do_waves && !z.user_out && z.wave_mode != hc::kWaveSpectral && (z.wave_mode != hc::kWaveIrregular || z.E) &&
-                   (z.wave_mode != hc::kWaveRegular || z.reg_mag);
-        for (int e = 0; hot && e < z.n_near; ++e) hot = z.near[e].b == 0.0 && z.near[e].c == 0.0;
-        if (hot) {
-            hc::StepHotArgs h{};
-            for (int e = 0; e < 2; ++e) {
-                const hc::NearEntry& ne = z.near[std::min(e, z.n_near - 1)];
-                const int f0 = ne.s * c->D, g0 = f0 >> 3, g1 = (f0 + c->D + 7) >> 3;
-                h.kfirst[e] = z.nearK.base + static_cast<size_t>(g0) * 128;
-                h.ng[e]     = g1 - g0;
-                h.off[e]    = f0 - 8 * g0;
-                h.a[e]      = ne.a;
-            }
-            h.Yc = z.Yc; h.P = z.P; h.E = z.E ? z.E : z.P;
-            h.lin = z.lin; h.cg = z.cg; h.cb_m_cg = z.cb_m_cg; h.disp_vol = z.disp_vol;
-            h.reg_mag = z.reg_mag ? z.reg_mag : z.P;
-            h.ngp = z.nearK.ngp; h.n_terms = z.n_terms; h.Dpad = z.Dpad; h.Dloc = z.Dloc; h.N = z.N; h.b0 = z.b0; h.ntiles = c->ntiles;
-            h.D = c->D; h.wave_mode = z.wave_mode; h.has_E = z.E ? 1 : 0;
-            h.rho = z.rho; h.gx = z.gx; h.gy = z.gy; h.gz = z.gz; h.t = z.t; h.reg_amplitude = z.reg_amplitude; h.reg_omega = z.reg_omega;
-            for (int i = 0; i < 6; ++i) h.reg_phase[i] = z.reg_phase[i];
-            h.seq = z.seq; h.hs = z.hs; h.rad = z.rad; h.waves = z.waves; h.total = z.total; h.host_tagged = z.host_tagged; h.canary_out = z.canary_out;
-            h.ring_t = z.ring_t; h.ring_v = z.ring_v; h.ring_vT = z.ring_vT; h.head = z.head; h.Hcap = z.Hcap; h.HcapT = z.HcapT;
-#ifdef HC_TUNING
-            h.stamps = z.stamps;
-#endif
+        if (hot_step_eligible(j, z)) {
+            const hc::StepHotArgs h = hot_step_args(c, z);
             const size_t lds = static_cast<size_t>(z.n_near) * c->D * sizeof(double);
             static const bool no_acquire = HC_TUNE_INT("HC_STEP_NO_ACQUIRE", 0) != 0;  // (tuning experiment: timing only, EXPERIMENTS.md round 6)
             c->dq->dispatch(c->dk_step_hot[z.n_near - 1], static_cast<uint32_t>(c->ntiles + 1), 256, static_cast<uint32_t>(lds), &h, sizeof h, direct_tag(c, hc::kEvStep), 0.0,
                             0, fill_slot_state, &fill, no_acquire);
             c->prof.hot_steps += 1;
         } else if (c->step_preload) {
-            // the addresses of the step kernel's first loads in front of its argument block, where the packet processor preloads them
+            // (tuning experiment) the addresses of the step kernel's first loads in front of its argument block, where the packet processor preloads them
             hc::FinalizePreArgs pz{};
             const bool near_on = z.do_rad && z.n_near > 0;
             const int f0 = near_on ? z.near[0].s * c->D : 0, g0 = f0 >> 3, g1 = (f0 + c->D + 7) >> 3;
@@ -669,43 +699,85 @@ void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out
             pz.a       = z;
             c->dq->dispatch(c->dk_finalize_pre, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &pz, sizeof pz, direct_tag(c, hc::kEvStep), 0.0, 0,
                             fill_slot_state, &fill);
-        } else
-        c->dq->dispatch(c->dk_finalize_slot, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &z, sizeof z, direct_tag(c, hc::kEvStep), 0.0, 0,
-                        fill_slot_state, &fill);
+        } else {
+            c->dq->dispatch(c->dk_finalize_slot, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &z, sizeof z, direct_tag(c, hc::kEvStep), 0.0, 0,
+                            fill_slot_state, &fill);
+        }
         c->prof.direct_dispatches += 1;
         c->prof.slot_state_steps += 1;
 #ifdef HC_TUNING
         if (z.stamps) {
-            c->host_stamps[seq % hc::kStampSteps][1] = c->dq->system_ticks();  // doorbell of the step kernel
-            c->host_stamps[seq % hc::kStampSteps][3] = static_cast<unsigned long long>(l.grid);
+            c->host_stamps[j.seq % hc::kStampSteps][1] = c->dq->system_ticks();  // doorbell of the step kernel
+            c->host_stamps[j.seq % hc::kStampSteps][3] = static_cast<unsigned long long>(l.grid);
         } else if (c->stamps_on) {
-            c->host_stamps[seq % hc::kStampSteps][3] = 0;
+            c->host_stamps[j.seq % hc::kStampSteps][3] = 0;
         }
 #endif
-    } else if (direct) {
-        if (!z.state) state_into_args();
+    } else if (j.direct) {
+        if (!z.state) state_into_args(j, z);
         const hc::FinalizeLaunch l = hc::finalize_launch_config(z);
         c->dq->dispatch(c->dk_finalize, static_cast<uint32_t>(l.grid), 256, static_cast<uint32_t>(l.smem), &z, sizeof z, direct_tag(c, hc::kEvStep));
         c->prof.direct_dispatches += 1;
     } else {
-        if (!z.state) state_into_args();
-        hc::EventPair* ev = ev_begin(c, hc::kEvStep, stream);
-        hc::launch_finalize(z, stream);
+        if (!z.state) state_into_args(j, z);
+        hc::EventPair* ev = ev_begin(c, hc::kEvStep, j.stream);
+        hc::launch_finalize(z, j.stream);
         c->prof.hip_launches += 1;
-        ev_end(ev, stream);
+        ev_end(ev, j.stream);
     }
-step_kernel_out:
+}
+
+// Enqueue the kernels of one evaluation at time t.  d_state: device-visible pointer to the 12N state (null with host_state: hc_step).
+// d_user_out (device) and host_tagged (mapped pinned granules) may be null.  defer_tail: the caller enqueues the work later steps need
+// itself (enqueue_tail) -- hc_step_multi, after all shard contexts have their step kernels on the way.
+void enqueue_step(hc_ctx* c, double t, const double* d_state, double* d_user_out, hipStream_t stream, StepFlags f,
+                  unsigned long long* host_tagged, unsigned long long seq, bool defer_tail, const HostState* host_state) {
+    require(!c->tail.pending, HC_ERR_INVALID, "a step begun with hc_step_begin has not been completed (hc_step_end)");
+    require(c->finalized, HC_ERR_INVALID, "hc_finalize has not been called");
+    const bool irregular = c->wave_kind == hc::kWaveIrregular;
+    if (f.waves) check_wave_ready(c, t);
+    profile_begin_step(c);
+    StepJob j{c, t, d_state, d_user_out, stream, f, host_tagged, seq, host_state};
+    if (f.rad) {
+        ensure_processed(c);
+        j.H = history_push(c, t);
+        j.m = plan_step(c, t, j.H);
+    }
+    j.run_rad = f.rad && j.H >= 2;  // "Nothing to convolve with if we don't yet have at least 2 time points" (:580)
+    j.run_exc = f.waves && irregular;
+    j.vw      = make_views(c);
+    j.block   = j.run_rad && j.m > 0;
+    order_streams(j);
+    j.P_row = j.block ? rows_P(c, false) + static_cast<size_t>(j.m - 1) * c->Dpad : nullptr;
+    j.E_row = (j.block && j.run_exc && c->plan.has_exc) ? rows_E(c, false) + static_cast<size_t>(j.m - 1) * c->Dpad : nullptr;
+    j.nchunks_ex = (j.run_exc && !j.E_row) ? c->nchunks_ex : 0;
+    route_step(j);
+    if (!host_state || !j.direct || !c->slot_state) j.staged_state();
+    if ((j.run_rad && !j.block) || j.nchunks_ex > 0) launch_plain_convolution(j);
+
+    hc::FinalizeArgs z{};
+    fill_step_args(j, z);
+    if (j.block) add_block_part(j, z);
+    static const bool dbg = HC_TUNE_INT("HC_DEBUG_PLAN", 0) != 0;
+    if (dbg) {
+        std::fprintf(stderr, "[hc] t=%.6f H=%d m=%d n_near=%d n_terms=%d sd=%d nchunks_rad=%d nchunks_ex=%d head=%d\n", t, j.H, j.m, z.n_near, z.n_terms,
+                     j.block ? c->plan.s_defer[j.m - 1] : -2, j.nchunks_rad, j.nchunks_ex, c->head);
+        for (int e = 0; e < z.n_near; ++e)
+            std::fprintf(stderr, "     near s=%d a=%.6g b=%.6g c=%.6g offb=%d offc=%d\n", z.near[e].s, z.near[e].a, z.near[e].b, z.near[e].c, z.near[e].off_b, z.near[e].off_c);
+    }
+    const bool wide = z.n_near > 0 && hc::near_slices_for(c->D) > 1;
+    if (!(wide && dispatch_wide_step(j, z))) dispatch_step_kernel(j, z);
 
     // ---- off the caller's critical path: what later steps need from this one (enqueue_tail) ----
     c->tail              = hc::StepTail{};
     c->tail.pending      = f.rad && c->lookahead > 0;
     c->tail.rad          = f.rad;
     c->tail.waves        = f.waves;
-    c->tail.block        = block;
-    c->tail.direct       = direct;
-    c->tail.caller_waits = caller_waits;
-    c->tail.m            = m;
-    c->tail.H            = H;
+    c->tail.block        = j.block;
+    c->tail.direct       = j.direct;
+    c->tail.caller_waits = j.caller_waits;
+    c->tail.m            = j.m;
+    c->tail.H            = j.H;
     c->tail.stream       = stream;
     if (!defer_tail) enqueue_tail(c);
     HC_HIP(hipGetLastError());
@@ -979,7 +1051,12 @@ struct MultiStatus {
     int finish(hc_ctx* const* ctxs, int n) const {
         for (int g = 0; g < n; ++g)
             if (status[static_cast<size_t>(g)] != HC_OK) {
-                for (int k = 0; k < n; ++k) ctxs[k]->err = message[static_cast<size_t>(g)];  // hc_last_error of any context of the group tells why
+                for (int k = 0; k < n; ++k) {
+                    ctxs[k]->err = message[static_cast<size_t>(g)];  // hc_last_error of any context of the group tells why
+                    // the shards that did step have counted a gap the failed one has not: the adaptive pass schedule of the group
+                    // starts its count afresh on ALL of them, so that they go on deciding alike
+                    reset_schedule_state(ctxs[k]);
+                }
                 return status[static_cast<size_t>(g)];
             }
         return HC_OK;

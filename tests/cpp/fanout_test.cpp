@@ -145,6 +145,30 @@ int main() {
         }
         CHECK(child2 > 0 && waitpid(child2, &status, 0) == child2, "waitpid failed");
         CHECK(WIFEXITED(status) && WEXITSTATUS(status) == 0, "teardown of an inherited pool in a forked child failed (status 0x%x)", status);
+        //  SEVERAL threads of the child enter run() before the pool has been re-initialised: one of them does it, the
+        // others run their items themselves meanwhile; every call completes, every item runs exactly once
+        std::fflush(stdout);
+        const pid_t child3 = fork();
+        if (child3 == 0) {
+            alarm(20);
+            std::atomic<int> go{0}, bad{0};
+            auto caller = [&] {
+                while (go.load() == 0) {
+                }
+                std::vector<long> count(6, 0);
+                auto item = [&](int g) { count[g] += 1; };
+                for (int r = 0; r < 200; ++r) pool.run(6, item);
+                for (int g = 0; g < 6; ++g) bad += count[g] != 200;
+            };
+            std::thread a(caller), b(caller), c2(caller);
+            go.store(1);
+            a.join();
+            b.join();
+            c2.join();
+            _exit(bad.load() ? 3 : 0);
+        }
+        CHECK(child3 > 0 && waitpid(child3, &status, 0) == child3, "waitpid failed");
+        CHECK(WIFEXITED(status) && WEXITSTATUS(status) == 0, "concurrent first calls in a forked child failed (status 0x%x)", status);
     }
 #endif
     std::printf("fanout_test: %d failures\n", failures);

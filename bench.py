@@ -34,12 +34,21 @@ scatter / step kernels), so that one run on a multi-GPU node says which rank was
 N > 1 in ONE process (`python bench.py --gpus N` without a launcher, or `--single-process` under one): the same coupled array
 row-sharded over N contexts of this process, one per visible GPU (all on GPU 0 when the box has fewer: a functional mode), evaluated
 with ONE hc_step_multi per step -- the C-ABI multi-GPU path of a Chrono host (no torch.distributed, no collective; host gather).
-Under torch.distributed.run rank 0 also reports this mode as the secondary `single_process_c_abi` (the other ranks wait).
+The timed region is aligned to a look-ahead block boundary like the N = 1 line; the line carries `roofline` (each shard's pass),
+`per_shard` kernel splits, `passes_in_timed_region`, an `exchange_check` (the rows of hc_step_multi against each shard's own hc_step
+on a second set of contexts), `cpu_baseline: null` with the reason -- and `rccl_ranks`: BEFORE this process touches a GPU it runs the
+launcher form as a child (`python -m torch.distributed.run --nproc-per-node N bench.py --exchange rccl --no-secondary`: one rank per
+GPU, RCCL all-gather of the force rows every step) and attaches that line, so that the one command also says whether RCCL saw N ranks.
+Under torch.distributed.run rank 0 also reports the one-process mode as the secondary `single_process_c_abi` (the other ranks wait).
 
 The JSON line also carries
   roofline      HBM roofline of the dominant kernel (the look-ahead pass): bytes the launch has to move ONCE / mean
                 HIP-event duration / 8 TB/s -- a fraction; the reuse over the 32 (or 16) steps one launch serves is
-                reported separately
+                reported separately; `whole_step`: the bytes of ONE steady-state step (pass / 32 + scatter + own samples)
+                against the memory at the mean and at the median step -- the step itself is latency-bound, and says so
+  init          the init half of the path stage by stage, each beside its bound and beside the oracle's init: BEMIO ingest of
+                a C3-size file (HDF5 read / PCIe copy / re-layout kernel), irregular-wave set-up (resample, spectrum, free-
+                surface synthesis: direct sum and rocFFT; C3 and the sphere-irregular size), TaperedDirect build, generator
   cpu_baseline  the CPU oracle (reference-faithful OpenMP restatement, oracle/) timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N=1 only)
   parity        every timed step compared with the CPU oracle (flat-array variant; the faithful one on its sample)
@@ -59,9 +68,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 # rocprofv3 --kernel-trace --stats of this very command (python bench.py --gpus 1 --steps 20 --warmup 5 --no-c4-share --no-c4-one-gpu
-# --no-small-configs, so that the pass kernel's row holds C3 launches only): roofline.frac = algorithmic_bytes_per_launch / its AverageNs / 8 TB/s
-ROOFLINE_PROFILE = ("profiles/r05/c3_driver_cmd_kernel_stats_by_grid.csv, row hc::conv_block_kernel<6, 4, 2, 1> on 256 workgroups "
-                    "(MEASURED.md: recomputing roofline.frac); PMC: profiles/r05/pmc_traffic.json")
+# --no-small-configs --no-init, so that the pass kernel's row holds C3 launches only): roofline.frac = algorithmic_bytes_per_launch / its AverageNs / 8 TB/s
+ROOFLINE_PROFILE = ("profiles/r06/c3_driver_cmd_kernel_stats_by_grid.csv, row hc::conv_block_kernel<6, 4, 2, 1> on 256 workgroups "
+                    "(MEASURED.md: recomputing roofline.frac); PMC: profiles/r06/pmc_traffic.json, pmc_step_traffic.json")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 HBM_STREAM_CEILING_GBS = 6300.0  # what a pure dwordx4 load stream reaches on this chip (profiles/r05/mfma_vmem_probe.txt: 6.30-6.38 TB/s; the guide: 6.29)
 FP64_MFMA_PEAK_TF = 78.6
@@ -769,7 +778,7 @@ def init_block(case, c3_wave_stats, sdt, duration):
     return out
 
 
-C4_ONE_GPU_FILES = ("profiles/r05/bench_c4_1gpu.json", "profiles/r04/bench_c4_1gpu.json", "profiles/r03/bench_c4_1gpu.json")
+C4_ONE_GPU_FILES = ("profiles/r06/bench_c4_1gpu.json", "profiles/r05/bench_c4_1gpu.json", "profiles/r04/bench_c4_1gpu.json", "profiles/r03/bench_c4_1gpu.json")
 
 
 def c4_one_gpu_reference():

@@ -24,8 +24,10 @@ BEMIO_LIB = os.path.join(LIBDIR, "libhc_bemio.so")
 
 SOURCES = ["hc_kernels.hip", "hc_runtime.cpp", "hc_step.cpp", "hc_pass.cpp", "hc_setup.cpp", "hc_query.cpp", "hc_direct.cpp", "hc_host_math.cpp", "hc_yaml.cpp",
            "hc_eta_fft.cpp"]
-# kernel-argument preload: the leading scalar / pointer arguments of a kernel arrive in scalar registers with the wave (finalize_pre_kernel,
-# hc_kernels.hip); kernels whose first argument is a struct are unaffected
+# kernel-argument preload: the leading scalar / pointer arguments of a kernel arrive in scalar registers with the wave (up to 16 words:
+# added_mass_mv_tagged_kernel starts without a single argument load; the finalize_pre_kernel experiment of the tuning build, EXPERIMENTS.md
+# round 6); kernels whose first argument is a struct -- the step path's -- are unaffected.  The code object only: the library's embedded
+# copies go through HIP launches.
 PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
 KERNEL_CO = os.path.join(LIBDIR, "hc_kernels.co")  # the same kernels as a stand-alone code object, for the direct AQL dispatch (hc_direct.hpp)
 TUNING_CO = os.path.join(LIBDIR, "hc_kernels_tuning.co")

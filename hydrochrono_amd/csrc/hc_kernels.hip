@@ -1685,6 +1685,7 @@ __global__ void __launch_bounds__(64 * NW) finalize_kernel(FinalizeArgs a) {
 }
 template __global__ void finalize_kernel<4, true>(FinalizeArgs);
 
+#ifdef HC_TUNING  // (measured in round 6 and not taken, EXPERIMENTS.md: the tuning build keeps it selectable with HC_STEP_PRELOAD=1)
 // finalize_pre_kernel: finalize_kernel<4, true> whose first dependent hop is gone.  The step kernel's chain is  arguments -> K words /
 // scatter results -> right-hand side -> contraction -> totals: two memory round trips before the first multiply, the first of them to
 // uncached memory (the argument slot the host has just written through the BAR).  The ten leading kernel arguments below are
@@ -1750,6 +1751,7 @@ __global__ void __launch_bounds__(64 * NW) finalize_pre_kernel(const double* __r
     finalize_tile<NW, false, true, true>(a, (int)blockIdx.x, U, red_near, red_term, [] { return true; }, sc, st, ev0, ev1, ev2, ev3, &el);
 }
 template __global__ void finalize_pre_kernel<4>(const double*, const double*, int, int, int, int, int, int, FinalizeArgs);
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // step_hot_kernel<NE>: the step kernel of the common block step (StepHotArgs, hc_kernels.hpp), written around what the stage clock of

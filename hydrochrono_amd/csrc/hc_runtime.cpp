@@ -660,9 +660,11 @@ void setup_direct(hc_ctx* c) {
     if (c->dk_wide.kernarg != sizeof(hc::WideStepArgs) || c->dk_wide.priv != 0) c->dk_wide = hc::DirectKernel{};
     if (c->dk_finalize_slot.kernarg != sizeof(hc::FinalizeArgs) || c->dk_finalize_slot.priv != 0) c->dk_finalize_slot = hc::DirectKernel{};
     c->slot_state = HC_TUNE_INT("HC_SLOT_STATE", 1) != 0 && c->dk_finalize_slot.ok() && c->N <= hc::kSlotStateMaxBodies;
-    c->dk_finalize_pre = q->find("finalize_pre_kernelILi4EEEv");  // optional
+#ifdef HC_TUNING
+    c->dk_finalize_pre = q->find("finalize_pre_kernelILi4EEEv");  // (the kernel-argument-preload experiment of round 6)
     if (c->dk_finalize_pre.kernarg != sizeof(hc::FinalizePreArgs) || c->dk_finalize_pre.priv != 0) c->dk_finalize_pre = hc::DirectKernel{};
     c->step_preload = c->slot_state && c->dk_finalize_pre.ok() && HC_TUNE_INT("HC_STEP_PRELOAD", 0) != 0;
+#endif
     c->dk_step_hot[0] = q->find("step_hot_kernelILi1EEEv");  // optional: without them the general step kernel runs every step
     c->dk_step_hot[1] = q->find("step_hot_kernelILi2EEEv");
     for (auto& k : c->dk_step_hot)

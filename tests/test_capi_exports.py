@@ -128,6 +128,8 @@ def test_release_code_object_has_no_spills_no_scratch_and_no_rejected_variants()
     assert not any("conv_block_kernelILi12E" in n for n in rel), "the 12-tile pass variant ships"
     assert not any(re.search(r"conv_block_kernelILi\dELi\dELi4E", n) for n in rel), "a depth-64 pass variant ships"
     assert not any(re.search(r"conv_step_kernelILi\dELi[13]E", n) for n in rel), "an unroll-sweep variant of the plain kernel ships"
+    assert not any("finalize_pre_kernel" in n for n in rel), "the kernel-argument-preload variant of the step kernel ships"
+    assert sum("step_hot_kernel" in n for n in rel) == 2, "the step kernel of the common block step (one and two own IRF samples) is missing"
     tun = _kernel_notes(hb.TUNING_CO)
     assert len(tun) > len(rel) and any(re.search(r"conv_block_kernelILi\dELi\dELi4E", n) for n in tun)
 

@@ -459,14 +459,17 @@ def test_wide_step_in_one_launch_is_bitwise_the_two_launch_form(hydro, direct, m
     runs, counts = [], []
     import tempfile
     with tempfile.TemporaryDirectory() as d:
-        for fused in ("1", "0"):
-            out = os.path.join(d, f"f{fused}.npy")
-            r = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, env=dict(os.environ, HC_WIDE_FUSED=fused, HC_DIRECT=str(direct), HYDROCHRONO_AMD_FLAVOR="tuning"))
+        # ... and once more on the SHIPPED library, which has the fused form only (it does not read the switch): the A/B reaches the
+        # release build's code object too (round-5 review: "the A/B test lives only in the tuning build")
+        for fused, flavor in (("1", "tuning"), ("0", "tuning"), ("1", "release")):
+            out = os.path.join(d, f"f{fused}_{flavor}.npy")
+            r = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, env=dict(os.environ, HC_WIDE_FUSED=fused, HC_DIRECT=str(direct), HYDROCHRONO_AMD_FLAVOR=flavor))
             assert r.returncode == 0, r.stderr[-2000:]
             counts.append(int(r.stdout.strip().splitlines()[-1]))
             runs.append(np.load(out))
-    assert counts[0] >= 300 and counts[1] == 0, counts
+    assert counts[0] >= 300 and counts[1] == 0 and counts[2] >= 300, counts
     assert np.array_equal(runs[0], runs[1])
+    assert np.array_equal(runs[2], runs[1])
     for n, tt in enumerate(times):
         assert relerr(runs[0][n], orc.step(tt, *motion.state(tt))) <= TIGHT_TOL, f"step {n}"
 

@@ -13,7 +13,7 @@
 #include <sstream>
 #include <vector>
 
-#include "../hydrochrono_amd/csrc/hydro_forces_amd.hpp"
+#include "../include/hydroc_amd/setup_hydro_from_yaml.h"
 
 using namespace hydroc_amd;
 

@@ -2,7 +2,7 @@
 //
 // Mirrors the reference's sphere regression drivers (tests/regression/sphere/demo_sphere_decay.cpp,
 // .../reg_waves/sphere_reg_waves_test.cpp, .../irreg_waves/sphere_irreg_waves_test.cpp) through the C++ mirror
-// (hydro_forces_amd.hpp): same TestHydro / wave-class calls, with a 1-DOF symplectic-Euler heave integrator in place
+// (include/hydroc_amd/*.h): same TestHydro / wave-class calls, with a 1-DOF symplectic-Euler heave integrator in place
 // of ChSystem::DoStepDynamics (force at (z_n, v_n, t_n), mass m + rho*Ainf_33).  Prints "t z" with 6 decimals like the
 // reference's result files.
 //   usage: sphere_mock_chrono <sphere.h5> decay|regular|irregular <nsteps>
@@ -11,7 +11,7 @@
 #include <cstring>
 #include <memory>
 
-#include "../hydrochrono_amd/csrc/hydro_forces_amd.hpp"
+#include "../include/hydroc_amd/setup_hydro_from_yaml.h"
 
 using namespace hydroc_amd;
 

@@ -3,7 +3,7 @@
  * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each entry point names
  * the reference interface (file:line relative to the HydroChrono tree @2025-10-31) it replaces.
  * INTEGRATION.md shows the Chrono-side binding (ChFunction / ChLoadCustomMultiple subclasses) that
- * forwards to these calls; hydrochrono_amd/csrc/hydro_forces_amd.hpp is that binding.
+ * forwards to these calls; the headers under include/hydroc_amd are that binding.
  *
  * Conventions
  *   N   = number of hydro bodies of the whole system, D = 6N degrees of freedom.

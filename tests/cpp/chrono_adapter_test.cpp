@@ -1,4 +1,4 @@
-// Drives the guarded Project Chrono adapter block of hydrochrono_amd/csrc/hydro_forces_amd.hpp (ComponentFunc, the two
+// Drives the guarded Project Chrono adapter block of include/hydroc_amd/hydro_forces.h (ComponentFunc, the two
 // WORLD_DIR ChForce objects per body, ChLoadAddedMass in a ChLoadContainer -- src/hydro_forces.cpp:63-168,223-234,
 // src/chloadaddedmass.cpp:27-70) against the stand-in Chrono headers under tests/cpp/chrono_stub/ (test infrastructure).
 //   usage: chrono_adapter_test <sphere.h5> <nsteps>
@@ -10,7 +10,7 @@
 #include <cstdlib>
 
 #define HYDROCHRONO_AMD_WITH_CHRONO 1
-#include "../../hydrochrono_amd/csrc/hydro_forces_amd.hpp"
+#include "../../include/hydroc_amd/setup_hydro_from_yaml.h"
 
 int main(int argc, char** argv) {
     if (argc < 3) return 2;

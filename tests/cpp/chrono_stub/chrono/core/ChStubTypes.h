@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE ONLY -- never shipped, never part of the product.
-// Minimal stand-ins for the few Project Chrono types the adapter block of hydrochrono_amd/csrc/hydro_forces_amd.hpp touches
+// Minimal stand-ins for the few Project Chrono types the adapter block of include/hydroc_amd/hydro_forces.h touches
 // (the classes the reference subclasses / calls: include/hydroc/hydro_forces.h:18-33,45-148, include/hydroc/chloadaddedmass.h:
 // 22-90, src/hydro_forces.cpp:96-101,146-168,223-234, src/chloadaddedmass.cpp:27-70).  Project Chrono is not installed in the
 // build image; these headers exist so that the guarded adapter code is compiled and driven by a test instead of rotting.

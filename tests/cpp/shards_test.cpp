@@ -16,7 +16,7 @@
 #include <vector>
 
 #define HYDROCHRONO_AMD_WITH_CHRONO 1
-#include "../../hydrochrono_amd/csrc/hydro_forces_amd.hpp"
+#include "../../include/hydroc_amd/setup_hydro_from_yaml.h"
 
 int main(int argc, char** argv) {
     if (argc < 7) return 2;

@@ -50,7 +50,7 @@ def test_product_never_touches_the_oracle():
 
 
 def test_cpp_mirror_header_and_example_compile_and_link(tmp_path):
-    """The header-only C++ mirror of the reference's plugin surface (hydro_forces_amd.hpp, Chrono-free part) and the
+    """The header-only C++ mirror of the reference's plugin surface (include/hydroc_amd/*.h, Chrono-free part) and the
     example driver build with plain g++ against the C-ABI library.  Running them needs a GPU (tests/test_gpu_cpp_mirror.py)."""
     import subprocess
     from hydrochrono_amd import build as hb

@@ -1,4 +1,4 @@
-"""The C++ host-side mirror of the reference's plugin surface (hydrochrono_amd/csrc/hydro_forces_amd.hpp) driven by a
+"""The C++ host-side mirror of the reference's plugin surface (include/hydroc_amd/hydro_forces.h) driven by a
 Chrono-free C++ program (examples/sphere_mock_chrono.cpp): BEMIO-HDF5 ingest -> TestHydro / wave classes ->
 CoordinateFuncForBody callbacks -> heave trajectory, compared with the reference's golden files."""
 import os

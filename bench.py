@@ -106,6 +106,7 @@ def parse():
                     "tests/stub_context.StubShard in place of the GPU contexts -- no physics, no timings worth reading")
     ap.add_argument("--no-small-configs", action="store_true", help="skip the c2_two_body / c5_one_body_2048 / added_mass_mv secondaries (each beside its CPU figure)")
     ap.add_argument("--no-c4-one-gpu", action="store_true", help="skip the c4_one_gpu secondary (the whole 512-body array, 77 GB of K, on this GPU)")
+    ap.add_argument("--no-pin", action="store_true", help="do not bind the stepping thread to the CPUs local to its GPU (hc_bind_thread_to_device)")
     ap.add_argument("--no-init", action="store_true", help="skip the `init` block (BEMIO ingest of a C3-size file, irregular-wave set-up, TaperedDirect build: each stage timed beside its bound)")
     ap.add_argument("--exchange", choices=["host", "rccl"], default="host",
                     help="N > 1 under a launcher: how every rank gets all force rows each step.  host (default): hc_step on every rank (direct "
@@ -890,6 +891,8 @@ def main():
         # ---- ONE process, G contexts, hc_step_multi: the multi-GPU path of a Chrono host through the C ABI ----
         G = args.gpus
         devices = [g % max(1, ndev) for g in range(G)]
+        if not stub and not args.no_pin:
+            capi.load().hc_bind_thread_to_device(devices[0])  # (the calling thread runs context 0; the workers of hc_step_multi bind themselves)
         info, _ = run_group_sync(args.bodies, G, devices, sdt, args.lookahead, args.warmup, args.steps, check_steps=0 if args.no_secondary else 40,
                                  stub_cls=HydroForces if stub else None)
         out = {"metric": "hydro-force evals/sec (all bodies)", "value": info["evals_per_s"], "unit": "evals/s", "n_gpus": G, "steps": args.steps,
@@ -939,6 +942,31 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from hydrochrono_amd.parallel import ForceExchange, body_shard
+    # The stepping thread next to its GPU (a synchronous step is a round trip between one host thread and one GPU;
+    # from the other socket it costs 1.4 us more, and an unpinned thread lands on either socket).  hc_bind_thread_to_device restricts
+    # THIS thread to the CPUs local to the device's PCIe root; the CPU baseline below gets the original mask back.
+    host_thread = {"bound_to_device_local_cpus": False}
+    affinity_before = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    if not stub and not args.no_pin and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # (the CPU oracle's OpenMP workers are created HERE, with the mask of every core, before the stepping thread narrows its own:
+        # threads inherit the mask of the thread that creates them)
+        try:
+            import oracle as orc_mod
+            from cases import load_into_oracle
+            orc_mod.set_num_threads(os.cpu_count() or 1)
+            tiny = many_body_case(1, S=16, dt_rirf=0.05, n_exc=9, dt_exc=0.1, seed=1)
+            o_ = load_into_oracle(tiny)
+            o_.add_waves_none()
+            z3 = np.zeros(3)
+            for k_ in range(3):
+                o_.step(0.05 * k_, z3, z3, z3 + 0.1 * k_, z3)
+            del o_
+        except Exception:  # noqa: BLE001
+            pass
+    if not stub and not args.no_pin:
+        buf = C.create_string_buffer(512)
+        if capi.load().hc_device_local_cpus(local_rank, buf, 512) == 0 and capi.load().hc_bind_thread_to_device(local_rank) == 0:
+            host_thread = {"bound_to_device_local_cpus": True, "cpus": buf.value.decode(), "how": "hc_bind_thread_to_device (sched_setaffinity of the stepping thread)"}
     N = args.bodies
     case = None
     if strong:
@@ -1006,6 +1034,8 @@ def main():
     # raw entry point: integer addresses straight through (the timed loop is the C-ABI call and nothing else)
     hc_step = None if stub else C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(
         ("hc_step", capi.load()))
+    hc_step_many_raw = None if stub else C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(
+        ("hc_step_many", capi.load()))
     ctx = gpu.ctx
     sp = [states.ctypes.data + k * states.strides[0] for k in range(n_all)]
     fp = [forces.ctypes.data + k * forces.strides[0] for k in range(n_all)]
@@ -1089,8 +1119,12 @@ def main():
     def run_sync(k0, k1):
         """K synchronous evaluations: state from host memory in, forces in host memory out, one call after the other."""
         if exchange is None and not args.python_loop:
-            # the library's own prescribed-motion loop: hc_step k0 .. k1 - 1 one after the other, no interpreter between the calls
-            gpu.step_many(times_np[k0:k1], states[k0:k1], forces[k0:k1], per_step[k0:k1])
+            # the library's own prescribed-motion loop: hc_step k0 .. k1 - 1 one after the other, no interpreter between the calls --
+            # entered through a raw prototype with the addresses worked out beforehand (the arrays are C-contiguous float64 by
+            # construction), so that a 20-step timed region holds the 20 steps and one foreign call, not the wrapper's array checks
+            rc = hc_step_many_raw(ctx, k1 - k0, times_np.ctypes.data + 8 * k0, sp[k0], fp[k0], per_step.ctypes.data + 8 * k0, None)
+            if rc:
+                gpu._chk(rc)
         elif exchange is None:
             pc = time.perf_counter
             for k in range(k0, k1):
@@ -1424,6 +1458,7 @@ def main():
                               "body-row shards of one coupled array + RCCL all-gather of forces every step") if strong else
                              "one independent farm per GPU, no data-path collective") if world > 1 else "single GPU",
             },
+            "host_thread": host_thread,
             "caller": ("hc_step_many (the C ABI's own loop of K synchronous hc_step calls)"
                        if (world == 1 and exchange is None and not args.python_loop) else "one hc_step (or begin / gather / end) per Python call"),
             "dispatch_mode": dinfo["dispatch_mode"] if (world == 1 or args.exchange == "host") else "HIP launches on the rank's stream (hc_step_device) + RCCL all-gather",
@@ -1506,6 +1541,8 @@ def main():
             except Exception as e:  # a secondary must not cost the run its line
                 out["init"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and case is not None:
+            if affinity_before is not None:
+                os.sched_setaffinity(0, affinity_before)  # the CPU oracle's threads on every core of the box, as before
             base, f_faithful, flat_threads = cpu_baseline(case, motion, t_hist, v_hist, args.cpu_seconds, sdt, duration)
             n_chk = k_next
             f_flat = oracle_all_steps(case, motion, t_hist, v_hist, sdt, duration, n_chk, flat_threads)

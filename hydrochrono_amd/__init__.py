@@ -10,15 +10,13 @@ Importing the package does not load the library; HydroForces() does, and raises 
 """
 import os as _os
 
-# The AQL packet ring of every HSA queue in device memory instead of host memory: 1.4-1.9 us less per synchronous hc_step (the packet
-# processor fetches its packets locally, profiles/r06/queue_dev_mem_ab.txt).  The HSA runtime reads the variable once, at its
-# initialisation, i.e. at the first HIP call of the process -- the library asks for it when it is loaded (hc_runtime.cpp), which in an
-# interpreter can be too late (torch.cuda.is_available() initialises HIP), so the package asks at import.  Not in the ranks of a
-# multi-process launch (WORLD_SIZE > 1): there it would also move RCCL's queues, for 2 % of a wide shard's step.  HC_QUEUE_DEV_MEM=0: never.
-if _os.environ.get("HC_QUEUE_DEV_MEM", "1") != "0" and int(_os.environ.get("WORLD_SIZE", "1") or 1) == 1:
+# HC_QUEUE_DEV_MEM=1 (opt-in): the AQL packet rings of the process's HSA queues in device memory instead of host
+# memory -- 1.0-1.8 us less per synchronous hc_step.  The HSA runtime reads its variable once, at the first HIP call of the process; the
+# library sets it when it is loaded (hc_runtime.cpp), which in an interpreter can be too late (torch.cuda.is_available() initialises
+# HIP), so the package sets it at import.  Not the default: it moves the HIP runtime's own queues too, whose dispatch path does not
+# order its packet stores against its doorbells through the HDP (two of ~2 600 differential cases died with it, EXPERIMENTS.md round 6).
+if _os.environ.get("HC_QUEUE_DEV_MEM", "0") not in ("", "0"):
     _os.environ.setdefault("HSA_ALLOCATE_QUEUE_DEV_MEM", "1")
-elif _os.environ.get("HC_QUEUE_DEV_MEM") is None:
-    _os.environ["HC_QUEUE_DEV_MEM"] = "0"  # (the library's own load-time request stays off as well)
 
 from .hydro import HydroError, HydroForces  # noqa: F401,E402
 

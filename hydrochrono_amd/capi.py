@@ -66,6 +66,8 @@ class InitStats(C.Structure):
 SIGNATURES = {
     "hc_version": (C.c_char_p, []),
     "hc_device_count": (C.c_int, []),
+    "hc_device_local_cpus": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "hc_bind_thread_to_device": (C.c_int, [C.c_int]),
     "hc_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "hc_create_sharded": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "hc_destroy": (None, [C.c_void_p]),

@@ -103,8 +103,17 @@ struct DirectQueue::Impl {
         // signal record of our own in fine-grained DEVICE memory written through the BAR -- the runtime keeps its signals in host memory,
         // so a packet processor parked on `gate` polls across PCIe.
         volatile amd_signal_t* dev_gate = nullptr;
+        bool ring_in_vram = false;  // the runtime put this lane's packet ring into device memory (ensure_lane)
     } lanes[DirectQueue::kLanes];
     char* ring_all = nullptr;
+    // The GPU's HDP flush register (HSA_AMD_AGENT_INFO_HDP_FLUSH), or null.  What the host stores through the BAR -- kernel arguments,
+    // body state and, with the packet ring in device memory, the AQL packets themselves -- passes the HDP on its way into VRAM, and a
+    // doorbell takes another way into the chip: it can reach the packet processor while the tail of those stores is still in the HDP.
+    // Harmless for arguments and state (the packet processor needs microseconds to start a wave; the per-step canary watches it), not
+    // for the packet it reads at once: round 6's long differential runs died twice in ~2 000 cases with the ring in device memory and
+    // no flush ("invalid code object", a memory fault at a garbage address: a packet whose header was new and whose second half was
+    // old).  One store to this register in front of every doorbell writes the HDP back; stores to one device arrive in order.
+    volatile uint32_t* hdp_flush = nullptr;
     uint64_t ticks_per_second = 0;
     struct Timed {
         hsa_signal_t sig;
@@ -138,7 +147,14 @@ struct DirectQueue::Impl {
         hsa_queue_t* queue = ln.queue;
         // header + setup go last, in one 32-bit release store: the packet processor must not see a half-written packet
         const uint32_t word = static_cast<uint32_t>(header) | (static_cast<uint32_t>(setup) << 16);
+        _mm_sfence();  // (a ring in device memory is write-combined memory: the packet's body leaves the core before its header)
         __atomic_store_n(reinterpret_cast<uint32_t*>(packet), word, __ATOMIC_RELEASE);
+        _mm_sfence();
+        if (ln.ring_in_vram) {  // (a ring in host memory is read across PCIe, a microsecond behind the doorbell: what went through the BAR has landed)
+            if (hdp_flush) *hdp_flush = 1u;  // everything stored through the BAR so far is in VRAM before the doorbell is acted on
+            else (void)*reinterpret_cast<volatile uint32_t*>(packet);  // (no flush register mapped: a read through the BAR completes the
+                                                                       // posted stores in front of it -- a PCIe round trip)
+        }
         hsa_signal_store_screlease(queue->doorbell_signal, static_cast<hsa_signal_value_t>(idx));
     }
 };
@@ -255,6 +271,11 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
     s = hsa_executable_iterate_agent_symbols(p.exe, p.agent, walk_symbol, &walk);
     if (s != HSA_STATUS_SUCCESS || p.kernels.empty()) return fail("no kernels in the code object");
 
+    {
+        hsa_amd_hdp_flush_t hdp{};
+        if (hsa_agent_get_info(p.agent, static_cast<hsa_agent_info_t>(HSA_AMD_AGENT_INFO_HDP_FLUSH), &hdp) == HSA_STATUS_SUCCESS && hdp.HDP_MEM_FLUSH_CNTL)
+            p.hdp_flush = hdp.HDP_MEM_FLUSH_CNTL;
+    }
     // lane 0 (the step path) now; lane 1 (added-mass products) when it is first used (ensure_lane): a process that holds many
     // contexts on one device -- row shards sharing a GPU -- then keeps half as many hardware queues busy
     if (!ensure_lane(0, why)) return false;
@@ -310,6 +331,7 @@ bool DirectQueue::ensure_lane(int lane, std::string* why) {
         p.lanes[lane].have_drain_sig = true;
     }
     if (!p.lanes[lane].have_gate && hsa_signal_create(1, 0, nullptr, &p.lanes[lane].gate) == HSA_STATUS_SUCCESS) p.lanes[lane].have_gate = true;
+    p.lanes[lane].ring_in_vram = ring_in_device_memory(lane) == 1;
     return true;
 }
 
@@ -527,6 +549,8 @@ uint64_t DirectQueue::gpu_to_system(uint64_t gpu_ticks) const {
     return t;
 }
 uint64_t DirectQueue::system_ticks_per_second() const { return p_->ticks_per_second; }
+
+bool DirectQueue::hdp_flush_available() const { return p_->hdp_flush != nullptr; }
 
 int DirectQueue::ring_in_device_memory(int lane) const {
     const Impl::Lane& ln = p_->lanes[lane];

@@ -99,6 +99,7 @@ class DirectQueue {
     // from doorbell to kernel start than over PCIe, profiles/r06/queue_dev_mem_ab.txt), 0 host memory, -1 unknown.  The runtime decides
     // when it is initialised (HSA_ALLOCATE_QUEUE_DEV_MEM, requested by this library at load time -- hc_runtime.cpp).
     int ring_in_device_memory(int lane = 0) const;
+    bool hdp_flush_available() const;  // the HDP flush register is mapped: every doorbell is preceded by a write-back of the HDP
 
     static constexpr size_t kSlotBytes  = 4096;   // kernarg bytes per dispatch (the largest argument block is the scatter's 2.6 KB)
     static constexpr size_t kExtraBytes = 16384;  // ... followed by room for data the kernel addresses relative to its kernarg pointer

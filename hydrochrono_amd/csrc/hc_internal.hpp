@@ -64,6 +64,8 @@ extern const char* const kVersion;
 
 
 // ---- hc_runtime.cpp ----
+std::string device_local_cpus(int device);      // the kernel's list of CPUs local to the device's PCIe root ("" when unknown)
+bool bind_calling_thread_to_device(int device); // restricts the calling thread to them (hc_bind_thread_to_device; the fan-out's workers)
 int contexts_on_device(int device);             // contexts this process holds on a device (hc_create_sharded / hc_destroy keep count)
 void count_context_on_device(int device, int delta);
 void quiesce_direct(hc_ctx* c);  // waits for what the direct queue still runs (bounded; HC_ERR_DEVICE on a lost device)

@@ -3,6 +3,10 @@
 // that runs in hc_kernels.hip on the GPU; there is no CPU fallback.
 #include "hc_internal.hpp"
 
+#include <sched.h>
+
+#include <cctype>
+
 #include <atomic>
 
 using namespace hc::detail;
@@ -53,6 +57,56 @@ int contexts_on_device(int device) {
 }
 void count_context_on_device(int device, int delta) {
     if (device >= 0 && device < 64) g_contexts_on_device[device].fetch_add(delta, std::memory_order_relaxed);
+}
+
+// ---- where the stepping thread should run (hc_device_local_cpus / hc_bind_thread_to_device) -------------------------------------
+// /sys/bus/pci/devices/<domain:bus:device.function>/local_cpulist of the HIP device: the CPUs of the NUMA node its PCIe root hangs on.
+std::string device_local_cpus(int device) {
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return "";
+    }
+    for (char* p = bdf; *p; ++p) *p = static_cast<char>(std::tolower(static_cast<unsigned char>(*p)));
+    std::ifstream f(std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist");
+    std::string line;
+    if (!f || !std::getline(f, line)) return "";
+    while (!line.empty() && (line.back() == '\n' || line.back() == ' ')) line.pop_back();
+    return line;
+}
+
+bool bind_calling_thread_to_device(int device) {
+    const std::string cpus = device_local_cpus(device);
+    if (cpus.empty()) return false;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n = 0;
+    const char* p = cpus.c_str();
+    while (*p) {  // "a-b,c,d-e"
+        char* end = nullptr;
+        const long a = std::strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = std::strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long k = a; k <= b && k < CPU_SETSIZE; ++k) {
+            if (k >= 0) { CPU_SET(static_cast<int>(k), &set); ++n; }
+        }
+        if (*p == ',') ++p;
+    }
+    // only CPUs this thread may use anyway (a container's cpuset): the intersection, and nothing if it is empty
+    cpu_set_t now;
+    CPU_ZERO(&now);
+    if (sched_getaffinity(0, sizeof now, &now) == 0) {
+        cpu_set_t both;
+        CPU_AND(&both, &set, &now);
+        if (CPU_COUNT(&both) == 0) return false;
+        set = both;
+    }
+    return n > 0 && sched_setaffinity(0, sizeof set, &set) == 0;
 }
 
 // Bounded: a queue that does not drain within HC_STEP_TIMEOUT_S (or reports an error) is a lost device -> HC_ERR_DEVICE.
@@ -634,13 +688,17 @@ static const char* const kKernelObjectName = "/hc_kernels_tuning.co";
 static const char* const kKernelObjectName = "/hc_kernels.co";
 #endif
 // The packet processor fetches AQL packets from the queue's ring; by default the HSA runtime puts that ring into HOST memory (a PCIe
-// read in front of every dispatch), with HSA_ALLOCATE_QUEUE_DEV_MEM=1 into device memory: 1.4-1.9 us less from doorbell to kernel start,
-// i.e. per synchronous hc_step and per hc_added_mass_mv (profiles/r06/queue_dev_mem_ab.txt: 8.47 -> 7.06 us at one body, 12.3 -> 10.5 us
-// at 64).  The runtime reads the variable once, when it is initialised, so the library asks for it when it is LOADED -- before main() of
-// a program linked against it, before the first HIP call of an interpreter that imports it first.  A host that initialises HIP earlier
-// sets the variable itself; HC_QUEUE_DEV_MEM=0 leaves the runtime's default alone; a value the host has set is kept.
+// read in front of every dispatch), with HSA_ALLOCATE_QUEUE_DEV_MEM=1 into device memory: 1.0-1.8 us less from doorbell to kernel start,
+// i.e. per synchronous hc_step and per hc_added_mass_mv (profiles/r06/queue_dev_mem_ab.txt, host_path_c.txt: 7.11 -> 6.15 us at one
+// body, 9.97 -> 8.85 us at 64).  OPT-IN (HC_QUEUE_DEV_MEM=1), not the default: the runtime's variable moves the rings of EVERY queue of the
+// process, the HIP runtime's included, and a doorbell can reach the packet processor before a packet stored through the BAR has left
+// the HDP for VRAM.  This library orders its own packets (DirectQueue: HDP write-back in front of every doorbell, hc_direct.cpp); the HIP
+// runtime's dispatch path does not, and round 6's long differential runs lost 2 of ~2 600 cases with the variable set -- a HIP queue
+// aborting with "invalid code object", a memory fault at a garbage address: packets read half new, half old (EXPERIMENTS.md).  The
+// runtime reads the variable once, when it is initialised, so a host that opts in gets it set when the library is LOADED -- before
+// main() of a program linked against it, before the first HIP call of an interpreter that imports it first.
 __attribute__((constructor)) static void request_device_memory_queue_rings() {
-    if (env_int("HC_QUEUE_DEV_MEM", 1) == 0) return;
+    if (env_int("HC_QUEUE_DEV_MEM", 0) == 0) return;
     (void)setenv("HSA_ALLOCATE_QUEUE_DEV_MEM", "1", 0);
 }
 
@@ -773,9 +831,10 @@ void setup_direct(hc_ctx* c) {
     c->direct_why.clear();
     {
         const int where = c->dq->ring_in_device_memory(0);
-        c->direct_how   = where == 1 ? "direct AQL dispatch (packet ring in device memory)"
-                          : where == 0 ? "direct AQL dispatch (packet ring in HOST memory: the HSA runtime was initialised before this library could ask for a ring in "
-                                         "device memory, or HC_QUEUE_DEV_MEM=0 -- about 1.5 us more per synchronous step, see INTEGRATION.md)"
+        c->direct_how   = where == 1 ? (c->dq->hdp_flush_available() ? "direct AQL dispatch (packet ring in device memory, HDP write-back in front of every doorbell)"
+                                                                         : "direct AQL dispatch (packet ring in device memory, read-back in front of every doorbell: no HDP flush register)")
+                          : where == 0 ? "direct AQL dispatch (packet ring in host memory; HC_QUEUE_DEV_MEM=1 moves the process's rings into device memory: "
+                                         "1.0-1.8 us less per synchronous step, at a risk for the HIP runtime's own queues -- INTEGRATION.md)"
                                        : "direct AQL dispatch";
     }
     if (HC_TUNE_INT("HC_DEBUG_PLAN", 0) != 0) std::fprintf(stderr, "[hc] direct AQL dispatch in use for the step path\n");

@@ -75,6 +75,15 @@ int hc_device_count(void) {
     return n;
 }
 
+int hc_device_local_cpus(int device_id, char* out, size_t out_bytes) {
+    if (!out || out_bytes == 0) return HC_ERR_INVALID;
+    const std::string cpus = device_local_cpus(device_id);
+    std::snprintf(out, out_bytes, "%s", cpus.c_str());
+    return cpus.empty() ? HC_ERR_UNSUPPORTED : HC_OK;
+}
+
+int hc_bind_thread_to_device(int device_id) { return bind_calling_thread_to_device(device_id) ? HC_OK : HC_ERR_UNSUPPORTED; }
+
 const char* hc_last_error(const hc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int hc_create_sharded(int num_bodies, int body_begin, int body_end, int device_id, hc_ctx** out) {

@@ -1019,6 +1019,9 @@ void bind_device(const hc_ctx* c) {
     } else if (worker_device != c->device) {
         HC_HIP(hipSetDevice(c->device));
         worker_device = c->device;
+        // a worker serves one context: it moves next to that context's GPU (its doorbell, its BAR, the memory its results arrive in)
+        static const bool pin = env_int("HC_MULTI_PIN", 1) != 0;
+        if (pin) (void)bind_calling_thread_to_device(c->device);
     }
 }
 // status and message per item: items run by the fan-out record their failure in their own slot, the one-thread form records in slot 0

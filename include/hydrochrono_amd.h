@@ -42,6 +42,16 @@ typedef enum hc_status {
  * ---------------------------------------------------------------------------------------------- */
 const char* hc_version(void);
 int hc_device_count(void); /* number of visible HIP devices; does not initialise a context */
+/* Where the host thread that steps should run.  A synchronous step is a round trip between one host thread and one GPU: a doorbell
+ * store into the GPU's MMIO page, stores through its BAR, and a spin on pinned memory the GPU writes.  From a core of the OTHER
+ * socket every one of them crosses the socket interconnect: 64 bodies 11.5-11.8 us per hc_step against 10.0-10.3 us from a core of the
+ * GPU's own NUMA node (profiles/r06/affinity_ahead_probe.txt) -- and an unpinned thread lands on either.
+ * hc_device_local_cpus: the CPUs local to the device's PCIe root as the kernel lists them ("0-63,128-191"; "" when unknown).
+ * hc_bind_thread_to_device: restricts the CALLING thread to those CPUs (sched_setaffinity; threads it creates afterwards inherit the
+ * mask -- a host that wants its worker pool on all sockets creates it first, or binds only its stepping thread).  HC_ERR_UNSUPPORTED
+ * when the CPUs are not known.  The worker threads of hc_step_multi bind themselves to their context's device (HC_MULTI_PIN=0: no). */
+int hc_device_local_cpus(int device_id, char* out, size_t out_bytes);
+int hc_bind_thread_to_device(int device_id);
 int hc_create(int num_bodies, int device_id, hc_ctx** out);
 /* Row-sharded context: owns output rows of bodies [body_begin, body_end) only. */
 int hc_create_sharded(int num_bodies, int body_begin, int body_end, int device_id, hc_ctx** out);

@@ -14,6 +14,8 @@
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static int run(int N, int b0, int b1, int S, double gap_us, int schedule, int slices_report) {
+    // the stepping thread next to its GPU (BIND=0: wherever the scheduler puts it)
+    if (!(std::getenv("BIND") && std::atoi(std::getenv("BIND")) == 0)) (void)hc_bind_thread_to_device(0);
     hc_ctx* c = nullptr;
     const int rc0 = (b1 - b0 == N) ? hc_create(N, 0, &c) : hc_create_sharded(N, b0, b1, 0, &c);
     if (rc0 != HC_OK) { std::printf("create: %s\n", hc_last_error(nullptr)); return 1; }

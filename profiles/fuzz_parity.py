@@ -253,6 +253,8 @@ def one_case(seed):
 t_end = time.time() + budget
 n_ok, worst_all, passes = 0, 0.0, np.zeros(7, dtype=np.int64)
 while time.time() < t_end:
+    if os.environ.get("FUZZ_PRINT_SEEDS"):  # (a case that takes the process down -- a GPU memory fault -- is the last one named)
+        print(f"case {seed}", flush=True)
     ok, desc, worst, npass = one_case(seed)
     if not ok:
         sys.exit(1)

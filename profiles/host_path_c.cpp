@@ -13,6 +13,8 @@
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static int run(int N, int S, double gap_us) {
+    // the stepping thread next to its GPU (BIND=0: wherever the scheduler puts it)
+    if (!(std::getenv("BIND") && std::atoi(std::getenv("BIND")) == 0)) (void)hc_bind_thread_to_device(0);
     hc_ctx* c = nullptr;
     if (hc_create(N, 0, &c) != HC_OK) { std::printf("hc_create: %s\n", hc_last_error(nullptr)); return 1; }
     if (hc_synth_fill(c, 20251031ull, S, 0.01, 0, 0.01) != HC_OK || hc_finalize(c) != HC_OK || hc_set_wave_none(c, N) != HC_OK) {

@@ -33,6 +33,8 @@ int main(int argc, char** argv) {
     const double gap_us = argc > 1 ? std::atof(argv[1]) : 0.0;
     const int schedule  = argc > 2 ? std::atoi(argv[2]) : 0;
     const int N = 64, S = 1024;
+    // the stepping thread next to its GPU (BIND=0: wherever the scheduler puts it)
+    if (!(std::getenv("BIND") && std::atoi(std::getenv("BIND")) == 0)) (void)hc_bind_thread_to_device(0);
     hc_ctx* c = nullptr;
     if (hc_create(N, 0, &c) != HC_OK) { std::printf("hc_create: %s\n", hc_last_error(nullptr)); return 1; }
     if (hc_synth_fill(c, 20251031ull, S, 0.01, 0, 0.01) != HC_OK || hc_finalize(c) != HC_OK || hc_set_wave_none(c, N) != HC_OK ||

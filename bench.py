@@ -1419,7 +1419,10 @@ def main():
                         "step_traffic_bytes": step_bytes, "step_traffic_parts": parts,
                         "step_traffic_bytes_pmc": pmc, "step_traffic_pmc_source": "profiles/r06/pmc_step_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)" if pmc else None,
                         "step_GBps_at_mean": step_bytes / mean_s / 1e9, "step_frac_of_hbm_peak_at_mean": step_bytes / mean_s / 1e9 / HBM_PEAK_GBS,
-                        "step_GBps_at_median": step_bytes / med_s / 1e9, "step_frac_of_hbm_peak_at_median": step_bytes / med_s / 1e9 / HBM_PEAK_GBS,
+                        # the median step holds no pass launch: its own bytes (scatter + own samples + terms) over its own time
+                        "median_step_traffic_bytes": step_bytes - parts["pass_share"],
+                        "median_step_GBps": (step_bytes - parts["pass_share"]) / med_s / 1e9,
+                        "median_step_frac_of_hbm_peak": (step_bytes - parts["pass_share"]) / med_s / 1e9 / HBM_PEAK_GBS,
                         "survey_8d_bytes_per_step": prof_all["conv_kernel_bytes"],
                         "reuse_over_survey_model": prof_all["conv_kernel_bytes"] / step_bytes,
                         "note": "algorithmic bytes of ONE steady-state step: the pass's K-once bytes / steps per pass + what the scatter behind the step streams "

@@ -174,6 +174,7 @@ struct hc_ctx {
     bool step_preload = false;          // ... in use for this context (tuning build, HC_STEP_PRELOAD=1: measured and not taken, EXPERIMENTS.md)
     hc::DirectKernel dk_step_hot[2];    // step_hot_kernel<1>, <2>: the common block step with a compact argument block (hc_kernels.hpp: StepHotArgs)
     bool step_hot = false;              // ... in use for this context
+    int step_halves = 1;                // 2: two workgroups per row tile in step_hot_kernel (systems of kStepHalvesMinColumns columns or more)
     bool slot_state = false;            // ... in use for this context (HC_SLOT_STATE, systems of up to kSlotStateMaxBodies bodies)
     hc::DirectKernel dk_finalize, dk_scatter, dk_reduce, dk_block16, dk_block32, dk_block64, dk_mini16, dk_mini32, dk_narrow, dk_wide, dk_added_mass, dk_step, dk_near;
     hc::StepTail tail;

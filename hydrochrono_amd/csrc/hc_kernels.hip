@@ -1765,7 +1765,7 @@ template __global__ void finalize_pre_kernel<4>(const double*, const double*, in
 //     afterwards), so nothing is waited for until all requests are out and the waits are counted exactly;
 //   * nothing else changes: the same products and sums in the same order as finalize_kernel (bitwise the same forces; the tuning
 //     build keeps the A/B switch HC_STEP_HOT, tests/test_gpu_boundary.py).
-// One workgroup per tile of 16 rows + one that stores the sample; 256 work-items; dynamic LDS NE * D doubles.
+// One workgroup per tile of 16 rows + one that stores the sample; 256 work-items; dynamic LDS NE * (D + 16) doubles.
 // ------------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HC_PIN_S(x) asm volatile("" : "+s"(x))
@@ -1841,9 +1841,9 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
     const double* kf0 = a.kfirst[0];
     const double* kf1 = a.kfirst[NE - 1];
     const double *Yc = a.Yc, *P = a.P, *E = a.E, *lin = a.lin, *cg = a.cg, *cbm = a.cb_m_cg, *vol = a.disp_vol, *regm = a.reg_mag;
-    int ngp = a.ngp, ng0 = a.ng[0], ng1 = a.ng[NE - 1], n_terms = a.n_terms, Dpad = a.Dpad, Dloc = a.Dloc, N = a.N, b0 = a.b0, ntiles = a.ntiles;
+    int ngp = a.ngp, ng0 = a.ng[0], ng1 = a.ng[NE - 1], n_terms = a.n_terms, Dpad = a.Dpad, Dloc = a.Dloc, N = a.N, b0 = a.b0, ntiles = a.ntiles, halves = a.halves;
     HC_PIN_S(kf0); HC_PIN_S(kf1); HC_PIN_S(Yc); HC_PIN_S(P); HC_PIN_S(E); HC_PIN_S(lin); HC_PIN_S(cg); HC_PIN_S(cbm); HC_PIN_S(vol); HC_PIN_S(regm);
-    HC_PIN_S(ngp); HC_PIN_S(ng0); HC_PIN_S(ng1); HC_PIN_S(n_terms); HC_PIN_S(Dpad); HC_PIN_S(Dloc); HC_PIN_S(N); HC_PIN_S(b0); HC_PIN_S(ntiles);
+    HC_PIN_S(ngp); HC_PIN_S(ng0); HC_PIN_S(ng1); HC_PIN_S(n_terms); HC_PIN_S(Dpad); HC_PIN_S(Dloc); HC_PIN_S(N); HC_PIN_S(b0); HC_PIN_S(ntiles); HC_PIN_S(halves);
     HC_MARK(sc, 1);
 
     if ((int)blockIdx.x >= ntiles) {
@@ -1887,18 +1887,27 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
         return;
     }
 
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), sub = tid & 15, rit = (tid >> 4) & 15, kk = lane >> 4;
-    const int tile = (int)blockIdx.x, row = tile * 16 + rit;
-    const bool live = row < Dloc;
-    const int rrow = live ? row : 0, bl = rrow / 6, i = rrow - 6 * bl, b = b0 + bl;
+    // rows are FINISHED by the first 16 lanes of wave 0 (lane r: row r of the tile): they alone request the tables, form the hydrostatic
+    // and wave terms and store the row -- one wave's 15 requests instead of four waves' (a request costs the workgroup's one address
+    // unit 16 cycles whatever its width and however many lanes are live: 39 requests per wave were the 1.1 us in front of the K words)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), rit = tid & 15, kk = lane >> 4;
+    const bool fin = tid < 16;
+    // halves == 2: two workgroups per tile of 16 rows, each finishing 8 of them.  A compute unit moves 40-50 GB/s and the K words of a
+    // tile are 48 KB per own sample: with twice the compute units each requests half of them.  The lanes of the other half's rows ask for
+    // THIS half's words a second time (the same cache lines: no traffic) and compute them a second time; every sum keeps its order.
+    const int wg = (int)blockIdx.x, tile = halves == 2 ? wg >> 1 : wg, half = halves == 2 ? wg & 1 : 0;
+    const int row = tile * 16 + rit;
+    const bool live = row < Dloc && (halves != 2 || (rit >> 3) == half);
+    const int row_h = tile * 16 + 8 * half, rrow = live ? row : (row_h < Dloc ? row_h : 0), bl = rrow / 6, i = rrow - 6 * bl, b = b0 + bl;
+    const int lane_k = halves == 2 ? ((lane & ~8) | (half << 3)) : lane;  // the lane whose K words this lane asks for
     // ---- every load of the step, unconditionally (clamped indices; masked where the values are used), in the order their values are
     //      needed: what the hydrostatic and wave terms take first (they are formed while the K words are still on their way) ----
     constexpr int PRE  = 12;  // C3: all 12 column groups a wave owns of one IRF sample
     constexpr int TPRE = kTermMax / 16;
-    constexpr int kLoadsBehindTerms1 = NE * PRE + TPRE;  // K words and scatter results: requested last, waited for last
-    double p_row, e_raw, V, rmag, pos2, rpy2, cg2, r2;
-    dvec2 pos01, rpy01, cg01, r01, k01, k23, k45;
-    {
+    constexpr int kLoadsBehindTerms1 = NE * PRE;  // the K words: requested last, waited for last
+    double p_row = 0.0, e_raw = 0.0, V = 0.0, rmag = 0.0, pos2 = 0.0, rpy2 = 0.0, cg2 = 0.0, r2 = 0.0;
+    dvec2 pos01{0.0, 0.0}, rpy01{0.0, 0.0}, cg01{0.0, 0.0}, r01{0.0, 0.0}, k01{0.0, 0.0}, k23{0.0, 0.0}, k45{0.0, 0.0};
+    if (fin) {
         const unsigned row_off = (unsigned)rrow * 8u, b3_off = (unsigned)b * 24u, bl3_off = (unsigned)bl * 24u, lin_off = (unsigned)(36 * bl + 6 * i) * 8u,
                        bl_off = (unsigned)bl * 8u;
         const double *st_pos = st + 6 * N, *st_rpy = st + 9 * N;
@@ -1918,10 +1927,22 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
         hot_lds(p_row, P, row_off);
         hot_lds(e_raw, E, row_off);
     }
+    // ... the term slots tid >> 4, + 16, ... of the step only as far as the step has terms (16 on average, 192 slots: one or two requests
+    // instead of twelve; requested in front of the K words, whose number is fixed, so that the first wait below still counts exactly) ...
+    double ypre[TPRE];
+    {
+        const unsigned y_off = ((unsigned)(tid & 15) + (unsigned)(tid >> 4) * (unsigned)Dpad) * 8u;
+        const double* __restrict__ y = Yc + tile * 16;
+#pragma unroll
+        for (int q = 0; q < TPRE; ++q) {
+            ypre[q] = 0.0;
+            if (16 * q < n_terms) hot_lds(ypre[q], y + (size_t)(16 * q) * Dpad, y_off);  // (slots past n_terms inside the group exist; masked where they are used)
+        }
+    }
     dvec2 pre[NE][PRE];
     {
         // K words: the wave's column groups wave, wave + 4, ... of own sample e -- one scalar base per load, the lane's 16 bytes as the offset
-        const unsigned lane_off = (unsigned)lane * 16u;
+        const unsigned lane_off = (unsigned)lane_k * 16u;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const double* __restrict__ kb = (e == 0 ? kf0 : kf1) + ((size_t)tile * ngp) * 128;
@@ -1932,14 +1953,6 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
                 hot_lds2(pre[e][q], kb + (size_t)(gp < ng ? gp : 0) * 128, lane_off);
             }
         }
-    }
-    double ypre[TPRE];
-    {
-        // term slots tid >> 4, + 16, ... of the step (all kTermMax slots of a step exist: the ones past n_terms are read and masked)
-        const unsigned y_off = ((unsigned)(tid & 15) + (unsigned)(tid >> 4) * (unsigned)Dpad) * 8u;
-        const double* __restrict__ y = Yc + tile * 16;
-#pragma unroll
-        for (int q = 0; q < TPRE; ++q) hot_lds(ypre[q], y + (size_t)(16 * q) * Dpad, y_off);
     }
     HC_MARK(sc, 2);
     // ---- the rest of the arguments, while the loads are in flight (read through a pointer the compiler cannot see through, so that
@@ -1971,18 +1984,54 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
     for (int k = 0; k < 4; ++k) hot_pin(ev[k]);
     hot_pin(p_row); hot_pin(e_raw); hot_pin(V); hot_pin(rmag); hot_pin(pos2); hot_pin(rpy2); hot_pin(cg2); hot_pin(r2);
     hot_pin(pos01); hot_pin(rpy01); hot_pin(cg01); hot_pin(r01); hot_pin(k01); hot_pin(k23); hot_pin(k45);
+    // (LDS: per own sample 8 zeros, the D right-hand-side values, 8 zeros -- a lane column in front of the sample's first or behind its last
+    //  reads a zero instead of being masked: U_e = U + 8 + e * (D + 16))
+    const int Dp = D + 16;
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const double ae = e == 0 ? a0 : a1;
+        double* __restrict__ ue = U + 8 + e * Dp;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int col = tid + 256 * k;
-            if (col < D) U[e * D + col] = (ae != 0.0) ? ae * ev[k] : 0.0;
+            if (col < D) ue[col] = (ae != 0.0) ? ae * ev[k] : 0.0;
         }
+        if (tid >= 240) ue[tid < 248 ? tid - 248 : D + tid - 248] = 0.0;  // (a wave whose lanes store no column of a 64-body system)
     }
     HC_MARK(sc, 3);
-    double wav = 0.0, hs;
-    {
+    __syncthreads();
+    HC_MARK(sc, 4);
+    // Every right-hand-side value the preloaded K words will meet, requested from LDS AT ONCE: written as `in range ? u[c] : 0` inside
+    // the product loop these were 24 LDS round trips one after the other, each with its own wait -- 1.3 us of the workgroup's 4 (stage
+    // clock: "contraction done"), more than the K words themselves took.  all_in[e]: every preloaded column group of this wave belongs
+    // to own sample e (a system of 62 bodies or more) -- then the 24 addresses are one register + constants, and the products below a
+    // straight line of 24 fused multiply-adds.
+    bool all_in[NE];
+    double u0v[NE][PRE], u1v[NE][PRE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int ng = e == 0 ? ng0 : ng1, off = e == 0 ? off0 : off1;
+        all_in[e] = wave + 4 * (PRE - 1) < ng;
+        const double* __restrict__ u = U + 8 + e * Dp;  // column c of the sample = lane column 8 * gp + kk (+ 4) - off, groups counted from the sample's first
+        if (all_in[e]) {
+            const double* __restrict__ ul = u + (wave * 8 + kk - off);
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) {
+                u0v[e][q] = ul[32 * q];
+                u1v[e][q] = ul[32 * q + 4];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) {
+                const int ca = (wave + 4 * q) * 8 + kk - off;  // (groups past the sample's last: any valid address, the value is not used)
+                u0v[e][q] = u[min(ca, D + 3)];
+                u1v[e][q] = u[min(ca, D + 3) + 4];
+            }
+        }
+    }
+    // ... and the hydrostatic and wave terms of the row formed in their shadow and in that of the K words
+    double wav = 0.0, hs = 0.0;
+    if (fin) {
         if (wave_mode == 2) wav = has_E ? e_raw : 0.0;
         if (wave_mode == 1) {
             const double ph = i == 0 ? ph0 : (i == 1 ? ph1 : (i == 2 ? ph2 : (i == 3 ? ph3 : (i == 4 ? ph4 : ph5))));
@@ -2014,11 +2063,11 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
         }
         hs += add;
     }
-    hot_pin(hs);  // (formed HERE, in the shadow of the K words, not behind the last barrier)
+    hot_pin(hs);
     hot_pin(wav);
-    __syncthreads();
-    HC_MARK(sc, 4);
+    HC_MARK(sc, 10);  // (hydrostatic / wave terms formed)
     hot_wait<0>();
+    HC_MARK(sc, 11);  // (every K word of this wave is in)
 #pragma unroll
     for (int e = 0; e < NE; ++e)
 #pragma unroll
@@ -2027,25 +2076,31 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int ng = e == 0 ? ng0 : ng1, off = e == 0 ? off0 : off1;
-        const double* __restrict__ u = U + e * D;  // column c of the sample = lane column 8 * gp + kk (+ 4) - off, groups counted from the sample's first
-        int gp = wave;
+        const double* __restrict__ u = U + 8 + e * Dp;
+        int gp = wave + 4 * PRE;
+        if (all_in[e]) {
 #pragma unroll
-        for (int q = 0; q < PRE; ++q, gp += 4) {
-            if (gp < ng) {
-                const int ca = gp * 8 + kk - off, cb = ca + 4;
-                const double u0 = (ca >= 0 && ca < D) ? u[ca] : 0.0, u1 = (cb >= 0 && cb < D) ? u[cb] : 0.0;
-                acc = fma(pre[e][q].x, u0, acc);
-                acc = fma(pre[e][q].y, u1, acc);
+            for (int q = 0; q < PRE; ++q) {
+                acc = fma(pre[e][q].x, u0v[e][q], acc);
+                acc = fma(pre[e][q].y, u1v[e][q], acc);
+            }
+        } else {
+            gp = wave;
+#pragma unroll
+            for (int q = 0; q < PRE; ++q, gp += 4) {
+                if (gp < ng) {
+                    acc = fma(pre[e][q].x, u0v[e][q], acc);
+                    acc = fma(pre[e][q].y, u1v[e][q], acc);
+                }
             }
         }
-        const double* __restrict__ kb = (e == 0 ? kf0 : kf1) + ((size_t)tile * ngp) * 128 + lane * 2;
+        const double* __restrict__ kb = (e == 0 ? kf0 : kf1) + ((size_t)tile * ngp) * 128 + lane_k * 2;
 #pragma unroll 4
         for (; gp < ng; gp += 4) {  // (more than 384 columns)
             const dvec2 kv = *reinterpret_cast<const dvec2*>(kb + (size_t)gp * 128);
-            const int ca = gp * 8 + kk - off, cb = ca + 4;
-            const double u0 = (ca >= 0 && ca < D) ? u[ca] : 0.0, u1 = (cb >= 0 && cb < D) ? u[cb] : 0.0;
-            acc = fma(kv.x, u0, acc);
-            acc = fma(kv.y, u1, acc);
+            const int ca = gp * 8 + kk - off;
+            acc = fma(kv.x, u[ca], acc);
+            acc = fma(kv.y, u[ca + 4], acc);
         }
     }
     acc += __shfl_xor(acc, 16, kWave);
@@ -2065,7 +2120,15 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
     }
     __syncthreads();
     HC_MARK(sc, 6);
-    if (!(live && sub == 0)) return;
+#ifdef HC_TUNING
+    if (stamps && tid == 0 && !live) {  // (halves == 2: the second workgroup of a tile finishes rows 8 .. 15; its clock row all the same)
+        HC_MARK(sc, 7);
+        HC_MARK(sc, 8);
+        HC_MARK(sc, 9);
+        sc.store(stamps);
+    }
+#endif
+    if (!(live && fin)) return;
 
     double rad = p_row + 0.0;
     if (n_terms > 0) {

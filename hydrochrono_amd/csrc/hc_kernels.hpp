@@ -259,7 +259,9 @@ struct StepHotArgs {
     const double *lin, *cg, *cb_m_cg, *disp_vol, *reg_mag;
     int ngp;                  // column groups per row tile of the panel
     int ng[2];                // column groups of own sample e
-    int n_terms, Dpad, Dloc, N, b0, ntiles, pad0_;
+    int n_terms, Dpad, Dloc, N, b0;
+    int ntiles;               // workgroups that finish rows: row tiles x halves (the workgroup behind them stores the sample)
+    int halves;               // 1: a workgroup finishes the 16 rows of a tile; 2: 8 of them (twice the compute units share the K words)
     // ---- second part: requested while the loads are in flight ----
     int off[2];               // first column of own sample e inside its first group (s * D - 8 * (s * D / 8))
     int D, wave_mode, has_E, pad1_;

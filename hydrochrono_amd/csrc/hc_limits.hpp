@@ -24,8 +24,10 @@ constexpr int kTargets        = 3;   // later block steps one (sample, IRF sampl
 // Stage clock of the step kernel (tuning build only: FinalizeArgs::stamps, hc_tuning_step_stamps): one row of kStampStages 100 MHz
 // s_memrealtime values per workgroup of a launch, for the last kStampSteps steps.
 constexpr int kStampStages    = 12;
-constexpr int kStampWGs       = 32;
+constexpr int kStampWGs       = 64;
 constexpr int kStampSteps     = 64;
+
+constexpr int kStepHalvesMinColumns = 96;  // step_hot_kernel: from this many columns on, two workgroups share a row tile (StepHotArgs::halves)
 
 constexpr int kSubBlock       = 8;   // steps per sub-block of the two-level form (wide systems)
 constexpr int kMiniChunks     = 256; // radiation chunks a NARROW short pass may have (one step offset per chunk travels in the argument block)

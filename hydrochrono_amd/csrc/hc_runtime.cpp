@@ -728,6 +728,7 @@ void setup_direct(hc_ctx* c) {
     for (auto& k : c->dk_step_hot)
         if (k.kernarg != sizeof(hc::StepHotArgs) || k.priv != 0) k = hc::DirectKernel{};
     c->step_hot = c->slot_state && c->dk_step_hot[0].ok() && c->dk_step_hot[1].ok() && HC_TUNE_INT("HC_STEP_HOT", 1) != 0;
+    c->step_halves = HC_TUNE_INT("HC_STEP_HALVES", 1) == 2 ? 2 : 1;
     c->dk_reduce   = q->find("reduce_block_kernelE");
     c->dk_added_mass = q->find("added_mass_mv_tagged_kernelE");  // optional: hc_added_mass_mv falls back to a HIP launch
     {   // the plain per-step convolution of this context's tiling; optional: without it plain steps go through HIP launches

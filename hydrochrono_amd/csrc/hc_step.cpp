@@ -649,7 +649,9 @@ hc::StepHotArgs hot_step_args(const hc_ctx* c, const hc::FinalizeArgs& z) {
     h.Yc = z.Yc; h.P = z.P; h.E = z.E ? z.E : z.P;
     h.lin = z.lin; h.cg = z.cg; h.cb_m_cg = z.cb_m_cg; h.disp_vol = z.disp_vol;
     h.reg_mag = z.reg_mag ? z.reg_mag : z.P;
-    h.ngp = z.nearK.ngp; h.n_terms = z.n_terms; h.Dpad = z.Dpad; h.Dloc = z.Dloc; h.N = z.N; h.b0 = z.b0; h.ntiles = c->ntiles;
+    h.ngp = z.nearK.ngp; h.n_terms = z.n_terms; h.Dpad = z.Dpad; h.Dloc = z.Dloc; h.N = z.N; h.b0 = z.b0;
+    h.halves = c->step_halves == 2 && c->D >= hc::kStepHalvesMinColumns ? 2 : 1;
+    h.ntiles = c->ntiles * h.halves;
     h.D = c->D; h.wave_mode = z.wave_mode; h.has_E = z.E ? 1 : 0;
     h.rho = z.rho; h.gx = z.gx; h.gy = z.gy; h.gz = z.gz; h.t = z.t; h.reg_amplitude = z.reg_amplitude; h.reg_omega = z.reg_omega;
     for (int i = 0; i < 6; ++i) h.reg_phase[i] = z.reg_phase[i];
@@ -667,7 +669,9 @@ void dispatch_step_kernel(StepJob& j, hc::FinalizeArgs& z) {
     hc_ctx* c = j.c;
     if (j.direct && !j.d_state && j.host_state && c->slot_state) {
         SlotStateFill fill{c, j.host_state};
-        const hc::FinalizeLaunch l = hc::finalize_launch_config(z);
+        hc::FinalizeLaunch l = hc::finalize_launch_config(z);
+        const bool hot = hot_step_eligible(j, z);
+        if (hot && c->step_halves == 2 && c->D >= hc::kStepHalvesMinColumns) l.grid = 2 * c->ntiles + 1;
 #ifdef HC_TUNING
         if (c->stamps_on && l.grid <= hc::kStampWGs) {
             if (c->d_stamps.n == 0) {
@@ -677,11 +681,11 @@ void dispatch_step_kernel(StepJob& j, hc::FinalizeArgs& z) {
             z.stamps = c->d_stamps.p + (j.seq % hc::kStampSteps) * hc::kStampWGs * hc::kStampStages;
         }
 #endif
-        if (hot_step_eligible(j, z)) {
+        if (hot) {
             const hc::StepHotArgs h = hot_step_args(c, z);
-            const size_t lds = static_cast<size_t>(z.n_near) * c->D * sizeof(double);
+            const size_t lds = static_cast<size_t>(z.n_near) * (c->D + 16) * sizeof(double);  // (own samples' right-hand sides between zero pads)
             static const bool no_acquire = HC_TUNE_INT("HC_STEP_NO_ACQUIRE", 0) != 0;  // (tuning experiment: timing only, EXPERIMENTS.md round 6)
-            c->dq->dispatch(c->dk_step_hot[z.n_near - 1], static_cast<uint32_t>(c->ntiles + 1), 256, static_cast<uint32_t>(lds), &h, sizeof h, direct_tag(c, hc::kEvStep), 0.0,
+            c->dq->dispatch(c->dk_step_hot[z.n_near - 1], static_cast<uint32_t>(h.ntiles + 1), 256, static_cast<uint32_t>(lds), &h, sizeof h, direct_tag(c, hc::kEvStep), 0.0,
                             0, fill_slot_state, &fill, no_acquire);
             c->prof.hot_steps += 1;
         } else if (c->step_preload) {

@@ -61,13 +61,13 @@ int main(int argc, char** argv) {
         if (hc_step(c, t, pos.data(), rpy.data(), lin.data(), ang.data(), out.data()) != HC_OK) { std::printf("hc_step: %s\n", hc_last_error(c)); return 1; }
     }
     hc_tuning_enable_step_stamps(c, 1);
-    constexpr int NS = 12, NW = 32;
+    constexpr int NS = 12, NW = 64;
     static const char* stage_name[NS] = {"entry", "arguments in registers", "every load requested", "right-hand side in LDS (state in)", "first barrier passed",
                                          "contraction done (K in)", "second barrier passed", "totals formed", "stores issued", "stores acknowledged", "", ""};
     std::vector<double> call_us, h_begin_to_bell, h_bell_to_seen, bell_to_first_entry, entry_skew, last_ack_to_seen, kernel_span, push_entry, push_ack;
-    std::vector<double> crit_delta[NS], mean_delta[NS], crit_abs[NS];
+    std::vector<double> crit_delta[NS], mean_delta[NS], crit_abs[NS], extra_a, extra_b;
     std::vector<double> call_by_pos[32];
-    int taken = 0, skipped = 0;
+    int taken = 0, skipped = 0, last_tiles = 0;
     for (int b = 0; b < blocks; ++b) {
         unsigned long long seq0 = 0;
         std::vector<double> calls(32);
@@ -94,6 +94,7 @@ int main(int argc, char** argv) {
             h_begin_to_bell.push_back(h3[1] - h3[0]);
             h_bell_to_seen.push_back(h3[2] - h3[1]);
             const int tiles = nwg - 1;  // the last workgroup stores the sample
+            last_tiles = tiles;
             double first_entry = 1e30, last_entry = -1e30, last_ack = -1e30;
             int crit = 0;
             for (int w = 0; w < tiles; ++w) {
@@ -114,6 +115,7 @@ int main(int argc, char** argv) {
                 mean_delta[s].push_back(m / tiles);
             }
             for (int s = 0; s <= 9; ++s) crit_abs[s].push_back(wg[crit * NS + s] - h3[1]);
+            if (wg[crit * NS + 10] > 0.0 && wg[crit * NS + 11] > 0.0) { extra_a.push_back(wg[crit * NS + 10] - h3[1]); extra_b.push_back(wg[crit * NS + 11] - h3[1]); }
         }
     }
     hc_profile_stats p{};
@@ -132,14 +134,16 @@ int main(int argc, char** argv) {
                 pct(h_bell_to_seen, 0.9));
     std::printf("GPU:    doorbell -> entry of the first tile workgroup               %6.2f us   (p10 %.2f  p90 %.2f)\n", med(bell_to_first_entry), pct(bell_to_first_entry, 0.1),
                 pct(bell_to_first_entry, 0.9));
-    std::printf("GPU:    first -> last tile workgroup's entry (24 workgroups)        %6.2f us\n", med(entry_skew));
+    std::printf("GPU:    first -> last tile workgroup's entry (%d workgroups)        %6.2f us\n", last_tiles, med(entry_skew));
     std::printf("GPU:    first entry -> last acknowledged store (the kernel's span)  %6.2f us\n", med(kernel_span));
     std::printf("        last acknowledged store -> totals seen by the host          %6.2f us\n", med(last_ack_to_seen));
     std::printf("        (the workgroup that stores the sample: entry %+.2f us, stores acknowledged %+.2f us after the doorbell)\n", med(push_entry), med(push_ack));
-    std::printf("stage                                   | critical workgroup: +us (median), at us after the doorbell | mean over the 24 tile workgroups\n");
+    std::printf("stage                                   | critical workgroup: +us (median), at us after the doorbell | mean over the tile workgroups\n");
     std::printf("  %-38s|          %6s   %6.2f |\n", stage_name[0], "", med(crit_abs[0]));
     for (int s = 1; s <= 9; ++s)
         std::printf("  %-38s|          %+6.2f   %6.2f | %+6.2f\n", stage_name[s], med(crit_delta[s]), med(crit_abs[s]), med(mean_delta[s]));
+    if (!extra_a.empty() && med(extra_a) > 0.0)
+        std::printf("  (step_hot_kernel, critical workgroup, wave 0: hydrostatic / wave terms formed at %.2f us, its last K word in at %.2f us after the doorbell)\n", med(extra_a), med(extra_b));
     std::printf("(dispatches: %lld direct, %lld HIP; steps with the state behind the arguments: %lld; blocks ahead / at start: %lld / %lld)\n", p.direct_dispatches, p.hip_launches,
                 p.slot_state_steps, p.schedule_blocks_ahead, p.schedule_blocks_at_start);
     hc_destroy(c);

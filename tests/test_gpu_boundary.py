@@ -318,6 +318,8 @@ def test_step_kernel_of_the_common_block_step_is_bitwise_the_general_one(monkeyp
     from hydrochrono_amd.synthetic import many_body_case, rest_positions
     monkeypatch.setenv("HC_DIRECT", "1")
     case = many_body_case(N, S=128 if N > 100 else 96, dt_rirf=0.01, n_exc=21, dt_exc=0.02, seed=900 + N)
+    if N in (3, 64):
+        case["g_sys"] = [0.3, -0.2, -9.7]  # (non-vertical gravity: every buoyancy-moment product is a rounded one)
     motion = PrescribedMotion(N, rest_positions(case), seed=3)
     times, t = [], 0.0
     for n in range(240):
@@ -326,8 +328,9 @@ def test_step_kernel_of_the_common_block_step_is_bitwise_the_general_one(monkeyp
     times[215] = times[211]  # a step back in time
     times = times[:216] + [times[215] + dt * (k + 1) for k in range(24)]
     runs, hot = [], []
-    for flag in ("1", "0"):
+    for flag, halves in (("1", "1"), ("0", "1"), ("1", "2")):  # (HC_STEP_HALVES=2: two workgroups per row tile from 96 columns on)
         monkeypatch.setenv("HC_STEP_HOT", flag)
+        monkeypatch.setenv("HC_STEP_HALVES", halves)
         h = hydro.HydroForces.from_case(case)
         if waves == "regular":
             h.add_waves_regular(0.4, 0.9)
@@ -343,10 +346,11 @@ def test_step_kernel_of_the_common_block_step_is_bitwise_the_general_one(monkeyp
         hot.append((p["hot_steps"], p["slot_state_steps"]))
         h.close()
     assert np.array_equal(runs[0], runs[1])
+    assert np.array_equal(runs[2], runs[1])
     # the block steps went to the kernel under test (not the first S steps: while the history is shorter than the IRF window one IRF
     # sample per step is left to the step with its whole bracket, which the general kernel takes; not the plain steps in between)
     assert hot[1][0] == 0 and hot[0][0] >= 40, hot
-    assert hot[0][0] <= hot[0][1]
+    assert hot[0][0] <= hot[0][1] and hot[2] == hot[0], hot
 
 
 def test_a_failed_step_of_a_wide_context_leaves_the_next_steps_on_the_direct_path(monkeypatch):

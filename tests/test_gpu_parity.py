@@ -760,6 +760,25 @@ def c3(HF, c3_case):
     gpu.close()
 
 
+_C3_ORACLE_STEPS = {}
+
+
+def _c3_oracle_steps(case, motion, dt, kw, t_hist, v_hist, nsteps=72):
+    """The oracle's 72 steps of the C3 test per step size, computed once: the twelve parametrisations below differ in how the GPU
+    evaluates (depth, dispatch mode), not in what the reference computes (7 s of oracle time each, most of this file's run time)."""
+    if dt not in _C3_ORACLE_STEPS:
+        orc = load_into_oracle(case)
+        orc.add_waves_irregular(**kw)
+        orc.prefill_history(t_hist, v_hist)
+        out = []
+        for n in range(nsteps):
+            t = 20.0 + n * dt
+            total = np.array(orc.step(t, *motion.state(t)), copy=True)
+            out.append((total, tuple(np.array(c, copy=True) for c in orc.components())))
+        _C3_ORACLE_STEPS[dt] = out
+    return _C3_ORACLE_STEPS[dt]
+
+
 @pytest.mark.parametrize("lookahead", [32, 16, 0])
 @pytest.mark.parametrize("dt", [0.01, 0.007])  # SURVEY 8d: the common dt = dt_rirf and a step that makes every sample interpolate
 def test_c3_full_size_against_oracle(c3_mode, dt, lookahead):
@@ -767,27 +786,25 @@ def test_c3_full_size_against_oracle(c3_mode, dt, lookahead):
     depth-32 blocks (pass -> 32 block steps -> the NEXT pass -> block steps) and the start of a third, totals and components
     against the oracle at every step."""
     case, gpu, motion, direct = c3_mode
-    orc = load_into_oracle(case)
     kw = dict(simulation_dt=dt, simulation_duration=60.0, wave_height=2.0, wave_period=8.0, frequency_min=0.02,
               frequency_max=0.5, nfrequencies=512, peak_enhancement_factor=3.3, seed=1)
     gpu.reset_history()
     gpu.set_lookahead(lookahead)
     gpu.add_waves_irregular(**kw)
-    orc.add_waves_irregular(**kw)
     t_hist = 20.0 - dt * np.arange(1, int(np.ceil(10.24 / dt)) + 6)  # newest first, covers the whole 10.23 s window
     v_hist = np.stack([motion.velocity6(t) for t in t_hist])
     gpu.set_pass_schedule(0)  # (the launch counts asserted below are those of the pass at block start)
     gpu.set_history(t_hist, v_hist)
-    orc.prefill_history(t_hist, v_hist)
     gpu.enable_profiling(1)
     gpu.reset_profile()
     nsteps = 72 if lookahead else 6
+    expected = _c3_oracle_steps(case, motion, dt, kw, t_hist, v_hist)
     for n in range(nsteps):
         t = 20.0 + n * dt
-        st = motion.state(t)
-        fg, fo = gpu.step(t, *st), orc.step(t, *st)
+        fg = gpu.step(t, *motion.state(t))
+        fo, comps = expected[n]
         assert_close(fg, fo, TIGHT_TOL, f"C3 total force, step {n}")
-        for g, o in zip(gpu.components(), orc.components()):
+        for g, o in zip(gpu.components(), comps):
             assert_close(g, o, TIGHT_TOL, f"C3 component, step {n}")
     p = assert_mode_was_used(gpu, (lookahead, direct), nsteps)
     if lookahead:

@@ -1819,6 +1819,85 @@ __device__ __forceinline__ void hot_pin(T& x) {
     asm volatile("" : "+v"(x));
 #endif
 }
+// Requests that are not always made must not become branches the compiler can see: a value that is "either 0 or what the load will
+// bring" is a register copy waiting to be placed in front of the wait (it happened: the release build of one revision copied a scatter
+// result before it had arrived -- the sphere-decay golden caught it, the tuning build of the same source was fine).  So the condition
+// lives INSIDE the statement: for the compiler the register is written either way, and what it holds when the request was skipped is
+// masked where it is used.
+// hot_lds_if_at_least<LIMIT>: the request goes out if n >= LIMIT (uniform).
+template <int LIMIT>
+__device__ __forceinline__ void hot_lds_if_at_least(double& d, const double* sbase, unsigned voff, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_cmp_lt_i32 %3, %4\n\ts_cbranch_scc1 .Lhot_skip_%=\n\tglobal_load_dwordx2 %0, %1, %2\n.Lhot_skip_%=:"
+                 : "=v"(d)
+                 : "v"(voff), "s"(sbase), "s"(n), "n"(LIMIT)
+                 : "memory", "scc");
+#else
+    if (n >= LIMIT) d = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sbase) + voff);
+#endif
+}
+// hot_tables_a / _b: what the finishing lanes (mask) need besides the sums -- state and tables of the row's body, the row's look-ahead
+// and excitation values -- requested by those lanes only, and by no lane of a wave that has none: the execution mask is narrowed,
+// the requests made and the mask restored INSIDE one statement each (nothing the compiler schedules can land under the narrow mask).
+__device__ __forceinline__ void hot_tables_a(dvec2& pos01, double& pos2, dvec2& rpy01, double& rpy2, dvec2& cg01, double& cg2, dvec2& r01, double& r2,
+                                             const double* st_pos, const double* st_rpy, const double* cg, const double* cbm, unsigned b3_off, unsigned bl3_off,
+                                             unsigned long long mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long sv;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "s_cbranch_execz .Lhot_ta_%=\n\t"
+                 "global_load_dwordx4 %[o0], %[b3], %[ppos]\n\t"
+                 "global_load_dwordx2 %[o1], %[b3], %[ppos] offset:16\n\t"
+                 "global_load_dwordx4 %[o2], %[b3], %[prpy]\n\t"
+                 "global_load_dwordx2 %[o3], %[b3], %[prpy] offset:16\n\t"
+                 "global_load_dwordx4 %[o4], %[bl3], %[pcg]\n\t"
+                 "global_load_dwordx2 %[o5], %[bl3], %[pcg] offset:16\n\t"
+                 "global_load_dwordx4 %[o6], %[bl3], %[pcb]\n\t"
+                 "global_load_dwordx2 %[o7], %[bl3], %[pcb] offset:16\n"
+                 ".Lhot_ta_%=:\n\t"
+                 "s_or_b64 exec, exec, %[sv]"
+                 : [sv] "=&s"(sv), [o0] "=&v"(pos01), [o1] "=&v"(pos2), [o2] "=&v"(rpy01), [o3] "=&v"(rpy2), [o4] "=&v"(cg01), [o5] "=&v"(cg2), [o6] "=&v"(r01),
+                   [o7] "=&v"(r2)
+                 : [m] "s"(mask), [b3] "v"(b3_off), [bl3] "v"(bl3_off), [ppos] "s"(st_pos), [prpy] "s"(st_rpy), [pcg] "s"(cg), [pcb] "s"(cbm)
+                 : "memory", "scc");
+#else
+    (void)mask;
+    const char *a = reinterpret_cast<const char*>(st_pos) + b3_off, *b = reinterpret_cast<const char*>(st_rpy) + b3_off;
+    const char *c = reinterpret_cast<const char*>(cg) + bl3_off, *d = reinterpret_cast<const char*>(cbm) + bl3_off;
+    auto at = [](const char* q, int k) { return reinterpret_cast<const double*>(q)[k]; };
+    pos01 = dvec2{at(a, 0), at(a, 1)}; pos2 = at(a, 2); rpy01 = dvec2{at(b, 0), at(b, 1)}; rpy2 = at(b, 2);
+    cg01 = dvec2{at(c, 0), at(c, 1)}; cg2 = at(c, 2); r01 = dvec2{at(d, 0), at(d, 1)}; r2 = at(d, 2);
+#endif
+}
+__device__ __forceinline__ void hot_tables_b(dvec2& k01, dvec2& k23, dvec2& k45, double& V, double& rmag, double& p_row, double& e_raw, const double* lin,
+                                             const double* vol, const double* regm, const double* P, const double* E, unsigned lin_off, unsigned bl_off,
+                                             unsigned row_off, unsigned long long mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long sv;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "s_cbranch_execz .Lhot_tb_%=\n\t"
+                 "global_load_dwordx4 %[o0], %[lo], %[plin]\n\t"
+                 "global_load_dwordx4 %[o1], %[lo], %[plin] offset:16\n\t"
+                 "global_load_dwordx4 %[o2], %[lo], %[plin] offset:32\n\t"
+                 "global_load_dwordx2 %[o3], %[bo], %[pvol]\n\t"
+                 "global_load_dwordx2 %[o4], %[ro], %[prm]\n\t"
+                 "global_load_dwordx2 %[o5], %[ro], %[pp]\n\t"
+                 "global_load_dwordx2 %[o6], %[ro], %[pe]\n"
+                 ".Lhot_tb_%=:\n\t"
+                 "s_or_b64 exec, exec, %[sv]"
+                 : [sv] "=&s"(sv), [o0] "=&v"(k01), [o1] "=&v"(k23), [o2] "=&v"(k45), [o3] "=&v"(V), [o4] "=&v"(rmag), [o5] "=&v"(p_row), [o6] "=&v"(e_raw)
+                 : [m] "s"(mask), [lo] "v"(lin_off), [bo] "v"(bl_off), [ro] "v"(row_off), [plin] "s"(lin), [pvol] "s"(vol), [prm] "s"(regm), [pp] "s"(P), [pe] "s"(E)
+                 : "memory", "scc");
+#else
+    (void)mask;
+    const double* l = reinterpret_cast<const double*>(reinterpret_cast<const char*>(lin) + lin_off);
+    k01 = dvec2{l[0], l[1]}; k23 = dvec2{l[2], l[3]}; k45 = dvec2{l[4], l[5]};
+    V     = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(vol) + bl_off);
+    rmag  = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(regm) + row_off);
+    p_row = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(P) + row_off);
+    e_raw = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(E) + row_off);
+#endif
+}
 
 template <int NE>
 __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
@@ -1905,27 +1984,14 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
     constexpr int PRE  = 12;  // C3: all 12 column groups a wave owns of one IRF sample
     constexpr int TPRE = kTermMax / 16;
     constexpr int kLoadsBehindTerms1 = NE * PRE;  // the K words: requested last, waited for last
-    double p_row = 0.0, e_raw = 0.0, V = 0.0, rmag = 0.0, pos2 = 0.0, rpy2 = 0.0, cg2 = 0.0, r2 = 0.0;
-    dvec2 pos01{0.0, 0.0}, rpy01{0.0, 0.0}, cg01{0.0, 0.0}, r01{0.0, 0.0}, k01{0.0, 0.0}, k23{0.0, 0.0}, k45{0.0, 0.0};
-    if (fin) {
+    double p_row, e_raw, V, rmag, pos2, rpy2, cg2, r2;
+    dvec2 pos01, rpy01, cg01, r01, k01, k23, k45;
+    {
         const unsigned row_off = (unsigned)rrow * 8u, b3_off = (unsigned)b * 24u, bl3_off = (unsigned)bl * 24u, lin_off = (unsigned)(36 * bl + 6 * i) * 8u,
                        bl_off = (unsigned)bl * 8u;
-        const double *st_pos = st + 6 * N, *st_rpy = st + 9 * N;
-        hot_lds2(pos01, st_pos, b3_off);
-        hot_lds<16>(pos2, st_pos, b3_off);
-        hot_lds2(rpy01, st_rpy, b3_off);
-        hot_lds<16>(rpy2, st_rpy, b3_off);
-        hot_lds2(cg01, cg, bl3_off);
-        hot_lds<16>(cg2, cg, bl3_off);
-        hot_lds2(r01, cbm, bl3_off);
-        hot_lds<16>(r2, cbm, bl3_off);
-        hot_lds2(k01, lin, lin_off);
-        hot_lds2<16>(k23, lin, lin_off);
-        hot_lds2<32>(k45, lin, lin_off);
-        hot_lds(V, vol, bl_off);
-        hot_lds(rmag, regm, row_off);
-        hot_lds(p_row, P, row_off);
-        hot_lds(e_raw, E, row_off);
+        const unsigned long long finishing = wave == 0 ? 0xFFFFull : 0ull;  // (in every other lane these registers keep what they held: never used there)
+        hot_tables_a(pos01, pos2, rpy01, rpy2, cg01, cg2, r01, r2, st + 6 * N, st + 9 * N, cg, cbm, b3_off, bl3_off, finishing);
+        hot_tables_b(k01, k23, k45, V, rmag, p_row, e_raw, lin, vol, regm, P, E, lin_off, bl_off, row_off, finishing);
     }
     // ... the term slots tid >> 4, + 16, ... of the step only as far as the step has terms (16 on average, 192 slots: one or two requests
     // instead of twelve; requested in front of the K words, whose number is fixed, so that the first wait below still counts exactly) ...
@@ -1933,11 +1999,19 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
     {
         const unsigned y_off = ((unsigned)(tid & 15) + (unsigned)(tid >> 4) * (unsigned)Dpad) * 8u;
         const double* __restrict__ y = Yc + tile * 16;
-#pragma unroll
-        for (int q = 0; q < TPRE; ++q) {
-            ypre[q] = 0.0;
-            if (16 * q < n_terms) hot_lds(ypre[q], y + (size_t)(16 * q) * Dpad, y_off);  // (slots past n_terms inside the group exist; masked where they are used)
-        }
+        hot_lds_if_at_least<1>(ypre[0], y, y_off, n_terms);  // (slots past n_terms inside a group of 16 exist; all are masked where they are used)
+        hot_lds_if_at_least<17>(ypre[1], y + (size_t)16 * Dpad, y_off, n_terms);
+        hot_lds_if_at_least<33>(ypre[2], y + (size_t)32 * Dpad, y_off, n_terms);
+        hot_lds_if_at_least<49>(ypre[3], y + (size_t)48 * Dpad, y_off, n_terms);
+        hot_lds_if_at_least<65>(ypre[4], y + (size_t)64 * Dpad, y_off, n_terms);
+        hot_lds_if_at_least<81>(ypre[5], y + (size_t)80 * Dpad, y_off, n_terms);
+        hot_lds_if_at_least<97>(ypre[6], y + (size_t)96 * Dpad, y_off, n_terms);
+        hot_lds_if_at_least<113>(ypre[7], y + (size_t)112 * Dpad, y_off, n_terms);
+        hot_lds_if_at_least<129>(ypre[8], y + (size_t)128 * Dpad, y_off, n_terms);
+        hot_lds_if_at_least<145>(ypre[9], y + (size_t)144 * Dpad, y_off, n_terms);
+        hot_lds_if_at_least<161>(ypre[10], y + (size_t)160 * Dpad, y_off, n_terms);
+        hot_lds_if_at_least<177>(ypre[11], y + (size_t)176 * Dpad, y_off, n_terms);
+        static_assert(TPRE == 12, "one request per group of 16 term slots");
     }
     dvec2 pre[NE][PRE];
     {
@@ -2085,13 +2159,11 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
                 acc = fma(pre[e][q].y, u1v[e][q], acc);
             }
         } else {
-            gp = wave;
+            const int nq = max(0, (ng - wave + 3) >> 2);  // the wave's groups inside the sample: a prefix (fewer than PRE here)
 #pragma unroll
-            for (int q = 0; q < PRE; ++q, gp += 4) {
-                if (gp < ng) {
-                    acc = fma(pre[e][q].x, u0v[e][q], acc);
-                    acc = fma(pre[e][q].y, u1v[e][q], acc);
-                }
+            for (int q = 0; q < PRE; ++q) {
+                const double t = fma(pre[e][q].y, u1v[e][q], fma(pre[e][q].x, u0v[e][q], acc));
+                acc            = q < nq ? t : acc;
             }
         }
         const double* __restrict__ kb = (e == 0 ? kf0 : kf1) + ((size_t)tile * ngp) * 128 + lane_k * 2;
@@ -2237,6 +2309,20 @@ __device__ __forceinline__ void near_slice(const NearArgs& a, const int rt, cons
         }
     }
     __syncthreads();
+    // the right-hand-side values the preloaded K words meet, requested from LDS at once (read inside the product loop they were one LDS
+    // round trip per column group, each with its own wait: step_hot_kernel has the measurement); nq: the wave's preloaded groups that
+    // lie inside the slice -- a prefix; the products below are a straight line, the ones past it computed and dropped
+    const int nq = min(PRE, max(0, (pg1 - pg0 - wave + 3) >> 2));
+    double u0v[PRE], u1v[PRE];
+    {
+        const double* __restrict__ u = U - pg0 * 8;
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+            const int gpc = max(min(pg0 + wave + 4 * q, pg1 - 1), pg0);  // (past the slice: any valid address, the value is not used)
+            u0v[q] = u[gpc * 8 + kk];
+            u1v[q] = u[gpc * 8 + 4 + kk];
+        }
+    }
     double acc = 0.0;
     for (int e = 0; e < a.n_near; ++e) {
         const int f0 = a.near[e].s * D, f1 = f0 + D;
@@ -2245,12 +2331,11 @@ __device__ __forceinline__ void near_slice(const NearArgs& a, const int rt, cons
         int gp = g0 + wave;
         if (e == 0) {
 #pragma unroll
-            for (int q = 0; q < PRE; ++q, gp += 4) {
-                if (gp < g1) {
-                    acc = fma(pre[q].x, u[gp * 8 + kk], acc);
-                    acc = fma(pre[q].y, u[gp * 8 + 4 + kk], acc);
-                }
+            for (int q = 0; q < PRE; ++q) {
+                const double t = fma(pre[q].y, u1v[q], fma(pre[q].x, u0v[q], acc));
+                acc            = q < nq ? t : acc;
             }
+            gp += 4 * PRE;
         }
 #pragma unroll 4
         for (; gp < g1; gp += 4) {

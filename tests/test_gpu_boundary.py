@@ -305,20 +305,24 @@ def test_state_behind_the_step_kernels_arguments_is_bitwise_the_classic_path(mon
         assert all(c == 0 for c in counts[0])
 
 
-@pytest.mark.parametrize("N, waves, dt", [(1, "regular", 0.01), (3, "irregular", 0.01), (6, "none", 0.007), (64, "irregular", 0.01), (64, "regular", 0.007), (170, "none", 0.01)],
-                         ids=["1-body-regular", "3-bodies-irregular", "6-bodies-two-own-samples", "64-bodies-irregular", "64-bodies-regular-two-own-samples", "170-bodies"])
+HOT_SHAPES = [(1, "regular", 0.01), (1, "none", 0.007), (2, "irregular", 0.007), (3, "irregular", 0.01), (6, "none", 0.007), (10, "regular", 0.01), (40, "none", 0.007),
+              (62, "irregular", 0.01), (63, "none", 0.007), (64, "irregular", 0.01), (64, "regular", 0.007), (65, "none", 0.01), (100, "regular", 0.007), (170, "none", 0.01)]
+
+
+@pytest.mark.parametrize("N, waves, dt", HOT_SHAPES, ids=[f"{n}-bodies-{w}-dt{d}" for n, w, d in HOT_SHAPES])
 def test_step_kernel_of_the_common_block_step_is_bitwise_the_general_one(monkeypatch, N, waves, dt, tuning_build):
     """step_hot_kernel (hc_kernels.hip; round 6) takes the block steps of the common shape -- the step's own IRF samples against its
     own velocity only, look-ahead row and scatter results there, state behind the arguments -- with a compact argument block and every
     load requested up front.  Same products and sums in the same order: bitwise the forces (and the three components) of
     finalize_kernel<4, true> (HC_STEP_HOT=0), over blocks with one own sample (dt = IRF spacing) and two (dt below it), column counts
-    that are and are not multiples of 8, every wave model that is eligible, plain steps in between and a step back in time."""
+    that are and are not multiples of 8, systems around the 62 bodies from which every preloaded column group of a wave belongs to the
+    sample (the straight-line product chain), more than 384 columns, every wave model that is eligible, plain steps in between and a step back in time."""
     import hydrochrono_amd.hydro as hydro
     from hydrochrono_amd.mock_chrono import PrescribedMotion
     from hydrochrono_amd.synthetic import many_body_case, rest_positions
     monkeypatch.setenv("HC_DIRECT", "1")
     case = many_body_case(N, S=128 if N > 100 else 96, dt_rirf=0.01, n_exc=21, dt_exc=0.02, seed=900 + N)
-    if N in (3, 64):
+    if N in (3, 40, 64):
         case["g_sys"] = [0.3, -0.2, -9.7]  # (non-vertical gravity: every buoyancy-moment product is a rounded one)
     motion = PrescribedMotion(N, rest_positions(case), seed=3)
     times, t = [], 0.0

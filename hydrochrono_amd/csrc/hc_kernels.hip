@@ -1899,6 +1899,17 @@ __device__ __forceinline__ void hot_tables_b(dvec2& k01, dvec2& k23, dvec2& k45,
 #endif
 }
 
+// HOT_MARK: a stamp of the stage clock in the tuning build; in the shipped build the same scheduling fence WITHOUT the stamp, at the same
+// places -- the requests and waits of this kernel are asm statements the compiler schedules around, and the build that is compared
+// bitwise with the general kernel (the tuning build, HC_STEP_HOT) should be the instruction order that ships.
+#ifdef HC_TUNING
+#define HOT_MARK(sc, K) HC_MARK(sc, K)
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define HOT_MARK(sc, K) __builtin_amdgcn_sched_barrier(0)
+#else
+#define HOT_MARK(sc, K) ((void)0)
+#endif
+
 template <int NE>
 __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -1907,7 +1918,7 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
     __shared__ double red_term[16][16];
     StageClock sc;
     (void)sc;
-    HC_MARK(sc, 0);
+    HOT_MARK(sc, 0);
     const double* __restrict__ st = nullptr;
 #if defined(__HIP_DEVICE_COMPILE__)
     st = (const double*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kSlotArgBytes);
@@ -1923,7 +1934,7 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
     int ngp = a.ngp, ng0 = a.ng[0], ng1 = a.ng[NE - 1], n_terms = a.n_terms, Dpad = a.Dpad, Dloc = a.Dloc, N = a.N, b0 = a.b0, ntiles = a.ntiles, halves = a.halves;
     HC_PIN_S(kf0); HC_PIN_S(kf1); HC_PIN_S(Yc); HC_PIN_S(P); HC_PIN_S(E); HC_PIN_S(lin); HC_PIN_S(cg); HC_PIN_S(cbm); HC_PIN_S(vol); HC_PIN_S(regm);
     HC_PIN_S(ngp); HC_PIN_S(ng0); HC_PIN_S(ng1); HC_PIN_S(n_terms); HC_PIN_S(Dpad); HC_PIN_S(Dloc); HC_PIN_S(N); HC_PIN_S(b0); HC_PIN_S(ntiles); HC_PIN_S(halves);
-    HC_MARK(sc, 1);
+    HOT_MARK(sc, 1);
 
     if ((int)blockIdx.x >= ntiles) {
         // ---- the workgroup that hands back the state canary and stores this step's sample into ring slot `head` (push_sample) ----
@@ -1957,9 +1968,9 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
         }
 #ifdef HC_TUNING
         if (stamps) {
-            HC_MARK(sc, 8);
+            HOT_MARK(sc, 8);
             hot_wait<0>();
-            HC_MARK(sc, 9);
+            HOT_MARK(sc, 9);
             sc.store(stamps);
         }
 #endif
@@ -2028,7 +2039,7 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
             }
         }
     }
-    HC_MARK(sc, 2);
+    HOT_MARK(sc, 2);
     // ---- the rest of the arguments, while the loads are in flight (read through a pointer the compiler cannot see through, so that
     //      these requests are not hoisted in front of the loads above, where they would compete for the scalar registers) ----
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2072,9 +2083,9 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
         }
         if (tid >= 240) ue[tid < 248 ? tid - 248 : D + tid - 248] = 0.0;  // (a wave whose lanes store no column of a 64-body system)
     }
-    HC_MARK(sc, 3);
+    HOT_MARK(sc, 3);
     __syncthreads();
-    HC_MARK(sc, 4);
+    HOT_MARK(sc, 4);
     // Every right-hand-side value the preloaded K words will meet, requested from LDS AT ONCE: written as `in range ? u[c] : 0` inside
     // the product loop these were 24 LDS round trips one after the other, each with its own wait -- 1.3 us of the workgroup's 4 (stage
     // clock: "contraction done"), more than the K words themselves took.  all_in[e]: every preloaded column group of this wave belongs
@@ -2139,9 +2150,9 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
     }
     hot_pin(hs);
     hot_pin(wav);
-    HC_MARK(sc, 10);  // (hydrostatic / wave terms formed)
+    HOT_MARK(sc, 10);  // (hydrostatic / wave terms formed)
     hot_wait<0>();
-    HC_MARK(sc, 11);  // (every K word of this wave is in)
+    HOT_MARK(sc, 11);  // (every K word of this wave is in)
 #pragma unroll
     for (int e = 0; e < NE; ++e)
 #pragma unroll
@@ -2180,7 +2191,7 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
 #ifdef HC_TUNING
     asm volatile("" ::"v"(acc));
 #endif
-    HC_MARK(sc, 5);
+    HOT_MARK(sc, 5);
     if (lane < 16) red_near[wave][lane] = acc;
     {
 #pragma unroll
@@ -2191,12 +2202,12 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
         red_term[tid >> 4][tid & 15] = tacc;
     }
     __syncthreads();
-    HC_MARK(sc, 6);
+    HOT_MARK(sc, 6);
 #ifdef HC_TUNING
     if (stamps && tid == 0 && !live) {  // (halves == 2: the second workgroup of a tile finishes rows 8 .. 15; its clock row all the same)
-        HC_MARK(sc, 7);
-        HC_MARK(sc, 8);
-        HC_MARK(sc, 9);
+        HOT_MARK(sc, 7);
+        HOT_MARK(sc, 8);
+        HOT_MARK(sc, 9);
         sc.store(stamps);
     }
 #endif
@@ -2219,7 +2230,7 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
 #ifdef HC_TUNING
     asm volatile("" ::"v"(total));
 #endif
-    HC_MARK(sc, 7);
+    HOT_MARK(sc, 7);
     o_hs[row]    = hs;
     o_rad[row]   = rad;
     o_waves[row] = wav;
@@ -2230,9 +2241,9 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
     }
 #ifdef HC_TUNING
     if (stamps) {
-        HC_MARK(sc, 8);
+        HOT_MARK(sc, 8);
         hot_wait<0>();
-        HC_MARK(sc, 9);
+        HOT_MARK(sc, 9);
         sc.store(stamps);
     }
 #endif

@@ -33,7 +33,8 @@ g++ -O2 -std=c++17 profiles/step_stamps_probe.cpp $L -lhydrochrono_amd_tuning -o
   echo "=== step_hot_kernel, stepping thread NOT bound (BIND=0), gap 0"; BIND=0 /tmp/stamps 0 0
   echo "=== step_hot_kernel, packet ring in DEVICE memory (opt-in HC_QUEUE_DEV_MEM=1), gap 0"; HC_QUEUE_DEV_MEM=1 /tmp/stamps 0 0
   echo "=== general step kernel, packet ring in DEVICE memory, gap 0"; HC_QUEUE_DEV_MEM=1 HC_STEP_HOT=0 /tmp/stamps 0 0
-  echo "=== step_hot_kernel, 100 us of host work between calls"; /tmp/stamps 100 0; } > $O/step_stage_clock.txt 2>&1
+  echo "=== step_hot_kernel, 100 us of host work between calls"; /tmp/stamps 100 0
+  echo "=== step_hot_kernel, two workgroups per row tile (tuning experiment HC_STEP_HALVES=2), gap 0"; HC_STEP_HALVES=2 /tmp/stamps 0 0; } > $O/step_stage_clock.txt 2>&1
 g++ -O2 -std=c++17 profiles/multi_path_c.cpp $L -lhydrochrono_amd -pthread -o /tmp/multi_path_c && {
   (echo "== worker thread per context (default)"; /tmp/multi_path_c 512 1024 600; echo "== one thread (HC_MULTI_THREADS=0)"; HC_MULTI_THREADS=0 /tmp/multi_path_c 512 1024 600) > $O/multi_path_c_c4.txt 2>&1
 }

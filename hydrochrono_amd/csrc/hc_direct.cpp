@@ -113,7 +113,11 @@ struct DirectQueue::Impl {
     // for the packet it reads at once: round 6's long differential runs died twice in ~2 000 cases with the ring in device memory and
     // no flush ("invalid code object", a memory fault at a garbage address: a packet whose header was new and whose second half was
     // old).  One store to this register in front of every doorbell writes the HDP back; stores to one device arrive in order.
+    // HC_HDP_FLUSH=1 asks for that store in front of EVERY doorbell, also with the packet ring in host memory: arguments and state then
+    // rest on the write-back instead of on the microseconds the packet processor takes (the HIP runtime guards its own device-side
+    // kernel arguments the same way); 0.3-0.5 us per synchronous step (profiles/r06/host_path_c_hdp_flush.txt).
     volatile uint32_t* hdp_flush = nullptr;
+    bool flush_always = false;  // HC_HDP_FLUSH=1
     uint64_t ticks_per_second = 0;
     struct Timed {
         hsa_signal_t sig;
@@ -150,7 +154,9 @@ struct DirectQueue::Impl {
         _mm_sfence();  // (a ring in device memory is write-combined memory: the packet's body leaves the core before its header)
         __atomic_store_n(reinterpret_cast<uint32_t*>(packet), word, __ATOMIC_RELEASE);
         _mm_sfence();
-        if (ln.ring_in_vram) {  // (a ring in host memory is read across PCIe, a microsecond behind the doorbell: what went through the BAR has landed)
+        if (flush_always && hdp_flush) {
+            *hdp_flush = 1u;
+        } else if (ln.ring_in_vram) {  // (a ring in host memory is read across PCIe, a microsecond behind the doorbell: what went through the BAR has landed)
             if (hdp_flush) *hdp_flush = 1u;  // everything stored through the BAR so far is in VRAM before the doorbell is acted on
             else (void)*reinterpret_cast<volatile uint32_t*>(packet);  // (no flush register mapped: a read through the BAR completes the
                                                                        // posted stores in front of it -- a PCIe round trip)
@@ -275,6 +281,7 @@ bool DirectQueue::init(int hip_device, const std::string& path, std::string* why
         hsa_amd_hdp_flush_t hdp{};
         if (hsa_agent_get_info(p.agent, static_cast<hsa_agent_info_t>(HSA_AMD_AGENT_INFO_HDP_FLUSH), &hdp) == HSA_STATUS_SUCCESS && hdp.HDP_MEM_FLUSH_CNTL)
             p.hdp_flush = hdp.HDP_MEM_FLUSH_CNTL;
+        if (const char* e = std::getenv("HC_HDP_FLUSH")) p.flush_always = std::atoi(e) != 0;
     }
     // lane 0 (the step path) now; lane 1 (added-mass products) when it is first used (ensure_lane): a process that holds many
     // contexts on one device -- row shards sharing a GPU -- then keeps half as many hardware queues busy

@@ -79,7 +79,7 @@ def test_kernel_code_object_is_built_next_to_the_library():
 
 
 OPERATIONAL_SWITCHES = {"HC_DIRECT", "HC_ARM", "HC_PASS_AHEAD", "HC_PASS_AHEAD_GAP_US", "HC_PASS_CONCURRENT", "HC_DEVICE_SHARED", "HC_MULTI_THREADS",
-                        "HC_MULTI_SPIN_US", "HC_STEP_TIMEOUT_S", "HC_QUEUE_DEV_MEM", "HC_MULTI_PIN"}
+                        "HC_MULTI_SPIN_US", "HC_STEP_TIMEOUT_S", "HC_QUEUE_DEV_MEM", "HC_MULTI_PIN", "HC_HDP_FLUSH"}
 
 
 def _hc_names(path):
@@ -88,7 +88,7 @@ def _hc_names(path):
 
 
 def test_release_library_reads_operational_switches_only():
-    """The shipped library knows eleven environment variables, all operational and all listed in INTEGRATION.md; every sweep / A-B /
+    """The shipped library knows twelve environment variables, all operational and all listed in INTEGRATION.md; every sweep / A-B /
     fault-injection switch lives in the tuning build (-DHC_TUNING) only.  Checked on the strings of the built binaries: a name
     that is not in the release library cannot be read by it."""
     from hydrochrono_amd import build as hb

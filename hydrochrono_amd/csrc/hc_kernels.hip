@@ -1755,17 +1755,20 @@ template __global__ void finalize_pre_kernel<4>(const double*, const double*, in
 
 // ------------------------------------------------------------------------------------------------
 // step_hot_kernel<NE>: the step kernel of the common block step (StepHotArgs, hc_kernels.hpp), written around what the stage clock of
-// finalize_kernel<4, true> showed (profiles/r06/step_stage_clock.txt): of the 4.8 us a tile workgroup lived, 0.3 were the argument
-// block, 1.2 the one memory round trip the step needs (K words, scatter results, state) -- and 3.3 were round trips the CODE made one
-// after the other: scalar loads of single arguments with a wait each (the argument slot is uncached memory: 0.1-0.3 us per trip), a
-// wait for the positions in front of the K requests (an eager subtraction), a full drain in the middle of the term loads (a register
-// re-used as an address).  Here
+// finalize_kernel<4, true> showed (profiles/r06/step_stage_clock*.txt).  First pass: of the 4.8 us a tile workgroup
+// lived, 0.3 were the argument block, 1.2 the one memory round trip the step needs -- and 3.3 were round trips the CODE made one after
+// the other (scalar loads of single arguments with a wait each, a wait for the positions in front of the K requests, a full drain in
+// the middle of the term loads).  Second pass, on the first form of this kernel (4.0 us): halving the bytes per compute unit changed
+// nothing -- a workgroup is ONE wave per SIMD, nothing hides a latency, and what was left were requests (16 cycles of the workgroup's
+// one address unit each, whatever their width and mask) and dependent operations (24 LDS round trips inside the product loop).  Here
 //   * every argument is a scalar register after ONE wait (the compact block is requested whole, then pinned: no argument is loaded twice);
-//   * every global load of the step is issued right behind it, unconditionally (indices clamped to something valid, the values masked
-//     afterwards), so nothing is waited for until all requests are out and the waits are counted exactly;
+//   * every global load is an asm request in program order, waited for by hand; the ones that are not always made (tables: the 16
+//     finishing lanes of wave 0 only; scatter results: only as far as the step has terms) carry their condition INSIDE the statement;
+//   * the right-hand sides sit in LDS between zero pads and are read in one batch; the products are a straight line;
+//   * the hydrostatic / wave terms of the finishing lanes are formed between those LDS requests and the wait for the K words;
 //   * nothing else changes: the same products and sums in the same order as finalize_kernel (bitwise the same forces; the tuning
-//     build keeps the A/B switch HC_STEP_HOT, tests/test_gpu_boundary.py).
-// One workgroup per tile of 16 rows + one that stores the sample; 256 work-items; dynamic LDS NE * (D + 16) doubles.
+//     build keeps the A/B switch HC_STEP_HOT, tests/test_gpu_boundary.py, 14 shapes).
+// 2.5 us per workgroup.  One workgroup per tile of 16 rows + one that stores the sample; 256 work-items; dynamic LDS NE * (D + 16) doubles.
 // ------------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HC_PIN_S(x) asm volatile("" : "+s"(x))

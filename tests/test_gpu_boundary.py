@@ -357,6 +357,33 @@ def test_step_kernel_of_the_common_block_step_is_bitwise_the_general_one(monkeyp
     assert hot[0][0] <= hot[0][1] and hot[2] == hot[0], hot
 
 
+@pytest.mark.parametrize("N", [3, 64])
+def test_hdp_write_back_switch_changes_no_bits(monkeypatch, N):
+    """HC_HDP_FLUSH=1: one store to the GPU's HDP write-back register in front of every doorbell, so that
+    arguments and state stored through the PCIe BAR rest on the write-back instead of on the packet processor's microseconds.  An
+    ordering measure: the forces are bitwise those of the default, and the steps stay on the direct path."""
+    import hydrochrono_amd.hydro as hydro
+    from hydrochrono_amd.mock_chrono import PrescribedMotion
+    from hydrochrono_amd.synthetic import many_body_case, rest_positions
+    monkeypatch.setenv("HC_DIRECT", "1")
+    case = many_body_case(N, S=64, dt_rirf=0.01, n_exc=21, dt_exc=0.02, seed=4100 + N)
+    motion = PrescribedMotion(N, rest_positions(case), seed=11)
+    times = [0.01 * (k + 1) for k in range(150)]
+    runs, direct = [], []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("HC_HDP_FLUSH", flag)
+        h = hydro.HydroForces.from_case(case)
+        h.add_waves_regular(0.3, 0.9)
+        runs.append(np.stack([h.step(t, *motion.state(t)) for t in times]))
+        p = h.profile()
+        direct.append((h.direct_dispatch()[0], p["direct_dispatches"], p["hip_launches"]))
+        h.close()
+    if not direct[0][0]:
+        pytest.skip("direct dispatch not available on this box")
+    assert np.array_equal(runs[0], runs[1])
+    assert direct[1][0] and direct[1][1] >= len(times) and direct[1][2] == direct[0][2], direct
+
+
 def test_a_failed_step_of_a_wide_context_leaves_the_next_steps_on_the_direct_path(monkeypatch):
     """Round-5 advisor finding: after a step that failed (step_abort marks the arrival counters of the fused wide step as suspect) the
     recovery -- everything in flight waited for, counters cleared -- ran AFTER the step had been routed to the direct queue and left

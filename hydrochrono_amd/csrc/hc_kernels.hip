@@ -1985,16 +1985,15 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
     // unit 16 cycles whatever its width and however many lanes are live: 39 requests per wave were the 1.1 us in front of the K words)
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), rit = tid & 15, kk = lane >> 4;
     const bool fin = tid < 16;
-    // halves == 2: two workgroups per tile of 16 rows, each finishing 8 of them.  A compute unit moves 40-50 GB/s and the K words of a
-    // tile are 48 KB per own sample: with twice the compute units each requests half of them.  The lanes of the other half's rows ask for
-    // THIS half's words a second time (the same cache lines: no traffic) and compute them a second time; every sum keeps its order.
+    // halves == 2 (tuning experiment HC_STEP_HALVES, EXPERIMENTS.md round 6; the shipped library always passes 1): two workgroups per tile
+    // of 16 rows, each finishing 8 of them.  The lanes of the other half's rows ask for THIS half's words a second time (the same cache
+    // lines) and compute them a second time; every sum keeps its order.  Measured: the bytes per compute unit were not the bound.
     const int wg = (int)blockIdx.x, tile = halves == 2 ? wg >> 1 : wg, half = halves == 2 ? wg & 1 : 0;
     const int row = tile * 16 + rit;
     const bool live = row < Dloc && (halves != 2 || (rit >> 3) == half);
     const int row_h = tile * 16 + 8 * half, rrow = live ? row : (row_h < Dloc ? row_h : 0), bl = rrow / 6, i = rrow - 6 * bl, b = b0 + bl;
     const int lane_k = halves == 2 ? ((lane & ~8) | (half << 3)) : lane;  // the lane whose K words this lane asks for
-    // ---- every load of the step, unconditionally (clamped indices; masked where the values are used), in the order their values are
-    //      needed: what the hydrostatic and wave terms take first (they are formed while the K words are still on their way) ----
+    // ---- the requests of the step, in the order their values are needed: the finishing lanes' tables, the scatter results, the K words ----
     constexpr int PRE  = 12;  // C3: all 12 column groups a wave owns of one IRF sample
     constexpr int TPRE = kTermMax / 16;
     constexpr int kLoadsBehindTerms1 = NE * PRE;  // the K words: requested last, waited for last

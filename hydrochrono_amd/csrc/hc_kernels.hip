@@ -1946,8 +1946,8 @@ __global__ void __launch_bounds__(256) step_hot_kernel(StepHotArgs a) {
         const unsigned long long seq = a.seq;
         unsigned long long *canary_out = a.canary_out, *stamps = a.stamps;
         (void)stamps;
-        double word = 0.0;
-        if (canary_out) hot_ld(word, st + 12 * N);
+        double word;
+        hot_ld(word, st + 12 * N);  // (requested whether or not it is handed back: no branch around a request, see hot_lds_if_at_least)
         hot_wait<0>();
 #pragma unroll
         for (int k = 0; k < 4; ++k) hot_pin(ev[k]);
